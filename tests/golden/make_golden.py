@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE itself (build container only).
+
+The reference (/root/reference, read-only) is imported with three throw-away shims that live in a
+temp dir created here (never committed, never shipped):
+  * stub modules for absent third-party imports (torchvision.ops.boxes, cv2, webcolors, imgaug ...),
+  * Tensor.cuda / Module.cuda patched to identity (the reference hard-codes .cuda()),
+  * sys.dont_write_bytecode (reference tree is read-only).
+Only *data* is written: inputs, the reference's state_dict, and the reference's outputs / losses /
+gradients.  Run:  python tests/golden/make_golden.py
+"""
+import functools
+import hashlib
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+import yaml
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference/model"
+sys.dont_write_bytecode = True
+sys.path.insert(0, ROOT)
+
+from oracle import hydranet_oracle as O  # noqa: E402  (used for the NMS stub + synthetic batch only)
+
+
+def _install_shims():
+    d = tempfile.mkdtemp(prefix="refstubs_")
+    os.makedirs(os.path.join(d, "torchvision", "ops"))
+    open(os.path.join(d, "torchvision", "__init__.py"), "w").write("")
+    open(os.path.join(d, "torchvision", "ops", "__init__.py"), "w").write("")
+    open(os.path.join(d, "torchvision", "ops", "boxes.py"), "w").write(
+        "import sys\nsys.path.insert(0, %r)\nfrom oracle.hydranet_oracle import nms_greedy as nms, batched_nms\n" % ROOT)
+    open(os.path.join(d, "cv2.py"), "w").write("INTER_NEAREST = 0\n")
+    open(os.path.join(d, "webcolors.py"), "w").write(
+        "class _C:\n    red = green = blue = 0\n\ndef name_to_rgb(name):\n    return _C()\n")
+    sys.path.insert(0, d)
+    sys.path.insert(0, REF)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def tiny_fixture():
+    from model import HydraNet  # the reference
+    from head_lane.lanedetect_loss import cal_loss_regress
+
+    cfgs = yaml.safe_load(open(os.path.join(ROOT, "cfgs", "hydranet_tiny.yml")))
+    h = w = 128
+    n = 2
+    torch.manual_seed(0)
+    net = HydraNet(cfgs)
+    # perturb BN affine / biases / fusion weights away from their trivial init so parity is meaningful
+    g = torch.Generator().manual_seed(123)
+    with torch.no_grad():
+        for k, v in net.state_dict().items():
+            if k.endswith("num_batches_tracked"):
+                continue
+            if k.endswith("running_var"):
+                v.copy_(0.5 + torch.rand(v.shape, generator=g))
+            elif k.endswith("running_mean") or k.endswith(".bias"):
+                v.copy_(0.1 * torch.randn(v.shape, generator=g))
+            elif v.dim() == 1 and "_w" in k.split(".")[-1]:           # BiFPN fusion weights (one negative -> relu)
+                v.copy_(torch.rand(v.shape, generator=g) + 0.1)
+            elif v.dim() == 1:                                       # BN gamma
+                v.copy_(0.5 + torch.rand(v.shape, generator=g))
+        net.state_dict()["neck.bifpn.1.p4_w2"][1] = -0.3
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    ppl = h // cfgs["lane"]["interval"]
+    net.loss_reg = functools.partial(cal_loss_regress, points_per_line=ppl)   # SURVEY section 0 #3 deviation
+
+    batch = O.synthetic_batch(cfgs, n, h, w, seed=1)
+    net.train()
+    x = batch["image"]
+    feats = net.backbone(x)
+    fused = net.neck(feats)
+    torch.manual_seed(0)
+    # second, clean forward for outputs (BN running stats get updated twice; record after this pass)
+    net.load_state_dict(sd0)
+    out = net(x)
+    ld = net.cal_loss(out, batch)
+    s, d, l = cfgs["segment"], cfgs["detection"], cfgs["lane"]
+    total = ld["loss_seg"] * s["segment_weight"] \
+        + (ld["loss_det_cls"] * d["loss_cls_weight"] + ld["loss_det_reg"] * d["loss_reg_weight"]) * d["detection_weight"] \
+        + (ld["loss_lane_cls_pos"] + ld["loss_lane_cls_neg"] + ld["loss_lane_loc"]) * l["lane_weight"]
+    total.backward()
+    res = {}
+    for k, v in sd0.items():
+        res["sd/" + k] = _np(v)
+    for k, v in net.state_dict().items():
+        if "running_" in k or "num_batches" in k:
+            res["sd_after/" + k] = _np(v)
+    for k, v in batch.items():
+        res["in/" + k] = _np(v)
+    for i, f in enumerate(feats):
+        res[f"feat/{i}"] = _np(f)
+    for i, f in enumerate(fused):
+        res[f"fused/{i}"] = _np(f)
+    res["out/seg"] = _np(out["seg"])
+    res["out/anchors"] = _np(out["detection"]["anchors"])
+    res["out/regression"] = _np(out["detection"]["regression"])
+    res["out/classification"] = _np(out["detection"]["classification"])
+    res["out/lane_cls"] = _np(out["lane"]["predict_cls"])
+    res["out/lane_loc"] = _np(out["lane"]["predict_loc"])
+    for k, v in ld.items():
+        res["loss/" + k] = _np(v)
+    res["loss/total"] = _np(total)
+    res["meta/lane_points_per_line"] = np.array(ppl)
+    nograd = []
+    for k, p in net.named_parameters():
+        if p.grad is None:
+            nograd.append(k)
+        else:
+            res["grad/" + k] = _np(p.grad)
+    res["meta/nograd"] = np.array(nograd)
+    # deploy tuple + eval-mode forward
+    net.eval()
+    with torch.no_grad():
+        dep = net(x, "deploy")
+    res["deploy/seg_argmax"] = _np(dep[0]).astype(np.int64)
+    res["deploy/regression"] = _np(dep[2])
+    res["deploy/classification"] = _np(dep[3])
+    res["deploy/lane_cls"] = _np(dep[4])
+    # postprocess through the reference's own code (NMS = restated stub; parity unpinned there)
+    from head_detect.detection import DetectionHeader
+    pp = DetectionHeader.decode(x, dep[2], dep[3], dep[1], conf_thres=float(dep[3].max()) * 0.9, iou_thres=0.3)
+    res["deploy/pp_thresh"] = np.array(float(dep[3].max()) * 0.9, dtype=np.float64)
+    for i, o in enumerate(pp):
+        res[f"deploy/pp{i}/rois"] = np.asarray(o["rois"], dtype=np.float32)
+        res[f"deploy/pp{i}/class_ids"] = np.asarray(o["class_ids"], dtype=np.int64)
+        res[f"deploy/pp{i}/scores"] = np.asarray(o["scores"], dtype=np.float32)
+    np.savez_compressed(os.path.join(HERE, "tiny_hydranet.npz"), **res)
+    print("tiny fixture: %d arrays, losses:" % len(res), {k: float(v) for k, v in ld.items()}, "nograd", nograd)
+
+
+def loss_kats():
+    """Known-answer tests built from the reference's own smoke inputs."""
+    from head_detect.detection_loss import FocalLoss, calc_iou
+    from head_lane.lanedetect_loss import cal_loss_cls, cal_loss_regress
+    from head_seg.segmentation_loss import CrossEntropyLoss
+    from head_detect.detection import Anchors
+
+    res = {}
+    g = torch.Generator().manual_seed(7)
+    # --- seg: gt = ones (segmentation.py:226) and random gt with ignore pixels, top-k and focal variants
+    logits = torch.randn(2, 5, 32, 64, generator=g)
+    gt1 = torch.ones(2, 32, 64).long()
+    gt2 = torch.randint(0, 5, (2, 32, 64), generator=g)
+    gt2[0, :3] = 255
+    cw = [0.1, 0.5, 1.0, 5.0, 5.0]
+    res["seg/logits"], res["seg/gt_ones"], res["seg/gt_rand"] = _np(logits), _np(gt1), _np(gt2)
+    for name, kw in (("topk", dict(use_top_k=True, top_k_ratio=0.3, use_focal=False)),
+                     ("plain", dict(use_top_k=False, top_k_ratio=1.0, use_focal=False)),
+                     ("focal", dict(use_top_k=False, top_k_ratio=0.3, use_focal=True))):
+        m = CrossEntropyLoss(class_weights=torch.tensor(cw), **kw)
+        res[f"seg/{name}/ones"] = _np(m(logits, gt1))
+        if name != "focal":                                          # focal path cannot take ignore=255 (scatter)
+            res[f"seg/{name}/rand"] = _np(m(logits, gt2))
+    # --- det: annotations = ones([B,16,5]) (detection.py:351), random boxes, and an empty image
+    cfgs = yaml.safe_load(open(os.path.join(ROOT, "cfgs", "hydranet_big.yml")))
+    x = torch.zeros(3, 3, 128, 256)
+    anc = Anchors(anchor_scale=2.0, pyramid_levels=[3, 4, 5, 6, 7], scales=[2 ** 0.0, 2 ** 0.333, 2 ** 0.667],
+                  ratio=[(1.0, 1.0), (1.4, 0.7), (0.7, 1.4)])(x, torch.float32)
+    a = anc.shape[1]
+    cls = torch.rand(3, a, 9, generator=g) * 0.2
+    reg = torch.randn(3, a, 4, generator=g) * 0.1
+    ann = O.synthetic_batch(cfgs, 3, 128, 256, seed=3)["gt_det"]
+    ann[:, :, :4] = ann[:, :, :4]
+    ann[1, 5:] = -1
+    ann[2] = -1
+    ones = torch.ones(3, 16, 5)
+    res["det/anchors"], res["det/cls"], res["det/reg"], res["det/ann"] = _np(anc), _np(cls), _np(reg), _np(ann)
+    for name, an in (("rand", ann), ("ones", ones)):
+        cl, rl = FocalLoss()(cls, reg, anc, an)
+        res[f"det/{name}/cls_loss"], res[f"det/{name}/reg_loss"] = _np(cl), _np(rl)
+    res["det/iou"] = _np(calc_iou(anc[0, ::97], ann[0, :, :4]))
+    # --- lane: cls_targets = ones; [:, 0:40, 1] = 0; loc_targets = ones (lanedetect.py:268-270) at 640x640
+    hw, width = 400, 162
+    cp = torch.randn(2, hw, 2, generator=g)
+    lp = torch.randn(2, hw, width, generator=g)
+    ct = torch.ones(2, hw, 2)
+    ct[:, 0:40, 1] = 0
+    lt = torch.ones(2, hw, width)
+    res["lane/cls_pred"], res["lane/loc_pred"] = _np(cp), _np(lp)
+    pos, neg, pmask, pnum = cal_loss_cls(ct, cp)
+    res["lane/smoke/pos"], res["lane/smoke/neg"], res["lane/smoke/pnum"] = _np(pos), _np(neg), _np(pnum)
+    res["lane/smoke/loc_default160"] = _np(cal_loss_regress(pmask, pnum, lt, lp))
+    res["lane/smoke/loc_ppl80"] = _np(cal_loss_regress(pmask, pnum, lt, lp, points_per_line=80))
+    b = O.synthetic_batch(cfgs, 2, 640, 640, seed=5)
+    pos, neg, pmask, pnum = cal_loss_cls(b["gt_cls"], cp)
+    res["lane/synth/pos"], res["lane/synth/neg"] = _np(pos), _np(neg)
+    res["lane/synth/loc_default160"] = _np(cal_loss_regress(pmask, pnum, b["gt_loc"], lp))
+    allbg = torch.zeros(2, hw, 2)
+    allbg[..., 0] = 1
+    pos, neg, pmask, pnum = cal_loss_cls(allbg, cp)
+    res["lane/allbg/pos"], res["lane/allbg/neg"], res["lane/allbg/pnum"] = _np(pos), _np(neg), _np(pnum)
+    # --- anchor tables (exact fp32 equality): sha256 + a strided sample
+    for (h, w) in ((640, 640), (512, 1024)):
+        t = _np(Anchors(anchor_scale=2.0, pyramid_levels=[3, 4, 5, 6, 7],
+                        scales=[2 ** 0.0, 2 ** 0.333, 2 ** 0.667],
+                        ratio=[(1.0, 1.0), (1.4, 0.7), (0.7, 1.4)])(torch.zeros(1, 3, h, w), torch.float32))[0]
+        res[f"anchors/{h}x{w}/shape"] = np.array(t.shape)
+        res[f"anchors/{h}x{w}/sha256"] = np.array(hashlib.sha256(np.ascontiguousarray(t).tobytes()).hexdigest())
+        res[f"anchors/{h}x{w}/sample"] = t[::997]
+    # --- width derivation for the three shipped cfgs (INT equality)
+    from net.regnet import RegNetY
+    import net.anynet as anynet
+    captured = {}
+    orig = anynet.AnyNetX.__init__
+
+    def spy(self, nb, bw, br, gw, stride, se):
+        captured["v"] = (list(map(int, nb)), list(map(int, bw)), list(map(int, gw)))
+        raise RuntimeError("captured")
+    anynet.AnyNetX.__init__ = spy
+    for name in ("hydranet_joint_big_backbone", "hydranet_joint_big_backbone_interview", "hydranet_joint_small_backbone"):
+        c = yaml.safe_load(open(f"{REF}/cfgs/{name}.yml"))["backbone"]
+        try:
+            RegNetY(c["initial_width"], c["slope"], c["quantized_param"], c["network_depth"], c["bottleneck_ratio"],
+                    c["group_width"], c["stride"], c["se_ratio"])
+        except RuntimeError:
+            pass
+        nb, bw, gw = captured["v"]
+        res[f"regnet/{name}/depths"], res[f"regnet/{name}/widths"], res[f"regnet/{name}/gw"] = \
+            np.array(nb), np.array(bw), np.array(gw)
+        res[f"regnet/{name}/args"] = np.array([c["initial_width"], c["slope"], c["quantized_param"], c["network_depth"],
+                                               c["bottleneck_ratio"], c["group_width"]], dtype=np.float64)
+    anynet.AnyNetX.__init__ = orig
+    np.savez_compressed(os.path.join(HERE, "loss_kats.npz"), **res)
+    print("loss KATs: %d arrays" % len(res))
+
+
+def big_digest():
+    """Big cfg at 640x640, B=1: state_dict key/shape list + output digests (weights too big to commit)."""
+    from model import HydraNet
+    cfgs = yaml.safe_load(open(f"{REF}/cfgs/hydranet_joint_big_backbone.yml"))
+    torch.manual_seed(0)
+    net = HydraNet(cfgs)
+    keys = list(net.state_dict().keys())
+    shapes = [tuple(v.shape) for v in net.state_dict().values()]
+    res = {"keys": np.array(keys), "shapes": np.array([",".join(map(str, s)) for s in shapes]),
+           "n_params": np.array(sum(p.numel() for p in net.parameters())),
+           "param_keys": np.array([k for k, _ in net.named_parameters()])}
+    np.savez_compressed(os.path.join(HERE, "big_keys.npz"), **res)
+    print("big cfg: %d state_dict entries, %d params" % (len(keys), int(res["n_params"])))
+
+
+if __name__ == "__main__":
+    _install_shims()
+    tiny_fixture()
+    loss_kats()
+    big_digest()

@@ -1,0 +1,189 @@
+"""CPU: the oracle (oracle/hydranet_oracle.py) against vectors recorded from the reference itself."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import hydranet_oracle as O
+from tests.helpers import assert_close, load_cfg, load_npz, tiny_state
+
+FP32_TOL = 2e-5   # fp32 CPU oracle vs fp32 CPU reference: identical ATen ops, only graph-order differences
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    z = load_npz("tiny_hydranet.npz")
+    cfgs = load_cfg("hydranet_tiny.yml")
+    sd = tiny_state(z)
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    batch = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in/")}
+    out = O.hydranet_forward(sd, cfgs, batch["image"], training=True, want_features=True)
+    ld = O.hydranet_losses(cfgs, out, batch, lane_points_per_line=int(z["meta/lane_points_per_line"]))
+    tot = O.total_loss(cfgs, ld)
+    tot.backward()
+    return z, cfgs, sd, batch, out, ld, tot
+
+
+def test_tiny_features_and_outputs(tiny):
+    z, cfgs, sd, batch, out, ld, tot = tiny
+    for i, f in enumerate(out["_feats"]):
+        assert_close(f, z[f"feat/{i}"], FP32_TOL, f"feat{i}")
+    for i, f in enumerate(out["_fused"]):
+        assert_close(f, z[f"fused/{i}"], FP32_TOL, f"fused{i}")
+    assert_close(out["seg"], z["out/seg"], FP32_TOL, "seg")
+    assert np.array_equal(out["detection"]["anchors"].numpy(), z["out/anchors"])
+    assert_close(out["detection"]["regression"], z["out/regression"], FP32_TOL, "regression")
+    assert_close(out["detection"]["classification"], z["out/classification"], FP32_TOL, "classification")
+    assert_close(out["lane"]["predict_cls"], z["out/lane_cls"], FP32_TOL, "lane_cls")
+    assert_close(out["lane"]["predict_loc"], z["out/lane_loc"], FP32_TOL, "lane_loc")
+
+
+def test_tiny_losses(tiny):
+    z, cfgs, sd, batch, out, ld, tot = tiny
+    for k, v in ld.items():
+        assert_close(v, z["loss/" + k], 1e-5, k)
+    assert_close(tot, z["loss/total"], 1e-5, "total")
+
+
+def test_tiny_gradients_and_unused_params(tiny):
+    z, cfgs, sd, batch, out, ld, tot = tiny
+    nograd = set(z["meta/nograd"].tolist())
+    assert nograd == {"neck.bifpn.0.p5_to_p6.0.conv.weight", "neck.bifpn.0.p5_to_p6.0.conv.bias",
+                      "neck.bifpn.0.p5_to_p6.1.weight", "neck.bifpn.0.p5_to_p6.1.bias"}
+    checked = 0
+    for k in z.files:
+        if not k.startswith("grad/"):
+            continue
+        name = k[5:]
+        g = sd[name].grad
+        assert g is not None, name
+        assert_close(g, z[k], 2e-4, "grad " + name, atol=1e-6)
+        checked += 1
+    assert checked > 300
+    for name in nograd:
+        assert sd[name].grad is None
+
+
+def test_tiny_running_stats(tiny):
+    z, cfgs, sd, *_ = tiny
+    for k in z.files:
+        if k.startswith("sd_after/"):
+            name = k[9:]
+            if name.startswith("neck.bifpn.0.p5_to_p6"):
+                continue                                             # unused in the 5-input path
+            if name.endswith("num_batches_tracked"):
+                assert int(sd[name]) == int(z[k]), name
+            else:
+                assert_close(sd[name], z[k], 1e-5, name)
+
+
+def test_tiny_deploy_and_postprocess():
+    z = load_npz("tiny_hydranet.npz")
+    cfgs = load_cfg("hydranet_tiny.yml")
+    sd = tiny_state(z)
+    for k in z.files:                                                # eval uses the post-training running stats
+        if k.startswith("sd_after/"):
+            sd[k[9:]] = torch.from_numpy(z[k].copy())
+    x = torch.from_numpy(z["in/image"])
+    with torch.no_grad():
+        dep = O.hydranet_forward(sd, cfgs, x, training=False, mode="deploy")
+    seg_ref = z["deploy/seg_argmax"]
+    agree = float((dep[0].numpy() == seg_ref).mean())
+    assert agree > 0.9999, agree                                     # fp32 reorder can flip exact ties only
+    assert_close(dep[2], z["deploy/regression"], FP32_TOL, "dep reg")
+    assert_close(dep[3], z["deploy/classification"], FP32_TOL, "dep cls")
+    # A15: bit-exact bookkeeping GIVEN IDENTICAL fp inputs (the reference's own tensors)
+    reg = torch.from_numpy(z["deploy/regression"])
+    cls = torch.from_numpy(z["deploy/classification"])
+    anc = torch.from_numpy(z["out/anchors"])
+    anchors = torch.stack([anc[0]] * x.shape[0], 0)
+    pp = O.postprocess((x.shape[2], x.shape[3]), anchors, reg, cls, float(z["deploy/pp_thresh"]), 0.3)
+    for i, o in enumerate(pp):
+        assert np.array_equal(np.asarray(o["rois"], np.float32), z[f"deploy/pp{i}/rois"])
+        assert np.array_equal(np.asarray(o["class_ids"], np.int64), z[f"deploy/pp{i}/class_ids"])
+        assert np.array_equal(np.asarray(o["scores"], np.float32), z[f"deploy/pp{i}/scores"])
+
+
+def test_loss_kats():
+    z = load_npz("loss_kats.npz")
+    t = lambda k: torch.from_numpy(z[k])
+    cw = [0.1, 0.5, 1.0, 5.0, 5.0]
+    for name, kw in (("topk", dict(use_top_k=True, top_k_ratio=0.3, use_focal=False)),
+                     ("plain", dict(use_top_k=False, top_k_ratio=1.0, use_focal=False)),
+                     ("focal", dict(use_top_k=False, top_k_ratio=0.3, use_focal=True))):
+        assert_close(O.seg_loss(t("seg/logits"), t("seg/gt_ones"), cw, **kw), z[f"seg/{name}/ones"], 1e-6, name)
+        if name != "focal":
+            assert_close(O.seg_loss(t("seg/logits"), t("seg/gt_rand"), cw, **kw), z[f"seg/{name}/rand"], 1e-6, name)
+    for name, ann in (("rand", t("det/ann")), ("ones", torch.ones(3, 16, 5))):
+        cl, rl = O.det_loss(t("det/cls"), t("det/reg"), t("det/anchors"), ann)
+        assert_close(cl, z[f"det/{name}/cls_loss"], 1e-6, "det cls " + name)
+        assert_close(rl, z[f"det/{name}/reg_loss"], 1e-6, "det reg " + name)
+    assert_close(O.box_iou_anchor_gt(t("det/anchors")[0, ::97], t("det/ann")[0, :, :4]), z["det/iou"], 1e-6, "iou")
+    hw, width = 400, 162
+    ct = torch.ones(2, hw, 2)
+    ct[:, 0:40, 1] = 0
+    lt = torch.ones(2, hw, width)
+    pos, neg, pmask, pnum = O.lane_cls_loss(ct, t("lane/cls_pred"))
+    assert_close(pos, z["lane/smoke/pos"], 1e-6)
+    assert_close(neg, z["lane/smoke/neg"], 1e-6)
+    assert int(pnum) == int(z["lane/smoke/pnum"])
+    assert_close(O.lane_loc_loss(pmask, pnum, lt, t("lane/loc_pred")), z["lane/smoke/loc_default160"], 1e-6)
+    assert_close(O.lane_loc_loss(pmask, pnum, lt, t("lane/loc_pred"), points_per_line=80), z["lane/smoke/loc_ppl80"], 1e-6)
+    cfgs = load_cfg("hydranet_big.yml")
+    b = O.synthetic_batch(cfgs, 2, 640, 640, seed=5)
+    pos, neg, pmask, pnum = O.lane_cls_loss(b["gt_cls"], t("lane/cls_pred"))
+    assert_close(pos, z["lane/synth/pos"], 1e-6)
+    assert_close(neg, z["lane/synth/neg"], 1e-6)
+    assert_close(O.lane_loc_loss(pmask, pnum, b["gt_loc"], t("lane/loc_pred")), z["lane/synth/loc_default160"], 1e-6)
+    allbg = torch.zeros(2, hw, 2)
+    allbg[..., 0] = 1
+    pos, neg, pmask, pnum = O.lane_cls_loss(allbg, t("lane/cls_pred"))
+    assert float(pos) == float(z["lane/allbg/pos"]) == 0.0
+    assert_close(neg, z["lane/allbg/neg"], 1e-6)
+    assert int(pnum) == int(z["lane/allbg/pnum"]) == 1
+
+
+def test_lane_loc_default_crashes_below_161_columns():
+    """The reference's cal_loss_regress default points_per_line=160 indexes column 161."""
+    lp = torch.zeros(1, 4, 130)
+    with pytest.raises(IndexError):
+        O.lane_loc_loss(torch.ones(4, dtype=torch.bool), torch.tensor(1), lp.clone(), lp)
+
+
+def test_anchor_tables_exact():
+    z = load_npz("loss_kats.npz")
+    cfgs = load_cfg("hydranet_big.yml")
+    for (h, w) in ((640, 640), (512, 1024)):
+        a = O.anchors_for(h, w, cfgs)
+        assert list(a.shape) == z[f"anchors/{h}x{w}/shape"].tolist()
+        assert hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest() == str(z[f"anchors/{h}x{w}/sha256"])
+        assert np.array_equal(a[::997], z[f"anchors/{h}x{w}/sample"])
+    assert O.anchors_for(640, 640, cfgs).shape[0] == 76725
+    assert O.anchors_for(512, 1024, cfgs).shape[0] == 98208
+
+
+def test_regnet_width_derivation():
+    z = load_npz("loss_kats.npz")
+    for name in ("hydranet_joint_big_backbone", "hydranet_joint_big_backbone_interview", "hydranet_joint_small_backbone"):
+        a = z[f"regnet/{name}/args"]
+        w, d, g = O.regnet_stages(int(a[0]), int(a[1]), float(a[2]), int(a[3]), int(a[4]), int(a[5]))
+        assert w == z[f"regnet/{name}/widths"].tolist()
+        assert d == z[f"regnet/{name}/depths"].tolist()
+        assert g == z[f"regnet/{name}/gw"].tolist()
+
+
+def test_nms_known_answers():
+    """Authored KATs for the restated torchvision NMS (parity unpinned: torchvision absent, unpinned in the reference)."""
+    boxes = torch.tensor([[0, 0, 10, 10], [1, 1, 11, 11], [20, 20, 30, 30], [0, 0, 10, 10.0]])
+    scores = torch.tensor([0.9, 0.8, 0.7, 0.95])
+    assert O.nms_greedy(boxes, scores, 0.5).tolist() == [3, 2]        # 0 (IoU 1.0) and 1 (IoU 0.68) suppressed
+    assert O.nms_greedy(boxes, scores, 0.7).tolist() == [3, 1, 2]     # IoU(3,1)=0.68 is not > 0.7
+    # IoU exactly at the threshold is kept (strict >): two 2x1 boxes sharing half -> IoU = 1/3
+    b = torch.tensor([[0, 0, 2, 1], [1, 0, 3, 1.0]])
+    assert O.nms_greedy(b, torch.tensor([0.9, 0.8]), 1.0 / 3.0).tolist() == [0, 1]
+    # classes never suppress each other
+    assert O.batched_nms(boxes, scores, torch.tensor([0, 0, 0, 1]), 0.5).tolist() == [3, 0, 2]
+    assert O.nms_greedy(torch.zeros(0, 4), torch.zeros(0), 0.5).numel() == 0
