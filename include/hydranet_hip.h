@@ -1,0 +1,142 @@
+/* hydranet_hip.h -- C ABI of libhydranet_hip.so, the MI355X (gfx950) kernels behind the HydraNet forward/backward hot path.
+ *
+ * Drop-in boundary.  The reference (FlowEternal/multitask-hydranet) has no FFI of its own: its hot path is the ATen op layer
+ * underneath model/model.py:159-264 and the one torch.autograd.Function it authors (SwishImplementation, model/net/common.py:11-22).
+ * Each entry point below replaces the ATen/cuDNN call(s) named in its comment (paths relative to /root/reference/model).
+ *
+ * Conventions
+ *   - Activations are NHWC ("channels last") bf16: a tensor is [rows = N*H*W][C] with an explicit row stride `ld*` in ELEMENTS so
+ *     producers can write channel slices of a concatenation buffer.  C and every ld must be a multiple of 8 (16-byte pieces).
+ *   - Parameters and statistics are fp32.  Packed weight operands are bf16 (see hn_pack_weight / hn_gconv_pack / hn_dw_pack).
+ *   - Every buffer is owned by the caller (PyTorch's caching allocator) and only borrowed for the call; the library keeps no state.
+ *   - Every function only enqueues kernels on `stream` (no allocation, no synchronisation => hipGraph-capturable) and returns
+ *     0 on success, 1 = bad argument, 2 = launch failure, 3 = unsupported shape.  No C++ exceptions cross the boundary.
+ *   - Activation codes: 0 none, 1 ReLU, 2 Swish, 3 ELU, 4 sigmoid.
+ */
+#ifndef HYDRANET_HIP_H
+#define HYDRANET_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* hipStream_t;
+
+/* ---- dense contractions on MFMA (hn_gemm.hip) ------------------------------------------------------------------------------- */
+
+/* fp32 conv weight [Cout][Cin][taps] -> bf16 forward operand wp[Cout][taps][KP(Cin)] and (optional) dgrad operand
+ * wt[Cin][taps][KP(Cout)], KP(x) = x rounded up to 32, zero filled.  Replaces the implicit weight cast of autocast convs. */
+int hn_pack_weight(const float* w, void* wp, void* wt, int Cout, int Cin, int taps, hipStream_t stream);
+
+/* out[pixel][cout] = act(bias[cout] + sum_{tap,c} X(pixel, tap)[c] * w[cout][tap][c]); X is gathered on the fly:
+ *   mode 0: X = x0 rows (1x1 conv; also every dgrad of a 1x1 conv)            nn.Conv2d k=1: net/anynet.py:29-33,52-60;
+ *           net/bifpn.py:58-102; net/common.py:95; head_lane/lanedetect.py:45-64
+ *   mode 1: 1x1 conv stride 2 (XBlock shortcut)                                 net/anynet.py:57-60
+ *   mode 2: 3x3 conv over reflect-pad-1 of cat[nearest_up2(x0) if up else x0, x1]   head_seg/segmentation.py:16-48,84-105
+ *   mode 3: 3x3 "full" correlation of zero-extended x0 (dgrad of mode 2 on the padded (H+2)x(W+2) grid; H, W passed here are the
+ *           PADDED sizes); fold back with hn_seg_fold.
+ * (n_img, H, W) describe the OUTPUT pixel grid, M = n_img*H*W rows.  psum/psq (optional) receive per-wave partial sums / sums of
+ * squares of the bf16-rounded outputs, [hn_nt_stat_rows(M, Nout)][Nout], for training-mode BatchNorm (F.batch_norm statistics).
+ * rpi/img_stride (optional, 0 = off): out offset(pixel) = (pixel / rpi) * img_stride + (pixel % rpi) * ldc, which writes a pyramid
+ * level straight into the per-image concatenation of head_detect/detection.py:37-44,74-83. */
+int hn_conv_gemm_nt(const void* x0, const void* x1, int mode, int n_img, int H, int W, int C0, int C1, int ld0, int ld1, int up, long M,
+                    const void* w, int Nout, int KP, int taps, const float* bias, int act, void* out, int out_f32, int ldc, long rpi,
+                    long img_stride, float* psum, float* psq, hipStream_t stream);
+int hn_nt_stat_rows(long M, int Nout);
+
+/* wgrad: dw[Cout][Cin][taps] (PyTorch layout, fp32) = sum_pixel dz[pixel][cout] * X(pixel, tap)[c]; X modes 0..2 as above.
+ * dz rows must be zero padded up to ldz >= Nout rounded up to 8.  workspace: fp32, size from hn_wgrad_plan.
+ * Replaces aten::convolution_backward's weight gradient. */
+int hn_wgrad_plan(long M, int Nout, int KP, int taps, int* splits, long* rows_per_split, long* ws_bytes);
+int hn_conv_gemm_tn(const void* x0, const void* x1, int mode, int n_img, int H, int W, int C0, int C1, int ld0, int ld1, int up, long M,
+                    const void* dz, int ldz, int Nout, int KP, int taps, float* workspace, float* dw, hipStream_t stream);
+
+/* ---- NHWC stencils (hn_stencil.hip) ----------------------------------------------------------------------------------------- */
+
+/* Stem: x NCHW fp32 [N,3,H,W], w fp32 [32][3][3][3] -> z NHWC bf16 [N,H/2,W/2,32] (conv 3x3 s2 p1, net/anynet.py:12,17). */
+int hn_stem_fwd(const float* x, const float* w, void* z, int N, int H, int W, hipStream_t stream);
+long hn_stem_wgrad_blocks(int N, int H, int W);
+int hn_stem_wgrad(const float* x, const void* dz, float* part, int N, int H, int W, hipStream_t stream);
+
+/* Grouped 3x3 conv, group width 8, pad 1, stride 1|2 (XBlock conv_block_2, net/anynet.py:34-35).
+ * hn_gconv_pack: fp32 [C][8][3][3] -> wk[tap][i][G][o] and wd (o/i swapped; flip=1 also flips the taps for stride-1 dgrad). */
+int hn_gconv_pack(const float* w, void* wk, void* wd, int C, int flip, hipStream_t stream);
+int hn_gconv_fwd(const void* in, int ldi, const void* wk, void* out, int ldo, int N, int Hi, int Wi, int C, int stride, hipStream_t stream);
+int hn_gconv_dgrad_s2(const void* dz, int ldz, const void* wd, void* dx, int ldx, int N, int Hi, int Wi, int C, hipStream_t stream);
+long hn_wgrad_chunks(long pixels, long items);
+int hn_gconv_wgrad(const void* x, int ldx, const void* dz, int ldz, float* part, int N, int Hi, int Wi, int C, int stride,
+                   hipStream_t stream);
+
+/* Depthwise 3x3, stride 1, zero pad 1 (SeparableConvBlock.depthwise_conv, net/common.py:91-92,104). */
+int hn_dw_pack(const float* w, void* wk, void* wkf, int C, hipStream_t stream);
+int hn_dwconv_fwd(const void* in, int ldi, const void* wk, void* out, int ldo, int N, int H, int W, int C, hipStream_t stream);
+int hn_dwconv_wgrad(const void* x, int ldx, const void* dz, int ldz, float* part, int N, int H, int W, int C, hipStream_t stream);
+
+/* 3x3/s2 max pools: mode 0 = zero pad right/bottom, zeros take part in the max (MaxPool2dStaticSamePadding, net/common.py:138-151);
+ * mode 1 = nn.MaxPool2d(3,2,1) (head_lane/lanedetect.py:40).  Backward recomputes the arg-max (first maximum wins). */
+int hn_maxpool_fwd(const void* in, int ldi, void* out, int ldo, int N, int H, int W, int C, int mode, hipStream_t stream);
+int hn_maxpool_bwd(const void* in, int ldi, const void* dout, int ldd, void* dx, int ldx, const float* wscale, int N, int H, int W, int C,
+                   int mode, hipStream_t stream);
+
+/* Nearest x2 up-sampling and its backward (F.interpolate / nn.Upsample, net/bifpn.py:43-46, head_lane/lanedetect.py:10-13). */
+int hn_up2_fwd(const void* in, int ldi, void* out, int ldo, int N, int H, int W, int C, hipStream_t stream);
+int hn_sum2x2(const void* g, int ldg, void* out, int ldo, const float* wscale, int N, int H, int W, int C, hipStream_t stream);
+
+/* BiFPN fusion node out = swish(sum_i w[i]*T_i(in_i)) (net/bifpn.py:177-231); mode[i]: 0 absent, 1 same res, 2 nearest x2 of a
+ * half-res map, 3 zero-pad-same max-pool of a double-res map.  w: 3 fp32 in device memory. */
+int hn_fuse_fwd(const void* const* in, const int* ld, const int* mode, const float* w, void* out, int ldo, int N, int H, int W, int C,
+                hipStream_t stream);
+int hn_fuse_bwd_blocks(int N, int H, int W, int C);
+int hn_fuse_bwd(const void* const* in, const int* ld, const int* mode, const float* w, const void* dout, int ldd, void* g, int ldg,
+                void* const* din, const int* ldin, float* pw, int N, int H, int W, int C, hipStream_t stream);
+
+/* Backward of ReflectionPad2d(1) (+ nearest x2, + channel split of the concat) for the seg decoder (head_seg/segmentation.py:40,92-99). */
+int hn_seg_fold(const void* dvp, int ldv, int c0, void* out, int ldo, const void* yprev, int ldy, int N, int H, int W, int C, int up,
+                hipStream_t stream);
+
+/* fp32 head-output gradient [N][rows][Nout] -> zero padded bf16 dz [N*rpi][ldz] (optionally times sigmoid'). */
+int hn_head_grad(const float* dy, const float* y, long rpi, long img_stride, int lds, int Nout, void* dz, int ldz, long M, int sigmoid,
+                 hipStream_t stream);
+
+/* ---- reductions, BatchNorm, SE, elementwise (hn_norm.hip) ------------------------------------------------------------------- */
+
+long hn_colred_rows(long M, long align);
+/* per-channel partial sums / sums of squares over row blocks of R rows: psum, psq are [ceil(M/R)][C] */
+int hn_col_stats(const void* x, int ldx, long M, int C, long R, float* psum, float* psq, hipStream_t stream);
+int hn_col_dot(const void* a, int lda, const void* b, int ldb, long M, int C, long R, float* pdot, float* psum, hipStream_t stream);
+int hn_rows_reduce(const float* in, float* out, int G, int S, int C, float alpha, hipStream_t stream);
+
+/* Training-mode nn.BatchNorm2d (F.batch_norm): statistics -> (scale, shift, mean, rstd) + running-stat update. */
+int hn_bn_finalize(const float* psum, const float* psq, int prows, int C, long count, const float* gamma, const float* beta, float eps,
+                   float momentum, float* running_mean, float* running_var, float* scale, float* shift, float* mean, float* rstd,
+                   hipStream_t stream);
+int hn_bn_eval_coeff(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C, float* scale, float* shift,
+                     hipStream_t stream);
+/* out = act(scale*z + shift [+ (rscale*res + rshift | res)])   (BN apply + ReLU/Swish + residual add, net/anynet.py:65-76) */
+int hn_bn_act(const void* z, int ldz, const float* scale, const float* shift, const void* res, int ldr, const float* rscale,
+              const float* rshift, int act, void* out, int ldo, long M, int C, hipStream_t stream);
+/* BN backward: g = dout*act'(pre) (or dout*[y>0] when the saved post-ReLU output y is given); partial sums of g and g*xhat */
+int hn_bn_bwd_reduce(const void* dout, int ldd, const void* z, int ldz, const void* y, int ldy, const float* scale, const float* shift,
+                     const float* mean, const float* rstd, int act, long M, int C, long R, float* pg, float* pgx, hipStream_t stream);
+int hn_bn_bwd_finalize(const float* pg, const float* pgx, int prows, int C, long count, float* dgamma, float* dbeta, float* mg, float* mgx,
+                       hipStream_t stream);
+int hn_bn_bwd_apply(const void* dout, int ldd, const void* z, int ldz, const void* y, int ldy, const float* scale, const float* shift,
+                    const float* mean, const float* rstd, const float* mg, const float* mgx, int act, void* dz, int lddz, void* gout, int ldg,
+                    long M, int C, hipStream_t stream);
+
+/* SE gating x * gate[n][c] and its data-path backward (net/anynet.py:40-48,68-69). */
+int hn_scale_rows(const void* x, int ldx, const float* gate, long HW, void* out, int ldo, long M, int C, hipStream_t stream);
+int hn_se_bwd_apply(const void* dout, int ldd, const float* gate, const float* dpool, long HW, void* db, int ldb, long M, int C,
+                    hipStream_t stream);
+
+/* op 0: a+b, 1: a*act'(b = post-activation; ELU/ReLU), 2: alpha*a, 3: act(a), 4: a*act'(b = pre-activation) */
+int hn_eltwise(int op, const void* a, int lda, const void* b, int ldb, void* out, int ldo, long M, int C, int act, float alpha,
+               hipStream_t stream);
+int hn_add_strided2(void* dx, int ldx, const void* dxs, int lds, int N, int Ho, int Wo, int C, hipStream_t stream);
+int hn_cast_f32_to_bf16_pad(const float* src, int lds, void* dst, int ldo, long M, int C, hipStream_t stream);
+int hn_cast_bf16_to_f32(const void* src, int lds, float* dst, int ldo, long M, int C, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,70 @@
+// Common device helpers for the HydraNet gfx950 kernels (CDNA4 only: wave64, MFMA, 160 KB LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short short4v __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+#define HN_OK 0
+#define HN_ERR_ARG 1
+#define HN_ERR_LAUNCH 2
+#define HN_ERR_UNSUPPORTED 3
+
+#define HN_CHECK_ARG(cond) do { if (!(cond)) return HN_ERR_ARG; } while (0)
+#define HN_LAUNCH_CHECK() do { if (hipGetLastError() != hipSuccess) return HN_ERR_LAUNCH; return HN_OK; } while (0)
+
+__device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
+__device__ __forceinline__ bf16 f2bf(float v) { return (bf16)v; }
+__device__ __forceinline__ float bfround(float v) { return (float)((bf16)v); }
+
+__device__ __forceinline__ bf16x8 ld8(const bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ void st8(bf16* p, bf16x8 v) { *reinterpret_cast<bf16x8*>(p) = v; }
+__device__ __forceinline__ bf16x8 zero8() {
+    bf16x8 z;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z[i] = (bf16)0.0f;
+    return z;
+}
+
+// activation codes shared by the C-ABI
+#define HN_ACT_NONE 0
+#define HN_ACT_RELU 1
+#define HN_ACT_SWISH 2
+#define HN_ACT_ELU 3
+#define HN_ACT_SIGMOID 4
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float act_fwd(float x, int act) {
+    switch (act) {
+        case HN_ACT_RELU: return x > 0.f ? x : 0.f;
+        case HN_ACT_SWISH: return x * sigmoidf_(x);
+        case HN_ACT_ELU: return x > 0.f ? x : (__expf(x) - 1.0f);
+        case HN_ACT_SIGMOID: return sigmoidf_(x);
+        default: return x;
+    }
+}
+// derivative w.r.t. the pre-activation x
+__device__ __forceinline__ float act_bwd(float x, int act) {
+    switch (act) {
+        case HN_ACT_RELU: return x > 0.f ? 1.f : 0.f;
+        case HN_ACT_SWISH: { float s = sigmoidf_(x); return s * (1.f + x * (1.f - s)); }
+        case HN_ACT_ELU: return x > 0.f ? 1.f : __expf(x);
+        case HN_ACT_SIGMOID: { float s = sigmoidf_(x); return s * (1.f - s); }
+        default: return 1.f;
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,472 @@
+// HBM-bound NHWC bf16 kernels: per-channel reductions (BatchNorm statistics, SE pooling, BN-backward sums),
+// BatchNorm finalize / apply / backward, SE gating, and small elementwise helpers.
+// All tensors are [rows][C] bf16 with an explicit row stride (so producers can write channel slices of a concat
+// buffer); every thread moves 16 bytes (8 channels).  Reductions are deterministic: each workgroup writes one
+// partial row, a second tiny kernel reduces the partial rows (no float atomics).
+// Reference ops covered: nn.BatchNorm2d training-mode forward/backward incl. running statistics
+// (net/anynet.py:13,31,36,54,59; net/common.py:98; net/bifpn.py:60-101; head_detect/detection.py:23,60;
+// head_lane/lanedetect.py:47,54,61), ReLU / Swish (net/common.py:11-22) / residual add (net/anynet.py:75),
+// SE pooling + gating (net/anynet.py:40-48,68-69), ELU backward (head_seg/segmentation.py:24).
+#include "hn_common.h"
+
+// ---------------------------------------------------------------------------------------------------------
+// column reductions: block b reduces rows [b*R, (b+1)*R) and writes partial row b of two [prows][C] fp32 arrays
+//   MODE 0 (stats):   o1 = sum x            o2 = sum x^2
+//   MODE 1 (dot):     o1 = sum a*b          o2 = sum a
+//   MODE 2 (bn bwd):  g = dout * act'(pre); o1 = sum g, o2 = sum g * xhat
+// ---------------------------------------------------------------------------------------------------------
+struct ColRed {
+    const bf16* a; int lda;
+    const bf16* b; int ldb;      // MODE 1: second operand; MODE 2: z (pre-BN conv output)
+    const bf16* y; int ldy;      // MODE 2: optional saved block output (ReLU mask = y > 0)
+    const float* scale; const float* shift; const float* mean; const float* rstd;
+    int act;
+    long M; int C; long R;
+    float* o1; float* o2;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void colred_kernel(const ColRed p) {
+    __shared__ float red[2][256 * 8];
+    const int C8 = p.C >> 3;
+    const int tid = threadIdx.x;
+    const int rpi = 256 / C8 > 0 ? 256 / C8 : 1;      // rows per iteration (C8 <= 256 enforced on the host)
+    const int cg = tid % C8, rr = tid / C8;
+    const bool active = rr < rpi;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
+    const long m0 = (long)blockIdx.x * p.R;
+    long m1 = m0 + p.R;
+    if (m1 > p.M) m1 = p.M;
+    float sc[8], sh[8], mu[8], rs[8];
+    if (MODE == 2 && active) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = cg * 8 + k;
+            sc[k] = p.scale[c]; sh[k] = p.shift[c]; mu[k] = p.mean[c]; rs[k] = p.rstd[c];
+        }
+    }
+    if (active) {
+        for (long m = m0 + rr; m < m1; m += rpi) {
+            const bf16x8 va = ld8(p.a + m * p.lda + cg * 8);
+            if (MODE == 0) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const float v = bf2f(va[k]); s1[k] += v; s2[k] += v * v; }
+            } else if (MODE == 1) {
+                const bf16x8 vb = ld8(p.b + m * p.ldb + cg * 8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const float v = bf2f(va[k]); s1[k] += v * bf2f(vb[k]); s2[k] += v; }
+            } else {
+                const bf16x8 vz = ld8(p.b + m * p.ldb + cg * 8);
+                bf16x8 vy;
+                if (p.y) vy = ld8(p.y + m * p.ldy + cg * 8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float z = bf2f(vz[k]);
+                    float g = bf2f(va[k]);
+                    if (p.y) g = bf2f(vy[k]) > 0.f ? g : 0.f;
+                    else g *= act_bwd(sc[k] * z + sh[k], p.act);
+                    s1[k] += g;
+                    s2[k] += g * (z - mu[k]) * rs[k];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { red[0][tid * 8 + k] = s1[k]; red[1][tid * 8 + k] = s2[k]; }
+    }
+    __syncthreads();
+    for (int c = tid; c < p.C; c += 256) {
+        const int g8 = c >> 3, k = c & 7;
+        float t1 = 0.f, t2 = 0.f;
+        for (int r = 0; r < rpi; ++r) {
+            t1 += red[0][(r * C8 + g8) * 8 + k];
+            t2 += red[1][(r * C8 + g8) * 8 + k];
+        }
+        p.o1[(long)blockIdx.x * p.C + c] = t1;
+        p.o2[(long)blockIdx.x * p.C + c] = t2;
+    }
+}
+
+// out[g][c] = alpha * sum_{j < S} in[(g*S + j)][c]      (one thread per (g, c))
+__global__ void rows_reduce_kernel(const float* in, float* out, int G, int S, int C, float alpha) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)G * C) return;
+    const int g = (int)(idx / C), c = (int)(idx - (long)g * C);
+    const float* src = in + (long)g * S * C + c;
+    double s = 0.0;
+    for (int j = 0; j < S; ++j) s += src[(long)j * C];
+    out[idx] = (float)(s * alpha);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// BatchNorm finalize (training): one wave per channel reduces the partial rows, then derives
+//   mean, biased var -> rstd, scale = gamma*rstd, shift = beta - mean*scale, and updates the running statistics
+//   (unbiased variance, PyTorch momentum convention) -- F.batch_norm semantics.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void bn_finalize_kernel(const float* psum, const float* psq, int prows, int C, double count,
+                                                         const float* gamma, const float* beta, float eps, float momentum,
+                                                         float* running_mean, float* running_var, float* scale, float* shift,
+                                                         float* mean, float* rstd) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = lane; r < prows; r += 64) { s1 += psum[(long)r * C + c]; s2 += psq[(long)r * C + c]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if (lane == 0) {
+        const double mu = s1 / count;
+        double var = s2 / count - mu * mu;
+        if (var < 0.0) var = 0.0;
+        const float rs = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[c] * rs;
+        scale[c] = sc;
+        shift[c] = beta[c] - (float)mu * sc;
+        mean[c] = (float)mu;
+        rstd[c] = rs;
+        if (running_mean) {
+            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+        }
+    }
+}
+
+// eval-mode BN: scale/shift from the running statistics
+__global__ void bn_eval_coeff_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C,
+                                     float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] / sqrtf(rv[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - rm[c] * sc;
+}
+
+// dgamma = sum g*xhat, dbeta = sum g, and the two per-channel means the apply pass needs
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* pg, const float* pgx, int prows, int C, double count,
+                                                             float* dgamma, float* dbeta, float* mg, float* mgx) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = lane; r < prows; r += 64) { s1 += pg[(long)r * C + c]; s2 += pgx[(long)r * C + c]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if (lane == 0) {
+        dbeta[c] = (float)s1;
+        dgamma[c] = (float)s2;
+        mg[c] = (float)(s1 / count);
+        mgx[c] = (float)(s2 / count);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// elementwise kernels (grid-stride over 16-byte pieces)
+// ---------------------------------------------------------------------------------------------------------
+struct BnAct {
+    const bf16* z; int ldz; const float* scale; const float* shift;
+    const bf16* res; int ldr; const float* rscale; const float* rshift;   // optional residual (+ its own BN)
+    int act; bf16* out; int ldo; long M; int C;
+};
+__global__ __launch_bounds__(256) void bn_act_kernel(const BnAct p) {
+    const int C8 = p.C >> 3;
+    const long total = p.M * C8;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long m = idx / C8;
+        const int c = (int)(idx - m * C8) * 8;
+        const bf16x8 vz = ld8(p.z + m * p.ldz + c);
+        bf16x8 vr;
+        if (p.res) vr = ld8(p.res + m * p.ldr + c);
+        bf16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float v = bf2f(vz[k]);
+            if (p.scale) v = v * p.scale[c + k] + p.shift[c + k];
+            if (p.res) {
+                float r = bf2f(vr[k]);
+                if (p.rscale) r = r * p.rscale[c + k] + p.rshift[c + k];
+                v += r;
+            }
+            o[k] = f2bf(act_fwd(v, p.act));
+        }
+        st8(p.out + m * p.ldo + c, o);
+    }
+}
+
+struct BnBwdApply {
+    const bf16* dout; int ldd; const bf16* z; int ldz; const bf16* y; int ldy;
+    const float* scale; const float* shift; const float* mean; const float* rstd; const float* mg; const float* mgx;
+    int act; bf16* dz; int lddz; bf16* gout; int ldg; long M; int C;
+};
+// dz = scale * (g - mean(g) - xhat * mean(g*xhat)),  g = dout * act'(pre)   (optionally also emits g)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApply p) {
+    const int C8 = p.C >> 3;
+    const long total = p.M * C8;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long m = idx / C8;
+        const int c = (int)(idx - m * C8) * 8;
+        const bf16x8 vd = ld8(p.dout + m * p.ldd + c);
+        const bf16x8 vz = ld8(p.z + m * p.ldz + c);
+        bf16x8 vy;
+        if (p.y) vy = ld8(p.y + m * p.ldy + c);
+        bf16x8 o, og;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float z = bf2f(vz[k]);
+            float g = bf2f(vd[k]);
+            if (p.y) g = bf2f(vy[k]) > 0.f ? g : 0.f;
+            else g *= act_bwd(p.scale[c + k] * z + p.shift[c + k], p.act);
+            const float xh = (z - p.mean[c + k]) * p.rstd[c + k];
+            o[k] = f2bf(p.scale[c + k] * (g - p.mg[c + k] - xh * p.mgx[c + k]));
+            og[k] = f2bf(g);
+        }
+        st8(p.dz + m * p.lddz + c, o);
+        if (p.gout) st8(p.gout + m * p.ldg + c, og);
+    }
+}
+
+// out[m][c] = x[m][c] * gate[m / HW][c]
+__global__ __launch_bounds__(256) void scale_rows_kernel(const bf16* x, int ldx, const float* gate, long HW, bf16* out, int ldo,
+                                                         long M, int C) {
+    const int C8 = C >> 3;
+    const long total = M * C8;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long m = idx / C8;
+        const int c = (int)(idx - m * C8) * 8;
+        const float* g = gate + (m / HW) * C + c;
+        const bf16x8 v = ld8(x + m * ldx + c);
+        bf16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = f2bf(bf2f(v[k]) * g[k]);
+        st8(out + m * ldo + c, o);
+    }
+}
+
+// SE backward, data path: db = dout * gate[n][c] + dpool[n][c] / HW
+__global__ __launch_bounds__(256) void se_bwd_apply_kernel(const bf16* dout, int ldd, const float* gate, const float* dpool, long HW,
+                                                           bf16* db, int ldb, long M, int C) {
+    const int C8 = C >> 3;
+    const long total = M * C8;
+    const float inv = 1.0f / (float)HW;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long m = idx / C8;
+        const int c = (int)(idx - m * C8) * 8;
+        const long n = m / HW;
+        const bf16x8 v = ld8(dout + m * ldd + c);
+        bf16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = f2bf(bf2f(v[k]) * gate[n * C + c + k] + dpool[n * C + c + k] * inv);
+        st8(db + m * ldb + c, o);
+    }
+}
+
+// generic binary / unary elementwise ops on [M][C] bf16:
+//   op 0: out = a + b          op 1: out = a * act'(y) with y = post-activation (ELU: y>0 ? 1 : y+1 ; RELU: y>0)
+//   op 2: out = alpha * a      op 3: out = act(a)      op 4: out = a * act'(b) with b = PRE-activation
+struct Ew { const bf16* a; int lda; const bf16* b; int ldb; bf16* out; int ldo; long M; int C; int op; int act; float alpha; };
+__global__ __launch_bounds__(256) void ew_kernel(const Ew p) {
+    const int C8 = p.C >> 3;
+    const long total = p.M * C8;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long m = idx / C8;
+        const int c = (int)(idx - m * C8) * 8;
+        const bf16x8 va = ld8(p.a + m * p.lda + c);
+        bf16x8 vb;
+        if (p.b) vb = ld8(p.b + m * p.ldb + c);
+        bf16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float a = bf2f(va[k]);
+            float r;
+            if (p.op == 0) r = a + bf2f(vb[k]);
+            else if (p.op == 1) {
+                const float y = bf2f(vb[k]);
+                r = p.act == HN_ACT_ELU ? (y > 0.f ? a : a * (y + 1.0f)) : (y > 0.f ? a : 0.f);
+            } else if (p.op == 2) r = p.alpha * a;
+            else if (p.op == 3) r = act_fwd(a, p.act);
+            else r = a * act_bwd(bf2f(vb[k]), p.act);
+            o[k] = f2bf(r);
+        }
+        st8(p.out + m * p.ldo + c, o);
+    }
+}
+
+// dx[n, 2y, 2x, :] += dxs[n, y, x, :]   (backward of a stride-2 1x1 conv's row gather)
+__global__ __launch_bounds__(256) void add_strided2_kernel(bf16* dx, int ldx, const bf16* dxs, int lds_, int N, int Ho, int Wo, int C) {
+    const int C8 = C >> 3;
+    const long total = (long)N * Ho * Wo * C8;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long ms = idx / C8;
+        const int c = (int)(idx - ms * C8) * 8;
+        const int ox = (int)(ms % Wo);
+        const long t = ms / Wo;
+        const int oy = (int)(t % Ho);
+        const long n = t / Ho;
+        const long m = (n * 2 * Ho + 2 * oy) * (2L * Wo) + 2 * ox;
+        const bf16x8 a = ld8(dx + m * ldx + c), b = ld8(dxs + ms * lds_ + c);
+        bf16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = f2bf(bf2f(a[k]) + bf2f(b[k]));
+        st8(dx + m * ldx + c, o);
+    }
+}
+
+// fp32 [M][C] (row stride lds) -> bf16 [M][ldo] zero padded; and back
+__global__ void cast_pad_kernel(const float* src, int lds_, bf16* dst, int ldo, long M, int C) {
+    const long total = M * ldo;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long m = idx / ldo;
+        const int c = (int)(idx - m * ldo);
+        dst[idx] = f2bf(c < C ? src[m * lds_ + c] : 0.f);
+    }
+}
+__global__ void cast_f32_kernel(const bf16* src, int lds_, float* dst, int ldo, long M, int C) {
+    const long total = M * C;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long m = idx / C;
+        const int c = (int)(idx - m * C);
+        dst[m * ldo + c] = bf2f(src[m * lds_ + c]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------
+static inline int ew_grid(long pieces) {
+    long b = (pieces + 255) / 256;
+    if (b > 2048 * 4) b = 2048 * 4;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// rows per block for a column reduction over M rows (~1024 partial rows; a multiple of `align` if given)
+extern "C" long hn_colred_rows(long M, long align) {
+    long R = (M + 1023) / 1024;
+    if (R < 64) R = 64;
+    if (align > 0) {
+        if (R > align) R = align;                 // keep partial rows inside one image (align = H*W)
+        while (align % R) --R;
+    }
+    return R;
+}
+
+static int launch_colred(int mode, const ColRed& p, hipStream_t st) {
+    HN_CHECK_ARG(p.a && p.o1 && p.o2 && (p.C & 7) == 0 && p.C <= 2048 && p.M > 0 && p.R > 0 && (p.lda & 7) == 0);
+    const int grid = cdiv(p.M, p.R);
+    if (mode == 0) hipLaunchKernelGGL(colred_kernel<0>, dim3(grid), dim3(256), 0, st, p);
+    else if (mode == 1) hipLaunchKernelGGL(colred_kernel<1>, dim3(grid), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(colred_kernel<2>, dim3(grid), dim3(256), 0, st, p);
+    HN_LAUNCH_CHECK();
+}
+
+extern "C" int hn_col_stats(const void* x, int ldx, long M, int C, long R, float* psum, float* psq, hipStream_t st) {
+    ColRed p = {};
+    p.a = (const bf16*)x; p.lda = ldx; p.M = M; p.C = C; p.R = R; p.o1 = psum; p.o2 = psq;
+    return launch_colred(0, p, st);
+}
+
+extern "C" int hn_col_dot(const void* a, int lda, const void* b, int ldb, long M, int C, long R, float* pdot, float* psum,
+                          hipStream_t st) {
+    HN_CHECK_ARG(b && (ldb & 7) == 0);
+    ColRed p = {};
+    p.a = (const bf16*)a; p.lda = lda; p.b = (const bf16*)b; p.ldb = ldb; p.M = M; p.C = C; p.R = R; p.o1 = pdot; p.o2 = psum;
+    return launch_colred(1, p, st);
+}
+
+extern "C" int hn_rows_reduce(const float* in, float* out, int G, int S, int C, float alpha, hipStream_t st) {
+    HN_CHECK_ARG(in && out && G > 0 && S > 0 && C > 0);
+    hipLaunchKernelGGL(rows_reduce_kernel, dim3(cdiv((long)G * C, 256)), dim3(256), 0, st, in, out, G, S, C, alpha);
+    HN_LAUNCH_CHECK();
+}
+
+extern "C" int hn_bn_finalize(const float* psum, const float* psq, int prows, int C, long count, const float* gamma,
+                              const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* scale,
+                              float* shift, float* mean, float* rstd, hipStream_t st) {
+    HN_CHECK_ARG(psum && psq && prows > 0 && C > 0 && count > 0 && gamma && beta && scale && shift && mean && rstd);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, st, psum, psq, prows, C, (double)count, gamma, beta, eps, momentum,
+                       running_mean, running_var, scale, shift, mean, rstd);
+    HN_LAUNCH_CHECK();
+}
+
+extern "C" int hn_bn_eval_coeff(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C,
+                                float* scale, float* shift, hipStream_t st) {
+    HN_CHECK_ARG(gamma && beta && rm && rv && scale && shift && C > 0);
+    hipLaunchKernelGGL(bn_eval_coeff_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, gamma, beta, rm, rv, eps, C, scale, shift);
+    HN_LAUNCH_CHECK();
+}
+
+extern "C" int hn_bn_act(const void* z, int ldz, const float* scale, const float* shift, const void* res, int ldr,
+                         const float* rscale, const float* rshift, int act, void* out, int ldo, long M, int C, hipStream_t st) {
+    HN_CHECK_ARG(z && out && M > 0 && (C & 7) == 0 && (ldz & 7) == 0 && (ldo & 7) == 0 && (!res || (ldr & 7) == 0));
+    BnAct p = {(const bf16*)z, ldz, scale, shift, (const bf16*)res, ldr, rscale, rshift, act, (bf16*)out, ldo, M, C};
+    hipLaunchKernelGGL(bn_act_kernel, dim3(ew_grid(M * (C >> 3))), dim3(256), 0, st, p);
+    HN_LAUNCH_CHECK();
+}
+
+extern "C" int hn_bn_bwd_reduce(const void* dout, int ldd, const void* z, int ldz, const void* y, int ldy, const float* scale,
+                                const float* shift, const float* mean, const float* rstd, int act, long M, int C, long R, float* pg,
+                                float* pgx, hipStream_t st) {
+    HN_CHECK_ARG(z && scale && shift && mean && rstd && (ldz & 7) == 0 && (!y || (ldy & 7) == 0));
+    ColRed p = {};
+    p.a = (const bf16*)dout; p.lda = ldd; p.b = (const bf16*)z; p.ldb = ldz; p.y = (const bf16*)y; p.ldy = ldy;
+    p.scale = scale; p.shift = shift; p.mean = mean; p.rstd = rstd; p.act = act; p.M = M; p.C = C; p.R = R; p.o1 = pg; p.o2 = pgx;
+    return launch_colred(2, p, st);
+}
+
+extern "C" int hn_bn_bwd_finalize(const float* pg, const float* pgx, int prows, int C, long count, float* dgamma, float* dbeta,
+                                  float* mg, float* mgx, hipStream_t st) {
+    HN_CHECK_ARG(pg && pgx && prows > 0 && C > 0 && count > 0 && dgamma && dbeta && mg && mgx);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, pg, pgx, prows, C, (double)count, dgamma, dbeta, mg, mgx);
+    HN_LAUNCH_CHECK();
+}
+
+extern "C" int hn_bn_bwd_apply(const void* dout, int ldd, const void* z, int ldz, const void* y, int ldy, const float* scale,
+                               const float* shift, const float* mean, const float* rstd, const float* mg, const float* mgx, int act,
+                               void* dz, int lddz, void* gout, int ldg, long M, int C, hipStream_t st) {
+    HN_CHECK_ARG(dout && z && dz && M > 0 && (C & 7) == 0 && ((ldd | ldz | lddz) & 7) == 0 && (!y || (ldy & 7) == 0) &&
+                 (!gout || (ldg & 7) == 0));
+    BnBwdApply p = {(const bf16*)dout, ldd, (const bf16*)z, ldz, (const bf16*)y, ldy, scale, shift, mean, rstd, mg, mgx, act,
+                    (bf16*)dz, lddz, (bf16*)gout, ldg, M, C};
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(M * (C >> 3))), dim3(256), 0, st, p);
+    HN_LAUNCH_CHECK();
+}
+
+extern "C" int hn_scale_rows(const void* x, int ldx, const float* gate, long HW, void* out, int ldo, long M, int C, hipStream_t st) {
+    HN_CHECK_ARG(x && gate && out && HW > 0 && M > 0 && (C & 7) == 0 && ((ldx | ldo) & 7) == 0);
+    hipLaunchKernelGGL(scale_rows_kernel, dim3(ew_grid(M * (C >> 3))), dim3(256), 0, st, (const bf16*)x, ldx, gate, HW, (bf16*)out, ldo,
+                       M, C);
+    HN_LAUNCH_CHECK();
+}
+
+extern "C" int hn_se_bwd_apply(const void* dout, int ldd, const float* gate, const float* dpool, long HW, void* db, int ldb, long M,
+                               int C, hipStream_t st) {
+    HN_CHECK_ARG(dout && gate && dpool && db && HW > 0 && M > 0 && (C & 7) == 0 && ((ldd | ldb) & 7) == 0);
+    hipLaunchKernelGGL(se_bwd_apply_kernel, dim3(ew_grid(M * (C >> 3))), dim3(256), 0, st, (const bf16*)dout, ldd, gate, dpool, HW,
+                       (bf16*)db, ldb, M, C);
+    HN_LAUNCH_CHECK();
+}
+
+extern "C" int hn_eltwise(int op, const void* a, int lda, const void* b, int ldb, void* out, int ldo, long M, int C, int act,
+                          float alpha, hipStream_t st) {
+    HN_CHECK_ARG(a && out && M > 0 && (C & 7) == 0 && ((lda | ldo) & 7) == 0 && op >= 0 && op <= 4);
+    HN_CHECK_ARG((op == 2 || op == 3) || (b && (ldb & 7) == 0));
+    Ew p = {(const bf16*)a, lda, (const bf16*)b, ldb, (bf16*)out, ldo, M, C, op, act, alpha};
+    hipLaunchKernelGGL(ew_kernel, dim3(ew_grid(M * (C >> 3))), dim3(256), 0, st, p);
+    HN_LAUNCH_CHECK();
+}
+
+extern "C" int hn_add_strided2(void* dx, int ldx, const void* dxs, int lds_, int N, int Ho, int Wo, int C, hipStream_t st) {
+    HN_CHECK_ARG(dx && dxs && N > 0 && Ho > 0 && Wo > 0 && (C & 7) == 0 && ((ldx | lds_) & 7) == 0);
+    hipLaunchKernelGGL(add_strided2_kernel, dim3(ew_grid((long)N * Ho * Wo * (C >> 3))), dim3(256), 0, st, (bf16*)dx, ldx,
+                       (const bf16*)dxs, lds_, N, Ho, Wo, C);
+    HN_LAUNCH_CHECK();
+}
+
+extern "C" int hn_cast_f32_to_bf16_pad(const float* src, int lds_, void* dst, int ldo, long M, int C, hipStream_t st) {
+    HN_CHECK_ARG(src && dst && M > 0 && C > 0 && ldo >= C);
+    hipLaunchKernelGGL(cast_pad_kernel, dim3(ew_grid(M * ldo)), dim3(256), 0, st, src, lds_, (bf16*)dst, ldo, M, C);
+    HN_LAUNCH_CHECK();
+}
+
+extern "C" int hn_cast_bf16_to_f32(const void* src, int lds_, float* dst, int ldo, long M, int C, hipStream_t st) {
+    HN_CHECK_ARG(src && dst && M > 0 && C > 0);
+    hipLaunchKernelGGL(cast_f32_kernel, dim3(ew_grid(M * C)), dim3(256), 0, st, (const bf16*)src, lds_, dst, ldo, M, C);
+    HN_LAUNCH_CHECK();
+}

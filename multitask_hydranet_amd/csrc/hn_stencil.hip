@@ -1,0 +1,858 @@
+// Im2col-free NHWC stencil kernels (VALU; channel counts per group are too thin for MFMA):
+//   stem 3x3/s2 dense conv from the NCHW fp32 frame, grouped 3x3 (group width 8) fwd/dgrad/wgrad, depthwise 3x3
+//   fwd/dgrad/wgrad, the two 3x3/s2 max-pool flavours fwd/bwd, nearest x2 up-sampling, the BiFPN weighted-fusion
+//   node fwd/bwd, and the fold that turns the segmentation decoder's padded-domain dgrad back into input gradients.
+// Reference ops covered: Stem (net/anynet.py:8-20), XBlock conv_block_2 (net/anynet.py:34-38), SeparableConvBlock's
+// depthwise conv (net/common.py:91-92,104), MaxPool2dStaticSamePadding (net/common.py:117-152; ZERO pad participates),
+// nn.MaxPool2d(3,2,1) (head_lane/lanedetect.py:40), F.interpolate nearest (net/bifpn.py:43-46),
+// BiFPN._forward_fast_attention fusion nodes (net/bifpn.py:177-231), ReflectionPad2d backward
+// (head_seg/segmentation.py:40).
+#include "hn_common.h"
+
+// ---------------------------------------------------------------------------------------------------------
+// stem: x NCHW fp32 [N,3,H,W] -> z NHWC bf16 [N,H/2,W/2,32]; weights fp32 [32][3][3][3]
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* x, const float* w, bf16* z, int N, int H, int W) {
+    __shared__ float sw[27][32];
+    for (int i = threadIdx.x; i < 27 * 32; i += 256) {
+        const int co = i & 31, t = i >> 5;        // t = ci*9 + ky*3 + kx
+        sw[t][co] = w[co * 27 + t];
+    }
+    __syncthreads();
+    const int Ho = H >> 1, Wo = W >> 1;
+    const long total = (long)N * Ho * Wo;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int ox = (int)(idx % Wo);
+    const long t1 = idx / Wo;
+    const int oy = (int)(t1 % Ho);
+    const long n = t1 / Ho;
+    float acc[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) acc[c] = 0.f;
+#pragma unroll 1
+    for (int t = 0; t < 9; ++t) {                  // t = ci*3 + ky ; kept rolled so the 864 weights are not hoisted
+        const int ci = t / 3, ky = t - ci * 3;
+        const int iy = 2 * oy + ky - 1;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = 2 * ox + kx - 1;
+            float v = 0.f;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[((n * 3 + ci) * H + iy) * (long)W + ix];
+            const float* wr = sw[t * 3 + kx];
+#pragma unroll
+            for (int c = 0; c < 32; ++c) acc[c] = fmaf(v, wr[c], acc[c]);
+        }
+    }
+    bf16* o = z + idx * 32;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        bf16x8 v;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = f2bf(acc[q * 8 + k]);
+        st8(o + q * 8, v);
+    }
+}
+
+// stem wgrad partials: part[block][co*27 + t] = sum over the block's pixels of dz[pix][co] * x[n, ci, 2oy+ky-1, 2ox+kx-1]
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* x, const bf16* dz, float* part, int N, int H, int W, long ppb) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    const long total = (long)N * Ho * Wo;
+    const int co = threadIdx.x & 31, tg = threadIdx.x >> 5;     // 8 tap groups: taps tg, tg+8, tg+16, tg+24 (<27)
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const long p0 = (long)blockIdx.x * ppb;
+    long p1 = p0 + ppb;
+    if (p1 > total) p1 = total;
+    for (long pix = p0; pix < p1; ++pix) {
+        const int ox = (int)(pix % Wo);
+        const long t1 = pix / Wo;
+        const int oy = (int)(t1 % Ho);
+        const long n = t1 / Ho;
+        const float g = bf2f(dz[pix * 32 + co]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int t = tg + 8 * k;
+            if (t < 27) {
+                const int ci = t / 9, r = t - ci * 9, ky = r / 3, kx = r - ky * 3;
+                const int iy = 2 * oy + ky - 1, ix = 2 * ox + kx - 1;
+                float v = 0.f;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[((n * 3 + ci) * H + iy) * (long)W + ix];
+                acc[k] = fmaf(g, v, acc[k]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int t = tg + 8 * k;
+        if (t < 27) part[(long)blockIdx.x * 864 + co * 27 + t] = acc[k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// grouped 3x3 conv, group width 8, pad 1.  Packed weights wk[tap][i][G][8 o] (bf16): 16 B per (tap, i, group).
+//   out[n, oy, ox, g*8 + o] = sum_{tap, i} in[n, oy*s + ky - 1, ox*s + kx - 1, g*8 + i] * wk[tap][i][g][o]
+// One thread = one group x a strip of 4 output pixels along x.
+// ---------------------------------------------------------------------------------------------------------
+template <int S>
+__global__ __launch_bounds__(256) void gconv_fwd_kernel(const bf16* in, int ldi, const bf16* wk, bf16* out, int ldo, int N, int Hi,
+                                                        int Wi, int Ho, int Wo, int G) {
+    const int strips = (Wo + 3) >> 2;
+    const long total = (long)N * Ho * strips * G;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int g = (int)(idx % G);
+    long t = idx / G;
+    const int sx = (int)(t % strips);
+    t /= strips;
+    const int oy = (int)(t % Ho);
+    const long n = t / Ho;
+    const int ox0 = sx * 4;
+    float acc[4][8];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int o = 0; o < 8; ++o) acc[p][o] = 0.f;
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {          // rolled: 4 pixel pieces + 8 weight pieces live per tap (L1-resident re-reads)
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int iy = oy * S + ky - 1;
+        if (iy < 0 || iy >= Hi) continue;
+        float xf[4][8];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int ix = (ox0 + p) * S + kx - 1;
+            const bf16x8 v = (ix >= 0 && ix < Wi) ? ld8(in + ((n * Hi + iy) * (long)Wi + ix) * ldi + g * 8) : zero8();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) xf[p][i] = bf2f(v[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bf16x8 wv = ld8(wk + (((long)tap * 8 + i) * G + g) * 8);
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {
+                const float wf = bf2f(wv[o]);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) acc[p][o] = fmaf(xf[p][i], wf, acc[p][o]);
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        if (ox0 + p >= Wo) break;
+        bf16x8 v;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) v[o] = f2bf(acc[p][o]);
+        st8(out + ((n * Ho + oy) * (long)Wo + ox0 + p) * ldo + g * 8, v);
+    }
+}
+
+// stride-2 dgrad: dx[n, iy, ix, g*8+i] = sum_{ky,kx,o : (iy+1-ky, ix+1-kx) even} dz[n, (iy+1-ky)/2, (ix+1-kx)/2, g*8+o] * wd[tap][o][g][i]
+// where wd is the forward weight packed with the o/i roles swapped (tap NOT flipped).
+__global__ __launch_bounds__(256) void gconv_dgrad_s2_kernel(const bf16* dz, int ldz, const bf16* wd, bf16* dx, int ldx, int N, int Hi,
+                                                             int Wi, int Ho, int Wo, int G) {
+    const long total = (long)N * Hi * Wi * G;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int g = (int)(idx % G);
+    long t = idx / G;
+    const int ix = (int)(t % Wi);
+    t /= Wi;
+    const int iy = (int)(t % Hi);
+    const long n = t / Hi;
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int ty = iy + 1 - ky;
+        if (ty < 0 || (ty & 1) || (ty >> 1) >= Ho) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int tx = ix + 1 - kx;
+            if (tx < 0 || (tx & 1) || (tx >> 1) >= Wo) continue;
+            const bf16x8 zv = ld8(dz + ((n * Ho + (ty >> 1)) * (long)Wo + (tx >> 1)) * ldz + g * 8);
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {
+                const bf16x8 wv = ld8(wd + (((long)(ky * 3 + kx) * 8 + o) * G + g) * 8);
+                const float zf = bf2f(zv[o]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] = fmaf(zf, bf2f(wv[i]), acc[i]);
+            }
+        }
+    }
+    bf16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = f2bf(acc[i]);
+    st8(dx + ((n * Hi + iy) * (long)Wi + ix) * ldx + g * 8, v);
+}
+
+// wgrad partials: part[chunk][((g*8+o)*8 + i)*9 + tap] = sum over the chunk's output pixels of dz[pix][g*8+o] * x[pix(tap)][g*8+i]
+__global__ __launch_bounds__(256) void gconv_wgrad_kernel(const bf16* x, int ldx, const bf16* dz, int ldz, float* part, int N, int Hi,
+                                                          int Wi, int Ho, int Wo, int G, int S, long ppc) {
+    const int items = G * 9;
+    const int item = blockIdx.y * 256 + threadIdx.x;
+    if (item >= items) return;
+    const int g = item % G, tap = item / G;
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const long total = (long)N * Ho * Wo;
+    const long p0 = (long)blockIdx.x * ppc;
+    long p1 = p0 + ppc;
+    if (p1 > total) p1 = total;
+    float acc[8][8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[o][i] = 0.f;
+    for (long pix = p0; pix < p1; ++pix) {
+        const int ox = (int)(pix % Wo);
+        const long t1 = pix / Wo;
+        const int oy = (int)(t1 % Ho);
+        const long n = t1 / Ho;
+        const int iy = oy * S + ky - 1, ix = ox * S + kx - 1;
+        if (iy < 0 || iy >= Hi || ix < 0 || ix >= Wi) continue;
+        const bf16x8 zv = ld8(dz + pix * ldz + g * 8);
+        const bf16x8 xv = ld8(x + ((n * Hi + iy) * (long)Wi + ix) * ldx + g * 8);
+        float xf[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xf[i] = bf2f(xv[i]);
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            const float zf = bf2f(zv[o]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[o][i] = fmaf(zf, xf[i], acc[o][i]);
+        }
+    }
+    float* dst = part + (long)blockIdx.x * G * 576;
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dst[((long)(g * 8 + o) * 8 + i) * 9 + tap] = acc[o][i];
+}
+
+// pack fp32 grouped weights [C][8][3][3] into wk[tap][i][G][o] (forward) and wd[tap'][o][G][i]:
+//   flip = 1: tap' = 8 - tap (stride-1 dgrad runs the forward kernel on dz);  flip = 0: tap' = tap (stride-2 dgrad kernel)
+__global__ void gconv_pack_kernel(const float* w, bf16* wk, bf16* wd, int G, int flip) {
+    const long total = (long)G * 576;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    // idx enumerates the destination layout [tap][a][G][b]
+    const int b = (int)(idx & 7);
+    long t = idx >> 3;
+    const int g = (int)(t % G);
+    t /= G;
+    const int a = (int)(t & 7);
+    const int tap = (int)(t >> 3);
+    wk[idx] = f2bf(w[((long)(g * 8 + b) * 8 + a) * 9 + tap]);                       // a = i, b = o
+    if (wd) wd[idx] = f2bf(w[((long)(g * 8 + a) * 8 + b) * 9 + (flip ? 8 - tap : tap)]);   // a = o, b = i
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// depthwise 3x3, stride 1, zero pad 1.  Packed weights wk[tap][C] bf16.  Thread = 8 channels x strip of 4 pixels.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const bf16* in, int ldi, const bf16* wk, bf16* out, int ldo, int N, int H, int W,
+                                                         int C) {
+    const int C8 = C >> 3, strips = (W + 3) >> 2;
+    const long total = (long)N * H * strips * C8;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int cg = (int)(idx % C8);
+    long t = idx / C8;
+    const int sx = (int)(t % strips);
+    t /= strips;
+    const int oy = (int)(t % H);
+    const long n = t / H;
+    const int ox0 = sx * 4;
+    float acc[4][8];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[p][k] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy + ky - 1;
+        if (iy < 0 || iy >= H) continue;
+        bf16x8 row[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int ix = ox0 - 1 + j;
+            row[j] = (ix >= 0 && ix < W) ? ld8(in + ((n * H + iy) * (long)W + ix) * ldi + cg * 8) : zero8();
+        }
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const bf16x8 wv = ld8(wk + (long)(ky * 3 + kx) * C + cg * 8);
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[p][k] = fmaf(bf2f(row[p + kx][k]), bf2f(wv[k]), acc[p][k]);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        if (ox0 + p >= W) break;
+        bf16x8 v;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = f2bf(acc[p][k]);
+        st8(out + ((n * H + oy) * (long)W + ox0 + p) * ldo + cg * 8, v);
+    }
+}
+
+// wgrad partials: part[chunk][c*9 + tap] = sum over the chunk's pixels of dz[pix][c] * x[pix + tap - 1][c]
+__global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const bf16* x, int ldx, const bf16* dz, int ldz, float* part, int N, int H,
+                                                           int W, int C, long ppc) {
+    const int C8 = C >> 3;
+    const int cg = blockIdx.y * 256 + threadIdx.x;
+    if (cg >= C8) return;
+    const long total = (long)N * H * W;
+    const long p0 = (long)blockIdx.x * ppc;
+    long p1 = p0 + ppc;
+    if (p1 > total) p1 = total;
+    float acc[9][8];
+#pragma unroll
+    for (int tq = 0; tq < 9; ++tq)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[tq][k] = 0.f;
+    for (long pix = p0; pix < p1; ++pix) {
+        const int ox = (int)(pix % W);
+        const long t1 = pix / W;
+        const int oy = (int)(t1 % H);
+        const long n = t1 / H;
+        const bf16x8 zv = ld8(dz + pix * ldz + cg * 8);
+        float zf[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) zf[k] = bf2f(zv[k]);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy + ky - 1;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox + kx - 1;
+                if (ix < 0 || ix >= W) continue;
+                const bf16x8 xv = ld8(x + ((n * H + iy) * (long)W + ix) * ldx + cg * 8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[ky * 3 + kx][k] = fmaf(zf[k], bf2f(xv[k]), acc[ky * 3 + kx][k]);
+            }
+        }
+    }
+    float* dst = part + (long)blockIdx.x * C * 9;
+#pragma unroll
+    for (int tq = 0; tq < 9; ++tq)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dst[(long)(cg * 8 + k) * 9 + tq] = acc[tq][k];
+}
+
+// fp32 [C][1][3][3] -> wk[tap][C] and flipped wkf[8 - tap][C]
+__global__ void dw_pack_kernel(const float* w, bf16* wk, bf16* wkf, int C) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 9 * C) return;
+    const int c = idx % C, tap = idx / C;
+    const bf16 v = f2bf(w[c * 9 + tap]);
+    wk[idx] = v;
+    if (wkf) wkf[(8 - tap) * C + c] = v;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// 3x3 stride-2 max pools.  mode 0: ZERO pad right/bottom (window rows 2oy..2oy+2, out-of-range taps contribute 0.0),
+// mode 1: -inf pad 1 (window rows 2oy-1..2oy+1, out-of-range taps ignored).  Ho = H/2, Wo = W/2 (H, W even) -- also
+// valid for odd-free shapes down to 2x2.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pool_window(const bf16* in, int ldi, long n, int H, int W, int oy, int ox, int c, int mode, float* best,
+                                            int* arg) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { best[k] = -INFINITY; arg[k] = -1; }
+    const int off = mode ? -1 : 0;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int iy = 2 * oy + ky + off, ix = 2 * ox + kx + off;
+            const bool inside = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            if (!inside && mode) continue;
+            bf16x8 v = inside ? ld8(in + ((n * H + iy) * (long)W + ix) * ldi + c) : zero8();
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float f = bf2f(v[k]);
+                if (f > best[k]) { best[k] = f; arg[k] = inside ? ky * 3 + kx : 9; }   // first maximum wins (strict >)
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const bf16* in, int ldi, bf16* out, int ldo, int N, int H, int W, int C,
+                                                          int mode) {
+    const int C8 = C >> 3, Ho = H >> 1, Wo = W >> 1;
+    const long total = (long)N * Ho * Wo * C8;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int cg = (int)(idx % C8);
+        long t = idx / C8;
+        const int ox = (int)(t % Wo);
+        t /= Wo;
+        const int oy = (int)(t % Ho);
+        const long n = t / Ho;
+        float best[8];
+        int arg[8];
+        pool_window(in, ldi, n, H, W, oy, ox, cg * 8, mode, best, arg);
+        bf16x8 v;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = f2bf(best[k]);
+        st8(out + ((n * Ho + oy) * (long)Wo + ox) * ldo + cg * 8, v);
+    }
+}
+
+// dx[n, iy, ix, c] = wscale * sum over windows whose (recomputed) arg-max is (iy, ix) of dout[window]
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const bf16* in, int ldi, const bf16* dout, int ldd, bf16* dx, int ldx,
+                                                          const float* wscale, int N, int H, int W, int C, int mode) {
+    const int C8 = C >> 3, Ho = H >> 1, Wo = W >> 1;
+    const long total = (long)N * H * W * C8;
+    const float ws = wscale ? *wscale : 1.0f;
+    const int off = mode ? -1 : 0;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int cg = (int)(idx % C8);
+        long t = idx / C8;
+        const int ix = (int)(t % W);
+        t /= W;
+        const int iy = (int)(t % H);
+        const long n = t / H;
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+        // windows oy with 2*oy + off <= iy <= 2*oy + off + 2
+        for (int oy = (iy - off - 2 + 1) >> 1; 2 * oy + off <= iy; ++oy) {
+            if (oy < 0 || oy >= Ho) continue;
+            for (int ox = (ix - off - 2 + 1) >> 1; 2 * ox + off <= ix; ++ox) {
+                if (ox < 0 || ox >= Wo) continue;
+                float best[8];
+                int arg[8];
+                pool_window(in, ldi, n, H, W, oy, ox, cg * 8, mode, best, arg);
+                const int mine = (iy - 2 * oy - off) * 3 + (ix - 2 * ox - off);
+                const bf16x8 g = ld8(dout + ((n * Ho + oy) * (long)Wo + ox) * ldd + cg * 8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (arg[k] == mine) acc[k] += bf2f(g[k]);
+            }
+        }
+        bf16x8 v;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = f2bf(acc[k] * ws);
+        st8(dx + ((n * H + iy) * (long)W + ix) * ldx + cg * 8, v);
+    }
+}
+
+// nearest x2 up-sampling (forward) and its backward (2x2 sum, optional device-side scale)
+__global__ __launch_bounds__(256) void up2_fwd_kernel(const bf16* in, int ldi, bf16* out, int ldo, int N, int H, int W, int C) {
+    const int C8 = C >> 3, Ho = 2 * H, Wo = 2 * W;
+    const long total = (long)N * Ho * Wo * C8;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int cg = (int)(idx % C8);
+        long t = idx / C8;
+        const int ox = (int)(t % Wo);
+        t /= Wo;
+        const int oy = (int)(t % Ho);
+        const long n = t / Ho;
+        st8(out + ((n * Ho + oy) * (long)Wo + ox) * ldo + cg * 8, ld8(in + ((n * H + (oy >> 1)) * (long)W + (ox >> 1)) * ldi + cg * 8));
+    }
+}
+__global__ __launch_bounds__(256) void sum2x2_kernel(const bf16* g, int ldg, bf16* out, int ldo, const float* wscale, int N, int H, int W,
+                                                     int C) {   // H, W = LOW resolution
+    const int C8 = C >> 3;
+    const long total = (long)N * H * W * C8;
+    const float ws = wscale ? *wscale : 1.0f;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int cg = (int)(idx % C8);
+        long t = idx / C8;
+        const int x = (int)(t % W);
+        t /= W;
+        const int y = (int)(t % H);
+        const long n = t / H;
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const bf16x8 v = ld8(g + ((n * 2 * H + 2 * y + dy) * (long)(2 * W) + 2 * x + dx) * ldg + cg * 8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] += bf2f(v[k]);
+            }
+        bf16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = f2bf(acc[k] * ws);
+        st8(out + ((n * H + y) * (long)W + x) * ldo + cg * 8, o);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// BiFPN fusion node: out = swish(sum_i w[i] * T_i(in_i)),  T in {1: identity, 2: nearest x2 of a half-res map,
+// 3: zero-pad-same 3x3/s2 max-pool of a double-res map}; mode 0 = absent.  w lives in device memory (normalised by the host
+// graph from the learnable fusion parameters, net/bifpn.py:179-180).
+// ---------------------------------------------------------------------------------------------------------
+struct Fuse {
+    const bf16* in[3]; int ld[3]; int mode[3];
+    const float* w;
+    bf16* out; int ldo;
+    int N, H, W, C;       // output resolution
+};
+__device__ __forceinline__ void fuse_gather(const Fuse& p, int i, long n, int y, int x, int c, float* v) {
+    if (p.mode[i] == 1) {
+        const bf16x8 t = ld8(p.in[i] + ((n * p.H + y) * (long)p.W + x) * p.ld[i] + c);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = bf2f(t[k]);
+    } else if (p.mode[i] == 2) {
+        const bf16x8 t = ld8(p.in[i] + ((n * (p.H >> 1) + (y >> 1)) * (long)(p.W >> 1) + (x >> 1)) * p.ld[i] + c);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = bf2f(t[k]);
+    } else {
+        int arg[8];
+        pool_window(p.in[i], p.ld[i], n, 2 * p.H, 2 * p.W, y, x, c, 0, v, arg);
+    }
+}
+__global__ __launch_bounds__(256) void fuse_fwd_kernel(const Fuse p) {
+    const int C8 = p.C >> 3;
+    const long total = (long)p.N * p.H * p.W * C8;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int cg = (int)(idx % C8);
+        long t = idx / C8;
+        const int x = (int)(t % p.W);
+        t /= p.W;
+        const int y = (int)(t % p.H);
+        const long n = t / p.H;
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (!p.mode[i]) continue;
+            float v[8];
+            fuse_gather(p, i, n, y, x, cg * 8, v);
+            const float wi = p.w[i];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] = fmaf(wi, v[k], acc[k]);
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = f2bf(act_fwd(acc[k], HN_ACT_SWISH));
+        st8(p.out + ((n * p.H + y) * (long)p.W + x) * p.ldo + cg * 8, o);
+    }
+}
+
+// backward part 1: g = dout * swish'(pre) (bf16, output resolution), d_in for identity inputs (= w[i] * g), and per-block partial
+// sums of dw[i] = sum g * T_i(in_i)  -> pw[block][3]
+struct FuseBwd {
+    Fuse f;
+    const bf16* dout; int ldd;
+    bf16* g; int ldg;
+    bf16* din[3]; int ldin[3];      // only for mode 1 inputs (else null)
+    float* pw;
+};
+__global__ __launch_bounds__(256) void fuse_bwd_kernel(const FuseBwd q) {
+    const Fuse& p = q.f;
+    const int C8 = p.C >> 3;
+    const long total = (long)p.N * p.H * p.W * C8;
+    float dw[3] = {0.f, 0.f, 0.f};
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int cg = (int)(idx % C8);
+        long t = idx / C8;
+        const int x = (int)(t % p.W);
+        t /= p.W;
+        const int y = (int)(t % p.H);
+        const long n = t / p.H;
+        float v[3][8], pre[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pre[k] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (!p.mode[i]) continue;
+            fuse_gather(p, i, n, y, x, cg * 8, v[i]);
+            const float wi = p.w[i];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) pre[k] = fmaf(wi, v[i][k], pre[k]);
+        }
+        const long orow = (n * p.H + y) * (long)p.W + x;
+        const bf16x8 d = ld8(q.dout + orow * q.ldd + cg * 8);
+        float gg[8];
+        bf16x8 go;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { gg[k] = bf2f(d[k]) * act_bwd(pre[k], HN_ACT_SWISH); go[k] = f2bf(gg[k]); }
+        st8(q.g + orow * q.ldg + cg * 8, go);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (!p.mode[i]) continue;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) dw[i] = fmaf(gg[k], v[i][k], dw[i]);
+            if (p.mode[i] == 1 && q.din[i]) {
+                const float wi = p.w[i];
+                bf16x8 o;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o[k] = f2bf(wi * gg[k]);
+                st8(q.din[i] + orow * q.ldin[i] + cg * 8, o);
+            }
+        }
+    }
+    __shared__ float red[4][3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float s = wave_sum(dw[i]);
+        if (lane == 0) red[wave][i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) q.pw[blockIdx.x * 3 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// fold of the seg decoder's padded-domain dgrad: dvp [N][H+2][W+2][ldv] (channels c0..c0+C) ->
+//   up = 0: out[n, y, x, :]  = sum over padded positions reflecting onto (y, x)
+//   up = 1: out[n, y, x, :]  = the same summed over the 2x2 block (2y..2y+1, 2x..2x+1)      (out is H/2 x W/2)
+//   optionally multiplied by ELU'(yprev) given the post-ELU activation of the producing ConvBlock (y > 0 ? 1 : y + 1)
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int refl_pre(int q, int L, int* pos) {   // padded coordinates (q+1) that reflect onto q
+    int n = 0;
+    pos[n++] = q + 1;
+    if (q == 1) pos[n++] = 0;
+    if (q == L - 2) pos[n++] = L + 1;
+    return n;
+}
+__global__ __launch_bounds__(256) void seg_fold_kernel(const bf16* dvp, int ldv, int c0, bf16* out, int ldo, const bf16* yprev, int ldy,
+                                                       int N, int H, int W, int C, int up) {
+    const int C8 = C >> 3, Ho = H >> up, Wo = W >> up;
+    const long total = (long)N * Ho * Wo * C8;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int cg = (int)(idx % C8);
+        long t = idx / C8;
+        const int x = (int)(t % Wo);
+        t /= Wo;
+        const int y = (int)(t % Ho);
+        const long n = t / Ho;
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+        for (int dy = 0; dy <= up; ++dy)
+            for (int dx = 0; dx <= up; ++dx) {
+                int py[3], px[3];
+                const int ny = refl_pre((y << up) + dy, H, py), nx = refl_pre((x << up) + dx, W, px);
+                for (int a = 0; a < ny; ++a)
+                    for (int b = 0; b < nx; ++b) {
+                        const bf16x8 v = ld8(dvp + ((n * (H + 2) + py[a]) * (long)(W + 2) + px[b]) * ldv + c0 + cg * 8);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) acc[k] += bf2f(v[k]);
+                    }
+            }
+        const long orow = (n * Ho + y) * (long)Wo + x;
+        bf16x8 o;
+        if (yprev) {
+            const bf16x8 yv = ld8(yprev + orow * ldy + cg * 8);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const float yy = bf2f(yv[k]); o[k] = f2bf(yy > 0.f ? acc[k] : acc[k] * (yy + 1.0f)); }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = f2bf(acc[k]);
+        }
+        st8(out + orow * ldo + cg * 8, o);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// head-gradient gather: fp32 gradient of a head output laid out [N][rows_total][Nout] (per-image stride img_stride, row stride
+// lds) -> zero-padded bf16 dz [M = N*rpi][ldz]; optional sigmoid' from the saved fp32 output.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void head_grad_kernel(const float* dy, const float* y, long rpi, long img_stride, int lds_, int Nout, bf16* dz, int ldz, long M,
+                                 int sigmoid) {
+    const long total = M * ldz;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long m = idx / ldz;
+        const int c = (int)(idx - m * ldz);
+        float v = 0.f;
+        if (c < Nout) {
+            const long o = (m / rpi) * img_stride + (m % rpi) * lds_ + c;
+            v = dy[o];
+            if (sigmoid) { const float s = y[o]; v *= s * (1.f - s); }
+        }
+        dz[idx] = f2bf(v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------
+static inline int ew_grid(long items) {
+    long b = (items + 255) / 256;
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+extern "C" int hn_stem_fwd(const float* x, const float* w, void* z, int N, int H, int W, hipStream_t st) {
+    HN_CHECK_ARG(x && w && z && N > 0 && H > 1 && W > 1 && !(H & 1) && !(W & 1));
+    const long total = (long)N * (H >> 1) * (W >> 1);
+    hipLaunchKernelGGL(stem_fwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, x, w, (bf16*)z, N, H, W);
+    HN_LAUNCH_CHECK();
+}
+extern "C" long hn_stem_wgrad_blocks(int N, int H, int W) {
+    const long total = (long)N * (H >> 1) * (W >> 1);
+    long blocks = total / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    return blocks;
+}
+// part: fp32 [hn_stem_wgrad_blocks][864]; reduce with hn_rows_reduce(part, dw, 1, blocks, 864, 1)
+extern "C" int hn_stem_wgrad(const float* x, const void* dz, float* part, int N, int H, int W, hipStream_t st) {
+    HN_CHECK_ARG(x && dz && part);
+    const long total = (long)N * (H >> 1) * (W >> 1);
+    const long blocks = hn_stem_wgrad_blocks(N, H, W);
+    const long ppb = (total + blocks - 1) / blocks;
+    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(blocks), dim3(256), 0, st, x, (const bf16*)dz, part, N, H, W, ppb);
+    HN_LAUNCH_CHECK();
+}
+
+extern "C" int hn_gconv_pack(const float* w, void* wk, void* wd, int C, int flip, hipStream_t st) {
+    HN_CHECK_ARG(w && wk && C > 0 && (C & 7) == 0);
+    const int G = C >> 3;
+    hipLaunchKernelGGL(gconv_pack_kernel, dim3(cdiv((long)G * 576, 256)), dim3(256), 0, st, w, (bf16*)wk, (bf16*)wd, G, flip);
+    HN_LAUNCH_CHECK();
+}
+// forward (and stride-1 dgrad when called on dz with the flipped/transposed pack)
+extern "C" int hn_gconv_fwd(const void* in, int ldi, const void* wk, void* out, int ldo, int N, int Hi, int Wi, int C, int stride,
+                            hipStream_t st) {
+    HN_CHECK_ARG(in && wk && out && (C & 7) == 0 && ((ldi | ldo) & 7) == 0 && (stride == 1 || stride == 2));
+    const int G = C >> 3, Ho = stride == 1 ? Hi : Hi >> 1, Wo = stride == 1 ? Wi : Wi >> 1;
+    const long total = (long)N * Ho * ((Wo + 3) >> 2) * G;
+    if (stride == 1)
+        hipLaunchKernelGGL(gconv_fwd_kernel<1>, dim3(cdiv(total, 256)), dim3(256), 0, st, (const bf16*)in, ldi, (const bf16*)wk, (bf16*)out,
+                           ldo, N, Hi, Wi, Ho, Wo, G);
+    else
+        hipLaunchKernelGGL(gconv_fwd_kernel<2>, dim3(cdiv(total, 256)), dim3(256), 0, st, (const bf16*)in, ldi, (const bf16*)wk, (bf16*)out,
+                           ldo, N, Hi, Wi, Ho, Wo, G);
+    HN_LAUNCH_CHECK();
+}
+extern "C" int hn_gconv_dgrad_s2(const void* dz, int ldz, const void* wd, void* dx, int ldx, int N, int Hi, int Wi, int C, hipStream_t st) {
+    HN_CHECK_ARG(dz && wd && dx && (C & 7) == 0 && ((ldz | ldx) & 7) == 0);
+    const int G = C >> 3;
+    const long total = (long)N * Hi * Wi * G;
+    hipLaunchKernelGGL(gconv_dgrad_s2_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, (const bf16*)dz, ldz, (const bf16*)wd, (bf16*)dx, ldx,
+                       N, Hi, Wi, Hi >> 1, Wi >> 1, G);
+    HN_LAUNCH_CHECK();
+}
+extern "C" long hn_wgrad_chunks(long pixels, long items) {          // pixel chunks so that chunks*items ~ 256k threads
+    long chunks = (262144 + items - 1) / items;
+    const long maxc = (pixels + 63) / 64;
+    if (chunks > maxc) chunks = maxc;
+    if (chunks > 4096) chunks = 4096;
+    if (chunks < 1) chunks = 1;
+    return chunks;
+}
+// part: fp32 [hn_wgrad_chunks(N*Ho*Wo, G*9)][C*72]; reduce with hn_rows_reduce(part, dw, 1, chunks, C*72, 1)
+extern "C" int hn_gconv_wgrad(const void* x, int ldx, const void* dz, int ldz, float* part, int N, int Hi, int Wi, int C, int stride,
+                              hipStream_t st) {
+    HN_CHECK_ARG(x && dz && part && (C & 7) == 0 && ((ldx | ldz) & 7) == 0 && (stride == 1 || stride == 2));
+    const int G = C >> 3, Ho = stride == 1 ? Hi : Hi >> 1, Wo = stride == 1 ? Wi : Wi >> 1;
+    const long pixels = (long)N * Ho * Wo;
+    const long chunks = hn_wgrad_chunks(pixels, G * 9);
+    const long ppc = (pixels + chunks - 1) / chunks;
+    hipLaunchKernelGGL(gconv_wgrad_kernel, dim3(chunks, cdiv(G * 9, 256)), dim3(256), 0, st, (const bf16*)x, ldx, (const bf16*)dz, ldz, part,
+                       N, Hi, Wi, Ho, Wo, G, stride, ppc);
+    HN_LAUNCH_CHECK();
+}
+
+extern "C" int hn_dw_pack(const float* w, void* wk, void* wkf, int C, hipStream_t st) {
+    HN_CHECK_ARG(w && wk && C > 0);
+    hipLaunchKernelGGL(dw_pack_kernel, dim3(cdiv(9L * C, 256)), dim3(256), 0, st, w, (bf16*)wk, (bf16*)wkf, C);
+    HN_LAUNCH_CHECK();
+}
+extern "C" int hn_dwconv_fwd(const void* in, int ldi, const void* wk, void* out, int ldo, int N, int H, int W, int C, hipStream_t st) {
+    HN_CHECK_ARG(in && wk && out && (C & 7) == 0 && ((ldi | ldo) & 7) == 0);
+    const long total = (long)N * H * ((W + 3) >> 2) * (C >> 3);
+    hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, (const bf16*)in, ldi, (const bf16*)wk, (bf16*)out, ldo, N,
+                       H, W, C);
+    HN_LAUNCH_CHECK();
+}
+// part: fp32 [hn_wgrad_chunks(N*H*W, C/8)][C*9]
+extern "C" int hn_dwconv_wgrad(const void* x, int ldx, const void* dz, int ldz, float* part, int N, int H, int W, int C, hipStream_t st) {
+    HN_CHECK_ARG(x && dz && part && (C & 7) == 0 && ((ldx | ldz) & 7) == 0);
+    const long pixels = (long)N * H * W;
+    const long chunks = hn_wgrad_chunks(pixels, C >> 3);
+    const long ppc = (pixels + chunks - 1) / chunks;
+    hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3(chunks, cdiv(C >> 3, 256)), dim3(256), 0, st, (const bf16*)x, ldx, (const bf16*)dz, ldz, part,
+                       N, H, W, C, ppc);
+    HN_LAUNCH_CHECK();
+}
+
+extern "C" int hn_maxpool_fwd(const void* in, int ldi, void* out, int ldo, int N, int H, int W, int C, int mode, hipStream_t st) {
+    HN_CHECK_ARG(in && out && (C & 7) == 0 && ((ldi | ldo) & 7) == 0 && !(H & 1) && !(W & 1) && (mode == 0 || mode == 1));
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid((long)N * (H >> 1) * (W >> 1) * (C >> 3))), dim3(256), 0, st, (const bf16*)in, ldi,
+                       (bf16*)out, ldo, N, H, W, C, mode);
+    HN_LAUNCH_CHECK();
+}
+extern "C" int hn_maxpool_bwd(const void* in, int ldi, const void* dout, int ldd, void* dx, int ldx, const float* wscale, int N, int H,
+                              int W, int C, int mode, hipStream_t st) {
+    HN_CHECK_ARG(in && dout && dx && (C & 7) == 0 && ((ldi | ldd | ldx) & 7) == 0 && !(H & 1) && !(W & 1));
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid((long)N * H * W * (C >> 3))), dim3(256), 0, st, (const bf16*)in, ldi,
+                       (const bf16*)dout, ldd, (bf16*)dx, ldx, wscale, N, H, W, C, mode);
+    HN_LAUNCH_CHECK();
+}
+extern "C" int hn_up2_fwd(const void* in, int ldi, void* out, int ldo, int N, int H, int W, int C, hipStream_t st) {
+    HN_CHECK_ARG(in && out && (C & 7) == 0 && ((ldi | ldo) & 7) == 0);
+    hipLaunchKernelGGL(up2_fwd_kernel, dim3(ew_grid((long)N * 4 * H * W * (C >> 3))), dim3(256), 0, st, (const bf16*)in, ldi, (bf16*)out, ldo,
+                       N, H, W, C);
+    HN_LAUNCH_CHECK();
+}
+extern "C" int hn_sum2x2(const void* g, int ldg, void* out, int ldo, const float* wscale, int N, int H, int W, int C, hipStream_t st) {
+    HN_CHECK_ARG(g && out && (C & 7) == 0 && ((ldg | ldo) & 7) == 0);
+    hipLaunchKernelGGL(sum2x2_kernel, dim3(ew_grid((long)N * H * W * (C >> 3))), dim3(256), 0, st, (const bf16*)g, ldg, (bf16*)out, ldo, wscale,
+                       N, H, W, C);
+    HN_LAUNCH_CHECK();
+}
+
+static int fill_fuse(Fuse& f, const void* const* in, const int* ld, const int* mode, const float* w, void* out, int ldo, int N, int H,
+                     int W, int C) {
+    HN_CHECK_ARG(in && ld && mode && w && (C & 7) == 0 && (ldo & 7) == 0);
+    for (int i = 0; i < 3; ++i) {
+        f.in[i] = (const bf16*)in[i]; f.ld[i] = ld[i]; f.mode[i] = mode[i];
+        HN_CHECK_ARG(mode[i] >= 0 && mode[i] <= 3 && (mode[i] == 0 || (in[i] && (ld[i] & 7) == 0)));
+        HN_CHECK_ARG(mode[i] != 2 || (!(H & 1) && !(W & 1)));
+    }
+    f.w = w; f.out = (bf16*)out; f.ldo = ldo; f.N = N; f.H = H; f.W = W; f.C = C;
+    return HN_OK;
+}
+extern "C" int hn_fuse_fwd(const void* const* in, const int* ld, const int* mode, const float* w, void* out, int ldo, int N, int H, int W,
+                           int C, hipStream_t st) {
+    Fuse f;
+    HN_CHECK_ARG(out);
+    const int rc = fill_fuse(f, in, ld, mode, w, out, ldo, N, H, W, C);
+    if (rc) return rc;
+    hipLaunchKernelGGL(fuse_fwd_kernel, dim3(ew_grid((long)N * H * W * (C >> 3))), dim3(256), 0, st, f);
+    HN_LAUNCH_CHECK();
+}
+extern "C" int hn_fuse_bwd_blocks(int N, int H, int W, int C) {
+    long b = ((long)N * H * W * (C >> 3) + 255) / 256;
+    if (b > 1024) b = 1024;
+    return (int)(b < 1 ? 1 : b);
+}
+// pw: fp32 [hn_fuse_bwd_blocks][3]; reduce with hn_rows_reduce(pw, dw, 1, blocks, 3, 1)
+extern "C" int hn_fuse_bwd(const void* const* in, const int* ld, const int* mode, const float* w, const void* dout, int ldd, void* g,
+                           int ldg, void* const* din, const int* ldin, float* pw, int N, int H, int W, int C, hipStream_t st) {
+    FuseBwd q;
+    HN_CHECK_ARG(dout && g && pw && din && ldin && ((ldd | ldg) & 7) == 0);
+    const int rc = fill_fuse(q.f, in, ld, mode, w, nullptr, 8, N, H, W, C);
+    if (rc) return rc;
+    q.dout = (const bf16*)dout; q.ldd = ldd; q.g = (bf16*)g; q.ldg = ldg; q.pw = pw;
+    for (int i = 0; i < 3; ++i) { q.din[i] = (bf16*)din[i]; q.ldin[i] = ldin[i]; }
+    hipLaunchKernelGGL(fuse_bwd_kernel, dim3(hn_fuse_bwd_blocks(N, H, W, C)), dim3(256), 0, st, q);
+    HN_LAUNCH_CHECK();
+}
+
+extern "C" int hn_seg_fold(const void* dvp, int ldv, int c0, void* out, int ldo, const void* yprev, int ldy, int N, int H, int W, int C,
+                           int up, hipStream_t st) {
+    HN_CHECK_ARG(dvp && out && (C & 7) == 0 && (c0 & 7) == 0 && ((ldv | ldo) & 7) == 0 && H >= 4 && W >= 4 && (up == 0 || up == 1));
+    HN_CHECK_ARG(!yprev || (ldy & 7) == 0);
+    hipLaunchKernelGGL(seg_fold_kernel, dim3(ew_grid((long)N * (H >> up) * (W >> up) * (C >> 3))), dim3(256), 0, st, (const bf16*)dvp, ldv, c0,
+                       (bf16*)out, ldo, (const bf16*)yprev, ldy, N, H, W, C, up);
+    HN_LAUNCH_CHECK();
+}
+
+extern "C" int hn_head_grad(const float* dy, const float* y, long rpi, long img_stride, int lds_, int Nout, void* dz, int ldz, long M,
+                            int sigmoid, hipStream_t st) {
+    HN_CHECK_ARG(dy && dz && rpi > 0 && Nout > 0 && ldz >= Nout && (ldz & 7) == 0 && M > 0 && (!sigmoid || y));
+    hipLaunchKernelGGL(head_grad_kernel, dim3(ew_grid(M * ldz)), dim3(256), 0, st, dy, y, rpi, img_stride, lds_, Nout, (bf16*)dz, ldz, M,
+                       sigmoid);
+    HN_LAUNCH_CHECK();
+}

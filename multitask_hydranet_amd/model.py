@@ -1,0 +1,504 @@
+"""HydraNet nn.Module surface (model/model.py:26-264 of the reference) over the MI355X HIP kernels.
+
+Same constructor (``HydraNet(cfgs: dict, onnx_export=False)``), same ``forward(x, mode)`` / ``cal_loss(pred, gt)`` contract, same
+sub-module attributes (backbone / neck / segheader / detectheader / laneheader) and the same 1177 ``state_dict`` keys as the
+reference, so checkpoints and train.py / demo.py style callers work unchanged.  Underneath, parameters live in a generic tree of
+containers built from a declarative spec, activations are NHWC bf16, and every tensor op on the path is a kernel of
+libhydranet_hip.so reached through multitask_hydranet_amd.ops.  There is no eager fallback: constructing the module on a machine
+without the shared library raises.
+"""
+from __future__ import annotations
+
+import itertools
+import math
+import sys
+import weakref
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import losses as L
+from . import ops as K
+from .ops import ACT_ELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SWISH
+
+BN_STD = dict(eps=1e-5, momentum=0.1)        # nn.BatchNorm2d defaults: backbone + lane head
+BN_FPN = dict(eps=1e-3, momentum=0.01)       # neck + detection towers (net/common.py:98)
+
+
+def regnet_stages(initial_width, slope, quantized_param, network_depth, bottleneck_ratio, group_width):
+    """Stage widths / depths / group widths of the RegNetY backbone (net/regnet.py:21-38)."""
+    u = initial_width + slope * np.arange(network_depth)
+    s = np.round(np.log(u / initial_width) / np.log(quantized_param))
+    q = 8 * np.round(initial_width * np.power(quantized_param, s) / 8)
+    widths, depths = np.unique(q.astype(np.int32), return_counts=True)
+    gws = np.array([min(group_width, int(v) // bottleneck_ratio) for v in widths]).astype(np.int32) * bottleneck_ratio
+    widths = (np.round(widths // bottleneck_ratio / group_width) * group_width).astype(np.int32)
+    return widths.tolist(), depths.tolist(), gws.tolist()
+
+
+class _Node(nn.Module):
+    """Plain container; the five top-level ones get a callable bound to the owning HydraNet."""
+
+    def __init__(self):
+        super().__init__()
+        object.__setattr__(self, "_fwd", None)
+
+    def forward(self, *a, **k):
+        if self._fwd is None:
+            raise RuntimeError("this container is only a parameter holder")
+        return self._fwd(*a, **k)
+
+
+class _Spec:
+    """Declares parameters/buffers by dotted name and materialises the container tree."""
+
+    def __init__(self, root: nn.Module):
+        self.root = root
+
+    def _walk(self, name):
+        parts = name.split(".")
+        m = self.root
+        for p in parts[:-1]:
+            if p not in m._modules:
+                m.add_module(p, _Node())
+            m = m._modules[p]
+        return m, parts[-1]
+
+    def param(self, name, tensor):
+        m, leaf = self._walk(name)
+        m.register_parameter(leaf, nn.Parameter(tensor))
+
+    def buffer(self, name, tensor):
+        m, leaf = self._walk(name)
+        m.register_buffer(leaf, tensor)
+
+    # --- initialisers ------------------------------------------------------------------------------------
+    def conv(self, name, cout, cin_g, k, bias, backbone_init=False):
+        w = torch.empty(cout, cin_g, k, k)
+        if backbone_init:                                  # net/anynet.py:124-128
+            w.normal_(0.0, math.sqrt(2.0 / (k * k * cout)))
+        else:                                              # nn.Conv2d default (kaiming_uniform(a=sqrt(5)))
+            nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+        self.param(name + ".weight", w)
+        if bias:
+            bound = 1.0 / math.sqrt(cin_g * k * k)
+            self.param(name + ".bias", torch.empty(cout).uniform_(-bound, bound))
+
+    def bn(self, name, c):
+        self.param(name + ".weight", torch.ones(c))
+        self.param(name + ".bias", torch.zeros(c))
+        self.buffer(name + ".running_mean", torch.zeros(c))
+        self.buffer(name + ".running_var", torch.ones(c))
+        self.buffer(name + ".num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+
+class HydraNet(nn.Module):
+    def __init__(self, cfgs: dict, onnx_export: bool = False):
+        super().__init__()
+        K.lib()                                            # fail loudly if libhydranet_hip.so is absent
+        self.cfgs = cfgs
+        self.onnx_export = onnx_export
+        self.net_input_width = cfgs["dataloader"]["network_input_width"]
+        self.net_input_height = cfgs["dataloader"]["network_input_height"]
+        b = cfgs["backbone"]
+        self.widths, self.depths, self.group_widths = regnet_stages(b["initial_width"], b["slope"], b["quantized_param"],
+                                                                    b["network_depth"], b["bottleneck_ratio"], b["group_width"])
+        assert b["bottleneck_ratio"] == 1 and all(g == 8 for g in self.group_widths), "kernels are built for group width 8"
+        self.backbone_stride = b["stride"]
+        self.se_ratio = b["se_ratio"]
+        self.fpn_num_filters = b["fpn_num_filters"]
+        self.fpn_cell_repeats = b["fpn_cell_repeats"]
+        self.conv_channel_coef = list(b["conv_channel_coef"])
+        t = cfgs["train"]
+        self.train_detect, self.train_seg, self.train_lane = t["train_detect"], t["train_seg"], t["train_lane"]
+        self.check_finite = True                           # the reference exit()s on a zero / non-finite loss (model.py:212-258)
+        self.lane_points_per_line = 160                    # cal_loss_regress default that model.py:246 never overrides
+        self._anchor_cache = {}
+
+        spec = _Spec(self)
+        self._declare_backbone(spec)
+        self._declare_neck(spec)
+        if self.train_detect:
+            self._declare_det(spec)
+            self.loss_detect = L.det_loss
+        else:
+            self.detectheader, self.loss_detect = None, None
+        if self.train_seg:
+            self._declare_seg(spec)
+            s = cfgs["segment"]
+            self.use_lovasz = s["use_lovasz"]
+            assert not self.use_lovasz, "Lovasz loss is off in every shipped cfg and outside the hot path"
+            cw = torch.tensor(s["class_weight"], dtype=torch.float32)
+            self.loss_seg = lambda logits, target: L.seg_loss(logits, target, cw, s["use_top_k"], s["top_k_ratio"], s["use_focal"])
+        else:
+            self.segheader, self.loss_seg = None, None
+        if self.train_lane:
+            self._declare_lane(spec)
+            self.loss_cls, self.loss_reg = L.lane_cls_loss, L.lane_loc_loss
+        else:
+            self.laneheader, self.loss_cls, self.loss_reg = None, None, None
+        self._bind_callables()
+        self._idx: Dict[str, torch.Tensor] = {}
+        self._reindex()
+
+    # ------------------------------------------------------------------------------------------------------
+    # parameter declaration (names, shapes and order = the reference's state_dict)
+    # ------------------------------------------------------------------------------------------------------
+    def _declare_backbone(self, s: _Spec):
+        p = "backbone.net."
+        s.conv(p + "stem.conv", 32, 3, 3, False, True)
+        s.bn(p + "stem.bn", 32)
+        prev = 32
+        for k, (w, d) in enumerate(zip(self.widths, self.depths)):
+            for i in range(d):
+                cin = prev if i == 0 else w
+                stride = self.backbone_stride if i == 0 else 1
+                q = f"{p}stage_{k}.blocks.block_{i}."
+                s.conv(q + "conv_block_1.0", w, cin, 1, False, True)
+                s.bn(q + "conv_block_1.1", w)
+                s.conv(q + "conv_block_2.0", w, 8, 3, False, True)
+                s.bn(q + "conv_block_2.1", w)
+                if self.se_ratio is not None:
+                    se = cin // self.se_ratio
+                    s.conv(q + "se.1", se, w, 1, True, True)
+                    s.conv(q + "se.3", w, se, 1, True, True)
+                s.conv(q + "conv_block_3.0", w, w, 1, False, True)
+                s.bn(q + "conv_block_3.1", w)
+                if stride != 1 or cin != w:
+                    s.conv(q + "shortcut.0", w, cin, 1, False, True)
+                    s.bn(q + "shortcut.1", w)
+            prev = w
+
+    def _sep(self, s: _Spec, name, cin, cout, norm):
+        s.conv(name + ".depthwise_conv.conv", cin, 1, 3, False)
+        s.conv(name + ".pointwise_conv.conv", cout, cin, 1, True)
+        if norm:
+            s.bn(name + ".bn", cout)
+
+    def _declare_neck(self, s: _Spec):
+        f = self.fpn_num_filters
+        cc = self.conv_channel_coef
+        for k in range(self.fpn_cell_repeats):
+            p = f"neck.bifpn.{k}."
+            for nm, n in (("p6_w1", 2), ("p5_w1", 2), ("p4_w1", 2), ("p3_w1", 2), ("p4_w2", 3), ("p5_w2", 3), ("p6_w2", 3), ("p7_w2", 2)):
+                s.param(p + nm, torch.ones(n))
+            for nm in ("conv6_up", "conv5_up", "conv4_up", "conv3_up", "conv4_down", "conv5_down", "conv6_down", "conv7_down"):
+                self._sep(s, p + nm, f, f, True)
+            if k == 0:
+                def red(nm, cin):
+                    s.conv(p + nm + ".0.conv", f, cin, 1, True)
+                    s.bn(p + nm + ".1", f)
+                red("p5_down_channel", cc[2])
+                red("p4_down_channel", cc[1])
+                red("p3_down_channel", cc[0])
+                red("p5_to_p6", cc[2])
+                if len(cc) == 4:
+                    red("p6_down_channel", cc[3])
+                red("p4_down_channel_2", cc[1])
+                red("p5_down_channel_2", cc[2])
+
+    def _declare_det(self, s: _Spec):
+        d = self.cfgs["detection"]
+        f, layers, levels = d["fpn_num_filters_detect"], d["box_class_repeats"], d["pyramid_levels"]
+        self.num_anchors = 9
+        for tower, cout in (("regressor", self.num_anchors * 4), ("classifier", self.num_anchors * d["num_classes"])):
+            p = f"detectheader.{tower}."
+            for i in range(layers):
+                self._sep(s, f"{p}conv_list.{i}", f, f, False)
+            for lv in range(levels):
+                for i in range(layers):
+                    s.bn(f"{p}bn_list.{lv}.{i}", f)
+            self._sep(s, p + "header", f, cout, False)
+
+    def _declare_seg(self, s: _Spec):
+        sc = self.cfgs["segment"]
+        enc, dec = sc["channel_dimension_seg_encode"], sc["channel_dimension_seg_decode"]
+        idx = 0
+        for i in range(len(enc) - 1, -1, -1):
+            cin = enc[-1] if i == len(enc) - 1 else dec[i + 1]
+            s.conv(f"segheader.decoder.{idx}.conv.conv", dec[i], cin, 3, True)
+            cin = dec[i] + (enc[i - 1] if i > 0 else 0)
+            s.conv(f"segheader.decoder.{idx + 1}.conv.conv", dec[i], cin, 3, True)
+            idx += 2
+        s.conv(f"segheader.decoder.{idx}.conv", len(sc["class_list"]), dec[0], 3, True)
+        self._seg_layers = idx
+
+    def _declare_lane(self, s: _Spec):
+        l = self.cfgs["lane"]
+        c = l["base_channel"]
+        ppl = int(self.net_input_height / l["interval"])
+        for nm, cout in (("conv_cls_conv", l["num_classes"]), ("conv_up_conv", ppl + 1), ("conv_down_conv", ppl + 1)):
+            p = f"laneheader.{nm}."
+            s.conv(p + "0", c, c, 1, False)
+            s.bn(p + "1", c)
+            s.conv(p + "3", cout, c, 1, True)
+
+    # ------------------------------------------------------------------------------------------------------
+    def _bind_callables(self):
+        me = weakref.ref(self)
+        object.__setattr__(self.backbone, "_fwd", lambda x: [K_to_nchw(t) for t in me()._backbone(x)])
+        object.__setattr__(self.neck, "_fwd", lambda feats: tuple(K_to_nchw(t) for t in me()._neck([K_to_nhwc(t) for t in feats])))
+        if self.train_seg:
+            object.__setattr__(self.segheader, "_fwd", lambda feats: me()._seg([K_to_nhwc(t) for t in feats]))
+            self.segheader.decode = _unavailable("segheader.decode (cv2 visualisation)")
+        if self.train_detect:
+            object.__setattr__(self.detectheader, "_fwd", lambda x, fused: me()._det(x, [K_to_nhwc(t) for t in fused]))
+            self.detectheader.decode = _det_decode
+        if self.train_lane:
+            object.__setattr__(self.laneheader, "_fwd", lambda fused: me()._lane([K_to_nhwc(t) for t in fused]))
+
+    def _reindex(self):
+        self._idx = {k: v for k, v in itertools.chain(self.named_parameters(), self.named_buffers())}
+
+    def _apply(self, fn, recurse=True):
+        r = super()._apply(fn, recurse)
+        self._reindex()
+        K.clear_pack_cache()
+        return r
+
+    def _bn(self, name):
+        P = self._idx
+        return (P[name + ".weight"], P[name + ".bias"], P[name + ".running_mean"], P[name + ".running_var"],
+                P[name + ".num_batches_tracked"])
+
+    # ------------------------------------------------------------------------------------------------------
+    # forward pieces (NHWC bf16 inside)
+    # ------------------------------------------------------------------------------------------------------
+    def _cba(self, x, conv, bn, bnkw, **kw):
+        P = self._idx
+        return K.conv_bn_act(x, P[conv + ".weight"], P.get(conv + ".bias"), self._bn(bn), training=self.training, **bnkw, **kw)
+
+    def _xblock(self, q, x, stride):
+        """XBlock.forward, net/anynet.py:65-76."""
+        P = self._idx
+        a = self._cba(x, q + "conv_block_1.0", q + "conv_block_1.1", BN_STD, act=ACT_RELU)
+        b = self._cba(a, q + "conv_block_2.0", q + "conv_block_2.1", BN_STD, kind="g3x3", stride=stride, act=ACT_RELU)
+        if (q + "se.1.weight") in P:
+            b = K.SEGate.apply(b, P[q + "se.1.weight"], P[q + "se.1.bias"], P[q + "se.3.weight"], P[q + "se.3.bias"])
+        if (q + "shortcut.0.weight") in P:
+            s = self._cba(x, q + "shortcut.0", q + "shortcut.1", BN_STD, stride=stride, act=ACT_NONE)
+        else:
+            s = x
+        return self._cba(b, q + "conv_block_3.0", q + "conv_block_3.1", BN_STD, res=s, act=ACT_RELU)
+
+    def _backbone(self, x):
+        """AnyNetX.forward, net/anynet.py:136-145: x NCHW fp32 -> list of NHWC bf16 stage outputs."""
+        p = "backbone.net."
+        x = x.contiguous().float()
+        t = self._cba(x, p + "stem.conv", p + "stem.bn", BN_STD, kind="stem", act=ACT_RELU)
+        feats = []
+        for k, d in enumerate(self.depths):
+            for i in range(d):
+                t = self._xblock(f"{p}stage_{k}.blocks.block_{i}.", t, self.backbone_stride if i == 0 else 1)
+            feats.append(t)
+        return feats
+
+    def _sepconv(self, name, x, act=ACT_NONE):
+        """SeparableConvBlock with BN (net/common.py:104-114)."""
+        P = self._idx
+        d = K.DwConv.apply(x, P[name + ".depthwise_conv.conv.weight"])
+        return self._cba(d, name + ".pointwise_conv.conv", name + ".bn", BN_FPN, act=act)
+
+    def _fusew(self, name):
+        w = torch.relu(self._idx[name])
+        return w / (torch.sum(w, dim=0) + 1e-4)
+
+    def _cell(self, p, inputs, first):
+        """BiFPN._forward_fast_attention, net/bifpn.py:156-233."""
+        red = lambda nm, t: self._cba(t, p + nm + ".0.conv", p + nm + ".1", BN_FPN, act=ACT_NONE)
+        if first:
+            if len(inputs) == 4 and len(self.conv_channel_coef) == 4:
+                p3, p4, p5, p6r = inputs[-4:]
+                p6_in = red("p6_down_channel", p6r)
+            else:
+                p3, p4, p5 = inputs[-3:]
+                p6_in = K.MaxPool.apply(red("p5_to_p6", p5), 0)
+            p7_in = K.MaxPool.apply(p6_in, 0)
+            p3_in, p4_in, p5_in = red("p3_down_channel", p3), red("p4_down_channel", p4), red("p5_down_channel", p5)
+        else:
+            p4 = p5 = None
+            p3_in, p4_in, p5_in, p6_in, p7_in = inputs
+        F = K.Fuse.apply
+        p6_up = self._sepconv(p + "conv6_up", F(self._fusew(p + "p6_w1"), 1, 2, 0, p6_in, p7_in, None))
+        p5_up = self._sepconv(p + "conv5_up", F(self._fusew(p + "p5_w1"), 1, 2, 0, p5_in, p6_up, None))
+        p4_up = self._sepconv(p + "conv4_up", F(self._fusew(p + "p4_w1"), 1, 2, 0, p4_in, p5_up, None))
+        p3_out = self._sepconv(p + "conv3_up", F(self._fusew(p + "p3_w1"), 1, 2, 0, p3_in, p4_up, None))
+        if first:
+            p4_in, p5_in = red("p4_down_channel_2", p4), red("p5_down_channel_2", p5)
+        p4_out = self._sepconv(p + "conv4_down", F(self._fusew(p + "p4_w2"), 1, 1, 3, p4_in, p4_up, p3_out))
+        p5_out = self._sepconv(p + "conv5_down", F(self._fusew(p + "p5_w2"), 1, 1, 3, p5_in, p5_up, p4_out))
+        p6_out = self._sepconv(p + "conv6_down", F(self._fusew(p + "p6_w2"), 1, 1, 3, p6_in, p6_up, p5_out))
+        p7_out = self._sepconv(p + "conv7_down", F(self._fusew(p + "p7_w2"), 1, 3, 0, p7_in, p6_out, None))
+        return p3_out, p4_out, p5_out, p6_out, p7_out
+
+    def _neck(self, feats):
+        x = list(feats)
+        if len(self.conv_channel_coef) == 4:
+            x = x[-4:]
+        for k in range(self.fpn_cell_repeats):
+            x = self._cell(f"neck.bifpn.{k}.", x, k == 0)
+        return x
+
+    def _seg(self, feats_seg):
+        """SegmentHeader.forward, head_seg/segmentation.py:84-105 -> fp32 logits, NCHW-shaped (channels-last memory)."""
+        P = self._idx
+        n = len(feats_seg)
+        x = feats_seg[-1]
+        p = "segheader.decoder."
+        for i in range(n):
+            x = K.SegConv.apply(x, None, P[f"{p}{2 * i}.conv.conv.weight"], P[f"{p}{2 * i}.conv.conv.bias"], 0, ACT_ELU, False)
+            skip = feats_seg[n - 2 - i] if i < n - 1 else None
+            x = K.SegConv.apply(x, skip, P[f"{p}{2 * i + 1}.conv.conv.weight"], P[f"{p}{2 * i + 1}.conv.conv.bias"], 1, ACT_ELU, False)
+        last = 2 * n
+        y = K.SegConv.apply(x, None, P[f"{p}{last}.conv.weight"], P[f"{p}{last}.conv.bias"], 1, ACT_NONE, True)
+        return y.permute(0, 3, 1, 2)
+
+    def anchors_for(self, h, w, device):
+        """Anchors.forward, head_detect/detection.py:108-170 (host numpy, cached per shape/device)."""
+        key = (h, w, str(device))
+        if key not in self._anchor_cache:
+            d = self.cfgs["detection"]
+            r1, r2 = d["aspect_ratios_factor"]
+            ratios = [(1.0, 1.0), (r1, r2), (r2, r1)]
+            scales = [2 ** v for v in d["scales_factor"]]
+            allb = []
+            for lv in range(d["pyramid_levels"]):
+                stride = 2 ** (lv + 3)
+                if w % stride or h % stride:
+                    raise ValueError("input size must be divided by the stride.")
+                per = []
+                for scale, ratio in itertools.product(scales, ratios):
+                    base = d["anchor_scale"] * stride * scale
+                    hx, hy = base * ratio[0] / 2.0, base * ratio[1] / 2.0
+                    xv, yv = np.meshgrid(np.arange(stride / 2, w, stride), np.arange(stride / 2, h, stride))
+                    xv, yv = xv.reshape(-1), yv.reshape(-1)
+                    per.append(np.stack((yv - hy, xv - hx, yv + hy, xv + hx), axis=1)[:, None, :])
+                allb.append(np.concatenate(per, axis=1).reshape(-1, 4))
+            a = torch.from_numpy(np.vstack(allb).astype(np.float32)).to(device).unsqueeze(0)
+            self._anchor_cache[key] = a
+        return self._anchor_cache[key]
+
+    def _det_tower(self, p, fused, k, act):
+        P = self._idx
+        layers = self.cfgs["detection"]["box_class_repeats"]
+        outs = []
+        for lv, f in enumerate(fused):
+            for i in range(layers):
+                d = K.DwConv.apply(f, P[f"{p}conv_list.{i}.depthwise_conv.conv.weight"])
+                f = self._cba(d, f"{p}conv_list.{i}.pointwise_conv.conv", f"{p}bn_list.{lv}.{i}", BN_FPN, act=ACT_SWISH)
+            outs.append(f)
+        return K.HeadOut.apply(P[p + "header.depthwise_conv.conv.weight"], P[p + "header.pointwise_conv.conv.weight"],
+                               P[p + "header.pointwise_conv.conv.bias"], k, act, *outs)
+
+    def _det(self, x, fused):
+        anchors = self.anchors_for(x.shape[2], x.shape[3], x.device)
+        reg = self._det_tower("detectheader.regressor.", fused, 4, ACT_NONE)
+        cls = self._det_tower("detectheader.classifier.", fused, self.cfgs["detection"]["num_classes"], ACT_SIGMOID)
+        return anchors, reg, cls
+
+    def _lane(self, fused):
+        """LaneHeader.forward, head_lane/lanedetect.py:66-96."""
+        P = self._idx
+        stride = self.cfgs["lane"]["anchor_stride"]
+        assert stride == 32, "only the stride-32 lane fusion of the shipped cfgs is on the hot path"
+        fl = K.LaneConcat.apply(fused[0], fused[1], fused[2], fused[3])
+
+        def branch(nm):
+            q = f"laneheader.{nm}."
+            t = self._cba(fl, q + "0", q + "1", BN_STD, act=ACT_RELU)
+            w = P[q + "3.weight"]
+            return K.HeadOut.apply(None, w, P[q + "3.bias"], w.shape[0], ACT_NONE, t)
+        cls = branch("conv_cls_conv")
+        up, down = branch("conv_up_conv"), branch("conv_down_conv")
+        return dict(predict_cls=cls, predict_loc=torch.cat([down, up], -1))
+
+    # ------------------------------------------------------------------------------------------------------
+    def forward(self, x, mode="train"):
+        """HydraNet.forward, model/model.py:159-198."""
+        K.clear_pack_cache()
+        feats = self._backbone(x)
+        fused = self._neck(feats)
+        out = {}
+        seg = anchors = reg = cls = lane_cls = lane_reg = None
+        if self.train_seg:
+            seg = self._seg([feats[0], fused[0], fused[1], fused[2]])
+            out["seg"] = seg
+        if self.train_detect:
+            anchors, reg, cls = self._det(x, fused)
+            out["detection"] = {"anchors": anchors, "regression": reg, "classification": cls}
+        if self.train_lane:
+            lane = self._lane(fused)
+            out["lane"] = lane
+            lane_cls, lane_reg = lane["predict_cls"], lane["predict_loc"]
+        if mode != "deploy":
+            return out
+        return torch.argmax(seg, dim=1), anchors, reg, cls, lane_cls, lane_reg
+
+    def _guard(self, value, what, allow_zero=False):
+        if self.check_finite and ((not allow_zero and value == 0) or not torch.isfinite(value)):
+            print(what)
+            sys.exit()
+
+    def cal_loss(self, pred_dict, gt_dict):
+        """HydraNet.cal_loss, model/model.py:201-264 (same keys, same divergence guard)."""
+        ld = {}
+        if self.train_seg:
+            loss_seg = self.loss_seg(pred_dict["seg"], gt_dict["gt_seg"].long())
+            self._guard(loss_seg, "cal segment loss diverge!")
+            ld["loss_seg"] = loss_seg
+        if self.train_detect:
+            d = pred_dict["detection"]
+            cl, rl = self.loss_detect(d["classification"], d["regression"], d["anchors"], gt_dict["gt_det"])
+            cl, rl = cl.mean(), rl.mean()
+            self._guard(cl, "cal det cls loss diverge!", allow_zero=True)
+            self._guard(rl, "cal det reg loss diverge!", allow_zero=True)
+            ld["loss_det_cls"], ld["loss_det_reg"] = cl, rl
+        if self.train_lane:
+            pos, neg, pmask, pnum = self.loss_cls(gt_dict["gt_cls"], pred_dict["lane"]["predict_cls"])
+            loc = self.loss_reg(pmask, pnum, gt_dict["gt_loc"], pred_dict["lane"]["predict_loc"],
+                                points_per_line=self.lane_points_per_line)
+            self._guard(pos, "cal lane pos loss diverge!")
+            self._guard(neg, "cal lane neg loss diverge!")
+            self._guard(loc, "cal lane loc loss diverge!")
+            ld["loss_lane_cls_pos"], ld["loss_lane_cls_neg"], ld["loss_lane_loc"] = pos, neg, loc
+        return ld
+
+    def total_loss(self, ld):
+        """HydraTrainer.cal_total_loss, model/train.py:192-203."""
+        c = self.cfgs
+        tot = 0.0
+        if self.train_seg:
+            tot = tot + ld["loss_seg"] * c["segment"]["segment_weight"]
+        if self.train_detect:
+            d = c["detection"]
+            tot = tot + (ld["loss_det_cls"] * d["loss_cls_weight"] + ld["loss_det_reg"] * d["loss_reg_weight"]) * d["detection_weight"]
+        if self.train_lane:
+            l = c["lane"]
+            tot = tot + (ld["loss_lane_cls_pos"] * l["loss_cls_pos_weight"] + ld["loss_lane_cls_neg"] * l["loss_cls_neg_weight"]
+                         + ld["loss_lane_loc"] * l["loss_loc_weight"]) * l["lane_weight"]
+        return tot
+
+
+def K_to_nchw(t):
+    return t.permute(0, 3, 1, 2)
+
+
+def K_to_nhwc(t):
+    """accept an NCHW-shaped tensor (any memory format / dtype) and return dense NHWC bf16."""
+    return t.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
+
+
+def _unavailable(what):
+    def f(*a, **k):
+        raise NotImplementedError(what + " is outside the forward/backward hot path (SURVEY.md section 8f)")
+    return f
+
+
+def _det_decode(imgs, regressions, classifications, anchors, conf_thres=0.6, iou_thres=0.3):
+    from .postprocess import postprocess
+    if imgs is None:
+        return None
+    return postprocess((imgs.shape[2], imgs.shape[3]), torch.stack([anchors[0]] * imgs.shape[0], 0).detach(), regressions.detach(),
+                       classifications.detach(), conf_thres, iou_thres)

@@ -1,0 +1,640 @@
+"""Host-side operator layer: thin wrappers that allocate outputs with torch and enqueue the HIP kernels of
+libhydranet_hip.so, plus the torch.autograd.Function objects that give them a backward.
+
+This is the same plug-in point the reference uses for its one hand-written fwd/bwd op (SwishImplementation,
+model/net/common.py:11-22): torch.autograd.Function.forward/backward.  Tensors here are NHWC bf16 ("channels last"):
+shape [N, H, W, C], unit channel stride, possibly a channel-slice view of a wider buffer (row stride = stride(2)).
+There is no eager / CPU fallback in this module: every op goes through lib().call and raises if the library is missing.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from ._lib import lib
+
+ACT_NONE, ACT_RELU, ACT_SWISH, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3, 4
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+# --------------------------------------------------------------------------------------------------------------
+# tensor helpers
+# --------------------------------------------------------------------------------------------------------------
+def ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def ld(t: torch.Tensor) -> int:
+    """row stride (elements) of an NHWC activation (or channel-slice view of one)."""
+    assert t.dim() == 4 and t.stride(3) == 1, (t.shape, t.stride())
+    n, h, w, c = t.shape
+    s = t.stride(2)
+    assert (h == 1 or t.stride(1) == w * s) and (n == 1 or t.stride(0) == h * w * s), (t.shape, t.stride())
+    return s
+
+
+def rows(t: torch.Tensor) -> int:
+    return t.shape[0] * t.shape[1] * t.shape[2]
+
+
+def new_act(n, h, w, c, device, dtype=BF16):
+    return torch.empty((n, h, w, c), device=device, dtype=dtype)
+
+
+def kp32(c: int) -> int:
+    return (c + 31) // 32 * 32
+
+
+def pad8(c: int) -> int:
+    return (c + 7) // 8 * 8
+
+
+def dense(t: torch.Tensor) -> torch.Tensor:
+    """make a gradient tensor usable by the kernels (NHWC, unit channel stride, dense rows)."""
+    if t.dtype != BF16:
+        t = t.to(BF16)
+    if t.stride(3) != 1 or t.stride(2) % 8 != 0 or (t.shape[1] > 1 and t.stride(1) != t.shape[2] * t.stride(2)) or \
+            (t.shape[0] > 1 and t.stride(0) != t.shape[1] * t.shape[2] * t.stride(2)):
+        t = t.contiguous()
+    return t
+
+
+# --------------------------------------------------------------------------------------------------------------
+# packed-weight cache: a weight is cast/packed once per optimizer step (keyed by storage + version counter)
+# --------------------------------------------------------------------------------------------------------------
+_PACK_CACHE = {}
+
+
+def clear_pack_cache():
+    _PACK_CACHE.clear()
+
+
+def _cached(key, w: torch.Tensor, make):
+    k = (key, w.data_ptr(), w._version, tuple(w.shape))
+    v = _PACK_CACHE.get(k)
+    if v is None:
+        v = make()
+        _PACK_CACHE[k] = v
+    return v
+
+
+def pack_conv_weight(w: torch.Tensor):
+    """fp32 [Cout, Cin, kh, kw] -> (wp [Cout, taps*KP(Cin)], wt [Cin, taps*KP(Cout)]) bf16."""
+    def make():
+        cout, cin = w.shape[0], w.shape[1]
+        taps = w.shape[2] * w.shape[3]
+        wp = torch.empty((cout, taps * kp32(cin)), device=w.device, dtype=BF16)
+        wt = torch.empty((cin, taps * kp32(cout)), device=w.device, dtype=BF16)
+        lib().call("hn_pack_weight", ptr(w), ptr(wp), ptr(wt), cout, cin, taps)
+        return wp, wt
+    return _cached("conv", w.detach(), make)
+
+
+def pack_gconv_weight(w: torch.Tensor, flip: int):
+    def make():
+        c = w.shape[0]
+        wk = torch.empty((9 * 8 * c,), device=w.device, dtype=BF16)
+        wd = torch.empty((9 * 8 * c,), device=w.device, dtype=BF16)
+        lib().call("hn_gconv_pack", ptr(w), ptr(wk), ptr(wd), c, flip)
+        return wk, wd
+    return _cached(("g", flip), w.detach(), make)
+
+
+def pack_dw_weight(w: torch.Tensor):
+    def make():
+        c = w.shape[0]
+        wk = torch.empty((9 * c,), device=w.device, dtype=BF16)
+        wf = torch.empty((9 * c,), device=w.device, dtype=BF16)
+        lib().call("hn_dw_pack", ptr(w), ptr(wk), ptr(wf), c)
+        return wk, wf
+    return _cached("dw", w.detach(), make)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# raw kernel wrappers (no autograd)
+# --------------------------------------------------------------------------------------------------------------
+def k_gemm_nt(x0, x1, mode, grid, wp, nout, kp, taps, bias=None, act=ACT_NONE, out=None, out_f32=False, up=0, stats=False,
+              c0=None, c1=None, rpi=0, img_stride=0, ldc=None):
+    """grid = (N, H, W) of the OUTPUT pixel grid.  Returns (out, psum, psq)."""
+    n, h, w = grid
+    m = n * h * w
+    dev = x0.device
+    c0 = x0.shape[3] if c0 is None else c0
+    c1 = (x1.shape[3] if x1 is not None else 0) if c1 is None else c1
+    if out is None:
+        out = torch.empty((n, h, w, nout), device=dev, dtype=F32 if out_f32 else BF16)
+    if ldc is None:
+        ldc = out.stride(2) if out.dim() == 4 else nout
+    psum = psq = None
+    if stats:
+        pr = lib().query("hn_nt_stat_rows", m, nout)
+        psum = torch.empty((pr, nout), device=dev, dtype=F32)
+        psq = torch.empty((pr, nout), device=dev, dtype=F32)
+    lib().call("hn_conv_gemm_nt", ptr(x0), ptr(x1), mode, n, h, w, c0, c1, ld(x0), ld(x1) if x1 is not None else 0, up, m,
+               ptr(wp), nout, kp, taps, ptr(bias), act, ptr(out), 1 if out_f32 else 0, ldc, rpi, img_stride, ptr(psum), ptr(psq))
+    return out, psum, psq
+
+
+def k_gemm_tn(x0, x1, mode, grid, dz, nout, kp, taps, cin, up=0, kh=1):
+    """weight gradient, returns fp32 [nout, cin, kh, kh]."""
+    n, h, w = grid
+    m = n * h * w
+    dev = x0.device
+    splits, rps, wsb = ctypes.c_int(), ctypes.c_long(), ctypes.c_long()
+    lib().query("hn_wgrad_plan", m, nout, kp, taps, ctypes.addressof(splits), ctypes.addressof(rps), ctypes.addressof(wsb))
+    ws = torch.empty((wsb.value // 4,), device=dev, dtype=F32)
+    dw = torch.empty((nout, cin, kh, kh), device=dev, dtype=F32)
+    c0 = x0.shape[3]
+    c1 = x1.shape[3] if x1 is not None else 0
+    ldz = dz.stride(2) if dz.dim() == 4 else dz.stride(0)
+    lib().call("hn_conv_gemm_tn", ptr(x0), ptr(x1), mode, n, h, w, c0, c1, ld(x0), ld(x1) if x1 is not None else 0, up, m,
+               ptr(dz), ldz, nout, kp, taps, ptr(ws), ptr(dw))
+    return dw
+
+
+def k_col_stats(x, align=0):
+    m, c = rows(x), x.shape[3]
+    r = lib().query("hn_colred_rows", m, align)
+    pr = (m + r - 1) // r
+    ps = torch.empty((pr, c), device=x.device, dtype=F32)
+    pq = torch.empty((pr, c), device=x.device, dtype=F32)
+    lib().call("hn_col_stats", ptr(x), ld(x), m, c, r, ptr(ps), ptr(pq))
+    return ps, pq, r
+
+
+def k_rows_reduce(part, groups, s, c, alpha=1.0):
+    out = torch.empty((groups, c), device=part.device, dtype=F32)
+    lib().call("hn_rows_reduce", ptr(part), ptr(out), groups, s, c, float(alpha))
+    return out
+
+
+def k_bn_finalize(psum, psq, count, gamma, beta, eps, momentum, rm, rv):
+    c = gamma.shape[0]
+    coef = torch.empty((4, c), device=gamma.device, dtype=F32)     # scale, shift, mean, rstd
+    lib().call("hn_bn_finalize", ptr(psum), ptr(psq), psum.shape[0], c, count, ptr(gamma), ptr(beta), float(eps), float(momentum),
+               ptr(rm), ptr(rv), ptr(coef[0]), ptr(coef[1]), ptr(coef[2]), ptr(coef[3]))
+    return coef
+
+
+def k_bn_eval_coeff(gamma, beta, rm, rv, eps):
+    c = gamma.shape[0]
+    coef = torch.empty((4, c), device=gamma.device, dtype=F32)
+    lib().call("hn_bn_eval_coeff", ptr(gamma), ptr(beta), ptr(rm), ptr(rv), float(eps), c, ptr(coef[0]), ptr(coef[1]))
+    return coef
+
+
+def k_bn_act(z, coef, act, res=None, out=None):
+    n, h, w, c = z.shape
+    if out is None:
+        out = new_act(n, h, w, c, z.device)
+    lib().call("hn_bn_act", ptr(z), ld(z), ptr(coef[0]) if coef is not None else None, ptr(coef[1]) if coef is not None else None,
+               ptr(res), ld(res) if res is not None else 0, None, None, act, ptr(out), ld(out), rows(z), c)
+    return out
+
+
+def k_eltwise(op, a, b=None, act=ACT_NONE, alpha=1.0, out=None):
+    n, h, w, c = a.shape
+    if out is None:
+        out = new_act(n, h, w, c, a.device)
+    lib().call("hn_eltwise", op, ptr(a), ld(a), ptr(b), ld(b) if b is not None else 0, ptr(out), ld(out), rows(a), c, act, float(alpha))
+    return out
+
+
+def bn_backward(dout, z, y, coef, act, count, want_g=False):
+    """shared BatchNorm(+activation) backward: returns (dz, dgamma, dbeta, g|None)."""
+    n, h, w, c = z.shape
+    m = rows(z)
+    r = lib().query("hn_colred_rows", m, 0)
+    pr = (m + r - 1) // r
+    dev = z.device
+    pg = torch.empty((pr, c), device=dev, dtype=F32)
+    pgx = torch.empty((pr, c), device=dev, dtype=F32)
+    lib().call("hn_bn_bwd_reduce", ptr(dout), ld(dout), ptr(z), ld(z), ptr(y), ld(y) if y is not None else 0, ptr(coef[0]), ptr(coef[1]),
+               ptr(coef[2]), ptr(coef[3]), act, m, c, r, ptr(pg), ptr(pgx))
+    red = torch.empty((4, c), device=dev, dtype=F32)               # dgamma, dbeta, mean(g), mean(g*xhat)
+    lib().call("hn_bn_bwd_finalize", ptr(pg), ptr(pgx), pr, c, count, ptr(red[0]), ptr(red[1]), ptr(red[2]), ptr(red[3]))
+    dz = new_act(n, h, w, c, dev)
+    g = new_act(n, h, w, c, dev) if want_g else None
+    lib().call("hn_bn_bwd_apply", ptr(dout), ld(dout), ptr(z), ld(z), ptr(y), ld(y) if y is not None else 0, ptr(coef[0]), ptr(coef[1]),
+               ptr(coef[2]), ptr(coef[3]), ptr(red[2]), ptr(red[3]), act, ptr(dz), ld(dz), ptr(g), ld(g) if g is not None else 0, m, c)
+    return dz, red[0], red[1], g
+
+
+# --------------------------------------------------------------------------------------------------------------
+# conv (1x1 | 1x1 stride 2 | grouped 3x3 | stem) + BatchNorm + activation (+ residual)
+# --------------------------------------------------------------------------------------------------------------
+class ConvBnAct(torch.autograd.Function):
+    """out = act(BN(conv(x) [+ conv_bias]) [+ res]).  kind: "1x1", "g3x3", "stem"."""
+
+    @staticmethod
+    def forward(ctx, x, weight, conv_bias, gamma, beta, rm, rv, nbt, res, kind, stride, act, eps, momentum, training):
+        dev = x.device
+        cout = weight.shape[0]
+        if kind == "stem":
+            n, _, hi, wi = x.shape
+            ho, wo = hi // 2, wi // 2
+            z = new_act(n, ho, wo, 32, dev)
+            lib().call("hn_stem_fwd", ptr(x), ptr(weight), ptr(z), n, hi, wi)
+            psum = psq = None
+            packs = None
+        elif kind == "g3x3":
+            n, hi, wi, c = x.shape
+            ho, wo = (hi, wi) if stride == 1 else (hi // 2, wi // 2)
+            packs = pack_gconv_weight(weight, 1 if stride == 1 else 0)
+            z = new_act(n, ho, wo, c, dev)
+            lib().call("hn_gconv_fwd", ptr(x), ld(x), ptr(packs[0]), ptr(z), ld(z), n, hi, wi, c, stride)
+            psum = psq = None
+        else:
+            n, hi, wi, cin = x.shape
+            ho, wo = (hi, wi) if stride == 1 else (hi // 2, wi // 2)
+            packs = pack_conv_weight(weight)
+            z, psum, psq = k_gemm_nt(x, None, 0 if stride == 1 else 1, (n, ho, wo), packs[0], cout, kp32(cin), 1, bias=conv_bias,
+                                     stats=training)
+        count = n * ho * wo
+        if training:
+            if psum is None:
+                psum, psq, _ = k_col_stats(z)
+            coef = k_bn_finalize(psum, psq, count, gamma, beta, eps, momentum, rm, rv)
+            if nbt is not None:
+                nbt.add_(1)
+        else:
+            coef = k_bn_eval_coeff(gamma, beta, rm, rv, eps)
+        out = k_bn_act(z, coef, act, res=res)
+        ctx.kind, ctx.stride, ctx.act, ctx.count = kind, stride, act, count
+        ctx.has_bias = conv_bias is not None
+        ctx.has_res = res is not None
+        ctx.training = training
+        ctx.packs = packs
+        y_save = out if (act == ACT_RELU) else None
+        ctx.save_for_backward(x, weight, z, coef, y_save, gamma)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, weight, z, coef, y, gamma = ctx.saved_tensors
+        assert ctx.training, "backward through eval-mode BatchNorm is not part of the hot path"
+        dout = dense(dout)
+        kind, stride = ctx.kind, ctx.stride
+        dz, dgamma, dbeta, g = bn_backward(dout, z, y, coef, ctx.act, ctx.count, want_g=ctx.has_res and ctx.act != ACT_NONE)
+        dres = None
+        if ctx.has_res:
+            dres = g if g is not None else dout
+        dev = z.device
+        n, ho, wo, cout = z.shape
+        dx = None
+        if kind == "stem":
+            hi, wi = x.shape[2], x.shape[3]
+            blocks = lib().query("hn_stem_wgrad_blocks", n, hi, wi)
+            part = torch.empty((blocks, 864), device=dev, dtype=F32)
+            lib().call("hn_stem_wgrad", ptr(x), ptr(dz), ptr(part), n, hi, wi)
+            dw = k_rows_reduce(part, 1, blocks, 864).view(32, 3, 3, 3)
+        elif kind == "g3x3":
+            _, hi, wi, c = x.shape
+            wk, wd = ctx.packs
+            if ctx.needs_input_grad[0]:
+                dx = new_act(n, hi, wi, c, dev)
+                if stride == 1:
+                    lib().call("hn_gconv_fwd", ptr(dz), ld(dz), ptr(wd), ptr(dx), ld(dx), n, hi, wi, c, 1)
+                else:
+                    lib().call("hn_gconv_dgrad_s2", ptr(dz), ld(dz), ptr(wd), ptr(dx), ld(dx), n, hi, wi, c)
+            chunks = lib().query("hn_wgrad_chunks", n * ho * wo, (c // 8) * 9)
+            part = torch.empty((chunks, c * 72), device=dev, dtype=F32)
+            lib().call("hn_gconv_wgrad", ptr(x), ld(x), ptr(dz), ld(dz), ptr(part), n, hi, wi, c, stride)
+            dw = k_rows_reduce(part, 1, chunks, c * 72).view(c, 8, 3, 3)
+        else:
+            _, hi, wi, cin = x.shape
+            wp, wt = ctx.packs
+            if ctx.needs_input_grad[0]:
+                dxs, _, _ = k_gemm_nt(dz, None, 0, (n, ho, wo), wt, cin, kp32(cout), 1)
+                if stride == 1:
+                    dx = dxs
+                else:
+                    dx = torch.zeros((n, hi, wi, cin), device=dev, dtype=BF16)
+                    lib().call("hn_add_strided2", ptr(dx), ld(dx), ptr(dxs), ld(dxs), n, ho, wo, cin)
+            dw = k_gemm_tn(x, None, 0 if stride == 1 else 1, (n, ho, wo), dz, cout, kp32(cin), 1, cin)
+        dbias = torch.zeros((cout,), device=dev, dtype=F32) if ctx.has_bias else None   # a bias feeding BatchNorm has zero gradient
+        return dx, dw, dbias, dgamma.clone(), dbeta.clone(), None, None, None, dres, None, None, None, None, None, None
+
+
+def conv_bn_act(x, weight, conv_bias, bn, res=None, kind="1x1", stride=1, act=ACT_NONE, eps=1e-5, momentum=0.1, training=True):
+    gamma, beta, rm, rv, nbt = bn
+    return ConvBnAct.apply(x, weight, conv_bias, gamma, beta, rm, rv, nbt, res, kind, stride, act, eps, momentum, training)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# Squeeze-and-Excitation: out = b * sigmoid(W2 relu(W1 avgpool(b) + b1) + b2)        (net/anynet.py:40-48,68-69)
+# pooling, gating and their data-path backward are HIP kernels; the [N, C] x [C, C/4] MLP is a plain library GEMM.
+# --------------------------------------------------------------------------------------------------------------
+class SEGate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, b, w1, b1, w2, b2):
+        n, h, w, c = b.shape
+        hw = h * w
+        ps, _, r = k_col_stats(b, align=hw)
+        pooled = k_rows_reduce(ps, n, hw // r, c, 1.0 / hw)                      # [N, C]
+        w1m, w2m = w1.view(w1.shape[0], -1), w2.view(w2.shape[0], -1)
+        hid = torch.relu(torch.addmm(b1, pooled, w1m.t()))                       # [N, Cs]
+        gate = torch.sigmoid(torch.addmm(b2, hid, w2m.t()))                      # [N, C]
+        out = new_act(n, h, w, c, b.device)
+        lib().call("hn_scale_rows", ptr(b), ld(b), ptr(gate), hw, ptr(out), ld(out), n * hw, c)
+        ctx.save_for_backward(b, pooled, hid, gate, w1, w2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        b, pooled, hid, gate, w1, w2 = ctx.saved_tensors
+        dout = dense(dout)
+        n, h, w, c = b.shape
+        hw = h * w
+        m = n * hw
+        r = lib().query("hn_colred_rows", m, hw)
+        pr = (m + r - 1) // r
+        pd = torch.empty((pr, c), device=b.device, dtype=F32)
+        pz = torch.empty((pr, c), device=b.device, dtype=F32)
+        lib().call("hn_col_dot", ptr(dout), ld(dout), ptr(b), ld(b), m, c, r, ptr(pd), ptr(pz))
+        dgate = k_rows_reduce(pd, n, hw // r, c, 1.0)                            # sum_hw dout * b
+        w1m, w2m = w1.view(w1.shape[0], -1), w2.view(w2.shape[0], -1)
+        dpre2 = dgate * gate * (1.0 - gate)
+        dw2 = dpre2.t().mm(hid)
+        db2 = dpre2.sum(0)
+        dpre1 = dpre2.mm(w2m) * (hid > 0).to(F32)
+        dw1 = dpre1.t().mm(pooled)
+        db1 = dpre1.sum(0)
+        dpool = dpre1.mm(w1m).contiguous()
+        db = new_act(n, h, w, c, b.device)
+        lib().call("hn_se_bwd_apply", ptr(dout), ld(dout), ptr(gate), ptr(dpool), hw, ptr(db), ld(db), m, c)
+        return db, dw1.view_as(w1), db1, dw2.view_as(w2), db2
+
+
+# --------------------------------------------------------------------------------------------------------------
+# depthwise 3x3 (zero pad 1)
+# --------------------------------------------------------------------------------------------------------------
+def k_dwconv(x, wk, out=None):
+    n, h, w, c = x.shape
+    if out is None:
+        out = new_act(n, h, w, c, x.device)
+    lib().call("hn_dwconv_fwd", ptr(x), ld(x), ptr(wk), ptr(out), ld(out), n, h, w, c)
+    return out
+
+
+def k_dwconv_wgrad(x, dz):
+    n, h, w, c = x.shape
+    chunks = lib().query("hn_wgrad_chunks", n * h * w, c // 8)
+    part = torch.empty((chunks, c * 9), device=x.device, dtype=F32)
+    lib().call("hn_dwconv_wgrad", ptr(x), ld(x), ptr(dz), ld(dz), ptr(part), n, h, w, c)
+    return k_rows_reduce(part, 1, chunks, c * 9).view(c, 1, 3, 3)
+
+
+class DwConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight):
+        wk, wf = pack_dw_weight(weight)
+        ctx.save_for_backward(x, wf)
+        return k_dwconv(x, wk)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, wf = ctx.saved_tensors
+        dout = dense(dout)
+        dx = k_dwconv(dout, wf) if ctx.needs_input_grad[0] else None
+        return dx, k_dwconv_wgrad(x, dout)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# max pools, up-sampling
+# --------------------------------------------------------------------------------------------------------------
+def k_maxpool(x, mode, out=None):
+    n, h, w, c = x.shape
+    if out is None:
+        out = new_act(n, h // 2, w // 2, c, x.device)
+    lib().call("hn_maxpool_fwd", ptr(x), ld(x), ptr(out), ld(out), n, h, w, c, mode)
+    return out
+
+
+def k_maxpool_bwd(x, dout, mode, wscale=None):
+    n, h, w, c = x.shape
+    dx = new_act(n, h, w, c, x.device)
+    lib().call("hn_maxpool_bwd", ptr(x), ld(x), ptr(dout), ld(dout), ptr(dx), ld(dx), ptr(wscale), n, h, w, c, mode)
+    return dx
+
+
+class MaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mode):
+        ctx.mode = mode
+        ctx.save_for_backward(x)
+        return k_maxpool(x, mode)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x,) = ctx.saved_tensors
+        return k_maxpool_bwd(x, dense(dout), ctx.mode), None
+
+
+# --------------------------------------------------------------------------------------------------------------
+# BiFPN fusion node
+# --------------------------------------------------------------------------------------------------------------
+def _fuse_args(ins, modes):
+    arr_p = (ctypes.c_void_p * 3)(*[ptr(t) if t is not None else None for t in ins])
+    arr_l = (ctypes.c_int * 3)(*[ld(t) if t is not None else 0 for t in ins])
+    arr_m = (ctypes.c_int * 3)(*modes)
+    return arr_p, arr_l, arr_m
+
+
+class Fuse(torch.autograd.Function):
+    """out = swish(w0*T0(a) + w1*T1(b) [+ w2*T2(c)]); w = normalised fusion weights (fp32 [3] on device)."""
+
+    @staticmethod
+    def forward(ctx, w, m0, m1, m2, a, b, c):
+        ins = [a, b, c]
+        modes = [m0, m1, m2]
+        ref = a
+        n, h, wd, ch = ref.shape                      # input 0 is always at the output resolution (mode 1)
+        assert m0 == 1
+        out = new_act(n, h, wd, ch, ref.device)
+        ap, al, am = _fuse_args(ins, modes)
+        lib().call("hn_fuse_fwd", ctypes.addressof(ap), ctypes.addressof(al), ctypes.addressof(am), ptr(w), ptr(out), ld(out), n, h, wd, ch)
+        ctx.modes = modes
+        ctx.save_for_backward(w, *[t for t in ins if t is not None])
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        w = ctx.saved_tensors[0]
+        rest = list(ctx.saved_tensors[1:])
+        modes = ctx.modes
+        ins = [rest.pop(0) if m else None for m in modes]
+        dout = dense(dout)
+        n, h, wd, ch = dout.shape
+        dev = dout.device
+        g = new_act(n, h, wd, ch, dev)
+        dins = [new_act(n, h, wd, ch, dev) if m == 1 else None for m in modes]
+        ap, al, am = _fuse_args(ins, modes)
+        dp = (ctypes.c_void_p * 3)(*[ptr(t) if t is not None else None for t in dins])
+        dl = (ctypes.c_int * 3)(*[ld(t) if t is not None else 0 for t in dins])
+        blocks = lib().query("hn_fuse_bwd_blocks", n, h, wd, ch)
+        pw = torch.empty((blocks, 3), device=dev, dtype=F32)
+        lib().call("hn_fuse_bwd", ctypes.addressof(ap), ctypes.addressof(al), ctypes.addressof(am), ptr(w), ptr(dout), ld(dout), ptr(g), ld(g),
+                   ctypes.addressof(dp), ctypes.addressof(dl), ptr(pw), n, h, wd, ch)
+        dw = k_rows_reduce(pw, 1, blocks, 3).view(3)
+        for i, m in enumerate(modes):
+            if m == 2:                                               # nearest x2 of a half-res input: 2x2 sum of g
+                t = ins[i]
+                d = new_act(*t.shape, dev)
+                lib().call("hn_sum2x2", ptr(g), ld(g), ptr(d), ld(d), ptr(w[i]), n, h // 2, wd // 2, ch)
+                dins[i] = d
+            elif m == 3:                                             # zero-pad-same max pool of a double-res input
+                dins[i] = k_maxpool_bwd(ins[i], g, 0, wscale=w[i])
+        return dw[:w.numel()].clone(), None, None, None, dins[0], dins[1], dins[2]
+
+
+# --------------------------------------------------------------------------------------------------------------
+# segmentation decoder block: y = act(conv3x3(reflect_pad(cat[up2(x0)|x0, x1])) + bias)
+# --------------------------------------------------------------------------------------------------------------
+class SegConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x0, x1, weight, bias, up, act, out_f32):
+        n, h0, w0, c0 = x0.shape
+        h, w = (h0 * 2, w0 * 2) if up else (h0, w0)
+        cout, cin = weight.shape[0], weight.shape[1]
+        wp, wt = pack_conv_weight(weight)
+        y, _, _ = k_gemm_nt(x0, x1, 2, (n, h, w), wp, cout, kp32(cin), 9, bias=bias, act=act, out_f32=out_f32, up=up)
+        ctx.up, ctx.act, ctx.out_f32 = up, act, out_f32
+        ctx.wt = wt
+        ctx.has_x1 = x1 is not None
+        ctx.save_for_backward(x0, x1, weight, y if act == ACT_ELU else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x0, x1, weight, y = ctx.saved_tensors
+        up = ctx.up
+        n, h0, w0, c0 = x0.shape
+        h, w = (h0 * 2, w0 * 2) if up else (h0, w0)
+        cout, cin = weight.shape[0], weight.shape[1]
+        c1 = cin - c0
+        dev = x0.device
+        m = n * h * w
+        if ctx.out_f32:                                              # logits gradient from the loss: fp32 [N,H,W,cout] -> padded bf16
+            dy = dy.contiguous()
+            dz = new_act(n, h, w, pad8(cout), dev)
+            lib().call("hn_cast_f32_to_bf16_pad", ptr(dy), cout, ptr(dz), pad8(cout), m, cout)
+        else:
+            dy = dense(dy)
+            dz = k_eltwise(1, dy, y, act=ACT_ELU) if ctx.act == ACT_ELU else dy
+        # bias gradient: per-channel sum of dz
+        ps, _, r = k_col_stats(dz)
+        dbias = k_rows_reduce(ps, 1, ps.shape[0], dz.shape[3]).view(-1)[:cout].clone()
+        dw = k_gemm_tn(x0, x1, 2, (n, h, w), dz, cout, kp32(cin), 9, cin, up=up, kh=3)
+        # data gradient on the padded (H+2)x(W+2) grid, then fold the reflection / up-sampling / concat back
+        dvp, _, _ = k_gemm_nt(dz, None, 3, (n, h + 2, w + 2), ctx.wt, cin, kp32(cout), 9, c0=dz.shape[3], c1=0)
+        dx0 = dx1 = None
+        if ctx.needs_input_grad[0]:
+            dx0 = new_act(n, h0, w0, c0, dev)
+            lib().call("hn_seg_fold", ptr(dvp), ld(dvp), 0, ptr(dx0), ld(dx0), None, 0, n, h, w, c0, up)
+        if ctx.has_x1 and ctx.needs_input_grad[1]:
+            dx1 = new_act(n, h, w, c1, dev)
+            lib().call("hn_seg_fold", ptr(dvp), ld(dvp), c0, ptr(dx1), ld(dx1), None, 0, n, h, w, c1, 0)
+        return dx0, dx1, dw, dbias, None, None, None
+
+
+# --------------------------------------------------------------------------------------------------------------
+# head outputs: (optional depthwise 3x3) -> 1x1 conv + bias -> fp32, written straight into the caller's layout
+# --------------------------------------------------------------------------------------------------------------
+class HeadOut(torch.autograd.Function):
+    """feats: list of NHWC maps (pyramid levels) sharing one (dw, pw, bias) -> fp32 [N, sum_l H_l*W_l*rep, k] (rep*k = Cout).
+    Covers SeparableConvBlock(norm=False) headers of the det towers (head_detect/detection.py:24,36-44,61,73-83) and, with
+    dw_weight=None, the final 1x1(+bias) of a lane branch (head_lane/lanedetect.py:49,56,63,86-92)."""
+
+    @staticmethod
+    def forward(ctx, dw_weight, pw_weight, bias, k, act, *feats):
+        n = feats[0].shape[0]
+        cout, cin = pw_weight.shape[0], pw_weight.shape[1]
+        wp, wt = pack_conv_weight(pw_weight)
+        rows_total = sum(f.shape[1] * f.shape[2] for f in feats)
+        rep = cout // k
+        out = torch.empty((n, rows_total * rep, k), device=feats[0].device, dtype=F32)
+        ldc, img_stride, ch_off = cout, rows_total * cout, 0
+        mids = []
+        off = 0
+        for f in feats:
+            _, h, w, _ = f.shape
+            mid = k_dwconv(f, pack_dw_weight(dw_weight)[0]) if dw_weight is not None else f
+            mids.append(mid if dw_weight is not None else None)
+            dst = out.view(-1)[off * ldc + ch_off:]
+            k_gemm_nt(mid, None, 0, (n, h, w), wp, cout, kp32(cin), 1, bias=bias, act=act, out=dst, out_f32=True, ldc=ldc,
+                      rpi=h * w, img_stride=img_stride)
+            off += h * w
+        ctx.meta = (k, act, ch_off, ldc, img_stride, dw_weight is not None, len(feats))
+        ctx.wt = wt
+        ctx.save_for_backward(dw_weight, pw_weight, out if act == ACT_SIGMOID else None, *feats, *[t for t in mids if t is not None])
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        k, act, ch_off, ldc, img_stride, has_dw, nf = ctx.meta
+        saved = ctx.saved_tensors
+        dw_weight, pw_weight, yout = saved[0], saved[1], saved[2]
+        feats = saved[3:3 + nf]
+        mids = saved[3 + nf:] if has_dw else feats
+        cout, cin = pw_weight.shape[0], pw_weight.shape[1]
+        dout = dout.contiguous()
+        dev = dout.device
+        ldz = pad8(cout)
+        dpw = torch.zeros_like(pw_weight)
+        dbias = torch.zeros((cout,), device=dev, dtype=F32)
+        ddw = torch.zeros_like(dw_weight) if has_dw else None
+        dfeats = []
+        off = 0
+        for f, mid in zip(feats, mids):
+            n, h, w, _ = f.shape
+            m = n * h * w
+            dz = new_act(n, h, w, ldz, dev)
+            base = off * ldc + ch_off
+            lib().call("hn_head_grad", ptr(dout.view(-1)[base:]), ptr(yout.view(-1)[base:]) if yout is not None else None, h * w, img_stride,
+                       ldc, cout, ptr(dz), ldz, m, 1 if act == ACT_SIGMOID else 0)
+            ps, _, _ = k_col_stats(dz)
+            dbias += k_rows_reduce(ps, 1, ps.shape[0], ldz).view(-1)[:cout]
+            dpw += k_gemm_tn(mid, None, 0, (n, h, w), dz, cout, kp32(cin), 1, cin)
+            dmid, _, _ = k_gemm_nt(dz, None, 0, (n, h, w), ctx.wt, cin, kp32(cout), 1, c0=ldz, c1=0)
+            if has_dw:
+                ddw += k_dwconv_wgrad(f, dmid)
+                dfeats.append(k_dwconv(dmid, pack_dw_weight(dw_weight)[1]))
+            else:
+                dfeats.append(dmid)
+            off += h * w
+        return (ddw, dpw, dbias, None, None, *dfeats)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# lane-head input fusion: cat[mp(mp(P3)), mp(P4), P5, up2(P6)] with nn.MaxPool2d(3,2,1)   (head_lane/lanedetect.py:76-80)
+# --------------------------------------------------------------------------------------------------------------
+class LaneConcat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p3, p4, p5, p6):
+        n, h, w, c = p5.shape
+        out = new_act(n, h, w, 4 * c, p5.device)
+        t3 = k_maxpool(p3, 1)
+        k_maxpool(t3, 1, out=out[..., 0:c])
+        k_maxpool(p4, 1, out=out[..., c:2 * c])
+        k_eltwise(2, p5, alpha=1.0, out=out[..., 2 * c:3 * c])
+        lib().call("hn_up2_fwd", ptr(p6), ld(p6), ptr(out[..., 3 * c:]), ld(out), n, h // 2, w // 2, c)
+        ctx.save_for_backward(p3, p4, t3)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        p3, p4, t3 = ctx.saved_tensors
+        dout = dense(dout)
+        n, h, w, c4 = dout.shape
+        c = c4 // 4
+        dt3 = k_maxpool_bwd(t3, dout[..., 0:c], 1)
+        d3 = k_maxpool_bwd(p3, dt3, 1)
+        d4 = k_maxpool_bwd(p4, dout[..., c:2 * c], 1)
+        d5 = k_eltwise(2, dout[..., 2 * c:3 * c], alpha=1.0)
+        d6 = new_act(n, h // 2, w // 2, c, dout.device)
+        lib().call("hn_sum2x2", ptr(dout[..., 3 * c:]), ld(dout), ptr(d6), ld(d6), None, n, h // 2, w // 2, c)
+        return d3, d4, d5, d6
