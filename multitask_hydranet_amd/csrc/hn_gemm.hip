@@ -286,7 +286,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN p) {
 
     // transposed-read lane addressing: group g = lane>>4 owns k rows {s*16 + g*4 + q}; lane 4q+pp supplies row q, cols 4pp..4pp+3
     const int g = lane >> 4, t16 = lane & 15, q = t16 >> 2, pp = t16 & 3;
-    typedef __attribute__((address_space(3))) short4v* lds_s4;
+    typedef __bf16 trv4 __attribute__((__vector_size__(4 * sizeof(__bf16))));
+    typedef __attribute__((address_space(3))) trv4* lds_b4;
 
     if (m_begin < m_end) {
         fetch(m_begin);
@@ -301,18 +302,16 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN p) {
 #pragma unroll
                 for (int i = 0; i < TC; ++i) {
                     const int col = wc * WC + i * 16 + pp * 4;
-                    short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(sZ + (ks * 32 + g * 4 + q) * PZ + col * 2));
-                    short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(sZ + (ks * 32 + 16 + g * 4 + q) * PZ + col * 2));
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { a[i][e] = __builtin_bit_cast(bf16, lo[e]); a[i][e + 4] = __builtin_bit_cast(bf16, hi[e]); }
+                    const trv4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(sZ + (ks * 32 + g * 4 + q) * PZ + col * 2));
+                    const trv4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(sZ + (ks * 32 + 16 + g * 4 + q) * PZ + col * 2));
+                    a[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int col = wn * WN + j * 16 + pp * 4;
-                    short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(sXm + (ks * 32 + g * 4 + q) * PX + col * 2));
-                    short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(sXm + (ks * 32 + 16 + g * 4 + q) * PX + col * 2));
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { b[j][e] = __builtin_bit_cast(bf16, lo[e]); b[j][e + 4] = __builtin_bit_cast(bf16, hi[e]); }
+                    const trv4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(sXm + (ks * 32 + g * 4 + q) * PX + col * 2));
+                    const trv4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(sXm + (ks * 32 + 16 + g * 4 + q) * PX + col * 2));
+                    b[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
 #pragma unroll
                 for (int i = 0; i < TC; ++i)

@@ -309,12 +309,12 @@ class HydraNet(nn.Module):
         """BiFPN._forward_fast_attention, net/bifpn.py:156-233."""
         red = lambda nm, t: self._cba(t, p + nm + ".0.conv", p + nm + ".1", BN_FPN, act=ACT_NONE)
         if first:
-            if len(inputs) == 4 and len(self.conv_channel_coef) == 4:
-                p3, p4, p5, p6r = inputs[-4:]
-                p6_in = red("p6_down_channel", p6r)
-            else:
+            if len(inputs) == 4:                       # 4 backbone stages (small cfg): P6 is pooled from P5 (net/bifpn.py:158-160)
                 p3, p4, p5 = inputs[-3:]
                 p6_in = K.MaxPool.apply(red("p5_to_p6", p5), 0)
+            else:                                      # 5 stages (big cfg): the last stage is P6 (net/bifpn.py:162-165)
+                p3, p4, p5, p6r = inputs[-4:]
+                p6_in = red("p6_down_channel", p6r)
             p7_in = K.MaxPool.apply(p6_in, 0)
             p3_in, p4_in, p5_in = red("p3_down_channel", p3), red("p4_down_channel", p4), red("p5_down_channel", p5)
         else:
@@ -335,8 +335,6 @@ class HydraNet(nn.Module):
 
     def _neck(self, feats):
         x = list(feats)
-        if len(self.conv_channel_coef) == 4:
-            x = x[-4:]
         for k in range(self.fpn_cell_repeats):
             x = self._cell(f"neck.bifpn.{k}.", x, k == 0)
         return x

@@ -28,11 +28,19 @@ def ptr(t: Optional[torch.Tensor]):
 
 
 def ld(t: torch.Tensor) -> int:
-    """row stride (elements) of an NHWC activation (or channel-slice view of one)."""
-    assert t.dim() == 4 and t.stride(3) == 1, (t.shape, t.stride())
+    """row stride (elements) of an NHWC activation (or channel-slice view of one).  Size-1 dims carry no stride information."""
+    assert t.dim() == 4 and (t.stride(3) == 1 or t.shape[3] == 1), (t.shape, t.stride())
     n, h, w, c = t.shape
-    s = t.stride(2)
-    assert (h == 1 or t.stride(1) == w * s) and (n == 1 or t.stride(0) == h * w * s), (t.shape, t.stride())
+    if w > 1:
+        s = t.stride(2)
+    elif h > 1:
+        s = t.stride(1)
+    elif n > 1:
+        s = t.stride(0)
+    else:
+        s = c
+    assert (w == 1 or h == 1 or t.stride(1) == w * s) and (n == 1 or h * w == 1 or t.stride(0) == h * w * s), (t.shape, t.stride())
+    assert s % 8 == 0, (t.shape, t.stride())
     return s
 
 
@@ -53,11 +61,12 @@ def pad8(c: int) -> int:
 
 
 def dense(t: torch.Tensor) -> torch.Tensor:
-    """make a gradient tensor usable by the kernels (NHWC, unit channel stride, dense rows)."""
+    """make a gradient tensor usable by the kernels (NHWC bf16, unit channel stride, uniform row stride)."""
     if t.dtype != BF16:
         t = t.to(BF16)
-    if t.stride(3) != 1 or t.stride(2) % 8 != 0 or (t.shape[1] > 1 and t.stride(1) != t.shape[2] * t.stride(2)) or \
-            (t.shape[0] > 1 and t.stride(0) != t.shape[1] * t.shape[2] * t.stride(2)):
+    try:
+        ld(t)
+    except AssertionError:
         t = t.contiguous()
     return t
 
@@ -73,11 +82,13 @@ def clear_pack_cache():
 
 
 def _cached(key, w: torch.Tensor, make):
-    k = (key, w.data_ptr(), w._version, tuple(w.shape))
-    v = _PACK_CACHE.get(k)
-    if v is None:
-        v = make()
-        _PACK_CACHE[k] = v
+    # the entry keeps a strong reference to the weight tensor, so its id() cannot be recycled while the entry lives
+    k = (key, id(w))
+    hit = _PACK_CACHE.get(k)
+    if hit is not None and hit[0] is w and hit[1] == w._version:
+        return hit[2]
+    v = make()
+    _PACK_CACHE[k] = (w, w._version, v)
     return v
 
 
@@ -90,7 +101,7 @@ def pack_conv_weight(w: torch.Tensor):
         wt = torch.empty((cin, taps * kp32(cout)), device=w.device, dtype=BF16)
         lib().call("hn_pack_weight", ptr(w), ptr(wp), ptr(wt), cout, cin, taps)
         return wp, wt
-    return _cached("conv", w.detach(), make)
+    return _cached("conv", w, make)
 
 
 def pack_gconv_weight(w: torch.Tensor, flip: int):
@@ -100,7 +111,7 @@ def pack_gconv_weight(w: torch.Tensor, flip: int):
         wd = torch.empty((9 * 8 * c,), device=w.device, dtype=BF16)
         lib().call("hn_gconv_pack", ptr(w), ptr(wk), ptr(wd), c, flip)
         return wk, wd
-    return _cached(("g", flip), w.detach(), make)
+    return _cached(("g", flip), w, make)
 
 
 def pack_dw_weight(w: torch.Tensor):
@@ -110,7 +121,7 @@ def pack_dw_weight(w: torch.Tensor):
         wf = torch.empty((9 * c,), device=w.device, dtype=BF16)
         lib().call("hn_dw_pack", ptr(w), ptr(wk), ptr(wf), c)
         return wk, wf
-    return _cached("dw", w.detach(), make)
+    return _cached("dw", w, make)
 
 
 # --------------------------------------------------------------------------------------------------------------

@@ -1,0 +1,351 @@
+"""GPU parity of every HIP operator (forward AND backward) against an fp32 PyTorch reference of the same op, evaluated on the same
+bf16-rounded inputs.  Tolerances: outputs are bf16 (8 significant bits) with fp32 accumulation, so max|err| <= 2e-2 * max|ref| for
+activations and 3e-2 for gradients; index-like results (max-pool routing) are exact.  All calls go through the C ABI."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+ACT_TOL = 2e-2
+GRAD_TOL = 3e-2
+
+
+@pytest.fixture(scope="module")
+def K():
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    import __graft_entry__ as g
+    g.build()
+    from multitask_hydranet_amd import ops
+    torch.manual_seed(0)
+    return ops
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, scale=1.0):
+    """bf16-representable fp32 tensor on the GPU."""
+    return (torch.randn(*shape, device=dev()) * scale).bfloat16().float()
+
+
+def nhwc(x):
+    """NCHW fp32 -> NHWC bf16 leaf."""
+    return x.permute(0, 2, 3, 1).contiguous().bfloat16()
+
+
+def nchw(x):
+    return x.float().permute(0, 3, 1, 2)
+
+
+def close(a, b, tol, name=""):
+    a, b = a.float(), b.float()
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    err = float((a - b).abs().max())
+    ref = float(b.abs().max())
+    assert err <= tol * ref + 1e-6, f"{name}: max err {err:.4e} vs ref max {ref:.4e} (tol {tol})"
+
+
+def bfr(z):
+    """round to bf16 with a straight-through gradient: the HIP path stores conv outputs in bf16 BEFORE BatchNorm, so the
+    reference must see the same values (otherwise a ReLU mask flips wherever |BN(z)| is within a bf16 ulp of zero)."""
+    return z + (z.bfloat16().float() - z).detach()
+
+
+def swish(x):
+    return x * torch.sigmoid(x)
+
+
+ACTS = {0: lambda x: x, 1: F.relu, 2: swish, 3: F.elu, 4: torch.sigmoid}
+
+
+def bn_tuple(c):
+    g = (torch.rand(c, device=dev()) + 0.5).requires_grad_(True)
+    b = (torch.randn(c, device=dev()) * 0.1).requires_grad_(True)
+    rm = torch.randn(c, device=dev()) * 0.1
+    rv = torch.rand(c, device=dev()) + 0.5
+    nbt = torch.tensor(0, device=dev())
+    return g, b, rm, rv, nbt
+
+
+@pytest.mark.parametrize("cin,cout,stride,act,res,bias,n,h,w", [
+    (24, 40, 1, 1, False, False, 2, 10, 6),
+    (152, 152, 1, 1, True, False, 2, 8, 8),
+    (32, 8, 1, 0, False, True, 1, 6, 10),
+    (64, 376, 2, 0, False, False, 2, 8, 12),
+    (376, 112, 1, 2, False, True, 3, 5, 7),
+    (936, 936, 1, 1, True, False, 2, 4, 4),
+])
+def test_conv1x1_bn_act(K, cin, cout, stride, act, res, bias, n, h, w):
+    x = rnd(n, cin, h, w)
+    wt = rnd(cout, cin, 1, 1, scale=cin ** -0.5)
+    cb = rnd(cout, scale=0.1) if bias else None
+    g, b, rm, rv, nbt = bn_tuple(cout)
+    ho, wo = h // stride, w // stride
+    r = rnd(n, cout, ho, wo) if res else None
+    up = rnd(n, cout, ho, wo)
+    # HIP
+    xk = nhwc(x).requires_grad_(True)
+    wk = wt.clone().requires_grad_(True)
+    cbk = cb.clone().requires_grad_(True) if bias else None
+    rk = nhwc(r).requires_grad_(True) if res else None
+    rm_k, rv_k = rm.clone(), rv.clone()
+    out = K.conv_bn_act(xk, wk, cbk, (g, b, rm_k, rv_k, nbt), res=rk, kind="1x1", stride=stride, act=act, eps=1e-3, momentum=0.01)
+    out.backward(nhwc(up))
+    gk, bk = g.grad.clone(), b.grad.clone()
+    g.grad = b.grad = None
+    # reference
+    xr = x.clone().requires_grad_(True)
+    wr = wt.clone().requires_grad_(True)
+    z = bfr(F.conv2d(xr, wr, cb, stride))
+    rm_r, rv_r = rm.clone(), rv.clone()
+    y = F.batch_norm(z, rm_r, rv_r, g, b, True, 0.01, 1e-3)
+    rr = r.clone().requires_grad_(True) if res else None
+    if res:
+        y = y + rr
+    y = ACTS[act](y)
+    y.backward(up)
+    close(nchw(out), y, ACT_TOL, "out")
+    close(nchw(xk.grad), xr.grad, GRAD_TOL, "dx")
+    close(wk.grad, wr.grad, GRAD_TOL, "dw")
+    close(gk, g.grad, GRAD_TOL, "dgamma")
+    close(bk, b.grad, GRAD_TOL, "dbeta")
+    if res:
+        close(nchw(rk.grad), rr.grad, GRAD_TOL, "dres")
+    close(rm_k, rm_r, 1e-2, "running_mean")
+    close(rv_k, rv_r, 1e-2, "running_var")
+    assert int(nbt) == 1
+    g.grad = b.grad = None
+
+
+@pytest.mark.parametrize("c,stride,n,h,w", [(24, 2, 2, 12, 16), (64, 1, 2, 9, 10), (152, 1, 1, 6, 6), (8, 2, 2, 8, 8), (936, 2, 1, 4, 8)])
+def test_grouped_conv_bn_relu(K, c, stride, n, h, w):
+    x = rnd(n, c, h, w)
+    wt = rnd(c, 8, 3, 3, scale=0.15)
+    g, b, rm, rv, nbt = bn_tuple(c)
+    ho, wo = h // stride, w // stride
+    up = rnd(n, c, ho, wo)
+    xk = nhwc(x).requires_grad_(True)
+    wk = wt.clone().requires_grad_(True)
+    out = K.conv_bn_act(xk, wk, None, (g, b, rm.clone(), rv.clone(), nbt), kind="g3x3", stride=stride, act=1)
+    out.backward(nhwc(up))
+    gk, bk = g.grad.clone(), b.grad.clone()
+    g.grad = b.grad = None
+    xr = x.clone().requires_grad_(True)
+    wr = wt.clone().requires_grad_(True)
+    y = F.relu(F.batch_norm(bfr(F.conv2d(xr, wr, None, stride, 1, 1, c // 8)), rm.clone(), rv.clone(), g, b, True, 0.1, 1e-5))
+    y.backward(up)
+    close(nchw(out), y, ACT_TOL, "out")
+    close(nchw(xk.grad), xr.grad, GRAD_TOL, "dx")
+    close(wk.grad, wr.grad, GRAD_TOL, "dw")
+    close(gk, g.grad, GRAD_TOL, "dgamma")
+    close(bk, b.grad, GRAD_TOL, "dbeta")
+    g.grad = b.grad = None
+
+
+def test_stem(K):
+    n, h, w = 2, 16, 24
+    x = torch.randn(n, 3, h, w, device=dev())
+    wt = torch.randn(32, 3, 3, 3, device=dev()) * 0.2
+    g, b, rm, rv, nbt = bn_tuple(32)
+    up = rnd(n, 32, h // 2, w // 2)
+    wk = wt.clone().requires_grad_(True)
+    out = K.conv_bn_act(x, wk, None, (g, b, rm.clone(), rv.clone(), nbt), kind="stem", act=1)
+    out.backward(nhwc(up))
+    gk = g.grad.clone()
+    g.grad = b.grad = None
+    wr = wt.clone().requires_grad_(True)
+    y = F.relu(F.batch_norm(bfr(F.conv2d(x, wr, None, 2, 1)), rm.clone(), rv.clone(), g, b, True, 0.1, 1e-5))
+    y.backward(up)
+    close(nchw(out), y, ACT_TOL, "out")
+    close(wk.grad, wr.grad, GRAD_TOL, "dw")
+    close(gk, g.grad, GRAD_TOL, "dgamma")
+    g.grad = b.grad = None
+
+
+@pytest.mark.parametrize("c,n,h,w", [(112, 2, 8, 12), (16, 1, 5, 5), (112, 2, 4, 8)])
+def test_depthwise(K, c, n, h, w):
+    x = rnd(n, c, h, w)
+    wt = rnd(c, 1, 3, 3, scale=0.3)
+    up = rnd(n, c, h, w)
+    xk = nhwc(x).requires_grad_(True)
+    wk = wt.clone().requires_grad_(True)
+    out = K.DwConv.apply(xk, wk)
+    out.backward(nhwc(up))
+    xr = x.clone().requires_grad_(True)
+    wr = wt.clone().requires_grad_(True)
+    y = F.conv2d(F.pad(xr, [1, 1, 1, 1]), wr, None, 1, 0, 1, c)
+    y.backward(up)
+    close(nchw(out), y, ACT_TOL, "out")
+    close(nchw(xk.grad), xr.grad, GRAD_TOL, "dx")
+    close(wk.grad, wr.grad, GRAD_TOL, "dw")
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("c,n,h,w", [(112, 2, 8, 12), (16, 1, 4, 4), (8, 2, 2, 2)])
+def test_maxpool(K, mode, c, n, h, w):
+    x = rnd(n, c, h, w)
+    if mode == 0:
+        x = (x - 0.3).bfloat16().float()            # negative regions so that the ZERO padding wins some windows
+    up = rnd(n, c, h // 2, w // 2)
+    xk = nhwc(x).requires_grad_(True)
+    out = K.MaxPool.apply(xk, mode)
+    out.backward(nhwc(up))
+    xr = x.clone().requires_grad_(True)
+    y = F.max_pool2d(F.pad(xr, [0, 1, 0, 1]), 3, 2) if mode == 0 else F.max_pool2d(xr, 3, 2, 1)
+    y.backward(up)
+    assert torch.equal(nchw(out), y), "max-pool values are exact"
+    close(nchw(xk.grad), xr.grad, 1e-2, "dx")          # only bf16 rounding of summed routed gradients
+
+
+@pytest.mark.parametrize("modes", [(1, 2, 0), (1, 1, 3), (1, 3, 0)])
+def test_bifpn_fuse(K, modes):
+    n, c, h, w = 2, 16, 8, 12
+    shapes = {1: (h, w), 2: (h // 2, w // 2), 3: (2 * h, 2 * w)}
+    ins = [rnd(n, c, *shapes[m]) if m else None for m in modes]
+    nw = 3 if modes[2] else 2
+    p = torch.rand(nw, device=dev()) + 0.2
+    up = rnd(n, c, h, w)
+    pk = p.clone().requires_grad_(True)
+    wk = torch.relu(pk)
+    wk = wk / (wk.sum() + 1e-4)
+    ik = [nhwc(t).requires_grad_(True) if t is not None else None for t in ins]
+    out = K.Fuse.apply(wk, modes[0], modes[1], modes[2], ik[0], ik[1], ik[2])
+    out.backward(nhwc(up))
+    pr = p.clone().requires_grad_(True)
+    wr = torch.relu(pr)
+    wr = wr / (wr.sum() + 1e-4)
+    ir = [t.clone().requires_grad_(True) if t is not None else None for t in ins]
+    acc = 0
+    for i, m in enumerate(modes):
+        if m == 1:
+            acc = acc + wr[i] * ir[i]
+        elif m == 2:
+            acc = acc + wr[i] * F.interpolate(ir[i], scale_factor=2, mode="nearest")
+        elif m == 3:
+            acc = acc + wr[i] * F.max_pool2d(F.pad(ir[i], [0, 1, 0, 1]), 3, 2)
+    y = swish(acc)
+    y.backward(up)
+    close(nchw(out), y, ACT_TOL, "out")
+    for i, m in enumerate(modes):
+        if m:
+            close(nchw(ik[i].grad), ir[i].grad, GRAD_TOL, f"din{i}")
+    close(pk.grad, pr.grad, GRAD_TOL, "dweights")
+
+
+def test_se_gate(K):
+    n, c, cs, h, w = 3, 64, 8, 6, 10
+    x = rnd(n, c, h, w)
+    w1, b1 = rnd(cs, c, 1, 1, scale=0.2), rnd(cs, scale=0.1)
+    w2, b2 = rnd(c, cs, 1, 1, scale=0.3), rnd(c, scale=0.1)
+    up = rnd(n, c, h, w)
+    xk = nhwc(x).requires_grad_(True)
+    pk = [t.clone().requires_grad_(True) for t in (w1, b1, w2, b2)]
+    out = K.SEGate.apply(xk, *pk)
+    out.backward(nhwc(up))
+    xr = x.clone().requires_grad_(True)
+    pr = [t.clone().requires_grad_(True) for t in (w1, b1, w2, b2)]
+    gate = torch.sigmoid(F.conv2d(F.relu(F.conv2d(F.adaptive_avg_pool2d(xr, 1), pr[0], pr[1])), pr[2], pr[3]))
+    y = xr * gate
+    y.backward(up)
+    close(nchw(out), y, ACT_TOL, "out")
+    close(nchw(xk.grad), xr.grad, GRAD_TOL, "dx")
+    for a, b, nm in zip(pk, pr, ("dw1", "db1", "dw2", "db2")):
+        close(a.grad, b.grad, GRAD_TOL, nm)
+
+
+@pytest.mark.parametrize("c0,c1,cout,up,act,f32,n,h,w", [
+    (16, 0, 64, 0, 3, False, 2, 4, 4),
+    (64, 16, 64, 1, 3, False, 2, 8, 8),
+    (112, 0, 512, 0, 3, False, 1, 6, 10),
+    (128, 24, 128, 1, 3, False, 1, 12, 8),
+    (64, 0, 5, 1, 0, True, 2, 8, 12),
+])
+def test_seg_conv(K, c0, c1, cout, up, act, f32, n, h, w):
+    """h, w = OUTPUT resolution; x0 lives at (h>>up, w>>up)."""
+    x0 = rnd(n, c0, h >> up, w >> up)
+    x1 = rnd(n, c1, h, w) if c1 else None
+    wt = rnd(cout, c0 + c1, 3, 3, scale=(9 * (c0 + c1)) ** -0.5)
+    bs = rnd(cout, scale=0.1)
+    upg = rnd(n, cout, h, w)
+    x0k = nhwc(x0).requires_grad_(True)
+    x1k = nhwc(x1).requires_grad_(True) if c1 else None
+    wk, bk = wt.clone().requires_grad_(True), bs.clone().requires_grad_(True)
+    out = K.SegConv.apply(x0k, x1k, wk, bk, up, act, f32)
+    out.backward(upg.permute(0, 2, 3, 1).contiguous() if f32 else nhwc(upg))
+    x0r = x0.clone().requires_grad_(True)
+    x1r = x1.clone().requires_grad_(True) if c1 else None
+    wr, br = wt.clone().requires_grad_(True), bs.clone().requires_grad_(True)
+    v = F.interpolate(x0r, scale_factor=2, mode="nearest") if up else x0r
+    if c1:
+        v = torch.cat([v, x1r], 1)
+    y = ACTS[act](F.conv2d(F.pad(v, [1, 1, 1, 1], mode="reflect"), wr, br))
+    y.backward(upg)
+    close(nchw(out), y, ACT_TOL, "out")
+    close(nchw(x0k.grad), x0r.grad, GRAD_TOL, "dx0")
+    if c1:
+        close(nchw(x1k.grad), x1r.grad, GRAD_TOL, "dx1")
+    close(wk.grad, wr.grad, GRAD_TOL, "dw")
+    close(bk.grad, br.grad, GRAD_TOL, "dbias")
+
+
+@pytest.mark.parametrize("with_dw,cout,k,act", [(True, 36, 4, 0), (True, 81, 9, 4), (False, 65, 65, 0), (False, 2, 2, 0)])
+def test_head_out(K, with_dw, cout, k, act):
+    n, c = 2, 16
+    sizes = [(8, 8), (4, 4), (2, 2)] if with_dw else [(4, 6)]
+    feats = [rnd(n, c, *s) for s in sizes]
+    dw = rnd(c, 1, 3, 3, scale=0.3) if with_dw else None
+    pw, bs = rnd(cout, c, 1, 1, scale=0.25), rnd(cout, scale=0.1)
+    fk = [nhwc(t).requires_grad_(True) for t in feats]
+    dwk = dw.clone().requires_grad_(True) if with_dw else None
+    pwk, bk = pw.clone().requires_grad_(True), bs.clone().requires_grad_(True)
+    out = K.HeadOut.apply(dwk, pwk, bk, k, act, *fk)
+    up = torch.randn_like(out)
+    out.backward(up)
+    fr = [t.clone().requires_grad_(True) for t in feats]
+    dwr = dw.clone().requires_grad_(True) if with_dw else None
+    pwr, br = pw.clone().requires_grad_(True), bs.clone().requires_grad_(True)
+    outs = []
+    for f in fr:
+        t = F.conv2d(F.pad(f, [1, 1, 1, 1]), dwr, None, 1, 0, 1, c) if with_dw else f
+        t = F.conv2d(t, pwr, br).permute(0, 2, 3, 1).contiguous()
+        outs.append(t.view(n, -1, k))
+    y = ACTS[act](torch.cat(outs, 1))
+    y.backward(up)
+    close(out, y, ACT_TOL, "out")
+    for a, b in zip(fk, fr):
+        close(nchw(a.grad), b.grad, GRAD_TOL, "dfeat")
+    close(pwk.grad, pwr.grad, GRAD_TOL, "dpw")
+    close(bk.grad, br.grad, GRAD_TOL, "dbias")
+    if with_dw:
+        close(dwk.grad, dwr.grad, GRAD_TOL, "ddw")
+
+
+def test_lane_concat(K):
+    n, c = 2, 16
+    p3, p4, p5, p6 = rnd(n, c, 16, 16), rnd(n, c, 8, 8), rnd(n, c, 4, 4), rnd(n, c, 2, 2)
+    ks = [nhwc(t).requires_grad_(True) for t in (p3, p4, p5, p6)]
+    out = K.LaneConcat.apply(*ks)
+    up = rnd(n, 4 * c, 4, 4)
+    out.backward(nhwc(up))
+    rs = [t.clone().requires_grad_(True) for t in (p3, p4, p5, p6)]
+    mp = lambda t: F.max_pool2d(t, 3, 2, 1)
+    y = torch.cat([mp(mp(rs[0])), mp(rs[1]), rs[2], F.interpolate(rs[3], scale_factor=2, mode="nearest")], 1)
+    y.backward(up)
+    assert torch.equal(nchw(out), y)
+    for a, b in zip(ks, rs):
+        close(nchw(a.grad), b.grad, 1e-2, "dpyr")
+
+
+def test_eval_mode_bn_uses_running_stats(K):
+    n, c, h, w = 2, 24, 6, 6
+    x = rnd(n, c, h, w)
+    wt = rnd(c, c, 1, 1, scale=0.2)
+    g, b, rm, rv, nbt = bn_tuple(c)
+    with torch.no_grad():
+        out = K.conv_bn_act(nhwc(x), wt, None, (g, b, rm, rv, nbt), act=1, training=False)
+        y = F.relu(F.batch_norm(F.conv2d(x, wt), rm, rv, g, b, False, 0.1, 1e-5))
+    close(nchw(out), y, ACT_TOL, "eval out")
+    assert int(nbt) == 0
