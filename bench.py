@@ -1,0 +1,289 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec for HydraNet forward+loss+backward on MI355X (BASELINE.json metric), HIP path only.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" = one forward + multitask loss + backward over one synthetic batch that is already resident in HBM (the optimizer step is
+not part of the reference's fwd+bwd metric; its time is reported separately as ms_optimizer_step).  At N=1 the workload is
+BASELINE.json configs[2]: full HydraNet (big cfg), batch 16, 3x512x1024, bf16 compute.  For N>1 every rank runs the same per-GPU
+batch (weak scaling) and the gradients are averaged with the bucketed RCCL all-reduce of multitask_hydranet_amd.ddp.
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant launch (largest seg-decoder implicit-GEMM conv), timed live with HIP
+events; `cpu_baseline` is the fp32 oracle (a port, oracle/hydranet_oracle.py) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+import yaml  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+FWD_GFLOP_PER_IMG_512x1024 = 81.13   # BASELINE.md section 3 (conv MACs x 2); fwd+bwd = 3x
+
+
+def synthetic_batch(cfgs, n, h, w, seed, device):
+    """SURVEY.md section 8(d) synthetic inputs (same recipe as oracle.synthetic_batch, restated so the product path never imports oracle/)."""
+    g = torch.Generator().manual_seed(seed)
+    stride, interval = cfgs["lane"]["anchor_stride"], cfgs["lane"]["interval"]
+    hw, ppl = (h // stride) * (w // stride), h // interval
+    image = torch.randn(n, 3, h, w, generator=g)
+    gt_seg = torch.randint(0, len(cfgs["segment"]["class_list"]), (n, h, w), generator=g).float()
+    m = 16
+    cx, cy = torch.rand(n, m, generator=g) * w, torch.rand(n, m, generator=g) * h
+    bw, bh = 16 + torch.rand(n, m, generator=g) * 240, 16 + torch.rand(n, m, generator=g) * 240
+    cls = torch.randint(0, cfgs["detection"]["num_classes"], (n, m), generator=g).float()
+    gt_det = torch.stack([(cx - bw / 2).clamp(0, w - 1), (cy - bh / 2).clamp(0, h - 1), (cx + bw / 2).clamp(0, w - 1),
+                          (cy + bh / 2).clamp(0, h - 1), cls], dim=2)
+    for i in range(n):
+        if i % 8 == 7:
+            gt_det[i] = -1.0
+    gt_cls = torch.zeros(n, hw, 2)
+    gt_cls[..., 0] = 1.0
+    gt_loc = torch.zeros(n, hw, 2 * ppl + 2)
+    for i in range(n):
+        idx = torch.randperm(hw, generator=g)[:8]
+        gt_cls[i, idx, 0], gt_cls[i, idx, 1] = 0.0, 1.0
+        gt_loc[i, idx] = torch.randn(8, 2 * ppl + 2, generator=g)
+    return {k: v.to(device) for k, v in dict(image=image, gt_seg=gt_seg, gt_det=gt_det, gt_cls=gt_cls, gt_loc=gt_loc).items()}
+
+
+def dominant_launch_roofline(net, n, h, w, iters=20):
+    """Time the largest seg-decoder launch (3x3 reflect conv over cat[up2(x), skip]: decoder.3 of the big cfg) with HIP events on the
+    stream it is launched on, and price it against the dense bf16 MFMA peak."""
+    from multitask_hydranet_amd import ops as K
+    P = net._idx
+    wgt = P["segheader.decoder.3.conv.conv.weight"]
+    cout, cin = wgt.shape[0], wgt.shape[1]
+    c1 = net.fpn_num_filters
+    c0 = cin - c1
+    hh, ww = h // 8, w // 8                                         # P3 resolution (stride 8)
+    dev = wgt.device
+    x0 = torch.randn(n, hh // 2, ww // 2, c0, device=dev).to(torch.bfloat16)
+    x1 = torch.randn(n, hh, ww, c1, device=dev).to(torch.bfloat16)
+    wp, _ = K.pack_conv_weight(wgt)
+    bias = P["segheader.decoder.3.conv.conv.bias"]
+    out = torch.empty(n, hh, ww, cout, device=dev, dtype=torch.bfloat16)
+    run = lambda: K.k_gemm_nt(x0, x1, 2, (n, hh, ww), wp, cout, K.kp32(cin), 9, bias=bias, act=K.ACT_ELU, out=out, up=1)
+    for _ in range(3):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = 2.0 * n * hh * ww * cout * cin * 9
+    ach = flops / (ms * 1e-3) / 1e12
+    alg_bytes = 2.0 * (n * (hh // 2) * (ww // 2) * c0 + n * hh * ww * c1 + n * hh * ww * cout + cout * cin * 9)
+    return {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+            "traffic": None, "kernel": "gemm_nt_kernel<128,128,2,2,bf16> seg decoder.3 (3x3 reflect, 368->256 @ %dx%d, N=%d) fwd" % (hh, ww, n),
+            "launch_ms": round(ms, 4), "flop_per_launch": flops, "algorithmic_bytes_per_launch": alg_bytes}
+
+
+def cpu_baseline(cfgs, h, w, budget_s=25.0):
+    """fp32 CPU oracle (port of the reference path) on this box's host cores: N=1 fwd+loss+bwd, bounded sample."""
+    from oracle import hydranet_oracle as O
+    import multitask_hydranet_amd as pkg
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    net = pkg.HydraNet(cfgs)                                         # CPU parameter container only (initial weights)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    batch = O.synthetic_batch(cfgs, 1, h, w, seed=1)
+    ppl = h // cfgs["lane"]["interval"]
+
+    def step():
+        for v in sd.values():
+            v.grad = None
+        out = O.hydranet_forward(sd, cfgs, batch["image"], training=True)
+        ld = O.hydranet_losses(cfgs, out, batch, lane_points_per_line=ppl)
+        O.total_loss(cfgs, ld).backward()
+    t0 = time.time()
+    step()                                                           # warm-up
+    warm = time.time() - t0
+    times = []
+    while len(times) < 5 and (sum(times) + warm) < budget_s:
+        t0 = time.time()
+        step()
+        times.append(time.time() - t0)
+    if not times:
+        times = [warm]
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(1.0 / med, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "fp32 oracle, big cfg, N=1, 3x%dx%d, fwd+loss+bwd, 1 warm-up + %d timed iterations (median)" % (h, w, len(times))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU")
+    ap.add_argument("--res", default="512x1024")
+    ap.add_argument("--cfg", default=os.path.join(ROOT, "cfgs", "hydranet_big.yml"))
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one captured hipGraph per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backbone-only", action="store_true", help="BASELINE config[1]: backbone fwd+bwd, loss = sum of feature means")
+    args = ap.parse_args()
+    h, w = (int(v) for v in args.res.split("x"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus or world == 1, "--gpus must equal WORLD_SIZE under torch.distributed.run"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    from multitask_hydranet_amd import HydraNet
+    from multitask_hydranet_amd.ddp import GradReducer, UNUSED_5STAGE, broadcast_state
+
+    cfgs = yaml.safe_load(open(args.cfg))
+    cfgs["dataloader"]["network_input_height"], cfgs["dataloader"]["network_input_width"] = h, w
+    torch.manual_seed(0)
+    net = HydraNet(cfgs).to(dev).train()
+    net.check_finite = False                       # the reference's exit()-on-NaN guard is a host sync; checked once after the run instead
+    net.lane_points_per_line = h // cfgs["lane"]["interval"]     # the reference default (160) raises IndexError at H=512
+    broadcast_state(net)
+    batch = synthetic_batch(cfgs, args.batch, h, w, seed=1 + rank, device=dev)
+    reducer = None
+    use_graph = not args.no_graph
+    if world > 1:
+        reducer = GradReducer(list(net.named_parameters()), world_size=world, skip=UNUSED_5STAGE if len(net.depths) == 5 else ())
+
+    def fwd_bwd():
+        if args.backbone_only:
+            feats = net._backbone(batch["image"])
+            loss = sum(f.float().mean() for f in feats)
+            loss.backward()
+            return loss
+        out = net(batch["image"])
+        ld = net.cal_loss(out, batch)
+        loss = net.total_loss(ld)
+        loss.backward()
+        return loss
+
+    graph = None
+    static_loss = None
+    if use_graph:
+        try:
+            if reducer is not None:
+                reducer.remove()                    # hooks cannot fire inside a replay; gradients are exchanged right after it
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(2):
+                    net.zero_grad(set_to_none=True)
+                    fwd_bwd()
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            net.zero_grad(set_to_none=True)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_loss = fwd_bwd()
+            if reducer is not None:
+                reducer = GradReducer(list(net.named_parameters()), world_size=world, skip=UNUSED_5STAGE if len(net.depths) == 5 else ())
+                reducer.remove()
+        except Exception as e:                      # noqa: BLE001
+            if rank == 0:
+                import traceback
+                traceback.print_exc()
+                print("hipGraph capture failed, falling back to eager launches: %r" % (e,), file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+            if world > 1:
+                reducer = GradReducer(list(net.named_parameters()), world_size=world, skip=UNUSED_5STAGE if len(net.depths) == 5 else ())
+
+    def step():
+        if graph is not None:
+            graph.replay()
+            if reducer is not None:
+                reducer.reduce_now()
+            return static_loss
+        net.zero_grad(set_to_none=False) if reducer is not None else net.zero_grad(set_to_none=True)
+        loss = fwd_bwd()
+        if reducer is not None:
+            reducer.finish()
+        return loss
+
+    for _ in range(args.warmup):
+        loss = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    loss_val = float(loss)
+    assert loss_val == loss_val and abs(loss_val) != float("inf"), "non-finite loss after the timed run"
+
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        value = args.batch * world * args.steps / dt
+        # optimizer step, reported separately (Adam as in model/train.py:147)
+        opt = torch.optim.Adam(net.parameters(), 1e-5, weight_decay=1e-8)
+        for _ in range(2):
+            opt.step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            opt.step()
+        torch.cuda.synchronize()
+        ms_opt = (time.perf_counter() - t1) / 5 * 1e3
+        scale = (h * w) / (512.0 * 1024.0)
+        gflop_img = 3 * FWD_GFLOP_PER_IMG_512x1024 * scale * (12.02 / 81.13 if args.backbone_only else 1.0)
+        res = {
+            "metric": "images/sec (fwd+bwd) HydraNet", "value": round(value, 2), "unit": "images/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": ("RegNetY backbone only" if args.backbone_only else "full HydraNet (backbone + BiFPN + seg/det/lane heads + multitask loss)")
+                       + ", big cfg, fwd+loss+bwd", "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                       "resolution": "3x%dx%d" % (h, w), "parallelism": "dp%d" % world, "hipgraph": graph is not None,
+                       "grad_allreduce": None if world == 1 else ("bucketed RCCL after graph replay" if graph is not None
+                                                                 else "bucketed RCCL on a side stream overlapped with backward")},
+            "ms_optimizer_step": round(ms_opt, 3), "loss": round(loss_val, 4),
+            "model_tflops": round(value * gflop_img / 1e3, 2),
+        }
+        try:
+            res["roofline"] = dominant_launch_roofline(net, args.batch, h, w)
+        except Exception as e:      # noqa: BLE001
+            res["roofline"] = {"error": repr(e)}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline(yaml.safe_load(open(args.cfg)) | {"dataloader": cfgs["dataloader"]}, h, w)
+            except Exception as e:  # noqa: BLE001
+                res["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -53,8 +53,10 @@ int hn_conv_gemm_tn(const void* x0, const void* x1, int mode, int n_img, int H, 
 
 /* ---- NHWC stencils (hn_stencil.hip) ----------------------------------------------------------------------------------------- */
 
-/* Stem: x NCHW fp32 [N,3,H,W], w fp32 [32][3][3][3] -> z NHWC bf16 [N,H/2,W/2,32] (conv 3x3 s2 p1, net/anynet.py:12,17). */
-int hn_stem_fwd(const float* x, const float* w, void* z, int N, int H, int W, hipStream_t stream);
+/* Stem: x NCHW fp32 [N,3,H,W], w fp32 [32][3][3][3] -> z NHWC bf16 [N,H/2,W/2,32] (conv 3x3 s2 p1, net/anynet.py:12,17).
+ * patches (optional): bf16 im2col rows [N*H/2*W/2][32] (27 taps in weight order + 5 zeros) so that the weight gradient is one
+ * hn_conv_gemm_tn(mode 0) call on MFMA; hn_stem_wgrad is the fp32 VALU alternative. */
+int hn_stem_fwd(const float* x, const float* w, void* z, void* patches, int N, int H, int W, hipStream_t stream);
 long hn_stem_wgrad_blocks(int N, int H, int W);
 int hn_stem_wgrad(const float* x, const void* dz, float* part, int N, int H, int W, hipStream_t stream);
 
@@ -70,6 +72,7 @@ int hn_gconv_wgrad(const void* x, int ldx, const void* dz, int ldz, float* part,
 /* Depthwise 3x3, stride 1, zero pad 1 (SeparableConvBlock.depthwise_conv, net/common.py:91-92,104). */
 int hn_dw_pack(const float* w, void* wk, void* wkf, int C, hipStream_t stream);
 int hn_dwconv_fwd(const void* in, int ldi, const void* wk, void* out, int ldo, int N, int H, int W, int C, hipStream_t stream);
+long hn_dwconv_wgrad_blocks(long pixels, int C);
 int hn_dwconv_wgrad(const void* x, int ldx, const void* dz, int ldz, float* part, int N, int H, int W, int C, hipStream_t stream);
 
 /* 3x3/s2 max pools: mode 0 = zero pad right/bottom, zeros take part in the max (MaxPool2dStaticSamePadding, net/common.py:138-151);

@@ -342,20 +342,28 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN p) {
         }
 }
 
-// dW[co][ci][tap] (PyTorch [Cout][Cin][kh][kw] order) = sum_split part[split][co][tap*KP + ci]
-__global__ void wgrad_reduce_kernel(const float* part, float* dw, int splits, int Nout, int Cin, int KP, int taps) {
-    const long total = (long)Nout * Cin * taps;
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int tap = (int)(idx % taps);
-    const long t = idx / taps;
-    const int ci = (int)(t % Cin);
-    const int co = (int)(t / Cin);
+// dW[co][ci][tap] (PyTorch [Cout][Cin][kh][kw] order) = sum_split part[split][co][tap*KP + ci].
+// block = 32 consecutive partial columns x 16 split lanes: coalesced rows, LDS tree over the lanes.
+__global__ __launch_bounds__(512) void wgrad_reduce_kernel(const float* part, float* dw, int splits, int Nout, int Cin, int KP, int taps) {
+    __shared__ float red[16][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const long Ktot = (long)taps * KP;
-    const float* src = part + (long)co * Ktot + tap * KP + ci;
+    const long cols = (long)Nout * Ktot;
+    const long col = (long)blockIdx.x * 32 + tx;
     float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += src[(long)k * Nout * Ktot];
-    dw[idx] = s;
+    if (col < cols)
+        for (int k = ty; k < splits; k += 16) s += part[(long)k * cols + col];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && col < cols) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][tx];
+        const int co = (int)(col / Ktot);
+        const int r = (int)(col - (long)co * Ktot);
+        const int tap = r / KP, ci = r - tap * KP;
+        if (ci < Cin) dw[((long)co * Cin + ci) * taps + tap] = t;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -502,8 +510,8 @@ extern "C" int hn_conv_gemm_tn(const void* x0, const void* x1, int mode, int n_i
     rc = HN_ERR_UNSUPPORTED;
 #undef TN_CASE
     if (rc != HN_OK) return rc;
-    const long total = (long)Nout * (C0 + C1) * taps;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, workspace, dw, splits, Nout, C0 + C1, KP, taps);
+    const long cols = (long)Nout * taps * KP;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(cols, 32)), dim3(512), 0, st, workspace, dw, splits, Nout, C0 + C1, KP, taps);
     HN_LAUNCH_CHECK();
 }
 

@@ -88,15 +88,24 @@ __global__ __launch_bounds__(256) void colred_kernel(const ColRed p) {
     }
 }
 
-// out[g][c] = alpha * sum_{j < S} in[(g*S + j)][c]      (one thread per (g, c))
-__global__ void rows_reduce_kernel(const float* in, float* out, int G, int S, int C, float alpha) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long)G * C) return;
-    const int g = (int)(idx / C), c = (int)(idx - (long)g * C);
-    const float* src = in + (long)g * S * C + c;
-    double s = 0.0;
-    for (int j = 0; j < S; ++j) s += src[(long)j * C];
-    out[idx] = (float)(s * alpha);
+// out[g][c] = alpha * sum_{j < S} in[(g*S + j)][c]      block = 32 columns x 16 row lanes (coalesced rows, LDS tree over the lanes)
+__global__ __launch_bounds__(512) void rows_reduce_kernel(const float* in, float* out, int G, int S, int C, float alpha) {
+    __shared__ float red[16][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + tx, g = blockIdx.y;
+    float s = 0.f;
+    if (c < C) {
+        const float* src = in + (long)g * S * C + c;
+        for (int j = ty; j < S; j += 16) s += src[(long)j * C];
+    }
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][tx];
+        out[(long)g * C + c] = t * alpha;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -372,7 +381,7 @@ extern "C" int hn_col_dot(const void* a, int lda, const void* b, int ldb, long M
 
 extern "C" int hn_rows_reduce(const float* in, float* out, int G, int S, int C, float alpha, hipStream_t st) {
     HN_CHECK_ARG(in && out && G > 0 && S > 0 && C > 0);
-    hipLaunchKernelGGL(rows_reduce_kernel, dim3(cdiv((long)G * C, 256)), dim3(256), 0, st, in, out, G, S, C, alpha);
+    hipLaunchKernelGGL(rows_reduce_kernel, dim3(cdiv(C, 32), G), dim3(512), 0, st, in, out, G, S, C, alpha);
     HN_LAUNCH_CHECK();
 }
 

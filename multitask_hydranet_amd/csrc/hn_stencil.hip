@@ -12,7 +12,7 @@
 // ---------------------------------------------------------------------------------------------------------
 // stem: x NCHW fp32 [N,3,H,W] -> z NHWC bf16 [N,H/2,W/2,32]; weights fp32 [32][3][3][3]
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* x, const float* w, bf16* z, int N, int H, int W) {
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* x, const float* w, bf16* z, bf16* patches, int N, int H, int W) {
     __shared__ float sw[27][32];
     for (int i = threadIdx.x; i < 27 * 32; i += 256) {
         const int co = i & 31, t = i >> 5;        // t = ci*9 + ky*3 + kx
@@ -30,6 +30,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* x, const flo
     float acc[32];
 #pragma unroll
     for (int c = 0; c < 32; ++c) acc[c] = 0.f;
+    bf16* prow = patches ? patches + idx * 32 : nullptr;      // im2col row (27 taps + 5 zeros) kept in bf16 for the MFMA wgrad
 #pragma unroll 1
     for (int t = 0; t < 9; ++t) {                  // t = ci*3 + ky ; kept rolled so the 864 weights are not hoisted
         const int ci = t / 3, ky = t - ci * 3;
@@ -39,10 +40,15 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* x, const flo
             const int ix = 2 * ox + kx - 1;
             float v = 0.f;
             if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[((n * 3 + ci) * H + iy) * (long)W + ix];
+            if (prow) prow[t * 3 + kx] = f2bf(v);
             const float* wr = sw[t * 3 + kx];
 #pragma unroll
             for (int c = 0; c < 32; ++c) acc[c] = fmaf(v, wr[c], acc[c]);
         }
+    }
+    if (prow) {
+#pragma unroll
+        for (int t = 27; t < 32; ++t) prow[t] = f2bf(0.f);
     }
     bf16* o = z + idx * 32;
 #pragma unroll
@@ -188,14 +194,16 @@ __global__ __launch_bounds__(256) void gconv_dgrad_s2_kernel(const bf16* dz, int
 
 // wgrad partials: part[chunk][((g*8+o)*8 + i)*9 + tap] = sum over the chunk's output pixels of dz[pix][g*8+o] * x[pix(tap)][g*8+i]
 __global__ __launch_bounds__(256) void gconv_wgrad_kernel(const bf16* x, int ldx, const bf16* dz, int ldz, float* part, int N, int Hi,
-                                                          int Wi, int Ho, int Wo, int G, int S, long ppc) {
+                                                          int Wi, int Ho, int Wo, int G, int S, long ppc, long nchunks) {
     const int items = G * 9;
-    const int item = blockIdx.y * 256 + threadIdx.x;
-    if (item >= items) return;
+    const long tid = (long)blockIdx.x * 256 + threadIdx.x;       // (chunk, item) flattened: neighbouring lanes = neighbouring groups
+    const long chunk = tid / items;
+    const int item = (int)(tid - chunk * items);
+    if (chunk >= nchunks) return;
     const int g = item % G, tap = item / G;
     const int ky = tap / 3, kx = tap - ky * 3;
     const long total = (long)N * Ho * Wo;
-    const long p0 = (long)blockIdx.x * ppc;
+    const long p0 = chunk * ppc;
     long p1 = p0 + ppc;
     if (p1 > total) p1 = total;
     float acc[8][8];
@@ -222,7 +230,7 @@ __global__ __launch_bounds__(256) void gconv_wgrad_kernel(const bf16* x, int ldx
             for (int i = 0; i < 8; ++i) acc[o][i] = fmaf(zf, xf[i], acc[o][i]);
         }
     }
-    float* dst = part + (long)blockIdx.x * G * 576;
+    float* dst = part + chunk * G * 576;
 #pragma unroll
     for (int o = 0; o < 8; ++o)
 #pragma unroll
@@ -296,49 +304,68 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const bf16* in, int ldi
     }
 }
 
-// wgrad partials: part[chunk][c*9 + tap] = sum over the chunk's pixels of dz[pix][c] * x[pix + tap - 1][c]
+// wgrad partials: part[block][c*9 + tap] = sum over the block's pixels of dz[pix][c] * x[pix + tap - 1][c].
+// A block = (C/8 channel groups) x (256 / (C/8) pixel lanes); every lane walks `ppl` consecutive pixels, then the lanes are summed
+// through LDS (three rounds of 24 accumulators) so that one partial row per block leaves the chip.
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const bf16* x, int ldx, const bf16* dz, int ldz, float* part, int N, int H,
-                                                           int W, int C, long ppc) {
+                                                           int W, int C, int ppl) {
+    __shared__ float red[256][25];
     const int C8 = C >> 3;
-    const int cg = blockIdx.y * 256 + threadIdx.x;
-    if (cg >= C8) return;
+    const int lanes = 256 / C8;
+    const int tid = threadIdx.x;
+    const int cg = tid % C8, lane = tid / C8;
+    const bool active = lane < lanes;
     const long total = (long)N * H * W;
-    const long p0 = (long)blockIdx.x * ppc;
-    long p1 = p0 + ppc;
+    const long p0 = ((long)blockIdx.x * lanes + lane) * ppl;
+    long p1 = p0 + ppl;
     if (p1 > total) p1 = total;
     float acc[9][8];
 #pragma unroll
     for (int tq = 0; tq < 9; ++tq)
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[tq][k] = 0.f;
-    for (long pix = p0; pix < p1; ++pix) {
-        const int ox = (int)(pix % W);
-        const long t1 = pix / W;
-        const int oy = (int)(t1 % H);
-        const long n = t1 / H;
-        const bf16x8 zv = ld8(dz + pix * ldz + cg * 8);
-        float zf[8];
+    if (active) {
+        for (long pix = p0; pix < p1; ++pix) {
+            const int ox = (int)(pix % W);
+            const long t1 = pix / W;
+            const int oy = (int)(t1 % H);
+            const long n = t1 / H;
+            const bf16x8 zv = ld8(dz + pix * ldz + cg * 8);
+            float zf[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) zf[k] = bf2f(zv[k]);
+            for (int k = 0; k < 8; ++k) zf[k] = bf2f(zv[k]);
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int iy = oy + ky - 1;
-            if (iy < 0 || iy >= H) continue;
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iy = oy + ky - 1;
+                if (iy < 0 || iy >= H) continue;
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int ix = ox + kx - 1;
-                if (ix < 0 || ix >= W) continue;
-                const bf16x8 xv = ld8(x + ((n * H + iy) * (long)W + ix) * ldx + cg * 8);
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int ix = ox + kx - 1;
+                    if (ix < 0 || ix >= W) continue;
+                    const bf16x8 xv = ld8(x + ((n * H + iy) * (long)W + ix) * ldx + cg * 8);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) acc[ky * 3 + kx][k] = fmaf(zf[k], bf2f(xv[k]), acc[ky * 3 + kx][k]);
+                    for (int k = 0; k < 8; ++k) acc[ky * 3 + kx][k] = fmaf(zf[k], bf2f(xv[k]), acc[ky * 3 + kx][k]);
+                }
             }
         }
     }
     float* dst = part + (long)blockIdx.x * C * 9;
 #pragma unroll
-    for (int tq = 0; tq < 9; ++tq)
+    for (int r = 0; r < 3; ++r) {
+        __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 8; ++k) dst[(long)(cg * 8 + k) * 9 + tq] = acc[tq][k];
+        for (int tq = 0; tq < 3; ++tq)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) red[tid][tq * 8 + k] = active ? acc[r * 3 + tq][k] : 0.f;
+        __syncthreads();
+        for (int o = tid; o < C8 * 24; o += 256) {
+            const int g = o / 24, v = o - g * 24;
+            float sum = 0.f;
+            for (int l = 0; l < lanes; ++l) sum += red[l * C8 + g][v];
+            const int tq = r * 3 + v / 8, k = v & 7;
+            dst[(long)(g * 8 + k) * 9 + tq] = sum;
+        }
+    }
 }
 
 // fp32 [C][1][3][3] -> wk[tap][C] and flipped wkf[8 - tap][C]
@@ -681,10 +708,10 @@ static inline int ew_grid(long items) {
     return (int)b;
 }
 
-extern "C" int hn_stem_fwd(const float* x, const float* w, void* z, int N, int H, int W, hipStream_t st) {
+extern "C" int hn_stem_fwd(const float* x, const float* w, void* z, void* patches, int N, int H, int W, hipStream_t st) {
     HN_CHECK_ARG(x && w && z && N > 0 && H > 1 && W > 1 && !(H & 1) && !(W & 1));
     const long total = (long)N * (H >> 1) * (W >> 1);
-    hipLaunchKernelGGL(stem_fwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, x, w, (bf16*)z, N, H, W);
+    hipLaunchKernelGGL(stem_fwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, x, w, (bf16*)z, (bf16*)patches, N, H, W);
     HN_LAUNCH_CHECK();
 }
 extern "C" long hn_stem_wgrad_blocks(int N, int H, int W) {
@@ -748,8 +775,8 @@ extern "C" int hn_gconv_wgrad(const void* x, int ldx, const void* dz, int ldz, f
     const long pixels = (long)N * Ho * Wo;
     const long chunks = hn_wgrad_chunks(pixels, G * 9);
     const long ppc = (pixels + chunks - 1) / chunks;
-    hipLaunchKernelGGL(gconv_wgrad_kernel, dim3(chunks, cdiv(G * 9, 256)), dim3(256), 0, st, (const bf16*)x, ldx, (const bf16*)dz, ldz, part,
-                       N, Hi, Wi, Ho, Wo, G, stride, ppc);
+    hipLaunchKernelGGL(gconv_wgrad_kernel, dim3(cdiv(chunks * G * 9, 256)), dim3(256), 0, st, (const bf16*)x, ldx, (const bf16*)dz, ldz, part,
+                       N, Hi, Wi, Ho, Wo, G, stride, ppc, chunks);
     HN_LAUNCH_CHECK();
 }
 
@@ -765,14 +792,20 @@ extern "C" int hn_dwconv_fwd(const void* in, int ldi, const void* wk, void* out,
                        H, W, C);
     HN_LAUNCH_CHECK();
 }
-// part: fp32 [hn_wgrad_chunks(N*H*W, C/8)][C*9]
+// number of partial rows (= blocks) of hn_dwconv_wgrad; part is fp32 [blocks][C*9], reduce with hn_rows_reduce(part, dw, 1, blocks, C*9, 1)
+extern "C" long hn_dwconv_wgrad_blocks(long pixels, int C) {
+    const int lanes = 256 / (C >> 3);
+    long ppl = (pixels + 2047L * lanes) / (2048L * lanes);       // aim for ~2048 blocks
+    if (ppl < 4) ppl = 4;
+    return (pixels + ppl * lanes - 1) / (ppl * lanes);
+}
 extern "C" int hn_dwconv_wgrad(const void* x, int ldx, const void* dz, int ldz, float* part, int N, int H, int W, int C, hipStream_t st) {
-    HN_CHECK_ARG(x && dz && part && (C & 7) == 0 && ((ldx | ldz) & 7) == 0);
+    HN_CHECK_ARG(x && dz && part && (C & 7) == 0 && C <= 2048 && ((ldx | ldz) & 7) == 0);
     const long pixels = (long)N * H * W;
-    const long chunks = hn_wgrad_chunks(pixels, C >> 3);
-    const long ppc = (pixels + chunks - 1) / chunks;
-    hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3(chunks, cdiv(C >> 3, 256)), dim3(256), 0, st, (const bf16*)x, ldx, (const bf16*)dz, ldz, part,
-                       N, H, W, C, ppc);
+    const int lanes = 256 / (C >> 3);
+    const long blocks = hn_dwconv_wgrad_blocks(pixels, C);
+    const int ppl = (int)((pixels + blocks * lanes - 1) / (blocks * lanes));
+    hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3(blocks), dim3(256), 0, st, (const bf16*)x, ldx, (const bf16*)dz, ldz, part, N, H, W, C, ppl);
     HN_LAUNCH_CHECK();
 }
 

@@ -53,7 +53,7 @@ def det_loss(classification: torch.Tensor, regression: torch.Tensor, anchors: to
     npos = pos.sum(dim=1).to(dtype)
     assigned = torch.gather(annotations, 1, iou_arg[:, :, None].expand(-1, -1, 5))  # [N, A, 5]
     cls_id = assigned[:, :, 4].long().clamp(min=0)
-    one_hot = F.one_hot(cls_id, c.shape[2]).to(torch.bool) & pos[:, :, None]
+    one_hot = (cls_id[:, :, None] == torch.arange(c.shape[2], device=c.device)) & pos[:, :, None]
     # targets: 1 at (positive, class), 0 at other positive/negative entries, -1 (ignored) elsewhere
     counted = pos[:, :, None] | neg[:, :, None]
     af = torch.where(one_hot, alpha, 1.0 - alpha)
@@ -79,8 +79,8 @@ def lane_cls_loss(cls_targets: torch.Tensor, cls_preds: torch.Tensor, negative_r
     fp, fn = pmask.float(), nmask.float()
     preds = cls_preds.reshape(-1, cls_preds.shape[-1])
     npos_f, nneg_f = fp.sum(), fn.sum()
-    neg_num = torch.clamp(npos_f * negative_ratio, max=nneg_f, min=1).to(torch.int64)
-    pos_num = torch.clamp(npos_f, min=1).int()
+    neg_num = torch.maximum(torch.minimum(npos_f * negative_ratio, nneg_f), torch.ones_like(npos_f)).to(torch.int64)
+    pos_num = torch.maximum(npos_f, torch.ones_like(npos_f)).int()
     lsm = F.log_softmax(preds, dim=-1)
     fg, bg = lsm[..., 1], lsm[..., 0]
     # k-th smallest background log-prob among the negatives (find_k_th_small_in_a_tensor, lanedetect_loss.py:5-8):

@@ -130,8 +130,10 @@ class HydraNet(nn.Module):
             s = cfgs["segment"]
             self.use_lovasz = s["use_lovasz"]
             assert not self.use_lovasz, "Lovasz loss is off in every shipped cfg and outside the hot path"
-            cw = torch.tensor(s["class_weight"], dtype=torch.float32)
-            self.loss_seg = lambda logits, target: L.seg_loss(logits, target, cw, s["use_top_k"], s["top_k_ratio"], s["use_focal"])
+            # device-resident copy of the class weights (non-persistent: not part of the reference's state_dict)
+            self.register_buffer("_seg_class_weight", torch.tensor(s["class_weight"], dtype=torch.float32), persistent=False)
+            self.loss_seg = lambda logits, target: L.seg_loss(logits, target, self._seg_class_weight, s["use_top_k"],
+                                                              s["top_k_ratio"], s["use_focal"])
         else:
             self.segheader, self.loss_seg = None, None
         if self.train_lane:
@@ -250,7 +252,7 @@ class HydraNet(nn.Module):
             object.__setattr__(self.laneheader, "_fwd", lambda fused: me()._lane([K_to_nhwc(t) for t in fused]))
 
     def _reindex(self):
-        self._idx = {k: v for k, v in itertools.chain(self.named_parameters(), self.named_buffers())}
+        self._idx = {k: v for k, v in itertools.chain(self.named_parameters(), self.named_buffers()) if not k.startswith("_")}
 
     def _apply(self, fn, recurse=True):
         r = super()._apply(fn, recurse)

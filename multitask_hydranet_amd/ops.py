@@ -225,13 +225,15 @@ def bn_backward(dout, z, y, coef, act, count, want_g=False):
     pgx = torch.empty((pr, c), device=dev, dtype=F32)
     lib().call("hn_bn_bwd_reduce", ptr(dout), ld(dout), ptr(z), ld(z), ptr(y), ld(y) if y is not None else 0, ptr(coef[0]), ptr(coef[1]),
                ptr(coef[2]), ptr(coef[3]), act, m, c, r, ptr(pg), ptr(pgx))
-    red = torch.empty((4, c), device=dev, dtype=F32)               # dgamma, dbeta, mean(g), mean(g*xhat)
-    lib().call("hn_bn_bwd_finalize", ptr(pg), ptr(pgx), pr, c, count, ptr(red[0]), ptr(red[1]), ptr(red[2]), ptr(red[3]))
+    red = torch.empty((2, c), device=dev, dtype=F32)               # mean(g), mean(g*xhat)
+    dgamma = torch.empty((c,), device=dev, dtype=F32)
+    dbeta = torch.empty((c,), device=dev, dtype=F32)
+    lib().call("hn_bn_bwd_finalize", ptr(pg), ptr(pgx), pr, c, count, ptr(dgamma), ptr(dbeta), ptr(red[0]), ptr(red[1]))
     dz = new_act(n, h, w, c, dev)
     g = new_act(n, h, w, c, dev) if want_g else None
     lib().call("hn_bn_bwd_apply", ptr(dout), ld(dout), ptr(z), ld(z), ptr(y), ld(y) if y is not None else 0, ptr(coef[0]), ptr(coef[1]),
-               ptr(coef[2]), ptr(coef[3]), ptr(red[2]), ptr(red[3]), act, ptr(dz), ld(dz), ptr(g), ld(g) if g is not None else 0, m, c)
-    return dz, red[0], red[1], g
+               ptr(coef[2]), ptr(coef[3]), ptr(red[0]), ptr(red[1]), act, ptr(dz), ld(dz), ptr(g), ld(g) if g is not None else 0, m, c)
+    return dz, dgamma, dbeta, g
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -248,9 +250,9 @@ class ConvBnAct(torch.autograd.Function):
             n, _, hi, wi = x.shape
             ho, wo = hi // 2, wi // 2
             z = new_act(n, ho, wo, 32, dev)
-            lib().call("hn_stem_fwd", ptr(x), ptr(weight), ptr(z), n, hi, wi)
+            packs = new_act(n, ho, wo, 32, dev) if training else None       # bf16 im2col rows for the MFMA weight gradient
+            lib().call("hn_stem_fwd", ptr(x), ptr(weight), ptr(z), ptr(packs), n, hi, wi)
             psum = psq = None
-            packs = None
         elif kind == "g3x3":
             n, hi, wi, c = x.shape
             ho, wo = (hi, wi) if stride == 1 else (hi // 2, wi // 2)
@@ -297,11 +299,7 @@ class ConvBnAct(torch.autograd.Function):
         n, ho, wo, cout = z.shape
         dx = None
         if kind == "stem":
-            hi, wi = x.shape[2], x.shape[3]
-            blocks = lib().query("hn_stem_wgrad_blocks", n, hi, wi)
-            part = torch.empty((blocks, 864), device=dev, dtype=F32)
-            lib().call("hn_stem_wgrad", ptr(x), ptr(dz), ptr(part), n, hi, wi)
-            dw = k_rows_reduce(part, 1, blocks, 864).view(32, 3, 3, 3)
+            dw = k_gemm_tn(ctx.packs, None, 0, (n, ho, wo), dz, 32, 32, 1, 32)[:, :27].reshape(32, 3, 3, 3)
         elif kind == "g3x3":
             _, hi, wi, c = x.shape
             wk, wd = ctx.packs
@@ -327,7 +325,7 @@ class ConvBnAct(torch.autograd.Function):
                     lib().call("hn_add_strided2", ptr(dx), ld(dx), ptr(dxs), ld(dxs), n, ho, wo, cin)
             dw = k_gemm_tn(x, None, 0 if stride == 1 else 1, (n, ho, wo), dz, cout, kp32(cin), 1, cin)
         dbias = torch.zeros((cout,), device=dev, dtype=F32) if ctx.has_bias else None   # a bias feeding BatchNorm has zero gradient
-        return dx, dw, dbias, dgamma.clone(), dbeta.clone(), None, None, None, dres, None, None, None, None, None, None
+        return dx, dw, dbias, dgamma, dbeta, None, None, None, dres, None, None, None, None, None, None
 
 
 def conv_bn_act(x, weight, conv_bias, bn, res=None, kind="1x1", stride=1, act=ACT_NONE, eps=1e-5, momentum=0.1, training=True):
@@ -393,7 +391,7 @@ def k_dwconv(x, wk, out=None):
 
 def k_dwconv_wgrad(x, dz):
     n, h, w, c = x.shape
-    chunks = lib().query("hn_wgrad_chunks", n * h * w, c // 8)
+    chunks = lib().query("hn_dwconv_wgrad_blocks", n * h * w, c)
     part = torch.empty((chunks, c * 9), device=x.device, dtype=F32)
     lib().call("hn_dwconv_wgrad", ptr(x), ld(x), ptr(dz), ld(dz), ptr(part), n, h, w, c)
     return k_rows_reduce(part, 1, chunks, c * 9).view(c, 1, 3, 3)

@@ -1,0 +1,74 @@
+"""CPU, world_size 2, gloo: the bucketed gradient exchange averages gradients exactly like a single process over the concatenated batch,
+skips named never-used parameters identically on both ranks, and re-arms for the next step."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _net():
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
+    m.unused = torch.nn.Parameter(torch.ones(3))
+    return m
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from multitask_hydranet_amd.ddp import GradReducer, broadcast_state
+    m = _net()
+    if rank == 1:
+        with torch.no_grad():
+            for p in m.parameters():
+                p.add_(1.0)                              # diverge on purpose; broadcast_state must undo it
+    broadcast_state(m)
+    red = GradReducer(list(m.named_parameters()), bucket_bytes=600, skip=("unused",))
+    assert len(red.buckets) >= 2
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 6, 8, generator=g)
+    y = torch.randn(2, 6, 4, generator=g)
+    out = {}
+    for step in range(2):
+        m.zero_grad(set_to_none=False) if step else None
+        loss = ((m(x[rank]) - y[rank]) ** 2).mean()
+        loss.backward()
+        red.finish()
+        out[step] = [p.grad.clone() for n, p in m.named_parameters() if n != "unused"]
+    assert m.unused.grad is None
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_matches_single_process_average():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    m = _net()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 6, 8, generator=g)
+    y = torch.randn(2, 6, 4, generator=g)
+    loss = 0.5 * (((m(x[0]) - y[0]) ** 2).mean() + ((m(x[1]) - y[1]) ** 2).mean())
+    loss.backward()
+    ref = [p.grad for n, p in m.named_parameters() if n != "unused"]
+    for step in (0, 1):
+        for a, b, r in zip(res[0][step], res[1][step], ref):
+            assert torch.equal(a, b)                                    # both ranks hold identical averaged gradients
+            assert torch.allclose(a, r, rtol=1e-5, atol=1e-7)
