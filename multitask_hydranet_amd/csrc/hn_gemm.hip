@@ -52,6 +52,62 @@ __device__ __forceinline__ bf16x8 load_x_piece(const XSrc& s, long m, int n, int
     return ld8(s.x0 + (((long)n * s.Hi + iy) * s.Wi + ix) * s.ld0 + c);
 }
 
+// 16 zero bytes: the source of every out-of-range / padded piece of an LDS-DMA (global_load_lds cannot zero-fill)
+__device__ __attribute__((aligned(16))) bf16 g_zero_piece[8];
+
+// address of the 16-byte piece (8 channels starting at c) of the gathered activation row, or the zero piece
+__device__ __forceinline__ const bf16* x_piece_ptr(const XSrc& s, long m, int n, int oy, int ox, int tap, int c) {
+    if (m >= s.M || c >= s.C0 + s.C1) return g_zero_piece;
+    if (s.mode == 0) return s.x0 + m * s.ld0 + c;
+    if (s.mode == 1) return s.x0 + (((long)n * s.Hi + 2 * oy) * s.Wi + 2 * ox) * s.ld0 + c;
+    const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+    if (s.mode == 2) {
+        int iy = oy + ky - 1, ix = ox + kx - 1;
+        iy = iy < 0 ? -iy : (iy >= s.Hi ? 2 * s.Hi - 2 - iy : iy);
+        ix = ix < 0 ? -ix : (ix >= s.Wi ? 2 * s.Wi - 2 - ix : ix);
+        if (c < s.C0) {
+            const int hh = s.Hi >> s.up, ww = s.Wi >> s.up;
+            return s.x0 + (((long)n * hh + (iy >> s.up)) * ww + (ix >> s.up)) * s.ld0 + c;
+        }
+        return s.x1 + (((long)n * s.Hi + iy) * s.Wi + ix) * s.ld1 + (c - s.C0);
+    }
+    const int iy = oy - ky, ix = ox - kx;                                    // mode 3
+    if (iy < 0 || iy >= s.Hi || ix < 0 || ix >= s.Wi) return g_zero_piece;
+    return s.x0 + (((long)n * s.Hi + iy) * s.Wi + ix) * s.ld0 + c;
+}
+
+// element offset (channel 0) into x0 (which = 0) or x1 (which = 1) of output row (n, oy, ox) under filter tap `tap`; -1 = reads as
+// zeros.  Evaluated once per (row, tap): the per-stage address is then just base + offset + channel.
+__device__ __forceinline__ long pixel_off(const XSrc& s, long m, int n, int oy, int ox, int tap, int which) {
+    if (m >= s.M) return -1;
+    if (s.mode == 0) return which ? -1 : m * s.ld0;
+    if (s.mode == 1) return which ? -1 : (((long)n * s.Hi + 2 * oy) * s.Wi + 2 * ox) * s.ld0;
+    const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+    if (s.mode == 2) {
+        int iy = oy + ky - 1, ix = ox + kx - 1;
+        iy = iy < 0 ? -iy : (iy >= s.Hi ? 2 * s.Hi - 2 - iy : iy);
+        ix = ix < 0 ? -ix : (ix >= s.Wi ? 2 * s.Wi - 2 - ix : ix);
+        if (which) return s.C1 ? (((long)n * s.Hi + iy) * s.Wi + ix) * s.ld1 : -1;
+        const int hh = s.Hi >> s.up, ww = s.Wi >> s.up;
+        return (((long)n * hh + (iy >> s.up)) * ww + (ix >> s.up)) * s.ld0;
+    }
+    const int iy = oy - ky, ix = ox - kx;                                    // mode 3
+    if (which || iy < 0 || iy >= s.Hi || ix < 0 || ix >= s.Wi) return -1;
+    return (((long)n * s.Hi + iy) * s.Wi + ix) * s.ld0;
+}
+
+// XCD-aware block order (8 XCDs, private L2s, workgroups dealt round-robin): hardware id -> logical id such that consecutive LOGICAL
+// ids run on one XCD, so tiles that share an operand panel hit that XCD's L2.  Bijective for any grid size.  Speed only.
+__device__ __forceinline__ int xcd_remap(int hw, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = hw & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (hw >> 3);
+}
+
+__device__ __forceinline__ void glds16(const bf16* src, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
 __device__ __forceinline__ int swz(int row, int piece) { return row * 128 + ((piece ^ (row & 7)) << 4); }
 
 struct GemmNT {
@@ -72,14 +128,18 @@ template <int BC, int BP, int WGC, int WGP, bool OUT_F32>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
     constexpr int WC = BC / WGC, WP = BP / WGP, TC = WC / 16, TP = WP / 16;
     constexpr int XR = BP / 32, WR = (BC + 31) / 32;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sW = smem;
-    char* sX = smem + BC * 128;
+    constexpr int STAGE = (BC + BP) * 128;                        // one K stage (64 k) of both operands
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // two stages, ONE array (keeps the compiler's LDS-DMA waits minimal)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wc = wave / WGP, wp = wave % WGP;
-    const int c_blk = blockIdx.y * BC;
-    const long p_blk = (long)blockIdx.x * BP;
-    const int pj = tid & 7, r0 = tid >> 3, half = pj >> 2, sub = (pj & 3) * 8;
+    const int ncy = (p.Nout + BC - 1) / BC;                       // cout tiles: fastest logical index => they share the pixel tile in L2
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int c_tile = lid % ncy, p_tile = lid / ncy;
+    const int c_blk = c_tile * BC;
+    const long p_blk = (long)p_tile * BP;
+    // LDS-DMA staging: a wave instruction writes 64 x 16 B = 8 consecutive tile rows (lane-linear).  Thread t owns PHYSICAL piece t&7 of
+    // rows (t>>3) + 32 i; the XOR swizzle is applied on the SOURCE side: it fetches logical piece (t&7) ^ (row&7).
+    const int r0 = tid >> 3, lp = (tid & 7) ^ (r0 & 7), half = lp >> 2, sub = (lp & 3) * 8;
     const int kc = p.KP >> 5, Q = p.taps * kc, S = (Q + 1) >> 1;
     const int Ktot = p.taps * p.KP;
 
@@ -88,31 +148,19 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
     for (int i = 0; i < XR; ++i) decomp_row(p.x, p_blk + r0 + 32 * i, xn[i], xy[i], xx[i]);
 
     int tap = half / kc, cidx = half - tap * kc;   // chunk q = 2*stage + half -> (tap, cidx)
-    bf16x8 xr[XR], wr[WR];
-
-    auto fetch = [&](int stage) {
-        const int q = 2 * stage + half;
-        const bool qv = q < Q;
-        const int c = cidx * 32 + sub;
+    const int Ctot = p.x.C0 + p.x.C1;
+    long xo0[XR], xo1[XR];                         // per-row source offsets for the current tap (-1 = zeros)
 #pragma unroll
-        for (int i = 0; i < XR; ++i)
-            xr[i] = qv ? load_x_piece(p.x, p_blk + r0 + 32 * i, xn[i], xy[i], xx[i], tap, c) : zero8();
+    for (int i = 0; i < XR; ++i) {
+        xo0[i] = pixel_off(p.x, p_blk + r0 + 32 * i, xn[i], xy[i], xx[i], tap, 0);
+        xo1[i] = pixel_off(p.x, p_blk + r0 + 32 * i, xn[i], xy[i], xx[i], tap, 1);
+    }
+    long wo[WR];                                   // weight row offset + this thread's in-chunk offset (-1 = zero row)
 #pragma unroll
-        for (int i = 0; i < WR; ++i) {
-            const int row = r0 + 32 * i;
-            const int co = c_blk + row;
-            wr[i] = (qv && row < BC && co < p.Nout) ? ld8(p.w + (long)co * Ktot + q * 32 + sub) : zero8();
-        }
-        cidx += 2;
-        while (cidx >= kc) { cidx -= kc; ++tap; }
-    };
-    auto stash = [&]() {
-#pragma unroll
-        for (int i = 0; i < XR; ++i) *reinterpret_cast<bf16x8*>(sX + swz(r0 + 32 * i, pj)) = xr[i];
-#pragma unroll
-        for (int i = 0; i < WR; ++i)
-            if (r0 + 32 * i < BC) *reinterpret_cast<bf16x8*>(sW + swz(r0 + 32 * i, pj)) = wr[i];
-    };
+    for (int i = 0; i < WR; ++i) {
+        const int co = c_blk + r0 + 32 * i;
+        wo[i] = (r0 + 32 * i < BC && co < p.Nout) ? (long)co * Ktot + sub : -1;
+    }
 
     f32x4 acc[TC][TP];
 #pragma unroll
@@ -120,29 +168,63 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
 #pragma unroll
         for (int j = 0; j < TP; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    fetch(0);
-    stash();
-    __syncthreads();
-    for (int s = 0; s < S; ++s) {
-        if (s + 1 < S) fetch(s + 1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 a[TC], b[TP];
-            const int piece = ks * 4 + (lane >> 4);
-#pragma unroll
-            for (int i = 0; i < TC; ++i) a[i] = *reinterpret_cast<const bf16x8*>(sW + swz(wc * WC + i * 16 + (lane & 15), piece));
-#pragma unroll
-            for (int j = 0; j < TP; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sX + swz(wp * WP + j * 16 + (lane & 15), piece));
-#pragma unroll
-            for (int i = 0; i < TC; ++i)
-#pragma unroll
-                for (int j = 0; j < TP; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
+    // software pipeline: iteration `it` issues the LDS-DMA of stage `it` and multiplies stage `it-1` (one barrier per stage)
+    for (int it = 0; it <= S; ++it) {
+        // LDS-DMA completion is only ordered by the issuing wave's own vmcnt wait followed by a barrier (hipcc does not add the wait
+        // for __syncthreads() here): stage it-1 has landed for every wave, and nobody still reads buffer it&1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (s + 1 < S) {
-            stash();
-            __syncthreads();
+        if (it < S) {
+            char* sW = smem + (it & 1) * STAGE;
+            char* sX = sW + BC * 128;
+            const int q = 2 * it + half;
+            const bool qv = q < Q;
+            const int c = cidx * 32 + sub;
+            const bool from0 = c < p.x.C0;
+            const bool cv = qv && c < Ctot;
+            const bf16* xbase = from0 ? p.x.x0 + c : p.x.x1 + (c - p.x.C0);
+#pragma unroll
+            for (int i = 0; i < XR; ++i) {
+                const long off = from0 ? xo0[i] : xo1[i];
+                const bf16* src = (cv && off >= 0) ? xbase + off : g_zero_piece;
+                glds16(src, sX + (wave * 8 + 32 * i) * 128);
+            }
+#pragma unroll
+            for (int i = 0; i < WR; ++i) {
+                if (wave * 8 + 32 * i < BC) {                          // wave-uniform
+                    const bf16* src = (qv && wo[i] >= 0) ? p.w + wo[i] + q * 32 : g_zero_piece;
+                    glds16(src, sW + (wave * 8 + 32 * i) * 128);
+                }
+            }
+            cidx += 2;
+            if (cidx >= kc) {
+                while (cidx >= kc) { cidx -= kc; ++tap; }
+                if (tap < p.taps) {
+#pragma unroll
+                    for (int i = 0; i < XR; ++i) {
+                        xo0[i] = pixel_off(p.x, p_blk + r0 + 32 * i, xn[i], xy[i], xx[i], tap, 0);
+                        xo1[i] = pixel_off(p.x, p_blk + r0 + 32 * i, xn[i], xy[i], xx[i], tap, 1);
+                    }
+                }
+            }
+        }
+        if (it > 0) {
+            const char* sW = smem + ((it - 1) & 1) * STAGE;
+            const char* sX = sW + BC * 128;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 a[TC], b[TP];
+                const int piece = ks * 4 + (lane >> 4);
+#pragma unroll
+                for (int i = 0; i < TC; ++i) a[i] = *reinterpret_cast<const bf16x8*>(sW + swz(wc * WC + i * 16 + (lane & 15), piece));
+#pragma unroll
+                for (int j = 0; j < TP; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sX + swz(wp * WP + j * 16 + (lane & 15), piece));
+#pragma unroll
+                for (int i = 0; i < TC; ++i)
+#pragma unroll
+                    for (int j = 0; j < TP; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
         }
     }
 
@@ -201,7 +283,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
                 }
             }
             if ((lane & 15) == 0) {
-                const long prow = (long)blockIdx.x * WGP + wp;
+                const long prow = (long)p_tile * WGP + wp;
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (co0 + r < p.Nout) {
@@ -222,25 +304,39 @@ struct GemmTN {
     int ldz, Nout, KP, taps;
     float* part;      // [splits][Nout][taps*KP]
     long rows_per_split;   // multiple of 64
+    int gy;           // number of cout tiles
 };
+
+// LDS image of a pixel-major tile: rows of COLS bf16, UNPADDED (LDS-DMA writes lane-linear 1 KiB runs), 16-byte pieces XOR-swizzled so
+// that the 8 rows x 32 B a half-wave touches in one ds_read_b64_tr_b16 cover all 64 banks exactly once:
+//   physical piece = piece ^ ((((row & 7) / (16 / NP)) << 1) & (NP - 1)),  NP = COLS / 8 pieces per row.
+template <int COLS>
+__device__ __forceinline__ int tn_swz(int row, int piece) {
+    constexpr int NP = COLS / 8, RPL = 16 / NP;
+    return piece ^ ((((row & 7) / RPL) << 1) & (NP - 1));
+}
 
 template <int BC, int BN, int WGC, int WGN>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN p) {
     constexpr int WC = BC / WGC, WN = BN / WGN, TC = WC / 16, TN = WN / 16;
-    constexpr int PZ = BC * 2 + 32, PX = BN * 2 + 32;            // LDS row pitches (bytes): cols/2 + 8 dwords
     constexpr int ZPR = BC / 8, XPR = BN / 8;                     // 16-byte pieces per row
     constexpr int ZL = (64 * ZPR + 255) / 256, XL = (64 * XPR + 255) / 256;
-    __shared__ __attribute__((aligned(16))) char sZ[64 * PZ];
-    __shared__ __attribute__((aligned(16))) char sXm[64 * PX];
+    constexpr int ZB = 64 * BC * 2, XB = 64 * BN * 2, STAGE = ZB + XB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // two stages of [dZ tile | X tile]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wc = wave / WGN, wn = wave % WGN;
     const int ntile = (p.KP + BN - 1) / BN;
-    const int tap = blockIdx.x / ntile;
-    const int ci_blk = (blockIdx.x - tap * ntile) * BN;
-    const int c_blk = blockIdx.y * BC;
-    const long m_begin = (long)blockIdx.z * p.rows_per_split;
+    // logical block id: (tap, ci tile) fastest, then cout tile, then pixel split -- the blocks of one split share dZ / X rows in one L2
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int gx = ntile * p.taps;
+    const int bx = lid % gx, by = (lid / gx) % p.gy, bz = lid / (gx * p.gy);
+    const int tap = bx / ntile;
+    const int ci_blk = (bx - tap * ntile) * BN;
+    const int c_blk = by * BC;
+    const long m_begin = (long)bz * p.rows_per_split;
     long m_end = m_begin + p.rows_per_split;
     if (m_end > p.x.M) m_end = p.x.M;
+    const int S = m_end > m_begin ? (int)((m_end - m_begin + 63) >> 6) : 0;
 
     f32x4 acc[TC][TN];
 #pragma unroll
@@ -248,69 +344,105 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    bf16x8 zr[ZL], xr[XL];
-    auto fetch = [&](long m0) {
+    // per-piece pixel coordinates, advanced by 64 rows per stage without divisions
+    int pn[XL], py[XL], px[XL];
 #pragma unroll
-        for (int i = 0; i < ZL; ++i) {
-            const int e = tid + 256 * i;
-            const int row = e / ZPR, cp = e - row * ZPR;
-            const long m = m0 + row;
-            const int co = c_blk + cp * 8;
-            // dZ rows are zero padded up to ldz (>= Nout rounded up to 8), so a piece that starts below Nout is readable
-            zr[i] = (row < 64 && m < m_end && co < p.Nout) ? ld8(p.dz + m * p.ldz + co) : zero8();
+    for (int i = 0; i < XL; ++i) decomp_row(p.x, m_begin + (tid + 256 * i) / XPR, pn[i], py[i], px[i]);
+    const int adv_q = p.x.mode ? 64 / p.x.W : 0, adv_r = p.x.mode ? 64 % p.x.W : 0;
+    const int Ctot = p.x.C0 + p.x.C1;
+    // mode 2 (3x3 reflect + up + concat), this block's tap: source coordinates are separable, so they are tabulated once per block:
+    //   ty0[oy], tx0[ox] = coordinates in x0's grid (after reflection and >> up), ty1/tx1 = coordinates in x1's (full-res) grid
+    int* ty0 = reinterpret_cast<int*>(smem + 2 * STAGE);
+    int* tx0 = ty0 + p.x.H;
+    int* ty1 = tx0 + p.x.W;
+    int* tx1 = ty1 + p.x.H;
+    if (p.x.mode == 2) {
+        const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+        for (int i = tid; i < p.x.H; i += 256) {
+            int iy = i + ky - 1;
+            iy = iy < 0 ? -iy : (iy >= p.x.Hi ? 2 * p.x.Hi - 2 - iy : iy);
+            ty1[i] = iy;
+            ty0[i] = iy >> p.x.up;
         }
-#pragma unroll
-        for (int i = 0; i < XL; ++i) {
-            const int e = tid + 256 * i;
-            const int row = e / XPR, cp = e - row * XPR;
-            const long m = m0 + row;
-            int n, oy, ox;
-            decomp_row(p.x, m, n, oy, ox);
-            xr[i] = (row < 64 && m < m_end) ? load_x_piece(p.x, m, n, oy, ox, tap, ci_blk + cp * 8) : zero8();
+        for (int i = tid; i < p.x.W; i += 256) {
+            int ix = i + kx - 1;
+            ix = ix < 0 ? -ix : (ix >= p.x.Wi ? 2 * p.x.Wi - 2 - ix : ix);
+            tx1[i] = ix;
+            tx0[i] = ix >> p.x.up;
         }
-    };
-    auto stash = [&]() {
-#pragma unroll
-        for (int i = 0; i < ZL; ++i) {
-            const int e = tid + 256 * i;
-            const int row = e / ZPR, cp = e - row * ZPR;
-            if (row < 64) *reinterpret_cast<bf16x8*>(sZ + row * PZ + cp * 16) = zr[i];
-        }
-#pragma unroll
-        for (int i = 0; i < XL; ++i) {
-            const int e = tid + 256 * i;
-            const int row = e / XPR, cp = e - row * XPR;
-            if (row < 64) *reinterpret_cast<bf16x8*>(sXm + row * PX + cp * 16) = xr[i];
-        }
-    };
+    }
+    const int hh0 = p.x.Hi >> p.x.up, ww0 = p.x.Wi >> p.x.up;
 
     // transposed-read lane addressing: group g = lane>>4 owns k rows {s*16 + g*4 + q}; lane 4q+pp supplies row q, cols 4pp..4pp+3
     const int g = lane >> 4, t16 = lane & 15, q = t16 >> 2, pp = t16 & 3;
     typedef __bf16 trv4 __attribute__((__vector_size__(4 * sizeof(__bf16))));
     typedef __attribute__((address_space(3))) trv4* lds_b4;
 
-    if (m_begin < m_end) {
-        fetch(m_begin);
-        stash();
-        __syncthreads();
-        for (long m0 = m_begin; m0 < m_end; m0 += 64) {
-            const bool more = m0 + 64 < m_end;
-            if (more) fetch(m0 + 64);
+    for (int it = 0; it <= S; ++it) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's LDS-DMA of stage it-1 has landed ...
+        __syncthreads();                                           // ... and so has everybody else's; buffer it&1 is free again
+        if (it < S) {
+            char* sZ = smem + (it & 1) * STAGE;
+            char* sX = sZ + ZB;
+            const long m0 = m_begin + (long)it * 64;
+#pragma unroll
+            for (int i = 0; i < ZL; ++i) {
+                if (256 * i + 64 * wave < 64 * ZPR) {              // wave-uniform: this 1 KiB run lies inside the tile
+                    const int e = tid + 256 * i;
+                    const int row = e / ZPR, cp = tn_swz<BC>(row, e - row * ZPR);
+                    const long m = m0 + row;
+                    const int co = c_blk + cp * 8;
+                    // dZ rows are zero padded up to ldz (>= Nout rounded up to 8), so a piece that starts below Nout is readable
+                    const bf16* src = (m < m_end && co < p.Nout) ? p.dz + m * p.ldz + co : g_zero_piece;
+                    glds16(src, sZ + (256 * i + 64 * wave) * 16);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < XL; ++i) {
+                if (256 * i + 64 * wave < 64 * XPR) {
+                    const int e = tid + 256 * i;
+                    const int row = e / XPR, cp = tn_swz<BN>(row, e - row * XPR);
+                    const long m = m0 + row;
+                    const int c = ci_blk + cp * 8;
+                    const bf16* src = g_zero_piece;
+                    if (m < m_end && c < Ctot) {
+                        if (p.x.mode == 2) {
+                            if (c < p.x.C0) src = p.x.x0 + c + (long)((pn[i] * hh0 + ty0[py[i]]) * ww0 + tx0[px[i]]) * p.x.ld0;
+                            else src = p.x.x1 + (c - p.x.C0) + (long)((pn[i] * p.x.Hi + ty1[py[i]]) * p.x.Wi + tx1[px[i]]) * p.x.ld1;
+                        } else {
+                            const long off = pixel_off(p.x, m, pn[i], py[i], px[i], tap, 0);
+                            if (off >= 0) src = p.x.x0 + c + off;
+                        }
+                    }
+                    glds16(src, sX + (256 * i + 64 * wave) * 16);
+                    if (p.x.mode) {                                // advance this piece's pixel by 64 rows
+                        px[i] += adv_r;
+                        py[i] += adv_q;
+                        if (px[i] >= p.x.W) { px[i] -= p.x.W; ++py[i]; }
+                        while (py[i] >= p.x.H) { py[i] -= p.x.H; ++pn[i]; }
+                    }
+                }
+            }
+        }
+        if (it > 0) {
+            const char* sZ = smem + ((it - 1) & 1) * STAGE;
+            const char* sX = sZ + ZB;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 bf16x8 a[TC], b[TN];
+                const int rlo = ks * 32 + g * 4 + q, rhi = rlo + 16;
 #pragma unroll
                 for (int i = 0; i < TC; ++i) {
-                    const int col = wc * WC + i * 16 + pp * 4;
-                    const trv4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(sZ + (ks * 32 + g * 4 + q) * PZ + col * 2));
-                    const trv4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(sZ + (ks * 32 + 16 + g * 4 + q) * PZ + col * 2));
+                    const int piece = (wc * WC + i * 16) / 8 + (pp >> 1);
+                    const trv4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(sZ + rlo * (BC * 2) + tn_swz<BC>(rlo, piece) * 16 + (pp & 1) * 8));
+                    const trv4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(sZ + rhi * (BC * 2) + tn_swz<BC>(rhi, piece) * 16 + (pp & 1) * 8));
                     a[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    const int col = wn * WN + j * 16 + pp * 4;
-                    const trv4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(sXm + (ks * 32 + g * 4 + q) * PX + col * 2));
-                    const trv4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(sXm + (ks * 32 + 16 + g * 4 + q) * PX + col * 2));
+                    const int piece = (wn * WN + j * 16) / 8 + (pp >> 1);
+                    const trv4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(sX + rlo * (BN * 2) + tn_swz<BN>(rlo, piece) * 16 + (pp & 1) * 8));
+                    const trv4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(sX + rhi * (BN * 2) + tn_swz<BN>(rhi, piece) * 16 + (pp & 1) * 8));
                     b[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
 #pragma unroll
@@ -319,15 +451,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN p) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
             }
-            __syncthreads();
-            if (more) {
-                stash();
-                __syncthreads();
-            }
         }
     }
     const int Ktot = p.taps * p.KP;
-    float* part = p.part + (long)blockIdx.z * p.Nout * Ktot;
+    float* part = p.part + (long)bz * p.Nout * Ktot;
 #pragma unroll
     for (int i = 0; i < TC; ++i)
 #pragma unroll
@@ -411,8 +538,8 @@ static XSrc make_xsrc(const void* x0, const void* x1, int mode, int n_img, int H
 
 template <int BC, int BP, int WGC, int WGP>
 static int launch_nt(const GemmNT& p, int out_f32, hipStream_t st) {
-    dim3 grid(cdiv(p.x.M, BP), cdiv(p.Nout, BC));
-    const size_t lds = (size_t)(BC + BP) * 128;
+    dim3 grid(cdiv(p.x.M, BP) * cdiv(p.Nout, BC));
+    const size_t lds = (size_t)(BC + BP) * 128 * 2;
     if (out_f32) hipLaunchKernelGGL((gemm_nt_kernel<BC, BP, WGC, WGP, true>), grid, dim3(256), lds, st, p);
     else hipLaunchKernelGGL((gemm_nt_kernel<BC, BP, WGC, WGP, false>), grid, dim3(256), lds, st, p);
     HN_LAUNCH_CHECK();
@@ -460,8 +587,11 @@ extern "C" int hn_conv_gemm_nt(const void* x0, const void* x1, int mode, int n_i
 
 template <int BC, int BN, int WGC, int WGN>
 static int launch_tn(const GemmTN& p, int splits, hipStream_t st) {
-    dim3 grid(cdiv(p.KP, BN) * p.taps, cdiv(p.Nout, BC), splits);
-    hipLaunchKernelGGL((gemm_tn_kernel<BC, BN, WGC, WGN>), grid, dim3(256), 0, st, p);
+    GemmTN q = p;
+    q.gy = cdiv(p.Nout, BC);
+    dim3 grid(cdiv(p.KP, BN) * p.taps * q.gy * splits);
+    const size_t tables = p.x.mode >= 2 ? (size_t)(2 * p.x.H + 2 * p.x.W) * 4 : 0;
+    hipLaunchKernelGGL((gemm_tn_kernel<BC, BN, WGC, WGN>), grid, dim3(256), (size_t)64 * (BC + BN) * 2 * 2 + tables, st, q);
     HN_LAUNCH_CHECK();
 }
 

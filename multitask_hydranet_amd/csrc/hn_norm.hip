@@ -174,25 +174,30 @@ struct BnAct {
     const bf16* res; int ldr; const float* rscale; const float* rshift;   // optional residual (+ its own BN)
     int act; bf16* out; int ldo; long M; int C;
 };
+// thread = one 8-channel group; its per-channel coefficients stay in registers while it walks rows (256 / C8 rows per block pass)
 __global__ __launch_bounds__(256) void bn_act_kernel(const BnAct p) {
     const int C8 = p.C >> 3;
-    const long total = p.M * C8;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const long m = idx / C8;
-        const int c = (int)(idx - m * C8) * 8;
+    const int rpb = 256 / C8 > 0 ? 256 / C8 : 1;
+    const int cg = threadIdx.x % C8, rr = threadIdx.x / C8;
+    if (rr >= rpb) return;
+    const int c = cg * 8;
+    float sc[8], sh[8], rsc[8], rsh[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        sc[k] = p.scale ? p.scale[c + k] : 1.f;
+        sh[k] = p.scale ? p.shift[c + k] : 0.f;
+        rsc[k] = p.rscale ? p.rscale[c + k] : 1.f;
+        rsh[k] = p.rscale ? p.rshift[c + k] : 0.f;
+    }
+    for (long m = (long)blockIdx.x * rpb + rr; m < p.M; m += (long)gridDim.x * rpb) {
         const bf16x8 vz = ld8(p.z + m * p.ldz + c);
         bf16x8 vr;
         if (p.res) vr = ld8(p.res + m * p.ldr + c);
         bf16x8 o;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            float v = bf2f(vz[k]);
-            if (p.scale) v = v * p.scale[c + k] + p.shift[c + k];
-            if (p.res) {
-                float r = bf2f(vr[k]);
-                if (p.rscale) r = r * p.rscale[c + k] + p.rshift[c + k];
-                v += r;
-            }
+            float v = bf2f(vz[k]) * sc[k] + sh[k];
+            if (p.res) v += bf2f(vr[k]) * rsc[k] + rsh[k];
             o[k] = f2bf(act_fwd(v, p.act));
         }
         st8(p.out + m * p.ldo + c, o);
@@ -207,10 +212,17 @@ struct BnBwdApply {
 // dz = scale * (g - mean(g) - xhat * mean(g*xhat)),  g = dout * act'(pre)   (optionally also emits g)
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApply p) {
     const int C8 = p.C >> 3;
-    const long total = p.M * C8;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const long m = idx / C8;
-        const int c = (int)(idx - m * C8) * 8;
+    const int rpb = 256 / C8 > 0 ? 256 / C8 : 1;
+    const int cg = threadIdx.x % C8, rr = threadIdx.x / C8;
+    if (rr >= rpb) return;
+    const int c = cg * 8;
+    float sc[8], sh[8], mu[8], rs[8], mg[8], mgx[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        sc[k] = p.scale[c + k]; sh[k] = p.shift[c + k]; mu[k] = p.mean[c + k]; rs[k] = p.rstd[c + k];
+        mg[k] = p.mg[c + k]; mgx[k] = p.mgx[c + k];
+    }
+    for (long m = (long)blockIdx.x * rpb + rr; m < p.M; m += (long)gridDim.x * rpb) {
         const bf16x8 vd = ld8(p.dout + m * p.ldd + c);
         const bf16x8 vz = ld8(p.z + m * p.ldz + c);
         bf16x8 vy;
@@ -221,9 +233,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApply p) {
             const float z = bf2f(vz[k]);
             float g = bf2f(vd[k]);
             if (p.y) g = bf2f(vy[k]) > 0.f ? g : 0.f;
-            else g *= act_bwd(p.scale[c + k] * z + p.shift[c + k], p.act);
-            const float xh = (z - p.mean[c + k]) * p.rstd[c + k];
-            o[k] = f2bf(p.scale[c + k] * (g - p.mg[c + k] - xh * p.mgx[c + k]));
+            else g *= act_bwd(sc[k] * z + sh[k], p.act);
+            const float xh = (z - mu[k]) * rs[k];
+            o[k] = f2bf(sc[k] * (g - mg[k] - xh * mgx[k]));
             og[k] = f2bf(g);
         }
         st8(p.dz + m * p.lddz + c, o);
@@ -345,6 +357,15 @@ static inline int ew_grid(long pieces) {
     return (int)b;
 }
 
+// grid for the row-walking elementwise kernels: 256/C8 rows per block pass, capped at ~16 blocks per CU
+static inline int row_grid(long M, int C) {
+    const int C8 = C >> 3;
+    const int rpb = 256 / C8 > 0 ? 256 / C8 : 1;
+    long b = (M + rpb - 1) / rpb;
+    if (b > 4096) b = 4096;
+    return (int)(b < 1 ? 1 : b);
+}
+
 // rows per block for a column reduction over M rows (~1024 partial rows; a multiple of `align` if given)
 extern "C" long hn_colred_rows(long M, long align) {
     long R = (M + 1023) / 1024;
@@ -404,8 +425,9 @@ extern "C" int hn_bn_eval_coeff(const float* gamma, const float* beta, const flo
 extern "C" int hn_bn_act(const void* z, int ldz, const float* scale, const float* shift, const void* res, int ldr,
                          const float* rscale, const float* rshift, int act, void* out, int ldo, long M, int C, hipStream_t st) {
     HN_CHECK_ARG(z && out && M > 0 && (C & 7) == 0 && (ldz & 7) == 0 && (ldo & 7) == 0 && (!res || (ldr & 7) == 0));
+    HN_CHECK_ARG(C <= 2048);
     BnAct p = {(const bf16*)z, ldz, scale, shift, (const bf16*)res, ldr, rscale, rshift, act, (bf16*)out, ldo, M, C};
-    hipLaunchKernelGGL(bn_act_kernel, dim3(ew_grid(M * (C >> 3))), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(bn_act_kernel, dim3(row_grid(M, C)), dim3(256), 0, st, p);
     HN_LAUNCH_CHECK();
 }
 
@@ -433,7 +455,8 @@ extern "C" int hn_bn_bwd_apply(const void* dout, int ldd, const void* z, int ldz
                  (!gout || (ldg & 7) == 0));
     BnBwdApply p = {(const bf16*)dout, ldd, (const bf16*)z, ldz, (const bf16*)y, ldy, scale, shift, mean, rstd, mg, mgx, act,
                     (bf16*)dz, lddz, (bf16*)gout, ldg, M, C};
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(M * (C >> 3))), dim3(256), 0, st, p);
+    HN_CHECK_ARG(C <= 2048 && scale && shift && mean && rstd && mg && mgx);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(row_grid(M, C)), dim3(256), 0, st, p);
     HN_LAUNCH_CHECK();
 }
 

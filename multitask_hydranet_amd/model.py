@@ -116,6 +116,7 @@ class HydraNet(nn.Module):
         self.check_finite = True                           # the reference exit()s on a zero / non-finite loss (model.py:212-258)
         self.lane_points_per_line = 160                    # cal_loss_regress default that model.py:246 never overrides
         self._anchor_cache = {}
+        self._pending_nbt = []
 
         spec = _Spec(self)
         self._declare_backbone(spec)
@@ -240,16 +241,19 @@ class HydraNet(nn.Module):
     # ------------------------------------------------------------------------------------------------------
     def _bind_callables(self):
         me = weakref.ref(self)
-        object.__setattr__(self.backbone, "_fwd", lambda x: [K_to_nchw(t) for t in me()._backbone(x)])
-        object.__setattr__(self.neck, "_fwd", lambda feats: tuple(K_to_nchw(t) for t in me()._neck([K_to_nhwc(t) for t in feats])))
+        def flushed(v):
+            me()._flush_nbt()
+            return v
+        object.__setattr__(self.backbone, "_fwd", lambda x: flushed([K_to_nchw(t) for t in me()._backbone(x)]))
+        object.__setattr__(self.neck, "_fwd", lambda feats: flushed(tuple(K_to_nchw(t) for t in me()._neck([K_to_nhwc(t) for t in feats]))))
         if self.train_seg:
             object.__setattr__(self.segheader, "_fwd", lambda feats: me()._seg([K_to_nhwc(t) for t in feats]))
             self.segheader.decode = _unavailable("segheader.decode (cv2 visualisation)")
         if self.train_detect:
-            object.__setattr__(self.detectheader, "_fwd", lambda x, fused: me()._det(x, [K_to_nhwc(t) for t in fused]))
+            object.__setattr__(self.detectheader, "_fwd", lambda x, fused: flushed(me()._det(x, [K_to_nhwc(t) for t in fused])))
             self.detectheader.decode = _det_decode
         if self.train_lane:
-            object.__setattr__(self.laneheader, "_fwd", lambda fused: me()._lane([K_to_nhwc(t) for t in fused]))
+            object.__setattr__(self.laneheader, "_fwd", lambda fused: flushed(me()._lane([K_to_nhwc(t) for t in fused])))
 
     def _reindex(self):
         self._idx = {k: v for k, v in itertools.chain(self.named_parameters(), self.named_buffers()) if not k.startswith("_")}
@@ -262,8 +266,14 @@ class HydraNet(nn.Module):
 
     def _bn(self, name):
         P = self._idx
-        return (P[name + ".weight"], P[name + ".bias"], P[name + ".running_mean"], P[name + ".running_var"],
-                P[name + ".num_batches_tracked"])
+        if self.training:                                   # counters are bumped once per forward with ONE multi-tensor add
+            self._pending_nbt.append(P[name + ".num_batches_tracked"])
+        return (P[name + ".weight"], P[name + ".bias"], P[name + ".running_mean"], P[name + ".running_var"], None)
+
+    def _flush_nbt(self):
+        if self._pending_nbt:
+            torch._foreach_add_(self._pending_nbt, 1)
+            self._pending_nbt = []
 
     # ------------------------------------------------------------------------------------------------------
     # forward pieces (NHWC bf16 inside)
@@ -432,6 +442,7 @@ class HydraNet(nn.Module):
             lane = self._lane(fused)
             out["lane"] = lane
             lane_cls, lane_reg = lane["predict_cls"], lane["predict_loc"]
+        self._flush_nbt()
         if mode != "deploy":
             return out
         return torch.argmax(seg, dim=1), anchors, reg, cls, lane_cls, lane_reg

@@ -261,6 +261,7 @@ def test_end_to_end_losses_features_and_statistics(env):
     gb = {k: v.to("cuda:0") for k, v in batch.items()}
     feats = net._backbone(gb["image"])
     fused = net._neck(feats)
+    net._flush_nbt()
     net.load_state_dict(sd)
     out = net(gb["image"])
     ld = net.cal_loss(out, gb)
