@@ -87,6 +87,9 @@ int hn_sum2x2(const void* g, int ldg, void* out, int ldo, const float* wscale, i
 
 /* BiFPN fusion node out = swish(sum_i w[i]*T_i(in_i)) (net/bifpn.py:177-231); mode[i]: 0 absent, 1 same res, 2 nearest x2 of a
  * half-res map, 3 zero-pad-same max-pool of a double-res map.  w: 3 fp32 in device memory. */
+/* w = relu(p)/(sum relu(p)+eps) into wn[3] (net/bifpn.py:179-180), and its backward from the per-block partials of hn_fuse_bwd */
+int hn_fuse_weights(const float* praw, int nw, float eps, float* wn, hipStream_t stream);
+int hn_fuse_dweights(const float* pw, int blocks, const float* praw, int nw, float eps, float* dp, hipStream_t stream);
 int hn_fuse_fwd(const void* const* in, const int* ld, const int* mode, const float* w, void* out, int ldo, int N, int H, int W, int C,
                 hipStream_t stream);
 int hn_fuse_bwd_blocks(int N, int H, int W, int C);
@@ -131,6 +134,14 @@ int hn_bn_bwd_apply(const void* dout, int ldd, const void* z, int ldz, const voi
 int hn_scale_rows(const void* x, int ldx, const float* gate, long HW, void* out, int ldo, long M, int C, hipStream_t stream);
 int hn_se_bwd_apply(const void* dout, int ldd, const float* gate, const float* dpool, long HW, void* db, int ldb, long M, int C,
                     hipStream_t stream);
+
+/* SE excitation MLP on the pooled [N,C] vectors: hid = relu(W1 p + b1) [N,Cs], gate = sigmoid(W2 hid + b2) [N,C]; backward gives dpool and
+ * the four parameter gradients (dpre2 [N,C], dpre1 [N,Cs] are scratch).  Replaces the two 1x1 nn.Conv2d of net/anynet.py:44-47. */
+int hn_se_mlp_fwd(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2, float* hid, float* gate, int N,
+                  int C, int Cs, hipStream_t stream);
+int hn_se_mlp_bwd(const float* dgate, const float* gate, const float* hid, const float* pooled, const float* w1, const float* w2,
+                  float* dpre2, float* dpre1, float* dpool, float* dw1, float* db1, float* dw2, float* db2, int N, int C, int Cs,
+                  hipStream_t stream);
 
 /* op 0: a+b, 1: a*act'(b = post-activation; ELU/ReLU), 2: alpha*a, 3: act(a), 4: a*act'(b = pre-activation) */
 int hn_eltwise(int op, const void* a, int lda, const void* b, int ldb, void* out, int ldo, long M, int C, int act, float alpha,

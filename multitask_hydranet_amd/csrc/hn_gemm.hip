@@ -147,13 +147,67 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
 #pragma unroll
     for (int i = 0; i < XR; ++i) decomp_row(p.x, p_blk + r0 + 32 * i, xn[i], xy[i], xx[i]);
 
+    // 3x3 modes: the source coordinates of a tap are separable in (oy, ky) and (ox, kx), so they are tabulated once per block in LDS:
+    //   ty0[ky][oy], tx0[kx][ox] in x0's grid (reflected, >> up for mode 2; -1 = outside for mode 3); ty1/tx1 in x1's full-res grid
+    int* ty0 = reinterpret_cast<int*>(smem + 2 * STAGE);
+    int* tx0 = ty0 + 3 * p.x.H;
+    int* ty1 = tx0 + 3 * p.x.W;
+    int* tx1 = ty1 + 3 * p.x.H;
+    if (p.x.mode >= 2) {
+        for (int i = tid; i < 3 * p.x.H; i += 256) {
+            const int k = i / p.x.H, o = i - k * p.x.H;
+            if (p.x.mode == 2) {
+                int v = o + k - 1;
+                v = v < 0 ? -v : (v >= p.x.Hi ? 2 * p.x.Hi - 2 - v : v);
+                ty0[i] = v >> p.x.up;
+                if (p.x.C1) ty1[i] = v;
+            } else {
+                const int v = o - k;
+                ty0[i] = (v < 0 || v >= p.x.Hi) ? -1 : v;
+            }
+        }
+        for (int i = tid; i < 3 * p.x.W; i += 256) {
+            const int k = i / p.x.W, o = i - k * p.x.W;
+            if (p.x.mode == 2) {
+                int v = o + k - 1;
+                v = v < 0 ? -v : (v >= p.x.Wi ? 2 * p.x.Wi - 2 - v : v);
+                tx0[i] = v >> p.x.up;
+                if (p.x.C1) tx1[i] = v;
+            } else {
+                const int v = o - k;
+                tx0[i] = (v < 0 || v >= p.x.Wi) ? -1 : v;
+            }
+        }
+        __syncthreads();
+    }
+    const int hh0 = p.x.mode == 2 ? p.x.Hi >> p.x.up : p.x.Hi, ww0 = p.x.mode == 2 ? p.x.Wi >> p.x.up : p.x.Wi;
+
     int tap = half / kc, cidx = half - tap * kc;   // chunk q = 2*stage + half -> (tap, cidx)
     const int Ctot = p.x.C0 + p.x.C1;
-    long xo0[XR], xo1[XR];                         // per-row source offsets for the current tap (-1 = zeros)
+    int pix0[XR], pix1[XR];                        // per-row source PIXEL index for the current tap (-1 = zeros); pixels fit int32
+    auto retap = [&]() {
+        const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
 #pragma unroll
-    for (int i = 0; i < XR; ++i) {
-        xo0[i] = pixel_off(p.x, p_blk + r0 + 32 * i, xn[i], xy[i], xx[i], tap, 0);
-        xo1[i] = pixel_off(p.x, p_blk + r0 + 32 * i, xn[i], xy[i], xx[i], tap, 1);
+        for (int i = 0; i < XR; ++i) {
+            const long m = p_blk + r0 + 32 * i;
+            int a0 = -1, a1 = -1;
+            if (m < p.x.M) {
+                if (p.x.mode == 0) a0 = (int)m;
+                else if (p.x.mode == 1) a0 = (xn[i] * p.x.Hi + 2 * xy[i]) * p.x.Wi + 2 * xx[i];
+                else {
+                    const int y0 = ty0[ky * p.x.H + xy[i]], x0c = tx0[kx * p.x.W + xx[i]];
+                    if ((y0 | x0c) >= 0) a0 = (xn[i] * hh0 + y0) * ww0 + x0c;
+                    if (p.x.C1) a1 = (xn[i] * p.x.Hi + ty1[ky * p.x.H + xy[i]]) * p.x.Wi + tx1[kx * p.x.W + xx[i]];
+                }
+            }
+            pix0[i] = a0;
+            pix1[i] = a1;
+        }
+    };
+    if (tap < p.taps) retap();
+    else {
+#pragma unroll
+        for (int i = 0; i < XR; ++i) { pix0[i] = -1; pix1[i] = -1; }
     }
     long wo[WR];                                   // weight row offset + this thread's in-chunk offset (-1 = zero row)
 #pragma unroll
@@ -183,10 +237,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
             const bool from0 = c < p.x.C0;
             const bool cv = qv && c < Ctot;
             const bf16* xbase = from0 ? p.x.x0 + c : p.x.x1 + (c - p.x.C0);
+            const long ldx = from0 ? p.x.ld0 : p.x.ld1;
 #pragma unroll
             for (int i = 0; i < XR; ++i) {
-                const long off = from0 ? xo0[i] : xo1[i];
-                const bf16* src = (cv && off >= 0) ? xbase + off : g_zero_piece;
+                const int pix = from0 ? pix0[i] : pix1[i];
+                const bf16* src = (cv && pix >= 0) ? xbase + (long)pix * ldx : g_zero_piece;
                 glds16(src, sX + (wave * 8 + 32 * i) * 128);
             }
 #pragma unroll
@@ -199,13 +254,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
             cidx += 2;
             if (cidx >= kc) {
                 while (cidx >= kc) { cidx -= kc; ++tap; }
-                if (tap < p.taps) {
-#pragma unroll
-                    for (int i = 0; i < XR; ++i) {
-                        xo0[i] = pixel_off(p.x, p_blk + r0 + 32 * i, xn[i], xy[i], xx[i], tap, 0);
-                        xo1[i] = pixel_off(p.x, p_blk + r0 + 32 * i, xn[i], xy[i], xx[i], tap, 1);
-                    }
-                }
+                if (tap < p.taps) retap();
             }
         }
         if (it > 0) {
@@ -290,6 +339,178 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
                         p.psum[prow * p.Nout + co0 + r] = s1[r];
                         p.psq[prow * p.Nout + co0 + r] = s2[r];
                     }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Direct 3x3 convolution (im2col-free): one workgroup = a 16x16 output-pixel patch x BC couts.  Per 64-channel chunk the 18x18 input
+// patch (with halo; reflection / nearest-up / concat or zero padding resolved while loading) is DMA'd into LDS ONCE and reused by all
+// nine taps; only the [BC][64] weight slice of a tap is streamed per stage.  L2 traffic per FLOP is ~3x lower than the row-gather
+// GEMM above (which re-reads the pixel rows for every tap), which is what bounds that kernel on MI355X.
+//   mode 2: out(y,x) = sum_tap V(refl(y+ky-1), refl(x+kx-1)) W[tap]        (forward of the seg decoder convs)
+//   mode 3: out(y,x) = sum_tap Z0(y-ky, x-kx) W[tap], Z0 zero outside       (their dgrad on the padded (H+2)x(W+2) grid)
+// 512 threads = 8 waves: WGC = BC/64 cout groups x (8/WGC) pixel-row groups; wave tile = 64 couts x (16/WGP rows x 16 px).
+// ---------------------------------------------------------------------------------------------------------
+template <int BC, bool OUT_F32>
+__global__ __launch_bounds__(512) void conv3x3_direct_kernel(const GemmNT p) {
+    constexpr int WGC = BC / 64, WGP = 8 / WGC, ROWS = 16 / WGP;      // rows of the patch per wave
+    constexpr int TC = 4, TP = ROWS;
+    constexpr int PPIX = 18 * 18, XBYTES = (PPIX * 128 + 1023) / 1024 * 1024, WBYTES = BC * 128;   // X buffer padded to whole 1 KiB DMA runs
+    constexpr int XL = (PPIX * 8 + 511) / 512, WL = BC * 8 / 512;
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // X patch x2 | W tile x2
+    char* sXb = smem;
+    char* sWb = smem + 2 * XBYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wc = wave / WGP, wp = wave % WGP;
+    const XSrc& xs = p.x;
+    const int ncy = (p.Nout + BC - 1) / BC;
+    const int tx_n = (xs.W + 15) >> 4, ty_n = (xs.H + 15) >> 4;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int c_tile = lid % ncy;
+    int t = lid / ncy;
+    const int tx = t % tx_n;
+    t /= tx_n;
+    const int ty = t % ty_n;
+    const int n = t / ty_n;
+    const int c_blk = c_tile * BC, oy0 = ty * 16, ox0 = tx * 16;
+    const int org = xs.mode == 2 ? -1 : -2;                           // patch origin relative to the output tile
+    const int Ctot = xs.C0 + xs.C1;
+    const int nchunk = (p.KP + 63) >> 6, S = nchunk * 9;
+    const int Ktot = 9 * p.KP;
+
+    // patch pieces owned by this thread: e = tid + 512 i -> patch pixel e>>3, PHYSICAL piece e&7 (logical = physical ^ (pixel&7))
+    int spix0[XL], spix1[XL];
+    int ssub[XL];
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+        const int e = tid + 512 * i;
+        const int pp = e >> 3;
+        ssub[i] = (((e & 7) ^ (pp & 7)) << 3);
+        spix0[i] = -1;
+        spix1[i] = -1;
+        if (pp < PPIX) {
+            const int py = pp / 18, px = pp - py * 18;
+            int gy = oy0 + org + py, gx = ox0 + org + px;
+            if (xs.mode == 2) {
+                gy = gy < 0 ? -gy : gy;
+                gx = gx < 0 ? -gx : gx;
+                gy = gy >= xs.Hi ? 2 * xs.Hi - 2 - gy : gy;
+                gx = gx >= xs.Wi ? 2 * xs.Wi - 2 - gx : gx;
+                if (gy >= 0 && gx >= 0) {                             // (negative only for pixels that feed no in-image output)
+                    spix0[i] = (n * (xs.Hi >> xs.up) + (gy >> xs.up)) * (xs.Wi >> xs.up) + (gx >> xs.up);
+                    if (xs.C1) spix1[i] = (n * xs.Hi + gy) * xs.Wi + gx;
+                }
+            } else if (gy >= 0 && gy < xs.Hi && gx >= 0 && gx < xs.Wi) {
+                spix0[i] = (n * xs.Hi + gy) * xs.Wi + gx;
+            }
+        }
+    }
+    // weight pieces: row = (tid>>3) + 64 i, physical piece tid&7
+    const int wsub = (((tid & 7) ^ ((tid >> 3) & 7)) << 3);
+    long wrow[WL];
+#pragma unroll
+    for (int i = 0; i < WL; ++i) {
+        const int co = c_blk + (tid >> 3) + 64 * i;
+        wrow[i] = co < p.Nout ? (long)co * Ktot + wsub : -1;
+    }
+
+    f32x4 acc[TC][TP];
+#pragma unroll
+    for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int j = 0; j < TP; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // stage st = chunk * 9 + tap.  Iteration `it` issues the DMA of stage `it` (+ the X patch of its chunk when tap == 0) and multiplies
+    // stage `it - 1`.
+    for (int it = 0; it <= S; ++it) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (it < S) {
+            const int chunk = it / 9, tap = it - chunk * 9;
+            const int k0 = chunk * 64;
+            char* sW = sWb + (it & 1) * WBYTES;
+#pragma unroll
+            for (int i = 0; i < WL; ++i) {
+                const bf16* src = (wrow[i] >= 0 && k0 + wsub < p.KP) ? p.w + wrow[i] + tap * p.KP + k0 : g_zero_piece;
+                glds16(src, sW + (wave * 8 + 64 * i) * 128);
+            }
+            if (tap == 0) {
+                char* sX = sXb + (chunk & 1) * XBYTES;
+#pragma unroll
+                for (int i = 0; i < XL; ++i) {
+                    if (512 * i + 64 * wave < PPIX * 8) {             // wave-uniform: this 1 KiB run starts inside the patch
+                        const int c = k0 + ssub[i];
+                        const bf16* src = g_zero_piece;
+                        if (c < Ctot) {
+                            if (c < xs.C0) { if (spix0[i] >= 0) src = xs.x0 + c + (long)spix0[i] * xs.ld0; }
+                            else if (spix1[i] >= 0) src = xs.x1 + (c - xs.C0) + (long)spix1[i] * xs.ld1;
+                        }
+                        glds16(src, sX + (512 * i + 64 * wave) * 16);
+                    }
+                }
+            }
+        }
+        if (it > 0) {
+            const int st = it - 1;
+            const int chunk = st / 9, tap = st - chunk * 9;
+            const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+            const int dy = xs.mode == 2 ? ky : 2 - ky, dx = xs.mode == 2 ? kx : 2 - kx;
+            const char* sW = sWb + (st & 1) * WBYTES;
+            const char* sX = sXb + (chunk & 1) * XBYTES;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 a[TC], b[TP];
+                const int piece = ks * 4 + (lane >> 4);
+#pragma unroll
+                for (int i = 0; i < TC; ++i) a[i] = *reinterpret_cast<const bf16x8*>(sW + swz(wc * 64 + i * 16 + (lane & 15), piece));
+#pragma unroll
+                for (int j = 0; j < TP; ++j) {
+                    const int pidx = (wp * ROWS + j + dy) * 18 + (lane & 15) + dx;
+                    b[j] = *reinterpret_cast<const bf16x8*>(sX + pidx * 128 + ((piece ^ (pidx & 7)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < TC; ++i)
+#pragma unroll
+                    for (int j = 0; j < TP; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+
+    // epilogue: bias, activation, store 4 consecutive couts per lane
+    const int ox = ox0 + (lane & 15);
+#pragma unroll
+    for (int i = 0; i < TC; ++i) {
+        const int co0 = c_blk + wc * 64 + i * 16 + (lane >> 4) * 4;
+        float bsv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bsv[r] = (p.bias && co0 + r < p.Nout) ? p.bias[co0 + r] : 0.f;
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            const int oy = oy0 + wp * ROWS + j;
+            if (oy >= xs.H || ox >= xs.W) continue;
+            const long orow = ((long)(n * xs.H + oy) * xs.W + ox) * p.ldc;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = act_fwd(acc[i][j][r] + bsv[r], p.act);
+            if (OUT_F32) {
+                float* o = reinterpret_cast<float*>(p.out) + orow + co0;
+                if (co0 + 3 < p.Nout && (reinterpret_cast<uintptr_t>(o) & 15) == 0) *reinterpret_cast<f32x4*>(o) = (f32x4){v[0], v[1], v[2], v[3]};
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (co0 + r < p.Nout) o[r] = v[r];
+                }
+            } else {
+                bf16* o = reinterpret_cast<bf16*>(p.out) + orow + co0;
+                if (co0 + 3 < p.Nout && (reinterpret_cast<uintptr_t>(o) & 7) == 0) {
+                    bf16x4 tv = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                    *reinterpret_cast<bf16x4*>(o) = tv;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (co0 + r < p.Nout) o[r] = f2bf(v[r]);
+                }
             }
         }
     }
@@ -539,7 +760,8 @@ static XSrc make_xsrc(const void* x0, const void* x1, int mode, int n_img, int H
 template <int BC, int BP, int WGC, int WGP>
 static int launch_nt(const GemmNT& p, int out_f32, hipStream_t st) {
     dim3 grid(cdiv(p.x.M, BP) * cdiv(p.Nout, BC));
-    const size_t lds = (size_t)(BC + BP) * 128 * 2;
+    const size_t tables = p.x.mode >= 2 ? (size_t)(3 * p.x.H + 3 * p.x.W) * 4 * (p.x.C1 ? 2 : 1) : 0;
+    const size_t lds = (size_t)(BC + BP) * 128 * 2 + tables;
     if (out_f32) hipLaunchKernelGGL((gemm_nt_kernel<BC, BP, WGC, WGP, true>), grid, dim3(256), lds, st, p);
     else hipLaunchKernelGGL((gemm_nt_kernel<BC, BP, WGC, WGP, false>), grid, dim3(256), lds, st, p);
     HN_LAUNCH_CHECK();
@@ -558,7 +780,7 @@ static int pick_bc(int Nout) {
 
 extern "C" int hn_nt_stat_rows(long M, int Nout) {
     const int bc = pick_bc(Nout);
-    if (bc == 16) return cdiv(M, 256) * 4;
+    if (bc == 16) return cdiv(M, 128) * 4;
     if (bc == 32) return cdiv(M, 128) * 4;
     return cdiv(M, 128) * 2;
 }
@@ -577,8 +799,30 @@ extern "C" int hn_conv_gemm_nt(const void* x0, const void* x1, int mode, int n_i
     p.w = (const bf16*)w; p.Nout = Nout; p.KP = KP; p.taps = taps;
     p.bias = bias; p.act = act; p.out = out; p.ldc = ldc; p.psum = psum; p.psq = psq;
     p.rpi = rpi; p.img_stride = img_stride;
+    if (mode >= 2 && Nout > 32 && !psum && !rpi) {
+        const int bc = Nout <= 64 ? 64 : 128;
+        dim3 grid((unsigned)(cdiv(Nout, bc) * cdiv(W, 16) * cdiv(H, 16) * n_img));
+        const size_t lds = 2 * (size_t)((18 * 18 * 128 + 1023) / 1024 * 1024) + 2 * (size_t)bc * 128;
+        // > 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel (done on the first, un-captured call)
+        static bool optin = false;
+        if (!optin) {
+            hipFuncSetAttribute((const void*)conv3x3_direct_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute((const void*)conv3x3_direct_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute((const void*)conv3x3_direct_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute((const void*)conv3x3_direct_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            optin = true;
+        }
+        if (bc == 64) {
+            if (out_f32) hipLaunchKernelGGL((conv3x3_direct_kernel<64, true>), grid, dim3(512), lds, st, p);
+            else hipLaunchKernelGGL((conv3x3_direct_kernel<64, false>), grid, dim3(512), lds, st, p);
+        } else {
+            if (out_f32) hipLaunchKernelGGL((conv3x3_direct_kernel<128, true>), grid, dim3(512), lds, st, p);
+            else hipLaunchKernelGGL((conv3x3_direct_kernel<128, false>), grid, dim3(512), lds, st, p);
+        }
+        HN_LAUNCH_CHECK();
+    }
     switch (pick_bc(Nout)) {
-        case 16: return launch_nt<16, 256, 1, 4>(p, out_f32, st);
+        case 16: return launch_nt<16, 128, 1, 4>(p, out_f32, st);
         case 32: return launch_nt<32, 128, 1, 4>(p, out_f32, st);
         case 64: return launch_nt<64, 128, 2, 2>(p, out_f32, st);
         default: return launch_nt<128, 128, 2, 2>(p, out_f32, st);

@@ -348,6 +348,85 @@ __global__ void cast_f32_kernel(const bf16* src, int lds_, float* dst, int ldo, 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// SE excitation MLP on the pooled vectors (net/anynet.py:42-47): hid = relu(W1 p + b1), gate = sigmoid(W2 hid + b2).
+// One block per image; forward keeps hid and gate for the backward pass.
+// ---------------------------------------------------------------------------------------------------------
+// out[n][o] = act(bias[o] + sum_i W[o][i] * in[n][i]) : one wave per (n, o), lanes stride the contraction (coalesced weight rows)
+__global__ __launch_bounds__(256) void se_fc_rows_kernel(const float* W, const float* bias, const float* in, float* out, int N, int O, int I,
+                                                         int act) {
+    const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (wid >= (long)N * O) return;
+    const int n = (int)(wid / O), o = (int)(wid - (long)n * O);
+    const float* wr = W + (long)o * I;
+    const float* xr = in + (long)n * I;
+    float s = 0.f;
+    for (int i = lane; i < I; i += 64) s += wr[i] * xr[i];
+    s = wave_sum(s);
+    if (lane == 0) {
+        s += bias[o];
+        out[wid] = act == HN_ACT_RELU ? (s > 0.f ? s : 0.f) : 1.f / (1.f + __expf(-s));
+    }
+}
+
+// out[n][o] = mask(o) * sum_i W[i][o] * f(in)[n][i]   (contraction over the ROW index of W: coalesced over o).
+// block = 64 outputs x 4 partitions of i.  pre: 0 = in as is, 1 = in * g * (1 - g) with g = aux[n][i] (sigmoid', result also stored to
+// `store`).  post: 0 none, 1 = zero where aux2[n][o] <= 0 (ReLU').
+__global__ __launch_bounds__(256) void se_fc_cols_kernel(const float* W, const float* in, const float* aux, float* store, const float* aux2,
+                                                         float* out, int N, int O, int I, int pre, int post) {
+    __shared__ float red[4][64];
+    const int ox = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int o = blockIdx.x * 64 + ox, n = blockIdx.y;
+    float s = 0.f;
+    const int i0 = (int)((long)I * part / 4), i1 = (int)((long)I * (part + 1) / 4);
+    for (int i = i0; i < i1; ++i) {
+        float v = in[(long)n * I + i];
+        if (pre) {
+            const float g = aux[(long)n * I + i];
+            v *= g * (1.f - g);
+            if (store && blockIdx.x == 0 && ox == 0) store[(long)n * I + i] = v;
+        }
+        if (o < O) s += W[(long)i * O + o] * v;
+    }
+    red[part][ox] = s;
+    __syncthreads();
+    if (part == 0 && o < O) {
+        float t = red[0][ox] + red[1][ox] + red[2][ox] + red[3][ox];
+        if (post && aux2[(long)n * O + o] <= 0.f) t = 0.f;
+        out[(long)n * O + o] = t;
+    }
+}
+
+// parameter gradients (sum over the N images): dW2[c][j] = sum dpre2[n][c] hid[n][j]; db2 = sum dpre2; dW1[j][c] = sum dpre1[n][j] pooled[n][c]
+__global__ void se_mlp_wgrad_kernel(const float* dpre2, const float* dpre1, const float* hid, const float* pooled, float* dw1, float* db1,
+                                    float* dw2, float* db2, int N, int C, int Cs) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n2 = (long)C * Cs;
+    if (idx < n2) {
+        const int c = (int)(idx / Cs), j = (int)(idx - (long)c * Cs);
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s += dpre2[(long)n * C + c] * hid[(long)n * Cs + j];
+        dw2[idx] = s;
+    } else if (idx < 2 * n2) {
+        const long k = idx - n2;
+        const int j = (int)(k / C), c = (int)(k - (long)j * C);
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s += dpre1[(long)n * Cs + j] * pooled[(long)n * C + c];
+        dw1[k] = s;
+    } else if (idx < 2 * n2 + C) {
+        const int c = (int)(idx - 2 * n2);
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s += dpre2[(long)n * C + c];
+        db2[c] = s;
+    } else if (idx < 2 * n2 + C + Cs) {
+        const int j = (int)(idx - 2 * n2 - C);
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s += dpre1[(long)n * Cs + j];
+        db1[j] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
 static inline int ew_grid(long pieces) {
@@ -500,5 +579,27 @@ extern "C" int hn_cast_f32_to_bf16_pad(const float* src, int lds_, void* dst, in
 extern "C" int hn_cast_bf16_to_f32(const void* src, int lds_, float* dst, int ldo, long M, int C, hipStream_t st) {
     HN_CHECK_ARG(src && dst && M > 0 && C > 0);
     hipLaunchKernelGGL(cast_f32_kernel, dim3(ew_grid(M * C)), dim3(256), 0, st, (const bf16*)src, lds_, dst, ldo, M, C);
+    HN_LAUNCH_CHECK();
+}
+
+extern "C" int hn_se_mlp_fwd(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2, float* hid, float* gate,
+                             int N, int C, int Cs, hipStream_t st) {
+    HN_CHECK_ARG(pooled && w1 && b1 && w2 && b2 && hid && gate && N > 0 && C > 0 && Cs > 0);
+    hipLaunchKernelGGL(se_fc_rows_kernel, dim3(cdiv((long)N * Cs, 4)), dim3(256), 0, st, w1, b1, pooled, hid, N, Cs, C, HN_ACT_RELU);
+    hipLaunchKernelGGL(se_fc_rows_kernel, dim3(cdiv((long)N * C, 4)), dim3(256), 0, st, w2, b2, hid, gate, N, C, Cs, HN_ACT_SIGMOID);
+    HN_LAUNCH_CHECK();
+}
+
+extern "C" int hn_se_mlp_bwd(const float* dgate, const float* gate, const float* hid, const float* pooled, const float* w1, const float* w2,
+                             float* dpre2, float* dpre1, float* dpool, float* dw1, float* db1, float* dw2, float* db2, int N, int C, int Cs,
+                             hipStream_t st) {
+    HN_CHECK_ARG(dgate && gate && hid && pooled && w1 && w2 && dpre2 && dpre1 && dpool && dw1 && db1 && dw2 && db2 && N > 0 && C > 0 && Cs > 0);
+    // dpre1[n][j] = [hid > 0] * sum_c W2[c][j] * (dgate * g (1-g))[n][c]        (also stores dpre2)
+    hipLaunchKernelGGL(se_fc_cols_kernel, dim3(cdiv(Cs, 64), N), dim3(256), 0, st, w2, dgate, gate, dpre2, hid, dpre1, N, Cs, C, 1, 1);
+    // dpool[n][c] = sum_j W1[j][c] * dpre1[n][j]
+    hipLaunchKernelGGL(se_fc_cols_kernel, dim3(cdiv(C, 64), N), dim3(256), 0, st, w1, (const float*)dpre1, (const float*)nullptr,
+                       (float*)nullptr, (const float*)nullptr, dpool, N, C, Cs, 0, 0);
+    const long total = 2L * C * Cs + C + Cs;
+    hipLaunchKernelGGL(se_mlp_wgrad_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, dpre2, dpre1, hid, pooled, dw1, db1, dw2, db2, N, C, Cs);
     HN_LAUNCH_CHECK();
 }

@@ -562,6 +562,38 @@ __global__ __launch_bounds__(256) void fuse_fwd_kernel(const Fuse p) {
     }
 }
 
+// fast-attention weights of a fusion node: w = relu(p) / (sum relu(p) + eps)   (net/bifpn.py:179-180); wn always has 3 slots
+__global__ void fuse_weights_kernel(const float* praw, int nw, float eps, float* wn) {
+    if (threadIdx.x == 0) {
+        float r[3], sum = 0.f;
+        for (int i = 0; i < 3; ++i) { r[i] = i < nw ? fmaxf(praw[i], 0.f) : 0.f; sum += r[i]; }
+        for (int i = 0; i < 3; ++i) wn[i] = r[i] / (sum + eps);
+    }
+}
+// dp_i = [p_i > 0] * (dw_i - sum_j w_j dw_j) / (sum relu(p) + eps), dw = column sums of the per-block partials pw[blocks][3]
+__global__ __launch_bounds__(256) void fuse_dweights_kernel(const float* pw, int blocks, const float* praw, int nw, float eps, float* dp) {
+    __shared__ float red[4][3];
+    float a[3] = {0.f, 0.f, 0.f};
+    for (int b = threadIdx.x; b < blocks; b += 256)
+        for (int i = 0; i < 3; ++i) a[i] += pw[b * 3 + i];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = 0; i < 3; ++i) {
+        const float t = wave_sum(a[i]);
+        if (lane == 0) red[wave][i] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float dw[3], r[3], sum = 0.f, dot = 0.f;
+        for (int i = 0; i < 3; ++i) {
+            dw[i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+            r[i] = i < nw ? fmaxf(praw[i], 0.f) : 0.f;
+            sum += r[i];
+        }
+        for (int i = 0; i < 3; ++i) dot += dw[i] * r[i] / (sum + eps);
+        for (int i = 0; i < nw; ++i) dp[i] = praw[i] > 0.f ? (dw[i] - dot) / (sum + eps) : 0.f;
+    }
+}
+
 // backward part 1: g = dout * swish'(pre) (bf16, output resolution), d_in for identity inputs (= w[i] * g), and per-block partial
 // sums of dw[i] = sum g * T_i(in_i)  -> pw[block][3]
 struct FuseBwd {
@@ -887,5 +919,16 @@ extern "C" int hn_head_grad(const float* dy, const float* y, long rpi, long img_
     HN_CHECK_ARG(dy && dz && rpi > 0 && Nout > 0 && ldz >= Nout && (ldz & 7) == 0 && M > 0 && (!sigmoid || y));
     hipLaunchKernelGGL(head_grad_kernel, dim3(ew_grid(M * ldz)), dim3(256), 0, st, dy, y, rpi, img_stride, lds_, Nout, (bf16*)dz, ldz, M,
                        sigmoid);
+    HN_LAUNCH_CHECK();
+}
+
+extern "C" int hn_fuse_weights(const float* praw, int nw, float eps, float* wn, hipStream_t st) {
+    HN_CHECK_ARG(praw && wn && nw >= 1 && nw <= 3);
+    hipLaunchKernelGGL(fuse_weights_kernel, dim3(1), dim3(64), 0, st, praw, nw, eps, wn);
+    HN_LAUNCH_CHECK();
+}
+extern "C" int hn_fuse_dweights(const float* pw, int blocks, const float* praw, int nw, float eps, float* dp, hipStream_t st) {
+    HN_CHECK_ARG(pw && praw && dp && blocks > 0 && nw >= 1 && nw <= 3);
+    hipLaunchKernelGGL(fuse_dweights_kernel, dim3(1), dim3(256), 0, st, pw, blocks, praw, nw, eps, dp);
     HN_LAUNCH_CHECK();
 }

@@ -314,8 +314,7 @@ class HydraNet(nn.Module):
         return self._cba(d, name + ".pointwise_conv.conv", name + ".bn", BN_FPN, act=act)
 
     def _fusew(self, name):
-        w = torch.relu(self._idx[name])
-        return w / (torch.sum(w, dim=0) + 1e-4)
+        return self._idx[name]                      # raw fusion parameter; relu / normalisation happen inside the Fuse op
 
     def _cell(self, p, inputs, first):
         """BiFPN._forward_fast_attention, net/bifpn.py:156-233."""

@@ -342,12 +342,14 @@ class SEGate(torch.autograd.Function):
     def forward(ctx, b, w1, b1, w2, b2):
         n, h, w, c = b.shape
         hw = h * w
+        cs = w1.shape[0]
+        dev = b.device
         ps, _, r = k_col_stats(b, align=hw)
         pooled = k_rows_reduce(ps, n, hw // r, c, 1.0 / hw)                      # [N, C]
-        w1m, w2m = w1.view(w1.shape[0], -1), w2.view(w2.shape[0], -1)
-        hid = torch.relu(torch.addmm(b1, pooled, w1m.t()))                       # [N, Cs]
-        gate = torch.sigmoid(torch.addmm(b2, hid, w2m.t()))                      # [N, C]
-        out = new_act(n, h, w, c, b.device)
+        hid = torch.empty((n, cs), device=dev, dtype=F32)
+        gate = torch.empty((n, c), device=dev, dtype=F32)
+        lib().call("hn_se_mlp_fwd", ptr(pooled), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(hid), ptr(gate), n, c, cs)
+        out = new_act(n, h, w, c, dev)
         lib().call("hn_scale_rows", ptr(b), ld(b), ptr(gate), hw, ptr(out), ld(out), n * hw, c)
         ctx.save_for_backward(b, pooled, hid, gate, w1, w2)
         return out
@@ -359,23 +361,24 @@ class SEGate(torch.autograd.Function):
         n, h, w, c = b.shape
         hw = h * w
         m = n * hw
+        cs = w1.shape[0]
+        dev = b.device
         r = lib().query("hn_colred_rows", m, hw)
         pr = (m + r - 1) // r
-        pd = torch.empty((pr, c), device=b.device, dtype=F32)
-        pz = torch.empty((pr, c), device=b.device, dtype=F32)
+        pd = torch.empty((pr, c), device=dev, dtype=F32)
+        pz = torch.empty((pr, c), device=dev, dtype=F32)
         lib().call("hn_col_dot", ptr(dout), ld(dout), ptr(b), ld(b), m, c, r, ptr(pd), ptr(pz))
         dgate = k_rows_reduce(pd, n, hw // r, c, 1.0)                            # sum_hw dout * b
-        w1m, w2m = w1.view(w1.shape[0], -1), w2.view(w2.shape[0], -1)
-        dpre2 = dgate * gate * (1.0 - gate)
-        dw2 = dpre2.t().mm(hid)
-        db2 = dpre2.sum(0)
-        dpre1 = dpre2.mm(w2m) * (hid > 0).to(F32)
-        dw1 = dpre1.t().mm(pooled)
-        db1 = dpre1.sum(0)
-        dpool = dpre1.mm(w1m).contiguous()
-        db = new_act(n, h, w, c, b.device)
+        dpre2 = torch.empty((n, c), device=dev, dtype=F32)
+        dpool = torch.empty((n, c), device=dev, dtype=F32)
+        dpre1 = torch.empty((n, cs), device=dev, dtype=F32)
+        dw1, db1 = torch.empty_like(w1), torch.empty((cs,), device=dev, dtype=F32)
+        dw2, db2 = torch.empty_like(w2), torch.empty((c,), device=dev, dtype=F32)
+        lib().call("hn_se_mlp_bwd", ptr(dgate), ptr(gate), ptr(hid), ptr(pooled), ptr(w1), ptr(w2), ptr(dpre2), ptr(dpre1), ptr(dpool),
+                   ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), n, c, cs)
+        db = new_act(n, h, w, c, dev)
         lib().call("hn_se_bwd_apply", ptr(dout), ld(dout), ptr(gate), ptr(dpool), hw, ptr(db), ld(db), m, c)
-        return db, dw1.view_as(w1), db1, dw2.view_as(w2), db2
+        return db, dw1, db1, dw2, db2
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -454,26 +457,28 @@ def _fuse_args(ins, modes):
 
 
 class Fuse(torch.autograd.Function):
-    """out = swish(w0*T0(a) + w1*T1(b) [+ w2*T2(c)]); w = normalised fusion weights (fp32 [3] on device)."""
+    """out = swish(w0*T0(a) + w1*T1(b) [+ w2*T2(c)]), w = relu(p)/(sum relu(p) + 1e-4) from the raw fusion parameter p (2 or 3 values)."""
 
     @staticmethod
-    def forward(ctx, w, m0, m1, m2, a, b, c):
+    def forward(ctx, praw, m0, m1, m2, a, b, c):
         ins = [a, b, c]
         modes = [m0, m1, m2]
-        ref = a
-        n, h, wd, ch = ref.shape                      # input 0 is always at the output resolution (mode 1)
+        n, h, wd, ch = a.shape                        # input 0 is always at the output resolution (mode 1)
         assert m0 == 1
-        out = new_act(n, h, wd, ch, ref.device)
+        dev = a.device
+        w = torch.empty((3,), device=dev, dtype=F32)
+        lib().call("hn_fuse_weights", ptr(praw), praw.numel(), 1e-4, ptr(w))
+        out = new_act(n, h, wd, ch, dev)
         ap, al, am = _fuse_args(ins, modes)
         lib().call("hn_fuse_fwd", ctypes.addressof(ap), ctypes.addressof(al), ctypes.addressof(am), ptr(w), ptr(out), ld(out), n, h, wd, ch)
         ctx.modes = modes
-        ctx.save_for_backward(w, *[t for t in ins if t is not None])
+        ctx.save_for_backward(praw, w, *[t for t in ins if t is not None])
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        w = ctx.saved_tensors[0]
-        rest = list(ctx.saved_tensors[1:])
+        praw, w = ctx.saved_tensors[0], ctx.saved_tensors[1]
+        rest = list(ctx.saved_tensors[2:])
         modes = ctx.modes
         ins = [rest.pop(0) if m else None for m in modes]
         dout = dense(dout)
@@ -482,13 +487,14 @@ class Fuse(torch.autograd.Function):
         g = new_act(n, h, wd, ch, dev)
         dins = [new_act(n, h, wd, ch, dev) if m == 1 else None for m in modes]
         ap, al, am = _fuse_args(ins, modes)
-        dp = (ctypes.c_void_p * 3)(*[ptr(t) if t is not None else None for t in dins])
+        dp_ = (ctypes.c_void_p * 3)(*[ptr(t) if t is not None else None for t in dins])
         dl = (ctypes.c_int * 3)(*[ld(t) if t is not None else 0 for t in dins])
         blocks = lib().query("hn_fuse_bwd_blocks", n, h, wd, ch)
         pw = torch.empty((blocks, 3), device=dev, dtype=F32)
         lib().call("hn_fuse_bwd", ctypes.addressof(ap), ctypes.addressof(al), ctypes.addressof(am), ptr(w), ptr(dout), ld(dout), ptr(g), ld(g),
-                   ctypes.addressof(dp), ctypes.addressof(dl), ptr(pw), n, h, wd, ch)
-        dw = k_rows_reduce(pw, 1, blocks, 3).view(3)
+                   ctypes.addressof(dp_), ctypes.addressof(dl), ptr(pw), n, h, wd, ch)
+        dpraw = torch.empty_like(praw)
+        lib().call("hn_fuse_dweights", ptr(pw), blocks, ptr(praw), praw.numel(), 1e-4, ptr(dpraw))
         for i, m in enumerate(modes):
             if m == 2:                                               # nearest x2 of a half-res input: 2x2 sum of g
                 t = ins[i]
@@ -497,7 +503,7 @@ class Fuse(torch.autograd.Function):
                 dins[i] = d
             elif m == 3:                                             # zero-pad-same max pool of a double-res input
                 dins[i] = k_maxpool_bwd(ins[i], g, 0, wscale=w[i])
-        return dw[:w.numel()].clone(), None, None, None, dins[0], dins[1], dins[2]
+        return dpraw, None, None, None, dins[0], dins[1], dins[2]
 
 
 # --------------------------------------------------------------------------------------------------------------

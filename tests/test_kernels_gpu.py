@@ -207,12 +207,11 @@ def test_bifpn_fuse(K, modes):
     ins = [rnd(n, c, *shapes[m]) if m else None for m in modes]
     nw = 3 if modes[2] else 2
     p = torch.rand(nw, device=dev()) + 0.2
+    p[1] = -0.3 if nw == 3 else p[1]          # one negative parameter exercises the relu gate
     up = rnd(n, c, h, w)
     pk = p.clone().requires_grad_(True)
-    wk = torch.relu(pk)
-    wk = wk / (wk.sum() + 1e-4)
     ik = [nhwc(t).requires_grad_(True) if t is not None else None for t in ins]
-    out = K.Fuse.apply(wk, modes[0], modes[1], modes[2], ik[0], ik[1], ik[2])
+    out = K.Fuse.apply(pk, modes[0], modes[1], modes[2], ik[0], ik[1], ik[2])
     out.backward(nhwc(up))
     pr = p.clone().requires_grad_(True)
     wr = torch.relu(pr)
