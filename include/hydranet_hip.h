@@ -47,7 +47,7 @@ int hn_nt_stat_rows(long M, int Nout);
 /* wgrad: dw[Cout][Cin][taps] (PyTorch layout, fp32) = sum_pixel dz[pixel][cout] * X(pixel, tap)[c]; X modes 0..2 as above.
  * dz rows must be zero padded up to ldz >= Nout rounded up to 8.  workspace: fp32, size from hn_wgrad_plan.
  * Replaces aten::convolution_backward's weight gradient. */
-int hn_wgrad_plan(long M, int Nout, int KP, int taps, int* splits, long* rows_per_split, long* ws_bytes);
+int hn_wgrad_plan(int mode, int n_img, int H, int W, long M, int Nout, int KP, int taps, int* splits, long* rows_per_split, long* ws_bytes);
 int hn_conv_gemm_tn(const void* x0, const void* x1, int mode, int n_img, int H, int W, int C0, int C1, int ld0, int ld1, int up, long M,
                     const void* dz, int ldz, int Nout, int KP, int taps, float* workspace, float* dw, hipStream_t stream);
 

@@ -372,26 +372,45 @@ __global__ __launch_bounds__(256) void se_fc_rows_kernel(const float* W, const f
 // out[n][o] = mask(o) * sum_i W[i][o] * f(in)[n][i]   (contraction over the ROW index of W: coalesced over o).
 // block = 64 outputs x 4 partitions of i.  pre: 0 = in as is, 1 = in * g * (1 - g) with g = aux[n][i] (sigmoid', result also stored to
 // `store`).  post: 0 none, 1 = zero where aux2[n][o] <= 0 (ReLU').
-__global__ __launch_bounds__(256) void se_fc_cols_kernel(const float* W, const float* in, const float* aux, float* store, const float* aux2,
-                                                         float* out, int N, int O, int I, int pre, int post) {
-    __shared__ float red[4][64];
-    const int ox = threadIdx.x & 63, part = threadIdx.x >> 6;
+__global__ __launch_bounds__(1024) void se_fc_cols_kernel(const float* W, const float* in, const float* aux, float* store, const float* aux2,
+                                                          float* out, int N, int O, int I, int pre, int post) {
+    __shared__ float red[16][64];
+    const int ox = threadIdx.x & 63, part = threadIdx.x >> 6;         // 64 outputs x 16 partitions of the contraction
     const int o = blockIdx.x * 64 + ox, n = blockIdx.y;
-    float s = 0.f;
-    const int i0 = (int)((long)I * part / 4), i1 = (int)((long)I * (part + 1) / 4);
-    for (int i = i0; i < i1; ++i) {
-        float v = in[(long)n * I + i];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const int i0 = (int)((long)I * part / 16), i1 = (int)((long)I * (part + 1) / 16);
+    const float* inr = in + (long)n * I;
+    const float* auxr = aux ? aux + (long)n * I : nullptr;
+    const bool ov = o < O;
+    auto val = [&](int i) {
+        float v = inr[i];
         if (pre) {
-            const float g = aux[(long)n * I + i];
+            const float g = auxr[i];
             v *= g * (1.f - g);
             if (store && blockIdx.x == 0 && ox == 0) store[(long)n * I + i] = v;
         }
-        if (o < O) s += W[(long)i * O + o] * v;
+        return v;
+    };
+    int i = i0;
+    for (; i + 4 <= i1; i += 4) {                                      // four independent loads in flight
+        const float v0 = val(i), v1 = val(i + 1), v2 = val(i + 2), v3 = val(i + 3);
+        if (ov) {
+            s0 += W[(long)i * O + o] * v0;
+            s1 += W[(long)(i + 1) * O + o] * v1;
+            s2 += W[(long)(i + 2) * O + o] * v2;
+            s3 += W[(long)(i + 3) * O + o] * v3;
+        }
     }
-    red[part][ox] = s;
+    for (; i < i1; ++i) {
+        const float v = val(i);
+        if (ov) s0 += W[(long)i * O + o] * v;
+    }
+    red[part][ox] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (part == 0 && o < O) {
-        float t = red[0][ox] + red[1][ox] + red[2][ox] + red[3][ox];
+    if (part == 0 && ov) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][ox];
         if (post && aux2[(long)n * O + o] <= 0.f) t = 0.f;
         out[(long)n * O + o] = t;
     }
@@ -595,9 +614,9 @@ extern "C" int hn_se_mlp_bwd(const float* dgate, const float* gate, const float*
                              hipStream_t st) {
     HN_CHECK_ARG(dgate && gate && hid && pooled && w1 && w2 && dpre2 && dpre1 && dpool && dw1 && db1 && dw2 && db2 && N > 0 && C > 0 && Cs > 0);
     // dpre1[n][j] = [hid > 0] * sum_c W2[c][j] * (dgate * g (1-g))[n][c]        (also stores dpre2)
-    hipLaunchKernelGGL(se_fc_cols_kernel, dim3(cdiv(Cs, 64), N), dim3(256), 0, st, w2, dgate, gate, dpre2, hid, dpre1, N, Cs, C, 1, 1);
+    hipLaunchKernelGGL(se_fc_cols_kernel, dim3(cdiv(Cs, 64), N), dim3(1024), 0, st, w2, dgate, gate, dpre2, hid, dpre1, N, Cs, C, 1, 1);
     // dpool[n][c] = sum_j W1[j][c] * dpre1[n][j]
-    hipLaunchKernelGGL(se_fc_cols_kernel, dim3(cdiv(C, 64), N), dim3(256), 0, st, w1, (const float*)dpre1, (const float*)nullptr,
+    hipLaunchKernelGGL(se_fc_cols_kernel, dim3(cdiv(C, 64), N), dim3(1024), 0, st, w1, (const float*)dpre1, (const float*)nullptr,
                        (float*)nullptr, (const float*)nullptr, dpool, N, C, Cs, 0, 0);
     const long total = 2L * C * Cs + C + Cs;
     hipLaunchKernelGGL(se_mlp_wgrad_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, dpre2, dpre1, hid, pooled, dw1, db1, dw2, db2, N, C, Cs);

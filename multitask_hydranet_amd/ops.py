@@ -155,7 +155,7 @@ def k_gemm_tn(x0, x1, mode, grid, dz, nout, kp, taps, cin, up=0, kh=1):
     m = n * h * w
     dev = x0.device
     splits, rps, wsb = ctypes.c_int(), ctypes.c_long(), ctypes.c_long()
-    lib().query("hn_wgrad_plan", m, nout, kp, taps, ctypes.addressof(splits), ctypes.addressof(rps), ctypes.addressof(wsb))
+    lib().query("hn_wgrad_plan", mode, n, h, w, m, nout, kp, taps, ctypes.addressof(splits), ctypes.addressof(rps), ctypes.addressof(wsb))
     ws = torch.empty((wsb.value // 4,), device=dev, dtype=F32)
     dw = torch.empty((nout, cin, kh, kh), device=dev, dtype=F32)
     c0 = x0.shape[3]

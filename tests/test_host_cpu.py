@@ -29,9 +29,9 @@ def test_library_exports_every_declared_symbol(built):
     l = built.lib()
     assert l.query("hn_nt_stat_rows", 1000, 64) == 16
     s, r, w = ctypes.c_int(), ctypes.c_long(), ctypes.c_long()
-    assert l.query("hn_wgrad_plan", 16 * 512 * 1024, 64, 64, 9, ctypes.addressof(s), ctypes.addressof(r), ctypes.addressof(w)) == 0
+    assert l.query("hn_wgrad_plan", 0, 16, 512, 1024, 16 * 512 * 1024, 64, 64, 1, ctypes.addressof(s), ctypes.addressof(r), ctypes.addressof(w)) == 0
     assert s.value >= 1 and r.value % 64 == 0 and s.value * r.value >= 16 * 512 * 1024
-    assert w.value == s.value * 64 * 9 * 64 * 4
+    assert w.value == s.value * 64 * 1 * 64 * 4
 
 
 def test_bad_arguments_are_rejected_without_a_gpu(built):
