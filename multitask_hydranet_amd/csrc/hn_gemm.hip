@@ -355,10 +355,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
 // ---------------------------------------------------------------------------------------------------------
 template <int BC, bool OUT_F32>
 __global__ __launch_bounds__(512) void conv3x3_direct_kernel(const GemmNT p) {
-    constexpr int WGC = BC / 64, WGP = 8 / WGC, ROWS = 16 / WGP;      // rows of the patch per wave
-    constexpr int TC = 4, TP = ROWS;
+    constexpr int WCO = BC >= 64 ? 64 : BC;                           // couts per wave
+    constexpr int WGC = BC / WCO, WGP = 8 / WGC, ROWS = 16 / WGP;     // rows of the patch per wave
+    constexpr int TC = WCO / 16, TP = ROWS;
     constexpr int PPIX = 18 * 18, XBYTES = (PPIX * 128 + 1023) / 1024 * 1024, WBYTES = BC * 128;   // X buffer padded to whole 1 KiB DMA runs
-    constexpr int XL = (PPIX * 8 + 511) / 512, WL = BC * 8 / 512;
+    constexpr int XL = (PPIX * 8 + 511) / 512, WL = (BC * 8 + 511) / 512;
     extern __shared__ __attribute__((aligned(16))) char smem[];       // X patch x2 | W tile x2
     char* sXb = smem;
     char* sWb = smem + 2 * XBYTES;
@@ -413,7 +414,7 @@ __global__ __launch_bounds__(512) void conv3x3_direct_kernel(const GemmNT p) {
 #pragma unroll
     for (int i = 0; i < WL; ++i) {
         const int co = c_blk + (tid >> 3) + 64 * i;
-        wrow[i] = co < p.Nout ? (long)co * Ktot + wsub : -1;
+        wrow[i] = ((tid >> 3) + 64 * i < BC && co < p.Nout) ? (long)co * Ktot + wsub : -1;
     }
 
     f32x4 acc[TC][TP];
@@ -433,8 +434,10 @@ __global__ __launch_bounds__(512) void conv3x3_direct_kernel(const GemmNT p) {
             char* sW = sWb + (it & 1) * WBYTES;
 #pragma unroll
             for (int i = 0; i < WL; ++i) {
-                const bf16* src = (wrow[i] >= 0 && k0 + wsub < p.KP) ? p.w + wrow[i] + tap * p.KP + k0 : g_zero_piece;
-                glds16(src, sW + (wave * 8 + 64 * i) * 128);
+                if (wave * 8 + 64 * i < BC) {                          // wave-uniform
+                    const bf16* src = (wrow[i] >= 0 && k0 + wsub < p.KP) ? p.w + wrow[i] + tap * p.KP + k0 : g_zero_piece;
+                    glds16(src, sW + (wave * 8 + 64 * i) * 128);
+                }
             }
             if (tap == 0) {
                 char* sX = sXb + (chunk & 1) * XBYTES;
@@ -464,7 +467,7 @@ __global__ __launch_bounds__(512) void conv3x3_direct_kernel(const GemmNT p) {
                 bf16x8 a[TC], b[TP];
                 const int piece = ks * 4 + (lane >> 4);
 #pragma unroll
-                for (int i = 0; i < TC; ++i) a[i] = *reinterpret_cast<const bf16x8*>(sW + swz(wc * 64 + i * 16 + (lane & 15), piece));
+                for (int i = 0; i < TC; ++i) a[i] = *reinterpret_cast<const bf16x8*>(sW + swz(wc * WCO + i * 16 + (lane & 15), piece));
 #pragma unroll
                 for (int j = 0; j < TP; ++j) {
                     const int pidx = (wp * ROWS + j + dy) * 18 + (lane & 15) + dx;
@@ -483,7 +486,7 @@ __global__ __launch_bounds__(512) void conv3x3_direct_kernel(const GemmNT p) {
     const int ox = ox0 + (lane & 15);
 #pragma unroll
     for (int i = 0; i < TC; ++i) {
-        const int co0 = c_blk + wc * 64 + i * 16 + (lane >> 4) * 4;
+        const int co0 = c_blk + wc * WCO + i * 16 + (lane >> 4) * 4;
         float bsv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) bsv[r] = (p.bias && co0 + r < p.Nout) ? p.bias[co0 + r] : 0.f;
@@ -698,16 +701,17 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN p) {
 // ---------------------------------------------------------------------------------------------------------
 template <int BC, int CI>
 __global__ __launch_bounds__(512) void wgrad3x3_patch_kernel(const GemmTN p, int patches_per_split, int n_patches) {
-    constexpr int WGC = BC / 64, WGN = 8 / WGC;
-    static_assert(WGN * 16 == CI, "8 waves must tile BC x CI");
-    constexpr int ZB = 128 * BC * 2;                                   // dZ tile bytes
+    constexpr int WCO = BC >= 64 ? 64 : BC, TC = WCO / 16;
+    constexpr int WGC = BC / WCO, WGN = CI / 16, KSPLIT = 8 / (WGC * WGN);   // KSPLIT > 1: waves also split the patch's k-steps
+    static_assert(WGC * WGN * KSPLIT == 8, "8 waves must tile BC x CI x k-split");
+    constexpr int ZB = (128 * BC * 2 + 1023) / 1024 * 1024;           // dZ tile bytes
     constexpr int XPIX = 10 * 18, XROW = CI * 2, XNP = CI / 8;
     constexpr int XB = ((XPIX * XNP + 511) / 512) * 512 * 16;          // X patch bytes, padded to whole 512-thread DMA rounds
-    constexpr int ZL = 128 * (BC / 8) / 512, XL = (XPIX * XNP + 511) / 512;
+    constexpr int ZL = (128 * (BC / 8) + 511) / 512, XL = (XPIX * XNP + 511) / 512;
     constexpr int STAGE = ZB + XB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wc = wave / WGN, wn = wave % WGN;
+    const int wn = wave % WGN, wc = (wave / WGN) % WGC, wk = wave / (WGN * WGC);
     const XSrc& xs = p.x;
     const int ntile = (p.KP + CI - 1) / CI;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
@@ -720,9 +724,9 @@ __global__ __launch_bounds__(512) void wgrad3x3_patch_kernel(const GemmTN p, int
     const int S = pe > pb ? pe - pb : 0;
     const int Ctot = xs.C0 + xs.C1;
 
-    f32x4 acc[4][9];
+    f32x4 acc[TC][9];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TC; ++i)
 #pragma unroll
         for (int t = 0; t < 9; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -744,12 +748,14 @@ __global__ __launch_bounds__(512) void wgrad3x3_patch_kernel(const GemmTN p, int
             char* sX = sZ + ZB;
 #pragma unroll
             for (int i = 0; i < ZL; ++i) {
-                const int e = tid + 512 * i;
-                const int row = e / (BC / 8), cp = tn_swz<BC>(row, e - row * (BC / 8));
-                const int oy = oy0 + (row >> 4), ox = ox0 + (row & 15);
-                const int co = c_blk + cp * 8;
-                const bf16* src = (oy < xs.H && ox < xs.W && co < p.Nout) ? p.dz + ((long)(n * xs.H + oy) * xs.W + ox) * p.ldz + co : g_zero_piece;
-                glds16(src, sZ + (512 * i + 64 * wave) * 16);
+                if (512 * i + 64 * wave < 128 * (BC / 8)) {           // wave-uniform
+                    const int e = tid + 512 * i;
+                    const int row = e / (BC / 8), cp = tn_swz<BC>(row, e - row * (BC / 8));
+                    const int oy = oy0 + (row >> 4), ox = ox0 + (row & 15);
+                    const int co = c_blk + cp * 8;
+                    const bf16* src = (oy < xs.H && ox < xs.W && co < p.Nout) ? p.dz + ((long)(n * xs.H + oy) * xs.W + ox) * p.ldz + co : g_zero_piece;
+                    glds16(src, sZ + (512 * i + 64 * wave) * 16);
+                }
             }
 #pragma unroll
             for (int i = 0; i < XL; ++i) {
@@ -776,12 +782,12 @@ __global__ __launch_bounds__(512) void wgrad3x3_patch_kernel(const GemmTN p, int
             const char* sZ = smem + ((it - 1) & 1) * STAGE;
             const char* sX = sZ + ZB;
 #pragma unroll 1
-            for (int ks = 0; ks < 4; ++ks) {                           // 32 pixels = patch rows 2ks, 2ks+1 (rolled: 144 accumulator VGPRs)
-                bf16x8 a[4];
+            for (int ks = wk; ks < 4; ks += KSPLIT) {                  // 32 pixels = patch rows 2ks, 2ks+1 (rolled: 144 accumulator VGPRs)
+                bf16x8 a[TC];
                 const int rlo = ks * 32 + g * 4 + q, rhi = rlo + 16;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int piece = (wc * 64 + i * 16) / 8 + (pp >> 1);
+                for (int i = 0; i < TC; ++i) {
+                    const int piece = (wc * WCO + i * 16) / 8 + (pp >> 1);
                     const trv4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(sZ + rlo * (BC * 2) + tn_swz<BC>(rlo, piece) * 16 + (pp & 1) * 8));
                     const trv4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(sZ + rhi * (BC * 2) + tn_swz<BC>(rhi, piece) * 16 + (pp & 1) * 8));
                     a[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -795,22 +801,22 @@ __global__ __launch_bounds__(512) void wgrad3x3_patch_kernel(const GemmTN p, int
                     const trv4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(sX + phi * XROW + tn_swz<CI>(phi, bpiece) * 16 + (pp & 1) * 8));
                     const bf16x8 b = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[i][tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b, acc[i][tap], 0, 0, 0);
+                    for (int i = 0; i < TC; ++i) acc[i][tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b, acc[i][tap], 0, 0, 0);
                 }
             }
         }
     }
     const int Ktot = 9 * p.KP;
-    float* part = p.part + (long)bz * p.Nout * Ktot;
+    float* part = p.part + ((long)bz * KSPLIT + wk) * p.Nout * Ktot;       // each k-split wave group owns its own partial slab
     const int ci = ci_blk + wn * 16 + (lane & 15);
     if (ci < p.KP) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < TC; ++i)
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int co = c_blk + wc * 64 + i * 16 + (lane >> 4) * 4 + r;
+                    const int co = c_blk + wc * WCO + i * 16 + (lane >> 4) * 4 + r;
                     if (co < p.Nout) part[(long)co * Ktot + tap * p.KP + ci] = acc[i][tap][r];
                 }
     }
@@ -925,26 +931,28 @@ extern "C" int hn_conv_gemm_nt(const void* x0, const void* x1, int mode, int n_i
     p.w = (const bf16*)w; p.Nout = Nout; p.KP = KP; p.taps = taps;
     p.bias = bias; p.act = act; p.out = out; p.ldc = ldc; p.psum = psum; p.psq = psq;
     p.rpi = rpi; p.img_stride = img_stride;
-    if (mode >= 2 && Nout > 32 && !psum && !rpi) {
-        const int bc = Nout <= 64 ? 64 : 128;
+    if (mode >= 2 && !psum && !rpi) {
+        const int bc = Nout <= 16 ? 16 : (Nout <= 64 ? 64 : 128);
         dim3 grid((unsigned)(cdiv(Nout, bc) * cdiv(W, 16) * cdiv(H, 16) * n_img));
         const size_t lds = 2 * (size_t)((18 * 18 * 128 + 1023) / 1024 * 1024) + 2 * (size_t)bc * 128;
         // > 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel (done on the first, un-captured call)
         static bool optin = false;
         if (!optin) {
+            hipFuncSetAttribute((const void*)conv3x3_direct_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute((const void*)conv3x3_direct_kernel<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             hipFuncSetAttribute((const void*)conv3x3_direct_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             hipFuncSetAttribute((const void*)conv3x3_direct_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             hipFuncSetAttribute((const void*)conv3x3_direct_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             hipFuncSetAttribute((const void*)conv3x3_direct_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             optin = true;
         }
-        if (bc == 64) {
-            if (out_f32) hipLaunchKernelGGL((conv3x3_direct_kernel<64, true>), grid, dim3(512), lds, st, p);
-            else hipLaunchKernelGGL((conv3x3_direct_kernel<64, false>), grid, dim3(512), lds, st, p);
-        } else {
-            if (out_f32) hipLaunchKernelGGL((conv3x3_direct_kernel<128, true>), grid, dim3(512), lds, st, p);
-            else hipLaunchKernelGGL((conv3x3_direct_kernel<128, false>), grid, dim3(512), lds, st, p);
+#define DIRECT_CASE(BC_) \
+        if (bc == BC_) { \
+            if (out_f32) hipLaunchKernelGGL((conv3x3_direct_kernel<BC_, true>), grid, dim3(512), lds, st, p); \
+            else hipLaunchKernelGGL((conv3x3_direct_kernel<BC_, false>), grid, dim3(512), lds, st, p); \
         }
+        DIRECT_CASE(16) DIRECT_CASE(64) DIRECT_CASE(128)
+#undef DIRECT_CASE
         HN_LAUNCH_CHECK();
     }
     switch (pick_bc(Nout)) {
@@ -971,7 +979,12 @@ static void tn_tiles(int Nout, int KP, int& bc, int& bn) {
     if (bc == 16 && bn < 64) bn = 64;                       // 4 waves need >= 16 columns each
 }
 
-static bool use_patch_wgrad(int mode, int Nout, int KP) { return mode == 2 && Nout >= 64 && KP >= 64; }
+static bool use_patch_wgrad(int mode, int Nout, int KP) { return mode == 2 && (Nout >= 64 || Nout <= 16) && KP >= 64; }
+static void patch_tiles(int Nout, int& bc, int& ci, int& ksplit) {
+    if (Nout <= 16) { bc = 16; ci = 64; ksplit = 2; }
+    else if (Nout <= 64) { bc = 64; ci = 128; ksplit = 1; }
+    else { bc = 128; ci = 64; ksplit = 1; }
+}
 
 // plan the pixel split for wgrad: returns splits, rows per split (multiple of 64; patches per split for the 3x3 patch kernel) and the
 // fp32 workspace size in bytes
@@ -979,14 +992,15 @@ extern "C" int hn_wgrad_plan(int mode, int n_img, int H, int W, long M, int Nout
                              long* ws_bytes) {
     HN_CHECK_ARG(M > 0 && Nout > 0 && KP > 0 && taps > 0 && splits && rows_per_split && ws_bytes);
     if (use_patch_wgrad(mode, Nout, KP)) {
-        const int bc = Nout > 64 ? 128 : 64, ci = bc == 128 ? 64 : 128;
+        int bc, ci, ksplit;
+        patch_tiles(Nout, bc, ci, ksplit);
         const long tiles = (long)cdiv(Nout, bc) * cdiv(KP, ci);
         const long patches = (long)n_img * cdiv(H, 8) * cdiv(W, 16);
         long want = (768 + tiles - 1) / tiles;
         if (want > patches / 2) want = patches / 2;
         if (want < 1) want = 1;
         const long pps = (patches + want - 1) / want;
-        *splits = (int)((patches + pps - 1) / pps);
+        *splits = (int)((patches + pps - 1) / pps) * ksplit;       // number of partial slabs
         *rows_per_split = pps;
         *ws_bytes = (long)(*splits) * Nout * taps * KP * 4;
         return HN_OK;
@@ -1023,16 +1037,19 @@ extern "C" int hn_conv_gemm_tn(const void* x0, const void* x1, int mode, int n_i
         if (!optin) {
             hipFuncSetAttribute((const void*)wgrad3x3_patch_kernel<128, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             hipFuncSetAttribute((const void*)wgrad3x3_patch_kernel<64, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute((const void*)wgrad3x3_patch_kernel<16, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             optin = true;
         }
-        const int pbc = Nout > 64 ? 128 : 64, pci = pbc == 128 ? 64 : 128;
+        int pbc, pci, ksplit;
+        patch_tiles(Nout, pbc, pci, ksplit);
         p.gy = cdiv(Nout, pbc);
         const int patches = n_img * cdiv(H, 8) * cdiv(W, 16);
-        dim3 grid((unsigned)(cdiv(KP, pci) * p.gy * splits));
+        dim3 grid((unsigned)(cdiv(KP, pci) * p.gy * (splits / ksplit)));
         const size_t xb = (size_t)((180 * (pci / 8) + 511) / 512) * 512 * 16;
-        const size_t lds = 2 * ((size_t)128 * pbc * 2 + xb);
+        const size_t lds = 2 * ((size_t)((128 * pbc * 2 + 1023) / 1024 * 1024) + xb);
         if (pbc == 128) hipLaunchKernelGGL((wgrad3x3_patch_kernel<128, 64>), grid, dim3(512), lds, st, p, (int)rps, patches);
-        else hipLaunchKernelGGL((wgrad3x3_patch_kernel<64, 128>), grid, dim3(512), lds, st, p, (int)rps, patches);
+        else if (pbc == 64) hipLaunchKernelGGL((wgrad3x3_patch_kernel<64, 128>), grid, dim3(512), lds, st, p, (int)rps, patches);
+        else hipLaunchKernelGGL((wgrad3x3_patch_kernel<16, 64>), grid, dim3(512), lds, st, p, (int)rps, patches);
         if (hipGetLastError() != hipSuccess) return HN_ERR_LAUNCH;
         const long cols = (long)Nout * taps * KP;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(cols, 32)), dim3(512), 0, st, workspace, dw, splits, Nout, C0 + C1, KP, taps);
