@@ -150,6 +150,20 @@ int hn_add_strided2(void* dx, int ldx, const void* dxs, int lds, int N, int Ho, 
 int hn_cast_f32_to_bf16_pad(const float* src, int lds, void* dst, int ldo, long M, int C, hipStream_t stream);
 int hn_cast_bf16_to_f32(const void* src, int lds, float* dst, int ldo, long M, int C, hipStream_t stream);
 
+/* ---- losses (hn_loss.hip) --------------------------------------------------------------------------------------------------- */
+
+/* Weighted cross entropy with ignore_index and optional top-k hardest pixels per image (CrossEntropyLoss.forward, use_focal=False,
+ * head_seg/segmentation_loss.py:48-65).  logits: fp32 NHWC [N*HW][C] (row stride ldl); target: int64 or float32 class ids [N*HW];
+ * k = int(top_k_ratio * HW).  The per-image k-th largest loss is found with an exact 3-level radix select instead of torch.sort.
+ * ws: hn_seg_loss_ws_bytes(N, HW) bytes, written by fwd and read by bwd.  out[0] = mean loss; bwd writes dlogits (fp32, row stride ldd). */
+long hn_seg_loss_ws_bytes(int N, long HW);
+int hn_seg_loss_fwd(const float* logits, int ldl, int C, const void* target, int target_is_float, const float* cw, int ignore_index, int N,
+                    long HW, int use_topk, long k, void* ws, float* out, hipStream_t stream);
+int hn_seg_loss_bwd(const float* logits, int ldl, int C, const void* target, int target_is_float, const float* cw, int ignore_index, int N,
+                    long HW, int use_topk, long k, const void* ws, const float* gout, float* dlogits, int ldd, hipStream_t stream);
+/* torch.argmax(seg, dim=1) of deploy mode (model/model.py:197): fp32 NHWC logits -> int64 class ids, first maximum wins. */
+int hn_argmax_channels(const float* logits, int ldl, int C, long M, long* out, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,6 +9,7 @@ without the shared library raises.
 """
 from __future__ import annotations
 
+import contextlib
 import itertools
 import math
 import sys
@@ -117,6 +118,8 @@ class HydraNet(nn.Module):
         self.lane_points_per_line = 160                    # cal_loss_regress default that model.py:246 never overrides
         self._anchor_cache = {}
         self._pending_nbt = []
+        self.heads_on_side_stream = False          # measured: no gain over the single-stream graph on MI355X (kept for experiments)
+        self._side_streams = {}
 
         spec = _Spec(self)
         self._declare_backbone(spec)
@@ -133,8 +136,8 @@ class HydraNet(nn.Module):
             assert not self.use_lovasz, "Lovasz loss is off in every shipped cfg and outside the hot path"
             # device-resident copy of the class weights (non-persistent: not part of the reference's state_dict)
             self.register_buffer("_seg_class_weight", torch.tensor(s["class_weight"], dtype=torch.float32), persistent=False)
-            self.loss_seg = lambda logits, target: L.seg_loss(logits, target, self._seg_class_weight, s["use_top_k"],
-                                                              s["top_k_ratio"], s["use_focal"])
+            self._seg_cfg = (s["use_top_k"], s["top_k_ratio"], s["use_focal"])
+            self.loss_seg = self._seg_loss
         else:
             self.segheader, self.loss_seg = None, None
         if self.train_lane:
@@ -431,20 +434,44 @@ class HydraNet(nn.Module):
         fused = self._neck(feats)
         out = {}
         seg = anchors = reg = cls = lane_cls = lane_reg = None
+        # The detection and lane heads are chains of small launches that are independent of the (large) segmentation decoder: they run on a
+        # side HIP stream (forked / joined with events, so the fork is also legal inside hipGraph capture); autograd replays the same
+        # stream assignment in backward.
+        side = None
+        if self.heads_on_side_stream and x.is_cuda and (self.train_detect or self.train_lane) and self.train_seg:
+            cur = torch.cuda.current_stream()
+            side = self._side_streams.get(x.device)
+            if side is None:
+                side = self._side_streams[x.device] = torch.cuda.Stream(device=x.device)
+            side.wait_stream(cur)
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            if self.train_detect:
+                anchors, reg, cls = self._det(x, fused)
+                out["detection"] = {"anchors": anchors, "regression": reg, "classification": cls}
+            if self.train_lane:
+                lane = self._lane(fused)
+                out["lane"] = lane
+                lane_cls, lane_reg = lane["predict_cls"], lane["predict_loc"]
         if self.train_seg:
             seg = self._seg([feats[0], fused[0], fused[1], fused[2]])
             out["seg"] = seg
-        if self.train_detect:
-            anchors, reg, cls = self._det(x, fused)
-            out["detection"] = {"anchors": anchors, "regression": reg, "classification": cls}
-        if self.train_lane:
-            lane = self._lane(fused)
-            out["lane"] = lane
-            lane_cls, lane_reg = lane["predict_cls"], lane["predict_loc"]
+        if side is not None:
+            cur.wait_stream(side)
+            for t in (reg, cls, lane_cls, lane_reg):
+                if t is not None:
+                    t.record_stream(cur)
         self._flush_nbt()
         if mode != "deploy":
             return out
-        return torch.argmax(seg, dim=1), anchors, reg, cls, lane_cls, lane_reg
+        return K.argmax_channels(seg), anchors, reg, cls, lane_cls, lane_reg
+
+    def _seg_loss(self, logits, target):
+        """CrossEntropyLoss.forward (head_seg/segmentation_loss.py:27-65): HIP kernels for the weighted-CE / top-k path of the shipped
+        big cfgs; the focal variant of the small cfg is a handful of elementwise torch ops (not on the benchmarked path)."""
+        use_top_k, ratio, use_focal = self._seg_cfg
+        if use_focal or not logits.is_cuda:
+            return L.seg_loss(logits, target, self._seg_class_weight, use_top_k, ratio, use_focal)
+        return K.seg_loss_hip(logits, target, self._seg_class_weight, use_top_k, ratio)
 
     def _guard(self, value, what, allow_zero=False):
         if self.check_finite and ((not allow_zero and value == 0) or not torch.isfinite(value)):
@@ -455,7 +482,8 @@ class HydraNet(nn.Module):
         """HydraNet.cal_loss, model/model.py:201-264 (same keys, same divergence guard)."""
         ld = {}
         if self.train_seg:
-            loss_seg = self.loss_seg(pred_dict["seg"], gt_dict["gt_seg"].long())
+            gt_seg = gt_dict["gt_seg"]
+            loss_seg = self.loss_seg(pred_dict["seg"], gt_seg if gt_seg.dtype == torch.float32 and gt_seg.is_cuda else gt_seg.long())
             self._guard(loss_seg, "cal segment loss diverge!")
             ld["loss_seg"] = loss_seg
         if self.train_detect:

@@ -653,3 +653,54 @@ class LaneConcat(torch.autograd.Function):
         d6 = new_act(n, h // 2, w // 2, c, dout.device)
         lib().call("hn_sum2x2", ptr(dout[..., 3 * c:]), ld(dout), ptr(d6), ld(d6), None, n, h // 2, w // 2, c)
         return d3, d4, d5, d6
+
+
+# --------------------------------------------------------------------------------------------------------------
+# segmentation loss (weighted CE + ignore_index + top-k hardest pixels) and deploy-mode argmax
+# --------------------------------------------------------------------------------------------------------------
+class SegLoss(torch.autograd.Function):
+    """logits: fp32 NHWC [N, H, W, C] (dense rows); target: [N, H, W] int64 or float32 class ids."""
+
+    @staticmethod
+    def forward(ctx, logits, target, class_weights, use_top_k, top_k_ratio, ignore_index):
+        n, h, w, c = logits.shape
+        hw = h * w
+        k = int(top_k_ratio * hw) if use_top_k else hw
+        dev = logits.device
+        ws = torch.empty((lib().query("hn_seg_loss_ws_bytes", n, hw),), device=dev, dtype=torch.uint8)
+        out = torch.empty((1,), device=dev, dtype=F32)
+        tf = 1 if target.dtype == torch.float32 else 0
+        assert target.dtype in (torch.float32, torch.int64) and target.is_contiguous()
+        lib().call("hn_seg_loss_fwd", ptr(logits), logits.stride(2), c, ptr(target), tf, ptr(class_weights), ignore_index, n, hw,
+                   1 if use_top_k else 0, k, ptr(ws), ptr(out))
+        ctx.meta = (n, hw, c, tf, 1 if use_top_k else 0, k, ignore_index)
+        ctx.save_for_backward(logits, target, class_weights, ws)
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        logits, target, cw, ws = ctx.saved_tensors
+        n, hw, c, tf, topk, k, ign = ctx.meta
+        dl = torch.empty_like(logits)
+        g = gout.contiguous().to(F32).view(1)
+        lib().call("hn_seg_loss_bwd", ptr(logits), logits.stride(2), c, ptr(target), tf, ptr(cw), ign, n, hw, topk, k, ptr(ws), ptr(g),
+                   ptr(dl), dl.stride(2))
+        return dl, None, None, None, None, None
+
+
+def seg_loss_hip(seg_nchw, target, class_weights, use_top_k, top_k_ratio, ignore_index=255):
+    """seg_nchw: the module's "seg" output (fp32, NCHW-shaped view of NHWC memory)."""
+    logits = seg_nchw.permute(0, 2, 3, 1)
+    if not logits.is_contiguous():
+        logits = logits.contiguous()
+    return SegLoss.apply(logits, target.contiguous(), class_weights, use_top_k, top_k_ratio, ignore_index)
+
+
+def argmax_channels(seg_nchw):
+    logits = seg_nchw.permute(0, 2, 3, 1)
+    if not logits.is_contiguous():
+        logits = logits.contiguous()
+    n, h, w, c = logits.shape
+    out = torch.empty((n, h, w), device=logits.device, dtype=torch.int64)
+    lib().call("hn_argmax_channels", ptr(logits), logits.stride(2), c, n * h * w, ptr(out))
+    return out

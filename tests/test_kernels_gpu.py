@@ -348,3 +348,33 @@ def test_eval_mode_bn_uses_running_stats(K):
         y = F.relu(F.batch_norm(F.conv2d(x, wt), rm, rv, g, b, False, 0.1, 1e-5))
     close(nchw(out), y, ACT_TOL, "eval out")
     assert int(nbt) == 0
+
+
+@pytest.mark.parametrize("use_top_k,n,h,w", [(True, 2, 32, 64), (False, 2, 16, 16), (True, 3, 128, 128)])
+def test_seg_loss_topk_radix_select(K, use_top_k, n, h, w):
+    """weighted CE + ignore_index + top-k mean: HIP radix select vs torch.sort (fp32: rtol 1e-5 on the scalar, 1e-4 on gradients)."""
+    logits = torch.randn(n, h, w, 5, device=dev()) * 2
+    tgt = torch.randint(0, 5, (n, h, w), device=dev())
+    tgt[0, :2] = 255
+    cw = torch.tensor([0.1, 0.5, 1.0, 5.0, 5.0], device=dev())
+    lk = logits.clone().requires_grad_(True)
+    for target in (tgt, tgt.float()):
+        lk.grad = None
+        out = K.SegLoss.apply(lk, target, cw, use_top_k, 0.3, 255)
+        (out * 3.0).backward()
+        lr = logits.clone().requires_grad_(True)
+        loss = F.cross_entropy(lr.permute(0, 3, 1, 2), tgt, weight=cw, ignore_index=255, reduction="none").reshape(n, -1)
+        if use_top_k:
+            k = int(0.3 * h * w)
+            loss = torch.sort(loss, dim=1, descending=True)[0][:, :k]
+        ref = loss.mean()
+        (ref * 3.0).backward()
+        assert abs(float(out) - float(ref)) <= 1e-5 * abs(float(ref)), (float(out), float(ref))
+        close(lk.grad, lr.grad, 1e-4, "dlogits")
+
+
+def test_argmax_channels_is_exact(K):
+    logits = torch.randn(2, 16, 24, 5, device=dev())
+    logits[0, 0, 0, :] = 1.0                              # a tie: the first maximum wins, like torch.argmax
+    got = K.argmax_channels(logits.permute(0, 3, 1, 2))
+    assert torch.equal(got, torch.argmax(logits.permute(0, 3, 1, 2), dim=1))
