@@ -161,6 +161,14 @@ int hn_seg_loss_fwd(const float* logits, int ldl, int C, const void* target, int
                     long HW, int use_topk, long k, void* ws, float* out, hipStream_t stream);
 int hn_seg_loss_bwd(const float* logits, int ldl, int C, const void* target, int target_is_float, const float* cw, int ignore_index, int N,
                     long HW, int use_topk, long k, const void* ws, const float* gout, float* dlogits, int ldd, hipStream_t stream);
+/* Detection loss (FocalLoss.forward, head_detect/detection_loss.py:132-267): cls fp32 [N][A][K] (post-sigmoid), reg [N][A][4], anchors
+ * [A][4] (y1,x1,y2,x2), ann [N][Mx][5] (x1,y1,x2,y2,class; rows with class -1 are padding).  out[0] / out[1] = batch-mean classification /
+ * regression loss.  assign: int16 [N][A]; part: fp32 [N][hn_det_loss_blocks(A)][3]; npos: fp32 [N] (all written by fwd, read by bwd). */
+int hn_det_loss_blocks(int A);
+int hn_det_loss_fwd(const float* cls, const float* reg, const float* anchors, const float* ann, int N, int A, int K, int Mx, void* assign,
+                    float* part, float* npos, float* out, hipStream_t stream);
+int hn_det_loss_bwd(const float* cls, const float* reg, const float* anchors, const float* ann, int N, int A, int K, int Mx,
+                    const void* assign, const float* npos, const float* gout, float* dcls, float* dreg, hipStream_t stream);
 /* torch.argmax(seg, dim=1) of deploy mode (model/model.py:197): fp32 NHWC logits -> int64 class ids, first maximum wins. */
 int hn_argmax_channels(const float* logits, int ldl, int C, long M, long* out, hipStream_t stream);
 

@@ -178,6 +178,151 @@ __global__ __launch_bounds__(256) void seg_count_ties_kernel(const float* loss, 
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(&ties[n], c);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Detection loss (FocalLoss.forward, head_detect/detection_loss.py:132-267): IoU assignment (neg < 0.4, pos >= 0.5, else ignored),
+// focal BCE (alpha 0.25, gamma 2) on probabilities clamped to [1e-4, 1-1e-4] divided by max(#pos, 1), smooth-L1 (beta 1/9) on
+// (dy, dx, dh, dw) averaged over positives x 4; batch mean.  One thread per (image, anchor); the per-image Python loop and the
+// A x M IoU matrix of the reference never exist.  assign[n][a]: >= 0 matched annotation, -1 background, -2 ignored.
+// ---------------------------------------------------------------------------------------------------------
+#define HN_DET_MAXK 32
+__device__ __forceinline__ int det_assign(const float* anc, const float* ann, int Mx, float& best_iou) {
+    const float ay1 = anc[0], ax1 = anc[1], ay2 = anc[2], ax2 = anc[3];
+    const float aarea = (ay2 - ay1) * (ax2 - ax1);
+    float best = -1.f;
+    int arg = -1;
+    bool any = false;
+    for (int j = 0; j < Mx; ++j) {
+        const float* b = ann + j * 5;
+        if (b[4] == -1.f) continue;
+        any = true;
+        const float area = (b[2] - b[0]) * (b[3] - b[1]);
+        float iw = fminf(ax2, b[2]) - fmaxf(ax1, b[0]);
+        float ih = fminf(ay2, b[3]) - fmaxf(ay1, b[1]);
+        iw = fmaxf(iw, 0.f);
+        ih = fmaxf(ih, 0.f);
+        float ua = aarea + area - iw * ih;
+        ua = fmaxf(ua, 1e-8f);
+        const float iou = iw * ih / ua;
+        if (iou > best) { best = iou; arg = j; }                      // first maximum wins, like torch.max
+    }
+    best_iou = best;
+    if (!any) return -1;                                              // image without boxes: every anchor is background
+    if (best >= 0.5f) return arg;
+    if (best < 0.4f) return -1;
+    return -2;
+}
+
+__global__ __launch_bounds__(256) void det_loss_fwd_kernel(const float* cls, const float* reg, const float* anchors, const float* ann, int A,
+                                                           int K, int Mx, short* assign, float* part /* [N][blocks][3] */) {
+    __shared__ float red[4][3];
+    const int n = blockIdx.y;
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    float s_cls = 0.f, s_reg = 0.f, s_pos = 0.f;
+    if (a < A) {
+        const float* anc = anchors + (long)a * 4;
+        const float* an = ann + (long)n * Mx * 5;
+        float biou;
+        const int as = det_assign(anc, an, Mx, biou);
+        assign[(long)n * A + a] = (short)as;
+        if (as != -2) {
+            const float* c = cls + ((long)n * A + a) * K;
+            const int cid = as >= 0 ? (int)an[as * 5 + 4] : -1;
+            for (int k = 0; k < K; ++k) {
+                const float p = fminf(fmaxf(c[k], 1e-4f), 1.f - 1e-4f);
+                if (k == cid) s_cls += 0.25f * (1.f - p) * (1.f - p) * -__logf(p);
+                else s_cls += 0.75f * p * p * -__logf(1.f - p);
+            }
+        }
+        if (as >= 0) {
+            s_pos = 1.f;
+            const float* b = an + as * 5;
+            const float aw = anc[3] - anc[1], ah = anc[2] - anc[0];
+            const float acx = anc[1] + 0.5f * aw, acy = anc[0] + 0.5f * ah;
+            float gw = b[2] - b[0], gh = b[3] - b[1];
+            const float gcx = b[0] + 0.5f * gw, gcy = b[1] + 0.5f * gh;
+            gw = fmaxf(gw, 1.f);
+            gh = fmaxf(gh, 1.f);
+            const float t[4] = {(gcy - acy) / ah, (gcx - acx) / aw, __logf(gh / ah), __logf(gw / aw)};
+            const float* r = reg + ((long)n * A + a) * 4;
+            for (int q = 0; q < 4; ++q) {
+                const float d = fabsf(t[q] - r[q]);
+                s_reg += d <= 1.f / 9.f ? 0.5f * 9.f * d * d : d - 0.5f / 9.f;
+            }
+        }
+    }
+    s_cls = wave_sum(s_cls); s_reg = wave_sum(s_reg); s_pos = wave_sum(s_pos);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = s_cls; red[threadIdx.x >> 6][1] = s_reg; red[threadIdx.x >> 6][2] = s_pos; }
+    __syncthreads();
+    if (threadIdx.x < 3) part[((long)n * gridDim.x + blockIdx.x) * 3 + threadIdx.x] =
+        red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// per image: cls = sum_cls / max(npos, 1), reg = sum_reg / max(4 npos, 1) (0 without positives); outputs = batch means; npos kept for bwd
+__global__ __launch_bounds__(64) void det_loss_finalize_kernel(const float* part, int blocks, int N, float* npos, float* out /* [2] */) {
+    __shared__ float acc[2];
+    if (threadIdx.x == 0) { acc[0] = 0.f; acc[1] = 0.f; }
+    __syncthreads();
+    for (int n = 0; n < N; ++n) {
+        float c = 0.f, r = 0.f, p = 0.f;
+        for (int b = threadIdx.x; b < blocks; b += 64) {
+            const float* q = part + ((long)n * blocks + b) * 3;
+            c += q[0]; r += q[1]; p += q[2];
+        }
+        c = wave_sum(c); r = wave_sum(r); p = wave_sum(p);
+        if (threadIdx.x == 0) {
+            npos[n] = p;
+            acc[0] += c / fmaxf(p, 1.f);
+            acc[1] += p > 0.f ? r / (4.f * p) : 0.f;
+        }
+    }
+    if (threadIdx.x == 0) { out[0] = acc[0] / N; out[1] = acc[1] / N; }
+}
+
+__global__ __launch_bounds__(256) void det_loss_bwd_kernel(const float* cls, const float* reg, const float* anchors, const float* ann, int N, int A,
+                                                           int K, int Mx, const short* assign, const float* npos, const float* gout /* [2] */,
+                                                           float* dcls, float* dreg) {
+    const int n = blockIdx.y;
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    if (a >= A) return;
+    const float p_n = npos[n];
+    const float fc = gout[0] / (N * fmaxf(p_n, 1.f));
+    const float fr = p_n > 0.f ? gout[1] / (N * 4.f * p_n) : 0.f;
+    const int as = assign[(long)n * A + a];
+    const float* an = ann + (long)n * Mx * 5;
+    const float* c = cls + ((long)n * A + a) * K;
+    float* dc = dcls + ((long)n * A + a) * K;
+    const int cid = as >= 0 ? (int)an[as * 5 + 4] : -1;
+    for (int k = 0; k < K; ++k) {
+        float g = 0.f;
+        const float p = c[k];
+        if (as != -2 && p > 1e-4f && p < 1.f - 1e-4f) {                // the clamp has zero slope outside its range
+            if (k == cid) g = 0.25f * (2.f * (1.f - p) * __logf(p) - (1.f - p) * (1.f - p) / p);
+            else g = 0.75f * (-2.f * p * __logf(1.f - p) + p * p / (1.f - p));
+        }
+        dc[k] = fc * g;
+    }
+    float* dr = dreg + ((long)n * A + a) * 4;
+    if (as >= 0) {
+        const float* anc = anchors + (long)a * 4;
+        const float* b = an + as * 5;
+        const float aw = anc[3] - anc[1], ah = anc[2] - anc[0];
+        const float acx = anc[1] + 0.5f * aw, acy = anc[0] + 0.5f * ah;
+        float gw = b[2] - b[0], gh = b[3] - b[1];
+        const float gcx = b[0] + 0.5f * gw, gcy = b[1] + 0.5f * gh;
+        gw = fmaxf(gw, 1.f);
+        gh = fmaxf(gh, 1.f);
+        const float t[4] = {(gcy - acy) / ah, (gcx - acx) / aw, __logf(gh / ah), __logf(gw / aw)};
+        const float* r = reg + ((long)n * A + a) * 4;
+        for (int q = 0; q < 4; ++q) {
+            const float d = t[q] - r[q];
+            const float ad = fabsf(d);
+            dr[q] = fr * (ad <= 1.f / 9.f ? -9.f * d : (d > 0.f ? -1.f : 1.f));
+        }
+    } else {
+        dr[0] = dr[1] = dr[2] = dr[3] = 0.f;
+    }
+}
+
 // deploy-mode argmax over C channel logits (NHWC fp32, first maximum wins like torch.argmax) -> int64
 __global__ void argmax_kernel(const float* logits, int ldl, int C, long M, long* out) {
     for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (long)gridDim.x * blockDim.x) {
@@ -257,5 +402,25 @@ extern "C" int hn_argmax_channels(const float* logits, int ldl, int C, long M, l
     long blocks = (M + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(argmax_kernel, dim3(blocks), dim3(256), 0, st, logits, ldl, C, M, out);
+    HN_LAUNCH_CHECK();
+}
+
+extern "C" int hn_det_loss_blocks(int A) { return (A + 255) / 256; }
+
+// fwd: out[0] = classification loss, out[1] = regression loss (batch means); assign int16 [N][A], part fp32 [N][blocks][3], npos fp32 [N]
+extern "C" int hn_det_loss_fwd(const float* cls, const float* reg, const float* anchors, const float* ann, int N, int A, int K, int Mx,
+                               void* assign, float* part, float* npos, float* out, hipStream_t st) {
+    HN_CHECK_ARG(cls && reg && anchors && ann && assign && part && npos && out && N > 0 && A > 0 && K > 0 && K <= HN_DET_MAXK && Mx > 0);
+    const int blocks = hn_det_loss_blocks(A);
+    hipLaunchKernelGGL(det_loss_fwd_kernel, dim3(blocks, N), dim3(256), 0, st, cls, reg, anchors, ann, A, K, Mx, (short*)assign, part);
+    hipLaunchKernelGGL(det_loss_finalize_kernel, dim3(1), dim3(64), 0, st, part, blocks, N, npos, out);
+    HN_LAUNCH_CHECK();
+}
+
+extern "C" int hn_det_loss_bwd(const float* cls, const float* reg, const float* anchors, const float* ann, int N, int A, int K, int Mx,
+                               const void* assign, const float* npos, const float* gout, float* dcls, float* dreg, hipStream_t st) {
+    HN_CHECK_ARG(cls && reg && anchors && ann && assign && npos && gout && dcls && dreg && N > 0 && A > 0 && K > 0 && Mx > 0);
+    hipLaunchKernelGGL(det_loss_bwd_kernel, dim3(hn_det_loss_blocks(A), N), dim3(256), 0, st, cls, reg, anchors, ann, N, A, K, Mx,
+                       (const short*)assign, npos, gout, dcls, dreg);
     HN_LAUNCH_CHECK();
 }

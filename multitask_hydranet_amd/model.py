@@ -126,7 +126,7 @@ class HydraNet(nn.Module):
         self._declare_neck(spec)
         if self.train_detect:
             self._declare_det(spec)
-            self.loss_detect = L.det_loss
+            self.loss_detect = lambda c, r, a, g: (K.det_loss_hip if c.is_cuda else L.det_loss)(c, r, a, g)
         else:
             self.detectheader, self.loss_detect = None, None
         if self.train_seg:

@@ -704,3 +704,41 @@ def argmax_channels(seg_nchw):
     out = torch.empty((n, h, w), device=logits.device, dtype=torch.int64)
     lib().call("hn_argmax_channels", ptr(logits), logits.stride(2), c, n * h * w, ptr(out))
     return out
+
+
+# --------------------------------------------------------------------------------------------------------------
+# detection loss (focal BCE + smooth-L1 with IoU anchor assignment)
+# --------------------------------------------------------------------------------------------------------------
+class DetLoss(torch.autograd.Function):
+    """returns a 2-vector (classification loss, regression loss), both batch means like FocalLoss.forward."""
+
+    @staticmethod
+    def forward(ctx, cls, reg, anchors, ann):
+        n, a, k = cls.shape
+        mx = ann.shape[1]
+        dev = cls.device
+        cls, reg, ann = cls.contiguous(), reg.contiguous(), ann.contiguous().float()
+        anc = anchors.reshape(-1, 4).contiguous()
+        blocks = lib().query("hn_det_loss_blocks", a)
+        assign = torch.empty((n, a), device=dev, dtype=torch.int16)
+        part = torch.empty((n, blocks, 3), device=dev, dtype=F32)
+        npos = torch.empty((n,), device=dev, dtype=F32)
+        out = torch.empty((2,), device=dev, dtype=F32)
+        lib().call("hn_det_loss_fwd", ptr(cls), ptr(reg), ptr(anc), ptr(ann), n, a, k, mx, ptr(assign), ptr(part), ptr(npos), ptr(out))
+        ctx.save_for_backward(cls, reg, anc, ann, assign, npos)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        cls, reg, anc, ann, assign, npos = ctx.saved_tensors
+        n, a, k = cls.shape
+        dcls, dreg = torch.empty_like(cls), torch.empty_like(reg)
+        g = gout.contiguous().to(F32)
+        lib().call("hn_det_loss_bwd", ptr(cls), ptr(reg), ptr(anc), ptr(ann), n, a, k, ann.shape[1], ptr(assign), ptr(npos), ptr(g), ptr(dcls),
+                   ptr(dreg))
+        return dcls, dreg, None, None
+
+
+def det_loss_hip(classification, regression, anchors, annotations):
+    out = DetLoss.apply(classification, regression, anchors, annotations)
+    return out[0:1], out[1:2]

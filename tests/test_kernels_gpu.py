@@ -378,3 +378,27 @@ def test_argmax_channels_is_exact(K):
     logits[0, 0, 0, :] = 1.0                              # a tie: the first maximum wins, like torch.argmax
     got = K.argmax_channels(logits.permute(0, 3, 1, 2))
     assert torch.equal(got, torch.argmax(logits.permute(0, 3, 1, 2), dim=1))
+
+
+def test_det_loss_matches_reference_loop(K):
+    """HIP detection loss vs the oracle's per-image loop (the reference algorithm) on the recorded KAT inputs: values 1e-5, grads 1e-4."""
+    import numpy as np
+    from oracle import hydranet_oracle as O
+    from tests.helpers import load_npz
+    z = load_npz("loss_kats.npz")
+    t = lambda k: torch.from_numpy(z[k])
+    anc = t("det/anchors")
+    for ann in (t("det/ann"), torch.ones(3, 16, 5)):
+        cls = (t("det/cls") * 4.5).clamp(0, 1)                   # spread over (0, 0.9]: exercises both focal branches and the clamp
+        cls[0, :50] = 0.0
+        cls[0, 50:100] = 1.0
+        c1, r1 = cls.clone().requires_grad_(True), t("det/reg").clone().requires_grad_(True)
+        ref_c, ref_r = O.det_loss(c1, r1, anc, ann)
+        (ref_c.sum() + 50 * ref_r.sum()).backward()
+        c2, r2 = cls.clone().to(dev()).requires_grad_(True), t("det/reg").clone().to(dev()).requires_grad_(True)
+        got_c, got_r = K.det_loss_hip(c2, r2, anc.to(dev()), ann.to(dev()))
+        (got_c.sum() + 50 * got_r.sum()).backward()
+        for a, b in ((got_c, ref_c), (got_r, ref_r)):
+            assert abs(float(a) - float(b)) <= 2e-5 * max(abs(float(b)), 1e-6), (float(a), float(b))
+        close(c2.grad.cpu(), c1.grad, 2e-4, "dcls")
+        close(r2.grad.cpu(), r1.grad if r1.grad is not None else torch.zeros_like(r1), 2e-4, "dreg")   # no positives: zero gradient
