@@ -124,12 +124,12 @@ struct GemmNT {
     long img_stride; // out offset(pix) = (pix / rpi) * img_stride + (pix % rpi) * ldc  (det-head level concat)
 };
 
-template <int BC, int BP, int WGC, int WGP, bool OUT_F32>
+template <int BC, int BP, int WGC, int WGP, bool OUT_F32, int R>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
     constexpr int WC = BC / WGC, WP = BP / WGP, TC = WC / 16, TP = WP / 16;
     constexpr int XR = BP / 32, WR = (BC + 31) / 32;
     constexpr int STAGE = (BC + BP) * 128;                        // one K stage (64 k) of both operands
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // two stages, ONE array (keeps the compiler's LDS-DMA waits minimal)
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // R stages, ONE array (keeps the compiler's LDS-DMA waits minimal)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wc = wave / WGP, wp = wave % WGP;
     const int ncy = (p.Nout + BC - 1) / BC;                       // cout tiles: fastest logical index => they share the pixel tile in L2
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
 
     // 3x3 modes: the source coordinates of a tap are separable in (oy, ky) and (ox, kx), so they are tabulated once per block in LDS:
     //   ty0[ky][oy], tx0[kx][ox] in x0's grid (reflected, >> up for mode 2; -1 = outside for mode 3); ty1/tx1 in x1's full-res grid
-    int* ty0 = reinterpret_cast<int*>(smem + 2 * STAGE);
+    int* ty0 = reinterpret_cast<int*>(smem + R * STAGE);
     int* tx0 = ty0 + 3 * p.x.H;
     int* ty1 = tx0 + 3 * p.x.W;
     int* tx1 = ty1 + 3 * p.x.H;
@@ -222,14 +222,16 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
 #pragma unroll
         for (int j = 0; j < TP; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // software pipeline: iteration `it` issues the LDS-DMA of stage `it` and multiplies stage `it-1` (one barrier per stage)
-    for (int it = 0; it <= S; ++it) {
-        // LDS-DMA completion is only ordered by the issuing wave's own vmcnt wait followed by a barrier (hipcc does not add the wait
-        // for __syncthreads() here): stage it-1 has landed for every wave, and nobody still reads buffer it&1
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (it < S) {
-            char* sW = smem + (it & 1) * STAGE;
+    // software pipeline over a ring of R LDS stages: iteration `it` issues the LDS-DMA of stage `it` and multiplies stage it-(R-1).
+    // LDS-DMA completion is only ordered by the issuing wave's own counted vmcnt wait followed by a barrier: every thread issues exactly
+    // G loads per stage (also past the end: zero pieces), so "all but the newest (R-2) stages have landed" is vmcnt((R-2)*G).
+    constexpr int G = XR + WR;
+    static_assert(R == 2 || BC >= 32, "deeper rings need every wave to issue the same number of loads");
+    for (int it = 0; it < S + R - 1; ++it) {
+        if (R == 2) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((R - 2) * G) : "memory");
+        {
+            char* sW = smem + (it % R) * STAGE;
             char* sX = sW + BC * 128;
             const int q = 2 * it + half;
             const bool qv = q < Q;
@@ -246,19 +248,21 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
             }
 #pragma unroll
             for (int i = 0; i < WR; ++i) {
-                if (wave * 8 + 32 * i < BC) {                          // wave-uniform
+                if (wave * 8 + 32 * i < BC) {                          // wave-uniform (always true for BC >= 32)
                     const bf16* src = (qv && wo[i] >= 0) ? p.w + wo[i] + q * 32 : g_zero_piece;
                     glds16(src, sW + (wave * 8 + 32 * i) * 128);
                 }
             }
-            cidx += 2;
-            if (cidx >= kc) {
-                while (cidx >= kc) { cidx -= kc; ++tap; }
-                if (tap < p.taps) retap();
+            if (qv) {
+                cidx += 2;
+                if (cidx >= kc) {
+                    while (cidx >= kc) { cidx -= kc; ++tap; }
+                    if (tap < p.taps) retap();
+                }
             }
         }
-        if (it > 0) {
-            const char* sW = smem + ((it - 1) & 1) * STAGE;
+        if (it >= R - 1) {
+            const char* sW = smem + ((it - (R - 1)) % R) * STAGE;
             const char* sX = sW + BC * 128;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -276,6 +280,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
             }
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // drain the trailing zero-piece loads before the LDS is released
 
     // ---- epilogue: bias, activation, store (4 consecutive couts per lane), optional BN partial statistics
     const bool want_stats = p.psum != nullptr;
@@ -889,14 +894,31 @@ static XSrc make_xsrc(const void* x0, const void* x1, int mode, int n_img, int H
     return s;
 }
 
-template <int BC, int BP, int WGC, int WGP>
-static int launch_nt(const GemmNT& p, int out_f32, hipStream_t st) {
+template <int BC, int BP, int WGC, int WGP, int R>
+static int launch_nt_r(const GemmNT& p, int out_f32, hipStream_t st) {
     dim3 grid(cdiv(p.x.M, BP) * cdiv(p.Nout, BC));
     const size_t tables = p.x.mode >= 2 ? (size_t)(3 * p.x.H + 3 * p.x.W) * 4 * (p.x.C1 ? 2 : 1) : 0;
-    const size_t lds = (size_t)(BC + BP) * 128 * 2 + tables;
-    if (out_f32) hipLaunchKernelGGL((gemm_nt_kernel<BC, BP, WGC, WGP, true>), grid, dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((gemm_nt_kernel<BC, BP, WGC, WGP, false>), grid, dim3(256), lds, st, p);
+    const size_t lds = (size_t)(BC + BP) * 128 * R + tables;
+    if (lds > 64 * 1024) {
+        static bool optin = false;                                   // one flag per instantiation
+        if (!optin) {
+            hipFuncSetAttribute((const void*)gemm_nt_kernel<BC, BP, WGC, WGP, true, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute((const void*)gemm_nt_kernel<BC, BP, WGC, WGP, false, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            optin = true;
+        }
+    }
+    if (out_f32) hipLaunchKernelGGL((gemm_nt_kernel<BC, BP, WGC, WGP, true, R>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((gemm_nt_kernel<BC, BP, WGC, WGP, false, R>), grid, dim3(256), lds, st, p);
     HN_LAUNCH_CHECK();
+}
+
+// ring depth: launches that fit on the chip in one round (<= 2 workgroups per CU) are latency-bound -> deeper prefetch ring
+template <int BC, int BP, int WGC, int WGP, int RDEEP>
+static int launch_nt(const GemmNT& p, int out_f32, hipStream_t st) {
+    const long blocks = (long)cdiv(p.x.M, BP) * cdiv(p.Nout, BC);
+    const int stages = (p.taps * (p.KP >> 5) + 1) >> 1;
+    if (RDEEP > 2 && blocks <= 512 && stages >= 4 && p.x.mode < 2) return launch_nt_r<BC, BP, WGC, WGP, RDEEP>(p, out_f32, st);
+    return launch_nt_r<BC, BP, WGC, WGP, 2>(p, out_f32, st);
 }
 
 static int pick_bc(int Nout) {
@@ -956,10 +978,10 @@ extern "C" int hn_conv_gemm_nt(const void* x0, const void* x1, int mode, int n_i
         HN_LAUNCH_CHECK();
     }
     switch (pick_bc(Nout)) {
-        case 16: return launch_nt<16, 128, 1, 4>(p, out_f32, st);
-        case 32: return launch_nt<32, 128, 1, 4>(p, out_f32, st);
-        case 64: return launch_nt<64, 128, 2, 2>(p, out_f32, st);
-        default: return launch_nt<128, 128, 2, 2>(p, out_f32, st);
+        case 16: return launch_nt<16, 128, 1, 4, 2>(p, out_f32, st);
+        case 32: return launch_nt<32, 128, 1, 4, 4>(p, out_f32, st);
+        case 64: return launch_nt<64, 128, 2, 2, 4>(p, out_f32, st);
+        default: return launch_nt<128, 128, 2, 2, 3>(p, out_f32, st);
     }
 }
 
