@@ -86,15 +86,41 @@ def dominant_launch_roofline(net, n, h, w, iters=20):
     ach = flops / (ms * 1e-3) / 1e12
     alg_bytes = 2.0 * (n * (hh // 2) * (ww // 2) * c0 + n * hh * ww * c1 + n * hh * ww * cout + cout * cin * 9)
     return {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-            "traffic": None, "kernel": "gemm_nt_kernel<128,128,2,2,bf16> seg decoder.3 (3x3 reflect, 368->256 @ %dx%d, N=%d) fwd" % (hh, ww, n),
+            "traffic": measured_traffic(alg_bytes),
+            "kernel": "conv3x3_direct_kernel<128,bf16> seg decoder.3 (reflect-pad 3x3 over cat[up2(x), skip], 368->256 @ %dx%d, N=%d) fwd" % (hh, ww, n),
             "launch_ms": round(ms, 4), "flop_per_launch": flops, "algorithmic_bytes_per_launch": alg_bytes}
+
+
+def measured_traffic(alg_bytes):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r01_dominant_pmc.json: FETCH_SIZE
+    doubled per the gfx950 correction + WRITE_SIZE, separate passes); None if the file is absent.  PMC counters cannot be read from
+    inside this process, so the figure is the one measured with `rocprofv3 --pmc` on `bench.py --dominant-only`."""
+    path = os.path.join(ROOT, "profiles", "r01_dominant_pmc.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["hbm_bytes_per_launch"]
+    except Exception:       # noqa: BLE001
+        return None
+
+
+def usable_cores():
+    """Host cores this process may actually use: the scheduler affinity capped by the cgroup CPU quota (the GPU box reports 256 logical
+    CPUs but grants 16; running 256 threads against that quota is ~1000x slower than 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:       # noqa: BLE001
+        pass
+    return n
 
 
 def cpu_baseline(cfgs, h, w, budget_s=25.0):
     """fp32 CPU oracle (port of the reference path) on this box's host cores: N=1 fwd+loss+bwd, bounded sample."""
     from oracle import hydranet_oracle as O
     import multitask_hydranet_amd as pkg
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     net = pkg.HydraNet(cfgs)                                         # CPU parameter container only (initial weights)
     sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
@@ -114,7 +140,7 @@ def cpu_baseline(cfgs, h, w, budget_s=25.0):
     step()                                                           # warm-up
     warm = time.time() - t0
     times = []
-    while len(times) < 5 and (sum(times) + warm) < budget_s:
+    while len(times) < 10 and (sum(times) + warm) < budget_s:
         t0 = time.time()
         step()
         times.append(time.time() - t0)
@@ -137,6 +163,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one captured hipGraph per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backbone-only", action="store_true", help="BASELINE config[1]: backbone fwd+bwd, loss = sum of feature means")
+    ap.add_argument("--dominant-only", action="store_true", help="launch only the dominant kernel (for rocprofv3 --pmc passes) and exit")
     args = ap.parse_args()
     h, w = (int(v) for v in args.res.split("x"))
     rank = int(os.environ.get("RANK", "0"))
@@ -164,6 +191,9 @@ def main():
     net.check_finite = False                       # the reference's exit()-on-NaN guard is a host sync; checked once after the run instead
     net.lane_points_per_line = h // cfgs["lane"]["interval"]     # the reference default (160) raises IndexError at H=512
     broadcast_state(net)
+    if args.dominant_only:
+        print(json.dumps(dominant_launch_roofline(net, args.batch, h, w, iters=args.steps)))
+        return
     batch = synthetic_batch(cfgs, args.batch, h, w, seed=1 + rank, device=dev)
     reducer = None
     use_graph = not args.no_graph
@@ -260,7 +290,7 @@ def main():
         scale = (h * w) / (512.0 * 1024.0)
         gflop_img = 3 * FWD_GFLOP_PER_IMG_512x1024 * scale * (12.02 / 81.13 if args.backbone_only else 1.0)
         res = {
-            "metric": "images/sec (fwd+bwd) HydraNet", "value": round(value, 2), "unit": "images/sec", "n_gpus": world,
+            "metric": "images/sec (fwd+bwd) HydraNet @ default res, 1/2/4/8 MI355X; CPU-ref same run", "value": round(value, 2), "unit": "images/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": ("RegNetY backbone only" if args.backbone_only else "full HydraNet (backbone + BiFPN + seg/det/lane heads + multitask loss)")
@@ -270,6 +300,8 @@ def main():
                                                                  else "bucketed RCCL on a side stream overlapped with backward")},
             "ms_optimizer_step": round(ms_opt, 3), "loss": round(loss_val, 4),
             "model_tflops": round(value * gflop_img / 1e3, 2),
+            # SURVEY 8(d) segment-wise roofline of the whole step (seg decoder on MFMA, everything else on HBM): 0.177 ms/img at 512x1024
+            "step_roofline": {"floor_ms_per_img": round(0.177 * scale, 4), "frac": round(value / world * 0.177e-3 * scale, 4)},
         }
         try:
             res["roofline"] = dominant_launch_roofline(net, args.batch, h, w)

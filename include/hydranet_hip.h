@@ -43,6 +43,8 @@ int hn_conv_gemm_nt(const void* x0, const void* x1, int mode, int n_img, int H, 
                     const void* w, int Nout, int KP, int taps, const float* bias, int act, void* out, int out_f32, int ldc, long rpi,
                     long img_stride, float* psum, float* psq, hipStream_t stream);
 int hn_nt_stat_rows(long M, int Nout);
+/* tuning hook for tools/: force the cout tile (16/32/64/128) and LDS ring depth (2..4) of later hn_conv_gemm_nt launches; 0 = automatic */
+int hn_debug_nt_config(int bc, int r);
 
 /* wgrad: dw[Cout][Cin][taps] (PyTorch layout, fp32) = sum_pixel dz[pixel][cout] * X(pixel, tap)[c]; X modes 0..2 as above.
  * dz rows must be zero padded up to ldz >= Nout rounded up to 8.  workspace: fp32, size from hn_wgrad_plan.

@@ -61,6 +61,57 @@ __device__ __forceinline__ float act_bwd(float x, int act) {
     }
 }
 
+// Array forms: ONE uniform branch on `act` around an unrolled loop.  A per-element switch costs a scalar branch chain per value, which
+// dominated the GEMM epilogues (~1000 branches per wave for a 64x64 wave tile); hoisting it is worth 2-3x on short-K launches.
+template <int N>
+__device__ __forceinline__ void act_fwd_n(float (&v)[N], int act) {
+    if (act == HN_ACT_NONE) return;
+    if (act == HN_ACT_RELU) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+    } else if (act == HN_ACT_SWISH) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = v[k] * sigmoidf_(v[k]);
+    } else if (act == HN_ACT_ELU) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = v[k] > 0.f ? v[k] : (__expf(v[k]) - 1.0f);
+    } else {
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = sigmoidf_(v[k]);
+    }
+}
+// g[k] *= act'(x[k])
+template <int N>
+__device__ __forceinline__ void act_bwd_n(const float (&x)[N], float (&g)[N], int act) {
+    if (act == HN_ACT_NONE) return;
+    if (act == HN_ACT_RELU) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) g[k] = x[k] > 0.f ? g[k] : 0.f;
+    } else if (act == HN_ACT_SWISH) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) { const float s = sigmoidf_(x[k]); g[k] *= s * (1.f + x[k] * (1.f - s)); }
+    } else if (act == HN_ACT_ELU) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) g[k] *= x[k] > 0.f ? 1.f : __expf(x[k]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < N; ++k) { const float s = sigmoidf_(x[k]); g[k] *= s * (1.f - s); }
+    }
+}
+
+// sum over each row of 16 lanes (all 16 get the total): DPP row rotations are plain VALU ops, ~10x cheaper than ds_bpermute shuffles
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<0x128>(v);   // row_ror:8
+    v += dpp_mov<0x124>(v);   // row_ror:4
+    v += dpp_mov<0x122>(v);   // row_ror:2
+    v += dpp_mov<0x121>(v);   // row_ror:1
+    return v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

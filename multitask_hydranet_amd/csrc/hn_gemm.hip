@@ -222,15 +222,20 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
 #pragma unroll
         for (int j = 0; j < TP; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // software pipeline over a ring of R LDS stages: iteration `it` issues the LDS-DMA of stage `it` and multiplies stage it-(R-1).
-    // LDS-DMA completion is only ordered by the issuing wave's own counted vmcnt wait followed by a barrier: every thread issues exactly
-    // G loads per stage (also past the end: zero pieces), so "all but the newest (R-2) stages have landed" is vmcnt((R-2)*G).
+    // software pipeline over a ring of R LDS stages.  Iteration `it` issues the LDS-DMA of stage `it` (while it < S) and multiplies stage
+    // c = it-(R-1).  LDS-DMA completion is only ordered by the issuing wave's own counted vmcnt wait followed by a barrier: every thread
+    // issues exactly G loads per stage, so "stage c has landed" is vmcnt(newer * G) with newer = stages issued after c.  The first R-1
+    // stages go out back to back (one memory latency for short K instead of one per stage); nothing is issued past the last stage.
     constexpr int G = XR + WR;
     static_assert(R == 2 || BC >= 32, "deeper rings need every wave to issue the same number of loads");
     for (int it = 0; it < S + R - 1; ++it) {
-        if (R == 2) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((R - 2) * G) : "memory");
-        {
+        if (it >= R - 1) {
+            const int newer = (it < S ? it : S) - 1 - (it - (R - 1));
+            if (R >= 4 && newer >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * G) : "memory");
+            else if (R >= 3 && newer >= 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(G) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        if (it < S) {
             char* sW = smem + (it % R) * STAGE;
             char* sX = sW + BC * 128;
             const int q = 2 * it + half;
@@ -280,33 +285,86 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
             }
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // drain the trailing zero-piece loads before the LDS is released
 
-    // ---- epilogue: bias, activation, store (4 consecutive couts per lane), optional BN partial statistics
+    // ---- epilogue: bias, activation, optional BN partial statistics; store.  bf16 outputs whose rows are 16-B aligned go through an
+    // LDS tile ([BP][BC], 16-B pieces XOR-swizzled by the pixel row) so that every wave writes whole contiguous row segments; the
+    // remaining cases (fp32 head outputs, ragged Nout) store 4 consecutive couts per lane directly.
     const bool want_stats = p.psum != nullptr;
+    constexpr int NPC = BC / 8;                                       // 16-B pieces per staged row
+    const bool staged = !OUT_F32 && (p.Nout & 7) == 0 && (p.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0 &&
+                        (p.rpi == 0 || (p.img_stride & 7) == 0);
+    if (staged) __syncthreads();                                      // every wave is done reading the last K stage
+    float vv[TC * TP * 4];                                            // the wave tile, flat: one uniform activation branch for all of it
 #pragma unroll
     for (int i = 0; i < TC; ++i) {
         const int co0 = c_blk + wc * WC + i * 16 + (lane >> 4) * 4;
         float bsv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) bsv[r] = (p.bias && co0 + r < p.Nout) ? p.bias[co0 + r] : 0.f;
-        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < TP; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vv[(i * TP + j) * 4 + r] = acc[i][j][r] + bsv[r];
+    }
+    if (want_stats) {
+#pragma unroll
+        for (int i = 0; i < TC; ++i) {
+            const int co0 = c_blk + wc * WC + i * 16 + (lane >> 4) * 4;
+            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                const bool pv = p_blk + wp * WP + j * 16 + (lane & 15) < p.x.M;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float q = OUT_F32 ? vv[(i * TP + j) * 4 + r] : bfround(vv[(i * TP + j) * 4 + r]);
+                    q = pv ? q : 0.f;
+                    s1[r] += q;
+                    s2[r] += q * q;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s1[r] = row16_sum(s1[r]);
+                s2[r] = row16_sum(s2[r]);
+            }
+            if ((lane & 15) == 0) {
+                const long prow = (long)p_tile * WGP + wp;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (co0 + r < p.Nout) {
+                        p.psum[prow * p.Nout + co0 + r] = s1[r];
+                        p.psq[prow * p.Nout + co0 + r] = s2[r];
+                    }
+            }
+        }
+    }
+    act_fwd_n(vv, p.act);
+    if (staged) {
+#pragma unroll
+        for (int i = 0; i < TC; ++i) {
+            const int col = wc * WC + i * 16 + (lane >> 4) * 4;
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                const int prow_l = wp * WP + j * 16 + (lane & 15);
+                const float* v = vv + (i * TP + j) * 4;
+                bf16x4 t = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                *reinterpret_cast<bf16x4*>(smem + prow_l * (BC * 2) + ((((col >> 3) ^ prow_l) & (NPC - 1)) << 4) + ((col >> 2) & 1) * 8) = t;
+            }
+        }
+    } else {
 #pragma unroll
         for (int j = 0; j < TP; ++j) {
             const long pix = p_blk + wp * WP + j * 16 + (lane & 15);
-            const bool pv = pix < p.x.M;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[r] = acc[i][j][r] + bsv[r];
-                if (want_stats) {
-                    const float q = OUT_F32 ? v[r] : bfround(v[r]);
-                    if (pv) { s1[r] += q; s2[r] += q * q; }
-                }
-                v[r] = act_fwd(v[r], p.act);
+            if (pix >= p.x.M) continue;
+            long orow = pix * p.ldc;
+            if (p.rpi) {
+                const unsigned im = (unsigned)pix / (unsigned)p.rpi;
+                orow = (long)im * p.img_stride + (long)((unsigned)pix - im * (unsigned)p.rpi) * p.ldc;
             }
-            if (pv) {
-                const long orow = p.rpi ? (pix / p.rpi) * p.img_stride + (pix % p.rpi) * p.ldc : pix * p.ldc;
+#pragma unroll
+            for (int i = 0; i < TC; ++i) {
+                const int co0 = c_blk + wc * WC + i * 16 + (lane >> 4) * 4;
+                const float* v = vv + (i * TP + j) * 4;
                 if (OUT_F32) {
                     float* o = reinterpret_cast<float*>(p.out) + orow + co0;
                     if (co0 + 3 < p.Nout && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
@@ -327,23 +385,23 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
                 }
             }
         }
-        if (want_stats) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    s1[r] += __shfl_xor(s1[r], o);
-                    s2[r] += __shfl_xor(s2[r], o);
+    }
+    if (staged) {
+        __syncthreads();
+        bf16* outp = reinterpret_cast<bf16*>(p.out);
+#pragma unroll 2
+        for (int idx = tid; idx < BP * NPC; idx += 256) {
+            const int row = idx / NPC, pc = idx % NPC;
+            const long pix = p_blk + row;
+            const int co = c_blk + pc * 8;
+            if (pix < p.x.M && co < p.Nout) {
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + row * (BC * 2) + (((pc ^ row) & (NPC - 1)) << 4));
+                long orow = pix * p.ldc;
+                if (p.rpi) {
+                    const unsigned im = (unsigned)pix / (unsigned)p.rpi;
+                    orow = (long)im * p.img_stride + (long)((unsigned)pix - im * (unsigned)p.rpi) * p.ldc;
                 }
-            }
-            if ((lane & 15) == 0) {
-                const long prow = (long)p_tile * WGP + wp;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (co0 + r < p.Nout) {
-                        p.psum[prow * p.Nout + co0 + r] = s1[r];
-                        p.psq[prow * p.Nout + co0 + r] = s2[r];
-                    }
+                *reinterpret_cast<bf16x8*>(outp + orow + co) = v;
             }
         }
     }
@@ -487,8 +545,9 @@ __global__ __launch_bounds__(512) void conv3x3_direct_kernel(const GemmNT p) {
         }
     }
 
-    // epilogue: bias, activation, store 4 consecutive couts per lane
+    // epilogue: bias, activation (one uniform branch for the whole wave tile), store 4 consecutive couts per lane
     const int ox = ox0 + (lane & 15);
+    float vv[TC * TP * 4];
 #pragma unroll
     for (int i = 0; i < TC; ++i) {
         const int co0 = c_blk + wc * WCO + i * 16 + (lane >> 4) * 4;
@@ -496,13 +555,20 @@ __global__ __launch_bounds__(512) void conv3x3_direct_kernel(const GemmNT p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) bsv[r] = (p.bias && co0 + r < p.Nout) ? p.bias[co0 + r] : 0.f;
 #pragma unroll
-        for (int j = 0; j < TP; ++j) {
-            const int oy = oy0 + wp * ROWS + j;
-            if (oy >= xs.H || ox >= xs.W) continue;
-            const long orow = ((long)(n * xs.H + oy) * xs.W + ox) * p.ldc;
-            float v[4];
+        for (int j = 0; j < TP; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = act_fwd(acc[i][j][r] + bsv[r], p.act);
+            for (int r = 0; r < 4; ++r) vv[(i * TP + j) * 4 + r] = acc[i][j][r] + bsv[r];
+    }
+    act_fwd_n(vv, p.act);
+#pragma unroll
+    for (int j = 0; j < TP; ++j) {
+        const int oy = oy0 + wp * ROWS + j;
+        if (oy >= xs.H || ox >= xs.W) continue;
+        const long orow = ((long)(n * xs.H + oy) * xs.W + ox) * p.ldc;
+#pragma unroll
+        for (int i = 0; i < TC; ++i) {
+            const int co0 = c_blk + wc * WCO + i * 16 + (lane >> 4) * 4;
+            const float* v = vv + (i * TP + j) * 4;
             if (OUT_F32) {
                 float* o = reinterpret_cast<float*>(p.out) + orow + co0;
                 if (co0 + 3 < p.Nout && (reinterpret_cast<uintptr_t>(o) & 15) == 0) *reinterpret_cast<f32x4*>(o) = (f32x4){v[0], v[1], v[2], v[3]};
@@ -912,16 +978,27 @@ static int launch_nt_r(const GemmNT& p, int out_f32, hipStream_t st) {
     HN_LAUNCH_CHECK();
 }
 
-// ring depth: launches that fit on the chip in one round (<= 2 workgroups per CU) are latency-bound -> deeper prefetch ring
+// Tuning hook (tools/ only): force the cout tile and/or ring depth of the next hn_conv_gemm_nt launches; 0 = automatic.
+static int g_nt_force_bc = 0, g_nt_force_r = 0;
+extern "C" int hn_debug_nt_config(int bc, int r) { g_nt_force_bc = bc; g_nt_force_r = r; return 0; }
+
+// Ring depth: R = 2 (double buffer) in production; R = 3/4 stay instantiated behind the tuning hook.
 template <int BC, int BP, int WGC, int WGP, int RDEEP>
 static int launch_nt(const GemmNT& p, int out_f32, hipStream_t st) {
     const long blocks = (long)cdiv(p.x.M, BP) * cdiv(p.Nout, BC);
     const int stages = (p.taps * (p.KP >> 5) + 1) >> 1;
-    if (RDEEP > 2 && blocks <= 512 && stages >= 4 && p.x.mode < 2) return launch_nt_r<BC, BP, WGC, WGP, RDEEP>(p, out_f32, st);
+    int r = 2;     // measured: the deeper rings never beat the double buffer (their LDS footprint costs the second resident workgroup)
+    (void)blocks; (void)stages;
+    if (g_nt_force_r && BC >= 32) r = g_nt_force_r;
+    if (BC >= 32) {
+        if (r == 3) return launch_nt_r<BC, BP, WGC, WGP, (BC >= 32 ? 3 : 2)>(p, out_f32, st);
+        if (r == 4) return launch_nt_r<BC, BP, WGC, WGP, (BC >= 32 ? 4 : 2)>(p, out_f32, st);
+    }
     return launch_nt_r<BC, BP, WGC, WGP, 2>(p, out_f32, st);
 }
 
 static int pick_bc(int Nout) {
+    if (g_nt_force_bc) return g_nt_force_bc;
     if (Nout <= 16) return 16;
     if (Nout <= 32) return 32;
     if (Nout <= 64) return 64;
@@ -981,7 +1058,7 @@ extern "C" int hn_conv_gemm_nt(const void* x0, const void* x1, int mode, int n_i
         case 16: return launch_nt<16, 128, 1, 4, 2>(p, out_f32, st);
         case 32: return launch_nt<32, 128, 1, 4, 4>(p, out_f32, st);
         case 64: return launch_nt<64, 128, 2, 2, 4>(p, out_f32, st);
-        default: return launch_nt<128, 128, 2, 2, 3>(p, out_f32, st);
+        default: return launch_nt<128, 128, 2, 2, 4>(p, out_f32, st);
     }
 }
 

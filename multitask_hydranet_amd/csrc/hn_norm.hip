@@ -61,14 +61,22 @@ __global__ __launch_bounds__(256) void colred_kernel(const ColRed p) {
                 const bf16x8 vz = ld8(p.b + m * p.ldb + cg * 8);
                 bf16x8 vy;
                 if (p.y) vy = ld8(p.y + m * p.ldy + cg * 8);
+                float z[8], g[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { z[k] = bf2f(vz[k]); g[k] = bf2f(va[k]); }
+                if (p.y) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) g[k] = bf2f(vy[k]) > 0.f ? g[k] : 0.f;
+                } else {
+                    float pre[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) pre[k] = sc[k] * z[k] + sh[k];
+                    act_bwd_n(pre, g, p.act);
+                }
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const float z = bf2f(vz[k]);
-                    float g = bf2f(va[k]);
-                    if (p.y) g = bf2f(vy[k]) > 0.f ? g : 0.f;
-                    else g *= act_bwd(sc[k] * z + sh[k], p.act);
-                    s1[k] += g;
-                    s2[k] += g * (z - mu[k]) * rs[k];
+                    s1[k] += g[k];
+                    s2[k] += g[k] * (z[k] - mu[k]) * rs[k];
                 }
             }
         }
@@ -194,12 +202,16 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const BnAct p) {
         bf16x8 vr;
         if (p.res) vr = ld8(p.res + m * p.ldr + c);
         bf16x8 o;
+        float v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            float v = bf2f(vz[k]) * sc[k] + sh[k];
-            if (p.res) v += bf2f(vr[k]) * rsc[k] + rsh[k];
-            o[k] = f2bf(act_fwd(v, p.act));
+        for (int k = 0; k < 8; ++k) v[k] = bf2f(vz[k]) * sc[k] + sh[k];
+        if (p.res) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += bf2f(vr[k]) * rsc[k] + rsh[k];
         }
+        act_fwd_n(v, p.act);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = f2bf(v[k]);
         st8(p.out + m * p.ldo + c, o);
     }
 }
@@ -228,15 +240,23 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApply p) {
         bf16x8 vy;
         if (p.y) vy = ld8(p.y + m * p.ldy + c);
         bf16x8 o, og;
+        float z[8], g[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { z[k] = bf2f(vz[k]); g[k] = bf2f(vd[k]); }
+        if (p.y) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) g[k] = bf2f(vy[k]) > 0.f ? g[k] : 0.f;
+        } else {
+            float pre[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) pre[k] = sc[k] * z[k] + sh[k];
+            act_bwd_n(pre, g, p.act);
+        }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const float z = bf2f(vz[k]);
-            float g = bf2f(vd[k]);
-            if (p.y) g = bf2f(vy[k]) > 0.f ? g : 0.f;
-            else g *= act_bwd(sc[k] * z + sh[k], p.act);
-            const float xh = (z - mu[k]) * rs[k];
-            o[k] = f2bf(sc[k] * (g - mg[k] - xh * mgx[k]));
-            og[k] = f2bf(g);
+            const float xh = (z[k] - mu[k]) * rs[k];
+            o[k] = f2bf(sc[k] * (g[k] - mg[k] - xh * mgx[k]));
+            og[k] = f2bf(g[k]);
         }
         st8(p.dz + m * p.lddz + c, o);
         if (p.gout) st8(p.gout + m * p.ldg + c, og);
@@ -292,19 +312,27 @@ __global__ __launch_bounds__(256) void ew_kernel(const Ew p) {
         bf16x8 vb;
         if (p.b) vb = ld8(p.b + m * p.ldb + c);
         bf16x8 o;
+        float a[8], b[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float a = bf2f(va[k]);
-            float r;
-            if (p.op == 0) r = a + bf2f(vb[k]);
-            else if (p.op == 1) {
-                const float y = bf2f(vb[k]);
-                r = p.act == HN_ACT_ELU ? (y > 0.f ? a : a * (y + 1.0f)) : (y > 0.f ? a : 0.f);
-            } else if (p.op == 2) r = p.alpha * a;
-            else if (p.op == 3) r = act_fwd(a, p.act);
-            else r = a * act_bwd(bf2f(vb[k]), p.act);
-            o[k] = f2bf(r);
-        }
+        for (int k = 0; k < 8; ++k) { a[k] = bf2f(va[k]); b[k] = p.b ? bf2f(vb[k]) : 0.f; }
+        if (p.op == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] += b[k];
+        } else if (p.op == 1) {
+            if (p.act == HN_ACT_ELU) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a[k] = b[k] > 0.f ? a[k] : a[k] * (b[k] + 1.0f);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a[k] = b[k] > 0.f ? a[k] : 0.f;
+            }
+        } else if (p.op == 2) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] *= p.alpha;
+        } else if (p.op == 3) act_fwd_n(a, p.act);
+        else act_bwd_n(b, a, p.act);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = f2bf(a[k]);
         st8(p.out + m * p.ldo + c, o);
     }
 }

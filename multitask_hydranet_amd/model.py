@@ -120,6 +120,7 @@ class HydraNet(nn.Module):
         self._pending_nbt = []
         self.heads_on_side_stream = False          # measured: no gain over the single-stream graph on MI355X (kept for experiments)
         self._side_streams = {}
+        self.levels_on_streams = False      # hipGraph branches cost more than they hide on gfx950 (55 vs 43 ms)
 
         spec = _Spec(self)
         self._declare_backbone(spec)
@@ -392,15 +393,40 @@ class HydraNet(nn.Module):
             self._anchor_cache[key] = a
         return self._anchor_cache[key]
 
+    def _streams(self, device, count):
+        pool = self._side_streams.setdefault(device, [])
+        while len(pool) < count:
+            pool.append(torch.cuda.Stream(device=device))
+        return pool[:count]
+
     def _det_tower(self, p, fused, k, act):
+        """Regressor / Classifier (head_detect/detection.py:26-44, 63-83).  The five pyramid levels are independent chains of small
+        launches (dw 3x3 -> 1x1+BN statistics -> BN+Swish, three times): each level runs on its own HIP stream, forked from and joined
+        to the caller's stream with events (legal inside hipGraph capture; autograd replays the assignment in backward)."""
         P = self._idx
         layers = self.cfgs["detection"]["box_class_repeats"]
+        dev = fused[0].device
+        multi = self.levels_on_streams and fused[0].is_cuda
+        cur = torch.cuda.current_stream() if multi else None
+        streams = self._streams(dev, len(fused)) if multi else [None] * len(fused)
+        # pack the shared weights once, on the caller's stream, before the fork
+        for i in range(layers):
+            K.pack_dw_weight(P[f"{p}conv_list.{i}.depthwise_conv.conv.weight"])
+            K.pack_conv_weight(P[f"{p}conv_list.{i}.pointwise_conv.conv.weight"])
         outs = []
         for lv, f in enumerate(fused):
-            for i in range(layers):
-                d = K.DwConv.apply(f, P[f"{p}conv_list.{i}.depthwise_conv.conv.weight"])
-                f = self._cba(d, f"{p}conv_list.{i}.pointwise_conv.conv", f"{p}bn_list.{lv}.{i}", BN_FPN, act=ACT_SWISH)
+            st = streams[lv]
+            if st is not None:
+                st.wait_stream(cur)
+            with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
+                for i in range(layers):
+                    d = K.DwConv.apply(f, P[f"{p}conv_list.{i}.depthwise_conv.conv.weight"])
+                    f = self._cba(d, f"{p}conv_list.{i}.pointwise_conv.conv", f"{p}bn_list.{lv}.{i}", BN_FPN, act=ACT_SWISH)
             outs.append(f)
+        if multi:
+            for st, f in zip(streams, outs):
+                cur.wait_stream(st)
+                f.record_stream(cur)
         return K.HeadOut.apply(P[p + "header.depthwise_conv.conv.weight"], P[p + "header.pointwise_conv.conv.weight"],
                                P[p + "header.pointwise_conv.conv.bias"], k, act, *outs)
 
@@ -440,9 +466,7 @@ class HydraNet(nn.Module):
         side = None
         if self.heads_on_side_stream and x.is_cuda and (self.train_detect or self.train_lane) and self.train_seg:
             cur = torch.cuda.current_stream()
-            side = self._side_streams.get(x.device)
-            if side is None:
-                side = self._side_streams[x.device] = torch.cuda.Stream(device=x.device)
+            side = self._streams(x.device, 6)[5]
             side.wait_stream(cur)
         with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
             if self.train_detect:

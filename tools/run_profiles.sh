@@ -1,0 +1,18 @@
+#!/bin/bash
+# Round-end measurement on the GPU box: default bench line, rocprofv3 kernel stats of the same command, PMC passes on the dominant launch.
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/prof
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+cd $R
+python bench.py > $O/bench_default.log 2>&1
+tail -1 $O/bench_default.log > $O/bench_n1.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py --no-cpu-baseline > $O/bench_rocprof.log 2>&1
+f=$(find $O/kt -name "*kernel_stats.csv" | head -1); cp "$f" $O/kernel_stats.csv
+t=$(find $O/kt -name "*kernel_trace.csv" | head -1); head -1 "$t" > $O/dominant_dispatches.csv; grep "conv3x3_direct_kernel<128" "$t" | tail -400 >> $O/dominant_dispatches.csv
+rm -rf $O/kt
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- python3 bench.py --dominant-only --steps 10 > $O/pmc_$c.log 2>&1
+  f=$(find $O/pmc_$c -name "*counter_collection.csv" | head -1); head -1 "$f" > $O/pmc_$c.csv; grep "conv3x3_direct" "$f" >> $O/pmc_$c.csv
+  rm -rf $O/pmc_$c
+done
