@@ -27,7 +27,7 @@ struct ColRed {
 
 template <int MODE>
 __global__ __launch_bounds__(256) void colred_kernel(const ColRed p) {
-    __shared__ float red[2][256 * 8];
+    __shared__ float red[4][256 * 8];                 // [0..1]: the block's partial sums; all four: MODE 2 coefficient staging (C <= 2048)
     const int C8 = p.C >> 3;
     const int tid = threadIdx.x;
     const int rpi = 256 / C8 > 0 ? 256 / C8 : 1;      // rows per iteration (C8 <= 256 enforced on the host)
@@ -40,30 +40,34 @@ __global__ __launch_bounds__(256) void colred_kernel(const ColRed p) {
     long m1 = m0 + p.R;
     if (m1 > p.M) m1 = p.M;
     float sc[8], sh[8], mu[8], rs[8];
-    if (MODE == 2 && active) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int c = cg * 8 + k;
-            sc[k] = p.scale[c]; sh[k] = p.shift[c]; mu[k] = p.mean[c]; rs[k] = p.rstd[c];
+    if (MODE == 2) {                                  // stage the 4 x C coefficients through LDS once per block (red is free until the end)
+        float* cf = &red[0][0];
+        for (int i = tid; i < p.C; i += 256) {
+            cf[i] = p.scale[i]; cf[p.C + i] = p.shift[i]; cf[2 * p.C + i] = p.mean[i]; cf[3 * p.C + i] = p.rstd[i];
         }
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int c = cg * 8 + k;
+                sc[k] = cf[c]; sh[k] = cf[p.C + c]; mu[k] = cf[2 * p.C + c]; rs[k] = cf[3 * p.C + c];
+            }
+        }
+        __syncthreads();
     }
     if (active) {
-        for (long m = m0 + rr; m < m1; m += rpi) {
-            const bf16x8 va = ld8(p.a + m * p.lda + cg * 8);
+        // two rows in flight per thread: the loads of both iterations are issued before either is consumed
+        auto accum = [&](const bf16x8& va, const bf16x8& vb, const bf16x8& vy) {
             if (MODE == 0) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { const float v = bf2f(va[k]); s1[k] += v; s2[k] += v * v; }
             } else if (MODE == 1) {
-                const bf16x8 vb = ld8(p.b + m * p.ldb + cg * 8);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { const float v = bf2f(va[k]); s1[k] += v * bf2f(vb[k]); s2[k] += v; }
             } else {
-                const bf16x8 vz = ld8(p.b + m * p.ldb + cg * 8);
-                bf16x8 vy;
-                if (p.y) vy = ld8(p.y + m * p.ldy + cg * 8);
                 float z[8], g[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) { z[k] = bf2f(vz[k]); g[k] = bf2f(va[k]); }
+                for (int k = 0; k < 8; ++k) { z[k] = bf2f(vb[k]); g[k] = bf2f(va[k]); }
                 if (p.y) {
 #pragma unroll
                     for (int k = 0; k < 8; ++k) g[k] = bf2f(vy[k]) > 0.f ? g[k] : 0.f;
@@ -79,6 +83,23 @@ __global__ __launch_bounds__(256) void colred_kernel(const ColRed p) {
                     s2[k] += g[k] * (z[k] - mu[k]) * rs[k];
                 }
             }
+        };
+        long m = m0 + rr;
+        for (; m + rpi < m1; m += 2 * rpi) {
+            const long mb = m + rpi;
+            const bf16x8 va0 = ld8(p.a + m * p.lda + cg * 8), va1 = ld8(p.a + mb * p.lda + cg * 8);
+            bf16x8 vb0 = va0, vb1 = va1, vy0 = va0, vy1 = va1;
+            if (MODE >= 1) { vb0 = ld8(p.b + m * p.ldb + cg * 8); vb1 = ld8(p.b + mb * p.ldb + cg * 8); }
+            if (MODE == 2 && p.y) { vy0 = ld8(p.y + m * p.ldy + cg * 8); vy1 = ld8(p.y + mb * p.ldy + cg * 8); }
+            accum(va0, vb0, vy0);
+            accum(va1, vb1, vy1);
+        }
+        if (m < m1) {
+            const bf16x8 va0 = ld8(p.a + m * p.lda + cg * 8);
+            bf16x8 vb0 = va0, vy0 = va0;
+            if (MODE >= 1) vb0 = ld8(p.b + m * p.ldb + cg * 8);
+            if (MODE == 2 && p.y) vy0 = ld8(p.y + m * p.ldy + cg * 8);
+            accum(va0, vb0, vy0);
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) { red[0][tid * 8 + k] = s1[k]; red[1][tid * 8 + k] = s2[k]; }
@@ -121,16 +142,21 @@ __global__ __launch_bounds__(512) void rows_reduce_kernel(const float* in, float
 //   mean, biased var -> rstd, scale = gamma*rstd, shift = beta - mean*scale, and updates the running statistics
 //   (unbiased variance, PyTorch momentum convention) -- F.batch_norm semantics.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void bn_finalize_kernel(const float* psum, const float* psq, int prows, int C, double count,
-                                                         const float* gamma, const float* beta, float eps, float momentum,
-                                                         float* running_mean, float* running_var, float* scale, float* shift,
-                                                         float* mean, float* rstd) {
-    const int c = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* psum, const float* psq, int prows, int C, double count,
+                                                          const float* gamma, const float* beta, float eps, float momentum,
+                                                          float* running_mean, float* running_var, float* scale, float* shift,
+                                                          float* mean, float* rstd) {
+    __shared__ double r1[32][33], r2[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + tx;
     double s1 = 0.0, s2 = 0.0;
-    for (int r = lane; r < prows; r += 64) { s1 += psum[(long)r * C + c]; s2 += psq[(long)r * C + c]; }
+    if (c < C)
+        for (int r = ty; r < prows; r += 32) { s1 += psum[(long)r * C + c]; s2 += psq[(long)r * C + c]; }
+    r1[ty][tx] = s1; r2[ty][tx] = s2;
+    __syncthreads();
+    if (ty == 0 && c < C) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-    if (lane == 0) {
+        for (int k = 1; k < 32; ++k) { s1 += r1[k][tx]; s2 += r2[k][tx]; }
         const double mu = s1 / count;
         double var = s2 / count - mu * mu;
         if (var < 0.0) var = 0.0;
@@ -159,14 +185,19 @@ __global__ void bn_eval_coeff_kernel(const float* gamma, const float* beta, cons
 }
 
 // dgamma = sum g*xhat, dbeta = sum g, and the two per-channel means the apply pass needs
-__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* pg, const float* pgx, int prows, int C, double count,
-                                                             float* dgamma, float* dbeta, float* mg, float* mgx) {
-    const int c = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* pg, const float* pgx, int prows, int C, double count,
+                                                              float* dgamma, float* dbeta, float* mg, float* mgx) {
+    __shared__ double r1[32][33], r2[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + tx;
     double s1 = 0.0, s2 = 0.0;
-    for (int r = lane; r < prows; r += 64) { s1 += pg[(long)r * C + c]; s2 += pgx[(long)r * C + c]; }
+    if (c < C)
+        for (int r = ty; r < prows; r += 32) { s1 += pg[(long)r * C + c]; s2 += pgx[(long)r * C + c]; }
+    r1[ty][tx] = s1; r2[ty][tx] = s2;
+    __syncthreads();
+    if (ty == 0 && c < C) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-    if (lane == 0) {
+        for (int k = 1; k < 32; ++k) { s1 += r1[k][tx]; s2 += r2[k][tx]; }
         dbeta[c] = (float)s1;
         dgamma[c] = (float)s2;
         mg[c] = (float)(s1 / count);
@@ -182,8 +213,17 @@ struct BnAct {
     const bf16* res; int ldr; const float* rscale; const float* rshift;   // optional residual (+ its own BN)
     int act; bf16* out; int ldo; long M; int C;
 };
-// thread = one 8-channel group; its per-channel coefficients stay in registers while it walks rows (256 / C8 rows per block pass)
+// thread = one 8-channel group; the block stages the per-channel coefficients in LDS once (a per-thread global fetch of 4 x 32 B of
+// coefficients for every 16 B of data dominated the small layers), each thread keeps its slice in registers while it walks rows
+// (256 / C8 rows per block pass), two rows in flight.
 __global__ __launch_bounds__(256) void bn_act_kernel(const BnAct p) {
+    extern __shared__ float coefs[];                      // [4][C]: scale, shift, rscale, rshift
+    for (int i = threadIdx.x; i < p.C; i += 256) {
+        coefs[i] = p.scale ? p.scale[i] : 1.f;
+        coefs[p.C + i] = p.scale ? p.shift[i] : 0.f;
+        if (p.rscale) { coefs[2 * p.C + i] = p.rscale[i]; coefs[3 * p.C + i] = p.rshift[i]; }
+    }
+    __syncthreads();
     const int C8 = p.C >> 3;
     const int rpb = 256 / C8 > 0 ? 256 / C8 : 1;
     const int cg = threadIdx.x % C8, rr = threadIdx.x / C8;
@@ -192,15 +232,12 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const BnAct p) {
     float sc[8], sh[8], rsc[8], rsh[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        sc[k] = p.scale ? p.scale[c + k] : 1.f;
-        sh[k] = p.scale ? p.shift[c + k] : 0.f;
-        rsc[k] = p.rscale ? p.rscale[c + k] : 1.f;
-        rsh[k] = p.rscale ? p.rshift[c + k] : 0.f;
+        sc[k] = coefs[c + k];
+        sh[k] = coefs[p.C + c + k];
+        rsc[k] = p.rscale ? coefs[2 * p.C + c + k] : 1.f;
+        rsh[k] = p.rscale ? coefs[3 * p.C + c + k] : 0.f;
     }
-    for (long m = (long)blockIdx.x * rpb + rr; m < p.M; m += (long)gridDim.x * rpb) {
-        const bf16x8 vz = ld8(p.z + m * p.ldz + c);
-        bf16x8 vr;
-        if (p.res) vr = ld8(p.res + m * p.ldr + c);
+    auto apply = [&](const bf16x8& vz, const bf16x8& vr, long m) {
         bf16x8 o;
         float v[8];
 #pragma unroll
@@ -213,6 +250,22 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const BnAct p) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) o[k] = f2bf(v[k]);
         st8(p.out + m * p.ldo + c, o);
+    };
+    const long step = (long)gridDim.x * rpb;
+    long m = (long)blockIdx.x * rpb + rr;
+    for (; m + step < p.M; m += 2 * step) {
+        const long mb = m + step;
+        const bf16x8 vz0 = ld8(p.z + m * p.ldz + c), vz1 = ld8(p.z + mb * p.ldz + c);
+        bf16x8 vr0 = vz0, vr1 = vz1;
+        if (p.res) { vr0 = ld8(p.res + m * p.ldr + c); vr1 = ld8(p.res + mb * p.ldr + c); }
+        apply(vz0, vr0, m);
+        apply(vz1, vr1, mb);
+    }
+    if (m < p.M) {
+        const bf16x8 vz0 = ld8(p.z + m * p.ldz + c);
+        bf16x8 vr0 = vz0;
+        if (p.res) vr0 = ld8(p.res + m * p.ldr + c);
+        apply(vz0, vr0, m);
     }
 }
 
@@ -223,6 +276,12 @@ struct BnBwdApply {
 };
 // dz = scale * (g - mean(g) - xhat * mean(g*xhat)),  g = dout * act'(pre)   (optionally also emits g)
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApply p) {
+    extern __shared__ float coefs[];                      // [6][C]: scale, shift, mean, rstd, mean(g), mean(g*xhat)
+    for (int i = threadIdx.x; i < p.C; i += 256) {
+        coefs[i] = p.scale[i]; coefs[p.C + i] = p.shift[i]; coefs[2 * p.C + i] = p.mean[i]; coefs[3 * p.C + i] = p.rstd[i];
+        coefs[4 * p.C + i] = p.mg[i]; coefs[5 * p.C + i] = p.mgx[i];
+    }
+    __syncthreads();
     const int C8 = p.C >> 3;
     const int rpb = 256 / C8 > 0 ? 256 / C8 : 1;
     const int cg = threadIdx.x % C8, rr = threadIdx.x / C8;
@@ -231,14 +290,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApply p) {
     float sc[8], sh[8], mu[8], rs[8], mg[8], mgx[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        sc[k] = p.scale[c + k]; sh[k] = p.shift[c + k]; mu[k] = p.mean[c + k]; rs[k] = p.rstd[c + k];
-        mg[k] = p.mg[c + k]; mgx[k] = p.mgx[c + k];
+        sc[k] = coefs[c + k]; sh[k] = coefs[p.C + c + k]; mu[k] = coefs[2 * p.C + c + k]; rs[k] = coefs[3 * p.C + c + k];
+        mg[k] = coefs[4 * p.C + c + k]; mgx[k] = coefs[5 * p.C + c + k];
     }
-    for (long m = (long)blockIdx.x * rpb + rr; m < p.M; m += (long)gridDim.x * rpb) {
-        const bf16x8 vd = ld8(p.dout + m * p.ldd + c);
-        const bf16x8 vz = ld8(p.z + m * p.ldz + c);
-        bf16x8 vy;
-        if (p.y) vy = ld8(p.y + m * p.ldy + c);
+    auto apply = [&](const bf16x8& vd, const bf16x8& vz, const bf16x8& vy, long m) {
         bf16x8 o, og;
         float z[8], g[8];
 #pragma unroll
@@ -260,6 +315,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApply p) {
         }
         st8(p.dz + m * p.lddz + c, o);
         if (p.gout) st8(p.gout + m * p.ldg + c, og);
+    };
+    const long step = (long)gridDim.x * rpb;
+    long m = (long)blockIdx.x * rpb + rr;
+    for (; m + step < p.M; m += 2 * step) {
+        const long mb = m + step;
+        const bf16x8 vd0 = ld8(p.dout + m * p.ldd + c), vd1 = ld8(p.dout + mb * p.ldd + c);
+        const bf16x8 vz0 = ld8(p.z + m * p.ldz + c), vz1 = ld8(p.z + mb * p.ldz + c);
+        bf16x8 vy0 = vz0, vy1 = vz1;
+        if (p.y) { vy0 = ld8(p.y + m * p.ldy + c); vy1 = ld8(p.y + mb * p.ldy + c); }
+        apply(vd0, vz0, vy0, m);
+        apply(vd1, vz1, vy1, mb);
+    }
+    if (m < p.M) {
+        const bf16x8 vd0 = ld8(p.dout + m * p.ldd + c);
+        const bf16x8 vz0 = ld8(p.z + m * p.ldz + c);
+        bf16x8 vy0 = vz0;
+        if (p.y) vy0 = ld8(p.y + m * p.ldy + c);
+        apply(vd0, vz0, vy0, m);
     }
 }
 
@@ -487,15 +560,15 @@ static inline int ew_grid(long pieces) {
 static inline int row_grid(long M, int C) {
     const int C8 = C >> 3;
     const int rpb = 256 / C8 > 0 ? 256 / C8 : 1;
-    long b = (M + rpb - 1) / rpb;
-    if (b > 4096) b = 4096;
+    long b = (M + 2 * rpb - 1) / (2 * rpb);       // >= 2 rows per thread where the tensor allows
+    if (b > 2048) b = 2048;
     return (int)(b < 1 ? 1 : b);
 }
 
-// rows per block for a column reduction over M rows (~1024 partial rows; a multiple of `align` if given)
+// rows per block for a column reduction over M rows (<= 1024 partial rows, >= 8 rows each; a divisor of `align` if given)
 extern "C" long hn_colred_rows(long M, long align) {
     long R = (M + 1023) / 1024;
-    if (R < 64) R = 64;
+    if (R < 8) R = 8;
     if (align > 0) {
         if (R > align) R = align;                 // keep partial rows inside one image (align = H*W)
         while (align % R) --R;
@@ -536,7 +609,7 @@ extern "C" int hn_bn_finalize(const float* psum, const float* psq, int prows, in
                               const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* scale,
                               float* shift, float* mean, float* rstd, hipStream_t st) {
     HN_CHECK_ARG(psum && psq && prows > 0 && C > 0 && count > 0 && gamma && beta && scale && shift && mean && rstd);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, st, psum, psq, prows, C, (double)count, gamma, beta, eps, momentum,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, st, psum, psq, prows, C, (double)count, gamma, beta, eps, momentum,
                        running_mean, running_var, scale, shift, mean, rstd);
     HN_LAUNCH_CHECK();
 }
@@ -553,7 +626,7 @@ extern "C" int hn_bn_act(const void* z, int ldz, const float* scale, const float
     HN_CHECK_ARG(z && out && M > 0 && (C & 7) == 0 && (ldz & 7) == 0 && (ldo & 7) == 0 && (!res || (ldr & 7) == 0));
     HN_CHECK_ARG(C <= 2048);
     BnAct p = {(const bf16*)z, ldz, scale, shift, (const bf16*)res, ldr, rscale, rshift, act, (bf16*)out, ldo, M, C};
-    hipLaunchKernelGGL(bn_act_kernel, dim3(row_grid(M, C)), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(bn_act_kernel, dim3(row_grid(M, C)), dim3(256), (size_t)4 * C * sizeof(float), st, p);
     HN_LAUNCH_CHECK();
 }
 
@@ -570,7 +643,7 @@ extern "C" int hn_bn_bwd_reduce(const void* dout, int ldd, const void* z, int ld
 extern "C" int hn_bn_bwd_finalize(const float* pg, const float* pgx, int prows, int C, long count, float* dgamma, float* dbeta,
                                   float* mg, float* mgx, hipStream_t st) {
     HN_CHECK_ARG(pg && pgx && prows > 0 && C > 0 && count > 0 && dgamma && dbeta && mg && mgx);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, pg, pgx, prows, C, (double)count, dgamma, dbeta, mg, mgx);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, st, pg, pgx, prows, C, (double)count, dgamma, dbeta, mg, mgx);
     HN_LAUNCH_CHECK();
 }
 
@@ -582,7 +655,7 @@ extern "C" int hn_bn_bwd_apply(const void* dout, int ldd, const void* z, int ldz
     BnBwdApply p = {(const bf16*)dout, ldd, (const bf16*)z, ldz, (const bf16*)y, ldy, scale, shift, mean, rstd, mg, mgx, act,
                     (bf16*)dz, lddz, (bf16*)gout, ldg, M, C};
     HN_CHECK_ARG(C <= 2048 && scale && shift && mean && rstd && mg && mgx);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(row_grid(M, C)), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(row_grid(M, C)), dim3(256), (size_t)6 * C * sizeof(float), st, p);
     HN_LAUNCH_CHECK();
 }
 

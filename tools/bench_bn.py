@@ -1,0 +1,48 @@
+"""Device time (hipGraph replay) of the BatchNorm pipeline pieces at the [rows x C] sizes of the small layers."""
+import sys, torch
+sys.path.insert(0, '.')
+from multitask_hydranet_amd import ops as K
+dev = torch.device('cuda:0')
+torch.manual_seed(0)
+def timeit(f, iters=20):
+    for _ in range(2): f()
+    st = torch.cuda.Stream(); st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st): f()
+    torch.cuda.current_stream().wait_stream(st); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(iters): f()
+    g.replay()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(5): g.replay()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (5 * iters) * 1e3
+shapes = [(16, 8, 16, 936), (16, 16, 32, 376), (16, 32, 64, 152), (16, 64, 128, 112), (16, 4, 8, 112), (16, 128, 256, 64), (16, 256, 512, 24)]
+print("shape                      MB   col_stats finalize  bn_act  bn_act+res | bwd(reduce+finalize+apply)")
+for (n, h, w, c) in shapes:
+    z = torch.randn(n, h, w, c, device=dev).bfloat16()
+    res = torch.randn(n, h, w, c, device=dev).bfloat16()
+    dout = torch.randn(n, h, w, c, device=dev).bfloat16()
+    gamma, beta = torch.rand(c, device=dev) + 0.5, torch.randn(c, device=dev)
+    rm, rv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+    ps, pq, _ = K.k_col_stats(z)
+    coef = K.k_bn_finalize(ps, pq, n * h * w, gamma, beta, 1e-5, 0.1, rm, rv)
+    y = K.k_bn_act(z, coef, K.ACT_RELU)
+    t1 = timeit(lambda: K.k_col_stats(z))
+    t2 = timeit(lambda: K.k_bn_finalize(ps, pq, n * h * w, gamma, beta, 1e-5, 0.1, rm, rv))
+    t3 = timeit(lambda: K.k_bn_act(z, coef, K.ACT_RELU))
+    t4 = timeit(lambda: K.k_bn_act(z, coef, K.ACT_RELU, res=res))
+    from multitask_hydranet_amd._lib import lib
+    ptr, ld = K.ptr, K.ld
+    m = n * h * w
+    r = lib().query("hn_colred_rows", m, 0); pr = (m + r - 1) // r
+    pg = torch.empty((pr, c), device=dev); pgx = torch.empty((pr, c), device=dev)
+    red = torch.empty((2, c), device=dev); dgam = torch.empty(c, device=dev); dbet = torch.empty(c, device=dev); dz = torch.empty_like(z)
+    tb1 = timeit(lambda: lib().call("hn_bn_bwd_reduce", ptr(dout), ld(dout), ptr(z), ld(z), ptr(y), ld(y), ptr(coef[0]), ptr(coef[1]), ptr(coef[2]), ptr(coef[3]), K.ACT_RELU, m, c, r, ptr(pg), ptr(pgx)))
+    tb2 = timeit(lambda: lib().call("hn_bn_bwd_finalize", ptr(pg), ptr(pgx), pr, c, m, ptr(dgam), ptr(dbet), ptr(red[0]), ptr(red[1])))
+    tb3 = timeit(lambda: lib().call("hn_bn_bwd_apply", ptr(dout), ld(dout), ptr(z), ld(z), ptr(y), ld(y), ptr(coef[0]), ptr(coef[1]), ptr(coef[2]), ptr(coef[3]), ptr(red[0]), ptr(red[1]), K.ACT_RELU, ptr(dz), ld(dz), None, 0, m, c))
+    t5 = timeit(lambda: K.bn_backward(dout, z, y, coef, K.ACT_RELU, n * h * w))
+    t6 = timeit(lambda: K.bn_backward(dout, z, None, coef, K.ACT_SWISH, n * h * w))
+    mb = n * h * w * c * 2 / 1e6
+    print(f"{str((n,h,w,c)):24s} {mb:6.1f}  {t1:8.1f} {t2:8.1f} {t3:8.1f} {t4:8.1f}   | relu {t5:8.1f}  swish {t6:8.1f}   (prows {ps.shape[0]})  bwd parts: reduce {tb1:.1f} finalize {tb2:.1f} apply {tb3:.1f}")
