@@ -211,23 +211,36 @@ __global__ __launch_bounds__(256) void gconv_wgrad_kernel(const bf16* x, int ldx
     for (int o = 0; o < 8; ++o)
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[o][i] = 0.f;
-    for (long pix = p0; pix < p1; ++pix) {
-        const int ox = (int)(pix % Wo);
-        const long t1 = pix / Wo;
-        const int oy = (int)(t1 % Ho);
-        const long n = t1 / Ho;
-        const int iy = oy * S + ky - 1, ix = ox * S + kx - 1;
-        if (iy < 0 || iy >= Hi || ix < 0 || ix >= Wi) continue;
-        const bf16x8 zv = ld8(dz + pix * ldz + g * 8);
-        const bf16x8 xv = ld8(x + ((n * Hi + iy) * (long)Wi + ix) * ldx + g * 8);
-        float xf[8];
+    // four pixels in flight per thread (the loads of a batch are all issued before the first FMA); out-of-image taps load nothing
+    for (long pb = p0; pb < p1; pb += 4) {
+        bf16x8 zv[4], xv[4];
+        bool ok[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) xf[i] = bf2f(xv[i]);
+        for (int u = 0; u < 4; ++u) {
+            const long pix = pb + u;
+            const int ox = (int)(pix % Wo);
+            const long t1 = pix / Wo;
+            const int oy = (int)(t1 % Ho);
+            const long n = t1 / Ho;
+            const int iy = oy * S + ky - 1, ix = ox * S + kx - 1;
+            ok[u] = pix < p1 && iy >= 0 && iy < Hi && ix >= 0 && ix < Wi;
+            if (ok[u]) {
+                zv[u] = ld8(dz + pix * ldz + g * 8);
+                xv[u] = ld8(x + ((n * Hi + iy) * (long)Wi + ix) * ldx + g * 8);
+            }
+        }
 #pragma unroll
-        for (int o = 0; o < 8; ++o) {
-            const float zf = bf2f(zv[o]);
+        for (int u = 0; u < 4; ++u) {
+            if (!ok[u]) continue;
+            float xf[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[o][i] = fmaf(zf, xf[i], acc[o][i]);
+            for (int i = 0; i < 8; ++i) xf[i] = bf2f(xv[u][i]);
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {
+                const float zf = bf2f(zv[u][o]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[o][i] = fmaf(zf, xf[i], acc[o][i]);
+            }
         }
     }
     float* dst = part + chunk * G * 576;
@@ -330,23 +343,29 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const bf16* x, int ld
             const long t1 = pix / W;
             const int oy = (int)(t1 % H);
             const long n = t1 / H;
+            // all ten loads of a pixel are issued before the first FMA: border taps read a clamped address and are masked to zero
             const bf16x8 zv = ld8(dz + pix * ldz + cg * 8);
+            bf16x8 xv[9];
+            float msk[9];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iy = oy + ky - 1;
+                const int iyc = iy < 0 ? 0 : (iy >= H ? H - 1 : iy);
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int ix = ox + kx - 1;
+                    const int ixc = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
+                    msk[ky * 3 + kx] = (iy == iyc && ix == ixc) ? 1.f : 0.f;
+                    xv[ky * 3 + kx] = ld8(x + ((n * H + iyc) * (long)W + ixc) * ldx + cg * 8);
+                }
+            }
             float zf[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) zf[k] = bf2f(zv[k]);
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const int iy = oy + ky - 1;
-                if (iy < 0 || iy >= H) continue;
+            for (int tq = 0; tq < 9; ++tq)
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int ix = ox + kx - 1;
-                    if (ix < 0 || ix >= W) continue;
-                    const bf16x8 xv = ld8(x + ((n * H + iy) * (long)W + ix) * ldx + cg * 8);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) acc[ky * 3 + kx][k] = fmaf(zf[k], bf2f(xv[k]), acc[ky * 3 + kx][k]);
-                }
-            }
+                for (int k = 0; k < 8; ++k) acc[tq][k] = fmaf(zf[k] * msk[tq], bf2f(xv[tq][k]), acc[tq][k]);
         }
     }
     float* dst = part + (long)blockIdx.x * C * 9;
