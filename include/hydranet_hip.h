@@ -113,6 +113,9 @@ long hn_colred_rows(long M, long align);
 int hn_col_stats(const void* x, int ldx, long M, int C, long R, float* psum, float* psq, hipStream_t stream);
 int hn_col_dot(const void* a, int lda, const void* b, int ldb, long M, int C, long R, float* pdot, float* psum, hipStream_t stream);
 int hn_rows_reduce(const float* in, float* out, int G, int S, int C, float alpha, hipStream_t stream);
+/* two arrays at once with ragged groups: outK[g][c] = sum of inK rows [g*S, min((g+1)*S, rows)), S = ceil(rows/G); folds the per-wave
+ * partial statistic rows of a GEMM epilogue (or of hn_bn_bwd_reduce) before hn_bn_finalize / hn_bn_bwd_finalize */
+int hn_rows_reduce2(const float* in1, const float* in2, float* out1, float* out2, int rows, int G, int C, hipStream_t stream);
 
 /* Training-mode nn.BatchNorm2d (F.batch_norm): statistics -> (scale, shift, mean, rstd) + running-stat update. */
 int hn_bn_finalize(const float* psum, const float* psq, int prows, int C, long count, const float* gamma, const float* beta, float eps,

@@ -137,26 +137,51 @@ __global__ __launch_bounds__(512) void rows_reduce_kernel(const float* in, float
     }
 }
 
+// two arrays at once, ragged groups: outK[g][c] = sum of inK rows [g*S, min((g+1)*S, rows)), S = ceil(rows / G).  Used to fold the
+// (up to M/64) per-wave partial statistic rows of a GEMM epilogue down to G rows before the finalize kernel.
+__global__ __launch_bounds__(512) void rows_reduce2_kernel(const float* in1, const float* in2, float* out1, float* out2, int rows, int G,
+                                                           int C) {
+    __shared__ float red[2][16][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + tx, g = blockIdx.y;
+    const int S = (rows + G - 1) / G;
+    const int r0 = g * S;
+    int r1 = r0 + S;
+    if (r1 > rows) r1 = rows;
+    float s1 = 0.f, s2 = 0.f;
+    if (c < C)
+        for (int j = r0 + ty; j < r1; j += 16) { s1 += in1[(long)j * C + c]; s2 += in2[(long)j * C + c]; }
+    red[0][ty][tx] = s1; red[1][ty][tx] = s2;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { t1 += red[0][k][tx]; t2 += red[1][k][tx]; }
+        out1[(long)g * C + c] = t1;
+        out2[(long)g * C + c] = t2;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // BatchNorm finalize (training): one wave per channel reduces the partial rows, then derives
 //   mean, biased var -> rstd, scale = gamma*rstd, shift = beta - mean*scale, and updates the running statistics
 //   (unbiased variance, PyTorch momentum convention) -- F.batch_norm semantics.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* psum, const float* psq, int prows, int C, double count,
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* psum, const float* psq, int prows, int C, double count,
                                                           const float* gamma, const float* beta, float eps, float momentum,
                                                           float* running_mean, float* running_var, float* scale, float* shift,
                                                           float* mean, float* rstd) {
-    __shared__ double r1[32][33], r2[32][33];
+    __shared__ double r1[8][33], r2[8][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + tx;
     double s1 = 0.0, s2 = 0.0;
     if (c < C)
-        for (int r = ty; r < prows; r += 32) { s1 += psum[(long)r * C + c]; s2 += psq[(long)r * C + c]; }
+        for (int r = ty; r < prows; r += 8) { s1 += psum[(long)r * C + c]; s2 += psq[(long)r * C + c]; }
     r1[ty][tx] = s1; r2[ty][tx] = s2;
     __syncthreads();
     if (ty == 0 && c < C) {
 #pragma unroll
-        for (int k = 1; k < 32; ++k) { s1 += r1[k][tx]; s2 += r2[k][tx]; }
+        for (int k = 1; k < 8; ++k) { s1 += r1[k][tx]; s2 += r2[k][tx]; }
         const double mu = s1 / count;
         double var = s2 / count - mu * mu;
         if (var < 0.0) var = 0.0;
@@ -185,19 +210,19 @@ __global__ void bn_eval_coeff_kernel(const float* gamma, const float* beta, cons
 }
 
 // dgamma = sum g*xhat, dbeta = sum g, and the two per-channel means the apply pass needs
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* pg, const float* pgx, int prows, int C, double count,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* pg, const float* pgx, int prows, int C, double count,
                                                               float* dgamma, float* dbeta, float* mg, float* mgx) {
-    __shared__ double r1[32][33], r2[32][33];
+    __shared__ double r1[8][33], r2[8][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + tx;
     double s1 = 0.0, s2 = 0.0;
     if (c < C)
-        for (int r = ty; r < prows; r += 32) { s1 += pg[(long)r * C + c]; s2 += pgx[(long)r * C + c]; }
+        for (int r = ty; r < prows; r += 8) { s1 += pg[(long)r * C + c]; s2 += pgx[(long)r * C + c]; }
     r1[ty][tx] = s1; r2[ty][tx] = s2;
     __syncthreads();
     if (ty == 0 && c < C) {
 #pragma unroll
-        for (int k = 1; k < 32; ++k) { s1 += r1[k][tx]; s2 += r2[k][tx]; }
+        for (int k = 1; k < 8; ++k) { s1 += r1[k][tx]; s2 += r2[k][tx]; }
         dbeta[c] = (float)s1;
         dgamma[c] = (float)s2;
         mg[c] = (float)(s1 / count);
@@ -605,11 +630,17 @@ extern "C" int hn_rows_reduce(const float* in, float* out, int G, int S, int C, 
     HN_LAUNCH_CHECK();
 }
 
+extern "C" int hn_rows_reduce2(const float* in1, const float* in2, float* out1, float* out2, int rows, int G, int C, hipStream_t st) {
+    HN_CHECK_ARG(in1 && in2 && out1 && out2 && rows > 0 && G > 0 && C > 0);
+    hipLaunchKernelGGL(rows_reduce2_kernel, dim3(cdiv(C, 32), G), dim3(512), 0, st, in1, in2, out1, out2, rows, G, C);
+    HN_LAUNCH_CHECK();
+}
+
 extern "C" int hn_bn_finalize(const float* psum, const float* psq, int prows, int C, long count, const float* gamma,
                               const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* scale,
                               float* shift, float* mean, float* rstd, hipStream_t st) {
     HN_CHECK_ARG(psum && psq && prows > 0 && C > 0 && count > 0 && gamma && beta && scale && shift && mean && rstd);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, st, psum, psq, prows, C, (double)count, gamma, beta, eps, momentum,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, psum, psq, prows, C, (double)count, gamma, beta, eps, momentum,
                        running_mean, running_var, scale, shift, mean, rstd);
     HN_LAUNCH_CHECK();
 }
@@ -643,7 +674,7 @@ extern "C" int hn_bn_bwd_reduce(const void* dout, int ldd, const void* z, int ld
 extern "C" int hn_bn_bwd_finalize(const float* pg, const float* pgx, int prows, int C, long count, float* dgamma, float* dbeta,
                                   float* mg, float* mgx, hipStream_t st) {
     HN_CHECK_ARG(pg && pgx && prows > 0 && C > 0 && count > 0 && dgamma && dbeta && mg && mgx);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, st, pg, pgx, prows, C, (double)count, dgamma, dbeta, mg, mgx);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, pg, pgx, prows, C, (double)count, dgamma, dbeta, mg, mgx);
     HN_LAUNCH_CHECK();
 }
 

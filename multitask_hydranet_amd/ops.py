@@ -182,8 +182,20 @@ def k_rows_reduce(part, groups, s, c, alpha=1.0):
     return out
 
 
+def fold_rows(p1, p2, limit=128, groups=32):
+    """partial-row arrays with more than `limit` rows are folded to `groups` rows by one 2-D launch (the finalize kernels walk the rows
+    with 8 lanes per channel)"""
+    rows_, c = p1.shape
+    if rows_ <= limit:
+        return p1, p2
+    o = torch.empty((2, groups, c), device=p1.device, dtype=F32)
+    lib().call("hn_rows_reduce2", ptr(p1), ptr(p2), ptr(o[0]), ptr(o[1]), rows_, groups, c)
+    return o[0], o[1]
+
+
 def k_bn_finalize(psum, psq, count, gamma, beta, eps, momentum, rm, rv):
     c = gamma.shape[0]
+    psum, psq = fold_rows(psum, psq)
     coef = torch.empty((4, c), device=gamma.device, dtype=F32)     # scale, shift, mean, rstd
     lib().call("hn_bn_finalize", ptr(psum), ptr(psq), psum.shape[0], c, count, ptr(gamma), ptr(beta), float(eps), float(momentum),
                ptr(rm), ptr(rv), ptr(coef[0]), ptr(coef[1]), ptr(coef[2]), ptr(coef[3]))
@@ -228,6 +240,8 @@ def bn_backward(dout, z, y, coef, act, count, want_g=False):
     red = torch.empty((2, c), device=dev, dtype=F32)               # mean(g), mean(g*xhat)
     dgamma = torch.empty((c,), device=dev, dtype=F32)
     dbeta = torch.empty((c,), device=dev, dtype=F32)
+    pg, pgx = fold_rows(pg, pgx)
+    pr = pg.shape[0]
     lib().call("hn_bn_bwd_finalize", ptr(pg), ptr(pgx), pr, c, count, ptr(dgamma), ptr(dbeta), ptr(red[0]), ptr(red[1]))
     dz = new_act(n, h, w, c, dev)
     g = new_act(n, h, w, c, dev) if want_g else None
