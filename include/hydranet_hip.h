@@ -74,8 +74,15 @@ int hn_gconv_wgrad(const void* x, int ldx, const void* dz, int ldz, float* part,
 /* Depthwise 3x3, stride 1, zero pad 1 (SeparableConvBlock.depthwise_conv, net/common.py:91-92,104). */
 int hn_dw_pack(const float* w, void* wk, void* wkf, int C, hipStream_t stream);
 int hn_dwconv_fwd(const void* in, int ldi, const void* wk, void* out, int ldo, int N, int H, int W, int C, hipStream_t stream);
+/* level-packed form: rows of nlev (<= 5) pyramid levels [N,H[l],W[l],C] stacked in one tensor, one launch (the det-head towers apply the
+ * same SeparableConvBlock to every level, head_detect/detection.py:30-35,67-72) */
+int hn_dwconv_fwd_levels(const void* in, int ldi, const void* wk, void* out, int ldo, int N, int C, int nlev, const int* H, const int* W,
+                         hipStream_t stream);
 long hn_dwconv_wgrad_blocks(long pixels, int C);
 int hn_dwconv_wgrad(const void* x, int ldx, const void* dz, int ldz, float* part, int N, int H, int W, int C, hipStream_t stream);
+/* level-packed: part is fp32 [hn_dwconv_wgrad_blocks(total pixels, C)][C*9] */
+int hn_dwconv_wgrad_levels(const void* x, int ldx, const void* dz, int ldz, float* part, int N, int C, int nlev, const int* H, const int* W,
+                           hipStream_t stream);
 
 /* 3x3/s2 max pools: mode 0 = zero pad right/bottom, zeros take part in the max (MaxPool2dStaticSamePadding, net/common.py:138-151);
  * mode 1 = nn.MaxPool2d(3,2,1) (head_lane/lanedetect.py:40).  Backward recomputes the arg-max (first maximum wins). */
@@ -134,6 +141,21 @@ int hn_bn_bwd_finalize(const float* pg, const float* pgx, int prows, int C, long
 int hn_bn_bwd_apply(const void* dout, int ldd, const void* z, int ldz, const void* y, int ldy, const float* scale, const float* shift,
                     const float* mean, const float* rstd, const float* mg, const float* mgx, int act, void* dz, int lddz, void* gout, int ldg,
                     long M, int C, hipStream_t stream);
+
+/* Level-packed BatchNorm with per-level parameters (bn_list[level][i] of the det towers, head_detect/detection.py:23,31-35,60,68-72).
+ * rows[l] = tensor rows of level l (each a multiple of 128); coef = [nlev][4][C] (scale, shift, mean, rstd), red = [nlev][2][C].
+ * gamma/beta/running_*/dgamma/dbeta are HOST arrays of nlev device pointers.  Partial-row inputs hold one row per `div` tensor rows. */
+int hn_bn_finalize_levels(const float* psum, const float* psq, int div, int C, int nlev, const long* rows, const long* count,
+                          const void* const* gamma, const void* const* beta, void* const* running_mean, void* const* running_var, float eps,
+                          float momentum, float* coef, hipStream_t stream);
+int hn_bn_act_levels(const void* z, int ldz, const float* coef, int act, void* out, int ldo, int C, int nlev, const long* rows,
+                     hipStream_t stream);
+int hn_bn_bwd_reduce_levels(const void* dout, int ldd, const void* z, int ldz, const void* y, int ldy, const float* coef, int act, int C,
+                            long R, int nlev, const long* rows, float* pg, float* pgx, hipStream_t stream);
+int hn_bn_bwd_finalize_levels(const float* pg, const float* pgx, int div, int C, int nlev, const long* rows, const long* count,
+                              void* const* dgamma, void* const* dbeta, float* red, hipStream_t stream);
+int hn_bn_bwd_apply_levels(const void* dout, int ldd, const void* z, int ldz, const void* y, int ldy, const float* coef, const float* red,
+                           int act, void* dz, int lddz, int C, int nlev, const long* rows, hipStream_t stream);
 
 /* SE gating x * gate[n][c] and its data-path backward (net/anynet.py:40-48,68-69). */
 int hn_scale_rows(const void* x, int ldx, const float* gate, long HW, void* out, int ldo, long M, int C, hipStream_t stream);

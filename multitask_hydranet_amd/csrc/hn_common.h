@@ -61,6 +61,21 @@ __device__ __forceinline__ float act_bwd(float x, int act) {
     }
 }
 
+// Pyramid levels packed into one [sum_l N*H_l*W_l rows][C] tensor (det-head towers: the five levels share the conv weights, so one
+// launch serves all of them).  Level l occupies rows [row_off[l], row_off[l+1]).
+#define HN_MAX_LEVELS 5
+struct Levels {
+    int n;
+    int H[HN_MAX_LEVELS], W[HN_MAX_LEVELS];
+    long row_off[HN_MAX_LEVELS + 1];
+    long work_off[HN_MAX_LEVELS + 1];      // kernel-specific cumulative work items per level
+};
+__device__ __forceinline__ int level_of_row(const Levels& L, long row) {
+    int lv = 0;
+    while (lv + 1 < L.n && row >= L.row_off[lv + 1]) ++lv;
+    return lv;
+}
+
 // Array forms: ONE uniform branch on `act` around an unrolled loop.  A per-element switch costs a scalar branch chain per value, which
 // dominated the GEMM epilogues (~1000 branches per wave for a 64x64 wave tile); hoisting it is worth 2-3x on short-K launches.
 template <int N>

@@ -23,6 +23,8 @@ struct ColRed {
     int act;
     long M; int C; long R;
     float* o1; float* o2;
+    Levels sg;                   // MODE 2 on level-packed rows (sg.n > 1): block's level -> coefficient set at + level*coef_stride
+    int coef_stride;
 };
 
 template <int MODE>
@@ -42,8 +44,9 @@ __global__ __launch_bounds__(256) void colred_kernel(const ColRed p) {
     float sc[8], sh[8], mu[8], rs[8];
     if (MODE == 2) {                                  // stage the 4 x C coefficients through LDS once per block (red is free until the end)
         float* cf = &red[0][0];
+        const long cofs = p.sg.n > 1 ? (long)level_of_row(p.sg, (long)blockIdx.x * p.R) * p.coef_stride : 0;
         for (int i = tid; i < p.C; i += 256) {
-            cf[i] = p.scale[i]; cf[p.C + i] = p.shift[i]; cf[2 * p.C + i] = p.mean[i]; cf[3 * p.C + i] = p.rstd[i];
+            cf[i] = p.scale[cofs + i]; cf[p.C + i] = p.shift[cofs + i]; cf[2 * p.C + i] = p.mean[cofs + i]; cf[3 * p.C + i] = p.rstd[cofs + i];
         }
         __syncthreads();
         if (active) {
@@ -358,6 +361,142 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApply p) {
         bf16x8 vy0 = vz0;
         if (p.y) vy0 = ld8(p.y + m * p.ldy + c);
         apply(vd0, vz0, vy0, m);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Level-packed variants (det-head towers): rows of all pyramid levels in one tensor, BatchNorm parameters per level.  A block owns RB
+// consecutive rows (RB divides every level's row count), looks its level up once and stages that level's coefficients in LDS.
+// coef layout: [level][4][C] = scale, shift, mean, rstd;  red layout: [level][2][C] = mean(g), mean(g*xhat).
+// ---------------------------------------------------------------------------------------------------------
+struct BnLevels {
+    const bf16* z; int ldz; const bf16* dout; int ldd; const bf16* y; int ldy;
+    const float* coef; const float* red;
+    int act; bf16* out; int ldo; int C; int RB;
+    Levels sg;
+};
+template <bool BWD>
+__global__ __launch_bounds__(256) void bn_levels_kernel(const BnLevels p) {
+    extern __shared__ float coefs[];                      // [4 or 6][C]
+    const long m0 = (long)blockIdx.x * p.RB;
+    const int lv = level_of_row(p.sg, m0);
+    const float* cf = p.coef + (long)lv * 4 * p.C;
+    for (int i = threadIdx.x; i < 4 * p.C; i += 256) coefs[i] = cf[i];
+    if (BWD) {
+        const float* rd = p.red + (long)lv * 2 * p.C;
+        for (int i = threadIdx.x; i < 2 * p.C; i += 256) coefs[4 * p.C + i] = rd[i];
+    }
+    __syncthreads();
+    const int C8 = p.C >> 3;
+    const int rpb = 256 / C8 > 0 ? 256 / C8 : 1;
+    const int cg = threadIdx.x % C8, rr = threadIdx.x / C8;
+    if (rr >= rpb) return;
+    const int c = cg * 8;
+    float sc[8], sh[8], mu[8], rs[8], mg[8], mgx[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        sc[k] = coefs[c + k]; sh[k] = coefs[p.C + c + k];
+        if (BWD) { mu[k] = coefs[2 * p.C + c + k]; rs[k] = coefs[3 * p.C + c + k]; mg[k] = coefs[4 * p.C + c + k]; mgx[k] = coefs[5 * p.C + c + k]; }
+    }
+    long m1 = m0 + p.RB;
+    const long total = p.sg.row_off[p.sg.n];
+    if (m1 > total) m1 = total;
+    auto one = [&](const bf16x8& vz, const bf16x8& vd, const bf16x8& vy, long m) {
+        bf16x8 o;
+        if (!BWD) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = bf2f(vz[k]) * sc[k] + sh[k];
+            act_fwd_n(v, p.act);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = f2bf(v[k]);
+        } else {
+            float z[8], g[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { z[k] = bf2f(vz[k]); g[k] = bf2f(vd[k]); }
+            if (p.y) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) g[k] = bf2f(vy[k]) > 0.f ? g[k] : 0.f;
+            } else {
+                float pre[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) pre[k] = sc[k] * z[k] + sh[k];
+                act_bwd_n(pre, g, p.act);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float xh = (z[k] - mu[k]) * rs[k];
+                o[k] = f2bf(sc[k] * (g[k] - mg[k] - xh * mgx[k]));
+            }
+        }
+        st8(p.out + m * p.ldo + c, o);
+    };
+    long m = m0 + rr;
+    for (; m + rpb < m1; m += 2 * rpb) {
+        const long mb = m + rpb;
+        const bf16x8 vz0 = ld8(p.z + m * p.ldz + c), vz1 = ld8(p.z + mb * p.ldz + c);
+        bf16x8 vd0 = vz0, vd1 = vz1, vy0 = vz0, vy1 = vz1;
+        if (BWD) { vd0 = ld8(p.dout + m * p.ldd + c); vd1 = ld8(p.dout + mb * p.ldd + c); }
+        if (BWD && p.y) { vy0 = ld8(p.y + m * p.ldy + c); vy1 = ld8(p.y + mb * p.ldy + c); }
+        one(vz0, vd0, vy0, m);
+        one(vz1, vd1, vy1, mb);
+    }
+    if (m < m1) {
+        const bf16x8 vz0 = ld8(p.z + m * p.ldz + c);
+        bf16x8 vd0 = vz0, vy0 = vz0;
+        if (BWD) vd0 = ld8(p.dout + m * p.ldd + c);
+        if (BWD && p.y) vy0 = ld8(p.y + m * p.ldy + c);
+        one(vz0, vd0, vy0, m);
+    }
+}
+
+// per-level finalize: block (x = 32-channel chunk, y = level) reduces that level's partial rows [row_off[l]/div, row_off[l+1]/div)
+struct FinLevels {
+    const float* p1; const float* p2; int C; int div; float eps, momentum;
+    Levels sg;
+    long count[HN_MAX_LEVELS];
+    const float* gamma[HN_MAX_LEVELS]; const float* beta[HN_MAX_LEVELS]; float* rm[HN_MAX_LEVELS]; float* rv[HN_MAX_LEVELS];
+    float* dgamma[HN_MAX_LEVELS]; float* dbeta[HN_MAX_LEVELS];
+    float* out;                  // fwd: coef [level][4][C]; bwd: red [level][2][C]
+};
+template <bool BWD>
+__global__ __launch_bounds__(1024) void bn_finalize_levels_kernel(const FinLevels p) {
+    __shared__ double r1[32][33], r2[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + tx, lv = blockIdx.y;
+    const long rb = p.sg.row_off[lv] / p.div, re = p.sg.row_off[lv + 1] / p.div;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < p.C)
+        for (long r = rb + ty; r < re; r += 32) { s1 += p.p1[r * p.C + c]; s2 += p.p2[r * p.C + c]; }
+    r1[ty][tx] = s1; r2[ty][tx] = s2;
+    __syncthreads();
+    if (ty == 0 && c < p.C) {
+#pragma unroll
+        for (int k = 1; k < 32; ++k) { s1 += r1[k][tx]; s2 += r2[k][tx]; }
+        const double count = (double)p.count[lv];
+        if (!BWD) {
+            float* coef = p.out + (long)lv * 4 * p.C;
+            const double mu = s1 / count;
+            double var = s2 / count - mu * mu;
+            if (var < 0.0) var = 0.0;
+            const float rs = (float)(1.0 / sqrt(var + (double)p.eps));
+            const float sc = p.gamma[lv][c] * rs;
+            coef[c] = sc;
+            coef[p.C + c] = p.beta[lv][c] - (float)mu * sc;
+            coef[2 * p.C + c] = (float)mu;
+            coef[3 * p.C + c] = rs;
+            if (p.rm[lv]) {
+                const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+                p.rm[lv][c] = (1.f - p.momentum) * p.rm[lv][c] + p.momentum * (float)mu;
+                p.rv[lv][c] = (1.f - p.momentum) * p.rv[lv][c] + p.momentum * (float)unb;
+            }
+        } else {
+            float* red = p.out + (long)lv * 2 * p.C;
+            p.dbeta[lv][c] = (float)s1;
+            p.dgamma[lv][c] = (float)s2;
+            red[c] = (float)(s1 / count);
+            red[p.C + c] = (float)(s2 / count);
+        }
     }
 }
 
@@ -687,6 +826,94 @@ extern "C" int hn_bn_bwd_apply(const void* dout, int ldd, const void* z, int ldz
                     (bf16*)dz, lddz, (bf16*)gout, ldg, M, C};
     HN_CHECK_ARG(C <= 2048 && scale && shift && mean && rstd && mg && mgx);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(row_grid(M, C)), dim3(256), (size_t)6 * C * sizeof(float), st, p);
+    HN_LAUNCH_CHECK();
+}
+
+static int fill_row_levels(Levels& L, int nlev, const long* rows, long block) {
+    HN_CHECK_ARG(nlev >= 1 && nlev <= HN_MAX_LEVELS && rows && block > 0);
+    L.n = nlev;
+    L.row_off[0] = 0;
+    for (int l = 0; l < nlev; ++l) {
+        HN_CHECK_ARG(rows[l] > 0 && rows[l] % block == 0);       // blocks never straddle a level
+        L.H[l] = 0; L.W[l] = 0;
+        L.row_off[l + 1] = L.row_off[l] + rows[l];
+    }
+    return HN_OK;
+}
+
+/* Level-packed BatchNorm (per-level parameters) for the det-head towers; see bn_levels_kernel. */
+extern "C" int hn_bn_act_levels(const void* z, int ldz, const float* coef, int act, void* out, int ldo, int C, int nlev, const long* rows,
+                                hipStream_t st) {
+    HN_CHECK_ARG(z && coef && out && (C & 7) == 0 && C <= 2048 && ((ldz | ldo) & 7) == 0);
+    BnLevels p = {};
+    p.z = (const bf16*)z; p.ldz = ldz; p.coef = coef; p.act = act; p.out = (bf16*)out; p.ldo = ldo; p.C = C; p.RB = 128;
+    const int rc = fill_row_levels(p.sg, nlev, rows, p.RB);
+    if (rc != HN_OK) return rc;
+    hipLaunchKernelGGL(bn_levels_kernel<false>, dim3(cdiv(p.sg.row_off[nlev], p.RB)), dim3(256), (size_t)4 * C * sizeof(float), st, p);
+    HN_LAUNCH_CHECK();
+}
+extern "C" int hn_bn_bwd_apply_levels(const void* dout, int ldd, const void* z, int ldz, const void* y, int ldy, const float* coef,
+                                      const float* red, int act, void* dz, int lddz, int C, int nlev, const long* rows, hipStream_t st) {
+    HN_CHECK_ARG(dout && z && coef && red && dz && (C & 7) == 0 && C <= 2048 && ((ldd | ldz | lddz) & 7) == 0 && (!y || (ldy & 7) == 0));
+    BnLevels p = {};
+    p.z = (const bf16*)z; p.ldz = ldz; p.dout = (const bf16*)dout; p.ldd = ldd; p.y = (const bf16*)y; p.ldy = ldy;
+    p.coef = coef; p.red = red; p.act = act; p.out = (bf16*)dz; p.ldo = lddz; p.C = C; p.RB = 128;
+    const int rc = fill_row_levels(p.sg, nlev, rows, p.RB);
+    if (rc != HN_OK) return rc;
+    hipLaunchKernelGGL(bn_levels_kernel<true>, dim3(cdiv(p.sg.row_off[nlev], p.RB)), dim3(256), (size_t)6 * C * sizeof(float), st, p);
+    HN_LAUNCH_CHECK();
+}
+extern "C" int hn_bn_bwd_reduce_levels(const void* dout, int ldd, const void* z, int ldz, const void* y, int ldy, const float* coef, int act,
+                                       int C, long R, int nlev, const long* rows, float* pg, float* pgx, hipStream_t st) {
+    HN_CHECK_ARG(z && coef && (ldz & 7) == 0 && (!y || (ldy & 7) == 0));
+    ColRed p = {};
+    p.a = (const bf16*)dout; p.lda = ldd; p.b = (const bf16*)z; p.ldb = ldz; p.y = (const bf16*)y; p.ldy = ldy;
+    p.scale = coef; p.shift = coef + C; p.mean = coef + 2 * C; p.rstd = coef + 3 * C; p.coef_stride = 4 * C;
+    p.act = act; p.C = C; p.R = R; p.o1 = pg; p.o2 = pgx;
+    const int rc = fill_row_levels(p.sg, nlev, rows, R);
+    if (rc != HN_OK) return rc;
+    p.M = p.sg.row_off[nlev];
+    return launch_colred(2, p, st);
+}
+static int fill_fin(FinLevels& p, const float* p1, const float* p2, int div, int C, int nlev, const long* rows, const long* count) {
+    HN_CHECK_ARG(p1 && p2 && div > 0 && C > 0 && count);
+    p.p1 = p1; p.p2 = p2; p.C = C; p.div = div;
+    const int rc = fill_row_levels(p.sg, nlev, rows, div);
+    if (rc != HN_OK) return rc;
+    for (int l = 0; l < nlev; ++l) { HN_CHECK_ARG(count[l] > 0); p.count[l] = count[l]; }
+    return HN_OK;
+}
+/* partial rows psum/psq: one per `div` tensor rows (64 for the hn_conv_gemm_nt epilogue statistics); coef out: [nlev][4][C] */
+extern "C" int hn_bn_finalize_levels(const float* psum, const float* psq, int div, int C, int nlev, const long* rows, const long* count,
+                                     const void* const* gamma, const void* const* beta, void* const* running_mean,
+                                     void* const* running_var, float eps, float momentum, float* coef, hipStream_t st) {
+    HN_CHECK_ARG(gamma && beta && coef);
+    FinLevels p = {};
+    const int rc = fill_fin(p, psum, psq, div, C, nlev, rows, count);
+    if (rc != HN_OK) return rc;
+    p.eps = eps; p.momentum = momentum; p.out = coef;
+    for (int l = 0; l < nlev; ++l) {
+        HN_CHECK_ARG(gamma[l] && beta[l]);
+        p.gamma[l] = (const float*)gamma[l]; p.beta[l] = (const float*)beta[l];
+        p.rm[l] = running_mean ? (float*)running_mean[l] : nullptr;
+        p.rv[l] = running_var ? (float*)running_var[l] : nullptr;
+    }
+    hipLaunchKernelGGL(bn_finalize_levels_kernel<false>, dim3(cdiv(C, 32), nlev), dim3(1024), 0, st, p);
+    HN_LAUNCH_CHECK();
+}
+/* red out: [nlev][2][C] = mean(g), mean(g*xhat); dgamma/dbeta: per-level fp32 [C] */
+extern "C" int hn_bn_bwd_finalize_levels(const float* pg, const float* pgx, int div, int C, int nlev, const long* rows, const long* count,
+                                         void* const* dgamma, void* const* dbeta, float* red, hipStream_t st) {
+    HN_CHECK_ARG(dgamma && dbeta && red);
+    FinLevels p = {};
+    const int rc = fill_fin(p, pg, pgx, div, C, nlev, rows, count);
+    if (rc != HN_OK) return rc;
+    p.out = red;
+    for (int l = 0; l < nlev; ++l) {
+        HN_CHECK_ARG(dgamma[l] && dbeta[l]);
+        p.dgamma[l] = (float*)dgamma[l]; p.dbeta[l] = (float*)dbeta[l];
+    }
+    hipLaunchKernelGGL(bn_finalize_levels_kernel<true>, dim3(cdiv(C, 32), nlev), dim3(1024), 0, st, p);
     HN_LAUNCH_CHECK();
 }
 

@@ -270,12 +270,17 @@ __global__ void gconv_pack_kernel(const float* w, bf16* wk, bf16* wd, int G, int
 // ---------------------------------------------------------------------------------------------------------
 // depthwise 3x3, stride 1, zero pad 1.  Packed weights wk[tap][C] bf16.  Thread = 8 channels x strip of 4 pixels.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const bf16* in, int ldi, const bf16* wk, bf16* out, int ldo, int N, int H, int W,
-                                                         int C) {
-    const int C8 = C >> 3, strips = (W + 3) >> 2;
-    const long total = (long)N * H * strips * C8;
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const bf16* in, int ldi, const bf16* wk, bf16* out, int ldo, int N, int C,
+                                                         const Levels L) {
+    const int C8 = C >> 3;
+    long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= L.work_off[L.n]) return;
+    int lv = 0;
+    while (lv + 1 < L.n && idx >= L.work_off[lv + 1]) ++lv;
+    idx -= L.work_off[lv];
+    const int H = L.H[lv], W = L.W[lv], strips = (W + 3) >> 2;
+    in += L.row_off[lv] * ldi;
+    out += L.row_off[lv] * ldo;
     const int cg = (int)(idx % C8);
     long t = idx / C8;
     const int sx = (int)(t % strips);
@@ -320,15 +325,15 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const bf16* in, int ldi
 // wgrad partials: part[block][c*9 + tap] = sum over the block's pixels of dz[pix][c] * x[pix + tap - 1][c].
 // A block = (C/8 channel groups) x (256 / (C/8) pixel lanes); every lane walks `ppl` consecutive pixels, then the lanes are summed
 // through LDS (three rounds of 24 accumulators) so that one partial row per block leaves the chip.
-__global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const bf16* x, int ldx, const bf16* dz, int ldz, float* part, int N, int H,
-                                                           int W, int C, int ppl) {
+__global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const bf16* x, int ldx, const bf16* dz, int ldz, float* part, int N, int C,
+                                                           int ppl, const Levels L) {
     __shared__ float red[256][25];
     const int C8 = C >> 3;
     const int lanes = 256 / C8;
     const int tid = threadIdx.x;
     const int cg = tid % C8, lane = tid / C8;
     const bool active = lane < lanes;
-    const long total = (long)N * H * W;
+    const long total = L.row_off[L.n];
     const long p0 = ((long)blockIdx.x * lanes + lane) * ppl;
     long p1 = p0 + ppl;
     if (p1 > total) p1 = total;
@@ -338,11 +343,16 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const bf16* x, int ld
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[tq][k] = 0.f;
     if (active) {
+        int lv = level_of_row(L, p0);
         for (long pix = p0; pix < p1; ++pix) {
-            const int ox = (int)(pix % W);
-            const long t1 = pix / W;
+            while (lv + 1 < L.n && pix >= L.row_off[lv + 1]) ++lv;
+            const int H = L.H[lv], W = L.W[lv];
+            const long lp = pix - L.row_off[lv];
+            const int ox = (int)(lp % W);
+            const long t1 = lp / W;
             const int oy = (int)(t1 % H);
             const long n = t1 / H;
+            const bf16* xl = x + L.row_off[lv] * ldx;
             // all ten loads of a pixel are issued before the first FMA: border taps read a clamped address and are masked to zero
             const bf16x8 zv = ld8(dz + pix * ldz + cg * 8);
             bf16x8 xv[9];
@@ -356,7 +366,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const bf16* x, int ld
                     const int ix = ox + kx - 1;
                     const int ixc = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
                     msk[ky * 3 + kx] = (iy == iyc && ix == ixc) ? 1.f : 0.f;
-                    xv[ky * 3 + kx] = ld8(x + ((n * H + iyc) * (long)W + ixc) * ldx + cg * 8);
+                    xv[ky * 3 + kx] = ld8(xl + ((n * H + iyc) * (long)W + ixc) * ldx + cg * 8);
                 }
             }
             float zf[8];
@@ -836,12 +846,35 @@ extern "C" int hn_dw_pack(const float* w, void* wk, void* wkf, int C, hipStream_
     hipLaunchKernelGGL(dw_pack_kernel, dim3(cdiv(9L * C, 256)), dim3(256), 0, st, w, (bf16*)wk, (bf16*)wkf, C);
     HN_LAUNCH_CHECK();
 }
-extern "C" int hn_dwconv_fwd(const void* in, int ldi, const void* wk, void* out, int ldo, int N, int H, int W, int C, hipStream_t st) {
+static int fill_levels(Levels& L, int N, int nlev, const int* H, const int* W) {
+    HN_CHECK_ARG(nlev >= 1 && nlev <= HN_MAX_LEVELS && H && W);
+    L.n = nlev;
+    L.row_off[0] = 0;
+    for (int l = 0; l < nlev; ++l) {
+        HN_CHECK_ARG(H[l] > 0 && W[l] > 0);
+        L.H[l] = H[l]; L.W[l] = W[l];
+        L.row_off[l + 1] = L.row_off[l] + (long)N * H[l] * W[l];
+    }
+    return HN_OK;
+}
+static int dwconv_fwd_launch(const void* in, int ldi, const void* wk, void* out, int ldo, int N, int C, Levels& L, hipStream_t st) {
     HN_CHECK_ARG(in && wk && out && (C & 7) == 0 && ((ldi | ldo) & 7) == 0);
-    const long total = (long)N * H * ((W + 3) >> 2) * (C >> 3);
-    hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, (const bf16*)in, ldi, (const bf16*)wk, (bf16*)out, ldo, N,
-                       H, W, C);
+    L.work_off[0] = 0;
+    for (int l = 0; l < L.n; ++l) L.work_off[l + 1] = L.work_off[l] + (long)N * L.H[l] * ((L.W[l] + 3) >> 2) * (C >> 3);
+    hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(cdiv(L.work_off[L.n], 256)), dim3(256), 0, st, (const bf16*)in, ldi, (const bf16*)wk, (bf16*)out,
+                       ldo, N, C, L);
     HN_LAUNCH_CHECK();
+}
+extern "C" int hn_dwconv_fwd(const void* in, int ldi, const void* wk, void* out, int ldo, int N, int H, int W, int C, hipStream_t st) {
+    Levels L;
+    const int rc = fill_levels(L, N, 1, &H, &W);
+    return rc != HN_OK ? rc : dwconv_fwd_launch(in, ldi, wk, out, ldo, N, C, L, st);
+}
+extern "C" int hn_dwconv_fwd_levels(const void* in, int ldi, const void* wk, void* out, int ldo, int N, int C, int nlev, const int* H,
+                                    const int* W, hipStream_t st) {
+    Levels L;
+    const int rc = fill_levels(L, N, nlev, H, W);
+    return rc != HN_OK ? rc : dwconv_fwd_launch(in, ldi, wk, out, ldo, N, C, L, st);
 }
 // number of partial rows (= blocks) of hn_dwconv_wgrad; part is fp32 [blocks][C*9], reduce with hn_rows_reduce(part, dw, 1, blocks, C*9, 1)
 extern "C" long hn_dwconv_wgrad_blocks(long pixels, int C) {
@@ -850,14 +883,25 @@ extern "C" long hn_dwconv_wgrad_blocks(long pixels, int C) {
     if (ppl < 4) ppl = 4;
     return (pixels + ppl * lanes - 1) / (ppl * lanes);
 }
-extern "C" int hn_dwconv_wgrad(const void* x, int ldx, const void* dz, int ldz, float* part, int N, int H, int W, int C, hipStream_t st) {
+static int dwconv_wgrad_launch(const void* x, int ldx, const void* dz, int ldz, float* part, int N, int C, const Levels& L, hipStream_t st) {
     HN_CHECK_ARG(x && dz && part && (C & 7) == 0 && C <= 2048 && ((ldx | ldz) & 7) == 0);
-    const long pixels = (long)N * H * W;
+    const long pixels = L.row_off[L.n];
     const int lanes = 256 / (C >> 3);
     const long blocks = hn_dwconv_wgrad_blocks(pixels, C);
     const int ppl = (int)((pixels + blocks * lanes - 1) / (blocks * lanes));
-    hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3(blocks), dim3(256), 0, st, (const bf16*)x, ldx, (const bf16*)dz, ldz, part, N, H, W, C, ppl);
+    hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3(blocks), dim3(256), 0, st, (const bf16*)x, ldx, (const bf16*)dz, ldz, part, N, C, ppl, L);
     HN_LAUNCH_CHECK();
+}
+extern "C" int hn_dwconv_wgrad(const void* x, int ldx, const void* dz, int ldz, float* part, int N, int H, int W, int C, hipStream_t st) {
+    Levels L;
+    const int rc = fill_levels(L, N, 1, &H, &W);
+    return rc != HN_OK ? rc : dwconv_wgrad_launch(x, ldx, dz, ldz, part, N, C, L, st);
+}
+extern "C" int hn_dwconv_wgrad_levels(const void* x, int ldx, const void* dz, int ldz, float* part, int N, int C, int nlev, const int* H,
+                                      const int* W, hipStream_t st) {
+    Levels L;
+    const int rc = fill_levels(L, N, nlev, H, W);
+    return rc != HN_OK ? rc : dwconv_wgrad_launch(x, ldx, dz, ldz, part, N, C, L, st);
 }
 
 extern "C" int hn_maxpool_fwd(const void* in, int ldi, void* out, int ldo, int N, int H, int W, int C, int mode, hipStream_t st) {

@@ -120,6 +120,7 @@ class HydraNet(nn.Module):
         self._pending_nbt = []
         self.heads_on_side_stream = False          # measured: no gain over the single-stream graph on MI355X (kept for experiments)
         self._side_streams = {}
+        self.pack_det_levels = True         # level-packed det towers when every level has a multiple of 128 rows
         self.levels_on_streams = False      # hipGraph branches cost more than they hide on gfx950 (55 vs 43 ms)
 
         spec = _Spec(self)
@@ -430,10 +431,33 @@ class HydraNet(nn.Module):
         return K.HeadOut.apply(P[p + "header.depthwise_conv.conv.weight"], P[p + "header.pointwise_conv.conv.weight"],
                                P[p + "header.pointwise_conv.conv.bias"], k, act, *outs)
 
+    def _det_tower_packed(self, p, xp, geom, k, act):
+        """Regressor / Classifier on level-packed rows: one launch per op for all five levels (ops.TowerLayer)."""
+        P = self._idx
+        layers = self.cfgs["detection"]["box_class_repeats"]
+        f = xp
+        for i in range(layers):
+            bn = []
+            for lv in range(len(geom[1])):
+                g, b, rm, rv, _ = self._bn(f"{p}bn_list.{lv}.{i}")
+                bn += [g, b, rm, rv]
+            f = K.TowerLayer.apply(f, P[f"{p}conv_list.{i}.depthwise_conv.conv.weight"], P[f"{p}conv_list.{i}.pointwise_conv.conv.weight"],
+                                   P.get(f"{p}conv_list.{i}.pointwise_conv.conv.bias"), geom, ACT_SWISH, BN_FPN["eps"], BN_FPN["momentum"],
+                                   self.training, *bn)
+        return K.HeadOutPacked.apply(P[p + "header.depthwise_conv.conv.weight"], P[p + "header.pointwise_conv.conv.weight"],
+                                     P[p + "header.pointwise_conv.conv.bias"], k, act, geom, f)
+
     def _det(self, x, fused):
         anchors = self.anchors_for(x.shape[2], x.shape[3], x.device)
-        reg = self._det_tower("detectheader.regressor.", fused, 4, ACT_NONE)
-        cls = self._det_tower("detectheader.classifier.", fused, self.cfgs["detection"]["num_classes"], ACT_SIGMOID)
+        ncls = self.cfgs["detection"]["num_classes"]
+        if self.pack_det_levels and K.levels_packable(fused):
+            geom = (fused[0].shape[0], tuple(f.shape[1] for f in fused), tuple(f.shape[2] for f in fused))
+            xp = K.PackLevels.apply(*fused)
+            reg = self._det_tower_packed("detectheader.regressor.", xp, geom, 4, ACT_NONE)
+            cls = self._det_tower_packed("detectheader.classifier.", xp, geom, ncls, ACT_SIGMOID)
+        else:
+            reg = self._det_tower("detectheader.regressor.", fused, 4, ACT_NONE)
+            cls = self._det_tower("detectheader.classifier.", fused, ncls, ACT_SIGMOID)
         return anchors, reg, cls
 
     def _lane(self, fused):

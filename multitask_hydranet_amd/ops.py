@@ -756,3 +756,197 @@ class DetLoss(torch.autograd.Function):
 def det_loss_hip(classification, regression, anchors, annotations):
     out = DetLoss.apply(classification, regression, anchors, annotations)
     return out[0:1], out[1:2]
+
+
+# --------------------------------------------------------------------------------------------------------------
+# Level-packed det-head towers.  Regressor / Classifier apply the SAME SeparableConvBlock to the five pyramid levels and differ only
+# in the per-level BatchNorm (head_detect/detection.py:20-35,57-72).  Launched level by level that is ~650 launches per step, most of
+# them on 4x8 ... 16x32 maps where a launch is pure latency.  Here the levels live stacked in one [sum_l N*H_l*W_l, C] tensor: the
+# depthwise conv, the pointwise GEMM (+ statistics), the BatchNorm passes and every backward kernel run ONCE for all levels, with the
+# per-level BatchNorm parameters selected per row block inside the kernels.  Requires every level's row count to be a multiple of 128.
+# --------------------------------------------------------------------------------------------------------------
+def levels_packable(feats):
+    return len(feats) <= 5 and all((f.shape[0] * f.shape[1] * f.shape[2]) % 128 == 0 for f in feats)
+
+
+def _geom_arrays(geom):
+    n, hs, ws = geom
+    nl = len(hs)
+    H = (ctypes.c_int * nl)(*hs)
+    W = (ctypes.c_int * nl)(*ws)
+    R = (ctypes.c_long * nl)(*[n * h * w for h, w in zip(hs, ws)])
+    return nl, H, W, R
+
+
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() if t is not None else None for t in tensors])
+
+
+def level_views(packed, geom):
+    """NHWC views of the levels of a packed [1, 1, rows, C] tensor"""
+    n, hs, ws = geom
+    out, off = [], 0
+    for h, w in zip(hs, ws):
+        m = n * h * w
+        out.append(packed[0, 0, off:off + m].view(n, h, w, packed.shape[3]))
+        off += m
+    return out
+
+
+def k_dwconv_levels(x, wk, geom):
+    nl, H, W, _ = _geom_arrays(geom)
+    out = torch.empty_like(x)
+    lib().call("hn_dwconv_fwd_levels", ptr(x), ld(x), ptr(wk), ptr(out), ld(out), geom[0], x.shape[3], nl, ctypes.addressof(H),
+               ctypes.addressof(W))
+    return out
+
+
+def k_dwconv_wgrad_levels(x, dz, geom):
+    nl, H, W, _ = _geom_arrays(geom)
+    c = x.shape[3]
+    chunks = lib().query("hn_dwconv_wgrad_blocks", x.shape[2], c)
+    part = torch.empty((chunks, c * 9), device=x.device, dtype=F32)
+    lib().call("hn_dwconv_wgrad_levels", ptr(x), ld(x), ptr(dz), ld(dz), ptr(part), geom[0], c, nl, ctypes.addressof(H), ctypes.addressof(W))
+    return k_rows_reduce(part, 1, chunks, c * 9).view(c, 1, 3, 3)
+
+
+class PackLevels(torch.autograd.Function):
+    """stack pyramid levels [N,H_l,W_l,C] into one [1, 1, sum rows, C] tensor (backward hands out views of the packed gradient)"""
+
+    @staticmethod
+    def forward(ctx, *feats):
+        n, c = feats[0].shape[0], feats[0].shape[3]
+        geom = (n, tuple(f.shape[1] for f in feats), tuple(f.shape[2] for f in feats))
+        total = sum(rows(f) for f in feats)
+        out = torch.empty((1, 1, total, c), device=feats[0].device, dtype=BF16)
+        for v, f in zip(level_views(out, geom), feats):
+            k_eltwise(2, f, alpha=1.0, out=v)
+        ctx.geom = geom
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(level_views(dense(g), ctx.geom))
+
+
+class TowerLayer(torch.autograd.Function):
+    """out = act(BN_level(pointwise(depthwise(x)) + bias)) on level-packed rows; bn = nlev x (gamma, beta, running_mean, running_var)."""
+
+    @staticmethod
+    def forward(ctx, x, dw_w, pw_w, pw_b, geom, act, eps, momentum, training, *bn):
+        nl, H, W, R = _geom_arrays(geom)
+        total, c = x.shape[2], x.shape[3]
+        cout = pw_w.shape[0]
+        dev = x.device
+        wk, wf = pack_dw_weight(dw_w)
+        d = k_dwconv_levels(x, wk, geom)
+        wp, wt = pack_conv_weight(pw_w)
+        z, psum, psq = k_gemm_nt(d, None, 0, (1, 1, total), wp, cout, kp32(c), 1, bias=pw_b, stats=training)
+        gam, bet = [bn[4 * l] for l in range(nl)], [bn[4 * l + 1] for l in range(nl)]
+        rms, rvs = [bn[4 * l + 2] for l in range(nl)], [bn[4 * l + 3] for l in range(nl)]
+        coef = torch.empty((nl, 4, cout), device=dev, dtype=F32)
+        if training:
+            div = total // psum.shape[0]
+            ga, ba, rma, rva = _ptr_array(gam), _ptr_array(bet), _ptr_array(rms), _ptr_array(rvs)    # keep the host arrays alive
+            lib().call("hn_bn_finalize_levels", ptr(psum), ptr(psq), div, cout, nl, ctypes.addressof(R), ctypes.addressof(R),
+                       ctypes.addressof(ga), ctypes.addressof(ba), ctypes.addressof(rma), ctypes.addressof(rva), float(eps),
+                       float(momentum), ptr(coef))
+        else:
+            for l in range(nl):
+                lib().call("hn_bn_eval_coeff", ptr(gam[l]), ptr(bet[l]), ptr(rms[l]), ptr(rvs[l]), float(eps), cout, ptr(coef[l, 0]),
+                           ptr(coef[l, 1]))
+        out = torch.empty((1, 1, total, cout), device=dev, dtype=BF16)
+        lib().call("hn_bn_act_levels", ptr(z), ld(z), ptr(coef), act, ptr(out), ld(out), cout, nl, ctypes.addressof(R))
+        ctx.geom, ctx.act, ctx.training = geom, act, training
+        ctx.has_bias = pw_b is not None
+        ctx.packs = (wf, wt)
+        ctx.save_for_backward(x, d, z, coef, pw_w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, d, z, coef, pw_w = ctx.saved_tensors
+        assert ctx.training, "backward through eval-mode BatchNorm is not part of the hot path"
+        geom, act = ctx.geom, ctx.act
+        nl, H, W, R = _geom_arrays(geom)
+        wf, wt = ctx.packs
+        dout = dense(dout)
+        total, c = x.shape[2], x.shape[3]
+        cout = z.shape[3]
+        dev = z.device
+        r = lib().query("hn_colred_rows", total, 128)
+        pr = total // r
+        pg = torch.empty((pr, cout), device=dev, dtype=F32)
+        pgx = torch.empty((pr, cout), device=dev, dtype=F32)
+        lib().call("hn_bn_bwd_reduce_levels", ptr(dout), ld(dout), ptr(z), ld(z), None, 0, ptr(coef), act, cout, r, nl, ctypes.addressof(R),
+                   ptr(pg), ptr(pgx))
+        red = torch.empty((nl, 2, cout), device=dev, dtype=F32)
+        dgb = torch.empty((nl, 2, cout), device=dev, dtype=F32)
+        dgam, dbet = [dgb[l, 0] for l in range(nl)], [dgb[l, 1] for l in range(nl)]
+        dga, dba = _ptr_array(dgam), _ptr_array(dbet)
+        lib().call("hn_bn_bwd_finalize_levels", ptr(pg), ptr(pgx), r, cout, nl, ctypes.addressof(R), ctypes.addressof(R),
+                   ctypes.addressof(dga), ctypes.addressof(dba), ptr(red))
+        dz = torch.empty_like(z)
+        lib().call("hn_bn_bwd_apply_levels", ptr(dout), ld(dout), ptr(z), ld(z), None, 0, ptr(coef), ptr(red), act, ptr(dz), ld(dz), cout, nl,
+                   ctypes.addressof(R))
+        dd, _, _ = k_gemm_nt(dz, None, 0, (1, 1, total), wt, c, kp32(cout), 1)
+        dpw = k_gemm_tn(d, None, 0, (1, 1, total), dz, cout, kp32(c), 1, c)
+        dbias = torch.zeros((cout,), device=dev, dtype=F32) if ctx.has_bias else None    # a bias feeding BatchNorm has zero gradient
+        ddw = k_dwconv_wgrad_levels(x, dd, geom)
+        dx = k_dwconv_levels(dd, wf, geom) if ctx.needs_input_grad[0] else None
+        bn_grads = []
+        for l in range(nl):
+            bn_grads += [dgam[l], dbet[l], None, None]
+        return (dx, ddw, dpw, dbias, None, None, None, None, None, *bn_grads)
+
+
+class HeadOutPacked(torch.autograd.Function):
+    """HeadOut on a level-packed input: depthwise, data gradient and all weight gradients run once for all levels; only the pointwise
+    GEMM forward (per-level output mapping into the [N, sum_l H_l*W_l*rep, k] concat) and its gradient gather stay per level."""
+
+    @staticmethod
+    def forward(ctx, dw_weight, pw_weight, bias, k, act, geom, x):
+        n, hs, ws = geom
+        cout, cin = pw_weight.shape[0], pw_weight.shape[1]
+        wp, wt = pack_conv_weight(pw_weight)
+        wk, wf = pack_dw_weight(dw_weight)
+        rows_total = sum(h * w for h, w in zip(hs, ws))
+        rep = cout // k
+        out = torch.empty((n, rows_total * rep, k), device=x.device, dtype=F32)
+        ldc, img_stride = cout, rows_total * cout
+        mid = k_dwconv_levels(x, wk, geom)
+        off = 0
+        for v, h, w in zip(level_views(mid, geom), hs, ws):
+            k_gemm_nt(v, None, 0, (n, h, w), wp, cout, kp32(cin), 1, bias=bias, act=act, out=out.view(-1)[off * ldc:], out_f32=True, ldc=ldc,
+                      rpi=h * w, img_stride=img_stride)
+            off += h * w
+        ctx.meta = (k, act, ldc, img_stride, geom)
+        ctx.packs = (wf, wt)
+        ctx.save_for_backward(pw_weight, out if act == ACT_SIGMOID else None, x, mid)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        k, act, ldc, img_stride, geom = ctx.meta
+        n, hs, ws = geom
+        pw_weight, yout, x, mid = ctx.saved_tensors
+        wf, wt = ctx.packs
+        cout, cin = pw_weight.shape[0], pw_weight.shape[1]
+        dout = dout.contiguous()
+        dev = dout.device
+        ldz = pad8(cout)
+        total = x.shape[2]
+        dz = torch.empty((1, 1, total, ldz), device=dev, dtype=BF16)
+        off = 0
+        for v, h, w in zip(level_views(dz, geom), hs, ws):
+            base = off * ldc
+            lib().call("hn_head_grad", ptr(dout.view(-1)[base:]), ptr(yout.view(-1)[base:]) if yout is not None else None, h * w, img_stride,
+                       ldc, cout, ptr(v), ldz, n * h * w, 1 if act == ACT_SIGMOID else 0)
+            off += h * w
+        ps, _, _ = k_col_stats(dz)
+        dbias = k_rows_reduce(ps, 1, ps.shape[0], ldz).view(-1)[:cout]
+        dpw = k_gemm_tn(mid, None, 0, (1, 1, total), dz, cout, kp32(cin), 1, cin)
+        dmid, _, _ = k_gemm_nt(dz, None, 0, (1, 1, total), wt, cin, kp32(cout), 1, c0=ldz, c1=0)
+        ddw = k_dwconv_wgrad_levels(x, dmid, geom)
+        dx = k_dwconv_levels(dmid, wf, geom)
+        return ddw, dpw, dbias, None, None, None, dx

@@ -326,3 +326,43 @@ def test_deploy_mode_and_bit_exact_bookkeeping(env):
         np.testing.assert_allclose(np.asarray(o["rois"], np.float32), z[f"deploy/pp{i}/rois"], rtol=1e-6, atol=1e-5)
         total += len(o["class_ids"])
     assert total > 0
+
+
+@pytest.mark.gpu
+def test_det_towers_level_packed_equals_per_level():
+    """ops.TowerLayer / HeadOutPacked (one launch per op for all five pyramid levels) against the per-level path on the same inputs:
+    same arithmetic, only the order of the BatchNorm partial sums differs."""
+    import copy
+    import yaml
+    from multitask_hydranet_amd import HydraNet
+    cfgs = yaml.safe_load(open(os.path.join(os.path.dirname(__file__), "..", "cfgs", "hydranet_tiny.yml")))
+    cfgs["dataloader"]["network_input_height"], cfgs["dataloader"]["network_input_width"] = 256, 512
+    torch.manual_seed(3)
+    net = HydraNet(cfgs).cuda().train()
+    n, c = 16, net.fpn_num_filters
+    img = torch.zeros(n, 3, 256, 512, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(5)
+    res = {}
+    for packed in (False, True):
+        net.pack_det_levels = packed
+        net.zero_grad(set_to_none=True)
+        fused = [torch.randn(n, 256 >> s, 512 >> s, c, device="cuda", generator=torch.Generator(device="cuda").manual_seed(7 + s))
+                 .to(torch.bfloat16).requires_grad_(True) for s in (3, 4, 5, 6, 7)]
+        _, reg, cls = net._det(img, fused)
+        wr = torch.randn(reg.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(11))
+        wc = torch.randn(cls.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(12))
+        ((reg * wr).mean() + (cls * wc).mean()).backward()
+        res[packed] = dict(reg=reg.detach().clone(), cls=cls.detach().clone(), dx=[f.grad.float().clone() for f in fused],
+                           dp={k: v.grad.clone() for k, v in net.named_parameters() if k.startswith("detectheader.") and v.grad is not None},
+                           rm={k: v.clone() for k, v in net.named_buffers() if k.startswith("detectheader.") and "running" in k})
+    a, b = res[False], res[True]
+    assert len(a["dp"]) == len(b["dp"]) and len(a["dp"]) > 0
+    def close(x, y, tol, what):
+        err = float((x - y).abs().max()) / max(float(x.abs().max()), 1e-12)
+        assert err <= tol, (what, err)
+    close(a["reg"], b["reg"], 1e-2, "reg")
+    close(a["cls"], b["cls"], 1e-2, "cls")
+    for i, (x, y) in enumerate(zip(a["dx"], b["dx"])):
+        close(x, y, 3e-2, f"dx level {i}")
+    for k in a["dp"]:
+        close(a["dp"][k], b["dp"][k], 3e-2, k)
