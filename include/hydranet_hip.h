@@ -35,6 +35,9 @@ int hn_pack_weight(const float* w, void* wp, void* wt, int Cout, int Cin, int ta
  *   mode 2: 3x3 conv over reflect-pad-1 of cat[nearest_up2(x0) if up else x0, x1]   head_seg/segmentation.py:16-48,84-105
  *   mode 3: 3x3 "full" correlation of zero-extended x0 (dgrad of mode 2 on the padded (H+2)x(W+2) grid; H, W passed here are the
  *           PADDED sizes); fold back with hn_seg_fold.
+ *   mode 4: mode 2 with replicate (clamp) padding, no up-sampling / concat: the low-resolution form of a 3x3 reflect-pad conv over a
+ *           nearest-x2 up-sampled map (reflection of the up-sampled index == clamping of the source index); used with 4-phase
+ *           effective weights for the final seg conv (head_seg/segmentation.py:101-104), see hn_depth_to_space.
  * (n_img, H, W) describe the OUTPUT pixel grid, M = n_img*H*W rows.  psum/psq (optional) receive per-wave partial sums / sums of
  * squares of the bf16-rounded outputs, [hn_nt_stat_rows(M, Nout)][Nout], for training-mode BatchNorm (F.batch_norm statistics).
  * rpi/img_stride (optional, 0 = off): out offset(pixel) = (pixel / rpi) * img_stride + (pixel % rpi) * ldc, which writes a pyramid
@@ -45,6 +48,7 @@ int hn_conv_gemm_nt(const void* x0, const void* x1, int mode, int n_img, int H, 
 int hn_nt_stat_rows(long M, int Nout);
 /* tuning hook for tools/: force the cout tile (16/32/64/128) and LDS ring depth (2..4) of later hn_conv_gemm_nt launches; 0 = automatic */
 int hn_debug_nt_config(int bc, int r);
+int hn_debug_tn_config(int bc, int bn, int splits);
 
 /* wgrad: dw[Cout][Cin][taps] (PyTorch layout, fp32) = sum_pixel dz[pixel][cout] * X(pixel, tap)[c]; X modes 0..2 as above.
  * dz rows must be zero padded up to ldz >= Nout rounded up to 8.  workspace: fp32, size from hn_wgrad_plan.
@@ -108,6 +112,12 @@ int hn_fuse_bwd(const void* const* in, const int* ld, const int* mode, const flo
 /* Backward of ReflectionPad2d(1) (+ nearest x2, + channel split of the concat) for the seg decoder (head_seg/segmentation.py:40,92-99). */
 int hn_seg_fold(const void* dvp, int ldv, int c0, void* out, int ldo, const void* yprev, int ldy, int N, int H, int W, int C, int up,
                 hipStream_t stream);
+/* up = 2 selects the replicate-padding fold (backward of mode 4). */
+
+/* Pixel shuffles of the phase-decomposed final seg conv: in [N][h][w][(py*2+px)*k + o] (row stride ldi) -> out [N][2h][2w][k] fp32, and
+ * the gradient gather fp32 [N][2h][2w][k] -> zero-padded bf16 [N][h][w][ldo]. */
+int hn_depth_to_space(const float* in, int ldi, float* out, int N, int h, int w, int k, hipStream_t stream);
+int hn_space_to_depth(const float* dy, void* out, int ldo, int N, int h, int w, int k, hipStream_t stream);
 
 /* fp32 head-output gradient [N][rows][Nout] -> zero padded bf16 dz [N*rpi][ldz] (optionally times sigmoid'). */
 int hn_head_grad(const float* dy, const float* y, long rpi, long img_stride, int lds, int Nout, void* dz, int ldz, long M, int sigmoid,

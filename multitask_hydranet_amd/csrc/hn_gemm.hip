@@ -20,7 +20,14 @@ struct XSrc {
     int ld0, ld1;  // row strides (elements)
     int up;        // mode 2: x0 lives at (Hi>>1, Wi>>1)
     long M;        // number of output rows
+    int clamp;     // mode 2: replicate (clamp) padding instead of reflection (API mode 4)
 };
+
+// padded-border source index of a 3x3 tap: ReflectionPad2d(1) or replicate padding
+__device__ __forceinline__ int border_idx(int v, int L, int clamp) {
+    if (clamp) return v < 0 ? 0 : (v >= L ? L - 1 : v);
+    return v < 0 ? -v : (v >= L ? 2 * L - 2 - v : v);
+}
 
 __device__ __forceinline__ void decomp_row(const XSrc& s, long m, int& n, int& oy, int& ox) {
     if (s.mode == 0) { n = 0; oy = 0; ox = 0; return; }
@@ -158,7 +165,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
             const int k = i / p.x.H, o = i - k * p.x.H;
             if (p.x.mode == 2) {
                 int v = o + k - 1;
-                v = v < 0 ? -v : (v >= p.x.Hi ? 2 * p.x.Hi - 2 - v : v);
+                v = border_idx(v, p.x.Hi, p.x.clamp);
                 ty0[i] = v >> p.x.up;
                 if (p.x.C1) ty1[i] = v;
             } else {
@@ -170,7 +177,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
             const int k = i / p.x.W, o = i - k * p.x.W;
             if (p.x.mode == 2) {
                 int v = o + k - 1;
-                v = v < 0 ? -v : (v >= p.x.Wi ? 2 * p.x.Wi - 2 - v : v);
+                v = border_idx(v, p.x.Wi, p.x.clamp);
                 tx0[i] = v >> p.x.up;
                 if (p.x.C1) tx1[i] = v;
             } else {
@@ -458,10 +465,8 @@ __global__ __launch_bounds__(512) void conv3x3_direct_kernel(const GemmNT p) {
             const int py = pp / 18, px = pp - py * 18;
             int gy = oy0 + org + py, gx = ox0 + org + px;
             if (xs.mode == 2) {
-                gy = gy < 0 ? -gy : gy;
-                gx = gx < 0 ? -gx : gx;
-                gy = gy >= xs.Hi ? 2 * xs.Hi - 2 - gy : gy;
-                gx = gx >= xs.Wi ? 2 * xs.Wi - 2 - gx : gx;
+                gy = border_idx(gy, xs.Hi, xs.clamp);
+                gx = border_idx(gx, xs.Wi, xs.clamp);
                 if (gy >= 0 && gx >= 0) {                             // (negative only for pixels that feed no in-image output)
                     spix0[i] = (n * (xs.Hi >> xs.up) + (gy >> xs.up)) * (xs.Wi >> xs.up) + (gx >> xs.up);
                     if (xs.C1) spix1[i] = (n * xs.Hi + gy) * xs.Wi + gx;
@@ -655,13 +660,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN p) {
         const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
         for (int i = tid; i < p.x.H; i += 256) {
             int iy = i + ky - 1;
-            iy = iy < 0 ? -iy : (iy >= p.x.Hi ? 2 * p.x.Hi - 2 - iy : iy);
+            iy = border_idx(iy, p.x.Hi, p.x.clamp);
             ty1[i] = iy;
             ty0[i] = iy >> p.x.up;
         }
         for (int i = tid; i < p.x.W; i += 256) {
             int ix = i + kx - 1;
-            ix = ix < 0 ? -ix : (ix >= p.x.Wi ? 2 * p.x.Wi - 2 - ix : ix);
+            ix = border_idx(ix, p.x.Wi, p.x.clamp);
             tx1[i] = ix;
             tx0[i] = ix >> p.x.up;
         }
@@ -837,10 +842,8 @@ __global__ __launch_bounds__(512) void wgrad3x3_patch_kernel(const GemmTN p, int
                 if (px_ < XPIX && c < Ctot) {
                     const int py = px_ / 18, pxx = px_ - py * 18;
                     int gy = oy0 - 1 + py, gx = ox0 - 1 + pxx;
-                    gy = gy < 0 ? -gy : gy;
-                    gx = gx < 0 ? -gx : gx;
-                    gy = gy >= xs.Hi ? 2 * xs.Hi - 2 - gy : gy;
-                    gx = gx >= xs.Wi ? 2 * xs.Wi - 2 - gx : gx;
+                    gy = border_idx(gy, xs.Hi, xs.clamp);
+                    gx = border_idx(gx, xs.Wi, xs.clamp);
                     if (gy >= 0 && gx >= 0) {
                         if (c < xs.C0) src = xs.x0 + c + (long)((n * (xs.Hi >> xs.up) + (gy >> xs.up)) * (xs.Wi >> xs.up) + (gx >> xs.up)) * xs.ld0;
                         else src = xs.x1 + (c - xs.C0) + (long)((n * xs.Hi + gy) * xs.Wi + gx) * xs.ld1;
@@ -949,6 +952,8 @@ static XSrc make_xsrc(const void* x0, const void* x1, int mode, int n_img, int H
     XSrc s;
     s.x0 = (const bf16*)x0;
     s.x1 = (const bf16*)x1;
+    s.clamp = mode == 4;
+    if (mode == 4) mode = 2;
     s.mode = mode;
     s.H = H; s.W = W;
     s.Hi = H; s.Wi = W;
@@ -1021,12 +1026,13 @@ extern "C" int hn_conv_gemm_nt(const void* x0, const void* x1, int mode, int n_i
                                int out_f32, int ldc, long rpi, long img_stride, float* psum, float* psq, hipStream_t st) {
     HN_CHECK_ARG(x0 && w && out && M > 0 && Nout > 0 && KP > 0 && (KP & 31) == 0 && taps >= 1 && taps <= 9);
     HN_CHECK_ARG((C0 & 7) == 0 && (C1 & 7) == 0 && (ld0 & 7) == 0 && (C1 == 0 || (x1 && (ld1 & 7) == 0)));
-    HN_CHECK_ARG(C0 + C1 <= KP && mode >= 0 && mode <= 3);
+    HN_CHECK_ARG(C0 + C1 <= KP && mode >= 0 && mode <= 4 && (mode != 4 || (up == 0 && C1 == 0)));
     HN_CHECK_ARG(mode == 0 || (long)n_img * H * W == M);
     HN_CHECK_ARG(mode < 2 ? taps == 1 : taps == 9);
     HN_CHECK_ARG(mode != 2 || (H >= 2 && W >= 2));
     GemmNT p;
     p.x = make_xsrc(x0, x1, mode, n_img, H, W, C0, C1, ld0, ld1, up, M);
+    mode = p.x.mode;
     p.w = (const bf16*)w; p.Nout = Nout; p.KP = KP; p.taps = taps;
     p.bias = bias; p.act = act; p.out = out; p.ldc = ldc; p.psum = psum; p.psq = psq;
     p.rpi = rpi; p.img_stride = img_stride;
@@ -1072,13 +1078,18 @@ static int launch_tn(const GemmTN& p, int splits, hipStream_t st) {
     HN_LAUNCH_CHECK();
 }
 
+// Tuning hook (tools/ only): force the wgrad tile and split count of later hn_conv_gemm_tn launches; 0 = automatic.
+static int g_tn_force_bc = 0, g_tn_force_bn = 0, g_tn_force_splits = 0;
+extern "C" int hn_debug_tn_config(int bc, int bn, int splits) { g_tn_force_bc = bc; g_tn_force_bn = bn; g_tn_force_splits = splits; return 0; }
+
 static void tn_tiles(int Nout, int KP, int& bc, int& bn) {
+    if (g_tn_force_bc && g_tn_force_bn) { bc = g_tn_force_bc; bn = g_tn_force_bn; return; }
     bc = Nout <= 16 ? 16 : (Nout <= 32 ? 32 : (Nout <= 64 ? 64 : 128));
     bn = KP <= 32 ? 32 : (KP <= 64 ? 64 : 128);
     if (bc == 16 && bn < 64) bn = 64;                       // 4 waves need >= 16 columns each
 }
 
-static bool use_patch_wgrad(int mode, int Nout, int KP) { return mode == 2 && (Nout >= 64 || Nout <= 16) && KP >= 64; }
+static bool use_patch_wgrad(int mode, int Nout, int KP) { return mode == 2 && KP >= 64; }
 static void patch_tiles(int Nout, int& bc, int& ci, int& ksplit) {
     if (Nout <= 16) { bc = 16; ci = 64; ksplit = 2; }
     else if (Nout <= 64) { bc = 64; ci = 128; ksplit = 1; }
@@ -1090,6 +1101,7 @@ static void patch_tiles(int Nout, int& bc, int& ci, int& ksplit) {
 extern "C" int hn_wgrad_plan(int mode, int n_img, int H, int W, long M, int Nout, int KP, int taps, int* splits, long* rows_per_split,
                              long* ws_bytes) {
     HN_CHECK_ARG(M > 0 && Nout > 0 && KP > 0 && taps > 0 && splits && rows_per_split && ws_bytes);
+    if (mode == 4) mode = 2;
     if (use_patch_wgrad(mode, Nout, KP)) {
         int bc, ci, ksplit;
         patch_tiles(Nout, bc, ci, ksplit);
@@ -1110,6 +1122,7 @@ extern "C" int hn_wgrad_plan(int mode, int n_img, int H, int W, long M, int Nout
     long want = (1024 + tiles - 1) / tiles;                 // ~4 workgroups per CU in total
     const long max_splits = (M + 255) / 256;                // at least 256 rows per split
     if (want > max_splits) want = max_splits;
+    if (g_tn_force_splits) want = g_tn_force_splits;
     if (want < 1) want = 1;
     long rps = ((M + want - 1) / want + 63) / 64 * 64;
     *splits = (int)((M + rps - 1) / rps);
@@ -1122,12 +1135,13 @@ extern "C" int hn_conv_gemm_tn(const void* x0, const void* x1, int mode, int n_i
                                int up, long M, const void* dz, int ldz, int Nout, int KP, int taps, float* workspace, float* dw,
                                hipStream_t st) {
     HN_CHECK_ARG(x0 && dz && workspace && dw && M > 0 && (KP & 31) == 0 && (ldz & 7) == 0 && ldz >= ((Nout + 7) & ~7));
-    HN_CHECK_ARG((C0 & 7) == 0 && (C1 & 7) == 0 && (ld0 & 7) == 0 && mode >= 0 && mode <= 2);
+    HN_CHECK_ARG((C0 & 7) == 0 && (C1 & 7) == 0 && (ld0 & 7) == 0 && ((mode >= 0 && mode <= 2) || (mode == 4 && up == 0 && C1 == 0)));
     HN_CHECK_ARG(mode == 0 || (long)n_img * H * W == M);
     int splits; long rps, wsb;
-    hn_wgrad_plan(mode, n_img, H, W, M, Nout, KP, taps, &splits, &rps, &wsb);
+    hn_wgrad_plan(mode == 4 ? 2 : mode, n_img, H, W, M, Nout, KP, taps, &splits, &rps, &wsb);
     GemmTN p;
     p.x = make_xsrc(x0, x1, mode, n_img, H, W, C0, C1, ld0, ld1, up, M);
+    mode = p.x.mode;
     p.dz = (const bf16*)dz; p.ldz = ldz; p.Nout = Nout; p.KP = KP; p.taps = taps;
     p.part = workspace; p.rows_per_split = rps;
     int bc, bn, rc;

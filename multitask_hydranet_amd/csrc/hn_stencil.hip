@@ -693,15 +693,15 @@ __global__ __launch_bounds__(256) void fuse_bwd_kernel(const FuseBwd q) {
 //   up = 1: out[n, y, x, :]  = the same summed over the 2x2 block (2y..2y+1, 2x..2x+1)      (out is H/2 x W/2)
 //   optionally multiplied by ELU'(yprev) given the post-ELU activation of the producing ConvBlock (y > 0 ? 1 : y + 1)
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int refl_pre(int q, int L, int* pos) {   // padded coordinates (q+1) that reflect onto q
+__device__ __forceinline__ int refl_pre(int q, int L, int* pos, int clamp) {   // padded coordinates (q+1) that reflect / clamp onto q
     int n = 0;
     pos[n++] = q + 1;
-    if (q == 1) pos[n++] = 0;
-    if (q == L - 2) pos[n++] = L + 1;
+    if (q == (clamp ? 0 : 1)) pos[n++] = 0;
+    if (q == (clamp ? L - 1 : L - 2)) pos[n++] = L + 1;
     return n;
 }
 __global__ __launch_bounds__(256) void seg_fold_kernel(const bf16* dvp, int ldv, int c0, bf16* out, int ldo, const bf16* yprev, int ldy,
-                                                       int N, int H, int W, int C, int up) {
+                                                       int N, int H, int W, int C, int up, int clamp) {
     const int C8 = C >> 3, Ho = H >> up, Wo = W >> up;
     const long total = (long)N * Ho * Wo * C8;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
@@ -717,7 +717,7 @@ __global__ __launch_bounds__(256) void seg_fold_kernel(const bf16* dvp, int ldv,
         for (int dy = 0; dy <= up; ++dy)
             for (int dx = 0; dx <= up; ++dx) {
                 int py[3], px[3];
-                const int ny = refl_pre((y << up) + dy, H, py), nx = refl_pre((x << up) + dx, W, px);
+                const int ny = refl_pre((y << up) + dy, H, py, clamp), nx = refl_pre((x << up) + dx, W, px, clamp);
                 for (int a = 0; a < ny; ++a)
                     for (int b = 0; b < nx; ++b) {
                         const bf16x8 v = ld8(dvp + ((n * (H + 2) + py[a]) * (long)(W + 2) + px[b]) * ldv + c0 + cg * 8);
@@ -736,6 +736,40 @@ __global__ __launch_bounds__(256) void seg_fold_kernel(const bf16* dvp, int ldv,
             for (int k = 0; k < 8; ++k) o[k] = f2bf(acc[k]);
         }
         st8(out + orow * ldo + cg * 8, o);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// pixel shuffles for the phase-decomposed final seg conv (3x3 over a nearest-x2 up-sampled map == four 2x2-phase 3x3 convs on the
+// low-resolution map): in [N][h][w][(py*2+px)*k + o] <-> out [N][2h][2w][k]
+// ---------------------------------------------------------------------------------------------------------
+__global__ void depth_to_space_kernel(const float* in, int ldi, float* out, int N, int h, int w, int k) {
+    const long total = (long)N * 4 * h * w * k;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int o = (int)(idx % k);
+        long t = idx / k;
+        const int X = (int)(t % (2 * w));
+        t /= 2 * w;
+        const int Y = (int)(t % (2 * h));
+        const long n = t / (2 * h);
+        out[idx] = in[((n * h + (Y >> 1)) * (long)w + (X >> 1)) * ldi + ((Y & 1) * 2 + (X & 1)) * k + o];
+    }
+}
+__global__ void space_to_depth_kernel(const float* dy, bf16* out, int ldo, int N, int h, int w, int k) {
+    const long total = (long)N * h * w * ldo;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % ldo);
+        long t = idx / ldo;
+        float v = 0.f;
+        if (c < 4 * k) {
+            const int x = (int)(t % w);
+            const long t2 = t / w;
+            const int y = (int)(t2 % h);
+            const long n = t2 / h;
+            const int ph = c / k, o = c - ph * k;
+            v = dy[((n * 2 * h + 2 * y + (ph >> 1)) * (long)(2 * w) + 2 * x + (ph & 1)) * k + o];
+        }
+        out[idx] = f2bf(v);
     }
 }
 
@@ -970,10 +1004,23 @@ extern "C" int hn_fuse_bwd(const void* const* in, const int* ld, const int* mode
 
 extern "C" int hn_seg_fold(const void* dvp, int ldv, int c0, void* out, int ldo, const void* yprev, int ldy, int N, int H, int W, int C,
                            int up, hipStream_t st) {
-    HN_CHECK_ARG(dvp && out && (C & 7) == 0 && (c0 & 7) == 0 && ((ldv | ldo) & 7) == 0 && H >= 4 && W >= 4 && (up == 0 || up == 1));
+    HN_CHECK_ARG(dvp && out && (C & 7) == 0 && (c0 & 7) == 0 && ((ldv | ldo) & 7) == 0 && H >= 4 && W >= 4 && up >= 0 && up <= 2);
     HN_CHECK_ARG(!yprev || (ldy & 7) == 0);
+    const int clamp = up == 2;                                  // up = 2: replicate-padding fold, no up-sampling
+    if (clamp) up = 0;
     hipLaunchKernelGGL(seg_fold_kernel, dim3(ew_grid((long)N * (H >> up) * (W >> up) * (C >> 3))), dim3(256), 0, st, (const bf16*)dvp, ldv, c0,
-                       (bf16*)out, ldo, (const bf16*)yprev, ldy, N, H, W, C, up);
+                       (bf16*)out, ldo, (const bf16*)yprev, ldy, N, H, W, C, up, clamp);
+    HN_LAUNCH_CHECK();
+}
+
+extern "C" int hn_depth_to_space(const float* in, int ldi, float* out, int N, int h, int w, int k, hipStream_t st) {
+    HN_CHECK_ARG(in && out && N > 0 && h > 0 && w > 0 && k > 0 && ldi >= 4 * k);
+    hipLaunchKernelGGL(depth_to_space_kernel, dim3(ew_grid((long)N * 4 * h * w * k)), dim3(256), 0, st, in, ldi, out, N, h, w, k);
+    HN_LAUNCH_CHECK();
+}
+extern "C" int hn_space_to_depth(const float* dy, void* out, int ldo, int N, int h, int w, int k, hipStream_t st) {
+    HN_CHECK_ARG(dy && out && N > 0 && h > 0 && w > 0 && k > 0 && ldo >= 4 * k && (ldo & 7) == 0);
+    hipLaunchKernelGGL(space_to_depth_kernel, dim3(ew_grid((long)N * h * w * ldo)), dim3(256), 0, st, dy, (bf16*)out, ldo, N, h, w, k);
     HN_LAUNCH_CHECK();
 }
 

@@ -120,6 +120,7 @@ class HydraNet(nn.Module):
         self._pending_nbt = []
         self.heads_on_side_stream = False          # measured: no gain over the single-stream graph on MI355X (kept for experiments)
         self._side_streams = {}
+        self.seg_phase_output = True
         self.pack_det_levels = True         # level-packed det towers when every level has a multiple of 128 rows
         self.levels_on_streams = False      # hipGraph branches cost more than they hide on gfx950 (55 vs 43 ms)
 
@@ -366,7 +367,10 @@ class HydraNet(nn.Module):
             skip = feats_seg[n - 2 - i] if i < n - 1 else None
             x = K.SegConv.apply(x, skip, P[f"{p}{2 * i + 1}.conv.conv.weight"], P[f"{p}{2 * i + 1}.conv.conv.bias"], 1, ACT_ELU, False)
         last = 2 * n
-        y = K.SegConv.apply(x, None, P[f"{p}{last}.conv.weight"], P[f"{p}{last}.conv.bias"], 1, ACT_NONE, True)
+        if self.seg_phase_output:          # final 3x3 over the up-sampled map as a 4-phase conv on the low-resolution grid (ops.SegOutUp)
+            y = K.SegOutUp.apply(x, P[f"{p}{last}.conv.weight"], P[f"{p}{last}.conv.bias"])
+        else:
+            y = K.SegConv.apply(x, None, P[f"{p}{last}.conv.weight"], P[f"{p}{last}.conv.bias"], 1, ACT_NONE, True)
         return y.permute(0, 3, 1, 2)
 
     def anchors_for(self, h, w, device):

@@ -950,3 +950,69 @@ class HeadOutPacked(torch.autograd.Function):
         ddw = k_dwconv_wgrad_levels(x, dmid, geom)
         dx = k_dwconv_levels(dmid, wf, geom)
         return ddw, dpw, dbias, None, None, None, dx
+
+
+# --------------------------------------------------------------------------------------------------------------
+# Final seg conv in phase form.  Conv3x3(reflect-pad(nearest_up2(x))) (head_seg/segmentation.py:101-104) on the up-sampled grid reads
+# every low-resolution pixel four times and, for the 5-class output layer, runs its data gradient on a 514x1026x64 padded grid.  On
+# the LOW-resolution grid the same function is a 3x3 conv with replicate padding and 4*k outputs (one k-vector per output phase
+# (py,px)): W_eff[(py,px,o)][c][dy][dx] = sum of the taps (ky,kx) whose up-sampled source row/col falls on low-res offset (dy,dx)
+#   phase 0: ky=0 -> dy=-1, ky=1,2 -> dy=0;   phase 1: ky=0,1 -> dy=0, ky=2 -> dy=+1     (same for kx/dx)
+# and reflection of the up-sampled index is exactly clamping of the low-res index.  4x fewer pixels forward, and the data gradient is
+# produced directly at the producer's resolution (no full-resolution padded dgrad, fold, 2x2 sum).
+# --------------------------------------------------------------------------------------------------------------
+_PHASE_T = {}
+
+
+def _phase_matrix(device):
+    """T[(py,px,dy,dx), (ky,kx)] in {0,1}: W_eff.view(k*c, 36) = W.view(k*c, 9) @ T^T"""
+    t = _PHASE_T.get(device)
+    if t is None:
+        a = torch.zeros(2, 3, 3)                       # a[p][d+1][k]
+        a[0, 0, 0] = 1; a[0, 1, 1] = 1; a[0, 1, 2] = 1
+        a[1, 1, 0] = 1; a[1, 1, 1] = 1; a[1, 2, 2] = 1
+        t = torch.einsum("pdk,qel->pqdekl", a, a).reshape(36, 9).to(device)
+        _PHASE_T[device] = t
+    return t
+
+
+class SegOutUp(torch.autograd.Function):
+    """logits[N, 2h, 2w, k] (fp32) = Conv3x3(ReflectionPad2d(1)(nearest_up2(x))) + bias, x [N, h, w, c] bf16."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        n, h, w, c = x.shape
+        k = weight.shape[0]
+        T = _phase_matrix(x.device)
+        w_eff = (weight.reshape(k * c, 9) @ T.t()).view(k, c, 2, 2, 3, 3).permute(2, 3, 0, 1, 4, 5).reshape(4 * k, c, 3, 3).contiguous()
+        b_eff = bias.repeat(4)
+        wp, wt = pack_conv_weight(w_eff)
+        y4, _, _ = k_gemm_nt(x, None, 4, (n, h, w), wp, 4 * k, kp32(c), 9, bias=b_eff, out_f32=True)
+        out = torch.empty((n, 2 * h, 2 * w, k), device=x.device, dtype=F32)
+        lib().call("hn_depth_to_space", ptr(y4), 4 * k, ptr(out), n, h, w, k)
+        ctx.wt = wt
+        ctx.k = k
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        n, h, w, c = x.shape
+        k = ctx.k
+        dev = x.device
+        dy = dy.contiguous()
+        ldz = pad8(4 * k)
+        dz = new_act(n, h, w, ldz, dev)
+        lib().call("hn_space_to_depth", ptr(dy), ptr(dz), ldz, n, h, w, k)
+        ps, _, _ = k_col_stats(dz)
+        dbias = k_rows_reduce(ps, 1, ps.shape[0], ldz).view(-1)[:4 * k].view(4, k).sum(0)
+        dw_eff = k_gemm_tn(x, None, 4, (n, h, w), dz, 4 * k, kp32(c), 9, c, kh=3)                       # [4k, c, 3, 3]
+        T = _phase_matrix(dev)
+        dw = (dw_eff.view(2, 2, k, c, 3, 3).permute(2, 3, 0, 1, 4, 5).reshape(k * c, 36) @ T).view(k, c, 3, 3)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dvp, _, _ = k_gemm_nt(dz, None, 3, (n, h + 2, w + 2), ctx.wt, c, kp32(4 * k), 9, c0=ldz, c1=0)
+            dx = new_act(n, h, w, c, dev)
+            lib().call("hn_seg_fold", ptr(dvp), ld(dvp), 0, ptr(dx), ld(dx), None, 0, n, h, w, c, 2)
+        return dx, dw, dbias

@@ -290,6 +290,27 @@ def test_seg_conv(K, c0, c1, cout, up, act, f32, n, h, w):
     close(bk.grad, br.grad, GRAD_TOL, "dbias")
 
 
+@pytest.mark.parametrize("c,k,n,h,w", [(64, 5, 2, 8, 12), (64, 5, 1, 20, 36), (16, 3, 2, 4, 4)])
+def test_seg_out_phase_form(K, c, k, n, h, w):
+    """ops.SegOutUp (4-phase conv with replicate padding on the low-resolution grid) == Conv3x3(reflect_pad(nearest_up2(x))); h, w = INPUT size."""
+    x = rnd(n, c, h, w)
+    wt = rnd(k, c, 3, 3, scale=(9 * c) ** -0.5)
+    bs = rnd(k, scale=0.1)
+    upg = rnd(n, k, 2 * h, 2 * w)
+    xk = nhwc(x).requires_grad_(True)
+    wk, bk = wt.clone().requires_grad_(True), bs.clone().requires_grad_(True)
+    out = K.SegOutUp.apply(xk, wk, bk)
+    out.backward(upg.permute(0, 2, 3, 1).contiguous())
+    xr = x.clone().requires_grad_(True)
+    wr, br = wt.clone().requires_grad_(True), bs.clone().requires_grad_(True)
+    y = F.conv2d(F.pad(F.interpolate(xr, scale_factor=2, mode="nearest"), [1, 1, 1, 1], mode="reflect"), wr, br)
+    y.backward(upg)
+    close(nchw(out), y, ACT_TOL, "out")
+    close(nchw(xk.grad), xr.grad, GRAD_TOL, "dx")
+    close(wk.grad, wr.grad, GRAD_TOL, "dw")
+    close(bk.grad, br.grad, GRAD_TOL, "dbias")
+
+
 @pytest.mark.parametrize("with_dw,cout,k,act", [(True, 36, 4, 0), (True, 81, 9, 4), (False, 65, 65, 0), (False, 2, 2, 0)])
 def test_head_out(K, with_dw, cout, k, act):
     n, c = 2, 16

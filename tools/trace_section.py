@@ -33,7 +33,7 @@ p = "backbone.net."
 chans = [32] + net.widths
 which = sys.argv[1]
 img = batch["image"]
-if which[0] == "s":
+if which[0] == "s" and which[1].isdigit():
     k, b = int(which[1]), int(which[3])
     x = act(chans[k + (1 if b else 0)], (2 if b else 1) * 2 * 2 ** k)
     fn, inputs = (lambda t: net._xblock(f"{p}stage_{k}.blocks.block_{b}.", t, 1 if b else 2)), [x]
