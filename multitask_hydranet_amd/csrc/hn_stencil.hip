@@ -743,35 +743,33 @@ __global__ __launch_bounds__(256) void seg_fold_kernel(const bf16* dvp, int ldv,
 // pixel shuffles for the phase-decomposed final seg conv (3x3 over a nearest-x2 up-sampled map == four 2x2-phase 3x3 convs on the
 // low-resolution map): in [N][h][w][(py*2+px)*k + o] <-> out [N][2h][2w][k]
 // ---------------------------------------------------------------------------------------------------------
-// thread = (n, Y, x): the two output pixels (Y, 2x) and (Y, 2x+1) are 2k contiguous floats on both sides
 __global__ void depth_to_space_kernel(const float* in, int ldi, float* out, int N, int h, int w, int k) {
-    const long total = (long)N * 2 * h * w;
+    const long total = (long)N * 4 * h * w * k;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int x = (int)(idx % w);
-        const long t = idx / w;
+        const int o = (int)(idx % k);
+        long t = idx / k;
+        const int X = (int)(t % (2 * w));
+        t /= 2 * w;
         const int Y = (int)(t % (2 * h));
         const long n = t / (2 * h);
-        const float2* src = reinterpret_cast<const float2*>(in + ((n * h + (Y >> 1)) * (long)w + x) * ldi + (Y & 1) * 2 * k);
-        float2* dst = reinterpret_cast<float2*>(out + ((n * 2 * h + Y) * (long)(2 * w) + 2 * x) * k);
-        for (int j = 0; j < k; ++j) dst[j] = src[j];
+        out[idx] = in[((n * h + (Y >> 1)) * (long)w + (X >> 1)) * ldi + ((Y & 1) * 2 + (X & 1)) * k + o];
     }
 }
 __global__ void space_to_depth_kernel(const float* dy, bf16* out, int ldo, int N, int h, int w, int k) {
-    const long total = (long)N * 2 * h * w;
+    const long total = (long)N * h * w * ldo;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int x = (int)(idx % w);
-        const long t = idx / w;
-        const int Y = (int)(t % (2 * h));
-        const long n = t / (2 * h);
-        const float2* src = reinterpret_cast<const float2*>(dy + ((n * 2 * h + Y) * (long)(2 * w) + 2 * x) * k);
-        bf16* dst = out + ((n * h + (Y >> 1)) * (long)w + x) * ldo + (Y & 1) * 2 * k;
-        for (int j = 0; j < k; ++j) {
-            const float2 v = src[j];
-            dst[2 * j] = f2bf(v.x);
-            dst[2 * j + 1] = f2bf(v.y);
+        const int c = (int)(idx % ldo);
+        long t = idx / ldo;
+        float v = 0.f;
+        if (c < 4 * k) {
+            const int x = (int)(t % w);
+            const long t2 = t / w;
+            const int y = (int)(t2 % h);
+            const long n = t2 / h;
+            const int ph = c / k, o = c - ph * k;
+            v = dy[((n * 2 * h + 2 * y + (ph >> 1)) * (long)(2 * w) + 2 * x + (ph & 1)) * k + o];
         }
-        if (Y & 1)
-            for (int c = 4 * k; c < ldo; ++c) dst[c - 2 * k] = f2bf(0.f);          // zero padding channels of the row
+        out[idx] = f2bf(v);
     }
 }
 
@@ -1016,13 +1014,13 @@ extern "C" int hn_seg_fold(const void* dvp, int ldv, int c0, void* out, int ldo,
 }
 
 extern "C" int hn_depth_to_space(const float* in, int ldi, float* out, int N, int h, int w, int k, hipStream_t st) {
-    HN_CHECK_ARG(in && out && N > 0 && h > 0 && w > 0 && k > 0 && ldi >= 4 * k && (ldi & 1) == 0);
-    hipLaunchKernelGGL(depth_to_space_kernel, dim3(ew_grid((long)N * 2 * h * w)), dim3(256), 0, st, in, ldi, out, N, h, w, k);
+    HN_CHECK_ARG(in && out && N > 0 && h > 0 && w > 0 && k > 0 && ldi >= 4 * k);
+    hipLaunchKernelGGL(depth_to_space_kernel, dim3(ew_grid((long)N * 4 * h * w * k)), dim3(256), 0, st, in, ldi, out, N, h, w, k);
     HN_LAUNCH_CHECK();
 }
 extern "C" int hn_space_to_depth(const float* dy, void* out, int ldo, int N, int h, int w, int k, hipStream_t st) {
     HN_CHECK_ARG(dy && out && N > 0 && h > 0 && w > 0 && k > 0 && ldo >= 4 * k && (ldo & 7) == 0);
-    hipLaunchKernelGGL(space_to_depth_kernel, dim3(ew_grid((long)N * 2 * h * w)), dim3(256), 0, st, dy, (bf16*)out, ldo, N, h, w, k);
+    hipLaunchKernelGGL(space_to_depth_kernel, dim3(ew_grid((long)N * h * w * ldo)), dim3(256), 0, st, dy, (bf16*)out, ldo, N, h, w, k);
     HN_LAUNCH_CHECK();
 }
 
