@@ -27,6 +27,9 @@ typedef struct ihipStream_t* hipStream_t;
 /* fp32 conv weight [Cout][Cin][taps] -> bf16 forward operand wp[Cout][taps][KP(Cin)] and (optional) dgrad operand
  * wt[Cin][taps][KP(Cout)], KP(x) = x rounded up to 32, zero filled.  Replaces the implicit weight cast of autocast convs. */
 int hn_pack_weight(const float* w, void* wp, void* wt, int Cout, int Cin, int taps, hipStream_t stream);
+/* every conv weight of a model in one launch: jobs = DEVICE table njobs x 8 int64 {w, wp, wt, Cout, Cin, taps, first_block, 0}, job j owns
+ * ceil((Cout*taps*KP(Cin) + Cin*taps*KP(Cout)) / 256) consecutive blocks starting at first_block */
+int hn_pack_weights_batched(const long* jobs, int njobs, long total_blocks, hipStream_t stream);
 
 /* out[pixel][cout] = act(bias[cout] + sum_{tap,c} X(pixel, tap)[c] * w[cout][tap][c]); X is gathered on the fly:
  *   mode 0: X = x0 rows (1x1 conv; also every dgrad of a 1x1 conv)            nn.Conv2d k=1: net/anynet.py:29-33,52-60;

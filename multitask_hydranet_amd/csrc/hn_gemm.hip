@@ -944,6 +944,38 @@ __global__ void pack_w_kernel(const float* w, bf16* wp, bf16* wt, int Cout, int 
     }
 }
 
+// all conv weights of a model in ONE launch: jobs[j] = {w, wp, wt, Cout, Cin, taps, first block, unused} (device int64 table, built once)
+__global__ void pack_w_batched_kernel(const long* jobs, int njobs) {
+    int lo = 0, hi = njobs - 1;                                      // last job whose first block <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid * 8 + 6] <= (long)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const long* jb = jobs + lo * 8;
+    const float* w = reinterpret_cast<const float*>(jb[0]);
+    bf16* wp = reinterpret_cast<bf16*>(jb[1]);
+    bf16* wt = reinterpret_cast<bf16*>(jb[2]);
+    const int Cout = (int)jb[3], Cin = (int)jb[4], taps = (int)jb[5];
+    const int KPi = (Cin + 31) / 32 * 32, KPo = (Cout + 31) / 32 * 32;
+    const long nf = (long)Cout * taps * KPi;
+    const long nt = wt ? (long)Cin * taps * KPo : 0;
+    const long idx = ((long)blockIdx.x - jb[6]) * blockDim.x + threadIdx.x;
+    if (idx < nf) {
+        const int k = (int)(idx % KPi);
+        const long t = idx / KPi;
+        const int tap = (int)(t % taps);
+        const int co = (int)(t / taps);
+        wp[idx] = f2bf(k < Cin ? w[((long)co * Cin + k) * taps + tap] : 0.f);
+    } else if (idx < nf + nt) {
+        const long j = idx - nf;
+        const int k = (int)(j % KPo);
+        const long t = j / KPo;
+        const int tap = (int)(t % taps);
+        const int ci = (int)(t / taps);
+        wt[j] = f2bf(k < Cout ? w[((long)k * Cin + ci) * taps + tap] : 0.f);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
@@ -1179,6 +1211,14 @@ extern "C" int hn_conv_gemm_tn(const void* x0, const void* x1, int mode, int n_i
     if (rc != HN_OK) return rc;
     const long cols = (long)Nout * taps * KP;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(cols, 32)), dim3(512), 0, st, workspace, dw, splits, Nout, C0 + C1, KP, taps);
+    HN_LAUNCH_CHECK();
+}
+
+/* jobs: DEVICE table of njobs x 8 int64 {w, wp, wt, Cout, Cin, taps, first_block, 0}; job j owns blocks [first_block_j, first_block_{j+1})
+ * of 256 threads, ceil((Cout*taps*KP(Cin) + Cin*taps*KP(Cout)) / 256) each; total_blocks = their sum. */
+extern "C" int hn_pack_weights_batched(const long* jobs, int njobs, long total_blocks, hipStream_t st) {
+    HN_CHECK_ARG(jobs && njobs > 0 && total_blocks > 0);
+    hipLaunchKernelGGL(pack_w_batched_kernel, dim3((unsigned)total_blocks), dim3(256), 0, st, jobs, njobs);
     HN_LAUNCH_CHECK();
 }
 

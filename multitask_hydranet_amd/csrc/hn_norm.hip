@@ -152,8 +152,13 @@ __global__ __launch_bounds__(512) void rows_reduce2_kernel(const float* in1, con
     int r1 = r0 + S;
     if (r1 > rows) r1 = rows;
     float s1 = 0.f, s2 = 0.f;
-    if (c < C)
-        for (int j = r0 + ty; j < r1; j += 16) { s1 += in1[(long)j * C + c]; s2 += in2[(long)j * C + c]; }
+    if (c < C) {
+        if (in2) {
+            for (int j = r0 + ty; j < r1; j += 16) { s1 += in1[(long)j * C + c]; s2 += in2[(long)j * C + c]; }
+        } else {
+            for (int j = r0 + ty; j < r1; j += 16) s1 += in1[(long)j * C + c];
+        }
+    }
     red[0][ty][tx] = s1; red[1][ty][tx] = s2;
     __syncthreads();
     if (ty == 0 && c < C) {
@@ -161,7 +166,7 @@ __global__ __launch_bounds__(512) void rows_reduce2_kernel(const float* in1, con
 #pragma unroll
         for (int k = 0; k < 16; ++k) { t1 += red[0][k][tx]; t2 += red[1][k][tx]; }
         out1[(long)g * C + c] = t1;
-        out2[(long)g * C + c] = t2;
+        if (in2) out2[(long)g * C + c] = t2;
     }
 }
 
@@ -770,7 +775,7 @@ extern "C" int hn_rows_reduce(const float* in, float* out, int G, int S, int C, 
 }
 
 extern "C" int hn_rows_reduce2(const float* in1, const float* in2, float* out1, float* out2, int rows, int G, int C, hipStream_t st) {
-    HN_CHECK_ARG(in1 && in2 && out1 && out2 && rows > 0 && G > 0 && C > 0);
+    HN_CHECK_ARG(in1 && out1 && (!in2 || out2) && rows > 0 && G > 0 && C > 0);       // in2/out2 optional
     hipLaunchKernelGGL(rows_reduce2_kernel, dim3(cdiv(C, 32), G), dim3(512), 0, st, in1, in2, out1, out2, rows, G, C);
     HN_LAUNCH_CHECK();
 }

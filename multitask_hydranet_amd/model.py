@@ -121,6 +121,7 @@ class HydraNet(nn.Module):
         self.heads_on_side_stream = False          # measured: no gain over the single-stream graph on MI355X (kept for experiments)
         self._side_streams = {}
         self.seg_phase_output = True
+        self._pack_plan = None
         self.pack_det_levels = True         # level-packed det towers when every level has a multiple of 128 rows
         self.levels_on_streams = False      # hipGraph branches cost more than they hide on gfx950 (55 vs 43 ms)
 
@@ -267,6 +268,7 @@ class HydraNet(nn.Module):
     def _apply(self, fn, recurse=True):
         r = super()._apply(fn, recurse)
         self._reindex()
+        self._pack_plan = None
         K.clear_pack_cache()
         return r
 
@@ -484,6 +486,20 @@ class HydraNet(nn.Module):
     def forward(self, x, mode="train"):
         """HydraNet.forward, model/model.py:159-198."""
         K.clear_pack_cache()
+        params = {id(t) for t in self.parameters()}
+        if self._pack_plan is not None and x.is_cuda:
+            self._pack_plan.run()                  # every dense conv weight -> bf16 operands, one launch
+        elif x.is_cuda:
+            K.start_pack_log()                     # first forward on this device: record which weights get packed
+        try:
+            return self._forward(x, mode)
+        finally:
+            if self._pack_plan is None and x.is_cuda:
+                log = [w for w in K.stop_pack_log() if id(w) in params]
+                if log:
+                    self._pack_plan = K.PackPlan(log)
+
+    def _forward(self, x, mode):
         feats = self._backbone(x)
         fused = self._neck(feats)
         out = {}

@@ -81,6 +81,9 @@ def clear_pack_cache():
     _PACK_CACHE.clear()
 
 
+_PACK_LOG = None            # when a list: conv weights packed one by one are recorded here (HydraNet builds its PackPlan from it)
+
+
 def _cached(key, w: torch.Tensor, make):
     # the entry keeps a strong reference to the weight tensor, so its id() cannot be recycled while the entry lives
     k = (key, id(w))
@@ -89,7 +92,46 @@ def _cached(key, w: torch.Tensor, make):
         return hit[2]
     v = make()
     _PACK_CACHE[k] = (w, w._version, v)
+    if _PACK_LOG is not None and key == "conv":
+        _PACK_LOG.append(w)
     return v
+
+
+def start_pack_log():
+    global _PACK_LOG
+    _PACK_LOG = []
+
+
+def stop_pack_log():
+    global _PACK_LOG
+    log, _PACK_LOG = _PACK_LOG, None
+    return log
+
+
+class PackPlan:
+    """bf16 operand packing of every dense conv weight of a model in ONE launch per step (118 launches one by one for the big cfg).
+    Owns persistent packed buffers; run() refreshes them and primes the pack cache so that pack_conv_weight() hits."""
+
+    def __init__(self, weights):
+        self.weights = list(weights)
+        dev = self.weights[0].device
+        self.packs = []
+        rows_, blk = [], 0
+        for w in self.weights:
+            cout, cin = w.shape[0], w.shape[1]
+            taps = w.shape[2] * w.shape[3]
+            wp = torch.empty((cout, taps * kp32(cin)), device=dev, dtype=BF16)
+            wt = torch.empty((cin, taps * kp32(cout)), device=dev, dtype=BF16)
+            self.packs.append((wp, wt))
+            rows_.append([w.data_ptr(), wp.data_ptr(), wt.data_ptr(), cout, cin, taps, blk, 0])
+            blk += (wp.numel() + wt.numel() + 255) // 256
+        self.blocks = blk
+        self.table = torch.tensor(rows_, dtype=torch.int64).to(dev)
+
+    def run(self):
+        lib().call("hn_pack_weights_batched", ptr(self.table), len(self.weights), self.blocks)
+        for w, pk in zip(self.weights, self.packs):
+            _PACK_CACHE[("conv", id(w))] = (w, w._version, pk)
 
 
 def pack_conv_weight(w: torch.Tensor):
@@ -177,6 +219,12 @@ def k_col_stats(x, align=0):
 
 
 def k_rows_reduce(part, groups, s, c, alpha=1.0):
+    """out[g][c] = alpha * sum_j part[g*s + j][c].  A single tall group (the partial rows of a wgrad / column reduction) is folded in two
+    2-D launches: 16 row lanes walking thousands of rows serially took 35 us, two short folds take < 10 us."""
+    if groups == 1 and s > 256:
+        tmp = torch.empty((32, c), device=part.device, dtype=F32)
+        lib().call("hn_rows_reduce2", ptr(part), None, ptr(tmp), None, s, 32, c)
+        part, s = tmp, 32
     out = torch.empty((groups, c), device=part.device, dtype=F32)
     lib().call("hn_rows_reduce", ptr(part), ptr(out), groups, s, c, float(alpha))
     return out
@@ -881,8 +929,9 @@ class TowerLayer(torch.autograd.Function):
         lib().call("hn_bn_bwd_reduce_levels", ptr(dout), ld(dout), ptr(z), ld(z), None, 0, ptr(coef), act, cout, r, nl, ctypes.addressof(R),
                    ptr(pg), ptr(pgx))
         red = torch.empty((nl, 2, cout), device=dev, dtype=F32)
-        dgb = torch.empty((nl, 2, cout), device=dev, dtype=F32)
-        dgam, dbet = [dgb[l, 0] for l in range(nl)], [dgb[l, 1] for l in range(nl)]
+        # one owning tensor per parameter gradient: autograd's AccumulateGrad clones views before storing them in .grad
+        dgam = [torch.empty((cout,), device=dev, dtype=F32) for _ in range(nl)]
+        dbet = [torch.empty((cout,), device=dev, dtype=F32) for _ in range(nl)]
         dga, dba = _ptr_array(dgam), _ptr_array(dbet)
         lib().call("hn_bn_bwd_finalize_levels", ptr(pg), ptr(pgx), r, cout, nl, ctypes.addressof(R), ctypes.addressof(R),
                    ctypes.addressof(dga), ctypes.addressof(dba), ptr(red))
