@@ -920,6 +920,24 @@ __global__ __launch_bounds__(512) void wgrad_reduce_kernel(const float* part, fl
     }
 }
 
+// few splits, many columns (the wide deep layers): thread = 4 consecutive columns, float4 loads, splits walked serially
+__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* part, float* dw, int splits, int Nout, int Cin, int KP, int taps) {
+    const long Ktot = (long)taps * KP;
+    const long cols = (long)Nout * Ktot;
+    const long col = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (col >= cols) return;
+    f32x4 s = *reinterpret_cast<const f32x4*>(part + col);
+#pragma unroll 4
+    for (int k = 1; k < splits; ++k) s += *reinterpret_cast<const f32x4*>(part + (long)k * cols + col);
+    const int co = (int)(col / Ktot);
+    const int r = (int)(col - (long)co * Ktot);
+    const int tap = r / KP, ci = r - tap * KP;                       // the 4 columns share co and tap (KP is a multiple of 32)
+    float* d = dw + ((long)co * Cin + ci) * taps + tap;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (ci + j < Cin) d[(long)j * taps] = s[j];
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // weight packing: fp32 master weights [Cout][Cin][taps] -> bf16 forward operand Wp[Cout][taps][KP(Cin)] and
 // dgrad operand Wt[Cin][taps][KP(Cout)]   (KP = channel count rounded up to 32, zero filled)
@@ -1197,7 +1215,10 @@ extern "C" int hn_conv_gemm_tn(const void* x0, const void* x1, int mode, int n_i
         else hipLaunchKernelGGL((wgrad3x3_patch_kernel<16, 64>), grid, dim3(512), lds, st, p, (int)rps, patches);
         if (hipGetLastError() != hipSuccess) return HN_ERR_LAUNCH;
         const long cols = (long)Nout * taps * KP;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(cols, 32)), dim3(512), 0, st, workspace, dw, splits, Nout, C0 + C1, KP, taps);
+        if (splits <= 128 && cols >= 65536)
+            hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(cdiv(cols / 4, 256)), dim3(256), 0, st, workspace, dw, splits, Nout, C0 + C1, KP, taps);
+        else
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(cols, 32)), dim3(512), 0, st, workspace, dw, splits, Nout, C0 + C1, KP, taps);
         HN_LAUNCH_CHECK();
     }
     tn_tiles(Nout, KP, bc, bn);
@@ -1210,7 +1231,10 @@ extern "C" int hn_conv_gemm_tn(const void* x0, const void* x1, int mode, int n_i
 #undef TN_CASE
     if (rc != HN_OK) return rc;
     const long cols = (long)Nout * taps * KP;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(cols, 32)), dim3(512), 0, st, workspace, dw, splits, Nout, C0 + C1, KP, taps);
+    if (splits <= 128 && cols >= 65536)
+        hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(cdiv(cols / 4, 256)), dim3(256), 0, st, workspace, dw, splits, Nout, C0 + C1, KP, taps);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(cols, 32)), dim3(512), 0, st, workspace, dw, splits, Nout, C0 + C1, KP, taps);
     HN_LAUNCH_CHECK();
 }
 
