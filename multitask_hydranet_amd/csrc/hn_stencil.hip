@@ -211,12 +211,12 @@ __global__ __launch_bounds__(256) void gconv_wgrad_kernel(const bf16* x, int ldx
     for (int o = 0; o < 8; ++o)
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[o][i] = 0.f;
-    // four pixels in flight per thread (the loads of a batch are all issued before the first FMA); out-of-image taps load nothing
-    for (long pb = p0; pb < p1; pb += 4) {
-        bf16x8 zv[4], xv[4];
-        bool ok[4];
+    // eight pixels in flight per thread (the loads of a batch are all issued before the first FMA); out-of-image taps load nothing
+    for (long pb = p0; pb < p1; pb += 8) {
+        bf16x8 zv[8], xv[8];
+        bool ok[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
             const long pix = pb + u;
             const int ox = (int)(pix % Wo);
             const long t1 = pix / Wo;
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void gconv_wgrad_kernel(const bf16* x, int ldx
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
             if (!ok[u]) continue;
             float xf[8];
 #pragma unroll
