@@ -617,7 +617,7 @@ __device__ __forceinline__ int tn_swz(int row, int piece) {
 }
 
 template <int BC, int BN, int WGC, int WGN>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN p) {
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {   // <= 256 VGPRs: two workgroups per CU overlap issue / wait / MFMA
     constexpr int WC = BC / WGC, WN = BN / WGN, TC = WC / 16, TN = WN / 16;
     constexpr int ZPR = BC / 8, XPR = BN / 8;                     // 16-byte pieces per row
     constexpr int ZL = (64 * ZPR + 255) / 256, XL = (64 * XPR + 255) / 256;
@@ -678,6 +678,25 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN p) {
     typedef __bf16 trv4 __attribute__((__vector_size__(4 * sizeof(__bf16))));
     typedef __attribute__((address_space(3))) trv4* lds_b4;
 
+    // per-piece source offsets, advanced by 64 rows per stage (the 1x1 wgrads are most of the launches: no index arithmetic in the loop)
+    long zoff[ZL], xoff[XL];
+    int zrow[ZL], xrow[XL];
+#pragma unroll
+    for (int i = 0; i < ZL; ++i) {
+        const int e = tid + 256 * i;
+        const int row = e / ZPR, cp = tn_swz<BC>(row, e - row * ZPR);
+        const int co = c_blk + cp * 8;
+        zrow[i] = row;
+        zoff[i] = co < p.Nout ? (m_begin + row) * (long)p.ldz + co : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+        const int e = tid + 256 * i;
+        const int row = e / XPR, cp = tn_swz<BN>(row, e - row * XPR);
+        const int c = ci_blk + cp * 8;
+        xrow[i] = row;
+        xoff[i] = (p.x.mode == 0 && c < Ctot) ? (m_begin + row) * (long)p.x.ld0 + c : -1;
+    }
     for (int it = 0; it <= S; ++it) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's LDS-DMA of stage it-1 has landed ...
         __syncthreads();                                           // ... and so has everybody else's; buffer it&1 is free again
@@ -688,18 +707,21 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN p) {
 #pragma unroll
             for (int i = 0; i < ZL; ++i) {
                 if (256 * i + 64 * wave < 64 * ZPR) {              // wave-uniform: this 1 KiB run lies inside the tile
-                    const int e = tid + 256 * i;
-                    const int row = e / ZPR, cp = tn_swz<BC>(row, e - row * ZPR);
-                    const long m = m0 + row;
-                    const int co = c_blk + cp * 8;
                     // dZ rows are zero padded up to ldz (>= Nout rounded up to 8), so a piece that starts below Nout is readable
-                    const bf16* src = (m < m_end && co < p.Nout) ? p.dz + m * p.ldz + co : g_zero_piece;
+                    const bf16* src = (m0 + zrow[i] < m_end && zoff[i] >= 0) ? p.dz + zoff[i] : g_zero_piece;
                     glds16(src, sZ + (256 * i + 64 * wave) * 16);
+                    zoff[i] += zoff[i] >= 0 ? 64L * p.ldz : 0;
                 }
             }
 #pragma unroll
             for (int i = 0; i < XL; ++i) {
                 if (256 * i + 64 * wave < 64 * XPR) {
+                    if (p.x.mode == 0) {                           // plain rows: pointer walk
+                        const bf16* src0 = (m0 + xrow[i] < m_end && xoff[i] >= 0) ? p.x.x0 + xoff[i] : g_zero_piece;
+                        glds16(src0, sX + (256 * i + 64 * wave) * 16);
+                        xoff[i] += xoff[i] >= 0 ? 64L * p.x.ld0 : 0;
+                        continue;
+                    }
                     const int e = tid + 256 * i;
                     const int row = e / XPR, cp = tn_swz<BN>(row, e - row * XPR);
                     const long m = m0 + row;
