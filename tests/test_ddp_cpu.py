@@ -44,7 +44,7 @@ def _worker(rank, world, port, q):
         loss = ((m(x[rank]) - y[rank]) ** 2).mean()
         loss.backward()
         red.finish()
-        out[step] = [p.grad.clone() for n, p in m.named_parameters() if n != "unused"]
+        out[step] = [p.grad.clone().numpy() for n, p in m.named_parameters() if n != "unused"]   # numpy: pickled by value (no fd passing race)
     assert m.unused.grad is None
     q.put((rank, out))
     dist.destroy_process_group()
@@ -70,5 +70,6 @@ def test_bucketed_allreduce_matches_single_process_average():
     ref = [p.grad for n, p in m.named_parameters() if n != "unused"]
     for step in (0, 1):
         for a, b, r in zip(res[0][step], res[1][step], ref):
+            a, b = torch.from_numpy(a), torch.from_numpy(b)
             assert torch.equal(a, b)                                    # both ranks hold identical averaged gradients
             assert torch.allclose(a, r, rtol=1e-5, atol=1e-7)
