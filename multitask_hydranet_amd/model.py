@@ -121,6 +121,7 @@ class HydraNet(nn.Module):
         self.heads_on_side_stream = False          # measured: no gain over the single-stream graph on MI355X (kept for experiments)
         self._side_streams = {}
         self.seg_phase_output = True
+        self.seg_fuse_elu_bwd = True       # ELU' of a decoder block applied by the next block's gradient fold
         self._pack_plan = None
         self.pack_det_levels = True         # level-packed det towers when every level has a multiple of 128 rows
         self.levels_on_streams = False      # hipGraph branches cost more than they hide on gfx950 (55 vs 43 ms)
@@ -364,15 +365,19 @@ class HydraNet(nn.Module):
         n = len(feats_seg)
         x = feats_seg[-1]
         p = "segheader.decoder."
+        # chain flags: (x0 is the previous block's ELU output, the next block folds this block's ELU' into its data gradient)
+        fuse = self.seg_fuse_elu_bwd
         for i in range(n):
-            x = K.SegConv.apply(x, None, P[f"{p}{2 * i}.conv.conv.weight"], P[f"{p}{2 * i}.conv.conv.bias"], 0, ACT_ELU, False)
+            x = K.SegConv.apply(x, None, P[f"{p}{2 * i}.conv.conv.weight"], P[f"{p}{2 * i}.conv.conv.bias"], 0, ACT_ELU, False,
+                                fuse and i > 0, fuse)
             skip = feats_seg[n - 2 - i] if i < n - 1 else None
-            x = K.SegConv.apply(x, skip, P[f"{p}{2 * i + 1}.conv.conv.weight"], P[f"{p}{2 * i + 1}.conv.conv.bias"], 1, ACT_ELU, False)
+            x = K.SegConv.apply(x, skip, P[f"{p}{2 * i + 1}.conv.conv.weight"], P[f"{p}{2 * i + 1}.conv.conv.bias"], 1, ACT_ELU, False,
+                                fuse, fuse)
         last = 2 * n
         if self.seg_phase_output:          # final 3x3 over the up-sampled map as a 4-phase conv on the low-resolution grid (ops.SegOutUp)
-            y = K.SegOutUp.apply(x, P[f"{p}{last}.conv.weight"], P[f"{p}{last}.conv.bias"])
+            y = K.SegOutUp.apply(x, P[f"{p}{last}.conv.weight"], P[f"{p}{last}.conv.bias"], fuse)
         else:
-            y = K.SegConv.apply(x, None, P[f"{p}{last}.conv.weight"], P[f"{p}{last}.conv.bias"], 1, ACT_NONE, True)
+            y = K.SegConv.apply(x, None, P[f"{p}{last}.conv.weight"], P[f"{p}{last}.conv.bias"], 1, ACT_NONE, True, fuse, False)
         return y.permute(0, 3, 1, 2)
 
     def anchors_for(self, h, w, device):

@@ -572,17 +572,23 @@ class Fuse(torch.autograd.Function):
 # segmentation decoder block: y = act(conv3x3(reflect_pad(cat[up2(x0)|x0, x1])) + bias)
 # --------------------------------------------------------------------------------------------------------------
 class SegConv(torch.autograd.Function):
+    """ConvBlock / Conv3x3 of the seg decoder.  Along the decoder chain every x0 is the ELU output of the previous block and has no other
+    consumer, so ELU' of the previous block is applied where this block folds its data gradient (x0_is_elu: hn_seg_fold multiplies by
+    ELU'(x0)) and the previous block is told that the gradient it receives is already its dz (dy_is_dz) -- one elementwise pass less per
+    block."""
+
     @staticmethod
-    def forward(ctx, x0, x1, weight, bias, up, act, out_f32):
+    def forward(ctx, x0, x1, weight, bias, up, act, out_f32, x0_is_elu=False, dy_is_dz=False):
         n, h0, w0, c0 = x0.shape
         h, w = (h0 * 2, w0 * 2) if up else (h0, w0)
         cout, cin = weight.shape[0], weight.shape[1]
         wp, wt = pack_conv_weight(weight)
         y, _, _ = k_gemm_nt(x0, x1, 2, (n, h, w), wp, cout, kp32(cin), 9, bias=bias, act=act, out_f32=out_f32, up=up)
         ctx.up, ctx.act, ctx.out_f32 = up, act, out_f32
+        ctx.x0_is_elu, ctx.dy_is_dz = x0_is_elu, dy_is_dz
         ctx.wt = wt
         ctx.has_x1 = x1 is not None
-        ctx.save_for_backward(x0, x1, weight, y if act == ACT_ELU else None)
+        ctx.save_for_backward(x0, x1, weight, y if (act == ACT_ELU and not dy_is_dz) else None)
         return y
 
     @staticmethod
@@ -601,7 +607,7 @@ class SegConv(torch.autograd.Function):
             lib().call("hn_cast_f32_to_bf16_pad", ptr(dy), cout, ptr(dz), pad8(cout), m, cout)
         else:
             dy = dense(dy)
-            dz = k_eltwise(1, dy, y, act=ACT_ELU) if ctx.act == ACT_ELU else dy
+            dz = k_eltwise(1, dy, y, act=ACT_ELU) if (ctx.act == ACT_ELU and not ctx.dy_is_dz) else dy
         # bias gradient: per-channel sum of dz
         ps, _, r = k_col_stats(dz)
         dbias = k_rows_reduce(ps, 1, ps.shape[0], dz.shape[3]).view(-1)[:cout].clone()
@@ -611,11 +617,12 @@ class SegConv(torch.autograd.Function):
         dx0 = dx1 = None
         if ctx.needs_input_grad[0]:
             dx0 = new_act(n, h0, w0, c0, dev)
-            lib().call("hn_seg_fold", ptr(dvp), ld(dvp), 0, ptr(dx0), ld(dx0), None, 0, n, h, w, c0, up)
+            yp = x0 if ctx.x0_is_elu else None
+            lib().call("hn_seg_fold", ptr(dvp), ld(dvp), 0, ptr(dx0), ld(dx0), ptr(yp), ld(yp) if yp is not None else 0, n, h, w, c0, up)
         if ctx.has_x1 and ctx.needs_input_grad[1]:
             dx1 = new_act(n, h, w, c1, dev)
             lib().call("hn_seg_fold", ptr(dvp), ld(dvp), c0, ptr(dx1), ld(dx1), None, 0, n, h, w, c1, 0)
-        return dx0, dx1, dw, dbias, None, None, None
+        return dx0, dx1, dw, dbias, None, None, None, None, None
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -1029,9 +1036,10 @@ class SegOutUp(torch.autograd.Function):
     """logits[N, 2h, 2w, k] (fp32) = Conv3x3(ReflectionPad2d(1)(nearest_up2(x))) + bias, x [N, h, w, c] bf16."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, x_is_elu=False):
         n, h, w, c = x.shape
         k = weight.shape[0]
+        ctx.x_is_elu = x_is_elu
         T = _phase_matrix(x.device)
         w_eff = (weight.reshape(k * c, 9) @ T.t()).view(k, c, 2, 2, 3, 3).permute(2, 3, 0, 1, 4, 5).reshape(4 * k, c, 3, 3).contiguous()
         b_eff = bias.repeat(4)
@@ -1063,5 +1071,6 @@ class SegOutUp(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dvp, _, _ = k_gemm_nt(dz, None, 3, (n, h + 2, w + 2), ctx.wt, c, kp32(4 * k), 9, c0=ldz, c1=0)
             dx = new_act(n, h, w, c, dev)
-            lib().call("hn_seg_fold", ptr(dvp), ld(dvp), 0, ptr(dx), ld(dx), None, 0, n, h, w, c, 2)
-        return dx, dw, dbias
+            yp = x if ctx.x_is_elu else None
+            lib().call("hn_seg_fold", ptr(dvp), ld(dvp), 0, ptr(dx), ld(dx), ptr(yp), ld(yp) if yp is not None else 0, n, h, w, c, 2)
+        return dx, dw, dbias, None
