@@ -26,6 +26,7 @@ typedef struct ihipStream_t* hipStream_t;
 
 /* fp32 conv weight [Cout][Cin][taps] -> bf16 forward operand wp[Cout][taps][KP(Cin)] and (optional) dgrad operand
  * wt[Cin][taps][KP(Cout)], KP(x) = x rounded up to 32, zero filled.  Replaces the implicit weight cast of autocast convs. */
+int hn_gconv_pack_diag(const float* w, void* wk, void* wd, int C, hipStream_t stream);
 int hn_pack_weight(const float* w, void* wp, void* wt, int Cout, int Cin, int taps, hipStream_t stream);
 /* every conv weight of a model in one launch: jobs = DEVICE table njobs x 8 int64 {w, wp, wt, Cout, Cin, taps, first_block, 0}, job j owns
  * ceil((Cout*taps*KP(Cin) + Cin*taps*KP(Cout)) / 256) consecutive blocks starting at first_block */
@@ -41,6 +42,9 @@ int hn_pack_weights_batched(const long* jobs, int njobs, long total_blocks, hipS
  *   mode 4: mode 2 with replicate (clamp) padding, no up-sampling / concat: the low-resolution form of a 3x3 reflect-pad conv over a
  *           nearest-x2 up-sampled map (reflection of the up-sampled index == clamping of the source index); used with 4-phase
  *           effective weights for the final seg conv (head_seg/segmentation.py:101-104), see hn_depth_to_space.
+ *   mode 5: grouped 3x3 conv, group width 8, stride 1, zero padding 1 (XBlock conv_block_2, net/anynet.py:34-38) on MFMA: cout tile t
+ *           (64 couts = 8 groups) contracts only over input channels [64t, 64t+64) with block-diagonal weights from
+ *           hn_gconv_pack_diag (w = wk for the forward, wd for the data gradient); Nout == C0, KP == 64, no statistics.
  * (n_img, H, W) describe the OUTPUT pixel grid, M = n_img*H*W rows.  psum/psq (optional) receive per-wave partial sums / sums of
  * squares of the bf16-rounded outputs, [hn_nt_stat_rows(M, Nout)][Nout], for training-mode BatchNorm (F.batch_norm statistics).
  * rpi/img_stride (optional, 0 = off): out offset(pixel) = (pixel / rpi) * img_stride + (pixel % rpi) * ldc, which writes a pyramid

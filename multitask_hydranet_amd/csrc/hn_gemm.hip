@@ -21,10 +21,13 @@ struct XSrc {
     int up;        // mode 2: x0 lives at (Hi>>1, Wi>>1)
     long M;        // number of output rows
     int clamp;     // mode 2: replicate (clamp) padding instead of reflection (API mode 4)
+    int diag;      // API mode 5 (grouped conv, group width 8): zero "same" padding, and cout tile t (64 couts = 8 groups) contracts only
+                   // over input channels [64t, 64t+64) with block-diagonal packed weights [C][9][64]
 };
 
 // padded-border source index of a 3x3 tap: ReflectionPad2d(1) or replicate padding
 __device__ __forceinline__ int border_idx(int v, int L, int clamp) {
+    if (clamp == 2) return (v < 0 || v >= L) ? -1 : v;              // zero padding: outside = no source
     if (clamp) return v < 0 ? 0 : (v >= L ? L - 1 : v);
     return v < 0 ? -v : (v >= L ? 2 * L - 2 - v : v);
 }
@@ -448,8 +451,9 @@ __global__ __launch_bounds__(512) void conv3x3_direct_kernel(const GemmNT p) {
     const int c_blk = c_tile * BC, oy0 = ty * 16, ox0 = tx * 16;
     const int org = xs.mode == 2 ? -1 : -2;                           // patch origin relative to the output tile
     const int Ctot = xs.C0 + xs.C1;
-    const int nchunk = (p.KP + 63) >> 6, S = nchunk * 9;
+    const int nchunk = xs.diag ? 1 : (p.KP + 63) >> 6, S = nchunk * 9;
     const int Ktot = 9 * p.KP;
+    const int xc0 = xs.diag ? c_blk : 0;                              // first input channel of chunk 0
 
     // patch pieces owned by this thread: e = tid + 512 i -> patch pixel e>>3, PHYSICAL piece e&7 (logical = physical ^ (pixel&7))
     int spix0[XL], spix1[XL];
@@ -512,7 +516,7 @@ __global__ __launch_bounds__(512) void conv3x3_direct_kernel(const GemmNT p) {
 #pragma unroll
                 for (int i = 0; i < XL; ++i) {
                     if (512 * i + 64 * wave < PPIX * 8) {             // wave-uniform: this 1 KiB run starts inside the patch
-                        const int c = k0 + ssub[i];
+                        const int c = xc0 + k0 + ssub[i];
                         const bf16* src = g_zero_piece;
                         if (c < Ctot) {
                             if (c < xs.C0) { if (spix0[i] >= 0) src = xs.x0 + c + (long)spix0[i] * xs.ld0; }
@@ -811,10 +815,12 @@ __global__ __launch_bounds__(512) void wgrad3x3_patch_kernel(const GemmTN p, int
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave % WGN, wc = (wave / WGN) % WGC, wk = wave / (WGN * WGC);
     const XSrc& xs = p.x;
-    const int ntile = (p.KP + CI - 1) / CI;
+    const int ntile = (p.KP + CI - 1) / CI;                            // (diag: KP == CI == 64 -> 1)
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int bx = lid % ntile, by = (lid / ntile) % p.gy, bz = lid / (ntile * p.gy);
-    const int ci_blk = bx * CI, c_blk = by * BC;
+    const int c_blk = by * BC;
+    const int ci_blk = p.x.diag ? c_blk : bx * CI;                    // input-channel base of this block's X patch
+    const int ci_out0 = p.x.diag ? 0 : ci_blk;                        // ... and its column base inside the partial slab
     const int tx_n = (xs.W + 15) >> 4, ty_n = (xs.H + 7) >> 3;
     const int pb = bz * patches_per_split;
     int pe = pb + patches_per_split;
@@ -904,7 +910,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_patch_kernel(const GemmTN p, int
     }
     const int Ktot = 9 * p.KP;
     float* part = p.part + ((long)bz * KSPLIT + wk) * p.Nout * Ktot;       // each k-split wave group owns its own partial slab
-    const int ci = ci_blk + wn * 16 + (lane & 15);
+    const int ci = ci_out0 + wn * 16 + (lane & 15);
     if (ci < p.KP) {
 #pragma unroll
         for (int i = 0; i < TC; ++i)
@@ -958,6 +964,34 @@ __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* part, f
 #pragma unroll
     for (int j = 0; j < 4; ++j)
         if (ci + j < Cin) d[(long)j * taps] = s[j];
+}
+
+// grouped conv (group width 8) weight gradient from the block-diagonal slabs: dw[co][i][tap] = sum_split part[split][co][tap*64 + ((co&63)>>3)*8 + i]
+__global__ void gconv_diag_extract_kernel(const float* part, float* dw, int splits, int C) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= C * 72) return;
+    const int tap = idx % 9, i = (idx / 9) & 7, co = idx / 72;
+    const long col = (long)co * 576 + tap * 64 + ((co & 63) >> 3) * 8 + i;
+    const long slab = (long)C * 576;
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += part[(long)k * slab + col];
+    dw[idx] = s;
+}
+// fp32 grouped weights [C][8][3][3] -> block-diagonal bf16 operands [C][9][64]: wk for the forward conv, wd for the stride-1 data
+// gradient (group-transposed, taps flipped)
+__global__ void gconv_pack_diag_kernel(const float* w, bf16* wk, bf16* wd, int C) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)C * 576) return;
+    const int j = (int)(idx & 63), tap = (int)((idx >> 6) % 9), co = (int)(idx / 576);
+    const int gl = (co & 63) >> 3;                                    // group slot of this row inside its 64-channel tile
+    float a = 0.f, b = 0.f;
+    if ((j >> 3) == gl) {
+        a = w[((long)co * 8 + (j & 7)) * 9 + tap];                    // forward: row = cout co, column = its group's input channel j&7
+        const int cosrc = (co & ~63) + j;                             // dgrad: row = input channel co, column = output channel of its group
+        if (cosrc < C) b = w[((long)cosrc * 8 + (co & 7)) * 9 + (8 - tap)];
+    }
+    wk[idx] = f2bf(a);
+    wd[idx] = f2bf(b);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1024,8 +1058,9 @@ static XSrc make_xsrc(const void* x0, const void* x1, int mode, int n_img, int H
     XSrc s;
     s.x0 = (const bf16*)x0;
     s.x1 = (const bf16*)x1;
-    s.clamp = mode == 4;
-    if (mode == 4) mode = 2;
+    s.clamp = mode == 4 ? 1 : (mode == 5 ? 2 : 0);
+    s.diag = mode == 5;
+    if (mode == 4 || mode == 5) mode = 2;
     s.mode = mode;
     s.H = H; s.W = W;
     s.Hi = H; s.Wi = W;
@@ -1098,7 +1133,8 @@ extern "C" int hn_conv_gemm_nt(const void* x0, const void* x1, int mode, int n_i
                                int out_f32, int ldc, long rpi, long img_stride, float* psum, float* psq, hipStream_t st) {
     HN_CHECK_ARG(x0 && w && out && M > 0 && Nout > 0 && KP > 0 && (KP & 31) == 0 && taps >= 1 && taps <= 9);
     HN_CHECK_ARG((C0 & 7) == 0 && (C1 & 7) == 0 && (ld0 & 7) == 0 && (C1 == 0 || (x1 && (ld1 & 7) == 0)));
-    HN_CHECK_ARG(C0 + C1 <= KP && mode >= 0 && mode <= 4 && (mode != 4 || (up == 0 && C1 == 0)));
+    HN_CHECK_ARG(mode >= 0 && mode <= 5 && (mode < 4 || (up == 0 && C1 == 0)));
+    HN_CHECK_ARG(mode == 5 ? (KP == 64 && Nout == C0 && !psum && !rpi) : C0 + C1 <= KP);
     HN_CHECK_ARG(mode == 0 || (long)n_img * H * W == M);
     HN_CHECK_ARG(mode < 2 ? taps == 1 : taps == 9);
     HN_CHECK_ARG(mode != 2 || (H >= 2 && W >= 2));
@@ -1109,7 +1145,7 @@ extern "C" int hn_conv_gemm_nt(const void* x0, const void* x1, int mode, int n_i
     p.bias = bias; p.act = act; p.out = out; p.ldc = ldc; p.psum = psum; p.psq = psq;
     p.rpi = rpi; p.img_stride = img_stride;
     if (mode >= 2 && !psum && !rpi) {
-        const int bc = Nout <= 16 ? 16 : (Nout <= 64 ? 64 : 128);
+        const int bc = p.x.diag ? 64 : (Nout <= 16 ? 16 : (Nout <= 64 ? 64 : 128));
         dim3 grid((unsigned)(cdiv(Nout, bc) * cdiv(W, 16) * cdiv(H, 16) * n_img));
         const size_t lds = 2 * (size_t)((18 * 18 * 128 + 1023) / 1024 * 1024) + 2 * (size_t)bc * 128;
         // > 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel (done on the first, un-captured call)
@@ -1173,10 +1209,12 @@ static void patch_tiles(int Nout, int& bc, int& ci, int& ksplit) {
 extern "C" int hn_wgrad_plan(int mode, int n_img, int H, int W, long M, int Nout, int KP, int taps, int* splits, long* rows_per_split,
                              long* ws_bytes) {
     HN_CHECK_ARG(M > 0 && Nout > 0 && KP > 0 && taps > 0 && splits && rows_per_split && ws_bytes);
-    if (mode == 4) mode = 2;
+    const int grouped = mode == 5;
+    if (mode == 4 || mode == 5) mode = 2;
     if (use_patch_wgrad(mode, Nout, KP)) {
         int bc, ci, ksplit;
         patch_tiles(Nout, bc, ci, ksplit);
+        if (grouped) { bc = 64; ci = 64; ksplit = 2; }
         const long tiles = (long)cdiv(Nout, bc) * cdiv(KP, ci);
         const long patches = (long)n_img * cdiv(H, 8) * cdiv(W, 16);
         long want = (768 + tiles - 1) / tiles;
@@ -1207,10 +1245,12 @@ extern "C" int hn_conv_gemm_tn(const void* x0, const void* x1, int mode, int n_i
                                int up, long M, const void* dz, int ldz, int Nout, int KP, int taps, float* workspace, float* dw,
                                hipStream_t st) {
     HN_CHECK_ARG(x0 && dz && workspace && dw && M > 0 && (KP & 31) == 0 && (ldz & 7) == 0 && ldz >= ((Nout + 7) & ~7));
-    HN_CHECK_ARG((C0 & 7) == 0 && (C1 & 7) == 0 && (ld0 & 7) == 0 && ((mode >= 0 && mode <= 2) || (mode == 4 && up == 0 && C1 == 0)));
+    HN_CHECK_ARG((C0 & 7) == 0 && (C1 & 7) == 0 && (ld0 & 7) == 0 && ((mode >= 0 && mode <= 2) || ((mode == 4 || mode == 5) && up == 0 && C1 == 0)));
+    HN_CHECK_ARG(mode != 5 || (KP == 64 && Nout == C0 && taps == 9));
+    const int grouped = mode == 5;
     HN_CHECK_ARG(mode == 0 || (long)n_img * H * W == M);
     int splits; long rps, wsb;
-    hn_wgrad_plan(mode == 4 ? 2 : mode, n_img, H, W, M, Nout, KP, taps, &splits, &rps, &wsb);
+    hn_wgrad_plan(mode, n_img, H, W, M, Nout, KP, taps, &splits, &rps, &wsb);
     GemmTN p;
     p.x = make_xsrc(x0, x1, mode, n_img, H, W, C0, C1, ld0, ld1, up, M);
     mode = p.x.mode;
@@ -1223,21 +1263,26 @@ extern "C" int hn_conv_gemm_tn(const void* x0, const void* x1, int mode, int n_i
             hipFuncSetAttribute((const void*)wgrad3x3_patch_kernel<128, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             hipFuncSetAttribute((const void*)wgrad3x3_patch_kernel<64, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             hipFuncSetAttribute((const void*)wgrad3x3_patch_kernel<16, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute((const void*)wgrad3x3_patch_kernel<64, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             optin = true;
         }
         int pbc, pci, ksplit;
         patch_tiles(Nout, pbc, pci, ksplit);
+        if (grouped) { pbc = 64; pci = 64; ksplit = 2; }
         p.gy = cdiv(Nout, pbc);
         const int patches = n_img * cdiv(H, 8) * cdiv(W, 16);
         dim3 grid((unsigned)(cdiv(KP, pci) * p.gy * (splits / ksplit)));
         const size_t xb = (size_t)((180 * (pci / 8) + 511) / 512) * 512 * 16;
         const size_t lds = 2 * ((size_t)((128 * pbc * 2 + 1023) / 1024 * 1024) + xb);
-        if (pbc == 128) hipLaunchKernelGGL((wgrad3x3_patch_kernel<128, 64>), grid, dim3(512), lds, st, p, (int)rps, patches);
+        if (grouped) hipLaunchKernelGGL((wgrad3x3_patch_kernel<64, 64>), grid, dim3(512), lds, st, p, (int)rps, patches);
+        else if (pbc == 128) hipLaunchKernelGGL((wgrad3x3_patch_kernel<128, 64>), grid, dim3(512), lds, st, p, (int)rps, patches);
         else if (pbc == 64) hipLaunchKernelGGL((wgrad3x3_patch_kernel<64, 128>), grid, dim3(512), lds, st, p, (int)rps, patches);
         else hipLaunchKernelGGL((wgrad3x3_patch_kernel<16, 64>), grid, dim3(512), lds, st, p, (int)rps, patches);
         if (hipGetLastError() != hipSuccess) return HN_ERR_LAUNCH;
         const long cols = (long)Nout * taps * KP;
-        if (splits <= 128 && cols >= 65536)
+        if (grouped)
+            hipLaunchKernelGGL(gconv_diag_extract_kernel, dim3(cdiv(Nout * 72, 256)), dim3(256), 0, st, workspace, dw, splits, Nout);
+        else if (splits <= 128 && cols >= 65536)
             hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(cdiv(cols / 4, 256)), dim3(256), 0, st, workspace, dw, splits, Nout, C0 + C1, KP, taps);
         else
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(cols, 32)), dim3(512), 0, st, workspace, dw, splits, Nout, C0 + C1, KP, taps);
@@ -1265,6 +1310,14 @@ extern "C" int hn_conv_gemm_tn(const void* x0, const void* x1, int mode, int n_i
 extern "C" int hn_pack_weights_batched(const long* jobs, int njobs, long total_blocks, hipStream_t st) {
     HN_CHECK_ARG(jobs && njobs > 0 && total_blocks > 0);
     hipLaunchKernelGGL(pack_w_batched_kernel, dim3((unsigned)total_blocks), dim3(256), 0, st, jobs, njobs);
+    HN_LAUNCH_CHECK();
+}
+
+/* grouped 3x3 conv (group width 8) as block-diagonal 64-channel MFMA tiles: w fp32 [C][8][3][3] -> wk, wd bf16 [C][9][64] for
+ * hn_conv_gemm_nt mode 5 (forward / stride-1 data gradient) */
+extern "C" int hn_gconv_pack_diag(const float* w, void* wk, void* wd, int C, hipStream_t st) {
+    HN_CHECK_ARG(w && wk && wd && C > 0 && (C & 7) == 0);
+    hipLaunchKernelGGL(gconv_pack_diag_kernel, dim3(cdiv((long)C * 576, 256)), dim3(256), 0, st, w, (bf16*)wk, (bf16*)wd, C);
     HN_LAUNCH_CHECK();
 }
 

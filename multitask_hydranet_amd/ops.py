@@ -16,6 +16,7 @@ import torch
 from ._lib import lib
 
 ACT_NONE, ACT_RELU, ACT_SWISH, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3, 4
+GCONV_MFMA = True          # stride-1 grouped 3x3 convs as block-diagonal 64-channel MFMA tiles (False: VALU stencil kernels)
 BF16 = torch.bfloat16
 F32 = torch.float32
 
@@ -154,6 +155,17 @@ def pack_gconv_weight(w: torch.Tensor, flip: int):
         lib().call("hn_gconv_pack", ptr(w), ptr(wk), ptr(wd), c, flip)
         return wk, wd
     return _cached(("g", flip), w, make)
+
+
+def pack_gconv_diag(w: torch.Tensor):
+    """grouped weights [C, 8, 3, 3] -> block-diagonal MFMA operands (wk forward, wd stride-1 dgrad), bf16 [C, 9*64]"""
+    def make():
+        c = w.shape[0]
+        wk = torch.empty((c, 9 * 64), device=w.device, dtype=BF16)
+        wd = torch.empty((c, 9 * 64), device=w.device, dtype=BF16)
+        lib().call("hn_gconv_pack_diag", ptr(w), ptr(wk), ptr(wd), c)
+        return wk, wd
+    return _cached("gdiag", w, make)
 
 
 def pack_dw_weight(w: torch.Tensor):
@@ -318,9 +330,13 @@ class ConvBnAct(torch.autograd.Function):
         elif kind == "g3x3":
             n, hi, wi, c = x.shape
             ho, wo = (hi, wi) if stride == 1 else (hi // 2, wi // 2)
-            packs = pack_gconv_weight(weight, 1 if stride == 1 else 0)
-            z = new_act(n, ho, wo, c, dev)
-            lib().call("hn_gconv_fwd", ptr(x), ld(x), ptr(packs[0]), ptr(z), ld(z), n, hi, wi, c, stride)
+            if stride == 1 and GCONV_MFMA:          # block-diagonal 64-channel tiles on MFMA (hn_conv_gemm_nt mode 5)
+                packs = pack_gconv_diag(weight)
+                z, _, _ = k_gemm_nt(x, None, 5, (n, ho, wo), packs[0], c, 64, 9)
+            else:
+                packs = pack_gconv_weight(weight, 1 if stride == 1 else 0)
+                z = new_act(n, ho, wo, c, dev)
+                lib().call("hn_gconv_fwd", ptr(x), ld(x), ptr(packs[0]), ptr(z), ld(z), n, hi, wi, c, stride)
             psum = psq = None
         else:
             n, hi, wi, cin = x.shape
@@ -365,16 +381,23 @@ class ConvBnAct(torch.autograd.Function):
         elif kind == "g3x3":
             _, hi, wi, c = x.shape
             wk, wd = ctx.packs
+            mfma = stride == 1 and GCONV_MFMA
             if ctx.needs_input_grad[0]:
-                dx = new_act(n, hi, wi, c, dev)
-                if stride == 1:
-                    lib().call("hn_gconv_fwd", ptr(dz), ld(dz), ptr(wd), ptr(dx), ld(dx), n, hi, wi, c, 1)
+                if mfma:
+                    dx, _, _ = k_gemm_nt(dz, None, 5, (n, hi, wi), wd, c, 64, 9)
                 else:
-                    lib().call("hn_gconv_dgrad_s2", ptr(dz), ld(dz), ptr(wd), ptr(dx), ld(dx), n, hi, wi, c)
-            chunks = lib().query("hn_wgrad_chunks", n * ho * wo, (c // 8) * 9)
-            part = torch.empty((chunks, c * 72), device=dev, dtype=F32)
-            lib().call("hn_gconv_wgrad", ptr(x), ld(x), ptr(dz), ld(dz), ptr(part), n, hi, wi, c, stride)
-            dw = k_rows_reduce(part, 1, chunks, c * 72).view(c, 8, 3, 3)
+                    dx = new_act(n, hi, wi, c, dev)
+                    if stride == 1:
+                        lib().call("hn_gconv_fwd", ptr(dz), ld(dz), ptr(wd), ptr(dx), ld(dx), n, hi, wi, c, 1)
+                    else:
+                        lib().call("hn_gconv_dgrad_s2", ptr(dz), ld(dz), ptr(wd), ptr(dx), ld(dx), n, hi, wi, c)
+            if mfma:
+                dw = k_gemm_tn(x, None, 5, (n, ho, wo), dz, c, 64, 9, 8, kh=3)
+            else:
+                chunks = lib().query("hn_wgrad_chunks", n * ho * wo, (c // 8) * 9)
+                part = torch.empty((chunks, c * 72), device=dev, dtype=F32)
+                lib().call("hn_gconv_wgrad", ptr(x), ld(x), ptr(dz), ld(dz), ptr(part), n, hi, wi, c, stride)
+                dw = k_rows_reduce(part, 1, chunks, c * 72).view(c, 8, 3, 3)
         else:
             _, hi, wi, cin = x.shape
             wp, wt = ctx.packs

@@ -120,7 +120,8 @@ def test_conv1x1_bn_act(K, cin, cout, stride, act, res, bias, n, h, w):
     g.grad = b.grad = None
 
 
-@pytest.mark.parametrize("c,stride,n,h,w", [(24, 2, 2, 12, 16), (64, 1, 2, 9, 10), (152, 1, 1, 6, 6), (8, 2, 2, 8, 8), (936, 2, 1, 4, 8)])
+@pytest.mark.parametrize("c,stride,n,h,w", [(24, 2, 2, 12, 16), (64, 1, 2, 9, 10), (152, 1, 1, 6, 6), (8, 2, 2, 8, 8), (936, 2, 1, 4, 8),
+                                            (24, 1, 2, 20, 36), (376, 1, 2, 16, 32), (936, 1, 3, 8, 16), (72, 1, 1, 17, 5)])
 def test_grouped_conv_bn_relu(K, c, stride, n, h, w):
     x = rnd(n, c, h, w)
     wt = rnd(c, 8, 3, 3, scale=0.15)
