@@ -228,7 +228,8 @@ def main():
             torch.cuda.synchronize()
             net.zero_grad(set_to_none=True)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # thread-local capture mode: the RCCL watchdog thread's event queries (N > 1) must not invalidate the capture
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 static_loss = fwd_bwd()
             if reducer is not None:
                 reducer = GradReducer(list(net.named_parameters()), world_size=world, skip=UNUSED_5STAGE if len(net.depths) == 5 else ())
