@@ -171,10 +171,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus or world == 1, "--gpus must equal WORLD_SIZE under torch.distributed.run"
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # test hooks for a 1-GPU box: HN_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and HN_BENCH_BACKEND=gloo replaces RCCL (which refuses
+    # two ranks on one device), so the whole N>1 control flow can be exercised without a second GPU.  Never set by the driver.
+    if os.environ.get("HN_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("HN_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import __graft_entry__ as ge
     if rank == 0:
@@ -223,7 +231,9 @@ def main():
             with torch.cuda.stream(s):
                 for _ in range(2):
                     net.zero_grad(set_to_none=True)
-                    fwd_bwd()
+                    l0 = fwd_bwd()
+                    if os.environ.get("HN_BENCH_DEBUG"):
+                        print("rank", rank, "eager loss", float(l0.detach()), file=sys.stderr, flush=True)
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
             net.zero_grad(set_to_none=True)
@@ -234,6 +244,7 @@ def main():
             if reducer is not None:
                 reducer = GradReducer(list(net.named_parameters()), world_size=world, skip=UNUSED_5STAGE if len(net.depths) == 5 else ())
                 reducer.remove()
+                reducer.bind_static_grads()         # every replay rewrites these tensors; reduce_now() gathers them into the buckets
         except Exception as e:                      # noqa: BLE001
             if rank == 0:
                 import traceback
@@ -247,7 +258,7 @@ def main():
     def step():
         if graph is not None:
             graph.replay()
-            if reducer is not None:
+            if reducer is not None and not os.environ.get("HN_BENCH_SKIP_REDUCE"):
                 reducer.reduce_now()
             return static_loss
         net.zero_grad(set_to_none=False) if reducer is not None else net.zero_grad(set_to_none=True)
@@ -258,12 +269,31 @@ def main():
 
     for _ in range(args.warmup):
         loss = step()
+        if os.environ.get("HN_BENCH_DEBUG"):
+            print("rank", rank, "warm-up loss", float(loss.detach()), file=sys.stderr, flush=True)
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    if os.environ.get("HN_BENCH_NO_DEVSYNC"):
+        torch.cuda.current_stream().synchronize()
+    else:
+        torch.cuda.synchronize()
+    if os.environ.get("HN_BENCH_DEBUG") and graph is not None:
+        print("rank", rank, "before timed loop (no replay)", float(static_loss.detach()), file=sys.stderr, flush=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+        if os.environ.get("HN_BENCH_DEBUG"):
+            lv = float(loss.detach())
+            print("rank", rank, "timed loss", lv, file=sys.stderr, flush=True)
+            if lv != lv:
+                bad = [k for k, v in net.state_dict().items() if v.is_floating_point() and not torch.isfinite(v).all()]
+                badb = [k for k, v in batch.items() if v.is_floating_point() and not torch.isfinite(v).all()]
+                print("rank", rank, "non-finite state:", bad[:6], len(bad), "batch:", badb, file=sys.stderr, flush=True)
+                with torch.no_grad():
+                    o2 = net(batch["image"])
+                    print("rank", rank, "eager forward after NaN: seg finite", bool(torch.isfinite(o2["seg"]).all()),
+                          "cls finite", bool(torch.isfinite(o2["detection"]["classification"]).all()), file=sys.stderr, flush=True)
+                break
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

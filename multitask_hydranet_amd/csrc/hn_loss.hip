@@ -351,6 +351,11 @@ extern "C" long hn_seg_loss_ws_bytes(int N, long HW) {
     return M * 4 + (long)N * 2048 * 4 + (long)N * 8 + (long)N * 4 + (long)hn_seg_loss_blocks(N, HW) * 4 + 64;
 }
 
+__global__ void zero_u32_kernel(unsigned int* p, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+
 // forward: returns the scalar loss in out[0]; ws is kept for the backward pass.  k = int(top_k_ratio * HW) when use_topk.
 extern "C" int hn_seg_loss_fwd(const float* logits, int ldl, int C, const void* target, int target_is_float, const float* cw,
                                int ignore_index, int N, long HW, int use_topk, long k, void* ws, float* out, hipStream_t st) {
@@ -363,7 +368,12 @@ extern "C" int hn_seg_loss_fwd(const float* logits, int ldl, int C, const void* 
     unsigned int* ties = (unsigned int*)(w + M * 4 + (long)N * 2048 * 4 + (long)N * 8);
     float* psum = (float*)(w + M * 4 + (long)N * 2048 * 4 + (long)N * 12);
     const int blocks = hn_seg_loss_blocks(N, HW);
-    if (hipMemsetAsync(hist, 0, (size_t)N * 2048 * 4 + (size_t)N * 12, st) != hipSuccess) return HN_ERR_LAUNCH;
+    // zero the histogram + selection state with a kernel, not hipMemsetAsync: inside a captured hipGraph the memset node was observed to
+    // lose its ordering against the following kernel (first replay after a host sync while another process shares the GPU -> NaN loss)
+    {
+        const long words = (long)N * 2048 + (long)N * 3;
+        hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, hist, words);
+    }
     hipLaunchKernelGGL(seg_ce_fwd_kernel, dim3(blocks), dim3(256), 0, st, logits, ldl, C, target, target_is_float, cw, ignore_index, HW, M, loss,
                        use_topk ? hist : (unsigned int*)nullptr);
     if (use_topk) {

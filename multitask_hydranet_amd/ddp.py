@@ -101,9 +101,24 @@ class GradReducer:
                     b["work"] = None
             b["pending"] = len(b["params"])
 
+    def bind_static_grads(self):
+        """hipGraph mode: a captured step always writes the SAME gradient tensors (graph-private memory).  Remember them, so that every
+        reduce_now() first gathers their fresh contents into the buckets (after the first exchange .grad points at the bucket views, which
+        a replay no longer touches)."""
+        for b in self.buckets:
+            if any(p.grad is None for _, p in b["params"]):
+                raise RuntimeError("bind_static_grads() needs the gradients of a captured step: " +
+                                   ", ".join(n for n, p in b["params"] if p.grad is None))
+            b["src"] = [p.grad for _, p in b["params"]]
+
     def reduce_now(self):
         """non-overlapped variant (after a hipGraph replay of forward+backward): exchange every bucket, then finish()."""
         for b in self.buckets:
+            src = b.get("src")
+            if src is not None:
+                torch._foreach_copy_(b["views"], src)
+                for (n, p), v in zip(b["params"], b["views"]):
+                    p.grad = v
             b["pending"] = 0
             self._launch(b)
         self.finish()

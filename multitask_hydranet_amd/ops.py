@@ -49,6 +49,12 @@ def rows(t: torch.Tensor) -> int:
     return t.shape[0] * t.shape[1] * t.shape[2]
 
 
+def zeros(shape, device, dtype=F32):
+    """zero tensor written by a fill KERNEL (torch.zeros / zero_() become hipMemsetAsync -> memset nodes inside a captured hipGraph, whose
+    ordering against the consumer kernel proved unreliable on this stack)"""
+    return torch.full(tuple(shape), 0.0, device=device, dtype=dtype)
+
+
 def new_act(n, h, w, c, device, dtype=BF16):
     return torch.empty((n, h, w, c), device=device, dtype=dtype)
 
@@ -406,10 +412,10 @@ class ConvBnAct(torch.autograd.Function):
                 if stride == 1:
                     dx = dxs
                 else:
-                    dx = torch.zeros((n, hi, wi, cin), device=dev, dtype=BF16)
+                    dx = zeros((n, hi, wi, cin), dev, BF16)
                     lib().call("hn_add_strided2", ptr(dx), ld(dx), ptr(dxs), ld(dxs), n, ho, wo, cin)
             dw = k_gemm_tn(x, None, 0 if stride == 1 else 1, (n, ho, wo), dz, cout, kp32(cin), 1, cin)
-        dbias = torch.zeros((cout,), device=dev, dtype=F32) if ctx.has_bias else None   # a bias feeding BatchNorm has zero gradient
+        dbias = zeros((cout,), dev) if ctx.has_bias else None   # a bias feeding BatchNorm has zero gradient
         return dx, dw, dbias, dgamma, dbeta, None, None, None, dres, None, None, None, None, None, None
 
 
@@ -691,9 +697,9 @@ class HeadOut(torch.autograd.Function):
         dout = dout.contiguous()
         dev = dout.device
         ldz = pad8(cout)
-        dpw = torch.zeros_like(pw_weight)
-        dbias = torch.zeros((cout,), device=dev, dtype=F32)
-        ddw = torch.zeros_like(dw_weight) if has_dw else None
+        dpw = zeros(pw_weight.shape, dev)
+        dbias = zeros((cout,), dev)
+        ddw = zeros(dw_weight.shape, dev) if has_dw else None
         dfeats = []
         off = 0
         for f, mid in zip(feats, mids):
@@ -970,7 +976,7 @@ class TowerLayer(torch.autograd.Function):
                    ctypes.addressof(R))
         dd, _, _ = k_gemm_nt(dz, None, 0, (1, 1, total), wt, c, kp32(cout), 1)
         dpw = k_gemm_tn(d, None, 0, (1, 1, total), dz, cout, kp32(c), 1, c)
-        dbias = torch.zeros((cout,), device=dev, dtype=F32) if ctx.has_bias else None    # a bias feeding BatchNorm has zero gradient
+        dbias = zeros((cout,), dev) if ctx.has_bias else None    # a bias feeding BatchNorm has zero gradient
         ddw = k_dwconv_wgrad_levels(x, dd, geom)
         dx = k_dwconv_levels(dd, wf, geom) if ctx.needs_input_grad[0] else None
         bn_grads = []

@@ -73,3 +73,43 @@ def test_bucketed_allreduce_matches_single_process_average():
             a, b = torch.from_numpy(a), torch.from_numpy(b)
             assert torch.equal(a, b)                                    # both ranks hold identical averaged gradients
             assert torch.allclose(a, r, rtol=1e-5, atol=1e-7)
+
+
+def _worker_static(rank, world, port, q):
+    """graph-replay mode: the 'captured step' rewrites the same gradient tensors; reduce_now() must pick the fresh values up every time"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from multitask_hydranet_amd.ddp import GradReducer
+    m = _net()
+    static = {n: torch.zeros_like(p) for n, p in m.named_parameters() if n != "unused"}
+    for n, p in m.named_parameters():
+        if n != "unused":
+            p.grad = static[n]
+    red = GradReducer(list(m.named_parameters()), bucket_bytes=600, skip=("unused",))
+    red.remove()
+    red.bind_static_grads()
+    out = {}
+    for step in range(3):
+        for i, (n, t) in enumerate(static.items()):          # "replay": new contents in the same tensors
+            t.fill_(float((rank + 1) * (step + 1) + i))
+        red.reduce_now()
+        out[step] = [p.grad.clone().numpy() for n, p in m.named_parameters() if n != "unused"]
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_reduce_now_tracks_static_graph_grads():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_static, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for step in range(3):
+        for i, (a, b) in enumerate(zip(res[0][step], res[1][step])):
+            expect = 0.5 * ((1 * (step + 1) + i) + (2 * (step + 1) + i))
+            assert (a == b).all() and abs(float(a.reshape(-1)[0]) - expect) < 1e-6 and (a == a.reshape(-1)[0]).all()

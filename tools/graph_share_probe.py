@@ -1,0 +1,38 @@
+"""hipGraph replays of the full step while another process shares the GPU: where does the loss turn non-finite?"""
+import sys, time, os, torch, yaml
+sys.path.insert(0, '.')
+import bench
+from multitask_hydranet_amd import HydraNet
+mode = sys.argv[1] if len(sys.argv) > 1 else "plain"
+cfgs = yaml.safe_load(open('cfgs/hydranet_big.yml'))
+h, w, n = 512, 1024, int(os.environ.get("PROBE_BATCH", "16"))
+cfgs["dataloader"]["network_input_height"], cfgs["dataloader"]["network_input_width"] = h, w
+dev = torch.device('cuda:0')
+torch.manual_seed(0)
+net = HydraNet(cfgs).to(dev).train(); net.check_finite = False; net.lane_points_per_line = h // 8
+batch = bench.synthetic_batch(cfgs, n, h, w, 1, dev)
+def fwd_bwd():
+    out = net(batch["image"]); ld = net.cal_loss(out, batch); loss = net.total_loss(ld); loss.backward(); return loss
+s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(s):
+    for _ in range(2):
+        net.zero_grad(set_to_none=True); fwd_bwd()
+torch.cuda.current_stream().wait_stream(s); torch.cuda.synchronize()
+net.zero_grad(set_to_none=True)
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g, capture_error_mode="thread_local"):
+    static_loss = fwd_bwd()
+t0 = time.time()
+def finite_report(tag):
+    bad = []
+    for k, v in net.state_dict().items():
+        if v.is_floating_point() and not torch.isfinite(v).all(): bad.append(k)
+    print(tag, "non-finite state entries:", bad[:5], len(bad), flush=True)
+for i in range(10):
+    if mode == "sleep" and i == 3: time.sleep(2.0)
+    g.replay()
+    v = float(static_loss.detach())
+    print(f"replay {i} t={time.time() - t0:.2f}s loss {v}", flush=True)
+    if v != v:
+        finite_report("after NaN:")
+        break

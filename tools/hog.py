@@ -1,0 +1,5 @@
+import torch, time
+a = torch.randn(4096, 4096, device='cuda'); t0 = time.time()
+while time.time() - t0 < 70:
+    for _ in range(50): b = a @ a
+    torch.cuda.synchronize()
