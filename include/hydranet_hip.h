@@ -214,6 +214,18 @@ int hn_det_loss_fwd(const float* cls, const float* reg, const float* anchors, co
 int hn_det_loss_bwd(const float* cls, const float* reg, const float* anchors, const float* ann, int N, int A, int K, int Mx,
                     const void* assign, const float* npos, const float* gout, float* dcls, float* dreg, hipStream_t stream);
 /* torch.argmax(seg, dim=1) of deploy mode (model/model.py:197): fp32 NHWC logits -> int64 class ids, first maximum wins. */
+/* Lane losses (head_lane/lanedetect_loss.py:18-78).  cls: logits / one-hot target fp32 [M][2]; out[0] = positive term, out[1] = OHEM
+ * negative term (NEGATIVE_RATIO 15, ALPHA 10: the k-th smallest background log-prob is found by a radix select, not a sort);
+ * lsm [M][2], pmask [M] bytes and aux[4] = {threshold, max(#pos,1), #pos, #neg} are kept for the backward pass and the location loss.
+ * loc: pred / target fp32 [M][L]; the x`alpha` weights sit at columns wcol, wcol+1 (the reference hard-codes wcol = 160). */
+int hn_lane_cls_loss_fwd(const float* logits, const float* target, long M, float neg_ratio, float alpha, float* lsm, void* pmask,
+                         float* out, float* aux, hipStream_t stream);
+int hn_lane_cls_loss_bwd(const float* lsm, const void* pmask, const float* aux, const float* gpos, const float* gneg, float alpha, long M,
+                         float* dlogits, hipStream_t stream);
+int hn_lane_loc_loss_fwd(const float* pred, const float* target, const void* pmask, const float* aux, long M, int L, int wcol, float alpha,
+                         float* rowloss, float* rownorm, float* out, hipStream_t stream);
+int hn_lane_loc_loss_bwd(const float* pred, const float* target, const void* pmask, const float* rownorm, const float* aux,
+                         const float* gout, long M, int L, int wcol, float alpha, float* dpred, hipStream_t stream);
 int hn_argmax_channels(const float* logits, int ldl, int C, long M, long* out, hipStream_t stream);
 
 #ifdef __cplusplus

@@ -434,3 +434,196 @@ extern "C" int hn_det_loss_bwd(const float* cls, const float* reg, const float* 
                        (const short*)assign, npos, gout, dcls, dreg);
     HN_LAUNCH_CHECK();
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Lane losses (head_lane/lanedetect_loss.py:5-78): OHEM classification loss and masked Huber location loss.
+//   cls: M = N*hw anchors, logits [M][2], target one-hot [M][2] (positive = t[1] > 0).  NEGATIVE_RATIO 15, ALPHA 10.
+//        neg_num = clamp(15 * #pos, 1, #neg); thr = neg_num-th smallest background log-prob among the negatives (detached);
+//        pos = -alpha * sum_{pos} log p_fg / max(#pos,1);  neg = -alpha * sum_{neg, log p_bg <= thr} log p_bg / max(#pos,1)
+//   One workgroup of 1024 threads does the whole problem (M is 8 192 at batch 16): log-softmax, counts, a 4-pass byte radix select of the
+//   k-th smallest value in LDS histograms (instead of torch.sort), and both sums.  aux[0..3] = {thr, max(#pos,1), #pos, #neg}.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned int f2ord(float f) {              // order-preserving float -> uint
+    const unsigned int u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned int o) {
+    const unsigned int u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ float block_sum_1024(float v, float* red) {  // red: >= 16 floats of LDS; all threads get the total
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
+    return t;
+}
+__global__ __launch_bounds__(1024) void lane_cls_fwd_kernel(const float* logits, const float* target, long M, float neg_ratio, float alpha,
+                                                            float* lsm, unsigned char* pmask, float* out, float* aux) {
+    __shared__ unsigned int hist[256];
+    __shared__ float red[16];
+    __shared__ unsigned int s_prefix, s_k;
+    const int tid = threadIdx.x;
+    float npos = 0.f, nneg = 0.f;
+    for (long i = tid; i < M; i += 1024) {
+        const float z0 = logits[2 * i], z1 = logits[2 * i + 1];
+        const float mx = fmaxf(z0, z1);
+        const float lse = mx + logf(expf(z0 - mx) + expf(z1 - mx));
+        lsm[2 * i] = z0 - lse;
+        lsm[2 * i + 1] = z1 - lse;
+        const bool p = target[2 * i + 1] > 0.f;
+        pmask[i] = p ? 1 : 0;
+        npos += p ? 1.f : 0.f;
+        nneg += p ? 0.f : 1.f;
+    }
+    npos = block_sum_1024(npos, red);
+    nneg = block_sum_1024(nneg, red);
+    const float posn = fmaxf(npos, 1.f);
+    long kk = (long)fmaxf(fminf(npos * neg_ratio, nneg), 1.f);       // 1-based rank among the negatives
+    float thr = __builtin_inff();
+    if (nneg >= 1.f) {
+        // byte-wise radix select, most significant byte first, over the order-preserving keys of the negatives' background log-probs
+        unsigned int prefix = 0, k = (unsigned int)kk;
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
+            const unsigned int himask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+            for (long i = tid; i < M; i += 1024) {
+                if (pmask[i]) continue;
+                const unsigned int key = f2ord(lsm[2 * i]);
+                if ((key & himask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                unsigned int acc = 0, b = 0;
+                for (; b < 256; ++b) {
+                    if (acc + hist[b] >= k) break;
+                    acc += hist[b];
+                }
+                s_prefix = prefix | (b << shift);
+                s_k = k - acc;
+            }
+            __syncthreads();
+            prefix = s_prefix;
+            k = s_k;
+        }
+        thr = ord2f(prefix);
+    }
+    float sp = 0.f, sn = 0.f;
+    for (long i = tid; i < M; i += 1024) {
+        const float bg = lsm[2 * i], fg = lsm[2 * i + 1];
+        if (pmask[i]) sp += fg;
+        else if (bg <= thr) sn += bg;
+    }
+    sp = block_sum_1024(sp, red);
+    sn = block_sum_1024(sn, red);
+    if (tid == 0) {
+        out[0] = -alpha * sp / posn;
+        out[1] = -alpha * sn / posn;
+        aux[0] = thr; aux[1] = posn; aux[2] = npos; aux[3] = nneg;
+    }
+}
+// dlogits = gpos * d(pos)/dz + gneg * d(neg)/dz
+__global__ void lane_cls_bwd_kernel(const float* lsm, const unsigned char* pmask, const float* aux, const float* gpos, const float* gneg,
+                                    float alpha, long M, float* dlogits) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const float thr = aux[0], posn = aux[1];
+    const float bg = lsm[2 * i], fg = lsm[2 * i + 1];
+    const float p0 = expf(bg), p1 = expf(fg);
+    float d0 = 0.f, d1 = 0.f;
+    if (pmask[i]) {                                    // -alpha/P * log p_fg
+        const float c = -alpha / posn * gpos[0];
+        d0 = -p0 * c;
+        d1 = (1.f - p1) * c;
+    } else if (bg <= thr) {                            // -alpha/P * log p_bg
+        const float c = -alpha / posn * gneg[0];
+        d0 = (1.f - p0) * c;
+        d1 = -p1 * c;
+    }
+    dlogits[2 * i] = d0;
+    dlogits[2 * i + 1] = d1;
+}
+// location loss: per row r (positive anchors only): sum_c huber(p - t) * w_c * [t != 0] / max(#[t != 0], 1); w = alpha at columns wcol, wcol+1.
+// block = 8 rows x 32 lanes; rowloss[r] (0 for negatives) and the per-row normaliser go to workspace; a 1-block finalize sums the rows.
+__global__ __launch_bounds__(256) void lane_loc_fwd_kernel(const float* pred, const float* tgt, const unsigned char* pmask, long M, int L,
+                                                           int wcol, float alpha, float* rowloss, float* rownorm) {
+    const int lane = threadIdx.x & 31, rr = threadIdx.x >> 5;
+    const long r = (long)blockIdx.x * 8 + rr;
+    float s = 0.f, cnt = 0.f;
+    if (r < M) {
+        const bool pos = pmask[r] != 0;
+        for (int c = lane; c < L; c += 32) {
+            const float t = tgt[r * L + c];
+            if (t != 0.f) {
+                cnt += 1.f;
+                if (pos) {
+                    const float d = pred[r * L + c] - t, ad = fabsf(d);
+                    const float hv = ad < 1.f ? 0.5f * d * d : ad - 0.5f;
+                    s += hv * ((c == wcol || c == wcol + 1) ? alpha : 1.f);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) { s += __shfl_xor(s, o); cnt += __shfl_xor(cnt, o); }
+    if (lane == 0 && r < M) {
+        const float nrm = fmaxf(cnt, 1.f);
+        rownorm[r] = nrm;
+        rowloss[r] = s / nrm;
+    }
+}
+__global__ __launch_bounds__(1024) void lane_loc_finalize_kernel(const float* rowloss, long M, const float* aux, float* out) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (long i = threadIdx.x; i < M; i += 1024) s += rowloss[i];
+    s = block_sum_1024(s, red);
+    if (threadIdx.x == 0) out[0] = s / aux[1];
+}
+__global__ void lane_loc_bwd_kernel(const float* pred, const float* tgt, const unsigned char* pmask, const float* rownorm, const float* aux,
+                                    const float* gout, long M, int L, int wcol, float alpha, float* dpred) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * L) return;
+    const long r = idx / L;
+    const int c = (int)(idx - r * L);
+    float g = 0.f;
+    const float t = tgt[idx];
+    if (pmask[r] && t != 0.f) {
+        const float d = pred[idx] - t;
+        const float dh = fabsf(d) < 1.f ? d : (d > 0.f ? 1.f : -1.f);
+        g = dh * ((c == wcol || c == wcol + 1) ? alpha : 1.f) / rownorm[r] / aux[1] * gout[0];
+    }
+    dpred[idx] = g;
+}
+
+extern "C" int hn_lane_cls_loss_fwd(const float* logits, const float* target, long M, float neg_ratio, float alpha, float* lsm,
+                                    void* pmask, float* out, float* aux, hipStream_t st) {
+    HN_CHECK_ARG(logits && target && lsm && pmask && out && aux && M > 0 && M <= (1L << 22));
+    hipLaunchKernelGGL(lane_cls_fwd_kernel, dim3(1), dim3(1024), 0, st, logits, target, M, neg_ratio, alpha, lsm, (unsigned char*)pmask, out, aux);
+    HN_LAUNCH_CHECK();
+}
+extern "C" int hn_lane_cls_loss_bwd(const float* lsm, const void* pmask, const float* aux, const float* gpos, const float* gneg, float alpha,
+                                    long M, float* dlogits, hipStream_t st) {
+    HN_CHECK_ARG(lsm && pmask && aux && gpos && gneg && dlogits && M > 0);
+    hipLaunchKernelGGL(lane_cls_bwd_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, lsm, (const unsigned char*)pmask, aux, gpos, gneg,
+                       alpha, M, dlogits);
+    HN_LAUNCH_CHECK();
+}
+extern "C" int hn_lane_loc_loss_fwd(const float* pred, const float* target, const void* pmask, const float* aux, long M, int L, int wcol,
+                                    float alpha, float* rowloss, float* rownorm, float* out, hipStream_t st) {
+    HN_CHECK_ARG(pred && target && pmask && aux && rowloss && rownorm && out && M > 0 && L > 0 && wcol >= 0 && wcol + 1 < L);
+    hipLaunchKernelGGL(lane_loc_fwd_kernel, dim3((unsigned)((M + 7) / 8)), dim3(256), 0, st, pred, target, (const unsigned char*)pmask, M, L, wcol,
+                       alpha, rowloss, rownorm);
+    hipLaunchKernelGGL(lane_loc_finalize_kernel, dim3(1), dim3(1024), 0, st, rowloss, M, aux, out);
+    HN_LAUNCH_CHECK();
+}
+extern "C" int hn_lane_loc_loss_bwd(const float* pred, const float* target, const void* pmask, const float* rownorm, const float* aux,
+                                    const float* gout, long M, int L, int wcol, float alpha, float* dpred, hipStream_t st) {
+    HN_CHECK_ARG(pred && target && pmask && rownorm && aux && gout && dpred && M > 0 && L > 0);
+    hipLaunchKernelGGL(lane_loc_bwd_kernel, dim3((unsigned)((M * L + 255) / 256)), dim3(256), 0, st, pred, target, (const unsigned char*)pmask,
+                       rownorm, aux, gout, M, L, wcol, alpha, dpred);
+    HN_LAUNCH_CHECK();
+}

@@ -639,7 +639,9 @@ class SegConv(torch.autograd.Function):
             dz = k_eltwise(1, dy, y, act=ACT_ELU) if (ctx.act == ACT_ELU and not ctx.dy_is_dz) else dy
         # bias gradient: per-channel sum of dz
         ps, _, r = k_col_stats(dz)
-        dbias = k_rows_reduce(ps, 1, ps.shape[0], dz.shape[3]).view(-1)[:cout].clone()
+        dbias = k_rows_reduce(ps, 1, ps.shape[0], dz.shape[3]).view(-1)
+        if dbias.numel() != cout:
+            dbias = dbias[:cout] + 0.0                               # owning copy by a kernel (a clone would be a memcpy node in the graph)
         dw = k_gemm_tn(x0, x1, 2, (n, h, w), dz, cout, kp32(cin), 9, cin, up=up, kh=3)
         # data gradient on the padded (H+2)x(W+2) grid, then fold the reflection / up-sampling / concat back
         dvp, _, _ = k_gemm_nt(dz, None, 3, (n, h + 2, w + 2), ctx.wt, cin, kp32(cout), 9, c0=dz.shape[3], c1=0)
@@ -1103,3 +1105,78 @@ class SegOutUp(torch.autograd.Function):
             yp = x if ctx.x_is_elu else None
             lib().call("hn_seg_fold", ptr(dvp), ld(dvp), 0, ptr(dx), ld(dx), ptr(yp), ld(yp) if yp is not None else 0, n, h, w, c, 2)
         return dx, dw, dbias, None
+
+
+# --------------------------------------------------------------------------------------------------------------
+# Lane losses on the device (head_lane/lanedetect_loss.py:18-78): one workgroup does the OHEM classification loss (log-softmax, counts,
+# radix select of the k-th smallest background log-prob instead of torch.sort/topk, both sums); the location loss is a row kernel + a
+# one-block finalize.  ~5 launches instead of ~60 tiny torch ops, and no memcpy nodes in the captured step.
+# --------------------------------------------------------------------------------------------------------------
+class LaneClsLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cls_targets, cls_preds, negative_ratio, alpha):
+        tgt = cls_targets.reshape(-1, 2).float().contiguous()
+        z = cls_preds.reshape(-1, 2).float().contiguous()
+        m = z.shape[0]
+        dev = z.device
+        lsm = torch.empty((m, 2), device=dev, dtype=F32)
+        pmask = torch.empty((m,), device=dev, dtype=torch.uint8)
+        out = torch.empty((2,), device=dev, dtype=F32)
+        aux = torch.empty((4,), device=dev, dtype=F32)
+        lib().call("hn_lane_cls_loss_fwd", ptr(z), ptr(tgt), m, float(negative_ratio), float(alpha), ptr(lsm), ptr(pmask), ptr(out), ptr(aux))
+        ctx.alpha, ctx.shape = float(alpha), cls_preds.shape
+        ctx.save_for_backward(lsm, pmask, aux)
+        ctx.mark_non_differentiable(pmask, aux)
+        return out[0], out[1], pmask, aux
+
+    @staticmethod
+    def backward(ctx, gpos, gneg, _gm, _ga):
+        lsm, pmask, aux = ctx.saved_tensors
+        m = lsm.shape[0]
+        dz = torch.empty((m, 2), device=lsm.device, dtype=F32)
+        gp = gpos.reshape(1).to(F32) if gpos is not None else zeros((1,), lsm.device)
+        gn = gneg.reshape(1).to(F32) if gneg is not None else zeros((1,), lsm.device)
+        lib().call("hn_lane_cls_loss_bwd", ptr(lsm), ptr(pmask), ptr(aux), ptr(gp), ptr(gn), ctx.alpha, m, ptr(dz))
+        return None, dz.view(ctx.shape), None, None
+
+
+class LaneLocLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pmask, aux, loc_targets, loc_preds, wcol, alpha):
+        L = loc_preds.shape[-1]
+        if wcol + 1 >= L:
+            raise IndexError(f"index {wcol + 1} is out of bounds for dimension 1 with size {L}")   # the reference's own failure mode
+        p = loc_preds.reshape(-1, L).float().contiguous()
+        t = loc_targets.reshape(-1, L).float().contiguous()
+        m = p.shape[0]
+        dev = p.device
+        rowloss = torch.empty((m,), device=dev, dtype=F32)
+        rownorm = torch.empty((m,), device=dev, dtype=F32)
+        out = torch.empty((1,), device=dev, dtype=F32)
+        lib().call("hn_lane_loc_loss_fwd", ptr(p), ptr(t), ptr(pmask), ptr(aux), m, L, int(wcol), float(alpha), ptr(rowloss), ptr(rownorm),
+                   ptr(out))
+        ctx.meta = (int(wcol), float(alpha), loc_preds.shape)
+        ctx.save_for_backward(p, t, pmask, rownorm, aux)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, gout):
+        p, t, pmask, rownorm, aux = ctx.saved_tensors
+        wcol, alpha, shape = ctx.meta
+        m, L = p.shape
+        dp = torch.empty((m, L), device=p.device, dtype=F32)
+        g = gout.reshape(1).to(F32)
+        lib().call("hn_lane_loc_loss_bwd", ptr(p), ptr(t), ptr(pmask), ptr(rownorm), ptr(aux), ptr(g), m, L, wcol, alpha, ptr(dp))
+        return None, None, None, dp.view(shape), None, None
+
+
+def lane_cls_loss_hip(cls_targets, cls_preds, negative_ratio=15, alpha=10.0):
+    """cal_loss_cls (lanedetect_loss.py:18-54): returns (pos, neg, pmask, positive_num) like the reference; pmask / positive_num are
+    device-side handles (byte mask, aux vector) consumed by lane_loc_loss_hip."""
+    pos, neg, pmask, aux = LaneClsLoss.apply(cls_targets, cls_preds, negative_ratio, alpha)
+    return pos, neg, pmask, aux
+
+
+def lane_loc_loss_hip(pmask, positive_num, loc_targets, loc_preds, alpha=10.0, points_per_line=160):
+    """cal_loss_regress (lanedetect_loss.py:57-78) incl. its hard-coded points_per_line = 160 default (x10 weights on columns 160/161)."""
+    return LaneLocLoss.apply(pmask, positive_num, loc_targets, loc_preds, points_per_line, alpha)
