@@ -28,11 +28,15 @@ def finite_report(tag):
     for k, v in net.state_dict().items():
         if v.is_floating_point() and not torch.isfinite(v).all(): bad.append(k)
     print(tag, "non-finite state entries:", bad[:5], len(bad), flush=True)
+grads = [p.grad for p in net.parameters() if p.grad is not None]
+def checksum():
+    return float(torch.stack(torch._foreach_norm(grads)).double().sum())
 for i in range(10):
     if mode == "sleep" and i == 3: time.sleep(2.0)
+    if i % 2 == 1: torch.cuda.synchronize()           # the trigger of the memset-node failure: a host sync between replays
     g.replay()
     v = float(static_loss.detach())
-    print(f"replay {i} t={time.time() - t0:.2f}s loss {v}", flush=True)
+    print(f"replay {i} t={time.time() - t0:.2f}s loss {v} grad-norm checksum {checksum():.10e}", flush=True)
     if v != v:
         finite_report("after NaN:")
         break
