@@ -13,11 +13,19 @@ net = HydraNet(cfgs).to(dev).train(); net.check_finite = False; net.lane_points_
 batch = bench.synthetic_batch(cfgs, n, h, w, 1, dev)
 def fwd_bwd():
     out = net(batch["image"]); ld = net.cal_loss(out, batch); loss = net.total_loss(ld); loss.backward(); return loss
+if os.environ.get("PROBE_NULLSTREAM"):
+    for _ in range(2):
+        net.zero_grad(set_to_none=True); fwd_bwd()
+    keep = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+    torch.cuda.synchronize()
 s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
 with torch.cuda.stream(s):
     for _ in range(2):
         net.zero_grad(set_to_none=True); fwd_bwd()
 torch.cuda.current_stream().wait_stream(s); torch.cuda.synchronize()
+if os.environ.get("PROBE_RELOAD"):
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    net.load_state_dict(state)
 net.zero_grad(set_to_none=True)
 g = torch.cuda.CUDAGraph()
 with torch.cuda.graph(g, capture_error_mode="thread_local"):
