@@ -226,6 +226,11 @@ int hn_lane_loc_loss_fwd(const float* pred, const float* target, const void* pma
                          float* rowloss, float* rownorm, float* out, hipStream_t stream);
 int hn_lane_loc_loss_bwd(const float* pred, const float* target, const void* pmask, const float* rownorm, const float* aux,
                          const float* gout, long M, int L, int wcol, float alpha, float* dpred, hipStream_t stream);
+/* Greedy NMS on the device for the detection post-process (head_detect/detection_loss.py:70-108; torchvision batched_nms semantics):
+ * boxes fp32 [K][4] (x1,y1,x2,y2) sorted by descending score with their class offsets added; suppress j > i when IoU > threshold, IoU in
+ * separately rounded fp32 ops (bit-identical decisions to the host path).  mask: hn_nms_mask_words(K) uint64 scratch; keep: K bytes. */
+long hn_nms_mask_words(int K);
+int hn_nms_sorted(const float* boxes, int K, float iou_threshold, void* mask, void* keep, hipStream_t stream);
 int hn_argmax_channels(const float* logits, int ldl, int C, long M, long* out, hipStream_t stream);
 
 #ifdef __cplusplus

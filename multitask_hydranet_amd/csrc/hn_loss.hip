@@ -627,3 +627,65 @@ extern "C" int hn_lane_loc_loss_bwd(const float* pred, const float* target, cons
                        rownorm, aux, gout, M, L, wcol, alpha, dpred);
     HN_LAUNCH_CHECK();
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Device NMS for the detection post-process (head_detect/detection_loss.py:70-108; torchvision.ops.batched_nms semantics restated in
+// postprocess.py): boxes are already sorted by descending score (stable) and carry their class offset.
+//   nms_mask_kernel: bit (i, j) of mask[i][j/64] = (j > i) and IoU(i, j) > thr, IoU = inter / (area_i + area_j - inter) in separately
+//                    rounded fp32 operations (no FMA contraction), so the comparisons are bit-identical to the numpy/torch host path;
+//   nms_scan_kernel: one wave walks the boxes in order, keeps box i unless an earlier kept box suppressed it (64-bit word per lane).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float iou_rn(const float4 a, const float4 b) {
+    const float area_a = __fmul_rn(__fsub_rn(a.z, a.x), __fsub_rn(a.w, a.y));
+    const float area_b = __fmul_rn(__fsub_rn(b.z, b.x), __fsub_rn(b.w, b.y));
+    float iw = __fsub_rn(fminf(a.z, b.z), fmaxf(a.x, b.x));
+    float ih = __fsub_rn(fminf(a.w, b.w), fmaxf(a.y, b.y));
+    iw = iw > 0.f ? iw : 0.f;
+    ih = ih > 0.f ? ih : 0.f;
+    const float inter = __fmul_rn(iw, ih);
+    return __fdiv_rn(inter, __fsub_rn(__fadd_rn(area_a, area_b), inter));
+}
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float4* boxes, int K, float thr, unsigned long long* mask, int words) {
+    const int i = blockIdx.y;                         // row box
+    const int wj = blockIdx.x;                        // 64-column word
+    const int j = wj * 64 + threadIdx.x;
+    bool sup = false;
+    if (j < K && j > i) sup = iou_rn(boxes[i], boxes[j]) > thr;
+    const unsigned long long bits = __ballot(sup);
+    if (threadIdx.x == 0) mask[(long)i * words + wj] = bits;
+}
+__global__ __launch_bounds__(64) void nms_scan_kernel(const unsigned long long* mask, int K, int words, unsigned char* keep) {
+    // lane l owns removed-words l, l+64, ...  (K <= 64 * 64 * NW)
+    constexpr int NW = 8;
+    unsigned long long removed[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) removed[w] = 0ull;
+    const int lane = threadIdx.x;
+    for (int i = 0; i < K; ++i) {
+        const int wi = i >> 6;
+        // is box i still alive?  its bit lives in word wi, owned by lane wi % 64, slot wi / 64
+        unsigned long long wv = 0ull;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) if ((wi >> 6) == w) wv = removed[w];
+        const unsigned long long word = __shfl(wv, wi & 63);
+        const bool alive = !((word >> (i & 63)) & 1ull);
+        if (lane == 0) keep[i] = alive ? 1 : 0;
+        if (alive) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const int ww = w * 64 + lane;
+                if (ww < words) removed[w] |= mask[(long)i * words + ww];
+            }
+        }
+    }
+}
+extern "C" long hn_nms_mask_words(int K) { return (long)K * ((K + 63) / 64); }
+/* boxes: fp32 [K][4] (x1, y1, x2, y2), sorted by descending score, class offsets already added; mask: hn_nms_mask_words(K) uint64;
+ * keep: K bytes (1 = kept).  K <= 32768. */
+extern "C" int hn_nms_sorted(const float* boxes, int K, float iou_threshold, void* mask, void* keep, hipStream_t st) {
+    HN_CHECK_ARG(boxes && mask && keep && K > 0 && K <= 32768);
+    const int words = (K + 63) / 64;
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(words, K), dim3(64), 0, st, (const float4*)boxes, K, iou_threshold, (unsigned long long*)mask, words);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 0, st, (const unsigned long long*)mask, K, words, (unsigned char*)keep);
+    HN_LAUNCH_CHECK();
+}

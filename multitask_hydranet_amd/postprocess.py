@@ -2,7 +2,8 @@
 greedy NMS.  Integer/index bookkeeping is bit-exact with the reference given identical fp inputs.  torchvision's batched_nms
 (unpinned third party in the reference) is restated from its published semantics: descending stable score order, suppress when
 IoU > threshold, IoU = inter / (a + b - inter), classes separated by a coordinate offset of class_id * (max_coord + 1).
-Round 1: host-side (torch) implementation over device tensors; the device kernel is a "next" row of SURVEY.md section 8(f)."""
+Decode / clip / threshold / sort are device tensor ops; the O(K^2) suppression runs in HIP kernels for CUDA inputs (nms_device, SURVEY.md
+section 8(f) row 1) and in numpy for CPU inputs (the form the CPU parity tests pin against the oracle)."""
 from __future__ import annotations
 
 import numpy as np
@@ -21,9 +22,23 @@ def decode_boxes(anchors: torch.Tensor, regression: torch.Tensor) -> torch.Tenso
     return torch.stack([xc - w / 2.0, yc - h / 2.0, xc + w / 2.0, yc + h / 2.0], dim=2)
 
 
+def nms_device(boxes: torch.Tensor, scores: torch.Tensor, thr: float) -> torch.Tensor:
+    """same contract as nms() with the O(K^2) part on the GPU (hn_nms_sorted: IoU bit-mask + one-wave scan); no host fallback"""
+    from ._lib import lib
+    order = torch.argsort(scores, descending=True, stable=True)
+    b = boxes[order].float().contiguous()
+    k = b.shape[0]
+    mask = torch.empty((lib().query("hn_nms_mask_words", k),), device=b.device, dtype=torch.int64)
+    keep = torch.empty((k,), device=b.device, dtype=torch.uint8)
+    lib().call("hn_nms_sorted", b.data_ptr(), k, float(thr), mask.data_ptr(), keep.data_ptr())
+    return order[keep.bool()]
+
+
 def nms(boxes: torch.Tensor, scores: torch.Tensor, thr: float) -> torch.Tensor:
     if boxes.numel() == 0:
         return torch.empty((0,), dtype=torch.int64, device=boxes.device)
+    if boxes.is_cuda and boxes.shape[0] <= 32768:
+        return nms_device(boxes, scores, thr)
     order = torch.argsort(scores, descending=True, stable=True)
     b = boxes[order].float().cpu().numpy()
     area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])

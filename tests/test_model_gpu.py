@@ -326,6 +326,12 @@ def test_deploy_mode_and_bit_exact_bookkeeping(env):
         np.testing.assert_allclose(np.asarray(o["rois"], np.float32), z[f"deploy/pp{i}/rois"], rtol=1e-6, atol=1e-5)
         total += len(o["class_ids"])
     assert total > 0
+    # the same post-process with every tensor on the device (device NMS kernels): identical kept boxes, classes, scores
+    dev = postprocess(hw, anc.cuda(), reg.cuda(), cls.cuda(), float(z["deploy/pp_thresh"]), 0.3)
+    for i, (o, d) in enumerate(zip(mine, dev)):
+        assert np.array_equal(np.asarray(d["class_ids"], np.int64), np.asarray(o["class_ids"], np.int64))
+        assert np.array_equal(np.asarray(d["scores"], np.float32), np.asarray(o["scores"], np.float32))
+        np.testing.assert_allclose(np.asarray(d["rois"], np.float32), np.asarray(o["rois"], np.float32), rtol=1e-6, atol=1e-5)
 
 
 @pytest.mark.gpu
