@@ -427,7 +427,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
 // 512 threads = 8 waves: WGC = BC/64 cout groups x (8/WGC) pixel-row groups; wave tile = 64 couts x (16/WGP rows x 16 px).
 // ---------------------------------------------------------------------------------------------------------
 template <int BC, bool OUT_F32>
-__global__ __launch_bounds__(512) void conv3x3_direct_kernel(const GemmNT p) {
+__global__ __launch_bounds__(512, (BC >= 128 ? 2 : 4)) void conv3x3_direct_kernel(const GemmNT p) {
+    // BC < 128: ONE patch buffer (57 KB of LDS instead of 98 KB) and <= 128 VGPRs -> two workgroups per CU cover each other's load /
+    // wait / MFMA phases; the patch of the next 64-channel chunk is then loaded after the last tap of the current one (one exposed
+    // round trip per chunk, and most of these launches have a single chunk).  BC = 128 keeps the double-buffered patch.
+    constexpr int XBUFS = BC >= 128 ? 2 : 1;
     constexpr int WCO = BC >= 64 ? 64 : BC;                           // couts per wave
     constexpr int WGC = BC / WCO, WGP = 8 / WGC, ROWS = 16 / WGP;     // rows of the patch per wave
     constexpr int TC = WCO / 16, TP = ROWS;
@@ -435,7 +439,7 @@ __global__ __launch_bounds__(512) void conv3x3_direct_kernel(const GemmNT p) {
     constexpr int XL = (PPIX * 8 + 511) / 512, WL = (BC * 8 + 511) / 512;
     extern __shared__ __attribute__((aligned(16))) char smem[];       // X patch x2 | W tile x2
     char* sXb = smem;
-    char* sWb = smem + 2 * XBYTES;
+    char* sWb = smem + XBUFS * XBYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wc = wave / WGP, wp = wave % WGP;
     const XSrc& xs = p.x;
@@ -497,9 +501,39 @@ __global__ __launch_bounds__(512) void conv3x3_direct_kernel(const GemmNT p) {
 
     // stage st = chunk * 9 + tap.  Iteration `it` issues the DMA of stage `it` (+ the X patch of its chunk when tap == 0) and multiplies
     // stage `it - 1`.
+    auto compute = [&](int st) {
+        const int chunk = st / 9, tap = st - chunk * 9;
+        const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+        const int dy = xs.mode == 2 ? ky : 2 - ky, dx = xs.mode == 2 ? kx : 2 - kx;
+        const char* sW = sWb + (st & 1) * WBYTES;
+        const char* sX = sXb + (XBUFS == 2 ? (chunk & 1) : 0) * XBYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[TC], b[TP];
+            const int piece = ks * 4 + (lane >> 4);
+#pragma unroll
+            for (int i = 0; i < TC; ++i) a[i] = *reinterpret_cast<const bf16x8*>(sW + swz(wc * WCO + i * 16 + (lane & 15), piece));
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                const int pidx = (wp * ROWS + j + dy) * 18 + (lane & 15) + dx;
+                b[j] = *reinterpret_cast<const bf16x8*>(sX + pidx * 128 + ((piece ^ (pidx & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int j = 0; j < TP; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    };
     for (int it = 0; it <= S; ++it) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        // single patch buffer: at a chunk boundary the last tap of the old chunk is multiplied BEFORE the new patch may overwrite it
+        const bool boundary = XBUFS == 1 && it > 0 && it < S && (it % 9) == 0;
+        if (boundary) {
+            compute(it - 1);
+            __syncthreads();
+        }
         if (it < S) {
             const int chunk = it / 9, tap = it - chunk * 9;
             const int k0 = chunk * 64;
@@ -512,7 +546,7 @@ __global__ __launch_bounds__(512) void conv3x3_direct_kernel(const GemmNT p) {
                 }
             }
             if (tap == 0) {
-                char* sX = sXb + (chunk & 1) * XBYTES;
+                char* sX = sXb + (XBUFS == 2 ? (chunk & 1) : 0) * XBYTES;
 #pragma unroll
                 for (int i = 0; i < XL; ++i) {
                     if (512 * i + 64 * wave < PPIX * 8) {             // wave-uniform: this 1 KiB run starts inside the patch
@@ -527,31 +561,7 @@ __global__ __launch_bounds__(512) void conv3x3_direct_kernel(const GemmNT p) {
                 }
             }
         }
-        if (it > 0) {
-            const int st = it - 1;
-            const int chunk = st / 9, tap = st - chunk * 9;
-            const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
-            const int dy = xs.mode == 2 ? ky : 2 - ky, dx = xs.mode == 2 ? kx : 2 - kx;
-            const char* sW = sWb + (st & 1) * WBYTES;
-            const char* sX = sXb + (chunk & 1) * XBYTES;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 a[TC], b[TP];
-                const int piece = ks * 4 + (lane >> 4);
-#pragma unroll
-                for (int i = 0; i < TC; ++i) a[i] = *reinterpret_cast<const bf16x8*>(sW + swz(wc * WCO + i * 16 + (lane & 15), piece));
-#pragma unroll
-                for (int j = 0; j < TP; ++j) {
-                    const int pidx = (wp * ROWS + j + dy) * 18 + (lane & 15) + dx;
-                    b[j] = *reinterpret_cast<const bf16x8*>(sX + pidx * 128 + ((piece ^ (pidx & 7)) << 4));
-                }
-#pragma unroll
-                for (int i = 0; i < TC; ++i)
-#pragma unroll
-                    for (int j = 0; j < TP; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-            }
-        }
+        if (it > 0 && !boundary) compute(it - 1);
     }
 
     // epilogue: bias, activation (one uniform branch for the whole wave tile), store 4 consecutive couts per lane
@@ -1147,7 +1157,7 @@ extern "C" int hn_conv_gemm_nt(const void* x0, const void* x1, int mode, int n_i
     if (mode >= 2 && !psum && !rpi) {
         const int bc = p.x.diag ? 64 : (Nout <= 16 ? 16 : (Nout <= 64 ? 64 : 128));
         dim3 grid((unsigned)(cdiv(Nout, bc) * cdiv(W, 16) * cdiv(H, 16) * n_img));
-        const size_t lds = 2 * (size_t)((18 * 18 * 128 + 1023) / 1024 * 1024) + 2 * (size_t)bc * 128;
+        const size_t lds = (bc >= 128 ? 2 : 1) * (size_t)((18 * 18 * 128 + 1023) / 1024 * 1024) + 2 * (size_t)bc * 128;
         // > 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel (done on the first, un-captured call)
         static bool optin = false;
         if (!optin) {
