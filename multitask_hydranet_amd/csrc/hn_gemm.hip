@@ -427,11 +427,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
 // 512 threads = 8 waves: WGC = BC/64 cout groups x (8/WGC) pixel-row groups; wave tile = 64 couts x (16/WGP rows x 16 px).
 // ---------------------------------------------------------------------------------------------------------
 template <int BC, bool OUT_F32>
-__global__ __launch_bounds__(512, (BC >= 128 ? 2 : 4)) void conv3x3_direct_kernel(const GemmNT p) {
+__global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) {
     // BC < 128: ONE patch buffer (57 KB of LDS instead of 98 KB) and <= 128 VGPRs -> two workgroups per CU cover each other's load /
     // wait / MFMA phases; the patch of the next 64-channel chunk is then loaded after the last tap of the current one (one exposed
     // round trip per chunk, and most of these launches have a single chunk).  BC = 128 keeps the double-buffered patch.
-    constexpr int XBUFS = BC >= 128 ? 2 : 1;
+    constexpr int XBUFS = 1;
     constexpr int WCO = BC >= 64 ? 64 : BC;                           // couts per wave
     constexpr int WGC = BC / WCO, WGP = 8 / WGC, ROWS = 16 / WGP;     // rows of the patch per wave
     constexpr int TC = WCO / 16, TP = ROWS;
@@ -564,9 +564,9 @@ __global__ __launch_bounds__(512, (BC >= 128 ? 2 : 4)) void conv3x3_direct_kerne
         if (it > 0 && !boundary) compute(it - 1);
     }
 
-    // epilogue: bias, activation (one uniform branch for the whole wave tile), store 4 consecutive couts per lane
+    // epilogue: bias, activation (one uniform branch per 4 values, in place on the accumulators: no second copy of the wave tile in
+    // registers), store 4 consecutive couts per lane
     const int ox = ox0 + (lane & 15);
-    float vv[TC * TP * 4];
 #pragma unroll
     for (int i = 0; i < TC; ++i) {
         const int co0 = c_blk + wc * WCO + i * 16 + (lane >> 4) * 4;
@@ -574,20 +574,14 @@ __global__ __launch_bounds__(512, (BC >= 128 ? 2 : 4)) void conv3x3_direct_kerne
 #pragma unroll
         for (int r = 0; r < 4; ++r) bsv[r] = (p.bias && co0 + r < p.Nout) ? p.bias[co0 + r] : 0.f;
 #pragma unroll
-        for (int j = 0; j < TP; ++j)
+        for (int j = 0; j < TP; ++j) {
+            const int oy = oy0 + wp * ROWS + j;
+            if (oy >= xs.H || ox >= xs.W) continue;
+            const long orow = ((long)(n * xs.H + oy) * xs.W + ox) * p.ldc;
+            float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) vv[(i * TP + j) * 4 + r] = acc[i][j][r] + bsv[r];
-    }
-    act_fwd_n(vv, p.act);
-#pragma unroll
-    for (int j = 0; j < TP; ++j) {
-        const int oy = oy0 + wp * ROWS + j;
-        if (oy >= xs.H || ox >= xs.W) continue;
-        const long orow = ((long)(n * xs.H + oy) * xs.W + ox) * p.ldc;
-#pragma unroll
-        for (int i = 0; i < TC; ++i) {
-            const int co0 = c_blk + wc * WCO + i * 16 + (lane >> 4) * 4;
-            const float* v = vv + (i * TP + j) * 4;
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bsv[r];
+            act_fwd_n(v, p.act);
             if (OUT_F32) {
                 float* o = reinterpret_cast<float*>(p.out) + orow + co0;
                 if (co0 + 3 < p.Nout && (reinterpret_cast<uintptr_t>(o) & 15) == 0) *reinterpret_cast<f32x4*>(o) = (f32x4){v[0], v[1], v[2], v[3]};
@@ -1157,7 +1151,7 @@ extern "C" int hn_conv_gemm_nt(const void* x0, const void* x1, int mode, int n_i
     if (mode >= 2 && !psum && !rpi) {
         const int bc = p.x.diag ? 64 : (Nout <= 16 ? 16 : (Nout <= 64 ? 64 : 128));
         dim3 grid((unsigned)(cdiv(Nout, bc) * cdiv(W, 16) * cdiv(H, 16) * n_img));
-        const size_t lds = (bc >= 128 ? 2 : 1) * (size_t)((18 * 18 * 128 + 1023) / 1024 * 1024) + 2 * (size_t)bc * 128;
+        const size_t lds = (size_t)((18 * 18 * 128 + 1023) / 1024 * 1024) + 2 * (size_t)bc * 128;
         // > 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel (done on the first, un-captured call)
         static bool optin = false;
         if (!optin) {
