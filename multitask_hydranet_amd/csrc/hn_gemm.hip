@@ -974,12 +974,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* part, f
 __global__ void gconv_diag_extract_kernel(const float* part, float* dw, int splits, int C) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= C * 72) return;
-    const int tap = idx % 9, i = (idx / 9) & 7, co = idx / 72;
+    const int i = idx & 7, tap = (idx >> 3) % 9, co = idx / 72;       // i fastest: 8 consecutive floats of a slab row per 8 lanes
     const long col = (long)co * 576 + tap * 64 + ((co & 63) >> 3) * 8 + i;
     const long slab = (long)C * 576;
     float s = 0.f;
+#pragma unroll 4
     for (int k = 0; k < splits; ++k) s += part[(long)k * slab + col];
-    dw[idx] = s;
+    dw[((long)co * 8 + i) * 9 + tap] = s;
 }
 // fp32 grouped weights [C][8][3][3] -> block-diagonal bf16 operands [C][9][64]: wk for the forward conv, wd for the stride-1 data
 // gradient (group-transposed, taps flipped)
@@ -1125,7 +1126,12 @@ static int pick_bc(int Nout) {
     return best;
 }
 
+// Few pixel rows x wide cout (the deep backbone stages: 2048...8192 rows, 376/936 channels): 64x64 tiles give >= 2 workgroups per CU,
+// which overlap each other's load / wait / MFMA phases (a 64x128 tiling leaves one workgroup per CU waiting on its own loads).
+static bool small_tile(long M, int Nout) { return !g_nt_force_bc && M <= 8192 && Nout >= 128; }
+
 extern "C" int hn_nt_stat_rows(long M, int Nout) {
+    if (small_tile(M, Nout)) return cdiv(M, 64) * 2;
     const int bc = pick_bc(Nout);
     if (bc == 16) return cdiv(M, 128) * 4;
     if (bc == 32) return cdiv(M, 128) * 4;
@@ -1172,6 +1178,7 @@ extern "C" int hn_conv_gemm_nt(const void* x0, const void* x1, int mode, int n_i
 #undef DIRECT_CASE
         HN_LAUNCH_CHECK();
     }
+    if (small_tile(M, Nout)) return launch_nt<64, 64, 2, 2, 4>(p, out_f32, st);
     switch (pick_bc(Nout)) {
         case 16: return launch_nt<16, 128, 1, 4, 2>(p, out_f32, st);
         case 32: return launch_nt<32, 128, 1, 4, 4>(p, out_f32, st);
