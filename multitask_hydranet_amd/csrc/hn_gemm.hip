@@ -1128,7 +1128,7 @@ static int pick_bc(int Nout) {
 
 // Few pixel rows x wide cout (the deep backbone stages: 2048...8192 rows, 376/936 channels): 64x64 tiles give >= 2 workgroups per CU,
 // which overlap each other's load / wait / MFMA phases (a 64x128 tiling leaves one workgroup per CU waiting on its own loads).
-static bool small_tile(long M, int Nout) { return !g_nt_force_bc && M <= 8192 && Nout >= 128; }
+static bool small_tile(long M, int Nout) { return !g_nt_force_bc && Nout > 64 && (M <= 8192 || (M <= 32768 && Nout <= 128)); }
 
 extern "C" int hn_nt_stat_rows(long M, int Nout) {
     if (small_tile(M, Nout)) return cdiv(M, 64) * 2;
