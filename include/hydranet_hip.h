@@ -100,6 +100,9 @@ int hn_dwconv_wgrad_levels(const void* x, int ldx, const void* dz, int ldz, floa
 int hn_maxpool_fwd(const void* in, int ldi, void* out, int ldo, int N, int H, int W, int C, int mode, hipStream_t stream);
 int hn_maxpool_bwd(const void* in, int ldi, const void* dout, int ldd, void* dx, int ldx, const float* wscale, int N, int H, int W, int C,
                    int mode, hipStream_t stream);
+/* two-pass form of the same backward (arg-max bytes of every window in arg_ws = N*(H/2)*(W/2)*C bytes, then a gather per input pixel) */
+int hn_maxpool_bwd2(const void* in, int ldi, const void* dout, int ldd, void* dx, int ldx, const float* wscale, void* arg_ws, int N, int H,
+                    int W, int C, int mode, hipStream_t stream);
 
 /* Nearest x2 up-sampling and its backward (F.interpolate / nn.Upsample, net/bifpn.py:43-46, head_lane/lanedetect.py:10-13). */
 int hn_up2_fwd(const void* in, int ldi, void* out, int ldo, int N, int H, int W, int C, hipStream_t stream);

@@ -493,6 +493,64 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const bf16* in, int ld
     }
 }
 
+// two-pass backward: (1) one thread per output window recomputes its arg-max (9 loads) and stores it as a byte per channel; (2) one thread
+// per input pixel visits its <= 4 windows and reads only their arg bytes and gradients (the one-pass kernel above re-reads 9 inputs per
+// window per pixel: 40 loads per pixel instead of ~8)
+__global__ __launch_bounds__(256) void maxpool_arg_kernel(const bf16* in, int ldi, unsigned char* arg, int N, int H, int W, int C, int mode) {
+    const int C8 = C >> 3, Ho = H >> 1, Wo = W >> 1;
+    const long total = (long)N * Ho * Wo * C8;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int cg = (int)(idx % C8);
+        long t = idx / C8;
+        const int ox = (int)(t % Wo);
+        t /= Wo;
+        const int oy = (int)(t % Ho);
+        const long n = t / Ho;
+        float best[8];
+        int a[8];
+        pool_window(in, ldi, n, H, W, oy, ox, cg * 8, mode, best, a);
+        unsigned long long packed = 0ull;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) packed |= (unsigned long long)(a[k] & 0xff) << (8 * k);
+        *reinterpret_cast<unsigned long long*>(arg + ((n * Ho + oy) * (long)Wo + ox) * C + cg * 8) = packed;
+    }
+}
+__global__ __launch_bounds__(256) void maxpool_bwd_arg_kernel(const unsigned char* arg, const bf16* dout, int ldd, bf16* dx, int ldx,
+                                                              const float* wscale, int N, int H, int W, int C, int mode) {
+    const int C8 = C >> 3, Ho = H >> 1, Wo = W >> 1;
+    const long total = (long)N * H * W * C8;
+    const float ws = wscale ? *wscale : 1.0f;
+    const int off = mode ? -1 : 0;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int cg = (int)(idx % C8);
+        long t = idx / C8;
+        const int ix = (int)(t % W);
+        t /= W;
+        const int iy = (int)(t % H);
+        const long n = t / H;
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+        for (int oy = (iy - off - 2 + 1) >> 1; 2 * oy + off <= iy; ++oy) {
+            if (oy < 0 || oy >= Ho) continue;
+            for (int ox = (ix - off - 2 + 1) >> 1; 2 * ox + off <= ix; ++ox) {
+                if (ox < 0 || ox >= Wo) continue;
+                const long wpix = (n * Ho + oy) * (long)Wo + ox;
+                const unsigned long long a = *reinterpret_cast<const unsigned long long*>(arg + wpix * C + cg * 8);
+                const int mine = (iy - 2 * oy - off) * 3 + (ix - 2 * ox - off);
+                const bf16x8 g = ld8(dout + wpix * ldd + cg * 8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if ((int)((a >> (8 * k)) & 0xff) == mine) acc[k] += bf2f(g[k]);
+            }
+        }
+        bf16x8 v;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = f2bf(acc[k] * ws);
+        st8(dx + ((n * H + iy) * (long)W + ix) * ldx + cg * 8, v);
+    }
+}
+
 // nearest x2 up-sampling (forward) and its backward (2x2 sum, optional device-side scale)
 __global__ __launch_bounds__(256) void up2_fwd_kernel(const bf16* in, int ldi, bf16* out, int ldo, int N, int H, int W, int C) {
     const int C8 = C >> 3, Ho = 2 * H, Wo = 2 * W;
@@ -948,6 +1006,16 @@ extern "C" int hn_maxpool_bwd(const void* in, int ldi, const void* dout, int ldd
                               int W, int C, int mode, hipStream_t st) {
     HN_CHECK_ARG(in && dout && dx && (C & 7) == 0 && ((ldi | ldd | ldx) & 7) == 0 && !(H & 1) && !(W & 1));
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid((long)N * H * W * (C >> 3))), dim3(256), 0, st, (const bf16*)in, ldi,
+                       (const bf16*)dout, ldd, (bf16*)dx, ldx, wscale, N, H, W, C, mode);
+    HN_LAUNCH_CHECK();
+}
+/* two-pass form: arg_ws = N*(H/2)*(W/2)*C bytes of scratch (arg-max of every window); same results as hn_maxpool_bwd */
+extern "C" int hn_maxpool_bwd2(const void* in, int ldi, const void* dout, int ldd, void* dx, int ldx, const float* wscale, void* arg_ws,
+                               int N, int H, int W, int C, int mode, hipStream_t st) {
+    HN_CHECK_ARG(in && dout && dx && arg_ws && (C & 7) == 0 && ((ldi | ldd | ldx) & 7) == 0 && !(H & 1) && !(W & 1));
+    hipLaunchKernelGGL(maxpool_arg_kernel, dim3(ew_grid((long)N * (H >> 1) * (W >> 1) * (C >> 3))), dim3(256), 0, st, (const bf16*)in, ldi,
+                       (unsigned char*)arg_ws, N, H, W, C, mode);
+    hipLaunchKernelGGL(maxpool_bwd_arg_kernel, dim3(ew_grid((long)N * H * W * (C >> 3))), dim3(256), 0, st, (const unsigned char*)arg_ws,
                        (const bf16*)dout, ldd, (bf16*)dx, ldx, wscale, N, H, W, C, mode);
     HN_LAUNCH_CHECK();
 }

@@ -520,7 +520,8 @@ def k_maxpool(x, mode, out=None):
 def k_maxpool_bwd(x, dout, mode, wscale=None):
     n, h, w, c = x.shape
     dx = new_act(n, h, w, c, x.device)
-    lib().call("hn_maxpool_bwd", ptr(x), ld(x), ptr(dout), ld(dout), ptr(dx), ld(dx), ptr(wscale), n, h, w, c, mode)
+    arg = torch.empty((n * (h // 2) * (w // 2) * c,), device=x.device, dtype=torch.uint8)
+    lib().call("hn_maxpool_bwd2", ptr(x), ld(x), ptr(dout), ld(dout), ptr(dx), ld(dx), ptr(wscale), ptr(arg), n, h, w, c, mode)
     return dx
 
 
