@@ -30,7 +30,10 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* x, const flo
     float acc[32];
 #pragma unroll
     for (int c = 0; c < 32; ++c) acc[c] = 0.f;
-    bf16* prow = patches ? patches + idx * 32 : nullptr;      // im2col row (27 taps + 5 zeros) kept in bf16 for the MFMA wgrad
+    // im2col row (27 taps + 5 zeros) kept in bf16 for the MFMA wgrad: staged in LDS (2-byte writes are cheap there) and written out as
+    // four 16-byte stores per pixel instead of 27 two-byte global stores
+    __shared__ __attribute__((aligned(16))) bf16 sp[256][40];
+    bf16* prow = patches ? sp[threadIdx.x] : nullptr;
 #pragma unroll 1
     for (int t = 0; t < 9; ++t) {                  // t = ci*3 + ky ; kept rolled so the 864 weights are not hoisted
         const int ci = t / 3, ky = t - ci * 3;
@@ -49,6 +52,9 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* x, const flo
     if (prow) {
 #pragma unroll
         for (int t = 27; t < 32; ++t) prow[t] = f2bf(0.f);
+        bf16* pg = patches + idx * 32;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) st8(pg + q * 8, ld8(prow + q * 8));     // own row: no barrier needed
     }
     bf16* o = z + idx * 32;
 #pragma unroll
