@@ -89,7 +89,8 @@ int hn_dwconv_fwd(const void* in, int ldi, const void* wk, void* out, int ldo, i
  * same SeparableConvBlock to every level, head_detect/detection.py:30-35,67-72) */
 int hn_dwconv_fwd_levels(const void* in, int ldi, const void* wk, void* out, int ldo, int N, int C, int nlev, const int* H, const int* W,
                          hipStream_t stream);
-long hn_dwconv_wgrad_blocks(long pixels, int C);
+/* partial rows of hn_dwconv_wgrad*: strips = sum over levels of N * H * ceil(W / 4) (the kernel walks 4-pixel strips) */
+long hn_dwconv_wgrad_blocks(long strips, int C);
 int hn_dwconv_wgrad(const void* x, int ldx, const void* dz, int ldz, float* part, int N, int H, int W, int C, hipStream_t stream);
 /* level-packed: part is fp32 [hn_dwconv_wgrad_blocks(total pixels, C)][C*9] */
 int hn_dwconv_wgrad_levels(const void* x, int ldx, const void* dz, int ldz, float* part, int N, int C, int nlev, const int* H, const int* W,

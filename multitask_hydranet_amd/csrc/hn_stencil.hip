@@ -329,59 +329,74 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const bf16* in, int ldi
 }
 
 // wgrad partials: part[block][c*9 + tap] = sum over the block's pixels of dz[pix][c] * x[pix + tap - 1][c].
-// A block = (C/8 channel groups) x (256 / (C/8) pixel lanes); every lane walks `ppl` consecutive pixels, then the lanes are summed
-// through LDS (three rounds of 24 accumulators) so that one partial row per block leaves the chip.
+// A block = (C/8 channel groups) x (256 / (C/8) lanes); every lane walks `spl` consecutive 4-pixel strips (global strip index over all
+// packed levels): per strip the 3x6 input window (18 loads) and 4 gradients serve 36 tap products -- 5.5 loads per pixel instead of 10.
+// Window elements outside the image read a clamped address and are masked to zero.  The lanes are then summed through LDS (three rounds
+// of 24 accumulators) so that one partial row per block leaves the chip.
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const bf16* x, int ldx, const bf16* dz, int ldz, float* part, int N, int C,
-                                                           int ppl, const Levels L) {
+                                                           int spl, const Levels L) {
     __shared__ float red[256][25];
     const int C8 = C >> 3;
     const int lanes = 256 / C8;
     const int tid = threadIdx.x;
     const int cg = tid % C8, lane = tid / C8;
     const bool active = lane < lanes;
-    const long total = L.row_off[L.n];
-    const long p0 = ((long)blockIdx.x * lanes + lane) * ppl;
-    long p1 = p0 + ppl;
-    if (p1 > total) p1 = total;
+    const long total = L.work_off[L.n];                               // strips
+    const long s0 = ((long)blockIdx.x * lanes + lane) * spl;
+    long s1 = s0 + spl;
+    if (s1 > total) s1 = total;
     float acc[9][8];
 #pragma unroll
     for (int tq = 0; tq < 9; ++tq)
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[tq][k] = 0.f;
     if (active) {
-        int lv = level_of_row(L, p0);
-        for (long pix = p0; pix < p1; ++pix) {
-            while (lv + 1 < L.n && pix >= L.row_off[lv + 1]) ++lv;
-            const int H = L.H[lv], W = L.W[lv];
-            const long lp = pix - L.row_off[lv];
-            const int ox = (int)(lp % W);
-            const long t1 = lp / W;
+        int lv = 0;
+        for (long sidx = s0; sidx < s1; ++sidx) {
+            while (lv + 1 < L.n && sidx >= L.work_off[lv + 1]) ++lv;
+            const int H = L.H[lv], W = L.W[lv], strips = (W + 3) >> 2;
+            const long ls = sidx - L.work_off[lv];
+            const int sx = (int)(ls % strips);
+            const long t1 = ls / strips;
             const int oy = (int)(t1 % H);
             const long n = t1 / H;
+            const int ox0 = sx * 4;
             const bf16* xl = x + L.row_off[lv] * ldx;
-            // all ten loads of a pixel are issued before the first FMA: border taps read a clamped address and are masked to zero
-            const bf16x8 zv = ld8(dz + pix * ldz + cg * 8);
-            bf16x8 xv[9];
-            float msk[9];
+            const bf16* zl = dz + L.row_off[lv] * ldz;
+            bf16x8 xw[3][6], zv[4];
+            float xm[3][6], zm[4];
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const int iy = oy + ky - 1;
+            for (int r = 0; r < 3; ++r) {
+                const int iy = oy + r - 1;
                 const int iyc = iy < 0 ? 0 : (iy >= H ? H - 1 : iy);
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int ix = ox + kx - 1;
+                for (int c = 0; c < 6; ++c) {
+                    const int ix = ox0 + c - 1;
                     const int ixc = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
-                    msk[ky * 3 + kx] = (iy == iyc && ix == ixc) ? 1.f : 0.f;
-                    xv[ky * 3 + kx] = ld8(xl + ((n * H + iyc) * (long)W + ixc) * ldx + cg * 8);
+                    xm[r][c] = (iy == iyc && ix == ixc) ? 1.f : 0.f;
+                    xw[r][c] = ld8(xl + ((n * H + iyc) * (long)W + ixc) * ldx + cg * 8);
                 }
             }
-            float zf[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) zf[k] = bf2f(zv[k]);
+            for (int p = 0; p < 4; ++p) {
+                const int ox = ox0 + p;
+                zm[p] = ox < W ? 1.f : 0.f;
+                zv[p] = ld8(zl + ((n * H + oy) * (long)W + (ox < W ? ox : W - 1)) * ldz + cg * 8);
+            }
 #pragma unroll
-            for (int tq = 0; tq < 9; ++tq)
+            for (int p = 0; p < 4; ++p) {
+                float zf[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) acc[tq][k] = fmaf(zf[k] * msk[tq], bf2f(xv[tq][k]), acc[tq][k]);
+                for (int k = 0; k < 8; ++k) zf[k] = bf2f(zv[p][k]) * zm[p];
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float m = xm[ky][p + kx];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) acc[ky * 3 + kx][k] = fmaf(zf[k] * m, bf2f(xw[ky][p + kx][k]), acc[ky * 3 + kx][k]);
+                    }
+            }
         }
     }
     float* dst = part + (long)blockIdx.x * C * 9;
@@ -975,19 +990,23 @@ extern "C" int hn_dwconv_fwd_levels(const void* in, int ldi, const void* wk, voi
     return rc != HN_OK ? rc : dwconv_fwd_launch(in, ldi, wk, out, ldo, N, C, L, st);
 }
 // number of partial rows (= blocks) of hn_dwconv_wgrad; part is fp32 [blocks][C*9], reduce with hn_rows_reduce(part, dw, 1, blocks, C*9, 1)
-extern "C" long hn_dwconv_wgrad_blocks(long pixels, int C) {
+// partial rows (= blocks) of hn_dwconv_wgrad* for `strips` = sum over levels of N * H * ceil(W / 4) four-pixel strips; part is fp32
+// [blocks][C*9], reduce with hn_rows_reduce(part, dw, 1, blocks, C*9, 1)
+extern "C" long hn_dwconv_wgrad_blocks(long strips, int C) {
     const int lanes = 256 / (C >> 3);
-    long ppl = (pixels + 2047L * lanes) / (2048L * lanes);       // aim for ~2048 blocks
-    if (ppl < 4) ppl = 4;
-    return (pixels + ppl * lanes - 1) / (ppl * lanes);
+    long spl = (strips + 2047L * lanes) / (2048L * lanes);       // aim for ~2048 blocks
+    if (spl < 2) spl = 2;
+    return (strips + spl * lanes - 1) / (spl * lanes);
 }
-static int dwconv_wgrad_launch(const void* x, int ldx, const void* dz, int ldz, float* part, int N, int C, const Levels& L, hipStream_t st) {
+static int dwconv_wgrad_launch(const void* x, int ldx, const void* dz, int ldz, float* part, int N, int C, Levels& L, hipStream_t st) {
     HN_CHECK_ARG(x && dz && part && (C & 7) == 0 && C <= 2048 && ((ldx | ldz) & 7) == 0);
-    const long pixels = L.row_off[L.n];
+    L.work_off[0] = 0;
+    for (int l = 0; l < L.n; ++l) L.work_off[l + 1] = L.work_off[l] + (long)N * L.H[l] * ((L.W[l] + 3) >> 2);
+    const long strips = L.work_off[L.n];
     const int lanes = 256 / (C >> 3);
-    const long blocks = hn_dwconv_wgrad_blocks(pixels, C);
-    const int ppl = (int)((pixels + blocks * lanes - 1) / (blocks * lanes));
-    hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3(blocks), dim3(256), 0, st, (const bf16*)x, ldx, (const bf16*)dz, ldz, part, N, C, ppl, L);
+    const long blocks = hn_dwconv_wgrad_blocks(strips, C);
+    const int spl = (int)((strips + blocks * lanes - 1) / (blocks * lanes));
+    hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3(blocks), dim3(256), 0, st, (const bf16*)x, ldx, (const bf16*)dz, ldz, part, N, C, spl, L);
     HN_LAUNCH_CHECK();
 }
 extern "C" int hn_dwconv_wgrad(const void* x, int ldx, const void* dz, int ldz, float* part, int N, int H, int W, int C, hipStream_t st) {

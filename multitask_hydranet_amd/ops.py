@@ -485,7 +485,7 @@ def k_dwconv(x, wk, out=None):
 
 def k_dwconv_wgrad(x, dz):
     n, h, w, c = x.shape
-    chunks = lib().query("hn_dwconv_wgrad_blocks", n * h * w, c)
+    chunks = lib().query("hn_dwconv_wgrad_blocks", n * h * ((w + 3) // 4), c)
     part = torch.empty((chunks, c * 9), device=x.device, dtype=F32)
     lib().call("hn_dwconv_wgrad", ptr(x), ld(x), ptr(dz), ld(dz), ptr(part), n, h, w, c)
     return k_rows_reduce(part, 1, chunks, c * 9).view(c, 1, 3, 3)
@@ -891,7 +891,7 @@ def k_dwconv_levels(x, wk, geom):
 def k_dwconv_wgrad_levels(x, dz, geom):
     nl, H, W, _ = _geom_arrays(geom)
     c = x.shape[3]
-    chunks = lib().query("hn_dwconv_wgrad_blocks", x.shape[2], c)
+    chunks = lib().query("hn_dwconv_wgrad_blocks", sum(geom[0] * hh * ((ww + 3) // 4) for hh, ww in zip(geom[1], geom[2])), c)
     part = torch.empty((chunks, c * 9), device=x.device, dtype=F32)
     lib().call("hn_dwconv_wgrad_levels", ptr(x), ld(x), ptr(dz), ld(dz), ptr(part), geom[0], c, nl, ctypes.addressof(H), ctypes.addressof(W))
     return k_rows_reduce(part, 1, chunks, c * 9).view(c, 1, 3, 3)
