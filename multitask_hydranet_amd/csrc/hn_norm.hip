@@ -466,18 +466,22 @@ struct FinLevels {
 };
 template <bool BWD>
 __global__ __launch_bounds__(1024) void bn_finalize_levels_kernel(const FinLevels p) {
-    __shared__ double r1[32][33], r2[32][33];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + tx, lv = blockIdx.y;
+    // block = 8 channels x 128 row lanes: level 0 of the det towers has 2048 partial rows (16 per lane)
+    __shared__ double r1[128][9], r2[128][9];
+    const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + tx, lv = blockIdx.y;
     const long rb = p.sg.row_off[lv] / p.div, re = p.sg.row_off[lv + 1] / p.div;
     double s1 = 0.0, s2 = 0.0;
     if (c < p.C)
-        for (long r = rb + ty; r < re; r += 32) { s1 += p.p1[r * p.C + c]; s2 += p.p2[r * p.C + c]; }
+        for (long r = rb + ty; r < re; r += 128) { s1 += p.p1[r * p.C + c]; s2 += p.p2[r * p.C + c]; }
     r1[ty][tx] = s1; r2[ty][tx] = s2;
     __syncthreads();
+    for (int st = 64; st > 0; st >>= 1) {
+        if (ty < st) { r1[ty][tx] += r1[ty + st][tx]; r2[ty][tx] += r2[ty + st][tx]; }
+        __syncthreads();
+    }
     if (ty == 0 && c < p.C) {
-#pragma unroll
-        for (int k = 1; k < 32; ++k) { s1 += r1[k][tx]; s2 += r2[k][tx]; }
+        s1 = r1[0][tx]; s2 = r2[0][tx];
         const double count = (double)p.count[lv];
         if (!BWD) {
             float* coef = p.out + (long)lv * 4 * p.C;
@@ -903,7 +907,7 @@ extern "C" int hn_bn_finalize_levels(const float* psum, const float* psq, int di
         p.rm[l] = running_mean ? (float*)running_mean[l] : nullptr;
         p.rv[l] = running_var ? (float*)running_var[l] : nullptr;
     }
-    hipLaunchKernelGGL(bn_finalize_levels_kernel<false>, dim3(cdiv(C, 32), nlev), dim3(1024), 0, st, p);
+    hipLaunchKernelGGL(bn_finalize_levels_kernel<false>, dim3(cdiv(C, 8), nlev), dim3(1024), 0, st, p);
     HN_LAUNCH_CHECK();
 }
 /* red out: [nlev][2][C] = mean(g), mean(g*xhat); dgamma/dbeta: per-level fp32 [C] */
@@ -918,7 +922,7 @@ extern "C" int hn_bn_bwd_finalize_levels(const float* pg, const float* pgx, int 
         HN_CHECK_ARG(dgamma[l] && dbeta[l]);
         p.dgamma[l] = (float*)dgamma[l]; p.dbeta[l] = (float*)dbeta[l];
     }
-    hipLaunchKernelGGL(bn_finalize_levels_kernel<true>, dim3(cdiv(C, 32), nlev), dim3(1024), 0, st, p);
+    hipLaunchKernelGGL(bn_finalize_levels_kernel<true>, dim3(cdiv(C, 8), nlev), dim3(1024), 0, st, p);
     HN_LAUNCH_CHECK();
 }
 
