@@ -1228,7 +1228,7 @@ extern "C" int hn_wgrad_plan(int mode, int n_img, int H, int W, long M, int Nout
         if (grouped) { bc = 64; ci = 64; ksplit = 2; }
         const long tiles = (long)cdiv(Nout, bc) * cdiv(KP, ci);
         const long patches = (long)n_img * cdiv(H, 8) * cdiv(W, 16);
-        long want = (768 + tiles - 1) / tiles;
+        long want = (256 + tiles - 1) / tiles;          // one workgroup per CU in total: every split costs a full fp32 slab of dW (write + reduce)
         if (want > patches / 2) want = patches / 2;
         if (want < 1) want = 1;
         const long pps = (patches + want - 1) / want;
