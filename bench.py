@@ -242,9 +242,11 @@ def main():
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 static_loss = fwd_bwd()
             if reducer is not None:
-                reducer = GradReducer(list(net.named_parameters()), world_size=world, skip=UNUSED_5STAGE if len(net.depths) == 5 else ())
+                # after a replay nothing is left to overlap with: ONE flat bucket = one gather + one all-reduce for all 693 gradients
+                reducer = GradReducer(list(net.named_parameters()), world_size=world, bucket_bytes=1 << 40,
+                                      skip=UNUSED_5STAGE if len(net.depths) == 5 else ())
                 reducer.remove()
-                reducer.bind_static_grads()         # every replay rewrites these tensors; reduce_now() gathers them into the buckets
+                reducer.bind_static_grads()         # every replay rewrites these tensors; reduce_now() gathers them into the bucket
         except Exception as e:                      # noqa: BLE001
             if rank == 0:
                 import traceback

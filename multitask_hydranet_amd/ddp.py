@@ -42,6 +42,9 @@ class GradReducer:
         if use_side_stream is None:
             use_side_stream = self.on_gpu
         self.stream = torch.cuda.Stream(device=dev) if (self.on_gpu and use_side_stream) else None
+        # RCCL averages in the collective itself (ncclAvg): no separate scaling pass over the 171 MB of gradients.  Falls back to
+        # SUM + scale on the first failure and for backends without AVG (gloo).
+        self._avg = self.on_gpu and dist.is_initialized() and dist.get_backend(group) == "nccl"
         self._hooks = []
         for bi, b in enumerate(self.buckets):
             for n, p in b["params"]:
@@ -77,13 +80,22 @@ class GradReducer:
             ev.record(torch.cuda.current_stream())
             self.stream.wait_event(ev)
             with torch.cuda.stream(self.stream):
-                dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group)
-                b["flat"].mul_(1.0 / self.world)
+                self._allreduce_mean(b["flat"])
                 done = torch.cuda.Event()
                 done.record(self.stream)
             b["event"] = done
         else:
             b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _allreduce_mean(self, flat):
+        if self._avg:
+            try:
+                dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
+                return
+            except Exception:                   # noqa: BLE001  (an RCCL build without ncclAvg)
+                self._avg = False
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        flat.mul_(1.0 / self.world)
 
     def finish(self):
         """call after loss.backward(): waits for every bucket and re-arms the hooks for the next step."""
