@@ -131,7 +131,7 @@ class HydraNet(nn.Module):
         self._declare_neck(spec)
         if self.train_detect:
             self._declare_det(spec)
-            self.loss_detect = lambda c, r, a, g: (K.det_loss_hip if c.is_cuda else L.det_loss)(c, r, a, g)
+            self.loss_detect = K.det_loss_hip            # HIP only (losses.det_loss is the torch form the tests use as a reference)
         else:
             self.detectheader, self.loss_detect = None, None
         if self.train_seg:
@@ -542,9 +542,9 @@ class HydraNet(nn.Module):
         """CrossEntropyLoss.forward (head_seg/segmentation_loss.py:27-65): HIP kernels for the weighted-CE / top-k path of the shipped
         big cfgs; the focal variant of the small cfg is a handful of elementwise torch ops (not on the benchmarked path)."""
         use_top_k, ratio, use_focal = self._seg_cfg
-        if use_focal or not logits.is_cuda:
+        if use_focal:                                   # small-cfg variant (a few elementwise device ops on the HIP logits), not benchmarked
             return L.seg_loss(logits, target, self._seg_class_weight, use_top_k, ratio, use_focal)
-        return K.seg_loss_hip(logits, target, self._seg_class_weight, use_top_k, ratio)
+        return K.seg_loss_hip(logits, target, self._seg_class_weight, use_top_k, ratio)      # no CPU fallback: raises off-device
 
     def _guard(self, value, what, allow_zero=False):
         if self.check_finite and ((not allow_zero and value == 0) or not torch.isfinite(value)):
