@@ -71,25 +71,61 @@ __global__ __launch_bounds__(256) void seg_hist_kernel(const float* loss, long H
         if (sh[i]) atomicAdd(&hist[(long)n * 2048 + i], sh[i]);
 }
 
-// one block per image: walk the histogram from the top bin down until the remaining rank falls inside a bin; fix that bin's bits
+// one wave per image: find the bin (from the top) in which the remaining rank falls and fix that bin's bits.  The 2048 bins are staged in
+// LDS, every lane sums its contiguous chunk, a wave suffix-scan locates the chunk and its lane walks at most 32 bins (a single thread
+// walking 2048 dependent global loads took 60 us).  Semantics of the serial walk: b runs from the top bin down to 1 and stops at the first
+// bin with h[b] >= need, otherwise need -= h[b]; b = 0 if no bin stops it.
 __global__ __launch_bounds__(64) void seg_select_kernel(unsigned int* hist, SelState* st, int level, unsigned int k) {
-    const int n = blockIdx.x;
-    if (threadIdx.x == 0) {
-        unsigned int* h = hist + (long)n * 2048;
-        unsigned int need = level == 0 ? k : st[n].remaining;
-        const int bins = level == 2 ? 1024 : 2048;
-        int b = bins - 1;
-        for (; b > 0; --b) {
-            if (h[b] >= need) break;
-            need -= h[b];
+    __shared__ unsigned int sh[2048];
+    __shared__ int s_b;
+    __shared__ unsigned int s_need;
+    const int n = blockIdx.x, lane = threadIdx.x;
+    unsigned int* h = hist + (long)n * 2048;
+    const int bins = level == 2 ? 1024 : 2048;
+    const int per = bins / 64;
+    for (int i = lane; i < bins; i += 64) sh[i] = h[i];
+    const unsigned int need0 = level == 0 ? k : st[n].remaining;
+    if (lane == 0) { s_b = 0; s_need = 0; }
+    __syncthreads();
+    unsigned int local = 0;
+    for (int j = 0; j < per; ++j) {
+        const int b = lane * per + j;
+        if (b >= 1) local += sh[b];                                   // bin 0 never stops the walk, it only receives what is left
+    }
+    // above = sum of the chunks of all higher lanes (inclusive suffix scan minus own)
+    unsigned int suf = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned int v = __shfl_down(suf, o);
+        if (lane + o < 64) suf += v;
+    }
+    const unsigned int above = suf - local;
+    // the walk stops inside this lane's chunk iff above < need0 <= above + local  (cumulative count from the top reaches need0 here)
+    const bool mine = above < need0 && need0 <= above + local;
+    if (mine) {
+        unsigned int need = need0 - above;
+        int b = lane * per + per - 1;
+        for (; b > lane * per && b > 0; --b) {
+            if (sh[b] >= need) break;
+            need -= sh[b];
         }
-        const int shift = level == 0 ? 21 : (level == 1 ? 10 : 0);
-        const unsigned int prefix = (level == 0 ? 0u : st[n].prefix) | ((unsigned int)b << shift);
-        st[n].prefix = prefix;
-        st[n].remaining = need;                        // elements of bin b (at this resolution) that still belong to the top-k
+        // b is now either the stopping bin or the lowest bin of the chunk (which must stop the walk because the chunk total reaches need)
+        s_b = b;
+        s_need = need;
+    }
+    const unsigned long long any = __ballot(mine);
+    if (!any && lane == 0) {                                          // fewer than need0 elements above bin 0: the walk ends at b = 0
+        s_b = 0;
+        s_need = need0 - suf;                                         // lane 0's inclusive suffix = everything in bins >= 1
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2048; i += 64) hist[(long)n * 2048 + i] = 0;     // ready for the next level
+    if (lane == 0) {
+        const int shift = level == 0 ? 21 : (level == 1 ? 10 : 0);
+        const unsigned int prefix = (level == 0 ? 0u : st[n].prefix) | ((unsigned int)s_b << shift);
+        st[n].prefix = prefix;
+        st[n].remaining = s_need;                      // elements of bin b (at this resolution) that still belong to the top-k
+    }
+    for (int i = lane; i < 2048; i += 64) h[i] = 0;                   // ready for the next level
 }
 
 // per image: sum of the losses strictly above the threshold (partial sums per block); the `remaining` ties at the threshold are added
