@@ -244,3 +244,28 @@ def test_fullsize_step_deterministic_and_graph_equals_eager(big):
         assert float(gl) == runs[0][0]
         for k in runs[0][1]:
             assert torch.equal(ggrads[k], runs[0][1][k]), k
+
+
+def test_fullsize_eval_deploy_packed_equals_per_level(big):
+    """eval-mode (running-statistics BatchNorm) deploy forward at N = 16: the level-packed det towers reproduce the per-level path, the
+    6-tuple has the reference's shapes and the seg mask is the arg-max of the logits"""
+    net, cfgs, O = big
+    import bench
+    batch = bench.synthetic_batch(cfgs, 16, H, W, seed=9, device="cuda:0")
+    net.eval()
+    try:
+        outs = {}
+        with torch.no_grad():
+            for packed in (True, False):
+                net.pack_det_levels = packed
+                outs[packed] = net(batch["image"], "deploy")
+    finally:
+        net.pack_det_levels = True
+        net.train()
+    a, b = outs[True], outs[False]
+    assert len(a) == 6 and a[0].dtype == torch.int64 and tuple(a[0].shape) == (16, H, W)
+    assert torch.equal(a[0], b[0])                                   # seg masks identical (same kernels)
+    assert torch.equal(a[1], b[1])                                   # anchors
+    assert rel(a[2], b[2]) <= 1e-2 and rel(a[3], b[3]) <= 1e-2       # regression / classification: same arithmetic, eval-mode BN
+    assert a[2].shape == (16, 98208, 4) and a[3].shape == (16, 98208, 9)
+    assert a[4].shape == (16, (H // 32) * (W // 32), 2) and a[5].shape[2] == 2 * (H // 8) + 2
