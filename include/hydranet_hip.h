@@ -41,7 +41,8 @@ int hn_pack_weights_batched(const long* jobs, int njobs, long total_blocks, hipS
  *           PADDED sizes); fold back with hn_seg_fold.
  *   mode 4: mode 2 with replicate (clamp) padding, no up-sampling / concat: the low-resolution form of a 3x3 reflect-pad conv over a
  *           nearest-x2 up-sampled map (reflection of the up-sampled index == clamping of the source index); used with 4-phase
- *           effective weights for the final seg conv (head_seg/segmentation.py:101-104), see hn_depth_to_space.
+ *           effective weights for the final seg conv (head_seg/segmentation.py:101-104), see hn_depth_to_space.  With out_f32 and
+ *           img_stride = -k (k = Nout / 4) the epilogue stores depth-to-space itself: out is fp32 [N][2H][2W][k].
  *   mode 5: grouped 3x3 conv, group width 8, stride 1, zero padding 1 (XBlock conv_block_2, net/anynet.py:34-38) on MFMA: cout tile t
  *           (64 couts = 8 groups) contracts only over input channels [64t, 64t+64) with block-diagonal weights from
  *           hn_gconv_pack_diag (w = wk for the forward, wd for the data gradient); Nout == C0, KP == 64, no statistics.

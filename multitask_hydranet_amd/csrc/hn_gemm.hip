@@ -132,6 +132,8 @@ struct GemmNT {
     float* psq;
     long rpi;        // rows per image for the per-image output mapping below (0 = plain pix*ldc)
     long img_stride; // out offset(pix) = (pix / rpi) * img_stride + (pix % rpi) * ldc  (det-head level concat)
+    int d2s;         // direct 3x3 kernel, fp32 out: cout c = phase*d2s + o is stored depth-to-space, out[n][2y+phase/2][2x+phase%2][o]
+                     // with d2s channels per output pixel (the 4-phase final seg conv writes the logits in place, no shuffle pass)
 };
 
 template <int BC, int BP, int WGC, int WGP, bool OUT_F32, int R>
@@ -582,7 +584,17 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bsv[r];
             act_fwd_n(v, p.act);
-            if (OUT_F32) {
+            if (OUT_F32 && p.d2s) {
+                float* ob = reinterpret_cast<float*>(p.out);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = co0 + r;
+                    if (c < p.Nout) {
+                        const int ph = c / p.d2s, oc = c - ph * p.d2s;
+                        ob[((long)(n * 2 * xs.H + 2 * oy + (ph >> 1)) * (2 * xs.W) + 2 * ox + (ph & 1)) * p.d2s + oc] = v[r];
+                    }
+                }
+            } else if (OUT_F32) {
                 float* o = reinterpret_cast<float*>(p.out) + orow + co0;
                 if (co0 + 3 < p.Nout && (reinterpret_cast<uintptr_t>(o) & 15) == 0) *reinterpret_cast<f32x4*>(o) = (f32x4){v[0], v[1], v[2], v[3]};
                 else {
@@ -1154,6 +1166,12 @@ extern "C" int hn_conv_gemm_nt(const void* x0, const void* x1, int mode, int n_i
     p.w = (const bf16*)w; p.Nout = Nout; p.KP = KP; p.taps = taps;
     p.bias = bias; p.act = act; p.out = out; p.ldc = ldc; p.psum = psum; p.psq = psq;
     p.rpi = rpi; p.img_stride = img_stride;
+    p.d2s = 0;
+    if (img_stride < 0) {                                            // mode 4 + fp32 out: -img_stride = channels per depth-to-space output pixel
+        HN_CHECK_ARG(p.x.clamp == 1 && out_f32 && rpi == 0 && !psum && Nout == 4 * (int)(-img_stride));
+        p.d2s = (int)(-img_stride);
+        p.img_stride = 0;
+    }
     if (mode >= 2 && !psum && !rpi) {
         const int bc = p.x.diag ? 64 : (Nout <= 16 ? 16 : (Nout <= 64 ? 64 : 128));
         dim3 grid((unsigned)(cdiv(Nout, bc) * cdiv(W, 16) * cdiv(H, 16) * n_img));

@@ -1076,9 +1076,9 @@ class SegOutUp(torch.autograd.Function):
         w_eff = (weight.reshape(k * c, 9) @ T.t()).view(k, c, 2, 2, 3, 3).permute(2, 3, 0, 1, 4, 5).reshape(4 * k, c, 3, 3).contiguous()
         b_eff = bias.repeat(4)
         wp, wt = pack_conv_weight(w_eff)
-        y4, _, _ = k_gemm_nt(x, None, 4, (n, h, w), wp, 4 * k, kp32(c), 9, bias=b_eff, out_f32=True)
         out = torch.empty((n, 2 * h, 2 * w, k), device=x.device, dtype=F32)
-        lib().call("hn_depth_to_space", ptr(y4), 4 * k, ptr(out), n, h, w, k)
+        # img_stride = -k: the conv epilogue scatters phase (py, px) of low-res pixel (y, x) to output pixel (2y+py, 2x+px) itself
+        k_gemm_nt(x, None, 4, (n, h, w), wp, 4 * k, kp32(c), 9, bias=b_eff, out=out, out_f32=True, ldc=4 * k, img_stride=-k)
         ctx.wt = wt
         ctx.k = k
         ctx.save_for_backward(x)
