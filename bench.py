@@ -116,7 +116,17 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(cfgs, h, w, budget_s=25.0):
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:       # noqa: BLE001
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfgs, h, w, budget_s=20.0):
     """fp32 CPU oracle (port of the reference path) on this box's host cores: N=1 fwd+loss+bwd, bounded sample."""
     from oracle import hydranet_oracle as O
     import multitask_hydranet_amd as pkg
@@ -148,8 +158,16 @@ def cpu_baseline(cfgs, h, w, budget_s=25.0):
         times = [warm]
     times.sort()
     med = times[len(times) // 2]
-    return {"value": round(1.0 / med, 4), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "fp32 oracle, big cfg, N=1, 3x%dx%d, fwd+loss+bwd, 1 warm-up + %d timed iterations (median)" % (h, w, len(times))}
+    # one-thread figure: ONE timed iteration after the warm multi-thread runs (a second would double the bounded sample)
+    torch.set_num_threads(1)
+    t0 = time.time()
+    step()
+    one = time.time() - t0
+    torch.set_num_threads(cores)
+    return {"value": round(1.0 / med, 4), "unit": "images/sec", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+            "value_1thread": round(1.0 / one, 4),
+            "sample": "fp32 oracle, big cfg, N=1, 3x%dx%d, fwd+loss+bwd, 1 warm-up + %d timed iterations (median) on %d threads; "
+                      "1 iteration on 1 thread" % (h, w, len(times), cores)}
 
 
 def main():

@@ -134,3 +134,19 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Opt-in for more than 64 KiB of dynamic LDS.  The attribute is per (kernel, device): `done` is one bit per device id, set after every
+// kernel of the list accepted the attribute on the calling thread's current device (atomic: backward runs on autograd worker threads).
+// Returns false when the runtime refuses (the caller reports HN_ERR_LAUNCH instead of launching a kernel that cannot get its LDS).
+#include <atomic>
+#include <initializer_list>
+static inline bool lds_optin(std::atomic<unsigned long long>& done, std::initializer_list<const void*> kernels) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    const unsigned long long bit = 1ull << dev;
+    if (done.load(std::memory_order_acquire) & bit) return true;
+    for (const void* k : kernels)
+        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+    done.fetch_or(bit, std::memory_order_release);
+    return true;
+}

@@ -1095,12 +1095,9 @@ static int launch_nt_r(const GemmNT& p, int out_f32, hipStream_t st) {
     const size_t tables = p.x.mode >= 2 ? (size_t)(3 * p.x.H + 3 * p.x.W) * 4 * (p.x.C1 ? 2 : 1) : 0;
     const size_t lds = (size_t)(BC + BP) * 128 * R + tables;
     if (lds > 64 * 1024) {
-        static bool optin = false;                                   // one flag per instantiation
-        if (!optin) {
-            hipFuncSetAttribute((const void*)gemm_nt_kernel<BC, BP, WGC, WGP, true, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            hipFuncSetAttribute((const void*)gemm_nt_kernel<BC, BP, WGC, WGP, false, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            optin = true;
-        }
+        static std::atomic<unsigned long long> optin{0};             // one per instantiation, one bit per device
+        if (!lds_optin(optin, {(const void*)gemm_nt_kernel<BC, BP, WGC, WGP, true, R>, (const void*)gemm_nt_kernel<BC, BP, WGC, WGP, false, R>}))
+            return HN_ERR_LAUNCH;
     }
     if (out_f32) hipLaunchKernelGGL((gemm_nt_kernel<BC, BP, WGC, WGP, true, R>), grid, dim3(256), lds, st, p);
     else hipLaunchKernelGGL((gemm_nt_kernel<BC, BP, WGC, WGP, false, R>), grid, dim3(256), lds, st, p);
@@ -1177,16 +1174,11 @@ extern "C" int hn_conv_gemm_nt(const void* x0, const void* x1, int mode, int n_i
         dim3 grid((unsigned)(cdiv(Nout, bc) * cdiv(W, 16) * cdiv(H, 16) * n_img));
         const size_t lds = (size_t)((18 * 18 * 128 + 1023) / 1024 * 1024) + 2 * (size_t)bc * 128;
         // > 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel (done on the first, un-captured call)
-        static bool optin = false;
-        if (!optin) {
-            hipFuncSetAttribute((const void*)conv3x3_direct_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            hipFuncSetAttribute((const void*)conv3x3_direct_kernel<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            hipFuncSetAttribute((const void*)conv3x3_direct_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            hipFuncSetAttribute((const void*)conv3x3_direct_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            hipFuncSetAttribute((const void*)conv3x3_direct_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            hipFuncSetAttribute((const void*)conv3x3_direct_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            optin = true;
-        }
+        static std::atomic<unsigned long long> optin{0};
+        if (!lds_optin(optin, {(const void*)conv3x3_direct_kernel<16, true>, (const void*)conv3x3_direct_kernel<16, false>,
+                               (const void*)conv3x3_direct_kernel<64, true>, (const void*)conv3x3_direct_kernel<64, false>,
+                               (const void*)conv3x3_direct_kernel<128, true>, (const void*)conv3x3_direct_kernel<128, false>}))
+            return HN_ERR_LAUNCH;
 #define DIRECT_CASE(BC_) \
         if (bc == BC_) { \
             if (out_f32) hipLaunchKernelGGL((conv3x3_direct_kernel<BC_, true>), grid, dim3(512), lds, st, p); \
@@ -1287,14 +1279,10 @@ extern "C" int hn_conv_gemm_tn(const void* x0, const void* x1, int mode, int n_i
     p.part = workspace; p.rows_per_split = rps;
     int bc, bn, rc;
     if (use_patch_wgrad(mode, Nout, KP)) {
-        static bool optin = false;
-        if (!optin) {
-            hipFuncSetAttribute((const void*)wgrad3x3_patch_kernel<128, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            hipFuncSetAttribute((const void*)wgrad3x3_patch_kernel<64, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            hipFuncSetAttribute((const void*)wgrad3x3_patch_kernel<16, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            hipFuncSetAttribute((const void*)wgrad3x3_patch_kernel<64, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            optin = true;
-        }
+        static std::atomic<unsigned long long> optin{0};
+        if (!lds_optin(optin, {(const void*)wgrad3x3_patch_kernel<128, 64>, (const void*)wgrad3x3_patch_kernel<64, 128>,
+                               (const void*)wgrad3x3_patch_kernel<16, 64>, (const void*)wgrad3x3_patch_kernel<64, 64>}))
+            return HN_ERR_LAUNCH;
         int pbc, pci, ksplit;
         patch_tiles(Nout, pbc, pci, ksplit);
         if (grouped) { pbc = 64; pci = 64; ksplit = 2; }

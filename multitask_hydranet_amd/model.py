@@ -273,6 +273,13 @@ class HydraNet(nn.Module):
         K.clear_pack_cache()
         return r
 
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        """Accepts checkpoints written from a DistributedDataParallel wrapper as well: the reference saves `model.state_dict()` of the DDP
+        module (train.py:437, keys "module.<name>") and strips the prefix when it loads them back (deparallel_model, train.py:96-109)."""
+        if state_dict and all(k.startswith("module.") for k in state_dict):
+            state_dict = type(state_dict)((k[len("module."):], v) for k, v in state_dict.items())
+        return super().load_state_dict(state_dict, strict=strict, assign=assign)
+
     def _bn(self, name):
         P = self._idx
         if self.training:                                   # counters are bumped once per forward with ONE multi-tensor add
@@ -412,9 +419,9 @@ class HydraNet(nn.Module):
         return pool[:count]
 
     def _det_tower(self, p, fused, k, act):
-        """Regressor / Classifier (head_detect/detection.py:26-44, 63-83).  The five pyramid levels are independent chains of small
-        launches (dw 3x3 -> 1x1+BN statistics -> BN+Swish, three times): each level runs on its own HIP stream, forked from and joined
-        to the caller's stream with events (legal inside hipGraph capture; autograd replays the assignment in backward)."""
+        """Regressor / Classifier (head_detect/detection.py:26-44, 63-83), level by level (dw 3x3 -> 1x1+BN statistics -> BN+Swish, three
+        times per level).  Used when the levels cannot be packed (ops.levels_packable); levels_on_streams (off: hipGraph branches measured
+        slower on gfx950) would put each level on its own HIP stream, forked from / joined to the caller's stream with events."""
         P = self._idx
         layers = self.cfgs["detection"]["box_class_repeats"]
         dev = fused[0].device
@@ -543,7 +550,8 @@ class HydraNet(nn.Module):
         big cfgs; the focal variant of the small cfg is a handful of elementwise torch ops (not on the benchmarked path)."""
         use_top_k, ratio, use_focal = self._seg_cfg
         if use_focal:                                   # small-cfg variant (a few elementwise device ops on the HIP logits), not benchmarked
-            return L.seg_loss(logits, target, self._seg_class_weight, use_top_k, ratio, use_focal)
+            # the reference always hands gt_seg.long() to the loss (model.py:212); to_gpu delivers float32 class ids
+            return L.seg_loss(logits, target.long(), self._seg_class_weight, use_top_k, ratio, use_focal)
         return K.seg_loss_hip(logits, target, self._seg_class_weight, use_top_k, ratio)      # no CPU fallback: raises off-device
 
     def _guard(self, value, what, allow_zero=False):

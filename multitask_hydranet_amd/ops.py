@@ -426,7 +426,7 @@ def conv_bn_act(x, weight, conv_bias, bn, res=None, kind="1x1", stride=1, act=AC
 
 # --------------------------------------------------------------------------------------------------------------
 # Squeeze-and-Excitation: out = b * sigmoid(W2 relu(W1 avgpool(b) + b1) + b2)        (net/anynet.py:40-48,68-69)
-# pooling, gating and their data-path backward are HIP kernels; the [N, C] x [C, C/4] MLP is a plain library GEMM.
+# pooling, the [N, C] x [C, C/4] excitation MLP (hn_se_mlp_fwd / hn_se_mlp_bwd), gating and their backward are all HIP kernels.
 # --------------------------------------------------------------------------------------------------------------
 class SEGate(torch.autograd.Function):
     @staticmethod

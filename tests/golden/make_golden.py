@@ -237,10 +237,25 @@ def loss_kats():
     print("loss KATs: %d arrays" % len(res))
 
 
+def _digest(t):
+    t = t.detach().double()
+    return np.array([float(t.mean()), float(t.abs().max()), float(t.norm())], dtype=np.float64)
+
+
 def big_digest():
-    """Big cfg at 640x640, B=1: state_dict key/shape list + output digests (weights too big to commit)."""
+    """Big cfg (the reference's own hydranet_joint_big_backbone.yml, repo-default 640x640), B=1: state_dict key/shape list and NUMERIC
+    digests (mean, abs-max, L2) of every feature map / head output / loss / parameter gradient of a training-mode step and of the
+    eval-mode forward.  The 171 MB of weights cannot be committed, so they come from a seeded recipe
+    (tests/helpers.synthetic_state) that the CPU test re-runs to feed the oracle the same values."""
     from model import HydraNet
+    from head_lane.lanedetect_loss import cal_loss_regress  # noqa: F401  (the default points_per_line=160 is live at H=640)
+    from tests.helpers import synthetic_state
     cfgs = yaml.safe_load(open(f"{REF}/cfgs/hydranet_joint_big_backbone.yml"))
+    ours = yaml.safe_load(open(os.path.join(ROOT, "cfgs", "hydranet_big.yml")))
+    for sec in ("backbone", "detection", "segment", "lane"):         # cfgs/hydranet_big.yml is the same model (paths blanked)
+        assert cfgs[sec] == ours[sec], sec
+    h = w = 640
+    assert cfgs["dataloader"]["network_input_height"] == h and cfgs["dataloader"]["network_input_width"] == w
     torch.manual_seed(0)
     net = HydraNet(cfgs)
     keys = list(net.state_dict().keys())
@@ -248,12 +263,58 @@ def big_digest():
     res = {"keys": np.array(keys), "shapes": np.array([",".join(map(str, s)) for s in shapes]),
            "n_params": np.array(sum(p.numel() for p in net.parameters())),
            "param_keys": np.array([k for k, _ in net.named_parameters()])}
+    sd = synthetic_state(keys, shapes, seed=11)
+    net.load_state_dict(sd)
+    res["digest/state_sha256"] = np.array(hashlib.sha256(b"".join(np.ascontiguousarray(_np(sd[k])).tobytes() for k in keys)).hexdigest())
+    batch = O.synthetic_batch(cfgs, 1, h, w, seed=1)
+    net.train()
+    x = batch["image"]
+    out = net(x)
+    ld = net.cal_loss(out, batch)
+    s, d, l = cfgs["segment"], cfgs["detection"], cfgs["lane"]
+    total = ld["loss_seg"] * s["segment_weight"] \
+        + (ld["loss_det_cls"] * d["loss_cls_weight"] + ld["loss_det_reg"] * d["loss_reg_weight"]) * d["detection_weight"] \
+        + (ld["loss_lane_cls_pos"] + ld["loss_lane_cls_neg"] + ld["loss_lane_loc"]) * l["lane_weight"]
+    total.backward()
+    for k, v in ld.items():
+        res["digest/loss/" + k] = _np(v).astype(np.float64)
+    res["digest/loss/total"] = _np(total).astype(np.float64)
+    res["digest/train/seg"] = _digest(out["seg"])
+    res["digest/train/regression"] = _digest(out["detection"]["regression"])
+    res["digest/train/classification"] = _digest(out["detection"]["classification"])
+    res["digest/train/lane_cls"] = _digest(out["lane"]["predict_cls"])
+    res["digest/train/lane_loc"] = _digest(out["lane"]["predict_loc"])
+    gk, gv = [], []
+    for k, p in net.named_parameters():
+        if p.grad is not None:
+            gk.append(k)
+            gv.append(float(p.grad.double().norm()))
+    res["digest/grad_keys"], res["digest/grad_l2"] = np.array(gk), np.array(gv, dtype=np.float64)
+    # eval-mode forward with the post-step running statistics: feature maps, fused maps, head outputs
+    net.eval()
+    with torch.no_grad():
+        feats = net.backbone(x)
+        fused = net.neck(feats)
+        dep = net(x, "deploy")
+    for i, f in enumerate(feats):
+        res[f"digest/eval/feat{i}"] = _digest(f)
+    for i, f in enumerate(fused):
+        res[f"digest/eval/fused{i}"] = _digest(f)
+    res["digest/eval/regression"], res["digest/eval/classification"] = _digest(dep[2]), _digest(dep[3])
+    res["digest/eval/lane_cls"], res["digest/eval/lane_loc"] = _digest(dep[4]), _digest(dep[5])
+    cnt = torch.bincount(dep[0].flatten(), minlength=5)
+    res["digest/eval/seg_argmax_hist"] = _np(cnt).astype(np.int64)
     np.savez_compressed(os.path.join(HERE, "big_keys.npz"), **res)
-    print("big cfg: %d state_dict entries, %d params" % (len(keys), int(res["n_params"])))
+    print("big cfg: %d state_dict entries, %d params; losses" % (len(keys), int(res["n_params"])),
+          {k: float(v) for k, v in ld.items()}, "argmax hist", cnt.tolist())
 
 
 if __name__ == "__main__":
     _install_shims()
-    tiny_fixture()
-    loss_kats()
-    big_digest()
+    which = sys.argv[1:] or ["tiny", "kats", "big"]
+    if "tiny" in which:
+        tiny_fixture()
+    if "kats" in which:
+        loss_kats()
+    if "big" in which:
+        big_digest()

@@ -42,3 +42,30 @@ def assert_close(a, b, rtol, name="", atol=0.0):
     bound = rtol * float(b.abs().max() if b.numel() else 0.0) + atol
     assert err <= bound, f"{name}: max error {err:.3e} > {bound:.3e} (rtol {rtol:.1e}, atol {atol:.1e})"
     return err
+
+
+def synthetic_state(keys, shapes, seed=11):
+    """Seeded state_dict recipe for configurations whose weights are too large to commit (big cfg: 171 MB): one generator per entry
+    (seed + position), He-style scale for conv weights, non-trivial BatchNorm affine / running statistics and fusion weights.  Used by
+    tests/golden/make_golden.py (loaded into the reference) and by the tests (loaded into the oracle / the HIP module)."""
+    sd = {}
+    for i, (k, shp) in enumerate(zip(keys, shapes)):
+        g = torch.Generator().manual_seed(seed * 100003 + i)
+        shp = tuple(int(v) for v in shp)
+        leaf = k.split(".")[-1]
+        if leaf == "num_batches_tracked":
+            sd[k] = torch.tensor(0, dtype=torch.long)
+        elif leaf == "running_var":
+            sd[k] = 0.5 + torch.rand(shp, generator=g)
+        elif leaf == "running_mean":
+            sd[k] = 0.1 * torch.randn(shp, generator=g)
+        elif len(shp) == 4:
+            fan_in = shp[1] * shp[2] * shp[3]
+            sd[k] = torch.randn(shp, generator=g) * (2.0 / fan_in) ** 0.5
+        elif leaf == "bias":
+            sd[k] = 0.1 * torch.randn(shp, generator=g)
+        elif len(shp) == 1 and "_w" in leaf:                 # BiFPN fusion weights p{3..7}_w{1,2}
+            sd[k] = torch.rand(shp, generator=g) + 0.1
+        else:                                                # BatchNorm gamma
+            sd[k] = 0.5 + torch.rand(shp, generator=g)
+    return sd

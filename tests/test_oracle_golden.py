@@ -187,3 +187,57 @@ def test_nms_known_answers():
     # classes never suppress each other
     assert O.batched_nms(boxes, scores, torch.tensor([0, 0, 0, 1]), 0.5).tolist() == [3, 0, 2]
     assert O.nms_greedy(torch.zeros(0, 4), torch.zeros(0), 0.5).numel() == 0
+
+
+def test_big_cfg_numeric_digest():
+    """the oracle on the big cfg at the repo-default 640x640 (B=1) against digests (mean, abs-max, L2) recorded from
+    the reference itself: training-mode losses, head outputs and all 693 parameter-gradient norms; eval-mode feature maps, fused maps,
+    head outputs and the arg-max class histogram.  Weights come from the seeded recipe both sides use (tests/helpers.synthetic_state,
+    pinned by a sha256 of the generated state).  The live `points_per_line = 160` default is exercised here (162 location columns)."""
+    from tests.helpers import synthetic_state
+    z = load_npz("big_keys.npz")
+    cfgs = load_cfg("hydranet_big.yml")
+    cfgs["dataloader"]["network_input_height"] = cfgs["dataloader"]["network_input_width"] = 640
+    keys = z["keys"].tolist()
+    shapes = [tuple(int(v) for v in s.split(",")) if s else () for s in z["shapes"].tolist()]
+    sd = synthetic_state(keys, shapes, seed=11)
+    sha = hashlib.sha256(b"".join(np.ascontiguousarray(sd[k].numpy()).tobytes() for k in keys)).hexdigest()
+    assert sha == str(z["digest/state_sha256"])
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    batch = O.synthetic_batch(cfgs, 1, 640, 640, seed=1)
+    out = O.hydranet_forward(sd, cfgs, batch["image"], training=True)
+    ld = O.hydranet_losses(cfgs, out, batch)                      # default lane_points_per_line = 160, as the reference runs it
+    tot = O.total_loss(cfgs, ld)
+    tot.backward()
+    dig = lambda t: np.array([float(t.detach().double().mean()), float(t.detach().abs().max()), float(t.detach().double().norm())])
+    for k, v in ld.items():
+        assert_close(v, z["digest/loss/" + k], 2e-5, k)
+    assert_close(tot, z["digest/loss/total"], 2e-5, "total")
+    pairs = {"seg": out["seg"], "regression": out["detection"]["regression"], "classification": out["detection"]["classification"],
+             "lane_cls": out["lane"]["predict_cls"], "lane_loc": out["lane"]["predict_loc"]}
+    for k, t in pairs.items():
+        got, ref = dig(t), z["digest/train/" + k]
+        assert abs(got[1] - ref[1]) <= 1e-4 * ref[1] and abs(got[2] - ref[2]) <= 1e-4 * ref[2], (k, got, ref)
+        assert abs(got[0] - ref[0]) <= 1e-4 * ref[1], (k, got, ref)
+    gk = z["digest/grad_keys"].tolist()
+    gl = z["digest/grad_l2"]
+    assert len(gk) == 693 and {k for k, v in sd.items() if v.requires_grad and v.grad is not None} == set(gk)
+    scale = float(gl.max())
+    for k, ref in zip(gk, gl):
+        got = float(sd[k].grad.double().norm())
+        assert abs(got - ref) <= 5e-4 * ref + 1e-7 * scale, (k, got, ref)
+    # eval mode with the post-step running statistics
+    esd = {k: v.detach() for k, v in sd.items()}
+    with torch.no_grad():
+        eo = O.hydranet_forward(esd, cfgs, batch["image"], training=False, want_features=True)
+    ev = {f"feat{i}": f for i, f in enumerate(eo["_feats"])}
+    ev.update({f"fused{i}": f for i, f in enumerate(eo["_fused"])})
+    ev.update(regression=eo["detection"]["regression"], classification=eo["detection"]["classification"],
+              lane_cls=eo["lane"]["predict_cls"], lane_loc=eo["lane"]["predict_loc"])
+    for k, t in ev.items():
+        got, ref = dig(t), z["digest/eval/" + k]
+        assert abs(got[1] - ref[1]) <= 1e-4 * ref[1] and abs(got[2] - ref[2]) <= 1e-4 * ref[2], (k, got, ref)
+    hist = torch.bincount(torch.argmax(eo["seg"], 1).flatten(), minlength=5).numpy()
+    assert np.abs(hist - z["digest/eval/seg_argmax_hist"]).sum() <= 4          # a handful of near-tie pixels may flip between graph orders
