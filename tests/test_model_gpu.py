@@ -309,6 +309,14 @@ def test_deploy_mode_and_bit_exact_bookkeeping(env):
     net.train()
     assert dep[0].dtype == torch.int64 and tuple(dep[0].shape) == tuple(z["deploy/seg_argmax"].shape)
     assert len(dep) == 6 and dep[2].shape == tuple(z["deploy/regression"].shape)
+    # eval-mode END-TO-END against the reference's own recorded fp32 outputs (running-statistics BatchNorm: a fixed function, no
+    # batch-statistics feedback): stated bf16-storage tolerance 4e-2 * max|ref| per tensor, plus the arg-max mask agreement
+    e2e = dict(regression=serr(dep[2], z["deploy/regression"]), classification=serr(dep[3], z["deploy/classification"]),
+               lane_cls=serr(dep[4], z["deploy/lane_cls"]),
+               seg_mask_agreement=float((dep[0].cpu() == torch.from_numpy(z["deploy/seg_argmax"])).float().mean()))
+    json.dump(e2e, open(os.path.join(ROOT, "gpurun_out", "tiny_eval_end_to_end.json"), "w"), indent=1)
+    print("tiny eval end-to-end vs reference fp32:", e2e)
+    assert e2e["regression"] <= 4e-2 and e2e["classification"] <= 4e-2 and e2e["lane_cls"] <= 4e-2 and e2e["seg_mask_agreement"] >= 0.97
     # argmax is bit-exact GIVEN identical logits (device argmax of the reference's logits == CPU argmax)
     ref_logits = torch.from_numpy(z["out/seg"])
     assert torch.equal(torch.argmax(ref_logits.cuda(), 1).cpu(), torch.argmax(ref_logits, 1))
@@ -372,3 +380,23 @@ def test_det_towers_level_packed_equals_per_level():
         close(x, y, 3e-2, f"dx level {i}")
     for k in a["dp"]:
         close(a["dp"][k], b["dp"][k], 3e-2, k)
+
+
+@pytest.mark.gpu
+def test_focal_seg_loss_takes_float_class_ids():
+    """small-backbone cfg variant (segment.use_focal): to_gpu delivers gt_seg as float32 class ids (train.py:228-239) and the reference
+    casts them with .long() (model.py:212); the drop-in must accept the same batch.  Value against the oracle's restatement."""
+    import copy
+    from multitask_hydranet_amd import HydraNet
+    from oracle import hydranet_oracle as O
+    cfgs = copy.deepcopy(load_cfg("hydranet_tiny.yml"))
+    cfgs["segment"]["use_focal"], cfgs["segment"]["use_top_k"] = True, False
+    torch.manual_seed(1)
+    net = HydraNet(cfgs).cuda().train()
+    g = torch.Generator(device="cuda").manual_seed(2)
+    logits = torch.randn(2, 5, 64, 64, device="cuda", generator=g, requires_grad=True)
+    gt = torch.randint(0, 5, (2, 64, 64), device="cuda", generator=g).float()
+    loss = net.loss_seg(logits, gt)
+    loss.backward()
+    ref = O.seg_loss(logits.detach().cpu(), gt.long().cpu(), cfgs["segment"]["class_weight"], False, cfgs["segment"]["top_k_ratio"], True)
+    assert abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref)) and logits.grad is not None
