@@ -179,6 +179,38 @@ int hn_bn_bwd_finalize_levels(const float* pg, const float* pgx, int div, int C,
 int hn_bn_bwd_apply_levels(const void* dout, int ldd, const void* z, int ldz, const void* y, int ldy, const float* coef, const float* red,
                            int act, void* dz, int lddz, int C, int nlev, const long* rows, hipStream_t stream);
 
+/* ---- fused BatchNorm passes (hn_fused.hip) ----------------------------------------------------------------------------------
+ * The finalize step of a training-mode nn.BatchNorm2d (partial statistics -> scale/shift/mean/rstd + running statistics; partial gradient
+ * sums -> dgamma/dbeta + the two means) runs in the PROLOGUE of the elementwise kernel that consumes it: grid = (64-channel chunks,
+ * row blocks of RB rows), every workgroup reduces the P partial rows of its own 64 channels.  Replaces hn_bn_finalize + hn_bn_act and
+ * hn_bn_bwd_finalize + hn_bn_bwd_apply (and the hn_rows_reduce2 folds in front of them) for net/anynet.py:31,36,54,59,65-76,
+ * net/common.py:98, net/bifpn.py:58-102, head_lane/lanedetect.py:45-64. */
+/* rows per row block for M rows x C channels (<= 512 row blocks; a divisor of `align` = rows per image when align > 0) */
+long hn_fused_row_block(long M, int C, long align);
+/* out = act(bn(z) [+ res]).  P > 0: training mode, statistics from psum/psq [P][C] (count = rows normalised over), row block 0 writes
+ * coef [4][C] (scale, shift, mean, rstd) and updates rm/rv; P == 0: use coef as is (null = identity); P < 0: eval mode (running statistics).
+ * out may be null when only pool is wanted; pool (optional) [ceil(M/RB)][C] = per-row-block channel sums of the bf16-rounded output
+ * (SE squeeze, net/anynet.py:42,68). */
+int hn_bn_apply_fused(const void* z, int ldz, long M, int C, const float* psum, const float* psq, int P, long count, const float* gamma,
+                      const float* beta, float eps, float momentum, float* rm, float* rv, float* coef, const void* res, int ldr, int act,
+                      void* out, int ldo, float* pool, long RB, hipStream_t stream);
+/* BatchNorm backward.  g = dout * act'(scale*z+shift), or dout * [y > 0] when the saved block output y is given (ReLU after the residual
+ * add), or, with gate/dpool (SE, RB divides HW): g = (dout*gate[n][c] + dpool[n][c]/HW) * [scale*z+shift > 0] where dout is the gradient of
+ * the gated tensor.  reduce: pg/pgx [ceil(M/RB)][C] partial sums of g and g*xhat.  apply: dz = scale*(g - mean g - xhat*mean(g*xhat)),
+ * dgamma/dbeta written by row block 0, gout (optional) = g in bf16 (the residual branch's gradient). */
+int hn_bn_bwd_reduce_fused(const void* dout, int ldd, const void* z, int ldz, const void* y, int ldy, const float* coef, int act,
+                           const float* gate, const float* dpool, long HW, long M, int C, long RB, float* pg, float* pgx, hipStream_t stream);
+int hn_bn_bwd_apply_fused(const void* dout, int ldd, const void* z, int ldz, const void* y, int ldy, const float* coef, int act,
+                          const float* gate, const float* dpool, long HW, const float* pg, const float* pgx, int P, long count, float* dgamma,
+                          float* dbeta, void* dz, int lddz, void* gout, int ldg, long M, int C, long RB, hipStream_t stream);
+/* per-row-block channel sums / sums of squares [ceil(M/RB)][C] of a bf16 tensor (statistics of convs without a statistics epilogue) */
+int hn_col_stats_fused(const void* x, int ldx, long M, int C, long RB, float* psum, float* psq, hipStream_t stream);
+/* SE backward, first pass over (dbg = gradient of the gated tensor, z = pre-BN conv_block_2 output): b = relu(scale*z+shift),
+ * pdot [ceil(M/RB)][C] = per-row-block sums of dbg*b (gate gradient), bg (optional) = b*gate[n][c] in bf16 (operand of conv_block_3's
+ * weight gradient). */
+int hn_se_bwd_reduce_fused(const void* dbg, int ldd, const void* z, int ldz, const float* coef, const float* gate, long HW, void* bg, int ldb,
+                           float* pdot, long M, int C, long RB, hipStream_t stream);
+
 /* SE gating x * gate[n][c] and its data-path backward (net/anynet.py:40-48,68-69). */
 int hn_scale_rows(const void* x, int ldx, const float* gate, long HW, void* out, int ldo, long M, int C, hipStream_t stream);
 int hn_se_bwd_apply(const void* dout, int ldd, const float* gate, const float* dpool, long HW, void* db, int ldb, long M, int C,

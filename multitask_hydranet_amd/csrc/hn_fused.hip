@@ -1,0 +1,492 @@
+// Fused BatchNorm passes: the per-channel "finalize" step (partial statistics -> mean / rstd / scale / shift, running-statistics update;
+// partial gradient sums -> dgamma / dbeta / the two means) runs in the PROLOGUE of the elementwise kernel that consumes it, so a
+// training-mode BatchNorm is two launches forward-free (statistics come out of the producing conv's epilogue) + one apply launch, and
+// reduce + apply backward -- no finalize launches, no partial-row fold launches.  SE pooling rides on the BN2 pass of an XBlock, the SE
+// gate gradient and the gated operand of conv_block_3's weight gradient come out of one pass over (dbg, z2).
+//
+// Layout: tensors are [rows][C] bf16 (row stride ld*).  grid = (channel chunks of 64, row blocks of RB rows); a workgroup owns
+// <= 64 channels (<= 8 lanes of 8 channels, one 128-byte line per row) and RB rows, so its prologue reduces only P x 64 partial values.
+// Everything is deterministic: fixed-order LDS reductions, no float atomics.
+// Reference ops: nn.BatchNorm2d training forward/backward (net/anynet.py:31,36,54,59; net/common.py:98; head_lane/lanedetect.py:47-61),
+// ReLU / Swish, residual add (net/anynet.py:75), SE squeeze / excite gating (net/anynet.py:40-48,68-69).
+#include "hn_common.h"
+
+#define FCH 64
+
+struct BnSrc {
+    const float* psum; const float* psq;   // [P][C] partial sums / sums of squares
+    int P;                                 // > 0: finalize from the partial rows; 0: read coef; < 0: eval mode (running statistics)
+    double count;
+    const float* gamma; const float* beta;
+    float eps, momentum;
+    float* rm; float* rv;                  // running statistics: updated by row block 0 when P > 0; read when P < 0
+    float* coef;                           // [4][C] scale, shift, mean, rstd: written by row block 0 (P != 0), read (P == 0); null = identity
+};
+
+struct FusedLds {
+    double r1[16][FCH + 1], r2[16][FCH + 1];
+    float coef[6][FCH];                    // scale, shift, mean, rstd, mean(g), mean(g*xhat)
+    float fr[2][4][FCH];
+};
+
+// sum of P partial rows for the chunk's channels: out in lds.r1[0][c], lds.r2[0][c] (doubles), c < nch.  16 channel quads x 16 row lanes.
+__device__ __forceinline__ void chunk_partial_sums(const float* p1, const float* p2, int P, int C, int c0, int nch, FusedLds& L) {
+    const int tid = threadIdx.x, q = tid & 15, rl = tid >> 4;
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    if (q * 4 < nch) {
+        const float* a = p1 + c0 + q * 4;
+        const float* b = p2 + c0 + q * 4;
+#pragma unroll 4
+        for (int r = rl; r < P; r += 16) {
+            const f32x4 va = *reinterpret_cast<const f32x4*>(a + (long)r * C);
+            const f32x4 vb = *reinterpret_cast<const f32x4*>(b + (long)r * C);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { s1[k] += va[k]; s2[k] += vb[k]; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { L.r1[rl][q * 4 + k] = s1[k]; L.r2[rl][q * 4 + k] = s2[k]; }
+    __syncthreads();
+    if (tid < FCH) {
+        double t1 = 0, t2 = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { t1 += L.r1[k][tid]; t2 += L.r2[k][tid]; }
+        L.r1[0][tid] = t1; L.r2[0][tid] = t2;       // only thread `tid` reads/writes column tid here
+    }
+    __syncthreads();
+}
+
+// coefficient set of the chunk into L.coef[0..3]; `writer` (row block 0) also stores it / updates the running statistics
+__device__ __forceinline__ void chunk_coefs(const BnSrc& b, int C, int c0, int nch, bool writer, FusedLds& L) {
+    const int tid = threadIdx.x;
+    if (b.P > 0) {
+        chunk_partial_sums(b.psum, b.psq, b.P, C, c0, nch, L);
+        if (tid < nch) {
+            const int c = c0 + tid;
+            const double mu = L.r1[0][tid] / b.count;
+            double var = L.r2[0][tid] / b.count - mu * mu;
+            if (var < 0.0) var = 0.0;
+            const float rs = (float)(1.0 / sqrt(var + (double)b.eps));
+            const float sc = b.gamma[c] * rs;
+            const float sh = b.beta[c] - (float)mu * sc;
+            L.coef[0][tid] = sc; L.coef[1][tid] = sh; L.coef[2][tid] = (float)mu; L.coef[3][tid] = rs;
+            if (writer) {
+                if (b.coef) { b.coef[c] = sc; b.coef[C + c] = sh; b.coef[2 * C + c] = (float)mu; b.coef[3 * C + c] = rs; }
+                if (b.rm) {
+                    const double unb = b.count > 1.0 ? var * b.count / (b.count - 1.0) : var;
+                    b.rm[c] = (1.f - b.momentum) * b.rm[c] + b.momentum * (float)mu;
+                    b.rv[c] = (1.f - b.momentum) * b.rv[c] + b.momentum * (float)unb;
+                }
+            }
+        }
+    } else if (tid < nch) {
+        const int c = c0 + tid;
+        if (b.P < 0) {                                                     // eval mode: nn.BatchNorm2d with running statistics
+            const float rs = 1.0f / sqrtf(b.rv[c] + b.eps);
+            const float sc = b.gamma[c] * rs;
+            L.coef[0][tid] = sc; L.coef[1][tid] = b.beta[c] - b.rm[c] * sc; L.coef[2][tid] = b.rm[c]; L.coef[3][tid] = rs;
+            if (writer && b.coef) { b.coef[c] = sc; b.coef[C + c] = L.coef[1][tid]; b.coef[2 * C + c] = b.rm[c]; b.coef[3 * C + c] = rs; }
+        } else if (b.coef) {
+            L.coef[0][tid] = b.coef[c]; L.coef[1][tid] = b.coef[C + c]; L.coef[2][tid] = b.coef[2 * C + c]; L.coef[3][tid] = b.coef[3 * C + c];
+        } else {
+            L.coef[0][tid] = 1.f; L.coef[1][tid] = 0.f; L.coef[2][tid] = 0.f; L.coef[3][tid] = 1.f;
+        }
+    }
+    __syncthreads();
+}
+
+// per-channel sums over the workgroup's row lanes of up to two per-thread accumulators -> o1/o2[blockIdx.y][c] (fixed order)
+template <int NARR>
+__device__ __forceinline__ void chunk_row_reduce(float (&a1)[8], float (&a2)[8], bool active, int cln, int rln, int cl, int rl, int c0, int nch,
+                                                 int C, float* o1, float* o2, float* scratch /* [NARR][256*8] */, FusedLds& L) {
+    const int tid = threadIdx.x;
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            scratch[(rl * cln + cl) * 8 + k] = a1[k];
+            if (NARR == 2) scratch[2048 + (rl * cln + cl) * 8 + k] = a2[k];
+        }
+    }
+    __syncthreads();
+    const int c = tid & 63, j = tid >> 6;
+    float t1 = 0.f, t2 = 0.f;
+    if (c < nch) {
+        const int g8 = c >> 3, k = c & 7;
+        for (int r = j; r < rln; r += 4) {
+            t1 += scratch[(r * cln + g8) * 8 + k];
+            if (NARR == 2) t2 += scratch[2048 + (r * cln + g8) * 8 + k];
+        }
+    }
+    L.fr[0][j][c] = t1; L.fr[1][j][c] = t2;
+    __syncthreads();
+    if (tid < nch) {
+        const long o = (long)blockIdx.y * C + c0 + tid;
+        o1[o] = (L.fr[0][0][tid] + L.fr[0][1][tid]) + (L.fr[0][2][tid] + L.fr[0][3][tid]);
+        if (NARR == 2) o2[o] = (L.fr[1][0][tid] + L.fr[1][1][tid]) + (L.fr[1][2][tid] + L.fr[1][3][tid]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// forward: out = act(bn(z) [+ res]); optional per-row-block channel sums of the bf16-rounded output (SE squeeze), optional no store
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct FApply {
+    const bf16* z; int ldz;
+    BnSrc bn;
+    const bf16* res; int ldr;
+    int act;
+    bf16* out; int ldo;
+    float* pool;                    // [gridDim.y][C] or null
+    long M; int C; long RB;
+};
+
+__global__ __launch_bounds__(256) void fused_apply_kernel(const FApply p) {
+    __shared__ FusedLds L;
+    __shared__ float scratch[2048];
+    const int c0 = blockIdx.x * FCH;
+    const int nch = p.C - c0 < FCH ? p.C - c0 : FCH;
+    chunk_coefs(p.bn, p.C, c0, nch, blockIdx.y == 0, L);
+    const int cln = nch >> 3, rln = 256 / cln;
+    const int tid = threadIdx.x, cl = tid % cln, rl = tid / cln;
+    const bool active = rl < rln;
+    float sc[8], sh[8], acc[8], dummy[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sc[k] = L.coef[0][cl * 8 + k]; sh[k] = L.coef[1][cl * 8 + k]; acc[k] = 0.f; dummy[k] = 0.f; }
+    const long m0 = (long)blockIdx.y * p.RB;
+    long m1 = m0 + p.RB;
+    if (m1 > p.M) m1 = p.M;
+    const int c = c0 + cl * 8;
+    auto apply = [&](const bf16x8& vz, const bf16x8& vr, long m) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = bf2f(vz[k]) * sc[k] + sh[k];
+        if (p.res) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += bf2f(vr[k]);
+        }
+        act_fwd_n(v, p.act);
+        bf16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = f2bf(v[k]);
+        if (p.pool) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += bf2f(o[k]);
+        }
+        if (p.out) st8(p.out + m * p.ldo + c, o);
+    };
+    if (active) {
+        long m = m0 + rl;
+        for (; m + rln < m1; m += 2 * rln) {
+            const long mb = m + rln;
+            const bf16x8 vz0 = ld8(p.z + m * p.ldz + c), vz1 = ld8(p.z + mb * p.ldz + c);
+            bf16x8 vr0 = vz0, vr1 = vz1;
+            if (p.res) { vr0 = ld8(p.res + m * p.ldr + c); vr1 = ld8(p.res + mb * p.ldr + c); }
+            apply(vz0, vr0, m);
+            apply(vz1, vr1, mb);
+        }
+        if (m < m1) {
+            const bf16x8 vz0 = ld8(p.z + m * p.ldz + c);
+            bf16x8 vr0 = vz0;
+            if (p.res) vr0 = ld8(p.res + m * p.ldr + c);
+            apply(vz0, vr0, m);
+        }
+    }
+    if (p.pool) chunk_row_reduce<1>(acc, dummy, active, cln, rln, cl, rl, c0, nch, p.C, p.pool, nullptr, scratch, L);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// backward.  g = upstream gradient at the BatchNorm output:
+//   plain:    g = dout * act'(scale*z + shift)            (act NONE: g = dout)
+//   masked:   g = dout * [y > 0]                          (y = saved block output: ReLU after the residual add)
+//   SE:       g = (dout * gate[n][c] + dpool[n][c] / HW) * [scale*z + shift > 0]     (dout = gradient of the gated tensor)
+// reduce: per-row-block partial sums of g and g*xhat;  apply: dz = scale * (g - mean(g) - xhat * mean(g*xhat)), optional copy of g.
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct FBwd {
+    const bf16* dout; int ldd; const bf16* z; int ldz; const bf16* y; int ldy;
+    const float* coef;              // [4][C] of the forward pass
+    int act;
+    const float* gate; const float* dpool; long HW;   // SE variant when gate != null (RB divides HW)
+    float* pg; float* pgx;          // reduce: written [gridDim.y][C]; apply: read [P][C]
+    int P; double count;
+    float* dgamma; float* dbeta;
+    bf16* dz; int lddz; bf16* gout; int ldg;
+    long M; int C; long RB;
+};
+
+template <bool APPLY>
+__global__ __launch_bounds__(256) void fused_bwd_kernel(const FBwd p) {
+    __shared__ FusedLds L;
+    __shared__ float scratch[APPLY ? 1 : 4096];
+    const int c0 = blockIdx.x * FCH;
+    const int nch = p.C - c0 < FCH ? p.C - c0 : FCH;
+    const int tid = threadIdx.x;
+    if (APPLY) {
+        chunk_partial_sums(p.pg, p.pgx, p.P, p.C, c0, nch, L);
+        if (tid < nch) {
+            const double s1 = L.r1[0][tid], s2 = L.r2[0][tid];
+            L.coef[4][tid] = (float)(s1 / p.count);
+            L.coef[5][tid] = (float)(s2 / p.count);
+            if (blockIdx.y == 0) { p.dbeta[c0 + tid] = (float)s1; p.dgamma[c0 + tid] = (float)s2; }
+        }
+    }
+    if (tid < nch) {
+        const int c = c0 + tid;
+        L.coef[0][tid] = p.coef[c]; L.coef[1][tid] = p.coef[p.C + c]; L.coef[2][tid] = p.coef[2 * p.C + c]; L.coef[3][tid] = p.coef[3 * p.C + c];
+    }
+    __syncthreads();
+    const int cln = nch >> 3, rln = 256 / cln;
+    const int cl = tid % cln, rl = tid / cln;
+    const bool active = rl < rln;
+    const int c = c0 + cl * 8;
+    float sc[8], sh[8], mu[8], rs[8], mg[8], mgx[8], gt[8], dp[8], s1[8], s2[8];
+    const long m0 = (long)blockIdx.y * p.RB;
+    long m1 = m0 + p.RB;
+    if (m1 > p.M) m1 = p.M;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        sc[k] = L.coef[0][cl * 8 + k]; sh[k] = L.coef[1][cl * 8 + k]; mu[k] = L.coef[2][cl * 8 + k]; rs[k] = L.coef[3][cl * 8 + k];
+        mg[k] = APPLY ? L.coef[4][cl * 8 + k] : 0.f; mgx[k] = APPLY ? L.coef[5][cl * 8 + k] : 0.f;
+        s1[k] = 0.f; s2[k] = 0.f; gt[k] = 1.f; dp[k] = 0.f;
+    }
+    if (p.gate && active) {
+        const long n = m0 / p.HW;
+        const float inv = 1.0f / (float)p.HW;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { gt[k] = p.gate[n * p.C + c + k]; dp[k] = p.dpool[n * p.C + c + k] * inv; }
+    }
+    auto one = [&](const bf16x8& vd, const bf16x8& vz, const bf16x8& vy, long m) {
+        float z[8], g[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { z[k] = bf2f(vz[k]); g[k] = bf2f(vd[k]); }
+        if (p.gate) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) g[k] = bfround(g[k] * gt[k] + dp[k]);       // db, rounded where the unfused path stored it
+        }
+        if (p.y) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) g[k] = bf2f(vy[k]) > 0.f ? g[k] : 0.f;
+        } else {
+            float pre[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) pre[k] = sc[k] * z[k] + sh[k];
+            act_bwd_n(pre, g, p.act);
+        }
+        if (!APPLY) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { s1[k] += g[k]; s2[k] += g[k] * (z[k] - mu[k]) * rs[k]; }
+        } else {
+            bf16x8 o, og;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float xh = (z[k] - mu[k]) * rs[k];
+                o[k] = f2bf(sc[k] * (g[k] - mg[k] - xh * mgx[k]));
+                og[k] = f2bf(g[k]);
+            }
+            st8(p.dz + m * p.lddz + c, o);
+            if (p.gout) st8(p.gout + m * p.ldg + c, og);
+        }
+    };
+    if (active) {
+        long m = m0 + rl;
+        for (; m + rln < m1; m += 2 * rln) {
+            const long mb = m + rln;
+            const bf16x8 vd0 = ld8(p.dout + m * p.ldd + c), vd1 = ld8(p.dout + mb * p.ldd + c);
+            const bf16x8 vz0 = ld8(p.z + m * p.ldz + c), vz1 = ld8(p.z + mb * p.ldz + c);
+            bf16x8 vy0 = vz0, vy1 = vz1;
+            if (p.y) { vy0 = ld8(p.y + m * p.ldy + c); vy1 = ld8(p.y + mb * p.ldy + c); }
+            one(vd0, vz0, vy0, m);
+            one(vd1, vz1, vy1, mb);
+        }
+        if (m < m1) {
+            const bf16x8 vd0 = ld8(p.dout + m * p.ldd + c);
+            const bf16x8 vz0 = ld8(p.z + m * p.ldz + c);
+            bf16x8 vy0 = vz0;
+            if (p.y) vy0 = ld8(p.y + m * p.ldy + c);
+            one(vd0, vz0, vy0, m);
+        }
+    }
+    if (!APPLY) chunk_row_reduce<2>(s1, s2, active, cln, rln, cl, rl, c0, nch, p.C, p.pg, p.pgx, scratch, L);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// per-channel statistics of a bf16 tensor (producers without a statistics epilogue: stem, grouped / depthwise convs):
+// psum / psq [gridDim.y][C] of the stored (bf16) values
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct FStats { const bf16* x; int ldx; float* psum; float* psq; long M; int C; long RB; };
+
+__global__ __launch_bounds__(256) void fused_stats_kernel(const FStats p) {
+    __shared__ FusedLds L;
+    __shared__ float scratch[4096];
+    const int c0 = blockIdx.x * FCH;
+    const int nch = p.C - c0 < FCH ? p.C - c0 : FCH;
+    const int cln = nch >> 3, rln = 256 / cln;
+    const int tid = threadIdx.x, cl = tid % cln, rl = tid / cln;
+    const bool active = rl < rln;
+    const int c = c0 + cl * 8;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
+    const long m0 = (long)blockIdx.y * p.RB;
+    long m1 = m0 + p.RB;
+    if (m1 > p.M) m1 = p.M;
+    if (active) {
+        long m = m0 + rl;
+        for (; m + 3 * rln < m1; m += 4 * rln) {
+            bf16x8 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = ld8(p.x + (m + i * rln) * p.ldx + c);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const float f = bf2f(v[i][k]); s1[k] += f; s2[k] += f * f; }
+        }
+        for (; m < m1; m += rln) {
+            const bf16x8 v = ld8(p.x + m * p.ldx + c);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const float f = bf2f(v[k]); s1[k] += f; s2[k] += f * f; }
+        }
+    }
+    chunk_row_reduce<2>(s1, s2, active, cln, rln, cl, rl, c0, nch, p.C, p.psum, p.psq, scratch, L);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// SE backward, first pass over (dbg, z2): b = relu(bn2(z2)) (bf16-rounded as the forward pass saw it),
+//   dgate partial[rb][c] = sum_rows dbg * b          (gradient of the gate, per row block inside one image)
+//   bg = b * gate[n][c]   (bf16)                      (the operand of conv_block_3's weight gradient, materialised only here)
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct FSeBwd {
+    const bf16* dbg; int ldd; const bf16* z; int ldz; const float* coef; const float* gate; long HW;
+    bf16* bg; int ldb; float* pdot; long M; int C; long RB;
+};
+
+__global__ __launch_bounds__(256) void fused_se_bwd_kernel(const FSeBwd p) {
+    __shared__ FusedLds L;
+    __shared__ float scratch[2048];
+    const int c0 = blockIdx.x * FCH;
+    const int nch = p.C - c0 < FCH ? p.C - c0 : FCH;
+    const int tid = threadIdx.x;
+    if (tid < nch) { L.coef[0][tid] = p.coef[c0 + tid]; L.coef[1][tid] = p.coef[p.C + c0 + tid]; }
+    __syncthreads();
+    const int cln = nch >> 3, rln = 256 / cln;
+    const int cl = tid % cln, rl = tid / cln;
+    const bool active = rl < rln;
+    const int c = c0 + cl * 8;
+    const long m0 = (long)blockIdx.y * p.RB;
+    long m1 = m0 + p.RB;
+    if (m1 > p.M) m1 = p.M;
+    float sc[8], sh[8], gt[8], acc[8], dummy[8];
+    const long n = m0 / p.HW;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        sc[k] = L.coef[0][cl * 8 + k]; sh[k] = L.coef[1][cl * 8 + k]; acc[k] = 0.f; dummy[k] = 0.f;
+        gt[k] = active ? p.gate[n * p.C + c + k] : 0.f;
+    }
+    auto one = [&](const bf16x8& vd, const bf16x8& vz, long m) {
+        bf16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float b = bf2f(vz[k]) * sc[k] + sh[k];
+            b = bfround(b > 0.f ? b : 0.f);
+            acc[k] += bf2f(vd[k]) * b;
+            o[k] = f2bf(b * gt[k]);
+        }
+        if (p.bg) st8(p.bg + m * p.ldb + c, o);
+    };
+    if (active) {
+        long m = m0 + rl;
+        for (; m + rln < m1; m += 2 * rln) {
+            const long mb = m + rln;
+            const bf16x8 vd0 = ld8(p.dbg + m * p.ldd + c), vd1 = ld8(p.dbg + mb * p.ldd + c);
+            const bf16x8 vz0 = ld8(p.z + m * p.ldz + c), vz1 = ld8(p.z + mb * p.ldz + c);
+            one(vd0, vz0, m);
+            one(vd1, vz1, mb);
+        }
+        if (m < m1) one(ld8(p.dbg + m * p.ldd + c), ld8(p.z + m * p.ldz + c), m);
+    }
+    chunk_row_reduce<1>(acc, dummy, active, cln, rln, cl, rl, c0, nch, p.C, p.pdot, nullptr, scratch, L);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------------------
+// rows per row block: ~2 workgroups per CU over (chunks x row blocks), at most 512 row blocks (= partial rows a consumer's prologue
+// reduces), at least 16 rows; a divisor of `align` (rows per image) when given.
+extern "C" long hn_fused_row_block(long M, int C, long align) {
+    const long chunks = (C + FCH - 1) / FCH;
+    long nrb = (512 + chunks - 1) / chunks;
+    if (nrb > 512) nrb = 512;
+    long RB = (M + nrb - 1) / nrb;
+    if (RB < 16) RB = 16;
+    if (align > 0) {
+        if (RB > align) RB = align;
+        while (align % RB) --RB;
+        while ((M + RB - 1) / RB > 512 && RB < align) { ++RB; while (align % RB) ++RB; }
+    }
+    return RB;
+}
+
+static dim3 fused_grid(long M, int C, long RB) { return dim3((unsigned)((C + FCH - 1) / FCH), (unsigned)((M + RB - 1) / RB)); }
+
+extern "C" int hn_bn_apply_fused(const void* z, int ldz, long M, int C, const float* psum, const float* psq, int P, long count, const float* gamma,
+                                 const float* beta, float eps, float momentum, float* rm, float* rv, float* coef, const void* res, int ldr,
+                                 int act, void* out, int ldo, float* pool, long RB, hipStream_t st) {
+    HN_CHECK_ARG(z && M > 0 && C > 0 && (C & 7) == 0 && (ldz & 7) == 0 && RB > 0 && (out || pool));
+    HN_CHECK_ARG(P <= 0 || (psum && psq && gamma && beta && count > 0));
+    HN_CHECK_ARG(P >= 0 || (gamma && beta && rm && rv));
+    HN_CHECK_ARG((!res || (ldr & 7) == 0) && (!out || (ldo & 7) == 0));
+    FApply p;
+    p.z = (const bf16*)z; p.ldz = ldz;
+    p.bn.psum = psum; p.bn.psq = psq; p.bn.P = P; p.bn.count = (double)count; p.bn.gamma = gamma; p.bn.beta = beta; p.bn.eps = eps;
+    p.bn.momentum = momentum; p.bn.rm = rm; p.bn.rv = rv; p.bn.coef = coef;
+    p.res = (const bf16*)res; p.ldr = ldr; p.act = act; p.out = (bf16*)out; p.ldo = ldo; p.pool = pool; p.M = M; p.C = C; p.RB = RB;
+    hipLaunchKernelGGL(fused_apply_kernel, fused_grid(M, C, RB), dim3(256), 0, st, p);
+    HN_LAUNCH_CHECK();
+}
+
+static int fill_bwd(FBwd& p, const void* dout, int ldd, const void* z, int ldz, const void* y, int ldy, const float* coef, int act,
+                    const float* gate, const float* dpool, long HW, float* pg, float* pgx, long M, int C, long RB) {
+    HN_CHECK_ARG(dout && z && coef && pg && pgx && M > 0 && C > 0 && (C & 7) == 0 && (ldd & 7) == 0 && (ldz & 7) == 0 && RB > 0);
+    HN_CHECK_ARG((!y || (ldy & 7) == 0) && (!gate || (dpool && HW > 0 && HW % RB == 0)));
+    p = FBwd{};
+    p.dout = (const bf16*)dout; p.ldd = ldd; p.z = (const bf16*)z; p.ldz = ldz; p.y = (const bf16*)y; p.ldy = ldy; p.coef = coef; p.act = act;
+    p.gate = gate; p.dpool = dpool; p.HW = HW; p.pg = pg; p.pgx = pgx; p.M = M; p.C = C; p.RB = RB;
+    return HN_OK;
+}
+
+extern "C" int hn_bn_bwd_reduce_fused(const void* dout, int ldd, const void* z, int ldz, const void* y, int ldy, const float* coef, int act,
+                                      const float* gate, const float* dpool, long HW, long M, int C, long RB, float* pg, float* pgx,
+                                      hipStream_t st) {
+    FBwd p;
+    const int rc = fill_bwd(p, dout, ldd, z, ldz, y, ldy, coef, act, gate, dpool, HW, pg, pgx, M, C, RB);
+    if (rc) return rc;
+    hipLaunchKernelGGL(fused_bwd_kernel<false>, fused_grid(M, C, RB), dim3(256), 0, st, p);
+    HN_LAUNCH_CHECK();
+}
+
+extern "C" int hn_bn_bwd_apply_fused(const void* dout, int ldd, const void* z, int ldz, const void* y, int ldy, const float* coef, int act,
+                                     const float* gate, const float* dpool, long HW, const float* pg, const float* pgx, int P, long count,
+                                     float* dgamma, float* dbeta, void* dz, int lddz, void* gout, int ldg, long M, int C, long RB,
+                                     hipStream_t st) {
+    FBwd p;
+    const int rc = fill_bwd(p, dout, ldd, z, ldz, y, ldy, coef, act, gate, dpool, HW, (float*)pg, (float*)pgx, M, C, RB);
+    if (rc) return rc;
+    HN_CHECK_ARG(P > 0 && count > 0 && dgamma && dbeta && dz && (lddz & 7) == 0 && (!gout || (ldg & 7) == 0));
+    p.P = P; p.count = (double)count; p.dgamma = dgamma; p.dbeta = dbeta; p.dz = (bf16*)dz; p.lddz = lddz; p.gout = (bf16*)gout; p.ldg = ldg;
+    hipLaunchKernelGGL(fused_bwd_kernel<true>, fused_grid(M, C, RB), dim3(256), 0, st, p);
+    HN_LAUNCH_CHECK();
+}
+
+extern "C" int hn_col_stats_fused(const void* x, int ldx, long M, int C, long RB, float* psum, float* psq, hipStream_t st) {
+    HN_CHECK_ARG(x && psum && psq && M > 0 && C > 0 && (C & 7) == 0 && (ldx & 7) == 0 && RB > 0);
+    FStats p = {(const bf16*)x, ldx, psum, psq, M, C, RB};
+    hipLaunchKernelGGL(fused_stats_kernel, fused_grid(M, C, RB), dim3(256), 0, st, p);
+    HN_LAUNCH_CHECK();
+}
+
+extern "C" int hn_se_bwd_reduce_fused(const void* dbg, int ldd, const void* z, int ldz, const float* coef, const float* gate, long HW, void* bg,
+                                      int ldb, float* pdot, long M, int C, long RB, hipStream_t st) {
+    HN_CHECK_ARG(dbg && z && coef && gate && pdot && M > 0 && C > 0 && (C & 7) == 0 && (ldd & 7) == 0 && (ldz & 7) == 0);
+    HN_CHECK_ARG(RB > 0 && HW > 0 && HW % RB == 0 && (!bg || (ldb & 7) == 0));
+    FSeBwd p = {(const bf16*)dbg, ldd, (const bf16*)z, ldz, coef, gate, HW, (bf16*)bg, ldb, pdot, M, C, RB};
+    hipLaunchKernelGGL(fused_se_bwd_kernel, fused_grid(M, C, RB), dim3(256), 0, st, p);
+    HN_LAUNCH_CHECK();
+}

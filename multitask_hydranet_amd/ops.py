@@ -292,6 +292,65 @@ def k_eltwise(op, a, b=None, act=ACT_NONE, alpha=1.0, out=None):
     return out
 
 
+FUSED_BN = True            # BatchNorm finalize in the prologue of the consuming elementwise kernel (hn_fused.hip); False: round-1 kernels
+MAX_PROLOGUE_ROWS = 512    # partial statistic rows a consumer prologue reduces itself; more are folded to 32 rows first (one launch)
+
+
+def k_col_stats_fused(x, align=0):
+    """per-row-block channel sums / sums of squares of a bf16 tensor: (psum, psq) [P <= 512][C]"""
+    m, c = rows(x), x.shape[3]
+    rb = lib().query("hn_fused_row_block", m, c, align)
+    pr = (m + rb - 1) // rb
+    ps = torch.empty((pr, c), device=x.device, dtype=F32)
+    pq = torch.empty((pr, c), device=x.device, dtype=F32)
+    lib().call("hn_col_stats_fused", ptr(x), ld(x), m, c, rb, ptr(ps), ptr(pq))
+    return ps, pq
+
+
+def k_bn_apply_fused(z, psum, psq, count, gamma, beta, eps, momentum, rm, rv, act, res=None, out=None, want_out=True, pool_align=0,
+                     training=True):
+    """out = act(BN(z) [+ res]) with the BatchNorm finalize in the kernel prologue.  Returns (out, coef [4, C], pool_partials | None, RB)."""
+    n, h, w, c = z.shape
+    m = rows(z)
+    dev = z.device
+    if training:
+        if psum.shape[0] > MAX_PROLOGUE_ROWS:
+            psum, psq = fold_rows(psum, psq, limit=MAX_PROLOGUE_ROWS)
+        P = psum.shape[0]
+    else:
+        P = -1
+    rb = lib().query("hn_fused_row_block", m, c, pool_align)
+    coef = torch.empty((4, c), device=dev, dtype=F32)
+    if want_out and out is None:
+        out = new_act(n, h, w, c, dev)
+    pool = torch.empty(((m + rb - 1) // rb, c), device=dev, dtype=F32) if pool_align else None
+    lib().call("hn_bn_apply_fused", ptr(z), ld(z), m, c, ptr(psum) if training else None, ptr(psq) if training else None, P, count,
+               ptr(gamma), ptr(beta), float(eps), float(momentum), ptr(rm), ptr(rv), ptr(coef), ptr(res), ld(res) if res is not None else 0,
+               act, ptr(out) if want_out else None, ld(out) if want_out else 0, ptr(pool), rb)
+    return out, coef, pool, rb
+
+
+def bn_backward_fused(dout, z, y, coef, act, count, want_g=False, gate=None, dpool=None, hw=0):
+    """BatchNorm(+activation) backward in two launches (reduce, apply with the finalize in its prologue): (dz, dgamma, dbeta, g|None)."""
+    n, h, w, c = z.shape
+    m = rows(z)
+    dev = z.device
+    rb = lib().query("hn_fused_row_block", m, c, hw)
+    pr = (m + rb - 1) // rb
+    pg = torch.empty((pr, c), device=dev, dtype=F32)
+    pgx = torch.empty((pr, c), device=dev, dtype=F32)
+    lib().call("hn_bn_bwd_reduce_fused", ptr(dout), ld(dout), ptr(z), ld(z), ptr(y), ld(y) if y is not None else 0, ptr(coef), act,
+               ptr(gate), ptr(dpool), hw, m, c, rb, ptr(pg), ptr(pgx))
+    dgamma = torch.empty((c,), device=dev, dtype=F32)
+    dbeta = torch.empty((c,), device=dev, dtype=F32)
+    dz = new_act(n, h, w, c, dev)
+    g = new_act(n, h, w, c, dev) if want_g else None
+    lib().call("hn_bn_bwd_apply_fused", ptr(dout), ld(dout), ptr(z), ld(z), ptr(y), ld(y) if y is not None else 0, ptr(coef), act,
+               ptr(gate), ptr(dpool), hw, ptr(pg), ptr(pgx), pr, count, ptr(dgamma), ptr(dbeta), ptr(dz), ld(dz), ptr(g),
+               ld(g) if g is not None else 0, m, c, rb)
+    return dz, dgamma, dbeta, g
+
+
 def bn_backward(dout, z, y, coef, act, count, want_g=False):
     """shared BatchNorm(+activation) backward: returns (dz, dgamma, dbeta, g|None)."""
     n, h, w, c = z.shape
@@ -351,21 +410,29 @@ class ConvBnAct(torch.autograd.Function):
             z, psum, psq = k_gemm_nt(x, None, 0 if stride == 1 else 1, (n, ho, wo), packs[0], cout, kp32(cin), 1, bias=conv_bias,
                                      stats=training)
         count = n * ho * wo
-        if training:
-            if psum is None:
-                psum, psq, _ = k_col_stats(z)
-            coef = k_bn_finalize(psum, psq, count, gamma, beta, eps, momentum, rm, rv)
-            if nbt is not None:
+        if FUSED_BN:
+            if training and psum is None:
+                psum, psq = k_col_stats_fused(z)
+            out, coef, _, _ = k_bn_apply_fused(z, psum, psq, count, gamma, beta, eps, momentum, rm, rv, act, res=res, training=training)
+            if training and nbt is not None:
                 nbt.add_(1)
         else:
-            coef = k_bn_eval_coeff(gamma, beta, rm, rv, eps)
-        out = k_bn_act(z, coef, act, res=res)
+            if training:
+                if psum is None:
+                    psum, psq, _ = k_col_stats(z)
+                coef = k_bn_finalize(psum, psq, count, gamma, beta, eps, momentum, rm, rv)
+                if nbt is not None:
+                    nbt.add_(1)
+            else:
+                coef = k_bn_eval_coeff(gamma, beta, rm, rv, eps)
+            out = k_bn_act(z, coef, act, res=res)
         ctx.kind, ctx.stride, ctx.act, ctx.count = kind, stride, act, count
         ctx.has_bias = conv_bias is not None
         ctx.has_res = res is not None
         ctx.training = training
         ctx.packs = packs
-        y_save = out if (act == ACT_RELU) else None
+        # ReLU mask: recomputed from z in backward (scale*z+shift > 0); the saved output is only needed when a residual went into the ReLU
+        y_save = out if (act == ACT_RELU and (res is not None or not FUSED_BN)) else None
         ctx.save_for_backward(x, weight, z, coef, y_save, gamma)
         return out
 
@@ -375,7 +442,8 @@ class ConvBnAct(torch.autograd.Function):
         assert ctx.training, "backward through eval-mode BatchNorm is not part of the hot path"
         dout = dense(dout)
         kind, stride = ctx.kind, ctx.stride
-        dz, dgamma, dbeta, g = bn_backward(dout, z, y, coef, ctx.act, ctx.count, want_g=ctx.has_res and ctx.act != ACT_NONE)
+        dz, dgamma, dbeta, g = (bn_backward_fused if FUSED_BN else bn_backward)(dout, z, y, coef, ctx.act, ctx.count,
+                                                                                want_g=ctx.has_res and ctx.act != ACT_NONE)
         dres = None
         if ctx.has_res:
             dres = g if g is not None else dout

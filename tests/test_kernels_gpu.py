@@ -77,6 +77,9 @@ def bn_tuple(c):
     (64, 376, 2, 0, False, False, 2, 8, 12),
     (376, 112, 1, 2, False, True, 3, 5, 7),
     (936, 936, 1, 1, True, False, 2, 4, 4),
+    (64, 152, 1, 1, True, False, 4, 64, 64),        # many row blocks, ragged last 64-channel chunk, 256 partial statistic rows
+    (32, 24, 1, 1, False, False, 4, 128, 256),      # > 512 partial rows: folded before the fused apply
+    (376, 376, 1, 2, False, False, 16, 16, 32),     # deep-stage shape (stage 3 at N = 16), Swish
 ])
 def test_conv1x1_bn_act(K, cin, cout, stride, act, res, bias, n, h, w):
     x = rnd(n, cin, h, w)
