@@ -54,6 +54,16 @@ int hn_conv_gemm_nt(const void* x0, const void* x1, int mode, int n_img, int H, 
                     const void* w, int Nout, int KP, int taps, const float* bias, int act, void* out, int out_f32, int ldc, long rpi,
                     long img_stride, float* psum, float* psq, hipStream_t stream);
 int hn_nt_stat_rows(long M, int Nout);
+/* mode 5 with psum/psq: one partial row per 16x16 output patch */
+int hn_direct_stat_rows(int n_img, int H, int W);
+/* hn_conv_gemm_nt with (a) an operand transform for modes 0/1 (bf16 output): the pixel operand is act(xscale[c]*x + xshift[c]) rounded to
+ * bf16 and optionally multiplied by xgate[row / xhw][c] -- BatchNorm apply (+ReLU, + SE gate) of the producer folded into this conv's
+ * operand path (net/anynet.py:67-70: conv_block_3 consumes SE(relu(bn2(conv_block_2)))), nothing materialised; and (b) an addend for the
+ * staged bf16 epilogue: out = bf16(bf16(acc) + addend[pixel][cout]) (the residual-gradient add of an XBlock's conv_block_1 dgrad). */
+int hn_conv_gemm_nt_ex(const void* x0, const void* x1, int mode, int n_img, int H, int W, int C0, int C1, int ld0, int ld1, int up, long M,
+                       const void* w, int Nout, int KP, int taps, const float* bias, int act, void* out, int out_f32, int ldc, long rpi,
+                       long img_stride, float* psum, float* psq, const float* xscale, const float* xshift, const float* xgate, long xhw,
+                       int xact, const void* addend, int ld_add, hipStream_t stream);
 /* tuning hook for tools/: force the cout tile (16/32/64/128) and LDS ring depth (2..4) of later hn_conv_gemm_nt launches; 0 = automatic */
 int hn_debug_nt_config(int bc, int r);
 int hn_debug_tn_config(int bc, int bn, int splits);
@@ -220,6 +230,13 @@ int hn_se_bwd_apply(const void* dout, int ldd, const float* gate, const float* d
  * the four parameter gradients (dpre2 [N,C], dpre1 [N,Cs] are scratch).  Replaces the two 1x1 nn.Conv2d of net/anynet.py:44-47. */
 int hn_se_mlp_fwd(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2, float* hid, float* gate, int N,
                   int C, int Cs, hipStream_t stream);
+/* forms fed by partial rows (S per image): pooled = alpha * sum of the squeeze partials of hn_bn_apply_fused (stored to `pooled`), and
+ * dgate = sum of the partials of hn_se_bwd_reduce_fused -- the reductions ride on the first MLP kernel instead of their own launches */
+int hn_se_mlp_fwd_parts(const float* pool_part, int S, float alpha, const float* w1, const float* b1, const float* w2, const float* b2,
+                        float* pooled, float* hid, float* gate, int N, int C, int Cs, hipStream_t stream);
+int hn_se_mlp_bwd_parts(const float* dgate_part, int S, const float* gate, const float* hid, const float* pooled, const float* w1,
+                        const float* w2, float* dpre2, float* dpre1, float* dpool, float* dw1, float* db1, float* dw2, float* db2, int N,
+                        int C, int Cs, hipStream_t stream);
 int hn_se_mlp_bwd(const float* dgate, const float* gate, const float* hid, const float* pooled, const float* w1, const float* w2,
                   float* dpre2, float* dpre1, float* dpool, float* dw1, float* db1, float* dw2, float* db2, int N, int C, int Cs,
                   hipStream_t stream);

@@ -134,10 +134,15 @@ struct GemmNT {
     long img_stride; // out offset(pix) = (pix / rpi) * img_stride + (pix % rpi) * ldc  (det-head level concat)
     int d2s;         // direct 3x3 kernel, fp32 out: cout c = phase*d2s + o is stored depth-to-space, out[n][2y+phase/2][2x+phase%2][o]
                      // with d2s channels per output pixel (the 4-phase final seg conv writes the logits in place, no shuffle pass)
+    // operand transform (XF kernels, mode 0/1): the pixel operand is act(xscale[c]*x + xshift[c]) (rounded to bf16) [* xgate[row / xhw][c]]
+    // applied between the global load and the LDS store -- a BatchNorm apply (+ ReLU, + SE gate) that is never materialised
+    const float* xscale; const float* xshift; const float* xgate; long xhw; int xact;
+    const bf16* addend; int ld_add;   // staged bf16 epilogue: out = bf16(bf16(acc) + addend[pix][co])  (residual-gradient add of a dgrad)
 };
 
-template <int BC, int BP, int WGC, int WGP, bool OUT_F32, int R>
+template <int BC, int BP, int WGC, int WGP, bool OUT_F32, int R, bool XF = false>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
+    static_assert(!XF || R == 2, "the register-staged operand transform is written for the double buffer");
     constexpr int WC = BC / WGC, WP = BP / WGP, TC = WC / 16, TP = WP / 16;
     constexpr int XR = BP / 32, WR = (BC + 31) / 32;
     constexpr int STAGE = (BC + BP) * 128;                        // one K stage (64 k) of both operands
@@ -240,13 +245,28 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
     // stages go out back to back (one memory latency for short K instead of one per stage); nothing is issued past the last stage.
     constexpr int G = XR + WR;
     static_assert(R == 2 || BC >= 32, "deeper rings need every wave to issue the same number of loads");
+    // XF: the pixel operand of the stage in flight lives in registers (raw rows + the per-channel coefficients of its 8 channels + the
+    // per-image gate) and is transformed / stored to LDS after the MFMAs of the previous stage
+    bf16x8 xraw[XF ? XR : 1];
+    f32x4 xsc[2], xsh[2], xgt[XF ? XR : 1][2];
+    bool xval[XF ? XR : 1];
+    int ximg[XF ? XR : 1];
+    if (XF) {
+#pragma unroll
+        for (int i = 0; i < XR; ++i) {
+            const long m = p_blk + r0 + 32 * i;
+            ximg[i] = (p.xgate && m < p.x.M) ? (int)(m / p.xhw) : 0;
+        }
+    }
     for (int it = 0; it < S + R - 1; ++it) {
         if (it >= R - 1) {
             const int newer = (it < S ? it : S) - 1 - (it - (R - 1));
-            if (R >= 4 && newer >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * G) : "memory");
+            if (XF) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else if (R >= 4 && newer >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * G) : "memory");
             else if (R >= 3 && newer >= 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(G) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         }
+        bool xcv = false;
         if (it < S) {
             char* sW = smem + (it % R) * STAGE;
             char* sX = sW + BC * 128;
@@ -257,11 +277,30 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
             const bool cv = qv && c < Ctot;
             const bf16* xbase = from0 ? p.x.x0 + c : p.x.x1 + (c - p.x.C0);
             const long ldx = from0 ? p.x.ld0 : p.x.ld1;
+            if (XF) {
+                xcv = cv;
+                if (cv) {
+                    xsc[0] = *reinterpret_cast<const f32x4*>(p.xscale + c); xsc[1] = *reinterpret_cast<const f32x4*>(p.xscale + c + 4);
+                    xsh[0] = *reinterpret_cast<const f32x4*>(p.xshift + c); xsh[1] = *reinterpret_cast<const f32x4*>(p.xshift + c + 4);
+                }
+#pragma unroll
+                for (int i = 0; i < XR; ++i) {
+                    const int pix = from0 ? pix0[i] : pix1[i];
+                    xval[i] = cv && pix >= 0;
+                    const bf16* src = xval[i] ? xbase + (long)pix * ldx : g_zero_piece;
+                    xraw[i] = ld8(src);
+                    if (p.xgate && xval[i]) {
+                        const float* gp = p.xgate + (long)ximg[i] * Ctot + c;
+                        xgt[i][0] = *reinterpret_cast<const f32x4*>(gp); xgt[i][1] = *reinterpret_cast<const f32x4*>(gp + 4);
+                    }
+                }
+            } else {
 #pragma unroll
             for (int i = 0; i < XR; ++i) {
                 const int pix = from0 ? pix0[i] : pix1[i];
                 const bf16* src = (cv && pix >= 0) ? xbase + (long)pix * ldx : g_zero_piece;
                 glds16(src, sX + (wave * 8 + 32 * i) * 128);
+            }
             }
 #pragma unroll
             for (int i = 0; i < WR; ++i) {
@@ -296,6 +335,27 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
             }
         }
+        if (XF && it < S) {                                       // transform the stage in flight and store it where the DMA would have
+            char* sX = smem + (it % R) * STAGE + BC * 128;
+#pragma unroll
+            for (int i = 0; i < XR; ++i) {
+                bf16x8 o = zero8();
+                if (xval[i]) {
+                    float v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = bf2f(xraw[i][k]) * xsc[k >> 2][k & 3] + xsh[k >> 2][k & 3];
+                    act_fwd_n(v, p.xact);
+                    if (p.xgate) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] = bfround(v[k]) * xgt[i][k >> 2][k & 3];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) o[k] = f2bf(v[k]);
+                }
+                *reinterpret_cast<bf16x8*>(sX + (wave * 8 + 32 * i) * 128 + lane * 16) = o;
+            }
+        }
+        (void)xcv;
     }
 
     // ---- epilogue: bias, activation, optional BN partial statistics; store.  bf16 outputs whose rows are 16-B aligned go through an
@@ -407,11 +467,16 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
             const long pix = p_blk + row;
             const int co = c_blk + pc * 8;
             if (pix < p.x.M && co < p.Nout) {
-                const bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + row * (BC * 2) + (((pc ^ row) & (NPC - 1)) << 4));
+                bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + row * (BC * 2) + (((pc ^ row) & (NPC - 1)) << 4));
                 long orow = pix * p.ldc;
                 if (p.rpi) {
                     const unsigned im = (unsigned)pix / (unsigned)p.rpi;
                     orow = (long)im * p.img_stride + (long)((unsigned)pix - im * (unsigned)p.rpi) * p.ldc;
+                }
+                if (p.addend) {
+                    const bf16x8 a = ld8(p.addend + pix * p.ld_add + co);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = f2bf(bf2f(v[k]) + bf2f(a[k]));
                 }
                 *reinterpret_cast<bf16x8*>(outp + orow + co) = v;
             }
@@ -564,6 +629,46 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
             }
         }
         if (it > 0 && !boundary) compute(it - 1);
+    }
+
+    // optional BatchNorm partial statistics of the bf16-rounded outputs: one row per workgroup (patch), psum/psq [gridDim.x / ncy][Nout];
+    // wave sums by DPP row rotations, the WGP pixel-row groups are folded through LDS (the operand buffers are free now)
+    if (p.psum) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);                  // [WGP][BC][2]
+        const int oxs = ox0 + (lane & 15);
+#pragma unroll
+        for (int i = 0; i < TC; ++i) {
+            const int cl = wc * WCO + i * 16 + (lane >> 4) * 4;
+            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                const bool pv = (oy0 + wp * ROWS + j) < xs.H && oxs < xs.W;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float bsr = (p.bias && c_blk + cl + r < p.Nout) ? p.bias[c_blk + cl + r] : 0.f;
+                    float q = OUT_F32 ? acc[i][j][r] + bsr : bfround(acc[i][j][r] + bsr);
+                    q = pv ? q : 0.f;
+                    s1[r] += q;
+                    s2[r] += q * q;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s1[r] = row16_sum(s1[r]); s2[r] = row16_sum(s2[r]); }
+            if ((lane & 15) == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { red[(wp * BC + cl + r) * 2] = s1[r]; red[(wp * BC + cl + r) * 2 + 1] = s2[r]; }
+            }
+        }
+        __syncthreads();
+        if (tid < BC && c_blk + tid < p.Nout) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < WGP; ++k) { t1 += red[(k * BC + tid) * 2]; t2 += red[(k * BC + tid) * 2 + 1]; }
+            const long prow = lid / ncy;
+            p.psum[prow * p.Nout + c_blk + tid] = t1;
+            p.psq[prow * p.Nout + c_blk + tid] = t2;
+        }
     }
 
     // epilogue: bias, activation (one uniform branch per 4 values, in place on the accumulators: no second copy of the wave tile in
@@ -1104,6 +1209,15 @@ static int launch_nt_r(const GemmNT& p, int out_f32, hipStream_t st) {
     HN_LAUNCH_CHECK();
 }
 
+// operand-transform variant (bf16 output, double buffer)
+template <int BC, int BP, int WGC, int WGP>
+static int launch_nt_xf(const GemmNT& p, hipStream_t st) {
+    dim3 grid(cdiv(p.x.M, BP) * cdiv(p.Nout, BC));
+    const size_t lds = (size_t)(BC + BP) * 128 * 2;
+    hipLaunchKernelGGL((gemm_nt_kernel<BC, BP, WGC, WGP, false, 2, true>), grid, dim3(256), lds, st, p);
+    HN_LAUNCH_CHECK();
+}
+
 // Tuning hook (tools/ only): force the cout tile and/or ring depth of the next hn_conv_gemm_nt launches; 0 = automatic.
 static int g_nt_force_bc = 0, g_nt_force_r = 0;
 extern "C" int hn_debug_nt_config(int bc, int r) { g_nt_force_bc = bc; g_nt_force_r = r; return 0; }
@@ -1139,6 +1253,9 @@ static int pick_bc(int Nout) {
 // which overlap each other's load / wait / MFMA phases (a 64x128 tiling leaves one workgroup per CU waiting on its own loads).
 static bool small_tile(long M, int Nout) { return !g_nt_force_bc && Nout > 64 && (M <= 8192 || (M <= 32768 && Nout <= 128)); }
 
+// partial statistic rows of a mode-5 (grouped 3x3 on the direct kernel) launch: one per 16x16 output patch
+extern "C" int hn_direct_stat_rows(int n_img, int H, int W) { return n_img * cdiv(H, 16) * cdiv(W, 16); }
+
 extern "C" int hn_nt_stat_rows(long M, int Nout) {
     if (small_tile(M, Nout)) return cdiv(M, 64) * 2;
     const int bc = pick_bc(Nout);
@@ -1147,13 +1264,39 @@ extern "C" int hn_nt_stat_rows(long M, int Nout) {
     return cdiv(M, 128) * 2;
 }
 
+static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img, int H, int W, int C0, int C1, int ld0, int ld1,
+                             int up, long M, const void* w, int Nout, int KP, int taps, const float* bias, int act, void* out,
+                             int out_f32, int ldc, long rpi, long img_stride, float* psum, float* psq, const float* xscale,
+                             const float* xshift, const float* xgate, long xhw, int xact, const void* addend, int ld_add, hipStream_t st);
+
 extern "C" int hn_conv_gemm_nt(const void* x0, const void* x1, int mode, int n_img, int H, int W, int C0, int C1, int ld0, int ld1,
                                int up, long M, const void* w, int Nout, int KP, int taps, const float* bias, int act, void* out,
                                int out_f32, int ldc, long rpi, long img_stride, float* psum, float* psq, hipStream_t st) {
+    return conv_gemm_nt_impl(x0, x1, mode, n_img, H, W, C0, C1, ld0, ld1, up, M, w, Nout, KP, taps, bias, act, out, out_f32, ldc, rpi,
+                             img_stride, psum, psq, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, st);
+}
+
+extern "C" int hn_conv_gemm_nt_ex(const void* x0, const void* x1, int mode, int n_img, int H, int W, int C0, int C1, int ld0, int ld1,
+                                  int up, long M, const void* w, int Nout, int KP, int taps, const float* bias, int act, void* out,
+                                  int out_f32, int ldc, long rpi, long img_stride, float* psum, float* psq, const float* xscale,
+                                  const float* xshift, const float* xgate, long xhw, int xact, const void* addend, int ld_add,
+                                  hipStream_t st) {
+    return conv_gemm_nt_impl(x0, x1, mode, n_img, H, W, C0, C1, ld0, ld1, up, M, w, Nout, KP, taps, bias, act, out, out_f32, ldc, rpi,
+                             img_stride, psum, psq, xscale, xshift, xgate, xhw, xact, addend, ld_add, st);
+}
+
+static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img, int H, int W, int C0, int C1, int ld0, int ld1,
+                             int up, long M, const void* w, int Nout, int KP, int taps, const float* bias, int act, void* out,
+                             int out_f32, int ldc, long rpi, long img_stride, float* psum, float* psq, const float* xscale,
+                             const float* xshift, const float* xgate, long xhw, int xact, const void* addend, int ld_add, hipStream_t st) {
     HN_CHECK_ARG(x0 && w && out && M > 0 && Nout > 0 && KP > 0 && (KP & 31) == 0 && taps >= 1 && taps <= 9);
+    // operand transform: plain / stride-2 row gathers, bf16 output; addend: staged bf16 epilogue only (aligned rows, no per-image mapping)
+    HN_CHECK_ARG(!xscale || (xshift && mode <= 1 && !out_f32 && C1 == 0 && (!xgate || xhw > 0)));
+    HN_CHECK_ARG(!addend || (!out_f32 && (Nout & 7) == 0 && (ldc & 7) == 0 && (ld_add & 7) == 0 && rpi == 0 && mode <= 1 &&
+                             (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(addend) & 15) == 0));
     HN_CHECK_ARG((C0 & 7) == 0 && (C1 & 7) == 0 && (ld0 & 7) == 0 && (C1 == 0 || (x1 && (ld1 & 7) == 0)));
     HN_CHECK_ARG(mode >= 0 && mode <= 5 && (mode < 4 || (up == 0 && C1 == 0)));
-    HN_CHECK_ARG(mode == 5 ? (KP == 64 && Nout == C0 && !psum && !rpi) : C0 + C1 <= KP);
+    HN_CHECK_ARG(mode == 5 ? (KP == 64 && Nout == C0 && !rpi) : C0 + C1 <= KP);
     HN_CHECK_ARG(mode == 0 || (long)n_img * H * W == M);
     HN_CHECK_ARG(mode < 2 ? taps == 1 : taps == 9);
     HN_CHECK_ARG(mode != 2 || (H >= 2 && W >= 2));
@@ -1164,12 +1307,14 @@ extern "C" int hn_conv_gemm_nt(const void* x0, const void* x1, int mode, int n_i
     p.bias = bias; p.act = act; p.out = out; p.ldc = ldc; p.psum = psum; p.psq = psq;
     p.rpi = rpi; p.img_stride = img_stride;
     p.d2s = 0;
+    p.xscale = xscale; p.xshift = xshift; p.xgate = xgate; p.xhw = xhw; p.xact = xact;
+    p.addend = (const bf16*)addend; p.ld_add = ld_add;
     if (img_stride < 0) {                                            // mode 4 + fp32 out: -img_stride = channels per depth-to-space output pixel
         HN_CHECK_ARG(p.x.clamp == 1 && out_f32 && rpi == 0 && !psum && Nout == 4 * (int)(-img_stride));
         p.d2s = (int)(-img_stride);
         p.img_stride = 0;
     }
-    if (mode >= 2 && !psum && !rpi) {
+    if (mode >= 2 && (!psum || p.x.diag) && !rpi) {      // statistics epilogue: grouped convs only (one partial row per 16x16 patch)
         const int bc = p.x.diag ? 64 : (Nout <= 16 ? 16 : (Nout <= 64 ? 64 : 128));
         dim3 grid((unsigned)(cdiv(Nout, bc) * cdiv(W, 16) * cdiv(H, 16) * n_img));
         const size_t lds = (size_t)((18 * 18 * 128 + 1023) / 1024 * 1024) + 2 * (size_t)bc * 128;
@@ -1187,6 +1332,15 @@ extern "C" int hn_conv_gemm_nt(const void* x0, const void* x1, int mode, int n_i
         DIRECT_CASE(16) DIRECT_CASE(64) DIRECT_CASE(128)
 #undef DIRECT_CASE
         HN_LAUNCH_CHECK();
+    }
+    if (xscale) {
+        if (small_tile(M, Nout)) return launch_nt_xf<64, 64, 2, 2>(p, st);
+        switch (pick_bc(Nout)) {
+            case 16: return launch_nt_xf<16, 128, 1, 4>(p, st);
+            case 32: return launch_nt_xf<32, 128, 1, 4>(p, st);
+            case 64: return launch_nt_xf<64, 128, 2, 2>(p, st);
+            default: return launch_nt_xf<128, 128, 2, 2>(p, st);
+        }
     }
     if (small_tile(M, Nout)) return launch_nt<64, 64, 2, 2, 4>(p, out_f32, st);
     switch (pick_bc(Nout)) {

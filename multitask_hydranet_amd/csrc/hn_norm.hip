@@ -626,16 +626,29 @@ __global__ void cast_f32_kernel(const bf16* src, int lds_, float* dst, int ldo, 
 // One block per image; forward keeps hid and gate for the backward pass.
 // ---------------------------------------------------------------------------------------------------------
 // out[n][o] = act(bias[o] + sum_i W[o][i] * in[n][i]) : one wave per (n, o), lanes stride the contraction (coalesced weight rows)
+// S > 0: `in` holds S partial rows per image (in[n][i] = alpha * sum_j part[(n*S + j)][i], e.g. the SE squeeze from the per-row-block
+// channel sums of hn_bn_apply_fused); the o == 0 wave also stores the assembled vector to `store` [N][I] (kept for the backward pass).
 __global__ __launch_bounds__(256) void se_fc_rows_kernel(const float* W, const float* bias, const float* in, float* out, int N, int O, int I,
-                                                         int act) {
+                                                         int act, int S, float alpha, float* store) {
     const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (wid >= (long)N * O) return;
     const int n = (int)(wid / O), o = (int)(wid - (long)n * O);
     const float* wr = W + (long)o * I;
-    const float* xr = in + (long)n * I;
     float s = 0.f;
-    for (int i = lane; i < I; i += 64) s += wr[i] * xr[i];
+    if (S > 0) {
+        const float* pr = in + (long)n * S * I;
+        for (int i = lane; i < I; i += 64) {
+            float v = 0.f;
+            for (int j = 0; j < S; ++j) v += pr[(long)j * I + i];
+            v *= alpha;
+            if (store && o == 0) store[(long)n * I + i] = v;
+            s += wr[i] * v;
+        }
+    } else {
+        const float* xr = in + (long)n * I;
+        for (int i = lane; i < I; i += 64) s += wr[i] * xr[i];
+    }
     s = wave_sum(s);
     if (lane == 0) {
         s += bias[o];
@@ -646,18 +659,20 @@ __global__ __launch_bounds__(256) void se_fc_rows_kernel(const float* W, const f
 // out[n][o] = mask(o) * sum_i W[i][o] * f(in)[n][i]   (contraction over the ROW index of W: coalesced over o).
 // block = 64 outputs x 4 partitions of i.  pre: 0 = in as is, 1 = in * g * (1 - g) with g = aux[n][i] (sigmoid', result also stored to
 // `store`).  post: 0 none, 1 = zero where aux2[n][o] <= 0 (ReLU').
+// S > 0: `in` holds S partial rows per image (summed on the fly: the SE gate gradient from the per-row-block sums of hn_se_bwd_reduce_fused)
 __global__ __launch_bounds__(1024) void se_fc_cols_kernel(const float* W, const float* in, const float* aux, float* store, const float* aux2,
-                                                          float* out, int N, int O, int I, int pre, int post) {
+                                                          float* out, int N, int O, int I, int pre, int post, int S) {
     __shared__ float red[16][64];
     const int ox = threadIdx.x & 63, part = threadIdx.x >> 6;         // 64 outputs x 16 partitions of the contraction
     const int o = blockIdx.x * 64 + ox, n = blockIdx.y;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     const int i0 = (int)((long)I * part / 16), i1 = (int)((long)I * (part + 1) / 16);
-    const float* inr = in + (long)n * I;
+    const float* inr = in + (long)n * (S > 0 ? S : 1) * I;
     const float* auxr = aux ? aux + (long)n * I : nullptr;
     const bool ov = o < O;
     auto val = [&](int i) {
         float v = inr[i];
+        for (int j = 1; j < S; ++j) v += inr[(long)j * I + i];
         if (pre) {
             const float g = auxr[i];
             v *= g * (1.f - g);
@@ -972,20 +987,48 @@ extern "C" int hn_cast_bf16_to_f32(const void* src, int lds_, float* dst, int ld
 extern "C" int hn_se_mlp_fwd(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2, float* hid, float* gate,
                              int N, int C, int Cs, hipStream_t st) {
     HN_CHECK_ARG(pooled && w1 && b1 && w2 && b2 && hid && gate && N > 0 && C > 0 && Cs > 0);
-    hipLaunchKernelGGL(se_fc_rows_kernel, dim3(cdiv((long)N * Cs, 4)), dim3(256), 0, st, w1, b1, pooled, hid, N, Cs, C, HN_ACT_RELU);
-    hipLaunchKernelGGL(se_fc_rows_kernel, dim3(cdiv((long)N * C, 4)), dim3(256), 0, st, w2, b2, hid, gate, N, C, Cs, HN_ACT_SIGMOID);
+    hipLaunchKernelGGL(se_fc_rows_kernel, dim3(cdiv((long)N * Cs, 4)), dim3(256), 0, st, w1, b1, pooled, hid, N, Cs, C, HN_ACT_RELU, 0, 1.f,
+                       (float*)nullptr);
+    hipLaunchKernelGGL(se_fc_rows_kernel, dim3(cdiv((long)N * C, 4)), dim3(256), 0, st, w2, b2, (const float*)hid, gate, N, C, Cs,
+                       HN_ACT_SIGMOID, 0, 1.f, (float*)nullptr);
     HN_LAUNCH_CHECK();
 }
 
+// the same MLP fed by S partial squeeze rows per image (pool_part [N*S][C], pooled = alpha * their sum, stored for the backward pass)
+extern "C" int hn_se_mlp_fwd_parts(const float* pool_part, int S, float alpha, const float* w1, const float* b1, const float* w2, const float* b2,
+                                   float* pooled, float* hid, float* gate, int N, int C, int Cs, hipStream_t st) {
+    HN_CHECK_ARG(pool_part && S > 0 && w1 && b1 && w2 && b2 && pooled && hid && gate && N > 0 && C > 0 && Cs > 0);
+    hipLaunchKernelGGL(se_fc_rows_kernel, dim3(cdiv((long)N * Cs, 4)), dim3(256), 0, st, w1, b1, pool_part, hid, N, Cs, C, HN_ACT_RELU, S,
+                       alpha, pooled);
+    hipLaunchKernelGGL(se_fc_rows_kernel, dim3(cdiv((long)N * C, 4)), dim3(256), 0, st, w2, b2, (const float*)hid, gate, N, C, Cs,
+                       HN_ACT_SIGMOID, 0, 1.f, (float*)nullptr);
+    HN_LAUNCH_CHECK();
+}
+
+static int se_mlp_bwd_impl(const float* dgate, int S, const float* gate, const float* hid, const float* pooled, const float* w1, const float* w2,
+                           float* dpre2, float* dpre1, float* dpool, float* dw1, float* db1, float* dw2, float* db2, int N, int C, int Cs,
+                           hipStream_t st);
 extern "C" int hn_se_mlp_bwd(const float* dgate, const float* gate, const float* hid, const float* pooled, const float* w1, const float* w2,
                              float* dpre2, float* dpre1, float* dpool, float* dw1, float* db1, float* dw2, float* db2, int N, int C, int Cs,
                              hipStream_t st) {
+    return se_mlp_bwd_impl(dgate, 0, gate, hid, pooled, w1, w2, dpre2, dpre1, dpool, dw1, db1, dw2, db2, N, C, Cs, st);
+}
+/* dgate given as S partial rows per image ([N*S][C], summed on the fly) */
+extern "C" int hn_se_mlp_bwd_parts(const float* dgate_part, int S, const float* gate, const float* hid, const float* pooled, const float* w1,
+                                   const float* w2, float* dpre2, float* dpre1, float* dpool, float* dw1, float* db1, float* dw2, float* db2,
+                                   int N, int C, int Cs, hipStream_t st) {
+    HN_CHECK_ARG(S > 0);
+    return se_mlp_bwd_impl(dgate_part, S, gate, hid, pooled, w1, w2, dpre2, dpre1, dpool, dw1, db1, dw2, db2, N, C, Cs, st);
+}
+static int se_mlp_bwd_impl(const float* dgate, int S, const float* gate, const float* hid, const float* pooled, const float* w1, const float* w2,
+                           float* dpre2, float* dpre1, float* dpool, float* dw1, float* db1, float* dw2, float* db2, int N, int C, int Cs,
+                           hipStream_t st) {
     HN_CHECK_ARG(dgate && gate && hid && pooled && w1 && w2 && dpre2 && dpre1 && dpool && dw1 && db1 && dw2 && db2 && N > 0 && C > 0 && Cs > 0);
     // dpre1[n][j] = [hid > 0] * sum_c W2[c][j] * (dgate * g (1-g))[n][c]        (also stores dpre2)
-    hipLaunchKernelGGL(se_fc_cols_kernel, dim3(cdiv(Cs, 64), N), dim3(1024), 0, st, w2, dgate, gate, dpre2, hid, dpre1, N, Cs, C, 1, 1);
+    hipLaunchKernelGGL(se_fc_cols_kernel, dim3(cdiv(Cs, 64), N), dim3(1024), 0, st, w2, dgate, gate, dpre2, hid, dpre1, N, Cs, C, 1, 1, S);
     // dpool[n][c] = sum_j W1[j][c] * dpre1[n][j]
     hipLaunchKernelGGL(se_fc_cols_kernel, dim3(cdiv(C, 64), N), dim3(1024), 0, st, w1, (const float*)dpre1, (const float*)nullptr,
-                       (float*)nullptr, (const float*)nullptr, dpool, N, C, Cs, 0, 0);
+                       (float*)nullptr, (const float*)nullptr, dpool, N, C, Cs, 0, 0, 0);
     const long total = 2L * C * Cs + C + Cs;
     hipLaunchKernelGGL(se_mlp_wgrad_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, dpre2, dpre1, hid, pooled, dw1, db1, dw2, db2, N, C, Cs);
     HN_LAUNCH_CHECK();

@@ -301,6 +301,12 @@ class HydraNet(nn.Module):
     def _xblock(self, q, x, stride):
         """XBlock.forward, net/anynet.py:65-76."""
         P = self._idx
+        has_se, has_sc = (q + "se.1.weight") in P, (q + "shortcut.0.weight") in P
+        if K.xblock_fusable(x, P[q + "conv_block_1.0.weight"], stride, has_se, has_sc):     # one autograd node, 8 + 21 launches
+            bn = [self._bn(q + f"conv_block_{i}.1")[:4] for i in (1, 2, 3)]
+            return K.XBlockFn.apply(x, P[q + "conv_block_1.0.weight"], *bn[0], P[q + "conv_block_2.0.weight"], *bn[1],
+                                    P[q + "se.1.weight"], P[q + "se.1.bias"], P[q + "se.3.weight"], P[q + "se.3.bias"],
+                                    P[q + "conv_block_3.0.weight"], *bn[2], BN_STD["eps"], BN_STD["momentum"], self.training)
         a = self._cba(x, q + "conv_block_1.0", q + "conv_block_1.1", BN_STD, act=ACT_RELU)
         b = self._cba(a, q + "conv_block_2.0", q + "conv_block_2.1", BN_STD, kind="g3x3", stride=stride, act=ACT_RELU)
         if (q + "se.1.weight") in P:

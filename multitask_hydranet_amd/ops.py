@@ -9,6 +9,7 @@ There is no eager / CPU fallback in this module: every op goes through lib().cal
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional, Sequence, Tuple
 
 import torch
@@ -188,8 +189,10 @@ def pack_dw_weight(w: torch.Tensor):
 # raw kernel wrappers (no autograd)
 # --------------------------------------------------------------------------------------------------------------
 def k_gemm_nt(x0, x1, mode, grid, wp, nout, kp, taps, bias=None, act=ACT_NONE, out=None, out_f32=False, up=0, stats=False,
-              c0=None, c1=None, rpi=0, img_stride=0, ldc=None):
-    """grid = (N, H, W) of the OUTPUT pixel grid.  Returns (out, psum, psq)."""
+              c0=None, c1=None, rpi=0, img_stride=0, ldc=None, xform=None, addend=None):
+    """grid = (N, H, W) of the OUTPUT pixel grid.  Returns (out, psum, psq).
+    xform = (scale, shift, gate | None, rows_per_image, act): operand transform of hn_conv_gemm_nt_ex; addend: bf16 tensor added in the
+    epilogue (same rows / channels as the output)."""
     n, h, w = grid
     m = n * h * w
     dev = x0.device
@@ -201,11 +204,17 @@ def k_gemm_nt(x0, x1, mode, grid, wp, nout, kp, taps, bias=None, act=ACT_NONE, o
         ldc = out.stride(2) if out.dim() == 4 else nout
     psum = psq = None
     if stats:
-        pr = lib().query("hn_nt_stat_rows", m, nout)
+        pr = lib().query("hn_direct_stat_rows", n, h, w) if mode == 5 else lib().query("hn_nt_stat_rows", m, nout)
         psum = torch.empty((pr, nout), device=dev, dtype=F32)
         psq = torch.empty((pr, nout), device=dev, dtype=F32)
-    lib().call("hn_conv_gemm_nt", ptr(x0), ptr(x1), mode, n, h, w, c0, c1, ld(x0), ld(x1) if x1 is not None else 0, up, m,
-               ptr(wp), nout, kp, taps, ptr(bias), act, ptr(out), 1 if out_f32 else 0, ldc, rpi, img_stride, ptr(psum), ptr(psq))
+    if xform is None and addend is None:
+        lib().call("hn_conv_gemm_nt", ptr(x0), ptr(x1), mode, n, h, w, c0, c1, ld(x0), ld(x1) if x1 is not None else 0, up, m,
+                   ptr(wp), nout, kp, taps, ptr(bias), act, ptr(out), 1 if out_f32 else 0, ldc, rpi, img_stride, ptr(psum), ptr(psq))
+    else:
+        xs, xh, xg, xhw, xact = xform if xform is not None else (None, None, None, 0, 0)
+        lib().call("hn_conv_gemm_nt_ex", ptr(x0), ptr(x1), mode, n, h, w, c0, c1, ld(x0), ld(x1) if x1 is not None else 0, up, m,
+                   ptr(wp), nout, kp, taps, ptr(bias), act, ptr(out), 1 if out_f32 else 0, ldc, rpi, img_stride, ptr(psum), ptr(psq),
+                   ptr(xs), ptr(xh), ptr(xg), xhw, xact, ptr(addend), ld(addend) if addend is not None else 0)
     return out, psum, psq
 
 
@@ -292,7 +301,7 @@ def k_eltwise(op, a, b=None, act=ACT_NONE, alpha=1.0, out=None):
     return out
 
 
-FUSED_BN = True            # BatchNorm finalize in the prologue of the consuming elementwise kernel (hn_fused.hip); False: round-1 kernels
+FUSED_BN = os.environ.get("HN_FUSED_BN", "1") != "0"   # BatchNorm finalize in the prologue of the consuming elementwise kernel (hn_fused.hip); False: round-1 kernels
 MAX_PROLOGUE_ROWS = 512    # partial statistic rows a consumer prologue reduces itself; more are folded to 32 rows first (one launch)
 
 
@@ -490,6 +499,94 @@ class ConvBnAct(torch.autograd.Function):
 def conv_bn_act(x, weight, conv_bias, bn, res=None, kind="1x1", stride=1, act=ACT_NONE, eps=1e-5, momentum=0.1, training=True):
     gamma, beta, rm, rv, nbt = bn
     return ConvBnAct.apply(x, weight, conv_bias, gamma, beta, rm, rv, nbt, res, kind, stride, act, eps, momentum, training)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# Stride-1 identity XBlock as ONE autograd node (net/anynet.py:65-76; 25 of the 30 blocks of the big backbone):
+#   z1 = conv1x1(x); a = relu(bn1(z1)); z2 = gconv3x3(a); b = relu(bn2(z2)); gate = SE(avgpool(b)); z3 = conv1x1(b * gate);
+#   out = relu(bn3(z3) + x)
+# Forward is 8 launches: the two 1x1 GEMMs and the grouped conv emit their BatchNorm partial statistics; BN1 apply and the final
+# BN3 + residual + ReLU are the two materialising passes; BN2 is never materialised -- one pass over z2 finalizes its statistics and
+# produces the SE squeeze, conv_block_3's operand loader applies scale/shift + ReLU + gate on the fly.  Backward is 21 launches
+# (BN backward = reduce + apply with the finalize in the prologue; the SE gate gradient and the gated wgrad operand come out of one pass
+# over (dbg, z2); the SE data-path backward is folded into the BN2 reduce/apply pair; the residual gradient is added in conv_block_1's
+# dgrad epilogue).  The unfused composition of ConvBnAct / SEGate nodes is ~16 + ~27 launches per block.
+# --------------------------------------------------------------------------------------------------------------
+FUSED_XBLOCK = os.environ.get("HN_FUSED_XBLOCK", "1") != "0"
+
+
+class XBlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, sw1, sb1, sw2, sb2, w3, g3, b3, rm3, rv3, eps, momentum, training):
+        n, h, w, c = x.shape
+        m, hw = n * h * w, h * w
+        cs = sw1.shape[0]
+        dev = x.device
+        grid = (n, h, w)
+        wp1, wt1 = pack_conv_weight(w1)
+        z1, ps, pq = k_gemm_nt(x, None, 0, grid, wp1, c, kp32(c), 1, stats=training)
+        a, coef1, _, _ = k_bn_apply_fused(z1, ps, pq, m, g1, b1, eps, momentum, rm1, rv1, ACT_RELU, training=training)
+        wk2, wd2 = pack_gconv_diag(w2)
+        z2, ps, pq = k_gemm_nt(a, None, 5, grid, wk2, c, 64, 9, stats=training)
+        _, coef2, pool, rb = k_bn_apply_fused(z2, ps, pq, m, g2, b2, eps, momentum, rm2, rv2, ACT_RELU, want_out=False, pool_align=hw,
+                                              training=training)
+        pooled = torch.empty((n, c), device=dev, dtype=F32)
+        hid = torch.empty((n, cs), device=dev, dtype=F32)
+        gate = torch.empty((n, c), device=dev, dtype=F32)
+        lib().call("hn_se_mlp_fwd_parts", ptr(pool), hw // rb, 1.0 / hw, ptr(sw1), ptr(sb1), ptr(sw2), ptr(sb2), ptr(pooled), ptr(hid),
+                   ptr(gate), n, c, cs)
+        wp3, wt3 = pack_conv_weight(w3)
+        z3, ps, pq = k_gemm_nt(z2, None, 0, grid, wp3, c, kp32(c), 1, stats=training, xform=(coef2[0], coef2[1], gate, hw, ACT_RELU))
+        out, coef3, _, _ = k_bn_apply_fused(z3, ps, pq, m, g3, b3, eps, momentum, rm3, rv3, ACT_RELU, res=x, training=training)
+        ctx.training = training
+        ctx.packs = (wt1, wd2, wt3)
+        ctx.save_for_backward(x, z1, a, z2, z3, out, coef1, coef2, coef3, pooled, hid, gate, sw1, sw2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, z1, a, z2, z3, out, coef1, coef2, coef3, pooled, hid, gate, sw1, sw2 = ctx.saved_tensors
+        assert ctx.training, "backward through eval-mode BatchNorm is not part of the hot path"
+        wt1, wd2, wt3 = ctx.packs
+        dout = dense(dout)
+        n, h, w, c = x.shape
+        m, hw = n * h * w, h * w
+        cs = sw1.shape[0]
+        dev = x.device
+        grid = (n, h, w)
+        # out = relu(bn3(z3) + x): g = dout * [out > 0] is also the gradient of the identity branch
+        dz3, dg3, db3, g = bn_backward_fused(dout, z3, out, coef3, ACT_RELU, m, want_g=True)
+        dbg, _, _ = k_gemm_nt(dz3, None, 0, grid, wt3, c, kp32(c), 1)
+        # one pass over (dbg, z2): gate-gradient partials and the gated operand bg = relu(bn2(z2)) * gate of conv_block_3's wgrad
+        rb = lib().query("hn_fused_row_block", m, c, hw)
+        bg = new_act(n, h, w, c, dev)
+        pdot = torch.empty(((m + rb - 1) // rb, c), device=dev, dtype=F32)
+        lib().call("hn_se_bwd_reduce_fused", ptr(dbg), ld(dbg), ptr(z2), ld(z2), ptr(coef2), ptr(gate), hw, ptr(bg), ld(bg), ptr(pdot), m, c, rb)
+        dw3 = k_gemm_tn(bg, None, 0, grid, dz3, c, kp32(c), 1, c)
+        dpre2 = torch.empty((n, c), device=dev, dtype=F32)
+        dpool = torch.empty((n, c), device=dev, dtype=F32)
+        dpre1 = torch.empty((n, cs), device=dev, dtype=F32)
+        dsw1, dsb1 = torch.empty_like(sw1), torch.empty((cs,), device=dev, dtype=F32)
+        dsw2, dsb2 = torch.empty_like(sw2), torch.empty((c,), device=dev, dtype=F32)
+        lib().call("hn_se_mlp_bwd_parts", ptr(pdot), hw // rb, ptr(gate), ptr(hid), ptr(pooled), ptr(sw1), ptr(sw2), ptr(dpre2), ptr(dpre1),
+                   ptr(dpool), ptr(dsw1), ptr(dsb1), ptr(dsw2), ptr(dsb2), n, c, cs)
+        # BN2 backward with the SE data path folded in: g2 = (dbg * gate + dpool / HW) * [bn2(z2) > 0]
+        dz2, dg2, db2, _ = bn_backward_fused(dbg, z2, None, coef2, ACT_RELU, m, gate=gate, dpool=dpool, hw=hw)
+        da, _, _ = k_gemm_nt(dz2, None, 5, grid, wd2, c, 64, 9)
+        dw2 = k_gemm_tn(a, None, 5, grid, dz2, c, 64, 9, 8, kh=3)
+        dz1, dg1, db1, _ = bn_backward_fused(da, z1, None, coef1, ACT_RELU, m)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx, _, _ = k_gemm_nt(dz1, None, 0, grid, wt1, c, kp32(c), 1, addend=g)      # + gradient of the identity branch
+        dw1 = k_gemm_tn(x, None, 0, grid, dz1, c, kp32(c), 1, c)
+        return (dx, dw1, dg1, db1, None, None, dw2, dg2, db2, None, None, dsw1, dsb1, dsw2, dsb2, dw3, dg3, db3, None, None,
+                None, None, None)
+
+
+def xblock_fusable(x, w1, stride, has_se, has_shortcut):
+    """the fused node covers the stride-1 identity blocks with SE whose channel count is a multiple of 8 (every non-first block of a stage)"""
+    return (FUSED_XBLOCK and FUSED_BN and GCONV_MFMA and x.is_cuda and stride == 1 and has_se and not has_shortcut
+            and w1.shape[0] == w1.shape[1] and w1.shape[0] % 8 == 0)
 
 
 # --------------------------------------------------------------------------------------------------------------

@@ -400,3 +400,54 @@ def test_focal_seg_loss_takes_float_class_ids():
     loss.backward()
     ref = O.seg_loss(logits.detach().cpu(), gt.long().cpu(), cfgs["segment"]["class_weight"], False, cfgs["segment"]["top_k_ratio"], True)
     assert abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref)) and logits.grad is not None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c,n,h,w", [(64, 2, 16, 24), (152, 4, 32, 64), (936, 8, 8, 16)])
+def test_xblock_fused_node_equals_unfused_composition(c, n, h, w):
+    """ops.XBlockFn (one autograd node, BatchNorm finalize in kernel prologues, SE squeeze on the BN2 pass, BN2 + ReLU + gate applied in
+    conv_block_3's operand loader, residual gradient added in conv_block_1's dgrad epilogue) against the composition of ConvBnAct /
+    SEGate nodes on identical inputs: same arithmetic and the same bf16 rounding points, only reduction orders differ."""
+    from multitask_hydranet_amd import ops as K
+    import __graft_entry__ as g
+    g.build()
+    dev = "cuda:0"
+    gen = torch.Generator(device=dev).manual_seed(c)
+    rn = lambda *s, scale=1.0: torch.randn(*s, device=dev, generator=gen) * scale
+    cs = c // 4
+    prm = dict(w1=rn(c, c, 1, 1, scale=c ** -0.5), w2=rn(c, 8, 3, 3, scale=72 ** -0.5), w3=rn(c, c, 1, 1, scale=c ** -0.5),
+               sw1=rn(cs, c, 1, 1, scale=c ** -0.5), sb1=rn(cs, scale=0.1), sw2=rn(c, cs, 1, 1, scale=cs ** -0.5), sb2=rn(c, scale=0.1))
+    bn0 = [(torch.rand(c, device=dev, generator=gen) + 0.5, rn(c, scale=0.1), rn(c, scale=0.1), torch.rand(c, device=dev, generator=gen) + 0.5)
+           for _ in range(3)]
+    x0 = torch.relu(rn(n, h, w, c)).to(torch.bfloat16)
+    up = rn(n, h, w, c).to(torch.bfloat16)
+    res = {}
+    for fused in (False, True):
+        p = {k: v.clone().requires_grad_(True) for k, v in prm.items()}
+        bn = [[t.clone() for t in b] for b in bn0]
+        for b in bn:
+            b[0].requires_grad_(True)
+            b[1].requires_grad_(True)
+        x = x0.clone().requires_grad_(True)
+        K.clear_pack_cache()
+        if fused:
+            out = K.XBlockFn.apply(x, p["w1"], *bn[0], p["w2"], *bn[1], p["sw1"], p["sb1"], p["sw2"], p["sb2"], p["w3"], *bn[2], 1e-5, 0.1, True)
+        else:
+            a = K.conv_bn_act(x, p["w1"], None, (*bn[0], None), act=K.ACT_RELU)
+            b_ = K.conv_bn_act(a, p["w2"], None, (*bn[1], None), kind="g3x3", stride=1, act=K.ACT_RELU)
+            b_ = K.SEGate.apply(b_, p["sw1"], p["sb1"], p["sw2"], p["sb2"])
+            out = K.conv_bn_act(b_, p["w3"], None, (*bn[2], None), res=x, act=K.ACT_RELU)
+        out.backward(up)
+        grads = {k: v.grad.clone() for k, v in p.items()}
+        grads.update({f"bn{i}_{j}": bn[i][j].grad.clone() for i in range(3) for j in range(2)})
+        res[fused] = dict(out=out.detach().float(), dx=x.grad.float(), grads=grads, run=[[b[2].clone(), b[3].clone()] for b in bn])
+    a, b = res[False], res[True]
+    rel = lambda u, v: float((u.float() - v.float()).abs().max() / v.float().abs().max().clamp(min=1e-20))
+    cos = lambda u, v: float(F.cosine_similarity(u.float().flatten(), v.float().flatten(), dim=0))
+    assert rel(b["out"], a["out"]) <= 1e-2, rel(b["out"], a["out"])
+    assert cos(b["dx"], a["dx"]) >= 0.999, cos(b["dx"], a["dx"])                       # (a flipped ReLU mask bit shows up in max-norm)
+    for k in a["grads"]:
+        assert cos(b["grads"][k], a["grads"][k]) >= 0.999 and rel(b["grads"][k], a["grads"][k]) <= 5e-2, (k, cos(b["grads"][k], a["grads"][k]),
+                                                                                                     rel(b["grads"][k], a["grads"][k]))
+    for i in range(3):
+        assert rel(b["run"][i][0], a["run"][i][0]) <= 1e-3 and rel(b["run"][i][1], a["run"][i][1]) <= 1e-3, i
