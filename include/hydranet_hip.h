@@ -285,6 +285,36 @@ int hn_lane_loc_loss_bwd(const float* pred, const float* target, const void* pma
  * separately rounded fp32 ops (bit-identical decisions to the host path).  mask: hn_nms_mask_words(K) uint64 scratch; keep: K bytes. */
 long hn_nms_mask_words(int K);
 int hn_nms_sorted(const float* boxes, int K, float iou_threshold, void* mask, void* keep, hipStream_t stream);
+/* ---- stages either side of the hot path (hn_post.hip; SURVEY.md section 8(f)) ---------------------------------------------------- */
+
+/* Detection post-process for a whole batch on the device (head_detect/detection_loss.py:7-108 BBoxTransform + ClipBoxes + postprocess;
+ * torchvision.ops.batched_nms semantics restated: stable descending-score order, suppress when IoU > threshold, classes separated by an
+ * offset of class_id * (max kept coordinate + 1)).  anchors fp32 [A][4] (y1,x1,y2,x2), regression [N][A][4], classification [N][A][K]
+ * (post-sigmoid).  cap <= 32768 = per-image capacity.  Per image n: kept[n] boxes in descending-score order in rois [N][cap][4] (x1,y1,x2,y2),
+ * class_ids int64 [N][cap], scores [N][cap]; total[n] = anchors over the threshold (total[n] > cap: overflow, results invalid).
+ * ws: hn_det_post_ws_bytes(N, cap) bytes of scratch. */
+long hn_det_post_ws_bytes(int N, int cap);
+int hn_det_postprocess(const float* anchors, const float* regression, const float* classification, int N, int A, int K, int img_h, int img_w,
+                       float threshold, float iou_threshold, int cap, void* ws, float* rois, long* class_ids, float* scores, int* kept,
+                       int* total, hipStream_t stream);
+
+/* Lane decode + lane NMS (LaneHeader.decode, head_lane/lanedetect.py:103-116 = softmax + LaneCodec.decode_lane, lane_codec.py:116-219 +
+ * nms_with_pos, lane_codec_utils.py:487-543) for a batch: one workgroup per image.  predict_cls fp32 [N][hw][2] (logits), predict_loc fp32
+ * [N][hw][2*ppl+2], hw = (W/stride)*(H/stride) <= 1024.  Outputs: X [N][hw][ppl] = x of anchor a at line position p (start[a] <= p < end[a]),
+ * prob / start / end [N][hw] per anchor, order [N][hw] = candidates in descending-prob order (counts[n] of them), keep [N][hw] = 1 for the
+ * candidates that survive. */
+int hn_lane_decode_nms(const float* predict_cls, const float* predict_loc, int N, int W, int H, int stride, int ppl, float exist_threshold,
+                       float nms_threshold, int use_mean, float margin, float* X, float* prob, int* start, int* end, int* order, int* keep,
+                       int* counts, hipStream_t stream);
+
+/* Input pre-processing (demo.py:26-50,186-196; dataset/utility.py:213-227): uint8 BGR frames [N][Hs][Ws][3] -> bilinear resize (cv2.resize
+ * INTER_LINEAR fixed-point form for 8-bit images) -> RGB -> (v/255 - mean)/std -> fp32 [N][3][Hd][Wd]. */
+int hn_preprocess_bgr(const void* src, int N, int Hs, int Ws, float* dst, int Hd, int Wd, hipStream_t stream);
+
+/* Streaming confusion counts for the segmentation mIoU (head_seg/seg_metrics.py:12-47): conf uint64 [(C+1)*(C+1)] += counts of
+ * (pred, target) pairs, both clamped to C (the ignore bucket).  pred int64 [M]; target int64 or float32 [M]. */
+int hn_seg_confusion(const long* pred, const void* target, int target_is_float, long M, int C, void* conf, hipStream_t stream);
+
 int hn_argmax_channels(const float* logits, int ldl, int C, long M, long* out, hipStream_t stream);
 
 #ifdef __cplusplus

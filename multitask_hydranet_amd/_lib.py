@@ -17,7 +17,7 @@ _ROOT = os.path.dirname(_PKG)
 HEADER = os.path.join(_ROOT, "include", "hydranet_hip.h")
 CSRC = os.path.join(_PKG, "csrc")
 SO_PATH = os.path.join(_PKG, "libhydranet_hip.so")
-SOURCES = ["hn_gemm.hip", "hn_norm.hip", "hn_fused.hip", "hn_stencil.hip", "hn_loss.hip"]
+SOURCES = ["hn_gemm.hip", "hn_norm.hip", "hn_fused.hip", "hn_stencil.hip", "hn_loss.hip", "hn_post.hip"]
 
 _ERR = {1: "bad argument", 2: "kernel launch failure", 3: "unsupported shape"}
 

@@ -123,6 +123,7 @@ class HydraNet(nn.Module):
         self.seg_phase_output = True
         self.seg_fuse_elu_bwd = True       # ELU' of a decoder block applied by the next block's gradient fold
         self._pack_plan = None
+        self.deploy_postprocess = None      # (conf_thres, iou_thres): forward(x, "deploy") then appends the device-side detections
         self.pack_det_levels = True         # level-packed det towers when every level has a multiple of 128 rows
         self.levels_on_streams = False      # hipGraph branches cost more than they hide on gfx950 (55 vs 43 ms)
 
@@ -262,6 +263,11 @@ class HydraNet(nn.Module):
             self.detectheader.decode = _det_decode
         if self.train_lane:
             object.__setattr__(self.laneheader, "_fwd", lambda fused: flushed(me()._lane([K_to_nhwc(t) for t in fused])))
+            from . import lane_codec as LC             # LaneHeader.decode / scale_to_org (head_lane/lanedetect.py:103-124) on the device
+            self.laneheader.decode = LC.decode
+            self.laneheader.decode_batch = LC.decode_batch
+            self.laneheader.scale_to_org = LC.scale_to_org
+            self.laneheader.visual = _unavailable("laneheader.visual (cv2 visualisation)")
 
     def _reindex(self):
         self._idx = {k: v for k, v in itertools.chain(self.named_parameters(), self.named_buffers()) if not k.startswith("_")}
@@ -549,7 +555,15 @@ class HydraNet(nn.Module):
         self._flush_nbt()
         if mode != "deploy":
             return out
-        return K.argmax_channels(seg), anchors, reg, cls, lane_cls, lane_reg
+        dep = (K.argmax_channels(seg), anchors, reg, cls, lane_cls, lane_reg)
+        if self.deploy_postprocess is not None and self.train_detect:
+            # decode + clip + threshold + class-offset NMS + gather on the device, same stream, no host round trip;
+            # a 7th element (dict of device tensors: rois / class_ids / scores [N, cap, ...], kept / total [N]) follows the reference's 6-tuple
+            from .postprocess import postprocess_device
+            conf, iou = self.deploy_postprocess[:2]
+            dep = dep + (postprocess_device((x.shape[2], x.shape[3]), anchors, reg, cls, conf, iou,
+                                            *(self.deploy_postprocess[2:3] or (4096,))),)
+        return dep
 
     def _seg_loss(self, logits, target):
         """CrossEntropyLoss.forward (head_seg/segmentation_loss.py:27-65): HIP kernels for the weighted-CE / top-k path of the shipped

@@ -1,16 +1,25 @@
-"""Detection post-processing (head_detect/detection_loss.py:7-108 of the reference): box decode, clip, score threshold, per-class
-greedy NMS.  Integer/index bookkeeping is bit-exact with the reference given identical fp inputs.  torchvision's batched_nms
-(unpinned third party in the reference) is restated from its published semantics: descending stable score order, suppress when
-IoU > threshold, IoU = inter / (a + b - inter), classes separated by a coordinate offset of class_id * (max_coord + 1).
-Decode / clip / threshold / sort are device tensor ops; the O(K^2) suppression runs in HIP kernels for CUDA inputs (nms_device, SURVEY.md
-section 8(f) row 1) and in numpy for CPU inputs (the form the CPU parity tests pin against the oracle)."""
+"""Detection post-processing on the device (head_detect/detection_loss.py:7-108 of the reference: BBoxTransform, ClipBoxes, postprocess).
+
+One HIP pipeline for the whole batch (hn_det_postprocess, csrc/hn_post.hip): box decode + clip + per-anchor max / arg-max class + score
+threshold compaction + stable descending-score order + class-offset greedy NMS + gather.  No per-image host loop, no host NMS: the only
+device-to-host traffic is the final result (kept boxes, classes, scores and two counters per image), which the reference's contract returns
+as numpy arrays.  Index bookkeeping is exact; torchvision.ops.batched_nms (unpinned third party in the reference, absent here) is restated
+from its published semantics -- stable descending score order, suppress when IoU > threshold, IoU = inter / (a + b - inter), classes
+separated by an offset of class_id * (max kept coordinate + 1) -- see DESIGN.md ("parity unpinned for NMS").
+There is no CPU path: CPU tensors are moved to the current HIP device first; without the HIP library this module raises.
+"""
 from __future__ import annotations
 
 import numpy as np
 import torch
 
+from ._lib import lib
+
+MAX_CAP = 32768
+
 
 def decode_boxes(anchors: torch.Tensor, regression: torch.Tensor) -> torch.Tensor:
+    """BBoxTransform.forward (detection_loss.py:7-33) as tensor ops, kept for callers that want the raw decoded boxes"""
     yca = (anchors[..., 0] + anchors[..., 2]) / 2
     xca = (anchors[..., 1] + anchors[..., 3]) / 2
     ha = anchors[..., 2] - anchors[..., 0]
@@ -22,70 +31,47 @@ def decode_boxes(anchors: torch.Tensor, regression: torch.Tensor) -> torch.Tenso
     return torch.stack([xc - w / 2.0, yc - h / 2.0, xc + w / 2.0, yc + h / 2.0], dim=2)
 
 
-def nms_device(boxes: torch.Tensor, scores: torch.Tensor, thr: float) -> torch.Tensor:
-    """same contract as nms() with the O(K^2) part on the GPU (hn_nms_sorted: IoU bit-mask + one-wave scan); no host fallback"""
-    from ._lib import lib
-    order = torch.argsort(scores, descending=True, stable=True)
-    b = boxes[order].float().contiguous()
-    k = b.shape[0]
-    mask = torch.empty((lib().query("hn_nms_mask_words", k),), device=b.device, dtype=torch.int64)
-    keep = torch.empty((k,), device=b.device, dtype=torch.uint8)
-    lib().call("hn_nms_sorted", b.data_ptr(), k, float(thr), mask.data_ptr(), keep.data_ptr())
-    return order[keep.bool()]
-
-
-def nms(boxes: torch.Tensor, scores: torch.Tensor, thr: float) -> torch.Tensor:
-    if boxes.numel() == 0:
-        return torch.empty((0,), dtype=torch.int64, device=boxes.device)
-    if boxes.is_cuda and boxes.shape[0] <= 32768:
-        return nms_device(boxes, scores, thr)
-    order = torch.argsort(scores, descending=True, stable=True)
-    b = boxes[order].float().cpu().numpy()
-    area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
-    alive = np.ones(b.shape[0], dtype=bool)
-    keep = []
-    t = np.float32(thr)
-    for i in range(b.shape[0]):
-        if not alive[i]:
-            continue
-        keep.append(i)
-        rest = slice(i + 1, None)
-        iw = np.clip(np.minimum(b[i, 2], b[rest, 2]) - np.maximum(b[i, 0], b[rest, 0]), 0, None).astype(np.float32)
-        ih = np.clip(np.minimum(b[i, 3], b[rest, 3]) - np.maximum(b[i, 1], b[rest, 1]), 0, None).astype(np.float32)
-        inter = iw * ih
-        alive[rest] &= ~(inter / (area[i] + area[rest] - inter) > t)
-    return order[torch.as_tensor(keep, dtype=torch.int64, device=order.device)]
-
-
-def batched_nms(boxes, scores, idxs, thr):
-    if boxes.numel() == 0:
-        return torch.empty((0,), dtype=torch.int64, device=boxes.device)
-    off = idxs.to(boxes) * (boxes.max() + torch.tensor(1).to(boxes))
-    return nms(boxes + off[:, None], scores, thr)
+def postprocess_device(img_hw, anchors, regression, classification, threshold, iou_threshold, cap: int = 4096):
+    """device tensors in, device tensors out: dict(rois [N,cap,4], class_ids [N,cap] int64, scores [N,cap], kept [N] int32, total [N] int32).
+    Row i < kept[n] of image n is its i-th detection in descending score order.  total[n] > cap means image n overflowed the capacity."""
+    h, w = img_hw
+    dev = regression.device if regression.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    reg = regression.detach().to(dev, torch.float32).contiguous()
+    cls = classification.detach().to(dev, torch.float32).contiguous()
+    anc = anchors.detach().to(dev, torch.float32)
+    anc = (anc[0] if anc.dim() == 3 else anc).contiguous()
+    n, a, k = cls.shape
+    assert reg.shape == (n, a, 4) and anc.shape == (a, 4), (reg.shape, anc.shape)
+    cap = int(min(max(cap, 1), MAX_CAP, a))
+    ws = torch.empty((lib().query("hn_det_post_ws_bytes", n, cap),), device=dev, dtype=torch.uint8)
+    out = dict(rois=torch.empty((n, cap, 4), device=dev, dtype=torch.float32), class_ids=torch.empty((n, cap), device=dev, dtype=torch.int64),
+               scores=torch.empty((n, cap), device=dev, dtype=torch.float32), kept=torch.empty((n,), device=dev, dtype=torch.int32),
+               total=torch.empty((n,), device=dev, dtype=torch.int32))
+    lib().call("hn_det_postprocess", anc.data_ptr(), reg.data_ptr(), cls.data_ptr(), n, a, k, int(h), int(w), float(threshold),
+               float(iou_threshold), cap, ws.data_ptr(), out["rois"].data_ptr(), out["class_ids"].data_ptr(), out["scores"].data_ptr(),
+               out["kept"].data_ptr(), out["total"].data_ptr())
+    out["cap"] = cap
+    return out
 
 
 def postprocess(img_hw, anchors, regression, classification, threshold, iou_threshold):
-    h, w = img_hw
-    boxes = decode_boxes(anchors, regression)
-    boxes[:, :, 0] = boxes[:, :, 0].clamp(min=0)
-    boxes[:, :, 1] = boxes[:, :, 1].clamp(min=0)
-    boxes[:, :, 2] = boxes[:, :, 2].clamp(max=w - 1)
-    boxes[:, :, 3] = boxes[:, :, 3].clamp(max=h - 1)
-    scores = torch.max(classification, dim=2, keepdim=True)[0]
-    over = (scores > threshold)[:, :, 0]
+    """the reference's return contract: one dict(rois, class_ids, scores) of numpy arrays per image (empty arrays when nothing is kept)"""
+    cap = 4096
+    while True:
+        res = postprocess_device(img_hw, anchors, regression, classification, threshold, iou_threshold, cap)
+        total = res["total"].cpu().numpy()
+        if int(total.max(initial=0)) <= res["cap"]:
+            break
+        if res["cap"] >= min(MAX_CAP, regression.shape[1]):
+            raise RuntimeError(f"{int(total.max())} anchors over the score threshold in one image: the device NMS holds at most {MAX_CAP}")
+        cap = min(MAX_CAP, max(2 * cap, int(total.max())))
+    kept = res["kept"].cpu().numpy()
+    rois, cids, scores = res["rois"].cpu().numpy(), res["class_ids"].cpu().numpy(), res["scores"].cpu().numpy()
     out = []
-    empty = lambda: dict(rois=np.array(()), class_ids=np.array(()), scores=np.array(()))
-    for i in range(regression.shape[0]):
-        if over[i].sum() == 0:
-            out.append(empty())
-            continue
-        cper = classification[i, over[i], :].permute(1, 0)
-        bper = boxes[i, over[i], :]
-        sper = scores[i, over[i], 0]
-        sc, cl = cper.max(dim=0)
-        keep = batched_nms(bper, sper, cl, iou_threshold)
-        if keep.shape[0] == 0:
-            out.append(empty())
+    for i in range(len(kept)):
+        k = int(kept[i])
+        if k == 0:
+            out.append(dict(rois=np.array(()), class_ids=np.array(()), scores=np.array(())))
         else:
-            out.append(dict(rois=bper[keep, :].cpu().numpy(), class_ids=cl[keep].cpu().numpy(), scores=sc[keep].cpu().numpy()))
+            out.append(dict(rois=rois[i, :k].copy(), class_ids=cids[i, :k].copy(), scores=scores[i, :k].copy()))
     return out

@@ -309,12 +309,101 @@ def big_digest():
           {k: float(v) for k, v in ld.items()}, "argmax hist", cnt.tolist())
 
 
+def lane_fixture():
+    """Lane decode + lane NMS through the reference's own codec (LaneCodec.decode_lane, nms_with_pos via LaneHeader.decode): synthetic
+    head outputs shaped like trained ones (a few smooth lanes seen by several neighbouring anchors + noise anchors), at 512x1024 and 640x640."""
+    from head_lane.lane_codec import LaneCodec
+    from head_lane.lanedetect import LaneHeader
+    res = {}
+    for tag, (h, w), seed in (("512x1024", (512, 1024), 21), ("640x640", (640, 640), 22), ("128x256", (128, 256), 23)):
+        stride, interval = 32, 8
+        ppl = h // interval
+        coder = LaneCodec(input_width=w, input_height=h, anchor_stride=stride, points_per_line=ppl, do_interpolate=True, anchor_lane_num=1,
+                          scale_invariance=True)
+        fh, fw = h // stride, w // stride
+        g = torch.Generator().manual_seed(seed)
+        hw = fh * fw
+        cls = torch.randn(hw, 2, generator=g)
+        cls[:, 0] += 2.0                                            # mostly background
+        loc = torch.randn(hw, 2 * ppl + 2, generator=g) * 0.3
+        loc[:, ppl] = torch.rand(hw, generator=g) * ppl             # down length
+        loc[:, ppl + 1] = torch.rand(hw, generator=g) * ppl         # up length
+        # a few ground-truth-like lanes: x(pos) = x0 + slope * pos (in pixels), every anchor within 1.5 cells of the lane fires
+        for li in range(5):
+            x0 = float(torch.rand(1, generator=g)) * w
+            slope = (float(torch.rand(1, generator=g)) - 0.5) * 6.0
+            for ah in range(fh):
+                pos0 = int((fh - 1 - ah) * (ppl / fh))
+                xl = x0 + slope * pos0
+                for aw in range(fw):
+                    cx = (aw + 0.5) * stride
+                    if abs(cx - xl) < 1.5 * stride and 0 <= xl < w:
+                        idx = ah * fw + aw
+                        cls[idx, 1] = cls[idx, 0] + 2.0 + 2.0 * float(torch.rand(1, generator=g))
+                        up = torch.arange(ppl).float()
+                        loc[idx, ppl + 2:] = ((x0 + slope * (pos0 + up)) - cx) / interval + torch.randn(ppl, generator=g) * 0.05
+                        loc[idx, :ppl] = ((x0 + slope * (pos0 - 1 - up)) - cx) / interval + torch.randn(ppl, generator=g) * 0.05
+                        loc[idx, ppl] = pos0 + 0.5
+                        loc[idx, ppl + 1] = ppl - pos0 + 0.5
+        res[f"{tag}/cls"], res[f"{tag}/loc"] = _np(cls), _np(loc)
+        res[f"{tag}/geom"] = np.array([w, h, stride, ppl])
+        for name, (thr, nms_thr, use_mean) in (("a", (0.5, 100, False)), ("b", (0.9, 40, False)), ("c", (0.3, 60, True))):
+            lanes = LaneHeader.decode(cls, loc, coder, thr, nms_thr, use_mean)
+            cand = coder.decode_lane(torch.softmax(cls, -1), loc, thr)
+            k = f"{tag}/{name}"
+            res[k + "/params"] = np.array([thr, nms_thr, float(use_mean)])
+            res[k + "/n_candidates"] = np.array(len(cand))
+            res[k + "/prob"] = np.array([float(l.prob) for l in lanes], np.float64)
+            res[k + "/start_pos"] = np.array([l.start_pos for l in lanes], np.int64)
+            res[k + "/end_pos"] = np.array([l.end_pos for l in lanes], np.int64)
+            res[k + "/ax"] = np.array([float(l.ax) for l in lanes], np.float64)
+            res[k + "/ay"] = np.array([float(l.ay) for l in lanes], np.float64)
+            res[k + "/npts"] = np.array([len(l.lane) for l in lanes], np.int64)
+            res[k + "/xs"] = np.array([float(p.x) for l in lanes for p in l.lane], np.float64)
+            res[k + "/ys"] = np.array([float(p.y) for l in lanes for p in l.lane], np.float64)
+            print("lane fixture", k, "candidates", len(cand), "kept", len(lanes))
+    np.savez_compressed(os.path.join(HERE, "lane_decode.npz"), **res)
+
+
+def aux_fixture():
+    """(f3) ImageNet normalisation through the reference's own imagenet_normalize (dataset/utility.py:213-227; the resize is cv2 = absent
+    third party, so only frames at the network size are recorded) and (f4) IoU statistics through head_seg/seg_metrics.py."""
+    from dataset.utility import imagenet_normalize
+    from head_seg.seg_metrics import IntersectionOverUnion, stat_scores_multiple_classes
+    res = {}
+    rng = np.random.RandomState(5)
+    frame = rng.randint(0, 256, size=(24, 40, 3)).astype(np.uint8)               # BGR, already at the "network size"
+    img = frame[:, :, ::-1].astype(np.float32)                                    # cv2.cvtColor(BGR2RGB) is a channel flip
+    img = imagenet_normalize(img=img)
+    res["pre/frame_bgr"] = frame
+    res["pre/expected"] = np.transpose(img, (2, 0, 1)).astype(np.float32)          # .transpose + torch.tensor(...).float()
+    g = torch.Generator().manual_seed(9)
+    pred = torch.randint(0, 5, (3, 32, 48), generator=g)
+    tgt = torch.randint(0, 5, (3, 32, 48), generator=g)
+    tgt[0, :4] = 255                                                               # ignore pixels
+    tgt[:, :, :6] = pred[:, :, :6]                                                 # some guaranteed hits
+    tp, fp, tn, fn, sup = stat_scores_multiple_classes(pred.clone(), tgt.clone(), 5)
+    res["iou/pred"], res["iou/target"] = _np(pred), _np(tgt)
+    res["iou/tp"], res["iou/fp"], res["iou/fn"], res["iou/sup"] = _np(tp), _np(fp), _np(fn), _np(sup)
+    for name, kw in (("plain", dict()), ("ignore0", dict(ignore_index=0)), ("absent", dict(absent_score=1.0))):
+        m = IntersectionOverUnion(n_classes=5 if name != "absent" else 7, **kw)
+        m.update(pred.clone(), tgt.clone())
+        m.update(tgt.clone().clamp_max(4), tgt.clone())                            # a second batch (streaming)
+        res[f"iou/{name}/scores"] = _np(m.compute())
+    np.savez_compressed(os.path.join(HERE, "aux_stages.npz"), **res)
+    print("aux fixture:", {k: v.shape for k, v in res.items()})
+
+
 if __name__ == "__main__":
     _install_shims()
-    which = sys.argv[1:] or ["tiny", "kats", "big"]
+    which = sys.argv[1:] or ["tiny", "kats", "big", "lane", "aux"]
     if "tiny" in which:
         tiny_fixture()
     if "kats" in which:
         loss_kats()
     if "big" in which:
         big_digest()
+    if "lane" in which:
+        lane_fixture()
+    if "aux" in which:
+        aux_fixture()

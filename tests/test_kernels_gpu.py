@@ -468,21 +468,23 @@ def test_lane_losses_hip_vs_torch(K, case):
 
 
 @pytest.mark.parametrize("k,spread", [(1, 50.0), (37, 30.0), (700, 200.0), (3000, 400.0)])
-def test_device_nms_bit_exact_vs_host(K, k, spread):
-    """hn_nms_sorted (IoU bit-mask + one-wave scan) keeps exactly the indices of the host numpy NMS of postprocess.py -- which the CPU
-    tests pin to the oracle / the reference's recorded post-process -- incl. the batched (per-class offset) form and score ties."""
-    from multitask_hydranet_amd import postprocess as PP
+def test_device_nms_bit_exact_vs_oracle(K, k, spread):
+    """hn_nms_sorted (IoU bit-mask + one-wave scan) keeps exactly the indices of the ORACLE's greedy NMS (oracle.nms_greedy, the restated
+    torchvision semantics the CPU tests pin with known answers), incl. many exact score ties (stable order)."""
+    from multitask_hydranet_amd._lib import lib
+    from oracle import hydranet_oracle as O
     g = torch.Generator(device="cuda").manual_seed(k)
     ctr = torch.rand(k, 2, device="cuda", generator=g) * spread
     wh = torch.rand(k, 2, device="cuda", generator=g) * 40 + 4
     boxes = torch.cat([ctr - wh / 2, ctr + wh / 2], 1)
-    scores = (torch.rand(k, device="cuda", generator=g) * 20).round() / 20            # many exact ties -> stable order matters
-    cls = torch.randint(0, 3, (k,), device="cuda", generator=g)
+    scores = (torch.rand(k, device="cuda", generator=g) * 20).round() / 20
     for thr in (0.3, 0.5):
-        dev_keep = PP.nms(boxes, scores, thr)
-        host_keep = PP.nms(boxes.cpu(), scores.cpu(), thr)
-        assert torch.equal(dev_keep.cpu(), host_keep), (k, thr)
-        dev_b = PP.batched_nms(boxes, scores, cls, thr)
-        host_b = PP.batched_nms(boxes.cpu(), scores.cpu(), cls.cpu(), thr)
-        assert torch.equal(dev_b.cpu(), host_b), (k, thr, "batched")
-        assert 0 < len(host_b) <= k
+        order = torch.argsort(scores, descending=True, stable=True)
+        b = boxes[order].contiguous()
+        mask = torch.empty((lib().query("hn_nms_mask_words", k),), device="cuda", dtype=torch.int64)
+        keep = torch.empty((k,), device="cuda", dtype=torch.uint8)
+        lib().call("hn_nms_sorted", b.data_ptr(), k, float(thr), mask.data_ptr(), keep.data_ptr())
+        dev_keep = order[keep.bool()].cpu()
+        ref = O.nms_greedy(boxes.cpu(), scores.cpu(), thr)
+        assert torch.equal(dev_keep, ref), (k, thr)
+        assert 0 < len(ref) <= k

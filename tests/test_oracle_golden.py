@@ -241,3 +241,52 @@ def test_big_cfg_numeric_digest():
         assert abs(got[1] - ref[1]) <= 1e-4 * ref[1] and abs(got[2] - ref[2]) <= 1e-4 * ref[2], (k, got, ref)
     hist = torch.bincount(torch.argmax(eo["seg"], 1).flatten(), minlength=5).numpy()
     assert np.abs(hist - z["digest/eval/seg_argmax_hist"]).sum() <= 4          # a handful of near-tie pixels may flip between graph orders
+
+
+@pytest.mark.parametrize("tag", ["512x1024", "640x640", "128x256"])
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_lane_decode_and_nms_vs_reference_codec(tag, case):
+    """oracle lane decode + lane NMS against the reference's own LaneHeader.decode / LaneCodec.decode_lane / nms_with_pos outputs
+    (tests/golden/lane_decode.npz): kept lanes, their order, start/end positions and point counts are exact (INT bookkeeping);
+    probabilities and point coordinates to float32 precision."""
+    z = load_npz("lane_decode.npz")
+    w, h, stride, ppl = (int(v) for v in z[f"{tag}/geom"])
+    thr, nms_thr, use_mean = z[f"{tag}/{case}/params"]
+    geo = O.LaneGeometry(w, h, stride, ppl)
+    cand = O.lane_decode(geo, z[f"{tag}/cls"], z[f"{tag}/loc"], float(thr))
+    assert len(cand) == int(z[f"{tag}/{case}/n_candidates"])
+    lanes = O.lane_nms(cand, float(nms_thr), bool(use_mean))
+    k = f"{tag}/{case}"
+    assert [l["start_pos"] for l in lanes] == z[k + "/start_pos"].tolist()
+    assert [l["end_pos"] for l in lanes] == z[k + "/end_pos"].tolist()
+    assert [len(l["xs"]) for l in lanes] == z[k + "/npts"].tolist()
+    np.testing.assert_allclose([l["prob"] for l in lanes], z[k + "/prob"], rtol=1e-6)
+    np.testing.assert_allclose([l["ax"] for l in lanes], z[k + "/ax"], rtol=0, atol=0)
+    np.testing.assert_allclose([l["ay"] for l in lanes], z[k + "/ay"], rtol=0, atol=0)
+    np.testing.assert_allclose(np.concatenate([l["xs"] for l in lanes]), z[k + "/xs"], rtol=1e-6, atol=1e-4)
+    np.testing.assert_allclose(np.concatenate([l["ys"] for l in lanes]), z[k + "/ys"], rtol=0, atol=1e-9)
+
+
+def test_preprocess_and_iou_vs_reference():
+    """(f3) oracle pre-processing at the network size against the reference's imagenet_normalize output (bit-exact: float64 arithmetic, one
+    final cast); (f4) oracle IoU statistics / scores against head_seg/seg_metrics.py, incl. ignore pixels, ignore_index and absent classes."""
+    z = load_npz("aux_stages.npz")
+    frame = z["pre/frame_bgr"]
+    got = O.preprocess_bgr(frame, frame.shape[:2])
+    assert got.dtype == np.float32 and np.array_equal(got, z["pre/expected"])
+    # the restated cv2 fixed-point resize: identity at equal size, exact on a constant image, within 1 grey level of float bilinear
+    const = np.full((10, 14, 3), 77, np.uint8)
+    assert np.array_equal(O.resize_bilinear_u8(const, (25, 31)), np.full((25, 31, 3), 77, np.uint8))
+    up = O.resize_bilinear_u8(frame, (48, 80)).astype(np.float64)
+    ref = torch.nn.functional.interpolate(torch.from_numpy(frame.astype(np.float64)).permute(2, 0, 1)[None], size=(48, 80), mode="bilinear",
+                                          align_corners=False)[0].permute(1, 2, 0).numpy()
+    assert np.abs(up - ref).max() <= 1.0
+    pred, tgt = torch.from_numpy(z["iou/pred"]), torch.from_numpy(z["iou/target"])
+    tp, fp, fn, sup = O.seg_stat_scores(pred, tgt, 5)
+    for name, v in (("tp", tp), ("fp", fp), ("fn", fn), ("sup", sup)):
+        assert np.array_equal(v.numpy().astype(np.float32), z["iou/" + name]), name
+    for name, nc, kw in (("plain", 5, {}), ("ignore0", 5, dict(ignore_index=0)), ("absent", 7, dict(absent_score=1.0))):
+        a = O.seg_stat_scores(pred, tgt, nc)
+        b = O.seg_stat_scores(tgt.clamp_max(4), tgt, nc)
+        sc = O.seg_iou_scores(*(x + y for x, y in zip(a, b)), **kw)
+        np.testing.assert_allclose(sc.numpy(), z[f"iou/{name}/scores"], rtol=1e-6)

@@ -1,0 +1,195 @@
+"""GPU parity of the stages either side of the hot path: device detection post-process, lane decode + lane NMS,
+input pre-processing, streaming segmentation IoU -- against the oracle restatements and the fixtures recorded from the reference itself.
+INT bookkeeping (kept indices, order, classes, lane positions, counts) is exact; fp32 values to float32 precision."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import load_cfg, load_npz
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    import __graft_entry__ as g
+    g.build()
+    import multitask_hydranet_amd as P
+    from oracle import hydranet_oracle as O
+    return P, O
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# (f1) detection post-process
+# ------------------------------------------------------------------------------------------------------------------------------------
+def _check_det(mine, ref):
+    assert len(mine) == len(ref)
+    total = 0
+    for i, (o, r) in enumerate(zip(mine, ref)):
+        assert np.array_equal(np.asarray(o["class_ids"], np.int64), np.asarray(r["class_ids"], np.int64)), i
+        assert np.array_equal(np.asarray(o["scores"], np.float32), np.asarray(r["scores"], np.float32)), i
+        # box corners go through exp(): the device expf and the host libm differ by an ulp
+        np.testing.assert_allclose(np.asarray(o["rois"], np.float32).reshape(-1, 4), np.asarray(r["rois"], np.float32).reshape(-1, 4),
+                                   rtol=1e-6, atol=1e-5)
+        total += len(o["class_ids"])
+    return total
+
+
+def test_det_postprocess_vs_reference_recording(pkg):
+    """the reference's own recorded postprocess output (tiny fixture, DetectionHeader.decode): identical kept boxes / classes / scores"""
+    P, O = pkg
+    from multitask_hydranet_amd.postprocess import postprocess
+    z = load_npz("tiny_hydranet.npz")
+    reg, cls = torch.from_numpy(z["deploy/regression"]), torch.from_numpy(z["deploy/classification"])
+    anc = torch.from_numpy(z["out/anchors"])
+    hw = tuple(z["in/image"].shape[2:])
+    mine = postprocess(hw, anc, reg, cls, float(z["deploy/pp_thresh"]), 0.3)
+    ref = [dict(rois=z[f"deploy/pp{i}/rois"], class_ids=z[f"deploy/pp{i}/class_ids"], scores=z[f"deploy/pp{i}/scores"]) for i in range(len(mine))]
+    assert _check_det(mine, ref) > 0
+
+
+@pytest.mark.parametrize("n,thr,iou,spread", [(4, 0.30, 0.3, 1.0), (2, 0.05, 0.5, 0.5), (3, 0.9999, 0.3, 1.0), (16, 0.2, 0.4, 2.0)])
+def test_det_postprocess_fullsize_vs_oracle(pkg, n, thr, iou, spread):
+    """98 208 anchors x 9 classes at 512x1024: clustered detections (many overlapping boxes per object so the NMS has work), an empty
+    image, score ties; kept indices / classes / scores identical to the oracle's host post-process, whole batch in one pipeline"""
+    P, O = pkg
+    cfgs = load_cfg("hydranet_big.yml")
+    H, W = 512, 1024
+    a = torch.from_numpy(O.anchors_for(H, W, cfgs))[None]
+    A = a.shape[1]
+    g = torch.Generator().manual_seed(int(thr * 1000) + n)
+    reg = torch.randn(n, A, 4, generator=g) * 0.2 * spread
+    cls = torch.sigmoid(torch.randn(n, A, 9, generator=g) * 1.5 - 4.0)
+    hot = torch.randint(0, A, (n, 300), generator=g)
+    for i in range(n):
+        cls[i, hot[i], torch.randint(0, 9, (300,), generator=g)] = 0.5 + 0.5 * torch.rand(300, generator=g)
+    cls[0, 100:110, 3] = 0.75                                     # exact score ties: order by anchor index
+    if n > 2:
+        cls[2] = cls[2] * 0.01                                    # an image with nothing over the threshold
+    from multitask_hydranet_amd.postprocess import postprocess
+    mine = postprocess((H, W), a.cuda(), reg.cuda(), cls.cuda(), thr, iou)
+    ref = O.postprocess((H, W), torch.stack([a[0]] * n), reg, cls, thr, iou)
+    total = _check_det(mine, ref)
+    if n > 2:
+        assert len(mine[2]["class_ids"]) == 0
+    assert total > 0 or thr > 0.999
+
+
+def test_deploy_forward_appends_device_detections(pkg):
+    P, O = pkg
+    from tests.helpers import tiny_state
+    z = load_npz("tiny_hydranet.npz")
+    net = P.HydraNet(load_cfg("hydranet_tiny.yml"))
+    net.load_state_dict(tiny_state(z))
+    net = net.cuda().eval()
+    thr = float(z["deploy/pp_thresh"])
+    net.deploy_postprocess = (thr, 0.3)
+    with torch.no_grad():
+        dep = net(torch.from_numpy(z["in/image"]).cuda(), "deploy")
+    assert len(dep) == 7 and dep[6]["rois"].is_cuda and dep[6]["kept"].shape == (2,)
+    det = dep[6]
+    ref = O.postprocess(tuple(z["in/image"].shape[2:]), torch.stack([dep[1][0].cpu()] * 2), dep[2].cpu(), dep[3].cpu(), thr, 0.3)
+    for i, r in enumerate(ref):
+        k = int(det["kept"][i])
+        assert k == len(r["class_ids"])
+        assert np.array_equal(det["class_ids"][i, :k].cpu().numpy(), np.asarray(r["class_ids"], np.int64))
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# (f2) lane decode + lane NMS
+# ------------------------------------------------------------------------------------------------------------------------------------
+def _check_lanes(lanes, ref_prob, ref_start, ref_end, ref_npts, ref_xs, ref_ys, ref_ax=None):
+    assert [l.start_pos for l in lanes] == list(ref_start)
+    assert [l.end_pos for l in lanes] == list(ref_end)
+    assert [len(l.lane) for l in lanes] == list(ref_npts)
+    np.testing.assert_allclose([float(l.prob) for l in lanes], ref_prob, rtol=2e-6)
+    if ref_ax is not None:
+        np.testing.assert_allclose([l.ax for l in lanes], ref_ax, rtol=0, atol=0)
+    np.testing.assert_allclose([float(p.x) for l in lanes for p in l.lane], ref_xs, rtol=1e-6, atol=1e-4)
+    np.testing.assert_allclose([float(p.y) for l in lanes for p in l.lane], ref_ys, rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("tag", ["512x1024", "640x640", "128x256"])
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_lane_decode_nms_vs_reference_codec(pkg, tag, case):
+    """HIP lane decode + NMS against the outputs of the reference's own LaneHeader.decode (tests/golden/lane_decode.npz)"""
+    P, O = pkg
+    from multitask_hydranet_amd import lane_codec as LC
+    z = load_npz("lane_decode.npz")
+    w, h, stride, ppl = (int(v) for v in z[f"{tag}/geom"])
+    thr, nms_thr, use_mean = z[f"{tag}/{case}/params"]
+    codec = LC.LaneCodec(w, h, stride, ppl, do_interpolate=True, anchor_lane_num=1, scale_invariance=True)
+    cls, loc = torch.from_numpy(z[f"{tag}/cls"]).cuda(), torch.from_numpy(z[f"{tag}/loc"]).cuda()
+    lanes = LC.decode(cls, loc, codec, float(thr), float(nms_thr), bool(use_mean))
+    k = f"{tag}/{case}"
+    _check_lanes(lanes, z[k + "/prob"], z[k + "/start_pos"], z[k + "/end_pos"], z[k + "/npts"], z[k + "/xs"], z[k + "/ys"], z[k + "/ax"])
+    cand = codec.decode_lane(torch.softmax(cls, -1), loc, float(thr))
+    assert len(cand) == int(z[k + "/n_candidates"])
+    d = LC.scale_to_org(lanes, w, h, 1920, 1080)                       # host bookkeeping runs on the device result
+    assert len(d["Lines"]) == len(lanes)
+
+
+def test_lane_decode_nms_batch_vs_oracle(pkg):
+    """a random batch of 16 images at 512x1024 (most anchors firing: hundreds of candidates per image) against the oracle, one launch"""
+    P, O = pkg
+    from multitask_hydranet_amd import lane_codec as LC
+    n, w, h, stride, ppl = 16, 1024, 512, 32, 64
+    g = torch.Generator().manual_seed(77)
+    hw = (w // stride) * (h // stride)
+    cls = torch.randn(n, hw, 2, generator=g) * 2
+    loc = torch.randn(n, hw, 2 * ppl + 2, generator=g) * 2.0
+    loc[:, :, ppl] = torch.rand(n, hw, generator=g) * ppl
+    loc[:, :, ppl + 1] = torch.rand(n, hw, generator=g) * ppl
+    codec = LC.LaneCodec(w, h, stride, ppl)
+    geo = O.LaneGeometry(w, h, stride, ppl)
+    res = LC.decode_batch(cls.cuda(), loc.cuda(), codec, 0.5, 30.0, False)
+    for i in range(n):
+        ref = O.lane_postprocess(geo, cls[i].numpy(), loc[i].numpy(), 0.5, 30.0, False)
+        _check_lanes(res[i], [l["prob"] for l in ref], [l["start_pos"] for l in ref], [l["end_pos"] for l in ref], [len(l["xs"]) for l in ref],
+                     np.concatenate([l["xs"] for l in ref]) if ref else [], np.concatenate([l["ys"] for l in ref]) if ref else [])
+        assert len(ref) > 3
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# (f3) pre-processing, (f4) streaming IoU
+# ------------------------------------------------------------------------------------------------------------------------------------
+def test_preprocess_bgr(pkg):
+    P, O = pkg
+    from multitask_hydranet_amd.preprocess import preprocess_bgr
+    z = load_npz("aux_stages.npz")
+    frame = z["pre/frame_bgr"]
+    out = preprocess_bgr(frame, frame.shape[:2])
+    assert out.shape == (1, 3) + frame.shape[:2] and np.array_equal(out[0].cpu().numpy(), z["pre/expected"])     # reference recording, bit-exact
+    rng = np.random.RandomState(3)
+    frames = rng.randint(0, 256, size=(2, 1080, 1920, 3)).astype(np.uint8)
+    for hw in ((512, 1024), (640, 640), (1152, 1920), (1080, 1920)):
+        got = preprocess_bgr(frames, hw).cpu().numpy()
+        for i in range(2):
+            assert np.array_equal(got[i], O.preprocess_bgr(frames[i], hw)), hw          # vs the oracle's restated cv2 fixed-point resize
+
+
+def test_streaming_iou(pkg):
+    P, O = pkg
+    from multitask_hydranet_amd.metrics import IntersectionOverUnion
+    z = load_npz("aux_stages.npz")
+    pred, tgt = torch.from_numpy(z["iou/pred"]), torch.from_numpy(z["iou/target"])
+    for name, nc, kw in (("plain", 5, {}), ("ignore0", 5, dict(ignore_index=0)), ("absent", 7, dict(absent_score=1.0))):
+        m = IntersectionOverUnion(nc, **kw)
+        m.update(pred.cuda(), tgt.cuda().float())                                       # float class ids, as to_gpu delivers them
+        m.update(tgt.clamp_max(4).cuda(), tgt.cuda())
+        np.testing.assert_allclose(m.compute().cpu().numpy(), z[f"iou/{name}/scores"], rtol=1e-6)
+    m = IntersectionOverUnion(5)
+    m.update(pred.cuda(), tgt.cuda())
+    tp, fp, fn, sup = m.stats()
+    for name, v in (("tp", tp), ("fp", fp), ("fn", fn), ("sup", sup)):
+        assert np.array_equal(v.cpu().numpy().astype(np.float32), z["iou/" + name]), name
+    # full-size mask (16 x 512 x 1024 = 8.4 M pixels): exact against the oracle's bincount
+    g = torch.Generator().manual_seed(1)
+    p2, t2 = torch.randint(0, 5, (16, 512, 1024), generator=g), torch.randint(0, 6, (16, 512, 1024), generator=g)
+    t2[t2 == 5] = 255
+    m = IntersectionOverUnion(5)
+    m.update(p2.cuda(), t2.cuda())
+    for a, b in zip(m.stats(), O.seg_stat_scores(p2, t2, 5)):
+        assert torch.equal(a.cpu(), b)
