@@ -195,8 +195,9 @@ int hn_bn_bwd_apply_levels(const void* dout, int ldd, const void* z, int ldz, co
  * row blocks of RB rows), every workgroup reduces the P partial rows of its own 64 channels.  Replaces hn_bn_finalize + hn_bn_act and
  * hn_bn_bwd_finalize + hn_bn_bwd_apply (and the hn_rows_reduce2 folds in front of them) for net/anynet.py:31,36,54,59,65-76,
  * net/common.py:98, net/bifpn.py:58-102, head_lane/lanedetect.py:45-64. */
-/* rows per row block for M rows x C channels (<= 512 row blocks; a divisor of `align` = rows per image when align > 0) */
-long hn_fused_row_block(long M, int C, long align);
+/* rows per row block for M rows x C channels whose consumer prologue reduces P partial rows (<= 512 row blocks; with align = rows per image
+ * > 0: a divisor of align, at most 4 row blocks per image) */
+long hn_fused_row_block(long M, int C, long align, int P);
 /* out = act(bn(z) [+ res]).  P > 0: training mode, statistics from psum/psq [P][C] (count = rows normalised over), row block 0 writes
  * coef [4][C] (scale, shift, mean, rstd) and updates rm/rv; P == 0: use coef as is (null = identity); P < 0: eval mode (running statistics).
  * out may be null when only pool is wanted; pool (optional) [ceil(M/RB)][C] = per-row-block channel sums of the bf16-rounded output

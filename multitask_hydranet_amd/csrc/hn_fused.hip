@@ -408,18 +408,30 @@ __global__ __launch_bounds__(256) void fused_se_bwd_kernel(const FSeBwd p) {
 // ---------------------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------------------
-// rows per row block: ~2 workgroups per CU over (chunks x row blocks), at most 512 row blocks (= partial rows a consumer's prologue
-// reduces), at least 16 rows; a divisor of `align` (rows per image) when given.
-extern "C" long hn_fused_row_block(long M, int C, long align) {
+// Rows per row block.  A workgroup's prologue reads P x 64 x 8 bytes of partial rows and its payload is RB x 64 x 2..6 bytes, and every
+// launch has a fixed cost, so small tensors want FEW fat workgroups: RB >= 4 P (prologue <= half the payload), RB >= 2 sqrt(M) (the
+// reduce -> apply pair of the backward pass hands over M/RB partial rows), >= 32 KB of rows per workgroup; then capped so that at least
+// ~128 workgroups exist and at most 512 row blocks.  With align (rows per image) RB divides align and is >= align / 4 (SE squeeze
+// partials: <= 4 per image).
+extern "C" long hn_fused_row_block(long M, int C, long align, int P) {
     const long chunks = (C + FCH - 1) / FCH;
-    long nrb = (512 + chunks - 1) / chunks;
-    if (nrb > 512) nrb = 512;
-    long RB = (M + nrb - 1) / nrb;
+    const long cw = C < FCH ? C : FCH;
+    long RB = 32768 / (cw * 2);
+    long sq = 1;
+    while (sq * sq < 4 * M) ++sq;                       // 2 sqrt(M)
+    if (sq > RB) RB = sq;
+    if (4L * P > RB) RB = 4L * P;
+    const long nrb_min = (128 + chunks - 1) / chunks;
+    const long cap = (M + nrb_min - 1) / nrb_min;
+    if (RB > cap) RB = cap;
+    const long lo = (M + 511) / 512;
+    if (RB < lo) RB = lo;
     if (RB < 16) RB = 16;
+    if (RB > M) RB = M;
     if (align > 0) {
         if (RB > align) RB = align;
-        while (align % RB) --RB;
-        while ((M + RB - 1) / RB > 512 && RB < align) { ++RB; while (align % RB) ++RB; }
+        if (RB < (align + 3) / 4) RB = (align + 3) / 4;
+        while (align % RB) ++RB;                        // smallest divisor of align that is >= RB (terminates at RB == align)
     }
     return RB;
 }

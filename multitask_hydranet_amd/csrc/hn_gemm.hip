@@ -248,15 +248,19 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
     // XF: the pixel operand of the stage in flight lives in registers (raw rows + the per-channel coefficients of its 8 channels + the
     // per-image gate) and is transformed / stored to LDS after the MFMAs of the previous stage
     bf16x8 xraw[XF ? XR : 1];
-    f32x4 xsc[2], xsh[2], xgt[XF ? XR : 1][2];
     bool xval[XF ? XR : 1];
-    int ximg[XF ? XR : 1];
+    int xch = 0;
+    // per-channel coefficients (scale, shift, gate of the tile's image: xhw is a multiple of BP) staged in LDS once, behind the ring
+    float* xcoef = reinterpret_cast<float*>(smem + R * STAGE);
     if (XF) {
-#pragma unroll
-        for (int i = 0; i < XR; ++i) {
-            const long m = p_blk + r0 + 32 * i;
-            ximg[i] = (p.xgate && m < p.x.M) ? (int)(m / p.xhw) : 0;
+        const long img = p.xgate ? p_blk / p.xhw : 0;
+        for (int i = tid; i < p.KP; i += 256) {
+            const bool v = i < Ctot;
+            xcoef[i] = v ? p.xscale[i] : 0.f;
+            xcoef[p.KP + i] = v ? p.xshift[i] : 0.f;
+            xcoef[2 * p.KP + i] = (v && p.xgate) ? p.xgate[img * Ctot + i] : 1.f;
         }
+        __syncthreads();                                          // the first transform (end of iteration 0) reads other threads' entries
     }
     for (int it = 0; it < S + R - 1; ++it) {
         if (it >= R - 1) {
@@ -279,20 +283,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
             const long ldx = from0 ? p.x.ld0 : p.x.ld1;
             if (XF) {
                 xcv = cv;
-                if (cv) {
-                    xsc[0] = *reinterpret_cast<const f32x4*>(p.xscale + c); xsc[1] = *reinterpret_cast<const f32x4*>(p.xscale + c + 4);
-                    xsh[0] = *reinterpret_cast<const f32x4*>(p.xshift + c); xsh[1] = *reinterpret_cast<const f32x4*>(p.xshift + c + 4);
-                }
+                xch = c;
 #pragma unroll
                 for (int i = 0; i < XR; ++i) {
                     const int pix = from0 ? pix0[i] : pix1[i];
                     xval[i] = cv && pix >= 0;
                     const bf16* src = xval[i] ? xbase + (long)pix * ldx : g_zero_piece;
                     xraw[i] = ld8(src);
-                    if (p.xgate && xval[i]) {
-                        const float* gp = p.xgate + (long)ximg[i] * Ctot + c;
-                        xgt[i][0] = *reinterpret_cast<const f32x4*>(gp); xgt[i][1] = *reinterpret_cast<const f32x4*>(gp + 4);
-                    }
                 }
             } else {
 #pragma unroll
@@ -337,17 +334,28 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
         }
         if (XF && it < S) {                                       // transform the stage in flight and store it where the DMA would have
             char* sX = smem + (it % R) * STAGE + BC * 128;
+            float sc[8], sh[8], gt[8];
+            if (xcv) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(xcoef + xch + 4 * h);
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(xcoef + p.KP + xch + 4 * h);
+                    const f32x4 g = *reinterpret_cast<const f32x4*>(xcoef + 2 * p.KP + xch + 4 * h);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { sc[4 * h + k] = a[k]; sh[4 * h + k] = b[k]; gt[4 * h + k] = g[k]; }
+                }
+            }
 #pragma unroll
             for (int i = 0; i < XR; ++i) {
                 bf16x8 o = zero8();
                 if (xval[i]) {
                     float v[8];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = bf2f(xraw[i][k]) * xsc[k >> 2][k & 3] + xsh[k >> 2][k & 3];
+                    for (int k = 0; k < 8; ++k) v[k] = bf2f(xraw[i][k]) * sc[k] + sh[k];
                     act_fwd_n(v, p.xact);
                     if (p.xgate) {
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) v[k] = bfround(v[k]) * xgt[i][k >> 2][k & 3];
+                        for (int k = 0; k < 8; ++k) v[k] = bfround(v[k]) * gt[k];
                     }
 #pragma unroll
                     for (int k = 0; k < 8; ++k) o[k] = f2bf(v[k]);
@@ -355,7 +363,6 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
                 *reinterpret_cast<bf16x8*>(sX + (wave * 8 + 32 * i) * 128 + lane * 16) = o;
             }
         }
-        (void)xcv;
     }
 
     // ---- epilogue: bias, activation, optional BN partial statistics; store.  bf16 outputs whose rows are 16-B aligned go through an
@@ -379,6 +386,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
             for (int r = 0; r < 4; ++r) vv[(i * TP + j) * 4 + r] = acc[i][j][r] + bsv[r];
     }
     if (want_stats) {
+        if (!staged) __syncthreads();                                 // the operand ring is free: [WGP][BC][2] floats of it hold the wave sums
+        float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
         for (int i = 0; i < TC; ++i) {
             const int co0 = c_blk + wc * WC + i * 16 + (lane >> 4) * 4;
@@ -400,15 +409,20 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
                 s2[r] = row16_sum(s2[r]);
             }
             if ((lane & 15) == 0) {
-                const long prow = (long)p_tile * WGP + wp;
+                const int cl = wc * WC + i * 16 + (lane >> 4) * 4;
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (co0 + r < p.Nout) {
-                        p.psum[prow * p.Nout + co0 + r] = s1[r];
-                        p.psq[prow * p.Nout + co0 + r] = s2[r];
-                    }
+                for (int r = 0; r < 4; ++r) { red[(wp * BC + cl + r) * 2] = s1[r]; red[(wp * BC + cl + r) * 2 + 1] = s2[r]; }
             }
         }
+        __syncthreads();
+        if (tid < BC && c_blk + tid < p.Nout) {                       // one partial row per pixel tile: the WGP wave sums in fixed order
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < WGP; ++k) { t1 += red[(k * BC + tid) * 2]; t2 += red[(k * BC + tid) * 2 + 1]; }
+            p.psum[(long)p_tile * p.Nout + c_blk + tid] = t1;
+            p.psq[(long)p_tile * p.Nout + c_blk + tid] = t2;
+        }
+        __syncthreads();                                              // before the staged epilogue reuses the same LDS
     }
     act_fwd_n(vv, p.act);
     if (staged) {
@@ -1213,7 +1227,9 @@ static int launch_nt_r(const GemmNT& p, int out_f32, hipStream_t st) {
 template <int BC, int BP, int WGC, int WGP>
 static int launch_nt_xf(const GemmNT& p, hipStream_t st) {
     dim3 grid(cdiv(p.x.M, BP) * cdiv(p.Nout, BC));
-    const size_t lds = (size_t)(BC + BP) * 128 * 2;
+    const size_t lds = (size_t)(BC + BP) * 128 * 2 + (size_t)3 * p.KP * sizeof(float);
+    if (p.xgate && p.xhw % BP != 0) return HN_ERR_UNSUPPORTED;     // a pixel tile must lie inside one image (per-image gate row in LDS)
+    if (lds > 64 * 1024) return HN_ERR_UNSUPPORTED;
     hipLaunchKernelGGL((gemm_nt_kernel<BC, BP, WGC, WGP, false, 2, true>), grid, dim3(256), lds, st, p);
     HN_LAUNCH_CHECK();
 }
@@ -1256,12 +1272,8 @@ static bool small_tile(long M, int Nout) { return !g_nt_force_bc && Nout > 64 &&
 // partial statistic rows of a mode-5 (grouped 3x3 on the direct kernel) launch: one per 16x16 output patch
 extern "C" int hn_direct_stat_rows(int n_img, int H, int W) { return n_img * cdiv(H, 16) * cdiv(W, 16); }
 
-extern "C" int hn_nt_stat_rows(long M, int Nout) {
-    if (small_tile(M, Nout)) return cdiv(M, 64) * 2;
-    const int bc = pick_bc(Nout);
-    if (bc == 16) return cdiv(M, 128) * 4;
-    if (bc == 32) return cdiv(M, 128) * 4;
-    return cdiv(M, 128) * 2;
+extern "C" int hn_nt_stat_rows(long M, int Nout) {               // one partial row per pixel tile of the tiling hn_conv_gemm_nt picks
+    return small_tile(M, Nout) ? cdiv(M, 64) : cdiv(M, 128);
 }
 
 static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img, int H, int W, int C0, int C1, int ld0, int ld1,

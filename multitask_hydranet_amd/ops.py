@@ -308,7 +308,7 @@ MAX_PROLOGUE_ROWS = 512    # partial statistic rows a consumer prologue reduces 
 def k_col_stats_fused(x, align=0):
     """per-row-block channel sums / sums of squares of a bf16 tensor: (psum, psq) [P <= 512][C]"""
     m, c = rows(x), x.shape[3]
-    rb = lib().query("hn_fused_row_block", m, c, align)
+    rb = lib().query("hn_fused_row_block", m, c, align, 0)
     pr = (m + rb - 1) // rb
     ps = torch.empty((pr, c), device=x.device, dtype=F32)
     pq = torch.empty((pr, c), device=x.device, dtype=F32)
@@ -328,7 +328,7 @@ def k_bn_apply_fused(z, psum, psq, count, gamma, beta, eps, momentum, rm, rv, ac
         P = psum.shape[0]
     else:
         P = -1
-    rb = lib().query("hn_fused_row_block", m, c, pool_align)
+    rb = lib().query("hn_fused_row_block", m, c, pool_align, max(P, 0))
     coef = torch.empty((4, c), device=dev, dtype=F32)
     if want_out and out is None:
         out = new_act(n, h, w, c, dev)
@@ -344,7 +344,7 @@ def bn_backward_fused(dout, z, y, coef, act, count, want_g=False, gate=None, dpo
     n, h, w, c = z.shape
     m = rows(z)
     dev = z.device
-    rb = lib().query("hn_fused_row_block", m, c, hw)
+    rb = lib().query("hn_fused_row_block", m, c, hw, 0)
     pr = (m + rb - 1) // rb
     pg = torch.empty((pr, c), device=dev, dtype=F32)
     pgx = torch.empty((pr, c), device=dev, dtype=F32)
@@ -558,7 +558,7 @@ class XBlockFn(torch.autograd.Function):
         dz3, dg3, db3, g = bn_backward_fused(dout, z3, out, coef3, ACT_RELU, m, want_g=True)
         dbg, _, _ = k_gemm_nt(dz3, None, 0, grid, wt3, c, kp32(c), 1)
         # one pass over (dbg, z2): gate-gradient partials and the gated operand bg = relu(bn2(z2)) * gate of conv_block_3's wgrad
-        rb = lib().query("hn_fused_row_block", m, c, hw)
+        rb = lib().query("hn_fused_row_block", m, c, hw, 0)
         bg = new_act(n, h, w, c, dev)
         pdot = torch.empty(((m + rb - 1) // rb, c), device=dev, dtype=F32)
         lib().call("hn_se_bwd_reduce_fused", ptr(dbg), ld(dbg), ptr(z2), ld(z2), ptr(coef2), ptr(gate), hw, ptr(bg), ld(bg), ptr(pdot), m, c, rb)
@@ -586,7 +586,8 @@ class XBlockFn(torch.autograd.Function):
 def xblock_fusable(x, w1, stride, has_se, has_shortcut):
     """the fused node covers the stride-1 identity blocks with SE whose channel count is a multiple of 8 (every non-first block of a stage)"""
     return (FUSED_XBLOCK and FUSED_BN and GCONV_MFMA and x.is_cuda and stride == 1 and has_se and not has_shortcut
-            and w1.shape[0] == w1.shape[1] and w1.shape[0] % 8 == 0)
+            and w1.shape[0] == w1.shape[1] and w1.shape[0] % 8 == 0 and (x.shape[1] * x.shape[2]) % 128 == 0
+            and 3 * kp32(w1.shape[0]) * 4 <= 32768)
 
 
 # --------------------------------------------------------------------------------------------------------------
