@@ -1,3 +1,65 @@
+    graph = None
+    static_loss = None
+    in_graph_exchange = False
+
+    def capture(with_hooks):
+        """two eager warm-up steps on a side stream, then the capture.  with_hooks: the reducer's autograd hooks stay armed, so every
+        bucket's gather + all-reduce is captured on the reducer's side stream, forked from / joined to the capture stream by events."""
+        s_ = torch.cuda.Stream()
+        s_.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s_):
+            for _ in range(2):
+                net.zero_grad(set_to_none=True)
+                l0 = fwd_bwd()
+                if reducer is not None and with_hooks:
+                    reducer.finish()
+                if os.environ.get("HN_BENCH_DEBUG"):
+                    print("rank", rank, "eager loss", float(l0.detach()), file=sys.stderr, flush=True)
+        torch.cuda.current_stream().wait_stream(s_)
+        torch.cuda.synchronize()
+        net.zero_grad(set_to_none=True)
+        g = torch.cuda.CUDAGraph()
+        # thread-local capture mode: the RCCL watchdog thread's event queries (N > 1) must not invalidate the capture
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            sl = fwd_bwd()
+            if reducer is not None and with_hooks:
+                reducer.join_capture()
+        return g, sl
+
+    if use_graph:
+        try:
+            if reducer is not None and not args.exchange_after_replay:
+                try:
+                    graph, static_loss = capture(with_hooks=True)
+                    reducer.adopt_bucket_grads()
+                    reducer.remove()
+                    in_graph_exchange = reducer.captured
+                except Exception as e:              # noqa: BLE001  (an RCCL build that cannot be captured)
+                    if rank == 0:
+                        print("capturing the all-reduce inside the hipGraph failed (%r): exchanging after the replay instead" % (e,), file=sys.stderr)
+                    torch.cuda.synchronize()
+                    graph = None
+                    reducer.remove()
+                    reducer = make_reducer()
+            if graph is None:
+                if reducer is not None:
+                    reducer.remove()                # no hooks during this capture; gradients are exchanged right after each replay
+                graph, static_loss = capture(with_hooks=False)
+                if reducer is not None:
+                    # after a replay nothing is left to overlap with: ONE flat bucket = one gather + one all-reduce for all 693 gradients
+                    reducer = make_reducer(bucket_bytes=1 << 40)
+                    reducer.remove()
+                    reducer.bind_static_grads()     # every replay rewrites these tensors; reduce_now() gathers them into the bucket
+        except Exception as e:                      # noqa: BLE001
+            if rank == 0:
+                import traceback
+                traceback.print_exc()
+                print("hipGraph capture failed, falling back to eager launches: %r" % (e,), file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+            if exchange:
+                reducer = make_reducer()
+
 #!/usr/bin/env python3
 """bench.py -- images/sec for HydraNet forward+loss+backward on MI355X (BASELINE.json metric), HIP path only.
 
@@ -87,7 +149,7 @@ def dominant_launch_roofline(net, n, h, w, iters=20):
     alg_bytes = 2.0 * (n * (hh // 2) * (ww // 2) * c0 + n * hh * ww * c1 + n * hh * ww * cout + cout * cin * 9)
     return {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
             "traffic": measured_traffic(alg_bytes),
-            "kernel": "conv3x3_direct_kernel<128,bf16> seg decoder.3 (reflect-pad 3x3 over cat[up2(x), skip], 368->256 @ %dx%d, N=%d) fwd" % (hh, ww, n),
+            "kernel": "conv3x3_direct_kernel<128,false> seg decoder.3 (reflect-pad 3x3 over cat[up2(x), skip], 368->256 @ %dx%d, N=%d) fwd" % (hh, ww, n),
             "launch_ms": round(ms, 4), "flop_per_launch": flops, "algorithmic_bytes_per_launch": alg_bytes}
 
 
@@ -182,6 +244,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backbone-only", action="store_true", help="BASELINE config[1]: backbone fwd+bwd, loss = sum of feature means")
     ap.add_argument("--dominant-only", action="store_true", help="launch only the dominant kernel (for rocprofv3 --pmc passes) and exit")
+    ap.add_argument("--ddp-world1", action="store_true", help="run the gradient exchange (RCCL init, ncclAvg, side stream, in-graph capture) "
+                    "at world size 1 -- exercises the N > 1 code path on a single GPU")
+    ap.add_argument("--grad-payload", default="fp32", choices=("fp32", "bf16"), help="gradient all-reduce payload type")
+    ap.add_argument("--exchange-after-replay", action="store_true", help="do not capture the all-reduce inside the hipGraph")
     args = ap.parse_args()
     h, w = (int(v) for v in args.res.split("x"))
     rank = int(os.environ.get("RANK", "0"))
@@ -196,7 +262,11 @@ def main():
     backend = os.environ.get("HN_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    exchange = world > 1 or args.ddp_world1
+    if exchange:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -223,8 +293,14 @@ def main():
     batch = synthetic_batch(cfgs, args.batch, h, w, seed=1 + rank, device=dev)
     reducer = None
     use_graph = not args.no_graph
-    if world > 1:
-        reducer = GradReducer(list(net.named_parameters()), world_size=world, skip=UNUSED_5STAGE if len(net.depths) == 5 else ())
+    payload = torch.bfloat16 if args.grad_payload == "bf16" else torch.float32
+    skip = UNUSED_5STAGE if len(net.depths) == 5 else ()
+
+    def make_reducer(**kw):
+        return GradReducer(list(net.named_parameters()), world_size=world, skip=skip, payload_dtype=payload,
+                           force_collectives=args.ddp_world1, **kw)
+    if exchange:
+        reducer = make_reducer()
 
     def fwd_bwd():
         if args.backbone_only:
@@ -278,7 +354,7 @@ def main():
     def step():
         if graph is not None:
             graph.replay()
-            if reducer is not None and not os.environ.get("HN_BENCH_SKIP_REDUCE"):
+            if reducer is not None and not in_graph_exchange and not os.environ.get("HN_BENCH_SKIP_REDUCE"):
                 reducer.reduce_now()
             return static_loss
         net.zero_grad(set_to_none=False) if reducer is not None else net.zero_grad(set_to_none=True)
@@ -347,8 +423,7 @@ def main():
             "config": {"workload": ("RegNetY backbone only" if args.backbone_only else "full HydraNet (backbone + BiFPN + seg/det/lane heads + multitask loss)")
                        + ", big cfg, fwd+loss+bwd", "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "resolution": "3x%dx%d" % (h, w), "parallelism": "dp%d" % world, "hipgraph": graph is not None,
-                       "grad_allreduce": None if world == 1 else ("bucketed RCCL after graph replay" if graph is not None
-                                                                 else "bucketed RCCL on a side stream overlapped with backward")},
+                       "grad_allreduce": None if reducer is None else ("%s backend: " % backend) + reducer.describe()},
             "ms_optimizer_step": round(ms_opt, 3), "loss": round(loss_val, 4),
             "model_tflops": round(value * gflop_img / 1e3, 2),
             # SURVEY 8(d) segment-wise roofline of the whole step (seg decoder on MFMA, everything else on HBM): 0.177 ms/img at 512x1024
@@ -364,7 +439,7 @@ def main():
             except Exception as e:  # noqa: BLE001
                 res["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(res))
-    if world > 1:
+    if exchange:
         dist.destroy_process_group()
 
 

@@ -195,16 +195,16 @@ int hn_bn_bwd_apply_levels(const void* dout, int ldd, const void* z, int ldz, co
  * row blocks of RB rows), every workgroup reduces the P partial rows of its own 64 channels.  Replaces hn_bn_finalize + hn_bn_act and
  * hn_bn_bwd_finalize + hn_bn_bwd_apply (and the hn_rows_reduce2 folds in front of them) for net/anynet.py:31,36,54,59,65-76,
  * net/common.py:98, net/bifpn.py:58-102, head_lane/lanedetect.py:45-64. */
-/* rows per row block for M rows x C channels whose consumer prologue reduces P partial rows (<= 512 row blocks; with align = rows per image
- * > 0: a divisor of align, at most 4 row blocks per image) */
-long hn_fused_row_block(long M, int C, long align, int P);
-/* out = act(bn(z) [+ res]).  P > 0: training mode, statistics from psum/psq [P][C] (count = rows normalised over), row block 0 writes
- * coef [4][C] (scale, shift, mean, rstd) and updates rm/rv; P == 0: use coef as is (null = identity); P < 0: eval mode (running statistics).
- * out may be null when only pool is wanted; pool (optional) [ceil(M/RB)][C] = per-row-block channel sums of the bf16-rounded output
- * (SE squeeze, net/anynet.py:42,68). */
+/* rows per row block for M rows x C channels.  kind 0: apply passes (P = partial rows their prologue reduces); kind 1: reduce passes (their
+ * row-block count becomes the P of the apply that follows).  align > 0 (rows per image): RB divides align, <= 8 row blocks per image. */
+long hn_fused_row_block(long M, int C, long align, int P, int kind);
+/* out = act(bn(z) [+ res]) [* gate[row / HW][c]].  P > 0: training mode, statistics from psum/psq [P][C] (count = rows normalised over),
+ * row block 0 writes coef [4][C] (scale, shift, mean, rstd) and updates rm/rv; P == 0: use coef as is (null = identity); P < 0: eval mode
+ * (running statistics).  out may be null when only pool is wanted; pool (optional) [ceil(M/RB)][C] = per-row-block channel sums of the
+ * bf16-rounded output (SE squeeze, net/anynet.py:42,68); gate (optional, RB divides HW): SE excite applied to the rounded output. */
 int hn_bn_apply_fused(const void* z, int ldz, long M, int C, const float* psum, const float* psq, int P, long count, const float* gamma,
                       const float* beta, float eps, float momentum, float* rm, float* rv, float* coef, const void* res, int ldr, int act,
-                      void* out, int ldo, float* pool, long RB, hipStream_t stream);
+                      void* out, int ldo, float* pool, const float* gate, long HW, long RB, hipStream_t stream);
 /* BatchNorm backward.  g = dout * act'(scale*z+shift), or dout * [y > 0] when the saved block output y is given (ReLU after the residual
  * add), or, with gate/dpool (SE, RB divides HW): g = (dout*gate[n][c] + dpool[n][c]/HW) * [scale*z+shift > 0] where dout is the gradient of
  * the gated tensor.  reduce: pg/pgx [ceil(M/RB)][C] partial sums of g and g*xhat.  apply: dz = scale*(g - mean g - xhat*mean(g*xhat)),

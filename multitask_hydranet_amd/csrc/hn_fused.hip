@@ -4,14 +4,16 @@
 // reduce + apply backward -- no finalize launches, no partial-row fold launches.  SE pooling rides on the BN2 pass of an XBlock, the SE
 // gate gradient and the gated operand of conv_block_3's weight gradient come out of one pass over (dbg, z2).
 //
-// Layout: tensors are [rows][C] bf16 (row stride ld*).  grid = (channel chunks of 64, row blocks of RB rows); a workgroup owns
-// <= 64 channels (<= 8 lanes of 8 channels, one 128-byte line per row) and RB rows, so its prologue reduces only P x 64 partial values.
+// Layout: tensors are [rows][C] bf16 (row stride ld*).  grid = (channel chunks of <= 128 channels, row blocks of RB rows); a workgroup
+// owns one chunk (<= 16 lanes of 8 channels: up to two 128-byte lines per row; C <= 128 is ONE chunk so whole rows stay contiguous) and
+// RB rows, so its prologue reduces only P x 128 partial values.  Measured on MI355X (tools/bench_fused.py): the passes want ~1000
+// workgroups (RB 32..512), the reduce pass of the backward pair a separate, larger RB (its row count is the apply pass's P).
 // Everything is deterministic: fixed-order LDS reductions, no float atomics.
 // Reference ops: nn.BatchNorm2d training forward/backward (net/anynet.py:31,36,54,59; net/common.py:98; head_lane/lanedetect.py:47-61),
 // ReLU / Swish, residual add (net/anynet.py:75), SE squeeze / excite gating (net/anynet.py:40-48,68-69).
 #include "hn_common.h"
 
-#define FCH 64
+#define FCH 128
 
 struct BnSrc {
     const float* psum; const float* psq;   // [P][C] partial sums / sums of squares
@@ -24,20 +26,20 @@ struct BnSrc {
 };
 
 struct FusedLds {
-    double r1[16][FCH + 1], r2[16][FCH + 1];
+    double r1[8][FCH + 1], r2[8][FCH + 1];
     float coef[6][FCH];                    // scale, shift, mean, rstd, mean(g), mean(g*xhat)
-    float fr[2][4][FCH];
+    float fr[2][2][FCH];
 };
 
-// sum of P partial rows for the chunk's channels: out in lds.r1[0][c], lds.r2[0][c] (doubles), c < nch.  16 channel quads x 16 row lanes.
+// sum of P partial rows for the chunk's channels: out in lds.r1[0][c], lds.r2[0][c] (doubles), c < nch.  32 channel quads x 8 row lanes.
 __device__ __forceinline__ void chunk_partial_sums(const float* p1, const float* p2, int P, int C, int c0, int nch, FusedLds& L) {
-    const int tid = threadIdx.x, q = tid & 15, rl = tid >> 4;
+    const int tid = threadIdx.x, q = tid & 31, rl = tid >> 5;
     double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
     if (q * 4 < nch) {
         const float* a = p1 + c0 + q * 4;
         const float* b = p2 + c0 + q * 4;
 #pragma unroll 4
-        for (int r = rl; r < P; r += 16) {
+        for (int r = rl; r < P; r += 8) {
             const f32x4 va = *reinterpret_cast<const f32x4*>(a + (long)r * C);
             const f32x4 vb = *reinterpret_cast<const f32x4*>(b + (long)r * C);
 #pragma unroll
@@ -50,7 +52,7 @@ __device__ __forceinline__ void chunk_partial_sums(const float* p1, const float*
     if (tid < FCH) {
         double t1 = 0, t2 = 0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { t1 += L.r1[k][tid]; t2 += L.r2[k][tid]; }
+        for (int k = 0; k < 8; ++k) { t1 += L.r1[k][tid]; t2 += L.r2[k][tid]; }
         L.r1[0][tid] = t1; L.r2[0][tid] = t2;       // only thread `tid` reads/writes column tid here
     }
     __syncthreads();
@@ -108,11 +110,11 @@ __device__ __forceinline__ void chunk_row_reduce(float (&a1)[8], float (&a2)[8],
         }
     }
     __syncthreads();
-    const int c = tid & 63, j = tid >> 6;
+    const int c = tid & 127, j = tid >> 7;
     float t1 = 0.f, t2 = 0.f;
     if (c < nch) {
         const int g8 = c >> 3, k = c & 7;
-        for (int r = j; r < rln; r += 4) {
+        for (int r = j; r < rln; r += 2) {
             t1 += scratch[(r * cln + g8) * 8 + k];
             if (NARR == 2) t2 += scratch[2048 + (r * cln + g8) * 8 + k];
         }
@@ -121,8 +123,8 @@ __device__ __forceinline__ void chunk_row_reduce(float (&a1)[8], float (&a2)[8],
     __syncthreads();
     if (tid < nch) {
         const long o = (long)blockIdx.y * C + c0 + tid;
-        o1[o] = (L.fr[0][0][tid] + L.fr[0][1][tid]) + (L.fr[0][2][tid] + L.fr[0][3][tid]);
-        if (NARR == 2) o2[o] = (L.fr[1][0][tid] + L.fr[1][1][tid]) + (L.fr[1][2][tid] + L.fr[1][3][tid]);
+        o1[o] = L.fr[0][0][tid] + L.fr[0][1][tid];
+        if (NARR == 2) o2[o] = L.fr[1][0][tid] + L.fr[1][1][tid];
     }
 }
 
@@ -136,14 +138,15 @@ struct FApply {
     int act;
     bf16* out; int ldo;
     float* pool;                    // [gridDim.y][C] or null
-    long M; int C; long RB;
+    const float* gate; long HW;     // optional: out = bf16(act(bn(z))) * gate[row / HW][c]  (SE excite; RB divides HW)
+    long M; int C; long RB; int cw;
 };
 
 __global__ __launch_bounds__(256) void fused_apply_kernel(const FApply p) {
     __shared__ FusedLds L;
     __shared__ float scratch[2048];
-    const int c0 = blockIdx.x * FCH;
-    const int nch = p.C - c0 < FCH ? p.C - c0 : FCH;
+    const int c0 = blockIdx.x * p.cw;
+    const int nch = p.C - c0 < p.cw ? p.C - c0 : p.cw;
     chunk_coefs(p.bn, p.C, c0, nch, blockIdx.y == 0, L);
     const int cln = nch >> 3, rln = 256 / cln;
     const int tid = threadIdx.x, cl = tid % cln, rl = tid / cln;
@@ -155,6 +158,9 @@ __global__ __launch_bounds__(256) void fused_apply_kernel(const FApply p) {
     long m1 = m0 + p.RB;
     if (m1 > p.M) m1 = p.M;
     const int c = c0 + cl * 8;
+    float gt[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) gt[k] = (p.gate && active) ? p.gate[(m0 / p.HW) * p.C + c + k] : 1.f;
     auto apply = [&](const bf16x8& vz, const bf16x8& vr, long m) {
         float v[8];
 #pragma unroll
@@ -167,6 +173,10 @@ __global__ __launch_bounds__(256) void fused_apply_kernel(const FApply p) {
         bf16x8 o;
 #pragma unroll
         for (int k = 0; k < 8; ++k) o[k] = f2bf(v[k]);
+        if (p.gate) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = f2bf(bf2f(o[k]) * gt[k]);
+        }
         if (p.pool) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) acc[k] += bf2f(o[k]);
@@ -209,15 +219,15 @@ struct FBwd {
     int P; double count;
     float* dgamma; float* dbeta;
     bf16* dz; int lddz; bf16* gout; int ldg;
-    long M; int C; long RB;
+    long M; int C; long RB; int cw;
 };
 
 template <bool APPLY>
 __global__ __launch_bounds__(256) void fused_bwd_kernel(const FBwd p) {
     __shared__ FusedLds L;
     __shared__ float scratch[APPLY ? 1 : 4096];
-    const int c0 = blockIdx.x * FCH;
-    const int nch = p.C - c0 < FCH ? p.C - c0 : FCH;
+    const int c0 = blockIdx.x * p.cw;
+    const int nch = p.C - c0 < p.cw ? p.C - c0 : p.cw;
     const int tid = threadIdx.x;
     if (APPLY) {
         chunk_partial_sums(p.pg, p.pgx, p.P, p.C, c0, nch, L);
@@ -311,13 +321,13 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(const FBwd p) {
 // per-channel statistics of a bf16 tensor (producers without a statistics epilogue: stem, grouped / depthwise convs):
 // psum / psq [gridDim.y][C] of the stored (bf16) values
 // ---------------------------------------------------------------------------------------------------------------------------------
-struct FStats { const bf16* x; int ldx; float* psum; float* psq; long M; int C; long RB; };
+struct FStats { const bf16* x; int ldx; float* psum; float* psq; long M; int C; long RB; int cw; };
 
 __global__ __launch_bounds__(256) void fused_stats_kernel(const FStats p) {
     __shared__ FusedLds L;
     __shared__ float scratch[4096];
-    const int c0 = blockIdx.x * FCH;
-    const int nch = p.C - c0 < FCH ? p.C - c0 : FCH;
+    const int c0 = blockIdx.x * p.cw;
+    const int nch = p.C - c0 < p.cw ? p.C - c0 : p.cw;
     const int cln = nch >> 3, rln = 256 / cln;
     const int tid = threadIdx.x, cl = tid % cln, rl = tid / cln;
     const bool active = rl < rln;
@@ -355,14 +365,14 @@ __global__ __launch_bounds__(256) void fused_stats_kernel(const FStats p) {
 // ---------------------------------------------------------------------------------------------------------------------------------
 struct FSeBwd {
     const bf16* dbg; int ldd; const bf16* z; int ldz; const float* coef; const float* gate; long HW;
-    bf16* bg; int ldb; float* pdot; long M; int C; long RB;
+    bf16* bg; int ldb; float* pdot; long M; int C; long RB; int cw;
 };
 
 __global__ __launch_bounds__(256) void fused_se_bwd_kernel(const FSeBwd p) {
     __shared__ FusedLds L;
     __shared__ float scratch[2048];
-    const int c0 = blockIdx.x * FCH;
-    const int nch = p.C - c0 < FCH ? p.C - c0 : FCH;
+    const int c0 = blockIdx.x * p.cw;
+    const int nch = p.C - c0 < p.cw ? p.C - c0 : p.cw;
     const int tid = threadIdx.x;
     if (tid < nch) { L.coef[0][tid] = p.coef[c0 + tid]; L.coef[1][tid] = p.coef[p.C + c0 + tid]; }
     __syncthreads();
@@ -408,40 +418,45 @@ __global__ __launch_bounds__(256) void fused_se_bwd_kernel(const FSeBwd p) {
 // ---------------------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------------------
-// Rows per row block.  A workgroup's prologue reads P x 64 x 8 bytes of partial rows and its payload is RB x 64 x 2..6 bytes, and every
-// launch has a fixed cost, so small tensors want FEW fat workgroups: RB >= 4 P (prologue <= half the payload), RB >= 2 sqrt(M) (the
-// reduce -> apply pair of the backward pass hands over M/RB partial rows), >= 32 KB of rows per workgroup; then capped so that at least
-// ~128 workgroups exist and at most 512 row blocks.  With align (rows per image) RB divides align and is >= align / 4 (SE squeeze
-// partials: <= 4 per image).
-extern "C" long hn_fused_row_block(long M, int C, long align, int P) {
-    const long chunks = (C + FCH - 1) / FCH;
-    const long cw = C < FCH ? C : FCH;
-    long RB = 32768 / (cw * 2);
-    long sq = 1;
-    while (sq * sq < 4 * M) ++sq;                       // 2 sqrt(M)
-    if (sq > RB) RB = sq;
-    if (4L * P > RB) RB = 4L * P;
-    const long nrb_min = (128 + chunks - 1) / chunks;
-    const long cap = (M + nrb_min - 1) / nrb_min;
-    if (RB > cap) RB = cap;
-    const long lo = (M + 511) / 512;
-    if (RB < lo) RB = lo;
-    if (RB < 16) RB = 16;
+// chunk width: C <= 128 is one chunk (whole rows contiguous); wider tensors are cut into equal chunks of <= 128 channels
+static int chunk_width(int C) {
+    const int n = (C + FCH - 1) / FCH;
+    return (((C >> 3) + n - 1) / n) << 3;
+}
+static int chunk_count(int C) { const int cw = chunk_width(C); return (C + cw - 1) / cw; }
+
+// Rows per row block (policy measured with tools/bench_fused.py on MI355X).
+//   kind 0 (apply passes, forward and backward): ~1000 workgroups over (chunks x row blocks), RB a power of two in [32, 1024]; larger when
+//           the prologue has many partial rows to reduce (P > 128);
+//   kind 1 (reduce passes: their row-block count is the P of the apply that follows): RB = max(128, M / 512).
+// With align (rows per image) RB divides align and is >= align / 8 (<= 8 SE partial rows per image).
+extern "C" long hn_fused_row_block(long M, int C, long align, int P, int kind) {
+    long RB;
+    if (kind == 1) {
+        RB = 128;
+        while (RB * 512 < M) RB <<= 1;
+    } else {
+        const long want = (M * chunk_count(C) + 1023) / 1024;
+        RB = 32;
+        while (RB < want && RB < 1024) RB <<= 1;
+        if (P > 128 && RB < 128) RB = 128;
+    }
     if (RB > M) RB = M;
     if (align > 0) {
         if (RB > align) RB = align;
-        if (RB < (align + 3) / 4) RB = (align + 3) / 4;
+        if (RB < (align + 7) / 8) RB = (align + 7) / 8;
         while (align % RB) ++RB;                        // smallest divisor of align that is >= RB (terminates at RB == align)
     }
     return RB;
 }
 
-static dim3 fused_grid(long M, int C, long RB) { return dim3((unsigned)((C + FCH - 1) / FCH), (unsigned)((M + RB - 1) / RB)); }
+static dim3 fused_grid(long M, int C, long RB) { return dim3((unsigned)chunk_count(C), (unsigned)((M + RB - 1) / RB)); }
 
 extern "C" int hn_bn_apply_fused(const void* z, int ldz, long M, int C, const float* psum, const float* psq, int P, long count, const float* gamma,
                                  const float* beta, float eps, float momentum, float* rm, float* rv, float* coef, const void* res, int ldr,
-                                 int act, void* out, int ldo, float* pool, long RB, hipStream_t st) {
+                                 int act, void* out, int ldo, float* pool, const float* gate, long HW, long RB, hipStream_t st) {
     HN_CHECK_ARG(z && M > 0 && C > 0 && (C & 7) == 0 && (ldz & 7) == 0 && RB > 0 && (out || pool));
+    HN_CHECK_ARG(!gate || (HW > 0 && HW % RB == 0));
     HN_CHECK_ARG(P <= 0 || (psum && psq && gamma && beta && count > 0));
     HN_CHECK_ARG(P >= 0 || (gamma && beta && rm && rv));
     HN_CHECK_ARG((!res || (ldr & 7) == 0) && (!out || (ldo & 7) == 0));
@@ -450,6 +465,7 @@ extern "C" int hn_bn_apply_fused(const void* z, int ldz, long M, int C, const fl
     p.bn.psum = psum; p.bn.psq = psq; p.bn.P = P; p.bn.count = (double)count; p.bn.gamma = gamma; p.bn.beta = beta; p.bn.eps = eps;
     p.bn.momentum = momentum; p.bn.rm = rm; p.bn.rv = rv; p.bn.coef = coef;
     p.res = (const bf16*)res; p.ldr = ldr; p.act = act; p.out = (bf16*)out; p.ldo = ldo; p.pool = pool; p.M = M; p.C = C; p.RB = RB;
+    p.gate = gate; p.HW = HW; p.cw = chunk_width(C);
     hipLaunchKernelGGL(fused_apply_kernel, fused_grid(M, C, RB), dim3(256), 0, st, p);
     HN_LAUNCH_CHECK();
 }
@@ -460,7 +476,7 @@ static int fill_bwd(FBwd& p, const void* dout, int ldd, const void* z, int ldz, 
     HN_CHECK_ARG((!y || (ldy & 7) == 0) && (!gate || (dpool && HW > 0 && HW % RB == 0)));
     p = FBwd{};
     p.dout = (const bf16*)dout; p.ldd = ldd; p.z = (const bf16*)z; p.ldz = ldz; p.y = (const bf16*)y; p.ldy = ldy; p.coef = coef; p.act = act;
-    p.gate = gate; p.dpool = dpool; p.HW = HW; p.pg = pg; p.pgx = pgx; p.M = M; p.C = C; p.RB = RB;
+    p.gate = gate; p.dpool = dpool; p.HW = HW; p.pg = pg; p.pgx = pgx; p.M = M; p.C = C; p.RB = RB; p.cw = chunk_width(C);
     return HN_OK;
 }
 
@@ -489,7 +505,7 @@ extern "C" int hn_bn_bwd_apply_fused(const void* dout, int ldd, const void* z, i
 
 extern "C" int hn_col_stats_fused(const void* x, int ldx, long M, int C, long RB, float* psum, float* psq, hipStream_t st) {
     HN_CHECK_ARG(x && psum && psq && M > 0 && C > 0 && (C & 7) == 0 && (ldx & 7) == 0 && RB > 0);
-    FStats p = {(const bf16*)x, ldx, psum, psq, M, C, RB};
+    FStats p = {(const bf16*)x, ldx, psum, psq, M, C, RB, chunk_width(C)};
     hipLaunchKernelGGL(fused_stats_kernel, fused_grid(M, C, RB), dim3(256), 0, st, p);
     HN_LAUNCH_CHECK();
 }
@@ -498,7 +514,7 @@ extern "C" int hn_se_bwd_reduce_fused(const void* dbg, int ldd, const void* z, i
                                       int ldb, float* pdot, long M, int C, long RB, hipStream_t st) {
     HN_CHECK_ARG(dbg && z && coef && gate && pdot && M > 0 && C > 0 && (C & 7) == 0 && (ldd & 7) == 0 && (ldz & 7) == 0);
     HN_CHECK_ARG(RB > 0 && HW > 0 && HW % RB == 0 && (!bg || (ldb & 7) == 0));
-    FSeBwd p = {(const bf16*)dbg, ldd, (const bf16*)z, ldz, coef, gate, HW, (bf16*)bg, ldb, pdot, M, C, RB};
+    FSeBwd p = {(const bf16*)dbg, ldd, (const bf16*)z, ldz, coef, gate, HW, (bf16*)bg, ldb, pdot, M, C, RB, chunk_width(C)};
     hipLaunchKernelGGL(fused_se_bwd_kernel, fused_grid(M, C, RB), dim3(256), 0, st, p);
     HN_LAUNCH_CHECK();
 }

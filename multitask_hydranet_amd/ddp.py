@@ -1,15 +1,22 @@
-"""Data-parallel gradient exchange for HydraNet: one process per GPU, bucketed sum-all-reduce over RCCL (torch.distributed backend
-"nccl" on ROCm) issued from autograd hooks on a side HIP stream so it overlaps the rest of backward; gradients are averaged over ranks.
+"""Data-parallel gradient exchange for HydraNet: one process per GPU, bucketed all-reduce over RCCL (torch.distributed backend "nccl" on
+ROCm) issued from autograd hooks on a side HIP stream so that it overlaps the rest of backward; gradients are averaged over ranks.
 
 Replaces the reference's single-rank torch DistributedDataParallel(find_unused_parameters=True) (model/train.py:130-137):
-  * buckets follow reverse execution order (heads -> neck -> backbone stage 4 .. stem), ~25 MiB each like DDP's default, and live
-    in flat fp32 buffers; after the exchange each parameter's .grad is a view into its bucket (no copy back),
-  * parameters that never receive a gradient (neck.bifpn.0.p5_to_p6.* in the 5-stage cfg) are excluded by NAME identically on every
-    rank, which replaces DDP's per-step used-parameter bitmap all-reduce,
-  * BatchNorm running statistics stay per-replica during training (the reference has no SyncBN); broadcast_buffers() reproduces DDP's
-    rank-0 broadcast when a checkpoint is written.
-xGMI note: 8 MI355X are fully meshed with point-to-point links, so the exchange is per-link bound; a few large buckets keep every link
-busy while the backbone's backward (the longest part) is still running.
+  * buckets follow reverse execution order (heads -> neck -> backbone stage 4 .. stem), ~25 MiB each like DDP's default, and live in flat
+    buffers (fp32, or bf16 for half the xGMI payload); after the exchange each parameter's .grad is a view into its bucket;
+  * parameters that never receive a gradient (neck.bifpn.0.p5_to_p6.* in the 5-stage cfg) are excluded by NAME identically on every rank,
+    which replaces DDP's per-step used-parameter bitmap all-reduce;
+  * BatchNorm running statistics stay per-replica during training (the reference has no SyncBN); broadcast_state() reproduces DDP's rank-0
+    broadcast at construction.
+Three ways to run a step:
+  1. eager: hooks fire during loss.backward(); finish() joins.                              (overlapped, one launch per kernel)
+  2. captured: the SAME hooks fire while the step is being captured into a hipGraph (torch.cuda.graph); each completed bucket forks the
+     side stream off the capture stream with an event, the bucket's gather + all-reduce are captured there, join_capture() joins the side
+     stream back before the capture ends.  A replay then runs backward and the bucket all-reduces CONCURRENTLY, in reverse execution
+     order -- the overlap of mode 1 without per-step host work.  adopt_bucket_grads() then points .grad at the averaged buckets.
+  3. reduce_now(): non-overlapped exchange after a replay of a graph that holds no collectives (fallback if RCCL capture is unavailable).
+xGMI note: 8 MI355X are fully meshed with point-to-point links, so a ring all-reduce is per-link bound; a few large buckets keep every
+link busy while the backbone's backward (the longest part) is still running.
 """
 from __future__ import annotations
 
@@ -19,19 +26,41 @@ import torch
 import torch.distributed as dist
 
 
+def _agree_on_avg(group, device) -> bool:
+    """ncclAvg availability decided ONCE, identically on every rank: every rank tries a 1-element AVG all-reduce, then the success flags
+    are summed (a rank-local try/except around a real exchange could leave ranks on different collectives)."""
+    ok = 1.0
+    try:
+        t = torch.ones(1, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group)
+        torch.cuda.synchronize(device)
+        ok = 1.0 if abs(float(t) - 1.0) < 1e-6 else 0.0
+    except Exception:       # noqa: BLE001  (an RCCL build without ncclAvg)
+        ok = 0.0
+    flag = torch.tensor([ok], device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.SUM, group=group)
+    return float(flag) == float(dist.get_world_size(group))
+
+
 class GradReducer:
     def __init__(self, named_params: Sequence, world_size: Optional[int] = None, bucket_bytes: int = 25 << 20,
-                 skip: Iterable[str] = (), group=None, use_side_stream: Optional[bool] = None):
+                 skip: Iterable[str] = (), group=None, use_side_stream: Optional[bool] = None, payload_dtype: torch.dtype = torch.float32,
+                 force_collectives: bool = False):
+        """force_collectives: issue the collectives even at world size 1 (exercises RCCL init, ncclAvg and the side-stream / capture path on
+        a single GPU)."""
         self.group = group
         self.world = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
+        self.active = self.world > 1 or (force_collectives and dist.is_initialized())
+        self.payload_dtype = payload_dtype
         skip = set(skip)
         params = [(n, p) for n, p in named_params if p.requires_grad and n not in skip]
         params.reverse()                                   # registration order ~ forward order -> reverse ~ backward order
         self.buckets: List[dict] = []
         cur, cur_bytes = [], 0
+        esize = torch.empty((), dtype=payload_dtype).element_size()
         for n, p in params:
             cur.append((n, p))
-            cur_bytes += p.numel() * 4
+            cur_bytes += p.numel() * esize
             if cur_bytes >= bucket_bytes:
                 self._close(cur)
                 cur, cur_bytes = [], 0
@@ -42,65 +71,104 @@ class GradReducer:
         if use_side_stream is None:
             use_side_stream = self.on_gpu
         self.stream = torch.cuda.Stream(device=dev) if (self.on_gpu and use_side_stream) else None
-        # RCCL averages in the collective itself (ncclAvg): no separate scaling pass over the 171 MB of gradients.  Falls back to
-        # SUM + scale on the first failure and for backends without AVG (gloo).
-        self._avg = self.on_gpu and dist.is_initialized() and dist.get_backend(group) == "nccl"
+        # RCCL averages inside the collective (ncclAvg): no separate scaling pass over the gradients.  Decided once, on every rank alike.
+        self._avg = bool(self.active and self.on_gpu and dist.is_initialized() and dist.get_backend(group) == "nccl" and
+                         _agree_on_avg(group, dev))
+        self.captured = False
         self._hooks = []
         for bi, b in enumerate(self.buckets):
             for n, p in b["params"]:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
 
+    # ------------------------------------------------------------------------------------------------------------------------------
     def _close(self, plist):
         total = sum(p.numel() for _, p in plist)
         dev = plist[0][1].device
-        flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        flat = torch.zeros(total, device=dev, dtype=self.payload_dtype)
         views, off = [], 0
         for _, p in plist:
             views.append(flat[off:off + p.numel()].view_as(p))
             off += p.numel()
-        self.buckets.append(dict(params=plist, flat=flat, views=views, pending=len(plist), work=None, event=None))
+        # fp32 payload: .grad becomes a view of the bucket; reduced payload: a separate fp32 landing buffer receives the averaged values
+        land = None
+        if self.payload_dtype != torch.float32:
+            lflat = torch.zeros(total, device=dev, dtype=torch.float32)
+            land, off = [], 0
+            for _, p in plist:
+                land.append(lflat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+        self.buckets.append(dict(params=plist, flat=flat, views=views, land=land, pending=len(plist), work=None, event=None, src=None))
 
     def _make_hook(self, bi):
         def hook(param):
             b = self.buckets[bi]
+            if b["pending"] <= 0 or b["work"] is not None or b["event"] is not None:
+                raise RuntimeError("a gradient hook fired for a bucket whose exchange is already in flight: call finish() after every "
+                                   "backward (gradient accumulation over several backward passes is not supported by this reducer)")
             b["pending"] -= 1
             if b["pending"] == 0:
                 self._launch(b)
         return hook
 
-    def _launch(self, b):
-        if self.world == 1:
-            return
-        for (n, p), v in zip(b["params"], b["views"]):
-            if p.grad.data_ptr() != v.data_ptr():
-                v.copy_(p.grad)
-                p.grad = v                                    # from now on autograd accumulates straight into the bucket
-        if self.stream is not None:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
-            self.stream.wait_event(ev)
-            with torch.cuda.stream(self.stream):
-                self._allreduce_mean(b["flat"])
-                done = torch.cuda.Event()
-                done.record(self.stream)
-            b["event"] = done
-        else:
-            b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+    def _gather(self, b):
+        """bring the bucket's gradients into its flat payload buffer (multi-tensor copy; converts when the payload is bf16)"""
+        src = b["src"] if b["src"] is not None else [p.grad for _, p in b["params"]]
+        need = [(v, s) for v, s in zip(b["views"], src) if s.data_ptr() != v.data_ptr()]
+        if need:
+            torch._foreach_copy_([v for v, _ in need], [s for _, s in need])
+
+    def _scatter(self, b):
+        """after the exchange: .grad = averaged values (a view of the bucket, or of the fp32 landing buffer for a reduced payload)"""
+        if b["land"] is not None:
+            torch._foreach_copy_(b["land"], b["views"])
+        dst = b["land"] if b["land"] is not None else b["views"]
+        for (n, p), v in zip(b["params"], dst):
+            p.grad = v
 
     def _allreduce_mean(self, flat):
         if self._avg:
-            try:
-                dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
-                return
-            except Exception:                   # noqa: BLE001  (an RCCL build without ncclAvg)
-                self._avg = False
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-        flat.mul_(1.0 / self.world)
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            if self.world > 1:
+                flat.mul_(1.0 / self.world)
 
+    def _launch(self, b):
+        if not self.active:
+            return
+        capturing = self.on_gpu and torch.cuda.is_current_stream_capturing()
+        if capturing:
+            b["src"] = [p.grad for _, p in b["params"]]        # graph-private tensors every replay rewrites
+            self.captured = True
+        if self.stream is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.stream.wait_event(ev)                          # fork: the side stream joins the capture through this dependency
+            with torch.cuda.stream(self.stream):
+                self._gather(b)
+                self._allreduce_mean(b["flat"])
+                if b["land"] is not None:
+                    torch._foreach_copy_(b["land"], b["views"])
+                done = torch.cuda.Event()
+                done.record(self.stream)
+            b["event"] = done
+            if not capturing:
+                self._point(b)
+        else:
+            self._gather(b)
+            self._point(b)
+            b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _point(self, b):
+        dst = b["land"] if b["land"] is not None else b["views"]
+        for (n, p), v in zip(b["params"], dst):
+            p.grad = v                                          # from now on autograd accumulates straight into the bucket
+
+    # ------------------------------------------------------------------------------------------------------------------------------
     def finish(self):
         """call after loss.backward(): waits for every bucket and re-arms the hooks for the next step."""
         for b in self.buckets:
-            if self.world > 1:
+            if self.active:
                 if b["pending"] != 0:
                     raise RuntimeError("a bucket never completed: parameters without gradient must be listed in `skip`: " +
                                        ", ".join(n for n, p in b["params"] if p.grad is None))
@@ -109,14 +177,27 @@ class GradReducer:
                     b["event"] = None
                 if b["work"] is not None:
                     b["work"].wait()
-                    b["flat"].mul_(1.0 / self.world)
+                    if self.world > 1:
+                        b["flat"].mul_(1.0 / self.world)
+                    if b["land"] is not None:
+                        torch._foreach_copy_(b["land"], b["views"])
                     b["work"] = None
             b["pending"] = len(b["params"])
 
+    def join_capture(self):
+        """inside torch.cuda.graph(...), after loss.backward(): join the side stream back into the capture stream (every bucket's all-reduce
+        becomes a branch of the graph that ends here) and re-arm."""
+        self.finish()
+
+    def adopt_bucket_grads(self):
+        """after the capture: .grad of every exchanged parameter = the averaged values a replay leaves in the buckets"""
+        for b in self.buckets:
+            if b["src"] is not None:
+                self._point(b)
+
     def bind_static_grads(self):
-        """hipGraph mode: a captured step always writes the SAME gradient tensors (graph-private memory).  Remember them, so that every
-        reduce_now() first gathers their fresh contents into the buckets (after the first exchange .grad points at the bucket views, which
-        a replay no longer touches)."""
+        """after-replay mode: a captured step always writes the SAME gradient tensors (graph-private memory).  Remember them, so that every
+        reduce_now() first gathers their fresh contents into the buckets."""
         for b in self.buckets:
             if any(p.grad is None for _, p in b["params"]):
                 raise RuntimeError("bind_static_grads() needs the gradients of a captured step: " +
@@ -124,21 +205,27 @@ class GradReducer:
             b["src"] = [p.grad for _, p in b["params"]]
 
     def reduce_now(self):
-        """non-overlapped variant (after a hipGraph replay of forward+backward): exchange every bucket, then finish()."""
+        """non-overlapped variant (after a replay of a graph without collectives): exchange every bucket, then finish()."""
         for b in self.buckets:
-            src = b.get("src")
-            if src is not None:
-                torch._foreach_copy_(b["views"], src)
-                for (n, p), v in zip(b["params"], b["views"]):
-                    p.grad = v
             b["pending"] = 0
             self._launch(b)
+            if self.stream is None or not self.active:
+                pass
         self.finish()
+        for b in self.buckets:
+            if b["src"] is not None and self.active:
+                self._point(b)
 
     def remove(self):
         for h in self._hooks:
             h.remove()
         self._hooks = []
+
+    def describe(self) -> str:
+        how = "captured inside the hipGraph on a side stream, overlapped with backward" if self.captured else \
+              ("on a side stream from autograd hooks, overlapped with backward" if self.stream is not None else "after backward")
+        return "%d buckets (%s payload, %s) %s" % (len(self.buckets), str(self.payload_dtype).replace("torch.", ""),
+                                                    "ncclAvg" if self._avg else "sum + scale", how)
 
 
 def broadcast_state(module: torch.nn.Module, src: int = 0, group=None):

@@ -308,7 +308,7 @@ MAX_PROLOGUE_ROWS = 512    # partial statistic rows a consumer prologue reduces 
 def k_col_stats_fused(x, align=0):
     """per-row-block channel sums / sums of squares of a bf16 tensor: (psum, psq) [P <= 512][C]"""
     m, c = rows(x), x.shape[3]
-    rb = lib().query("hn_fused_row_block", m, c, align, 0)
+    rb = lib().query("hn_fused_row_block", m, c, align, 0, 1)
     pr = (m + rb - 1) // rb
     ps = torch.empty((pr, c), device=x.device, dtype=F32)
     pq = torch.empty((pr, c), device=x.device, dtype=F32)
@@ -317,46 +317,52 @@ def k_col_stats_fused(x, align=0):
 
 
 def k_bn_apply_fused(z, psum, psq, count, gamma, beta, eps, momentum, rm, rv, act, res=None, out=None, want_out=True, pool_align=0,
-                     training=True):
-    """out = act(BN(z) [+ res]) with the BatchNorm finalize in the kernel prologue.  Returns (out, coef [4, C], pool_partials | None, RB)."""
+                     training=True, coef=None, gate=None, hw=0):
+    """out = act(BN(z) [+ res]) [* gate] with the BatchNorm finalize in the kernel prologue.  coef given: use it as is (no statistics).
+    Returns (out, coef [4, C], pool_partials | None, RB)."""
     n, h, w, c = z.shape
     m = rows(z)
     dev = z.device
-    if training:
+    if coef is not None:
+        P = 0
+    elif training:
         if psum.shape[0] > MAX_PROLOGUE_ROWS:
             psum, psq = fold_rows(psum, psq, limit=MAX_PROLOGUE_ROWS)
         P = psum.shape[0]
     else:
         P = -1
-    rb = lib().query("hn_fused_row_block", m, c, pool_align, max(P, 0))
-    coef = torch.empty((4, c), device=dev, dtype=F32)
+    rb = lib().query("hn_fused_row_block", m, c, pool_align or hw, max(P, 0), 0)
+    if coef is None:
+        coef = torch.empty((4, c), device=dev, dtype=F32)
     if want_out and out is None:
         out = new_act(n, h, w, c, dev)
     pool = torch.empty(((m + rb - 1) // rb, c), device=dev, dtype=F32) if pool_align else None
-    lib().call("hn_bn_apply_fused", ptr(z), ld(z), m, c, ptr(psum) if training else None, ptr(psq) if training else None, P, count,
+    lib().call("hn_bn_apply_fused", ptr(z), ld(z), m, c, ptr(psum) if P > 0 else None, ptr(psq) if P > 0 else None, P, count,
                ptr(gamma), ptr(beta), float(eps), float(momentum), ptr(rm), ptr(rv), ptr(coef), ptr(res), ld(res) if res is not None else 0,
-               act, ptr(out) if want_out else None, ld(out) if want_out else 0, ptr(pool), rb)
+               act, ptr(out) if want_out else None, ld(out) if want_out else 0, ptr(pool), ptr(gate), hw, rb)
     return out, coef, pool, rb
 
 
 def bn_backward_fused(dout, z, y, coef, act, count, want_g=False, gate=None, dpool=None, hw=0):
-    """BatchNorm(+activation) backward in two launches (reduce, apply with the finalize in its prologue): (dz, dgamma, dbeta, g|None)."""
+    """BatchNorm(+activation) backward in two launches (reduce, apply with the finalize in its prologue): (dz, dgamma, dbeta, g|None).
+    The two passes use their own row blocks: the reduce pass's block count is the number of partial rows the apply prologue folds."""
     n, h, w, c = z.shape
     m = rows(z)
     dev = z.device
-    rb = lib().query("hn_fused_row_block", m, c, hw, 0)
-    pr = (m + rb - 1) // rb
+    rb_r = lib().query("hn_fused_row_block", m, c, hw, 0, 1)
+    pr = (m + rb_r - 1) // rb_r
     pg = torch.empty((pr, c), device=dev, dtype=F32)
     pgx = torch.empty((pr, c), device=dev, dtype=F32)
     lib().call("hn_bn_bwd_reduce_fused", ptr(dout), ld(dout), ptr(z), ld(z), ptr(y), ld(y) if y is not None else 0, ptr(coef), act,
-               ptr(gate), ptr(dpool), hw, m, c, rb, ptr(pg), ptr(pgx))
+               ptr(gate), ptr(dpool), hw, m, c, rb_r, ptr(pg), ptr(pgx))
+    rb_a = lib().query("hn_fused_row_block", m, c, hw, pr, 0)
     dgamma = torch.empty((c,), device=dev, dtype=F32)
     dbeta = torch.empty((c,), device=dev, dtype=F32)
     dz = new_act(n, h, w, c, dev)
     g = new_act(n, h, w, c, dev) if want_g else None
     lib().call("hn_bn_bwd_apply_fused", ptr(dout), ld(dout), ptr(z), ld(z), ptr(y), ld(y) if y is not None else 0, ptr(coef), act,
                ptr(gate), ptr(dpool), hw, ptr(pg), ptr(pgx), pr, count, ptr(dgamma), ptr(dbeta), ptr(dz), ld(dz), ptr(g),
-               ld(g) if g is not None else 0, m, c, rb)
+               ld(g) if g is not None else 0, m, c, rb_a)
     return dz, dgamma, dbeta, g
 
 
@@ -505,14 +511,15 @@ def conv_bn_act(x, weight, conv_bias, bn, res=None, kind="1x1", stride=1, act=AC
 # Stride-1 identity XBlock as ONE autograd node (net/anynet.py:65-76; 25 of the 30 blocks of the big backbone):
 #   z1 = conv1x1(x); a = relu(bn1(z1)); z2 = gconv3x3(a); b = relu(bn2(z2)); gate = SE(avgpool(b)); z3 = conv1x1(b * gate);
 #   out = relu(bn3(z3) + x)
-# Forward is 8 launches: the two 1x1 GEMMs and the grouped conv emit their BatchNorm partial statistics; BN1 apply and the final
-# BN3 + residual + ReLU are the two materialising passes; BN2 is never materialised -- one pass over z2 finalizes its statistics and
-# produces the SE squeeze, conv_block_3's operand loader applies scale/shift + ReLU + gate on the fly.  Backward is 21 launches
+# Forward is 9 launches: the two 1x1 GEMMs and the grouped conv emit their BatchNorm partial statistics; BN1 apply and the final
+# BN3 + residual + ReLU are materialising passes; BN2's output is never stored on its own -- one pass over z2 finalizes its statistics
+# and produces the SE squeeze, a second one writes relu(bn2(z2)) * gate, the operand of conv_block_3.  Backward is 21 launches
 # (BN backward = reduce + apply with the finalize in the prologue; the SE gate gradient and the gated wgrad operand come out of one pass
 # over (dbg, z2); the SE data-path backward is folded into the BN2 reduce/apply pair; the residual gradient is added in conv_block_1's
 # dgrad epilogue).  The unfused composition of ConvBnAct / SEGate nodes is ~16 + ~27 launches per block.
 # --------------------------------------------------------------------------------------------------------------
 FUSED_XBLOCK = os.environ.get("HN_FUSED_XBLOCK", "1") != "0"
+XBLOCK_XF_GEMM = os.environ.get("HN_XBLOCK_XF", "0") == "1"
 
 
 class XBlockFn(torch.autograd.Function):
@@ -536,16 +543,21 @@ class XBlockFn(torch.autograd.Function):
         lib().call("hn_se_mlp_fwd_parts", ptr(pool), hw // rb, 1.0 / hw, ptr(sw1), ptr(sb1), ptr(sw2), ptr(sb2), ptr(pooled), ptr(hid),
                    ptr(gate), n, c, cs)
         wp3, wt3 = pack_conv_weight(w3)
-        z3, ps, pq = k_gemm_nt(z2, None, 0, grid, wp3, c, kp32(c), 1, stats=training, xform=(coef2[0], coef2[1], gate, hw, ACT_RELU))
+        if XBLOCK_XF_GEMM:      # BN2 + ReLU + gate in conv_block_3's operand loader (register-staged: measured 7-10 us slower per launch
+            bg = None           # than the LDS-DMA loader, more than the extra pass below costs)
+            z3, ps, pq = k_gemm_nt(z2, None, 0, grid, wp3, c, kp32(c), 1, stats=training, xform=(coef2[0], coef2[1], gate, hw, ACT_RELU))
+        else:                   # second pass over z2: bg = relu(bn2(z2)) * gate, kept for conv_block_3's weight gradient
+            bg, _, _, _ = k_bn_apply_fused(z2, None, None, m, g2, b2, eps, momentum, None, None, ACT_RELU, coef=coef2, gate=gate, hw=hw)
+            z3, ps, pq = k_gemm_nt(bg, None, 0, grid, wp3, c, kp32(c), 1, stats=training)
         out, coef3, _, _ = k_bn_apply_fused(z3, ps, pq, m, g3, b3, eps, momentum, rm3, rv3, ACT_RELU, res=x, training=training)
         ctx.training = training
         ctx.packs = (wt1, wd2, wt3)
-        ctx.save_for_backward(x, z1, a, z2, z3, out, coef1, coef2, coef3, pooled, hid, gate, sw1, sw2)
+        ctx.save_for_backward(x, z1, a, z2, z3, out, coef1, coef2, coef3, pooled, hid, gate, sw1, sw2, bg)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, z1, a, z2, z3, out, coef1, coef2, coef3, pooled, hid, gate, sw1, sw2 = ctx.saved_tensors
+        x, z1, a, z2, z3, out, coef1, coef2, coef3, pooled, hid, gate, sw1, sw2, bg = ctx.saved_tensors
         assert ctx.training, "backward through eval-mode BatchNorm is not part of the hot path"
         wt1, wd2, wt3 = ctx.packs
         dout = dense(dout)
@@ -558,10 +570,13 @@ class XBlockFn(torch.autograd.Function):
         dz3, dg3, db3, g = bn_backward_fused(dout, z3, out, coef3, ACT_RELU, m, want_g=True)
         dbg, _, _ = k_gemm_nt(dz3, None, 0, grid, wt3, c, kp32(c), 1)
         # one pass over (dbg, z2): gate-gradient partials and the gated operand bg = relu(bn2(z2)) * gate of conv_block_3's wgrad
-        rb = lib().query("hn_fused_row_block", m, c, hw, 0)
-        bg = new_act(n, h, w, c, dev)
+        rb = lib().query("hn_fused_row_block", m, c, hw, 0, 1)
+        make_bg = bg is None
+        if make_bg:
+            bg = new_act(n, h, w, c, dev)
         pdot = torch.empty(((m + rb - 1) // rb, c), device=dev, dtype=F32)
-        lib().call("hn_se_bwd_reduce_fused", ptr(dbg), ld(dbg), ptr(z2), ld(z2), ptr(coef2), ptr(gate), hw, ptr(bg), ld(bg), ptr(pdot), m, c, rb)
+        lib().call("hn_se_bwd_reduce_fused", ptr(dbg), ld(dbg), ptr(z2), ld(z2), ptr(coef2), ptr(gate), hw, ptr(bg) if make_bg else None,
+                   ld(bg), ptr(pdot), m, c, rb)
         dw3 = k_gemm_tn(bg, None, 0, grid, dz3, c, kp32(c), 1, c)
         dpre2 = torch.empty((n, c), device=dev, dtype=F32)
         dpool = torch.empty((n, c), device=dev, dtype=F32)
