@@ -1,65 +1,3 @@
-    graph = None
-    static_loss = None
-    in_graph_exchange = False
-
-    def capture(with_hooks):
-        """two eager warm-up steps on a side stream, then the capture.  with_hooks: the reducer's autograd hooks stay armed, so every
-        bucket's gather + all-reduce is captured on the reducer's side stream, forked from / joined to the capture stream by events."""
-        s_ = torch.cuda.Stream()
-        s_.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s_):
-            for _ in range(2):
-                net.zero_grad(set_to_none=True)
-                l0 = fwd_bwd()
-                if reducer is not None and with_hooks:
-                    reducer.finish()
-                if os.environ.get("HN_BENCH_DEBUG"):
-                    print("rank", rank, "eager loss", float(l0.detach()), file=sys.stderr, flush=True)
-        torch.cuda.current_stream().wait_stream(s_)
-        torch.cuda.synchronize()
-        net.zero_grad(set_to_none=True)
-        g = torch.cuda.CUDAGraph()
-        # thread-local capture mode: the RCCL watchdog thread's event queries (N > 1) must not invalidate the capture
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
-            sl = fwd_bwd()
-            if reducer is not None and with_hooks:
-                reducer.join_capture()
-        return g, sl
-
-    if use_graph:
-        try:
-            if reducer is not None and not args.exchange_after_replay:
-                try:
-                    graph, static_loss = capture(with_hooks=True)
-                    reducer.adopt_bucket_grads()
-                    reducer.remove()
-                    in_graph_exchange = reducer.captured
-                except Exception as e:              # noqa: BLE001  (an RCCL build that cannot be captured)
-                    if rank == 0:
-                        print("capturing the all-reduce inside the hipGraph failed (%r): exchanging after the replay instead" % (e,), file=sys.stderr)
-                    torch.cuda.synchronize()
-                    graph = None
-                    reducer.remove()
-                    reducer = make_reducer()
-            if graph is None:
-                if reducer is not None:
-                    reducer.remove()                # no hooks during this capture; gradients are exchanged right after each replay
-                graph, static_loss = capture(with_hooks=False)
-                if reducer is not None:
-                    # after a replay nothing is left to overlap with: ONE flat bucket = one gather + one all-reduce for all 693 gradients
-                    reducer = make_reducer(bucket_bytes=1 << 40)
-                    reducer.remove()
-                    reducer.bind_static_grads()     # every replay rewrites these tensors; reduce_now() gathers them into the bucket
-        except Exception as e:                      # noqa: BLE001
-            if rank == 0:
-                import traceback
-                traceback.print_exc()
-                print("hipGraph capture failed, falling back to eager launches: %r" % (e,), file=sys.stderr)
-            graph = None
-            torch.cuda.synchronize()
-            if exchange:
-                reducer = make_reducer()
-
 #!/usr/bin/env python3
 """bench.py -- images/sec for HydraNet forward+loss+backward on MI355X (BASELINE.json metric), HIP path only.
 
@@ -316,31 +254,56 @@ def main():
 
     graph = None
     static_loss = None
+    in_graph_exchange = False
+
+    def capture(with_hooks):
+        """two eager warm-up steps on a side stream, then the capture.  with_hooks: the reducer's autograd hooks stay armed, so every
+        bucket's gather + all-reduce is captured on the reducer's side stream, forked from / joined to the capture stream by events."""
+        s_ = torch.cuda.Stream()
+        s_.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s_):
+            for _ in range(2):
+                net.zero_grad(set_to_none=True)
+                l0 = fwd_bwd()
+                if reducer is not None and with_hooks:
+                    reducer.finish()
+                if os.environ.get("HN_BENCH_DEBUG"):
+                    print("rank", rank, "eager loss", float(l0.detach()), file=sys.stderr, flush=True)
+        torch.cuda.current_stream().wait_stream(s_)
+        torch.cuda.synchronize()
+        net.zero_grad(set_to_none=True)
+        g = torch.cuda.CUDAGraph()
+        # thread-local capture mode: the RCCL watchdog thread's event queries (N > 1) must not invalidate the capture
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            sl = fwd_bwd()
+            if reducer is not None and with_hooks:
+                reducer.join_capture()
+        return g, sl
+
     if use_graph:
         try:
-            if reducer is not None:
-                reducer.remove()                    # hooks cannot fire inside a replay; gradients are exchanged right after it
-            s = torch.cuda.Stream()
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
-                for _ in range(2):
-                    net.zero_grad(set_to_none=True)
-                    l0 = fwd_bwd()
-                    if os.environ.get("HN_BENCH_DEBUG"):
-                        print("rank", rank, "eager loss", float(l0.detach()), file=sys.stderr, flush=True)
-            torch.cuda.current_stream().wait_stream(s)
-            torch.cuda.synchronize()
-            net.zero_grad(set_to_none=True)
-            graph = torch.cuda.CUDAGraph()
-            # thread-local capture mode: the RCCL watchdog thread's event queries (N > 1) must not invalidate the capture
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                static_loss = fwd_bwd()
-            if reducer is not None:
-                # after a replay nothing is left to overlap with: ONE flat bucket = one gather + one all-reduce for all 693 gradients
-                reducer = GradReducer(list(net.named_parameters()), world_size=world, bucket_bytes=1 << 40,
-                                      skip=UNUSED_5STAGE if len(net.depths) == 5 else ())
-                reducer.remove()
-                reducer.bind_static_grads()         # every replay rewrites these tensors; reduce_now() gathers them into the bucket
+            if reducer is not None and not args.exchange_after_replay:
+                try:
+                    graph, static_loss = capture(with_hooks=True)
+                    reducer.adopt_bucket_grads()
+                    reducer.remove()
+                    in_graph_exchange = reducer.captured
+                except Exception as e:              # noqa: BLE001  (an RCCL build that cannot be captured)
+                    if rank == 0:
+                        print("capturing the all-reduce inside the hipGraph failed (%r): exchanging after the replay instead" % (e,), file=sys.stderr)
+                    torch.cuda.synchronize()
+                    graph = None
+                    reducer.remove()
+                    reducer = make_reducer()
+            if graph is None:
+                if reducer is not None:
+                    reducer.remove()                # no hooks during this capture; gradients are exchanged right after each replay
+                graph, static_loss = capture(with_hooks=False)
+                if reducer is not None:
+                    # after a replay nothing is left to overlap with: ONE flat bucket = one gather + one all-reduce for all 693 gradients
+                    reducer = make_reducer(bucket_bytes=1 << 40)
+                    reducer.remove()
+                    reducer.bind_static_grads()     # every replay rewrites these tensors; reduce_now() gathers them into the bucket
         except Exception as e:                      # noqa: BLE001
             if rank == 0:
                 import traceback
@@ -348,8 +311,8 @@ def main():
                 print("hipGraph capture failed, falling back to eager launches: %r" % (e,), file=sys.stderr)
             graph = None
             torch.cuda.synchronize()
-            if world > 1:
-                reducer = GradReducer(list(net.named_parameters()), world_size=world, skip=UNUSED_5STAGE if len(net.depths) == 5 else ())
+            if exchange:
+                reducer = make_reducer()
 
     def step():
         if graph is not None:

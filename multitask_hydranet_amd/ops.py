@@ -302,7 +302,8 @@ def k_eltwise(op, a, b=None, act=ACT_NONE, alpha=1.0, out=None):
 
 
 FUSED_BN = os.environ.get("HN_FUSED_BN", "1") != "0"   # BatchNorm finalize in the prologue of the consuming elementwise kernel (hn_fused.hip); False: round-1 kernels
-MAX_PROLOGUE_ROWS = 512    # partial statistic rows a consumer prologue reduces itself; more are folded to 32 rows first (one launch)
+MAX_PROLOGUE_ROWS = 128    # partial rows a consumer prologue reduces itself (+1.5 us at 128 rows); more are folded to 32 rows first (one
+                           # ~5 us launch, only for the large early-stage tensors whose passes take 15-40 us anyway)
 
 
 def k_col_stats_fused(x, align=0):
@@ -355,6 +356,9 @@ def bn_backward_fused(dout, z, y, coef, act, count, want_g=False, gate=None, dpo
     pgx = torch.empty((pr, c), device=dev, dtype=F32)
     lib().call("hn_bn_bwd_reduce_fused", ptr(dout), ld(dout), ptr(z), ld(z), ptr(y), ld(y) if y is not None else 0, ptr(coef), act,
                ptr(gate), ptr(dpool), hw, m, c, rb_r, ptr(pg), ptr(pgx))
+    if pr > MAX_PROLOGUE_ROWS:
+        pg, pgx = fold_rows(pg, pgx, limit=MAX_PROLOGUE_ROWS)
+        pr = pg.shape[0]
     rb_a = lib().query("hn_fused_row_block", m, c, hw, pr, 0)
     dgamma = torch.empty((c,), device=dev, dtype=F32)
     dbeta = torch.empty((c,), device=dev, dtype=F32)

@@ -91,6 +91,13 @@ def main():
             # weight gradient (TN GEMM + reduce) and the grouped conv trio
             dz = torch.randn(n, h, w, c, device=dev).to(torch.bfloat16)
             line += f" | wgrad tn+reduce {timeit(lambda: K.k_gemm_tn(z, None, 0, (n, h, w), dz, c, K.kp32(c), 1, c)):.1f}"
+            for cfg in ((128, 128, 4), (128, 128, 2), (64, 64, 1), (64, 64, 2), (64, 64, 4), (128, 64, 2), (128, 64, 4), (64, 128, 2)):
+                lib().query("hn_debug_tn_config", *cfg)
+                try:
+                    line += f" tn{cfg}={timeit(lambda: K.k_gemm_tn(z, None, 0, (n, h, w), dz, c, K.kp32(c), 1, c)):.1f}"
+                except Exception as e:
+                    line += f" tn{cfg}=ERR"
+            lib().query("hn_debug_tn_config", 0, 0, 0)
             w2 = torch.randn(c, 8, 3, 3, device=dev) * 0.1
             wk2, wd2 = K.pack_gconv_diag(w2)
             line += f" | gconv fwd+stats {timeit(lambda: K.k_gemm_nt(z, None, 5, (n, h, w), wk2, c, 64, 9, stats=True, out=out)):.1f}"
