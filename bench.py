@@ -170,6 +170,64 @@ def cpu_baseline(cfgs, h, w, budget_s=20.0):
                       "1 iteration on 1 thread" % (h, w, len(times), cores)}
 
 
+def infer_bench(args, net, cfgs, h, w, dev, rank, world):
+    """BASELINE config 5: inference-only deploy forward (seg arg-max + detection / lane head outputs), batch per GPU, replicas only (no
+    collective on the data path).  One captured hipGraph per step; BatchNorm folded into the packed weights (HydraNet.prepare_inference)."""
+    net.eval()
+    net.prepare_inference()
+    g = torch.Generator().manual_seed(1 + rank)
+    x = torch.randn(args.batch, 3, h, w, generator=g).to(dev)
+    with torch.no_grad():
+        s_ = torch.cuda.Stream()
+        s_.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s_):
+            for _ in range(2):
+                out = net(x, "deploy")
+        torch.cuda.current_stream().wait_stream(s_)
+        torch.cuda.synchronize()
+        graph = None
+        if not args.no_graph:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = net(x, "deploy")
+        step = graph.replay if graph is not None else (lambda: net(x, "deploy"))
+        for _ in range(args.warmup):
+            step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.destroy_process_group()
+    dt = float(tmax)
+    if rank != 0:
+        return
+    assert bool(torch.isfinite(out[2]).all()) and out[0].dtype == torch.int64
+    value = args.batch * world * args.steps / dt
+    scale = (h * w) / (512.0 * 1024.0)
+    res = {"metric": "images/sec (inference fwd) HydraNet, deploy mode, BASELINE config 5", "value": round(value, 2), "unit": "images/sec",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": "full HydraNet eval-mode deploy forward (seg arg-max, det + lane head outputs), big cfg, BatchNorm folded",
+                      "batch_per_gpu": args.batch, "global_batch": args.batch * world, "resolution": "3x%dx%d" % (h, w),
+                      "parallelism": "replicas x%d (no collective)" % world, "hipgraph": graph is not None,
+                      "padding": "1080-row frames are zero-padded (post-normalisation) by 36 rows top and bottom to 1152 = 9 x 128"},
+           "model_tflops": round(value * FWD_GFLOP_PER_IMG_512x1024 * scale / 1e3, 2)}
+    try:
+        res["roofline"] = dominant_launch_roofline(net, args.batch, h, w)
+    except Exception as e:      # noqa: BLE001
+        res["roofline"] = {"error": repr(e)}
+    print(json.dumps(res))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -182,6 +240,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backbone-only", action="store_true", help="BASELINE config[1]: backbone fwd+bwd, loss = sum of feature means")
     ap.add_argument("--dominant-only", action="store_true", help="launch only the dominant kernel (for rocprofv3 --pmc passes) and exit")
+    ap.add_argument("--infer", action="store_true", help="BASELINE config 5: eval-mode deploy forward with folded BatchNorm, hipGraph-captured "
+                    "(use with --res 1152x1920 --batch 32: a 1080-row frame is zero-padded by 36 rows top and bottom after normalisation)")
     ap.add_argument("--ddp-world1", action="store_true", help="run the gradient exchange (RCCL init, ncclAvg, side stream, in-graph capture) "
                     "at world size 1 -- exercises the N > 1 code path on a single GPU")
     ap.add_argument("--grad-payload", default="fp32", choices=("fp32", "bf16"), help="gradient all-reduce payload type")
@@ -228,6 +288,8 @@ def main():
     if args.dominant_only:
         print(json.dumps(dominant_launch_roofline(net, args.batch, h, w, iters=args.steps)))
         return
+    if args.infer:
+        return infer_bench(args, net, cfgs, h, w, dev, rank, world)
     batch = synthetic_batch(cfgs, args.batch, h, w, seed=1 + rank, device=dev)
     reducer = None
     use_graph = not args.no_graph

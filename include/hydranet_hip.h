@@ -59,7 +59,9 @@ int hn_direct_stat_rows(int n_img, int H, int W);
 /* hn_conv_gemm_nt with (a) an operand transform for modes 0/1 (bf16 output): the pixel operand is act(xscale[c]*x + xshift[c]) rounded to
  * bf16 and optionally multiplied by xgate[row / xhw][c] -- BatchNorm apply (+ReLU, + SE gate) of the producer folded into this conv's
  * operand path (net/anynet.py:67-70: conv_block_3 consumes SE(relu(bn2(conv_block_2)))), nothing materialised; and (b) an addend for the
- * staged bf16 epilogue: out = bf16(bf16(acc) + addend[pixel][cout]) (the residual-gradient add of an XBlock's conv_block_1 dgrad). */
+ * staged bf16 epilogue: out = bf16(bf16(acc) + addend[pixel][cout]) (the residual-gradient add of an XBlock's conv_block_1 dgrad); with
+ * ld_add < 0 the addend (row stride -ld_add) goes in BEFORE the activation: out = act(acc + bias + addend) -- inference with folded
+ * BatchNorm: conv_block_3 + identity branch + ReLU of an XBlock in one launch (net/anynet.py:70-76). */
 int hn_conv_gemm_nt_ex(const void* x0, const void* x1, int mode, int n_img, int H, int W, int C0, int C1, int ld0, int ld1, int up, long M,
                        const void* w, int Nout, int KP, int taps, const float* bias, int act, void* out, int out_f32, int ldc, long rpi,
                        long img_stride, float* psum, float* psq, const float* xscale, const float* xshift, const float* xgate, long xhw,

@@ -138,6 +138,8 @@ struct GemmNT {
     // applied between the global load and the LDS store -- a BatchNorm apply (+ ReLU, + SE gate) that is never materialised
     const float* xscale; const float* xshift; const float* xgate; long xhw; int xact;
     const bf16* addend; int ld_add;   // staged bf16 epilogue: out = bf16(bf16(acc) + addend[pix][co])  (residual-gradient add of a dgrad)
+    int add_pre;                      // 1: the addend goes in BEFORE the activation: out = act(acc + bias + addend) (inference: folded
+                                      // BatchNorm + identity branch + ReLU of an XBlock in conv_block_3's epilogue)
 };
 
 template <int BC, int BP, int WGC, int WGP, bool OUT_F32, int R, bool XF = false>
@@ -385,6 +387,25 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) vv[(i * TP + j) * 4 + r] = acc[i][j][r] + bsv[r];
     }
+    if (p.addend && p.add_pre) {
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            const long pix = p_blk + wp * WP + j * 16 + (lane & 15);
+            if (pix >= p.x.M) continue;
+#pragma unroll
+            for (int i = 0; i < TC; ++i) {
+                const int co0 = c_blk + wc * WC + i * 16 + (lane >> 4) * 4;
+                if (co0 + 3 < p.Nout) {
+                    const bf16x4 a = *reinterpret_cast<const bf16x4*>(p.addend + pix * p.ld_add + co0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) vv[(i * TP + j) * 4 + r] += bf2f(a[r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (co0 + r < p.Nout) vv[(i * TP + j) * 4 + r] += bf2f(p.addend[pix * p.ld_add + co0 + r]);
+                }
+            }
+        }
+    }
     if (want_stats) {
         if (!staged) __syncthreads();                                 // the operand ring is free: [WGP][BC][2] floats of it hold the wave sums
         float* red = reinterpret_cast<float*>(smem);
@@ -487,7 +508,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
                     const unsigned im = (unsigned)pix / (unsigned)p.rpi;
                     orow = (long)im * p.img_stride + (long)((unsigned)pix - im * (unsigned)p.rpi) * p.ldc;
                 }
-                if (p.addend) {
+                if (p.addend && !p.add_pre) {
                     const bf16x8 a = ld8(p.addend + pix * p.ld_add + co);
 #pragma unroll
                     for (int k = 0; k < 8; ++k) v[k] = f2bf(bf2f(v[k]) + bf2f(a[k]));
@@ -1304,8 +1325,10 @@ static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img
     HN_CHECK_ARG(x0 && w && out && M > 0 && Nout > 0 && KP > 0 && (KP & 31) == 0 && taps >= 1 && taps <= 9);
     // operand transform: plain / stride-2 row gathers, bf16 output; addend: staged bf16 epilogue only (aligned rows, no per-image mapping)
     HN_CHECK_ARG(!xscale || (xshift && mode <= 1 && !out_f32 && C1 == 0 && (!xgate || xhw > 0)));
-    HN_CHECK_ARG(!addend || (!out_f32 && (Nout & 7) == 0 && (ldc & 7) == 0 && (ld_add & 7) == 0 && rpi == 0 && mode <= 1 &&
-                             (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(addend) & 15) == 0));
+    // ld_add < 0: the addend (row stride -ld_add) is added BEFORE the activation (any epilogue form)
+    HN_CHECK_ARG(!addend || ld_add < 0 || (!out_f32 && (Nout & 7) == 0 && (ldc & 7) == 0 && (ld_add & 7) == 0 && rpi == 0 && mode <= 1 &&
+                                           (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(addend) & 15) == 0));
+    HN_CHECK_ARG(!addend || ld_add >= 0 || (mode <= 1 && rpi == 0 && ((-ld_add) & 3) == 0));
     HN_CHECK_ARG((C0 & 7) == 0 && (C1 & 7) == 0 && (ld0 & 7) == 0 && (C1 == 0 || (x1 && (ld1 & 7) == 0)));
     HN_CHECK_ARG(mode >= 0 && mode <= 5 && (mode < 4 || (up == 0 && C1 == 0)));
     HN_CHECK_ARG(mode == 5 ? (KP == 64 && Nout == C0 && !rpi) : C0 + C1 <= KP);
@@ -1320,7 +1343,7 @@ static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img
     p.rpi = rpi; p.img_stride = img_stride;
     p.d2s = 0;
     p.xscale = xscale; p.xshift = xshift; p.xgate = xgate; p.xhw = xhw; p.xact = xact;
-    p.addend = (const bf16*)addend; p.ld_add = ld_add;
+    p.addend = (const bf16*)addend; p.ld_add = ld_add < 0 ? -ld_add : ld_add; p.add_pre = ld_add < 0 ? 1 : 0;
     if (img_stride < 0) {                                            // mode 4 + fp32 out: -img_stride = channels per depth-to-space output pixel
         HN_CHECK_ARG(p.x.clamp == 1 && out_f32 && rpi == 0 && !psum && Nout == 4 * (int)(-img_stride));
         p.d2s = (int)(-img_stride);

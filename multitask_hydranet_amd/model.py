@@ -123,6 +123,7 @@ class HydraNet(nn.Module):
         self.seg_phase_output = True
         self.seg_fuse_elu_bwd = True       # ELU' of a decoder block applied by the next block's gradient fold
         self._pack_plan = None
+        self._folded = None                 # prepare_inference(): conv name -> (packed folded weights, fp32 bias)
         self.deploy_postprocess = None      # (conf_thres, iou_thres): forward(x, "deploy") then appends the device-side detections
         self.pack_det_levels = True         # level-packed det towers when every level has a multiple of 128 rows
         self.levels_on_streams = False      # hipGraph branches cost more than they hide on gfx950 (55 vs 43 ms)
@@ -276,6 +277,7 @@ class HydraNet(nn.Module):
         r = super()._apply(fn, recurse)
         self._reindex()
         self._pack_plan = None
+        self._folded = None
         K.clear_pack_cache()
         return r
 
@@ -285,6 +287,50 @@ class HydraNet(nn.Module):
         if state_dict and all(k.startswith("module.") for k in state_dict):
             state_dict = type(state_dict)((k[len("module."):], v) for k, v in state_dict.items())
         return super().load_state_dict(state_dict, strict=strict, assign=assign)
+
+    # ------------------------------------------------------------------------------------------------------
+    # inference with folded BatchNorm (BASELINE config 5)
+    # ------------------------------------------------------------------------------------------------------
+    def prepare_inference(self):
+        """Fold every eval-mode BatchNorm that directly follows a convolution into that convolution's packed bf16 weights and an fp32 bias
+        (backbone conv_block_1/2/3 and shortcuts, BiFPN channel reducers and separable blocks, lane branches).  Call after .eval() and after
+        loading weights; forward() in eval mode then runs conv + BN + activation (+ the XBlock identity branch) as one launch per conv.
+        .train() or any parameter change invalidates it (call again)."""
+        assert not self.training, "prepare_inference() folds the RUNNING statistics: call .eval() first"
+        P = self._idx
+        folded = {}
+        for name in P:
+            if not name.endswith(".running_mean"):
+                continue
+            bn = name[:-len(".running_mean")]
+            conv, kind, eps = None, "1x1", BN_STD["eps"]
+            if bn.startswith("backbone.net.stage_"):
+                conv = bn[:-1] + "0"                                  # conv_block_k.1 -> conv_block_k.0, shortcut.1 -> shortcut.0
+                if ".conv_block_2." in bn:
+                    blk0 = bn.split(".blocks.block_")[1].split(".")[0] == "0"
+                    if blk0 and self.backbone_stride != 1:
+                        continue                                      # stride-2 grouped conv: VALU stencil kernel, BN applied after it
+                    kind = "g3x3"
+            elif bn.startswith("neck.") and bn.endswith(".bn"):
+                conv, eps = bn[:-3] + ".pointwise_conv.conv", BN_FPN["eps"]
+            elif bn.startswith("neck.") and bn.endswith(".1"):
+                conv, eps = bn[:-2] + ".0.conv", BN_FPN["eps"]
+            elif bn.startswith("laneheader."):
+                conv = bn[:-1] + "0"
+            if conv is None or (conv + ".weight") not in P:
+                continue
+            w = P[conv + ".weight"]
+            if not w.is_cuda:
+                raise RuntimeError("prepare_inference() packs device operands: move the module to the GPU first")
+            folded[conv] = K.fold_conv_bn(w, P.get(conv + ".bias"), P[bn + ".weight"], P[bn + ".bias"], P[bn + ".running_mean"],
+                                          P[bn + ".running_var"], eps, kind)
+        self._folded = folded
+        return self
+
+    def train(self, mode: bool = True):
+        if mode:
+            self._folded = None
+        return super().train(mode)
 
     def _bn(self, name):
         P = self._idx
@@ -302,13 +348,24 @@ class HydraNet(nn.Module):
     # ------------------------------------------------------------------------------------------------------
     def _cba(self, x, conv, bn, bnkw, **kw):
         P = self._idx
+        f = self._folded.get(conv) if (self._folded is not None and not self.training) else None
+        if f is not None and x.dim() == 4 and x.dtype == torch.bfloat16:
+            return K.conv_infer(x, f[0], f[1], P[conv + ".weight"].shape[0], kw.get("kind", "1x1"), kw.get("stride", 1), kw.get("act", ACT_NONE),
+                                kw.get("res"))
         return K.conv_bn_act(x, P[conv + ".weight"], P.get(conv + ".bias"), self._bn(bn), training=self.training, **bnkw, **kw)
 
     def _xblock(self, q, x, stride):
         """XBlock.forward, net/anynet.py:65-76."""
         P = self._idx
         has_se, has_sc = (q + "se.1.weight") in P, (q + "shortcut.0.weight") in P
-        if K.xblock_fusable(x, P[q + "conv_block_1.0.weight"], stride, has_se, has_sc):     # one autograd node, 8 + 21 launches
+        if self._folded is not None and not self.training:            # inference: 7 launches per block, nothing but GEMM epilogues
+            a = self._cba(x, q + "conv_block_1.0", q + "conv_block_1.1", BN_STD, act=ACT_RELU)
+            b = self._cba(a, q + "conv_block_2.0", q + "conv_block_2.1", BN_STD, kind="g3x3", stride=stride, act=ACT_RELU)
+            if has_se:
+                b = K.se_gate_infer(b, P[q + "se.1.weight"], P[q + "se.1.bias"], P[q + "se.3.weight"], P[q + "se.3.bias"])
+            s = self._cba(x, q + "shortcut.0", q + "shortcut.1", BN_STD, stride=stride, act=ACT_NONE) if has_sc else x
+            return self._cba(b, q + "conv_block_3.0", q + "conv_block_3.1", BN_STD, res=s, act=ACT_RELU)
+        if K.xblock_fusable(x, P[q + "conv_block_1.0.weight"], stride, has_se, has_sc):     # one autograd node, 9 + 21 launches
             bn = [self._bn(q + f"conv_block_{i}.1")[:4] for i in (1, 2, 3)]
             return K.XBlockFn.apply(x, P[q + "conv_block_1.0.weight"], *bn[0], P[q + "conv_block_2.0.weight"], *bn[1],
                                     P[q + "se.1.weight"], P[q + "se.1.bias"], P[q + "se.3.weight"], P[q + "se.3.bias"],

@@ -189,7 +189,7 @@ def pack_dw_weight(w: torch.Tensor):
 # raw kernel wrappers (no autograd)
 # --------------------------------------------------------------------------------------------------------------
 def k_gemm_nt(x0, x1, mode, grid, wp, nout, kp, taps, bias=None, act=ACT_NONE, out=None, out_f32=False, up=0, stats=False,
-              c0=None, c1=None, rpi=0, img_stride=0, ldc=None, xform=None, addend=None):
+              c0=None, c1=None, rpi=0, img_stride=0, ldc=None, xform=None, addend=None, add_pre=False):
     """grid = (N, H, W) of the OUTPUT pixel grid.  Returns (out, psum, psq).
     xform = (scale, shift, gate | None, rows_per_image, act): operand transform of hn_conv_gemm_nt_ex; addend: bf16 tensor added in the
     epilogue (same rows / channels as the output)."""
@@ -214,7 +214,8 @@ def k_gemm_nt(x0, x1, mode, grid, wp, nout, kp, taps, bias=None, act=ACT_NONE, o
         xs, xh, xg, xhw, xact = xform if xform is not None else (None, None, None, 0, 0)
         lib().call("hn_conv_gemm_nt_ex", ptr(x0), ptr(x1), mode, n, h, w, c0, c1, ld(x0), ld(x1) if x1 is not None else 0, up, m,
                    ptr(wp), nout, kp, taps, ptr(bias), act, ptr(out), 1 if out_f32 else 0, ldc, rpi, img_stride, ptr(psum), ptr(psq),
-                   ptr(xs), ptr(xh), ptr(xg), xhw, xact, ptr(addend), ld(addend) if addend is not None else 0)
+                   ptr(xs), ptr(xh), ptr(xg), xhw, xact, ptr(addend),
+                   (-ld(addend) if add_pre else ld(addend)) if addend is not None else 0)
     return out, psum, psq
 
 
@@ -600,6 +601,69 @@ class XBlockFn(torch.autograd.Function):
         dw1 = k_gemm_tn(x, None, 0, grid, dz1, c, kp32(c), 1, c)
         return (dx, dw1, dg1, db1, None, None, dw2, dg2, db2, None, None, dsw1, dsb1, dsw2, dsb2, dw3, dg3, db3, None, None,
                 None, None, None)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# Inference with folded BatchNorm (BASELINE config 5; reference: demo.py:191-202 runs the eval-mode module).  In eval mode
+# BN(conv(x)) = conv(x, W * scale) + shift with scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale (+ conv bias
+# * scale): HydraNet.prepare_inference() folds scale into the packed bf16 weights once and keeps shift as an fp32 bias, so conv + BN +
+# activation (+ the XBlock's identity branch) is ONE GEMM launch with a bias / addend / activation epilogue.
+# --------------------------------------------------------------------------------------------------------------
+def fold_conv_bn(w, conv_bias, gamma, beta, rm, rv, eps, kind):
+    """-> (packed bf16 operand, fp32 bias) for the inference path; kind "1x1" or "g3x3" """
+    with torch.no_grad():
+        scale = gamma.float() / torch.sqrt(rv.float() + eps)
+        shift = beta.float() - rm.float() * scale
+        if conv_bias is not None:
+            shift = shift + conv_bias.float() * scale
+        wf = (w.float() * scale.view(-1, 1, 1, 1)).contiguous()
+        if kind == "g3x3":
+            c = wf.shape[0]
+            wk = torch.empty((c, 9 * 64), device=wf.device, dtype=BF16)
+            wd = torch.empty((c, 9 * 64), device=wf.device, dtype=BF16)
+            lib().call("hn_gconv_pack_diag", ptr(wf), ptr(wk), ptr(wd), c)
+            return wk, shift.contiguous()
+        cout, cin = wf.shape[0], wf.shape[1]
+        wp = torch.empty((cout, kp32(cin)), device=wf.device, dtype=BF16)
+        lib().call("hn_pack_weight", ptr(wf), ptr(wp), None, cout, cin, 1)
+        return wp, shift.contiguous()
+
+
+def conv_infer(x, packed, bias, cout, kind, stride, act, res=None):
+    """act(conv(x) + bias [+ res]) with folded-BatchNorm operands: one launch"""
+    n, hi, wi, cin = x.shape
+    ho, wo = (hi, wi) if stride == 1 else (hi // 2, wi // 2)
+    if kind == "g3x3":
+        assert stride == 1 and res is None
+        out, _, _ = k_gemm_nt(x, None, 5, (n, ho, wo), packed, cout, 64, 9, bias=bias, act=act)
+    else:
+        out, _, _ = k_gemm_nt(x, None, 0 if stride == 1 else 1, (n, ho, wo), packed, cout, kp32(cin), 1, bias=bias, act=act, addend=res,
+                              add_pre=res is not None)
+    return out
+
+
+def se_gate_infer(b, w1, b1, w2, b2):
+    """SE squeeze / excite for the inference path: per-image channel sums (one pass), the MLP fed by the partial rows, then b * gate"""
+    n, h, w, c = b.shape
+    hw, m = h * w, n * h * w
+    cs = w1.shape[0]
+    dev = b.device
+    rb = lib().query("hn_fused_row_block", m, c, hw, 0, 1)
+    if hw % rb:
+        rb = hw
+    pr = m // rb
+    ps = torch.empty((pr, c), device=dev, dtype=F32)
+    pq = torch.empty((pr, c), device=dev, dtype=F32)
+    lib().call("hn_col_stats_fused", ptr(b), ld(b), m, c, rb, ptr(ps), ptr(pq))
+    pooled = torch.empty((n, c), device=dev, dtype=F32)
+    hid = torch.empty((n, cs), device=dev, dtype=F32)
+    gate = torch.empty((n, c), device=dev, dtype=F32)
+    lib().call("hn_se_mlp_fwd_parts", ptr(ps), hw // rb, 1.0 / hw, ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(pooled), ptr(hid), ptr(gate), n, c, cs)
+    out = new_act(n, h, w, c, dev)
+    rb2 = lib().query("hn_fused_row_block", m, c, hw, 0, 0)
+    lib().call("hn_bn_apply_fused", ptr(b), ld(b), m, c, None, None, 0, m, None, None, 0.0, 0.0, None, None, None, None, 0, ACT_NONE, ptr(out),
+               ld(out), None, ptr(gate), hw, rb2)
+    return out
 
 
 def xblock_fusable(x, w1, stride, has_se, has_shortcut):

@@ -1,0 +1,142 @@
+"""Training-loop surface around the HIP hot path (reference: model/train.py:31-269 HydraTrainer).
+
+Same roles and names as the reference's trainer for the part that touches the hot path: model construction (+ `module.`-prefixed
+checkpoint loading, train.py:96-126), the data-parallel wrap (train.py:130-137 -> multitask_hydranet_amd.ddp.GradReducer, one process per
+GPU over RCCL), Adam + per-iteration CosineAnnealingLR (train.py:147-150), `cal_total_loss` (train.py:192-203), `to_gpu` (train.py:228-239),
+`train_one_epoch` (train.py:241-269) and the segmentation part of `valid` (streaming mIoU on the device, train.py:402-407).  The dataset /
+augmentation pipeline (cv2 + imgaug), COCO json evaluation (pycocotools) and the lane F1 metric stay outside (out of
+scope); any iterable of batch dicts with the Collater contract (dataset/dataloader.py:557-633) drives the loop.
+
+Launch for N GPUs of one node:  python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 your_script.py
+(the trainer reads RANK / LOCAL_RANK / WORLD_SIZE; world size 1 needs no launcher).
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Iterable, Optional
+
+import torch
+import torch.distributed as dist
+
+from .ddp import UNUSED_5STAGE, GradReducer, broadcast_state
+from .metrics import IntersectionOverUnion
+from .model import HydraNet
+
+
+class HydraTrainer:
+    def __init__(self, cfgs: dict, trainloader: Optional[Iterable] = None, validloader: Optional[Iterable] = None, iters_per_epoch: Optional[int] = None,
+                 grad_payload: torch.dtype = torch.float32):
+        self.cfgs = cfgs
+        t = cfgs["train"]
+        self.train_detect, self.train_seg, self.train_lane = t["train_detect"], t["train_seg"], t["train_lane"]
+        self.print_interval = t.get("print_interval", 10)
+        self.trainloader, self.validloader = trainloader, validloader
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(self.device)
+        if self.world > 1 and not dist.is_initialized():
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.device)
+
+        self.hydranet = HydraNet(cfgs=cfgs).to(self.device)
+        if t.get("continue_train") and t.get("weight_file"):
+            # files written from a DDP wrapper carry "module." prefixes (train.py:96-109 deparallel_model): load_state_dict strips them
+            self.hydranet.load_state_dict(torch.load(t["weight_file"], map_location=self.device))
+        broadcast_state(self.hydranet)                               # what DDP does at construction (train.py:137)
+        self.use_distribute = self.world > 1
+        self.reducer = None
+        if self.use_distribute:
+            skip = UNUSED_5STAGE if len(self.hydranet.depths) == 5 else ()
+            self.reducer = GradReducer(list(self.hydranet.named_parameters()), world_size=self.world, skip=skip, payload_dtype=grad_payload)
+
+        self.lr, self.weight_decay, self.epoch = t["lr"], t["weight_decay"], t["epoch"]
+        n_iter = iters_per_epoch if iters_per_epoch is not None else (len(trainloader) if hasattr(trainloader, "__len__") else 1)
+        self.total_iters = max(1, n_iter * self.epoch)
+        self.optimizer = torch.optim.Adam(self.hydranet.parameters(), self.lr, weight_decay=self.weight_decay)
+        self.scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(self.optimizer, self.total_iters, eta_min=1e-8)     # iteration based
+
+        s, d, l = cfgs["segment"], cfgs["detection"], cfgs["lane"]
+        self.segment_weight = s["segment_weight"]
+        self.loss_cls_weight, self.loss_reg_weight, self.detection_weight = d["loss_cls_weight"], d["loss_reg_weight"], d["detection_weight"]
+        self.loss_cls_pos_weight, self.loss_cls_neg_weight = l["loss_cls_pos_weight"], l["loss_cls_neg_weight"]
+        self.loss_loc_weight, self.lane_weight = l["loss_loc_weight"], l["lane_weight"]
+        if self.train_seg:
+            self.metric_evaluator_iou = IntersectionOverUnion(n_classes=len(s["class_list"]), device=self.device)
+
+    # ------------------------------------------------------------------------------------------------------------------------------
+    def cal_total_loss(self, loss_dict: Dict[str, torch.Tensor]):
+        """train.py:192-203"""
+        total = 0.0
+        if self.train_seg:
+            total = total + loss_dict["loss_seg"] * self.segment_weight
+        if self.train_detect:
+            total = total + (loss_dict["loss_det_cls"] * self.loss_cls_weight + loss_dict["loss_det_reg"] * self.loss_reg_weight) * self.detection_weight
+        if self.train_lane:
+            total = total + (loss_dict["loss_lane_cls_pos"] * self.loss_cls_pos_weight + loss_dict["loss_lane_cls_neg"] * self.loss_cls_neg_weight
+                             + loss_dict["loss_lane_loc"] * self.loss_loc_weight) * self.lane_weight
+        return total
+
+    def to_gpu(self, batch_data: dict) -> dict:
+        """train.py:228-239"""
+        batch_data["image"] = batch_data["image"].to(self.device).float()
+        if self.train_lane:
+            batch_data["gt_loc"] = batch_data["gt_loc"].to(self.device).float()
+            batch_data["gt_cls"] = batch_data["gt_cls"].to(self.device).float()
+        if self.train_seg:
+            batch_data["gt_seg"] = batch_data["gt_seg"].to(self.device).float()
+        if self.train_detect:
+            batch_data["gt_det"] = batch_data["gt_det"].to(self.device).float()
+        return batch_data
+
+    def train_step(self, batch_data: dict) -> Dict[str, torch.Tensor]:
+        """one iteration of train.py:243-267: forward, multitask loss, backward (gradient exchange overlapped), Adam step, LR step"""
+        batch_data = self.to_gpu(batch_data)
+        outputs = self.hydranet(batch_data["image"])
+        loss_dict = self.hydranet.cal_loss(outputs, batch_data)
+        loss_total = self.cal_total_loss(loss_dict)
+        loss_dict.update({"total_loss": loss_total})
+        # gradients accumulate straight into the exchange buckets after the first step: zero them in place instead of dropping them
+        self.optimizer.zero_grad(set_to_none=self.reducer is None)
+        loss_total.backward()
+        if self.reducer is not None:
+            self.reducer.finish()
+        self.optimizer.step()
+        self.scheduler.step()
+        return loss_dict
+
+    def train_one_epoch(self, epoch: int):
+        self.hydranet.train()
+        for iter_idx, batch_data in enumerate(self.trainloader):
+            loss_dict = self.train_step(batch_data)
+            if self.rank == 0 and iter_idx % self.print_interval == 0:
+                self.print_loss_info(loss_dict, epoch, iter_idx)
+
+    def print_loss_info(self, loss_dict, epoch, batch_idx, mode="train"):
+        lr = self.optimizer.param_groups[0]["lr"]
+        print("%s Epoch [%i|%i] Iter [%i] Lr %.5f  " % (mode.upper(), epoch, self.epoch, batch_idx, lr) +
+              "  ".join("%s %.3f" % (k, float(v.detach())) for k, v in loss_dict.items()))
+
+    @torch.no_grad()
+    def valid(self, epoch: int = 0):
+        """the segmentation part of train.py:271-438: deploy forward, streaming mIoU on the device (the detection COCO json and the lane F1
+        need pycocotools / cv2 and are out of scope); returns the per-class IoU tensor"""
+        self.hydranet.eval()
+        if self.train_seg:
+            self.metric_evaluator_iou = IntersectionOverUnion(n_classes=self.metric_evaluator_iou.n_classes, device=self.device)
+        for batch_data in self.validloader:
+            batch_data = self.to_gpu(batch_data)
+            dep = self.hydranet(batch_data["image"], "deploy")
+            if self.train_seg:
+                self.metric_evaluator_iou.update(dep[0], batch_data["gt_seg"])
+        self.hydranet.train()
+        return self.metric_evaluator_iou.compute() if self.train_seg else None
+
+    def save(self, path: str):
+        """checkpoint in the reference's format: a DDP-wrapped module's state_dict carries "module." prefixes (train.py:437)"""
+        if self.rank != 0:
+            return
+        sd = self.hydranet.state_dict()
+        if self.use_distribute:
+            sd = {"module." + k: v for k, v in sd.items()}
+        torch.save(sd, path)
