@@ -203,3 +203,38 @@ def test_det_postprocess_capacity_overflow_raises(pkg):
     a[..., 2:] += a[..., :2] + 1
     with pytest.raises(RuntimeError, match="32768"):
         postprocess((512, 1024), a.cuda(), torch.zeros(1, 40000, 4).cuda(), torch.full((1, 40000, 9), 0.9).cuda(), 0.5, 0.5)
+
+
+def test_dispatcher_ops_match_the_module_path(pkg):
+    """torch.ops.hydranet_hip.* (multitask_hydranet_amd/torch_ops.py) run the same C-ABI calls as the nn.Module path: identical outputs,
+    gradients and running statistics for conv1x1 + BN + ReLU; the top-k CE loss op reproduces ops.SegLoss incl. its gradient"""
+    import multitask_hydranet_amd.torch_ops as T
+    from multitask_hydranet_amd import ops as K
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x0 = torch.randn(4, 16, 24, 64, device="cuda", generator=g).to(torch.bfloat16)
+    w0 = torch.randn(152, 64, 1, 1, device="cuda", generator=g) * 0.1
+    up = torch.randn(4, 16, 24, 152, device="cuda", generator=g).to(torch.bfloat16)
+    res = []
+    for which in ("module", "dispatcher"):
+        x, w = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+        gm, bt = torch.ones(152, device="cuda", requires_grad=True), torch.zeros(152, device="cuda", requires_grad=True)
+        rm, rv = torch.zeros(152, device="cuda"), torch.ones(152, device="cuda")
+        K.clear_pack_cache()
+        if which == "module":
+            out = K.conv_bn_act(x, w, None, (gm, bt, rm, rv, None), act=K.ACT_RELU)
+        else:
+            out = T.conv1x1_bn_act(x, w, gm, bt, rm, rv, K.ACT_RELU, 1e-5, 0.1, True)
+        out.backward(up)
+        res.append((out.detach().float(), x.grad.float(), w.grad, gm.grad, bt.grad, rm, rv))
+    for a, b in zip(*res):
+        assert float((a - b).abs().max()) <= 1e-3 * max(float(a.abs().max()), 1e-6)
+    logits = torch.randn(2, 32, 64, 5, device="cuda", generator=g, requires_grad=True)
+    tgt = torch.randint(0, 5, (2, 32, 64), device="cuda", generator=g)
+    cw = torch.tensor([0.1, 0.5, 1.0, 5.0, 5.0], device="cuda")
+    l1 = K.SegLoss.apply(logits, tgt, cw, True, 0.3, 255)
+    g1, = torch.autograd.grad(l1, logits)
+    l2, _ = torch.ops.hydranet_hip.seg_topk_ce_fwd(logits, tgt, cw, True, 0.3, 255)
+    g2, = torch.autograd.grad(l2, logits)
+    assert float(l1) == float(l2) and torch.equal(g1, g2)
+    m = torch.ops.hydranet_hip.argmax_channels(logits.detach())
+    assert torch.equal(m, torch.argmax(logits.detach(), 3))
