@@ -457,7 +457,10 @@ def test_inference_folded_batchnorm(env):
     folded forward must reproduce the reference's recorded eval-mode outputs (tiny fixture, fp32) within the stated 4e-2, agree with the
     unfolded eval forward, give the identical 6-tuple structure, and be capturable in a hipGraph (replay == eager, bit for bit)."""
     z, cfgs, net, batch, oracle, sd = env
-    net.load_state_dict(sd)
+    # the reference recorded its deploy outputs AFTER one training step: eval mode saw the post-step running statistics ("sd_after/")
+    state = dict(sd)
+    state.update({k[9:]: torch.from_numpy(z[k].copy()) for k in z.files if k.startswith("sd_after/")})
+    net.load_state_dict(state)
     x = batch["image"].to("cuda:0")
     net.eval()
     try:
