@@ -100,14 +100,16 @@ int hn_dw_pack(const float* w, void* wk, void* wkf, int C, hipStream_t stream);
 int hn_dwconv_fwd(const void* in, int ldi, const void* wk, void* out, int ldo, int N, int H, int W, int C, hipStream_t stream);
 /* level-packed form: rows of nlev (<= 5) pyramid levels [N,H[l],W[l],C] stacked in one tensor, one launch (the det-head towers apply the
  * same SeparableConvBlock to every level, head_detect/detection.py:30-35,67-72) */
+/* row_align (>= 1): every level starts on a multiple of row_align rows ("ragged" packing: levels whose row count is not a multiple of the
+ * 128-row GEMM / BatchNorm blocks are padded; this kernel writes ZEROS to the alignment rows so downstream sums can be corrected exactly) */
 int hn_dwconv_fwd_levels(const void* in, int ldi, const void* wk, void* out, int ldo, int N, int C, int nlev, const int* H, const int* W,
-                         hipStream_t stream);
+                         int row_align, hipStream_t stream);
 /* partial rows of hn_dwconv_wgrad*: strips = sum over levels of N * H * ceil(W / 4) (the kernel walks 4-pixel strips) */
 long hn_dwconv_wgrad_blocks(long strips, int C);
 int hn_dwconv_wgrad(const void* x, int ldx, const void* dz, int ldz, float* part, int N, int H, int W, int C, hipStream_t stream);
 /* level-packed: part is fp32 [hn_dwconv_wgrad_blocks(total pixels, C)][C*9] */
 int hn_dwconv_wgrad_levels(const void* x, int ldx, const void* dz, int ldz, float* part, int N, int C, int nlev, const int* H, const int* W,
-                           hipStream_t stream);
+                           int row_align, hipStream_t stream);
 
 /* 3x3/s2 max pools: mode 0 = zero pad right/bottom, zeros take part in the max (MaxPool2dStaticSamePadding, net/common.py:138-151);
  * mode 1 = nn.MaxPool2d(3,2,1) (head_lane/lanedetect.py:40).  Backward recomputes the arg-max (first maximum wins). */
@@ -177,11 +179,12 @@ int hn_bn_bwd_apply(const void* dout, int ldd, const void* z, int ldz, const voi
                     long M, int C, hipStream_t stream);
 
 /* Level-packed BatchNorm with per-level parameters (bn_list[level][i] of the det towers, head_detect/detection.py:23,31-35,60,68-72).
- * rows[l] = tensor rows of level l (each a multiple of 128); coef = [nlev][4][C] (scale, shift, mean, rstd), red = [nlev][2][C].
+ * rows[l] = tensor rows of level l INCLUDING its alignment rows (each a multiple of 128), count[l] = real rows; the alignment rows of the
+ * conv output hold bf16(conv_bias) exactly and are subtracted from the statistics; coef = [nlev][4][C] (scale, shift, mean, rstd), red = [nlev][2][C].
  * gamma/beta/running_*/dgamma/dbeta are HOST arrays of nlev device pointers.  Partial-row inputs hold one row per `div` tensor rows. */
 int hn_bn_finalize_levels(const float* psum, const float* psq, int div, int C, int nlev, const long* rows, const long* count,
                           const void* const* gamma, const void* const* beta, void* const* running_mean, void* const* running_var, float eps,
-                          float momentum, float* coef, hipStream_t stream);
+                          float momentum, const float* conv_bias, float* coef, hipStream_t stream);
 int hn_bn_act_levels(const void* z, int ldz, const float* coef, int act, void* out, int ldo, int C, int nlev, const long* rows,
                      hipStream_t stream);
 int hn_bn_bwd_reduce_levels(const void* dout, int ldd, const void* z, int ldz, const void* y, int ldy, const float* coef, int act, int C,

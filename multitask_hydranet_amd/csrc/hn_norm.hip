@@ -463,6 +463,8 @@ struct FinLevels {
     const float* gamma[HN_MAX_LEVELS]; const float* beta[HN_MAX_LEVELS]; float* rm[HN_MAX_LEVELS]; float* rv[HN_MAX_LEVELS];
     float* dgamma[HN_MAX_LEVELS]; float* dbeta[HN_MAX_LEVELS];
     float* out;                  // fwd: coef [level][4][C]; bwd: red [level][2][C]
+    const float* bias;           // fwd, ragged packing: the conv bias -- the (rows - count) alignment rows of a level hold exactly
+                                 // bf16(bias[c]) (their conv input is zero), which is subtracted from the sums
 };
 template <bool BWD>
 __global__ __launch_bounds__(1024) void bn_finalize_levels_kernel(const FinLevels p) {
@@ -484,6 +486,12 @@ __global__ __launch_bounds__(1024) void bn_finalize_levels_kernel(const FinLevel
         s1 = r1[0][tx]; s2 = r2[0][tx];
         const double count = (double)p.count[lv];
         if (!BWD) {
+            const long npad = (p.sg.row_off[lv + 1] - p.sg.row_off[lv]) - p.count[lv];
+            if (npad > 0 && p.bias) {
+                const double q = (double)bfround(p.bias[c]);
+                s1 -= (double)npad * q;
+                s2 -= (double)npad * q * q;
+            }
             float* coef = p.out + (long)lv * 4 * p.C;
             const double mu = s1 / count;
             double var = s2 / count - mu * mu;
@@ -910,12 +918,13 @@ static int fill_fin(FinLevels& p, const float* p1, const float* p2, int div, int
 /* partial rows psum/psq: one per `div` tensor rows (64 for the hn_conv_gemm_nt epilogue statistics); coef out: [nlev][4][C] */
 extern "C" int hn_bn_finalize_levels(const float* psum, const float* psq, int div, int C, int nlev, const long* rows, const long* count,
                                      const void* const* gamma, const void* const* beta, void* const* running_mean,
-                                     void* const* running_var, float eps, float momentum, float* coef, hipStream_t st) {
+                                     void* const* running_var, float eps, float momentum, const float* conv_bias, float* coef,
+                                     hipStream_t st) {
     HN_CHECK_ARG(gamma && beta && coef);
     FinLevels p = {};
     const int rc = fill_fin(p, psum, psq, div, C, nlev, rows, count);
     if (rc != HN_OK) return rc;
-    p.eps = eps; p.momentum = momentum; p.out = coef;
+    p.eps = eps; p.momentum = momentum; p.out = coef; p.bias = conv_bias;
     for (int l = 0; l < nlev; ++l) {
         HN_CHECK_ARG(gamma[l] && beta[l]);
         p.gamma[l] = (const float*)gamma[l]; p.beta[l] = (const float*)beta[l];

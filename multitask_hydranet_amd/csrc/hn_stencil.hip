@@ -280,7 +280,21 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const bf16* in, int ldi
                                                          const Levels L) {
     const int C8 = C >> 3;
     long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= L.work_off[L.n]) return;
+    if (idx >= L.work_off[L.n]) {
+        // ragged level packing: every level is padded to a multiple of the row alignment; the work items behind the real ones ZERO those
+        // alignment rows, so that downstream GEMMs see exact zeros there (their BatchNorm statistics are corrected analytically)
+        idx -= L.work_off[L.n];
+        for (int l = 0; l < L.n; ++l) {
+            const long real = (long)N * L.H[l] * L.W[l];
+            const long pad = L.row_off[l + 1] - L.row_off[l] - real;
+            if (idx < pad * C8) {
+                st8(out + (L.row_off[l] + real + idx / C8) * ldo + (idx % C8) * 8, zero8());
+                return;
+            }
+            idx -= pad * C8;
+        }
+        return;
+    }
     int lv = 0;
     while (lv + 1 < L.n && idx >= L.work_off[lv + 1]) ++lv;
     idx -= L.work_off[lv];
@@ -959,14 +973,15 @@ extern "C" int hn_dw_pack(const float* w, void* wk, void* wkf, int C, hipStream_
     hipLaunchKernelGGL(dw_pack_kernel, dim3(cdiv(9L * C, 256)), dim3(256), 0, st, w, (bf16*)wk, (bf16*)wkf, C);
     HN_LAUNCH_CHECK();
 }
-static int fill_levels(Levels& L, int N, int nlev, const int* H, const int* W) {
-    HN_CHECK_ARG(nlev >= 1 && nlev <= HN_MAX_LEVELS && H && W);
+static int fill_levels(Levels& L, int N, int nlev, const int* H, const int* W, int row_align = 1) {
+    HN_CHECK_ARG(nlev >= 1 && nlev <= HN_MAX_LEVELS && H && W && row_align >= 1);
     L.n = nlev;
     L.row_off[0] = 0;
     for (int l = 0; l < nlev; ++l) {
         HN_CHECK_ARG(H[l] > 0 && W[l] > 0);
         L.H[l] = H[l]; L.W[l] = W[l];
-        L.row_off[l + 1] = L.row_off[l] + (long)N * H[l] * W[l];
+        const long real = (long)N * H[l] * W[l];
+        L.row_off[l + 1] = L.row_off[l] + (real + row_align - 1) / row_align * row_align;     // ragged packing: levels start on aligned rows
     }
     return HN_OK;
 }
@@ -974,7 +989,9 @@ static int dwconv_fwd_launch(const void* in, int ldi, const void* wk, void* out,
     HN_CHECK_ARG(in && wk && out && (C & 7) == 0 && ((ldi | ldo) & 7) == 0);
     L.work_off[0] = 0;
     for (int l = 0; l < L.n; ++l) L.work_off[l + 1] = L.work_off[l] + (long)N * L.H[l] * ((L.W[l] + 3) >> 2) * (C >> 3);
-    hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(cdiv(L.work_off[L.n], 256)), dim3(256), 0, st, (const bf16*)in, ldi, (const bf16*)wk, (bf16*)out,
+    long pad_items = 0;
+    for (int l = 0; l < L.n; ++l) pad_items += (L.row_off[l + 1] - L.row_off[l] - (long)N * L.H[l] * L.W[l]) * (C >> 3);
+    hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(cdiv(L.work_off[L.n] + pad_items, 256)), dim3(256), 0, st, (const bf16*)in, ldi, (const bf16*)wk, (bf16*)out,
                        ldo, N, C, L);
     HN_LAUNCH_CHECK();
 }
@@ -984,9 +1001,9 @@ extern "C" int hn_dwconv_fwd(const void* in, int ldi, const void* wk, void* out,
     return rc != HN_OK ? rc : dwconv_fwd_launch(in, ldi, wk, out, ldo, N, C, L, st);
 }
 extern "C" int hn_dwconv_fwd_levels(const void* in, int ldi, const void* wk, void* out, int ldo, int N, int C, int nlev, const int* H,
-                                    const int* W, hipStream_t st) {
+                                    const int* W, int row_align, hipStream_t st) {
     Levels L;
-    const int rc = fill_levels(L, N, nlev, H, W);
+    const int rc = fill_levels(L, N, nlev, H, W, row_align);
     return rc != HN_OK ? rc : dwconv_fwd_launch(in, ldi, wk, out, ldo, N, C, L, st);
 }
 // number of partial rows (= blocks) of hn_dwconv_wgrad; part is fp32 [blocks][C*9], reduce with hn_rows_reduce(part, dw, 1, blocks, C*9, 1)
@@ -1015,9 +1032,9 @@ extern "C" int hn_dwconv_wgrad(const void* x, int ldx, const void* dz, int ldz, 
     return rc != HN_OK ? rc : dwconv_wgrad_launch(x, ldx, dz, ldz, part, N, C, L, st);
 }
 extern "C" int hn_dwconv_wgrad_levels(const void* x, int ldx, const void* dz, int ldz, float* part, int N, int C, int nlev, const int* H,
-                                      const int* W, hipStream_t st) {
+                                      const int* W, int row_align, hipStream_t st) {
     Levels L;
-    const int rc = fill_levels(L, N, nlev, H, W);
+    const int rc = fill_levels(L, N, nlev, H, W, row_align);
     return rc != HN_OK ? rc : dwconv_wgrad_launch(x, ldx, dz, ldz, part, N, C, L, st);
 }
 

@@ -1099,19 +1099,40 @@ def det_loss_hip(classification, regression, anchors, annotations):
 # in the per-level BatchNorm (head_detect/detection.py:20-35,57-72).  Launched level by level that is ~650 launches per step, most of
 # them on 4x8 ... 16x32 maps where a launch is pure latency.  Here the levels live stacked in one [sum_l N*H_l*W_l, C] tensor: the
 # depthwise conv, the pointwise GEMM (+ statistics), the BatchNorm passes and every backward kernel run ONCE for all levels, with the
-# per-level BatchNorm parameters selected per row block inside the kernels.  Requires every level's row count to be a multiple of 128.
+# per-level BatchNorm parameters selected per row block inside the kernels.  Levels whose row count is not a multiple of 128 (640x640: P7 =
+# 25 rows per image) are padded up to one ("ragged" packing): the depthwise kernel writes zeros to the alignment rows, so the pointwise conv
+# output there is exactly bf16(bias) and is subtracted from the BatchNorm statistics; gradients at those rows are zero by construction.
 # --------------------------------------------------------------------------------------------------------------
+LEVEL_ALIGN = 128           # rows: GEMM pixel tiles / BatchNorm row blocks never straddle two pyramid levels
+
+
 def levels_packable(feats):
-    return len(feats) <= 5 and all((f.shape[0] * f.shape[1] * f.shape[2]) % 128 == 0 for f in feats)
+    return len(feats) <= 5
+
+
+def _pad_rows(r):
+    return (r + LEVEL_ALIGN - 1) // LEVEL_ALIGN * LEVEL_ALIGN
 
 
 def _geom_arrays(geom):
+    """(nlev, H[], W[], padded rows per level R[], real rows per level CNT[]) as ctypes arrays"""
     n, hs, ws = geom
     nl = len(hs)
     H = (ctypes.c_int * nl)(*hs)
     W = (ctypes.c_int * nl)(*ws)
-    R = (ctypes.c_long * nl)(*[n * h * w for h, w in zip(hs, ws)])
-    return nl, H, W, R
+    R = (ctypes.c_long * nl)(*[_pad_rows(n * h * w) for h, w in zip(hs, ws)])
+    CNT = (ctypes.c_long * nl)(*[n * h * w for h, w in zip(hs, ws)])
+    return nl, H, W, R, CNT
+
+
+def packed_rows(geom):
+    n, hs, ws = geom
+    return sum(_pad_rows(n * h * w) for h, w in zip(hs, ws))
+
+
+def has_pad_rows(geom):
+    n, hs, ws = geom
+    return any((n * h * w) % LEVEL_ALIGN for h, w in zip(hs, ws))
 
 
 def _ptr_array(tensors):
@@ -1119,30 +1140,31 @@ def _ptr_array(tensors):
 
 
 def level_views(packed, geom):
-    """NHWC views of the levels of a packed [1, 1, rows, C] tensor"""
+    """NHWC views of the (real rows of the) levels of a packed [1, 1, rows, C] tensor; every level starts on an aligned row"""
     n, hs, ws = geom
     out, off = [], 0
     for h, w in zip(hs, ws):
         m = n * h * w
         out.append(packed[0, 0, off:off + m].view(n, h, w, packed.shape[3]))
-        off += m
+        off += _pad_rows(m)
     return out
 
 
 def k_dwconv_levels(x, wk, geom):
-    nl, H, W, _ = _geom_arrays(geom)
+    nl, H, W, _, _ = _geom_arrays(geom)
     out = torch.empty_like(x)
     lib().call("hn_dwconv_fwd_levels", ptr(x), ld(x), ptr(wk), ptr(out), ld(out), geom[0], x.shape[3], nl, ctypes.addressof(H),
-               ctypes.addressof(W))
+               ctypes.addressof(W), LEVEL_ALIGN)
     return out
 
 
 def k_dwconv_wgrad_levels(x, dz, geom):
-    nl, H, W, _ = _geom_arrays(geom)
+    nl, H, W, _, _ = _geom_arrays(geom)
     c = x.shape[3]
     chunks = lib().query("hn_dwconv_wgrad_blocks", sum(geom[0] * hh * ((ww + 3) // 4) for hh, ww in zip(geom[1], geom[2])), c)
     part = torch.empty((chunks, c * 9), device=x.device, dtype=F32)
-    lib().call("hn_dwconv_wgrad_levels", ptr(x), ld(x), ptr(dz), ld(dz), ptr(part), geom[0], c, nl, ctypes.addressof(H), ctypes.addressof(W))
+    lib().call("hn_dwconv_wgrad_levels", ptr(x), ld(x), ptr(dz), ld(dz), ptr(part), geom[0], c, nl, ctypes.addressof(H), ctypes.addressof(W),
+               LEVEL_ALIGN)
     return k_rows_reduce(part, 1, chunks, c * 9).view(c, 1, 3, 3)
 
 
@@ -1153,7 +1175,7 @@ class PackLevels(torch.autograd.Function):
     def forward(ctx, *feats):
         n, c = feats[0].shape[0], feats[0].shape[3]
         geom = (n, tuple(f.shape[1] for f in feats), tuple(f.shape[2] for f in feats))
-        total = sum(rows(f) for f in feats)
+        total = packed_rows(geom)
         out = torch.empty((1, 1, total, c), device=feats[0].device, dtype=BF16)
         for v, f in zip(level_views(out, geom), feats):
             k_eltwise(2, f, alpha=1.0, out=v)
@@ -1170,7 +1192,7 @@ class TowerLayer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, dw_w, pw_w, pw_b, geom, act, eps, momentum, training, *bn):
-        nl, H, W, R = _geom_arrays(geom)
+        nl, H, W, R, CNT = _geom_arrays(geom)
         total, c = x.shape[2], x.shape[3]
         cout = pw_w.shape[0]
         dev = x.device
@@ -1184,9 +1206,9 @@ class TowerLayer(torch.autograd.Function):
         if training:
             div = total // psum.shape[0]
             ga, ba, rma, rva = _ptr_array(gam), _ptr_array(bet), _ptr_array(rms), _ptr_array(rvs)    # keep the host arrays alive
-            lib().call("hn_bn_finalize_levels", ptr(psum), ptr(psq), div, cout, nl, ctypes.addressof(R), ctypes.addressof(R),
+            lib().call("hn_bn_finalize_levels", ptr(psum), ptr(psq), div, cout, nl, ctypes.addressof(R), ctypes.addressof(CNT),
                        ctypes.addressof(ga), ctypes.addressof(ba), ctypes.addressof(rma), ctypes.addressof(rva), float(eps),
-                       float(momentum), ptr(coef))
+                       float(momentum), ptr(pw_b), ptr(coef))
         else:
             for l in range(nl):
                 lib().call("hn_bn_eval_coeff", ptr(gam[l]), ptr(bet[l]), ptr(rms[l]), ptr(rvs[l]), float(eps), cout, ptr(coef[l, 0]),
@@ -1204,7 +1226,7 @@ class TowerLayer(torch.autograd.Function):
         x, d, z, coef, pw_w = ctx.saved_tensors
         assert ctx.training, "backward through eval-mode BatchNorm is not part of the hot path"
         geom, act = ctx.geom, ctx.act
-        nl, H, W, R = _geom_arrays(geom)
+        nl, H, W, R, CNT = _geom_arrays(geom)
         wf, wt = ctx.packs
         dout = dense(dout)
         total, c = x.shape[2], x.shape[3]
@@ -1221,7 +1243,7 @@ class TowerLayer(torch.autograd.Function):
         dgam = [torch.empty((cout,), device=dev, dtype=F32) for _ in range(nl)]
         dbet = [torch.empty((cout,), device=dev, dtype=F32) for _ in range(nl)]
         dga, dba = _ptr_array(dgam), _ptr_array(dbet)
-        lib().call("hn_bn_bwd_finalize_levels", ptr(pg), ptr(pgx), r, cout, nl, ctypes.addressof(R), ctypes.addressof(R),
+        lib().call("hn_bn_bwd_finalize_levels", ptr(pg), ptr(pgx), r, cout, nl, ctypes.addressof(R), ctypes.addressof(CNT),
                    ctypes.addressof(dga), ctypes.addressof(dba), ptr(red))
         dz = torch.empty_like(z)
         lib().call("hn_bn_bwd_apply_levels", ptr(dout), ld(dout), ptr(z), ld(z), None, 0, ptr(coef), ptr(red), act, ptr(dz), ld(dz), cout, nl,
@@ -1273,7 +1295,8 @@ class HeadOutPacked(torch.autograd.Function):
         dev = dout.device
         ldz = pad8(cout)
         total = x.shape[2]
-        dz = torch.empty((1, 1, total, ldz), device=dev, dtype=BF16)
+        # alignment rows of a ragged packing must read as zeros in the bias / weight gradient sums and in the data gradient
+        dz = zeros((1, 1, total, ldz), dev, BF16) if has_pad_rows(geom) else torch.empty((1, 1, total, ldz), device=dev, dtype=BF16)
         off = 0
         for v, h, w in zip(level_views(dz, geom), hs, ws):
             base = off * ldc

@@ -341,24 +341,31 @@ def test_deploy_mode_and_bit_exact_bookkeeping(env):
 
 
 @pytest.mark.gpu
-def test_det_towers_level_packed_equals_per_level():
+@pytest.mark.parametrize("hh,ww,n", [(256, 512, 16), (640, 640, 3), (384, 640, 5)])
+def test_det_towers_level_packed_equals_per_level(hh, ww, n):
     """ops.TowerLayer / HeadOutPacked (one launch per op for all five pyramid levels) against the per-level path on the same inputs:
-    same arithmetic, only the order of the BatchNorm partial sums differs."""
+    same arithmetic, only the order of the BatchNorm partial sums differs.  640x640 / 384x640 exercise the RAGGED packing (pyramid levels
+    of 1200 / 300 / 75 ... rows, padded to multiples of 128 with analytically corrected statistics)."""
     import copy
     import yaml
     from multitask_hydranet_amd import HydraNet
     cfgs = yaml.safe_load(open(os.path.join(os.path.dirname(__file__), "..", "cfgs", "hydranet_tiny.yml")))
-    cfgs["dataloader"]["network_input_height"], cfgs["dataloader"]["network_input_width"] = 256, 512
+    cfgs["dataloader"]["network_input_height"], cfgs["dataloader"]["network_input_width"] = hh, ww
     torch.manual_seed(3)
     net = HydraNet(cfgs).cuda().train()
-    n, c = 16, net.fpn_num_filters
-    img = torch.zeros(n, 3, 256, 512, device="cuda")
+    c = net.fpn_num_filters
+    # non-trivial conv biases: the alignment rows of a ragged packing hold bf16(bias), which the statistics correction relies on
+    with torch.no_grad():
+        for k, v in net.named_parameters():
+            if k.startswith("detectheader.") and k.endswith("pointwise_conv.conv.bias"):
+                v.normal_(0.0, 0.5)
+    img = torch.zeros(n, 3, hh, ww, device="cuda")
     g = torch.Generator(device="cuda").manual_seed(5)
     res = {}
     for packed in (False, True):
         net.pack_det_levels = packed
         net.zero_grad(set_to_none=True)
-        fused = [torch.randn(n, 256 >> s, 512 >> s, c, device="cuda", generator=torch.Generator(device="cuda").manual_seed(7 + s))
+        fused = [torch.randn(n, hh >> s, ww >> s, c, device="cuda", generator=torch.Generator(device="cuda").manual_seed(7 + s))
                  .to(torch.bfloat16).requires_grad_(True) for s in (3, 4, 5, 6, 7)]
         _, reg, cls = net._det(img, fused)
         wr = torch.randn(reg.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(11))
