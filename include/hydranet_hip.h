@@ -145,6 +145,24 @@ int hn_seg_fold(const void* dvp, int ldv, int c0, void* out, int ldo, const void
 int hn_depth_to_space(const float* in, int ldi, float* out, int N, int h, int w, int k, hipStream_t stream);
 int hn_space_to_depth(const float* dy, void* out, int ldo, int N, int h, int w, int k, hipStream_t stream);
 
+/* bf16 form: in [N][2h][2w][k] (row stride ldi) -> out [N][h][w][4k], phase-major channels (the operand layout of the phase-form convs) */
+int hn_space_to_depth_bf16(const void* in, int ldi, void* out, int N, int h, int w, int k, hipStream_t stream);
+
+/* Phase form of Conv3x3(ReflectionPad2d(1)(nearest_up2(x0))) (head_seg/segmentation.py:92-104, decoder blocks 1/3/5/7) on the LOW-resolution
+ * grid: effective weights W_eff[(py,px,o)][c][dy][dx] = sum of the original taps that land on low-res offset (dy, dx) for output phase
+ * (py, px); phase (py, px) is non-zero only on ky in {py, py+1}, kx in {px, px+1}, and only those 4 taps are visited (16 instead of 36
+ * tap products per low-res pixel = 2.25x fewer MACs than convolving the up-sampled map).
+ *   mode 4 (forward): x0 [N][H][W][C0] (low-res), w = packed W_eff [4k][9][KP(C0)], bias [4k], out bf16 [N][2H][2W][k] (row stride ldc),
+ *           addend (optional, row stride ld_add, the output's layout) = pre-activation partial result of the full-resolution skip operand;
+ *   mode 3 (data gradient): x0 = space-to-depth output gradient [N][H-2][W-2][4k] (H, W are the PADDED sizes), w = packed transposed
+ *           weights [C][9][KP(4k)], out = padded-grid gradient [N][H][W][Nout] (fold with hn_seg_fold, up = 2).
+ * hn_conv_gemm_tn_phase: gradient of W_eff (fp32 [4k][C0][3][3], zeros at unused taps) from x0 and the space-to-depth output gradient. */
+int hn_conv3x3_phase(const void* x0, int mode, int n_img, int H, int W, int C0, int ld0, const void* w, int Nout, int KP, const float* bias,
+                     int act, void* out, int ldc, int k, const void* addend, int ld_add, hipStream_t stream);
+int hn_wgrad_plan_phase(int n_img, int H, int W, int Nout, int KP, int phase_span, int* splits, long* rows_per_split, long* ws_bytes);
+int hn_conv_gemm_tn_phase(const void* x0, int n_img, int H, int W, int C0, int ld0, const void* dz, int ldz, int Nout, int KP, int phase_span,
+                          float* workspace, float* dw, hipStream_t stream);
+
 /* fp32 head-output gradient [N][rows][Nout] -> zero padded bf16 dz [N*rpi][ldz] (optionally times sigmoid'). */
 int hn_head_grad(const float* dy, const float* y, long rpi, long img_stride, int lds, int Nout, void* dz, int ldz, long M, int sigmoid,
                  hipStream_t stream);

@@ -138,6 +138,11 @@ struct GemmNT {
     // applied between the global load and the LDS store -- a BatchNorm apply (+ ReLU, + SE gate) that is never materialised
     const float* xscale; const float* xshift; const float* xgate; long xhw; int xact;
     const bf16* addend; int ld_add;   // staged bf16 epilogue: out = bf16(bf16(acc) + addend[pix][co])  (residual-gradient add of a dgrad)
+    // Phase form of a 3x3 conv over a nearest-x2 up-sampled map (direct kernel): the conv runs on the LOW-resolution grid with 4 * k
+    // outputs (one k-vector per output phase (py, px)) and summed-tap effective weights; phase (py, px) only has non-zero weights on the
+    // taps ky in {py, py+1}, kx in {px, px+1}, so 4 of the 9 taps are visited (2.25x fewer MACs than convolving the up-sampled map):
+    //   phase_mode 1 (forward): the cout tile's phase = cout / phase_span;  2 (data gradient, mode 3): the K chunk's phase = channel / phase_span
+    int phase_mode, phase_span;
     int add_pre;                      // 1: the addend goes in BEFORE the activation: out = act(acc + bias + addend) (inference: folded
                                       // BatchNorm + identity branch + ReLU of an XBlock in conv_block_3's epilogue)
 };
@@ -557,8 +562,15 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
     const int c_blk = c_tile * BC, oy0 = ty * 16, ox0 = tx * 16;
     const int org = xs.mode == 2 ? -1 : -2;                           // patch origin relative to the output tile
     const int Ctot = xs.C0 + xs.C1;
-    const int nchunk = xs.diag ? 1 : (p.KP + 63) >> 6, S = nchunk * 9;
+    const int NT = p.phase_mode ? 4 : 9;                              // taps visited per 64-channel chunk
+    const int nchunk = xs.diag ? 1 : (p.KP + 63) >> 6, S = nchunk * NT;
     const int Ktot = 9 * p.KP;
+    const int tile_phase = p.phase_mode == 1 ? c_blk / p.phase_span : 0;
+    auto tap_of = [&](int chunk, int ti) {
+        if (!p.phase_mode) return ti;
+        const int ph = p.phase_mode == 1 ? tile_phase : (chunk * 64) / p.phase_span;
+        return ((ph >> 1) + (ti >> 1)) * 3 + (ph & 1) + (ti & 1);
+    };
     const int xc0 = xs.diag ? c_blk : 0;                              // first input channel of chunk 0
 
     // patch pieces owned by this thread: e = tid + 512 i -> patch pixel e>>3, PHYSICAL piece e&7 (logical = physical ^ (pixel&7))
@@ -604,7 +616,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
     // stage st = chunk * 9 + tap.  Iteration `it` issues the DMA of stage `it` (+ the X patch of its chunk when tap == 0) and multiplies
     // stage `it - 1`.
     auto compute = [&](int st) {
-        const int chunk = st / 9, tap = st - chunk * 9;
+        const int chunk = st / NT, tap = tap_of(chunk, st - chunk * NT);
         const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
         const int dy = xs.mode == 2 ? ky : 2 - ky, dx = xs.mode == 2 ? kx : 2 - kx;
         const char* sW = sWb + (st & 1) * WBYTES;
@@ -631,13 +643,13 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         // single patch buffer: at a chunk boundary the last tap of the old chunk is multiplied BEFORE the new patch may overwrite it
-        const bool boundary = XBUFS == 1 && it > 0 && it < S && (it % 9) == 0;
+        const bool boundary = XBUFS == 1 && it > 0 && it < S && (it % NT) == 0;
         if (boundary) {
             compute(it - 1);
             __syncthreads();
         }
         if (it < S) {
-            const int chunk = it / 9, tap = it - chunk * 9;
+            const int chunk = it / NT, ti = it - chunk * NT, tap = tap_of(chunk, ti);
             const int k0 = chunk * 64;
             char* sW = sWb + (it & 1) * WBYTES;
 #pragma unroll
@@ -647,7 +659,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
                     glds16(src, sW + (wave * 8 + 64 * i) * 128);
                 }
             }
-            if (tap == 0) {
+            if (ti == 0) {
                 char* sX = sXb + (XBUFS == 2 ? (chunk & 1) : 0) * XBYTES;
 #pragma unroll
                 for (int i = 0; i < XL; ++i) {
@@ -723,6 +735,23 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bsv[r];
+            if (!OUT_F32 && p.d2s) {
+                // phase form, bf16: the 4 couts of a lane belong to one phase; output pixel (2y+py, 2x+px), d2s channels per pixel;
+                // the partial result of the full-resolution (skip connection) operand arrives as a pre-activation addend
+                if (co0 < p.Nout) {
+                    const int ph = co0 / p.d2s, oc = co0 - ph * p.d2s;
+                    const long opix = ((long)(n * 2 * xs.H + 2 * oy + (ph >> 1)) * (2 * xs.W) + 2 * ox + (ph & 1));
+                    if (p.addend) {
+                        const bf16x4 a = *reinterpret_cast<const bf16x4*>(p.addend + opix * p.ld_add + oc);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += bf2f(a[r]);
+                    }
+                    act_fwd_n(v, p.act);
+                    bf16x4 tv = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.out) + opix * p.ldc + oc) = tv;
+                }
+                continue;
+            }
             act_fwd_n(v, p.act);
             if (OUT_F32 && p.d2s) {
                 float* ob = reinterpret_cast<float*>(p.out);
@@ -765,6 +794,8 @@ struct GemmTN {
     float* part;      // [splits][Nout][taps*KP]
     long rows_per_split;   // multiple of 64
     int gy;           // number of cout tiles
+    int phase_span;   // patch wgrad of a phase-form conv (see GemmNT::phase_mode): couts per phase; the cout tile's phase only has
+                      // non-zero effective weights on 4 of the 9 taps, the other five are skipped (their slab entries stay zero)
 };
 
 // LDS image of a pixel-major tile: rows of COLS bf16, UNPADDED (LDS-DMA writes lane-linear 1 KiB runs), 16-byte pieces XOR-swizzled so
@@ -989,6 +1020,13 @@ __global__ __launch_bounds__(512) void wgrad3x3_patch_kernel(const GemmTN p, int
     for (int i = 0; i < TC; ++i)
 #pragma unroll
         for (int t = 0; t < 9; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    unsigned tapmask = 0x1ffu;
+    if (p.phase_span) {
+        const int ph = c_blk / p.phase_span, py = ph >> 1, px = ph & 1;
+        tapmask = 0;
+        for (int a = 0; a < 2; ++a)
+            for (int b = 0; b < 2; ++b) tapmask |= 1u << ((py + a) * 3 + px + b);
+    }
 
     const int g = lane >> 4, t16 = lane & 15, q = t16 >> 2, pp = t16 & 3;
     typedef __bf16 trv4 __attribute__((__vector_size__(4 * sizeof(__bf16))));
@@ -1053,6 +1091,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_patch_kernel(const GemmTN p, int
                 const int bpiece = (wn * 16) / 8 + (pp >> 1);
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
+                    if (!((tapmask >> tap) & 1u)) continue;            // workgroup-uniform
                     const int ky = tap / 3, kx = tap - 3 * ky;
                     const int plo = (2 * ks + ky) * 18 + kx + g * 4 + q, phi = plo + 18;
                     const trv4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(sX + plo * XROW + tn_swz<CI>(plo, bpiece) * 16 + (pp & 1) * 8));
@@ -1300,13 +1339,14 @@ extern "C" int hn_nt_stat_rows(long M, int Nout) {               // one partial 
 static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img, int H, int W, int C0, int C1, int ld0, int ld1,
                              int up, long M, const void* w, int Nout, int KP, int taps, const float* bias, int act, void* out,
                              int out_f32, int ldc, long rpi, long img_stride, float* psum, float* psq, const float* xscale,
-                             const float* xshift, const float* xgate, long xhw, int xact, const void* addend, int ld_add, hipStream_t st);
+                             const float* xshift, const float* xgate, long xhw, int xact, const void* addend, int ld_add, int phase_mode,
+                             int phase_span, hipStream_t st);
 
 extern "C" int hn_conv_gemm_nt(const void* x0, const void* x1, int mode, int n_img, int H, int W, int C0, int C1, int ld0, int ld1,
                                int up, long M, const void* w, int Nout, int KP, int taps, const float* bias, int act, void* out,
                                int out_f32, int ldc, long rpi, long img_stride, float* psum, float* psq, hipStream_t st) {
     return conv_gemm_nt_impl(x0, x1, mode, n_img, H, W, C0, C1, ld0, ld1, up, M, w, Nout, KP, taps, bias, act, out, out_f32, ldc, rpi,
-                             img_stride, psum, psq, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, st);
+                             img_stride, psum, psq, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, 0, 0, st);
 }
 
 extern "C" int hn_conv_gemm_nt_ex(const void* x0, const void* x1, int mode, int n_img, int H, int W, int C0, int C1, int ld0, int ld1,
@@ -1315,20 +1355,40 @@ extern "C" int hn_conv_gemm_nt_ex(const void* x0, const void* x1, int mode, int 
                                   const float* xshift, const float* xgate, long xhw, int xact, const void* addend, int ld_add,
                                   hipStream_t st) {
     return conv_gemm_nt_impl(x0, x1, mode, n_img, H, W, C0, C1, ld0, ld1, up, M, w, Nout, KP, taps, bias, act, out, out_f32, ldc, rpi,
-                             img_stride, psum, psq, xscale, xshift, xgate, xhw, xact, addend, ld_add, st);
+                             img_stride, psum, psq, xscale, xshift, xgate, xhw, xact, addend, ld_add, 0, 0, st);
+}
+
+/* Phase form of Conv3x3(ReflectionPad2d(1)(nearest_up2(x0))) on the low-resolution grid (head_seg/segmentation.py:92-104 decoder blocks
+ * 1/3/5/7): mode 4 (forward; w = effective weights [4*k][9][KP(C0)], out = bf16 [N][2H][2W][k], bias [4*k], addend (optional, ld_add) =
+ * pre-activation partial result of the full-resolution skip operand at the output's layout) or mode 3 (data gradient on the padded
+ * low-resolution grid; x0 = space-to-depth gradient [N][H][W][4*k], w = transposed effective weights).  Only the 4 non-zero taps of each
+ * phase are visited. */
+extern "C" int hn_conv3x3_phase(const void* x0, int mode, int n_img, int H, int W, int C0, int ld0, const void* w, int Nout, int KP,
+                                const float* bias, int act, void* out, int ldc, int k, const void* addend, int ld_add, hipStream_t st) {
+    HN_CHECK_ARG((mode == 4 || mode == 3) && k > 0 && (k & 3) == 0);
+    if (mode == 4) {
+        HN_CHECK_ARG(Nout == 4 * k && (k % 64 == 0) && (!addend || (ld_add & 3) == 0));
+        return conv_gemm_nt_impl(x0, nullptr, 4, n_img, H, W, C0, 0, ld0, 0, 0, (long)n_img * H * W, w, Nout, KP, 9, bias, act, out, 0, ldc, 0,
+                                 -(long)k, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, addend, -ld_add, 1, k, st);
+    }
+    HN_CHECK_ARG(C0 == 4 * k && (k % 64 == 0) && !addend);
+    return conv_gemm_nt_impl(x0, nullptr, 3, n_img, H, W, C0, 0, ld0, 0, 0, (long)n_img * H * W, w, Nout, KP, 9, bias, act, out, 0, ldc, 0, 0,
+                             nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, 2, k, st);
 }
 
 static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img, int H, int W, int C0, int C1, int ld0, int ld1,
                              int up, long M, const void* w, int Nout, int KP, int taps, const float* bias, int act, void* out,
                              int out_f32, int ldc, long rpi, long img_stride, float* psum, float* psq, const float* xscale,
-                             const float* xshift, const float* xgate, long xhw, int xact, const void* addend, int ld_add, hipStream_t st) {
+                             const float* xshift, const float* xgate, long xhw, int xact, const void* addend, int ld_add, int phase_mode,
+                             int phase_span, hipStream_t st) {
     HN_CHECK_ARG(x0 && w && out && M > 0 && Nout > 0 && KP > 0 && (KP & 31) == 0 && taps >= 1 && taps <= 9);
     // operand transform: plain / stride-2 row gathers, bf16 output; addend: staged bf16 epilogue only (aligned rows, no per-image mapping)
     HN_CHECK_ARG(!xscale || (xshift && mode <= 1 && !out_f32 && C1 == 0 && (!xgate || xhw > 0)));
     // ld_add < 0: the addend (row stride -ld_add) is added BEFORE the activation (any epilogue form)
+    HN_CHECK_ARG(phase_mode == 0 || ((mode == 3 || mode == 4) && phase_span >= 64 && phase_span % 64 == 0 && !psum && !rpi));
     HN_CHECK_ARG(!addend || ld_add < 0 || (!out_f32 && (Nout & 7) == 0 && (ldc & 7) == 0 && (ld_add & 7) == 0 && rpi == 0 && mode <= 1 &&
                                            (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(addend) & 15) == 0));
-    HN_CHECK_ARG(!addend || ld_add >= 0 || (mode <= 1 && rpi == 0 && ((-ld_add) & 3) == 0));
+    HN_CHECK_ARG(!addend || ld_add >= 0 || ((mode <= 1 || phase_mode == 1) && rpi == 0 && ((-ld_add) & 3) == 0));
     HN_CHECK_ARG((C0 & 7) == 0 && (C1 & 7) == 0 && (ld0 & 7) == 0 && (C1 == 0 || (x1 && (ld1 & 7) == 0)));
     HN_CHECK_ARG(mode >= 0 && mode <= 5 && (mode < 4 || (up == 0 && C1 == 0)));
     HN_CHECK_ARG(mode == 5 ? (KP == 64 && Nout == C0 && !rpi) : C0 + C1 <= KP);
@@ -1344,13 +1404,15 @@ static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img
     p.d2s = 0;
     p.xscale = xscale; p.xshift = xshift; p.xgate = xgate; p.xhw = xhw; p.xact = xact;
     p.addend = (const bf16*)addend; p.ld_add = ld_add < 0 ? -ld_add : ld_add; p.add_pre = ld_add < 0 ? 1 : 0;
-    if (img_stride < 0) {                                            // mode 4 + fp32 out: -img_stride = channels per depth-to-space output pixel
-        HN_CHECK_ARG(p.x.clamp == 1 && out_f32 && rpi == 0 && !psum && Nout == 4 * (int)(-img_stride));
+    p.phase_mode = phase_mode; p.phase_span = phase_span;
+    if (img_stride < 0) {                                            // mode 4: -img_stride = channels per depth-to-space output pixel
+        HN_CHECK_ARG(p.x.clamp == 1 && (out_f32 || phase_mode == 1) && rpi == 0 && !psum && Nout == 4 * (int)(-img_stride));
         p.d2s = (int)(-img_stride);
         p.img_stride = 0;
     }
     if (mode >= 2 && (!psum || p.x.diag) && !rpi) {      // statistics epilogue: grouped convs only (one partial row per 16x16 patch)
-        const int bc = p.x.diag ? 64 : (Nout <= 16 ? 16 : (Nout <= 64 ? 64 : 128));
+        int bc = p.x.diag ? 64 : (Nout <= 16 ? 16 : (Nout <= 64 ? 64 : 128));
+        if (phase_mode == 1 && phase_span < bc) bc = 64;            // a cout tile must lie inside one phase
         dim3 grid((unsigned)(cdiv(Nout, bc) * cdiv(W, 16) * cdiv(H, 16) * n_img));
         const size_t lds = (size_t)((18 * 18 * 128 + 1023) / 1024 * 1024) + 2 * (size_t)bc * 128;
         // > 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel (done on the first, un-captured call)
@@ -1416,8 +1478,18 @@ static void patch_tiles(int Nout, int& bc, int& ci, int& ksplit) {
 
 // plan the pixel split for wgrad: returns splits, rows per split (multiple of 64; patches per split for the 3x3 patch kernel) and the
 // fp32 workspace size in bytes
+static int wgrad_plan_impl(int mode, int n_img, int H, int W, long M, int Nout, int KP, int taps, int phase_span, int* splits,
+                           long* rows_per_split, long* ws_bytes);
 extern "C" int hn_wgrad_plan(int mode, int n_img, int H, int W, long M, int Nout, int KP, int taps, int* splits, long* rows_per_split,
                              long* ws_bytes) {
+    return wgrad_plan_impl(mode, n_img, H, W, M, Nout, KP, taps, 0, splits, rows_per_split, ws_bytes);
+}
+/* plan of hn_conv_gemm_tn_phase (phase_span = couts per phase) */
+extern "C" int hn_wgrad_plan_phase(int n_img, int H, int W, int Nout, int KP, int phase_span, int* splits, long* rows_per_split, long* ws_bytes) {
+    return wgrad_plan_impl(4, n_img, H, W, (long)n_img * H * W, Nout, KP, 9, phase_span, splits, rows_per_split, ws_bytes);
+}
+static int wgrad_plan_impl(int mode, int n_img, int H, int W, long M, int Nout, int KP, int taps, int phase_span, int* splits,
+                           long* rows_per_split, long* ws_bytes) {
     HN_CHECK_ARG(M > 0 && Nout > 0 && KP > 0 && taps > 0 && splits && rows_per_split && ws_bytes);
     const int grouped = mode == 5;
     if (mode == 4 || mode == 5) mode = 2;
@@ -1425,6 +1497,7 @@ extern "C" int hn_wgrad_plan(int mode, int n_img, int H, int W, long M, int Nout
         int bc, ci, ksplit;
         patch_tiles(Nout, bc, ci, ksplit);
         if (grouped) { bc = 64; ci = 64; ksplit = 2; }
+        if (phase_span && phase_span < bc) { bc = 64; ci = 128; ksplit = 1; }      // a cout tile must lie inside one phase
         const long tiles = (long)cdiv(Nout, bc) * cdiv(KP, ci);
         const long patches = (long)n_img * cdiv(H, 8) * cdiv(W, 16);
         long want = (256 + tiles - 1) / tiles;          // one workgroup per CU in total: every split costs a full fp32 slab of dW (write + reduce)
@@ -1451,21 +1524,37 @@ extern "C" int hn_wgrad_plan(int mode, int n_img, int H, int W, long M, int Nout
     return HN_OK;
 }
 
+static int conv_gemm_tn_impl(const void* x0, const void* x1, int mode, int n_img, int H, int W, int C0, int C1, int ld0, int ld1,
+                             int up, long M, const void* dz, int ldz, int Nout, int KP, int taps, int phase_span, float* workspace, float* dw,
+                             hipStream_t st);
 extern "C" int hn_conv_gemm_tn(const void* x0, const void* x1, int mode, int n_img, int H, int W, int C0, int C1, int ld0, int ld1,
                                int up, long M, const void* dz, int ldz, int Nout, int KP, int taps, float* workspace, float* dw,
                                hipStream_t st) {
+    return conv_gemm_tn_impl(x0, x1, mode, n_img, H, W, C0, C1, ld0, ld1, up, M, dz, ldz, Nout, KP, taps, 0, workspace, dw, st);
+}
+/* weight gradient of the phase-form conv (hn_conv3x3_phase mode 4): x0 = low-resolution input [N][H][W][C0], dz = space-to-depth output
+ * gradient [N][H][W][Nout = 4*k] (hn_space_to_depth_bf16), dw = gradient of the EFFECTIVE weights fp32 [4*k][C0][3][3] (zeros at the
+ * five taps a phase does not use).  workspace from hn_wgrad_plan_phase. */
+extern "C" int hn_conv_gemm_tn_phase(const void* x0, int n_img, int H, int W, int C0, int ld0, const void* dz, int ldz, int Nout, int KP,
+                                     int phase_span, float* workspace, float* dw, hipStream_t st) {
+    HN_CHECK_ARG(phase_span >= 64 && phase_span % 64 == 0 && Nout == 4 * phase_span && KP >= 64);
+    return conv_gemm_tn_impl(x0, nullptr, 4, n_img, H, W, C0, 0, ld0, 0, 0, (long)n_img * H * W, dz, ldz, Nout, KP, 9, phase_span, workspace, dw, st);
+}
+static int conv_gemm_tn_impl(const void* x0, const void* x1, int mode, int n_img, int H, int W, int C0, int C1, int ld0, int ld1,
+                             int up, long M, const void* dz, int ldz, int Nout, int KP, int taps, int phase_span, float* workspace, float* dw,
+                             hipStream_t st) {
     HN_CHECK_ARG(x0 && dz && workspace && dw && M > 0 && (KP & 31) == 0 && (ldz & 7) == 0 && ldz >= ((Nout + 7) & ~7));
     HN_CHECK_ARG((C0 & 7) == 0 && (C1 & 7) == 0 && (ld0 & 7) == 0 && ((mode >= 0 && mode <= 2) || ((mode == 4 || mode == 5) && up == 0 && C1 == 0)));
     HN_CHECK_ARG(mode != 5 || (KP == 64 && Nout == C0 && taps == 9));
     const int grouped = mode == 5;
     HN_CHECK_ARG(mode == 0 || (long)n_img * H * W == M);
     int splits; long rps, wsb;
-    hn_wgrad_plan(mode, n_img, H, W, M, Nout, KP, taps, &splits, &rps, &wsb);
+    wgrad_plan_impl(mode, n_img, H, W, M, Nout, KP, taps, phase_span, &splits, &rps, &wsb);
     GemmTN p;
     p.x = make_xsrc(x0, x1, mode, n_img, H, W, C0, C1, ld0, ld1, up, M);
     mode = p.x.mode;
     p.dz = (const bf16*)dz; p.ldz = ldz; p.Nout = Nout; p.KP = KP; p.taps = taps;
-    p.part = workspace; p.rows_per_split = rps;
+    p.part = workspace; p.rows_per_split = rps; p.phase_span = phase_span;
     int bc, bn, rc;
     if (use_patch_wgrad(mode, Nout, KP)) {
         static std::atomic<unsigned long long> optin{0};
@@ -1475,6 +1564,7 @@ extern "C" int hn_conv_gemm_tn(const void* x0, const void* x1, int mode, int n_i
         int pbc, pci, ksplit;
         patch_tiles(Nout, pbc, pci, ksplit);
         if (grouped) { pbc = 64; pci = 64; ksplit = 2; }
+        if (phase_span && phase_span < pbc) { pbc = 64; pci = 128; ksplit = 1; }
         p.gy = cdiv(Nout, pbc);
         const int patches = n_img * cdiv(H, 8) * cdiv(W, 16);
         dim3 grid((unsigned)(cdiv(KP, pci) * p.gy * (splits / ksplit)));

@@ -866,6 +866,23 @@ __global__ void space_to_depth_kernel(const float* dy, bf16* out, int ldo, int N
     }
 }
 
+// bf16 [N][2h][2w][k] (row stride ldi) -> bf16 [N][h][w][4k]: channel (py*2+px)*k + o of low-res pixel (y, x) = in(2y+py, 2x+px, o); 16-byte pieces
+__global__ void space_to_depth_bf16_kernel(const bf16* in, int ldi, bf16* out, int N, int h, int w, int k) {
+    const int k8 = k >> 3;
+    const long total = (long)N * h * w * 4 * k8;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c8 = (int)(idx % (4 * k8));
+        long t = idx / (4 * k8);
+        const int x = (int)(t % w);
+        t /= w;
+        const int y = (int)(t % h);
+        const long n = t / h;
+        const int ph = c8 / k8, o = (c8 - ph * k8) * 8;
+        const bf16x8 v = ld8(in + ((n * 2 * h + 2 * y + (ph >> 1)) * (long)(2 * w) + 2 * x + (ph & 1)) * ldi + o);
+        st8(out + idx * 8, v);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // head-gradient gather: fp32 gradient of a head output laid out [N][rows_total][Nout] (per-image stride img_stride, row stride
 // lds) -> zero-padded bf16 dz [M = N*rpi][ldz]; optional sigmoid' from the saved fp32 output.
@@ -1131,6 +1148,13 @@ extern "C" int hn_depth_to_space(const float* in, int ldi, float* out, int N, in
 extern "C" int hn_space_to_depth(const float* dy, void* out, int ldo, int N, int h, int w, int k, hipStream_t st) {
     HN_CHECK_ARG(dy && out && N > 0 && h > 0 && w > 0 && k > 0 && ldo >= 4 * k && (ldo & 7) == 0);
     hipLaunchKernelGGL(space_to_depth_kernel, dim3(ew_grid((long)N * h * w * ldo)), dim3(256), 0, st, dy, (bf16*)out, ldo, N, h, w, k);
+    HN_LAUNCH_CHECK();
+}
+
+extern "C" int hn_space_to_depth_bf16(const void* in, int ldi, void* out, int N, int h, int w, int k, hipStream_t st) {
+    HN_CHECK_ARG(in && out && N > 0 && h > 0 && w > 0 && k > 0 && (k & 7) == 0 && (ldi & 7) == 0);
+    hipLaunchKernelGGL(space_to_depth_bf16_kernel, dim3(ew_grid((long)N * h * w * 4 * (k >> 3))), dim3(256), 0, st, (const bf16*)in, ldi,
+                       (bf16*)out, N, h, w, k);
     HN_LAUNCH_CHECK();
 }
 

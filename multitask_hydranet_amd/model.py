@@ -447,8 +447,11 @@ class HydraNet(nn.Module):
             x = K.SegConv.apply(x, None, P[f"{p}{2 * i}.conv.conv.weight"], P[f"{p}{2 * i}.conv.conv.bias"], 0, ACT_ELU, False,
                                 fuse and i > 0, fuse)
             skip = feats_seg[n - 2 - i] if i < n - 1 else None
-            x = K.SegConv.apply(x, skip, P[f"{p}{2 * i + 1}.conv.conv.weight"], P[f"{p}{2 * i + 1}.conv.conv.bias"], 1, ACT_ELU, False,
-                                fuse, fuse)
+            wgt = P[f"{p}{2 * i + 1}.conv.conv.weight"]
+            if K.seg_up_phase_ok(x, skip, wgt):        # conv over the up-sampled map in phase form on the low-resolution grid
+                x = K.SegConvUp.apply(x, skip, wgt, P[f"{p}{2 * i + 1}.conv.conv.bias"], fuse, fuse)
+            else:
+                x = K.SegConv.apply(x, skip, wgt, P[f"{p}{2 * i + 1}.conv.conv.bias"], 1, ACT_ELU, False, fuse, fuse)
         last = 2 * n
         if self.seg_phase_output:          # final 3x3 over the up-sampled map as a 4-phase conv on the low-resolution grid (ops.SegOutUp)
             y = K.SegOutUp.apply(x, P[f"{p}{last}.conv.weight"], P[f"{p}{last}.conv.bias"], fuse)

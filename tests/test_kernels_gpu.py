@@ -294,6 +294,42 @@ def test_seg_conv(K, c0, c1, cout, up, act, f32, n, h, w):
     close(bk.grad, br.grad, GRAD_TOL, "dbias")
 
 
+@pytest.mark.parametrize("c0,c1,cout,n,h,w", [
+    (64, 0, 64, 2, 16, 24),          # decoder.7 shape class: no skip, one 64-cout tile per phase
+    (128, 24, 128, 1, 24, 16),       # decoder.5: skip operand joins as a pre-activation addend
+    (256, 112, 256, 1, 16, 32),      # decoder.3 (the dominant launch): 128-cout tiles, four K chunks per phase in the data gradient
+    (64, 16, 64, 3, 10, 6),          # ragged tiles (output 10x6 low-res cells)
+])
+def test_seg_conv_up_phase_form(K, c0, c1, cout, n, h, w):
+    """ops.SegConvUp (phase form on the low-resolution grid, 4 of 9 taps per phase) == ELU(Conv3x3(reflect_pad(cat[up2(x0), x1])) + b):
+    forward, both data gradients, weight / bias gradients.  h, w = LOW resolution of x0; the output is 2h x 2w."""
+    x0 = rnd(n, c0, h, w)
+    x1 = rnd(n, c1, 2 * h, 2 * w) if c1 else None
+    wt = rnd(cout, c0 + c1, 3, 3, scale=(9 * (c0 + c1)) ** -0.5)
+    bs = rnd(cout, scale=0.1)
+    upg = rnd(n, cout, 2 * h, 2 * w)
+    x0k = nhwc(x0).requires_grad_(True)
+    x1k = nhwc(x1).requires_grad_(True) if c1 else None
+    wk, bk = wt.clone().requires_grad_(True), bs.clone().requires_grad_(True)
+    assert K.seg_up_phase_ok(x0k, x1k, wk)
+    out = K.SegConvUp.apply(x0k, x1k, wk, bk, False, False)
+    out.backward(nhwc(upg))
+    x0r = x0.clone().requires_grad_(True)
+    x1r = x1.clone().requires_grad_(True) if c1 else None
+    wr, br = wt.clone().requires_grad_(True), bs.clone().requires_grad_(True)
+    v = F.interpolate(x0r, scale_factor=2, mode="nearest")
+    if c1:
+        v = torch.cat([v, x1r], 1)
+    y = F.elu(F.conv2d(F.pad(v, [1, 1, 1, 1], mode="reflect"), wr, br))
+    y.backward(upg)
+    close(nchw(out), y, ACT_TOL, "out")
+    close(nchw(x0k.grad), x0r.grad, GRAD_TOL, "dx0")
+    if c1:
+        close(nchw(x1k.grad), x1r.grad, GRAD_TOL, "dx1")
+    close(wk.grad, wr.grad, GRAD_TOL, "dw")
+    close(bk.grad, br.grad, GRAD_TOL, "dbias")
+
+
 @pytest.mark.parametrize("c,k,n,h,w", [(64, 5, 2, 8, 12), (64, 5, 1, 20, 36), (16, 3, 2, 4, 4)])
 def test_seg_out_phase_form(K, c, k, n, h, w):
     """ops.SegOutUp (4-phase conv with replicate padding on the low-resolution grid) == Conv3x3(reflect_pad(nearest_up2(x))); h, w = INPUT size."""
