@@ -533,17 +533,21 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
 //   mode 3: out(y,x) = sum_tap Z0(y-ky, x-kx) W[tap], Z0 zero outside       (their dgrad on the padded (H+2)x(W+2) grid)
 // 512 threads = 8 waves: WGC = BC/64 cout groups x (8/WGC) pixel-row groups; wave tile = 64 couts x (16/WGP rows x 16 px).
 // ---------------------------------------------------------------------------------------------------------
-template <int BC, bool OUT_F32>
-__global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) {
-    // BC < 128: ONE patch buffer (57 KB of LDS instead of 98 KB) and <= 128 VGPRs -> two workgroups per CU cover each other's load /
-    // wait / MFMA phases; the patch of the next 64-channel chunk is then loaded after the last tap of the current one (one exposed
-    // round trip per chunk, and most of these launches have a single chunk).  BC = 128 keeps the double-buffered patch.
-    constexpr int XBUFS = 1;
+// PIPE = false: one patch buffer + two weight buffers (73 KB LDS, 128 VGPRs): two workgroups per CU cover each other's DMA waits; every
+//   tap step still exposes most of the weight-tile DMA latency (measured 2.2 us per tap step against 0.43 us of MFMA time).
+// PIPE = true: ONE workgroup per CU with a software pipeline inside it: two patch buffers (the next chunk's patch lands during the
+//   current chunk's taps) and a ring of three weight tiles with counted s_waitcnt vmcnt (the tile of tap step i+2 is issued before the
+//   MFMAs of step i, so two tile loads are always in flight); up to 256 VGPRs (no scratch spills).
+template <int BC, bool OUT_F32, bool PIPE>
+__global__ __launch_bounds__(512, PIPE ? 2 : 4) void conv3x3_direct_kernel(const GemmNT p) {
+    constexpr int XBUFS = PIPE ? 2 : 1, WBUFS = PIPE ? 3 : 2;
     constexpr int WCO = BC >= 64 ? 64 : BC;                           // couts per wave
     constexpr int WGC = BC / WCO, WGP = 8 / WGC, ROWS = 16 / WGP;     // rows of the patch per wave
     constexpr int TC = WCO / 16, TP = ROWS;
-    constexpr int PPIX = 18 * 18, XBYTES = (PPIX * 128 + 1023) / 1024 * 1024, WBYTES = BC * 128;   // X buffer padded to whole 1 KiB DMA runs
-    constexpr int XL = (PPIX * 8 + 511) / 512, WL = (BC * 8 + 511) / 512;
+    // X buffer padded to whole 1 KiB DMA runs (PIPE: to whole 512-thread rounds, so that every wave issues the same number of loads and
+    // the counted waits hold for all of them)
+    constexpr int PPIX = 18 * 18, XL = (PPIX * 8 + 511) / 512, WL = (BC * 8 + 511) / 512;
+    constexpr int XBYTES = PIPE ? XL * 512 * 16 : (PPIX * 128 + 1023) / 1024 * 1024, WBYTES = BC * 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];       // X patch x2 | W tile x2
     char* sXb = smem;
     char* sWb = smem + XBUFS * XBYTES;
@@ -619,7 +623,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
         const int chunk = st / NT, tap = tap_of(chunk, st - chunk * NT);
         const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
         const int dy = xs.mode == 2 ? ky : 2 - ky, dx = xs.mode == 2 ? kx : 2 - kx;
-        const char* sW = sWb + (st & 1) * WBYTES;
+        const char* sW = sWb + (st % WBUFS) * WBYTES;
         const char* sX = sXb + (XBUFS == 2 ? (chunk & 1) : 0) * XBYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -639,6 +643,54 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     };
+    auto issue_w = [&](int st) {
+        const int chunk = st / NT, tap = tap_of(chunk, st - chunk * NT);
+        const int k0 = chunk * 64;
+        char* sW = sWb + (st % WBUFS) * WBYTES;
+#pragma unroll
+        for (int i = 0; i < WL; ++i) {
+            if (wave * 8 + 64 * i < BC) {                              // wave-uniform (all waves for BC >= 64)
+                const bf16* src = (wrow[i] >= 0 && k0 + wsub < p.KP) ? p.w + wrow[i] + tap * p.KP + k0 : g_zero_piece;
+                glds16(src, sW + (wave * 8 + 64 * i) * 128);
+            }
+        }
+    };
+    auto issue_x = [&](int chunk) {
+        const int k0 = chunk * 64;
+        char* sX = sXb + (XBUFS == 2 ? (chunk & 1) : 0) * XBYTES;
+#pragma unroll
+        for (int i = 0; i < XL; ++i) {
+            if (PIPE || 512 * i + 64 * wave < PPIX * 8) {              // PIPE: every wave issues all XL rounds (padded buffer)
+                const int c = xc0 + k0 + ssub[i];
+                const bf16* src = g_zero_piece;
+                if (c < Ctot) {
+                    if (c < xs.C0) { if (spix0[i] >= 0) src = xs.x0 + c + (long)spix0[i] * xs.ld0; }
+                    else if (spix1[i] >= 0) src = xs.x1 + (c - xs.C0) + (long)spix1[i] * xs.ld1;
+                }
+                glds16(src, sX + (512 * i + 64 * wave) * 16);
+            }
+        }
+    };
+    if (PIPE) {
+        static_assert(!PIPE || BC >= 64, "the counted waits need every wave to issue the same number of weight loads");
+        issue_x(0);
+        issue_w(0);
+        if (S > 1) issue_w(1);
+        bool x_prev = false;                                           // did the previous iteration issue a patch (before its weight tile)?
+        for (int i = 0; i < S; ++i) {
+            // everything up to and including the weight tile of step i has landed; what the previous iteration issued may stay in flight
+            const bool w_next = i + 1 < S;
+            if (w_next && x_prev) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(WL + XL) : "memory");
+            else if (w_next) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(WL) : "memory");
+            else if (x_prev) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(XL) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            const int chunk = i / NT, ti = i - chunk * NT;
+            x_prev = ti == 0 && chunk + 1 < nchunk;
+            if (x_prev) issue_x(chunk + 1);                            // its buffer was last read by the previous chunk's last tap
+            if (i + 2 < S) issue_w(i + 2);                             // its ring slot was last read by step i - 1
+            compute(i);
+        }
+    } else
     for (int it = 0; it <= S; ++it) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -1283,6 +1335,10 @@ static int launch_nt_r(const GemmNT& p, int out_f32, hipStream_t st) {
     HN_LAUNCH_CHECK();
 }
 
+// direct 3x3 kernel: software-pipelined variant on/off (tools/ A/B hook; default on)
+static int g_direct_pipe = 1;
+extern "C" int hn_debug_direct_pipe(int on) { g_direct_pipe = on; return 0; }
+
 // operand-transform variant (bf16 output, double buffer)
 template <int BC, int BP, int WGC, int WGP>
 static int launch_nt_xf(const GemmNT& p, hipStream_t st) {
@@ -1414,17 +1470,26 @@ static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img
         int bc = p.x.diag ? 64 : (Nout <= 16 ? 16 : (Nout <= 64 ? 64 : 128));
         if (phase_mode == 1 && phase_span < bc) bc = 64;            // a cout tile must lie inside one phase
         dim3 grid((unsigned)(cdiv(Nout, bc) * cdiv(W, 16) * cdiv(H, 16) * n_img));
-        const size_t lds = (size_t)((18 * 18 * 128 + 1023) / 1024 * 1024) + 2 * (size_t)bc * 128;
+        // software-pipelined variant (one workgroup per CU, 3 weight tiles + 2 patch buffers): the bf16 launches with >= 64 couts per tile
+        const bool pipe = g_direct_pipe && bc >= 64 && !out_f32;
+        const size_t lds = pipe ? (size_t)2 * (((18 * 18 * 8 + 511) / 512) * 512 * 16) + 3 * (size_t)bc * 128
+                                : (size_t)((18 * 18 * 128 + 1023) / 1024 * 1024) + 2 * (size_t)bc * 128;
         // > 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel (done on the first, un-captured call)
         static std::atomic<unsigned long long> optin{0};
-        if (!lds_optin(optin, {(const void*)conv3x3_direct_kernel<16, true>, (const void*)conv3x3_direct_kernel<16, false>,
-                               (const void*)conv3x3_direct_kernel<64, true>, (const void*)conv3x3_direct_kernel<64, false>,
-                               (const void*)conv3x3_direct_kernel<128, true>, (const void*)conv3x3_direct_kernel<128, false>}))
+        if (!lds_optin(optin, {(const void*)conv3x3_direct_kernel<16, true, false>, (const void*)conv3x3_direct_kernel<16, false, false>,
+                               (const void*)conv3x3_direct_kernel<64, true, false>, (const void*)conv3x3_direct_kernel<64, false, false>,
+                               (const void*)conv3x3_direct_kernel<128, true, false>, (const void*)conv3x3_direct_kernel<128, false, false>,
+                               (const void*)conv3x3_direct_kernel<64, false, true>, (const void*)conv3x3_direct_kernel<128, false, true>}))
             return HN_ERR_LAUNCH;
+        if (pipe) {
+            if (bc == 64) hipLaunchKernelGGL((conv3x3_direct_kernel<64, false, true>), grid, dim3(512), lds, st, p);
+            else hipLaunchKernelGGL((conv3x3_direct_kernel<128, false, true>), grid, dim3(512), lds, st, p);
+            HN_LAUNCH_CHECK();
+        }
 #define DIRECT_CASE(BC_) \
         if (bc == BC_) { \
-            if (out_f32) hipLaunchKernelGGL((conv3x3_direct_kernel<BC_, true>), grid, dim3(512), lds, st, p); \
-            else hipLaunchKernelGGL((conv3x3_direct_kernel<BC_, false>), grid, dim3(512), lds, st, p); \
+            if (out_f32) hipLaunchKernelGGL((conv3x3_direct_kernel<BC_, true, false>), grid, dim3(512), lds, st, p); \
+            else hipLaunchKernelGGL((conv3x3_direct_kernel<BC_, false, false>), grid, dim3(512), lds, st, p); \
         }
         DIRECT_CASE(16) DIRECT_CASE(64) DIRECT_CASE(128)
 #undef DIRECT_CASE
