@@ -68,8 +68,8 @@ int hn_conv_gemm_nt_ex(const void* x0, const void* x1, int mode, int n_img, int 
                        int xact, const void* addend, int ld_add, hipStream_t stream);
 /* tuning hook for tools/: force the cout tile (16/32/64/128) and LDS ring depth (2..4) of later hn_conv_gemm_nt launches; 0 = automatic */
 int hn_debug_nt_config(int bc, int r);
-/* tools/ A/B hook: 1 (default) = software-pipelined direct 3x3 kernel (one workgroup per CU, weight ring of 3 + 2 patch buffers), 0 = the
- * two-workgroups-per-CU double-buffer form */
+/* tools/ A/B hook: 1 = software-pipelined direct 3x3 kernel (one workgroup per CU, weight ring of 3 + 2 patch buffers), 0 (default, faster
+ * on every measured shape) = the two-workgroups-per-CU double-buffer form */
 int hn_debug_direct_pipe(int on);
 int hn_debug_tn_config(int bc, int bn, int splits);
 

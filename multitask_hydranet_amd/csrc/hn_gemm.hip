@@ -1335,8 +1335,10 @@ static int launch_nt_r(const GemmNT& p, int out_f32, hipStream_t st) {
     HN_LAUNCH_CHECK();
 }
 
-// direct 3x3 kernel: software-pipelined variant on/off (tools/ A/B hook; default on)
-static int g_direct_pipe = 1;
+// direct 3x3 kernel: software-pipelined variant on/off (tools/ A/B hook).  Default OFF: measured on MI355X (tools/bench_seg.py) the
+// one-workgroup-per-CU ring-of-3 pipeline is 10-60 % SLOWER than two co-resident double-buffer workgroups on every seg-decoder shape
+// (decoder.3 forward 306 vs 231 us): the second resident workgroup hides more latency than the deeper prefetch does.
+static int g_direct_pipe = 0;
 extern "C" int hn_debug_direct_pipe(int on) { g_direct_pipe = on; return 0; }
 
 // operand-transform variant (bf16 output, double buffer)

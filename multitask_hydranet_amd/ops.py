@@ -1399,16 +1399,28 @@ class SegConvUp(torch.autograd.Function):
         w_eff = (w0 @ T.t()).view(k, c0, 2, 2, 3, 3).permute(2, 3, 0, 1, 4, 5).reshape(4 * k, c0, 3, 3).contiguous()
         wp_eff, wt_eff = pack_conv_weight(w_eff)
         b_eff = bias.repeat(4)
-        z1 = wt1 = None
-        if c1:
+        z1 = wt1 = wt_full = None
+        # Per-layer choice of form (measured, tools/bench_seg.py): the forward runs full-resolution when the skip operand is so narrow that its
+        # own conv would be mostly K padding (decoder.5: 24 channels); the data gradient w.r.t. x0 runs full-resolution when the padded
+        # low-resolution grid cannot fill the chip (decoder.1: 18x34 cells -> 384 workgroups); the weight gradient is always in phase form.
+        fwd_phase = (c1 == 0 or c1 >= 32) if SEG_FWD_PHASE is None else SEG_FWD_PHASE
+        tiles = n * ((h + 2 + 15) // 16) * ((w + 2 + 15) // 16) * ((c0 + 127) // 128)
+        ctx.dgrad_phase = (tiles >= 448) if SEG_DGRAD_PHASE is None else SEG_DGRAD_PHASE
+        if c1 and (fwd_phase or ctx.dgrad_phase):
             w1 = weight[:, c0:].contiguous()
             wp1, wt1 = pack_conv_weight(w1)
-            z1, _, _ = k_gemm_nt(x1, None, 2, (n, 2 * h, 2 * w), wp1, k, kp32(c1), 9)          # skip operand: plain reflect-pad 3x3, no bias / act
-        y = new_act(n, 2 * h, 2 * w, k, dev)
-        lib().call("hn_conv3x3_phase", ptr(x0), 4, n, h, w, c0, ld(x0), ptr(wp_eff), 4 * k, kp32(c0), ptr(b_eff), ACT_ELU, ptr(y), ld(y), k,
-                   ptr(z1), ld(z1) if z1 is not None else 0)
+        if not fwd_phase or not ctx.dgrad_phase:
+            wp_full, wt_full = pack_conv_weight(weight)
+        if fwd_phase:
+            if c1:
+                z1, _, _ = k_gemm_nt(x1, None, 2, (n, 2 * h, 2 * w), wp1, k, kp32(c1), 9)      # skip operand: plain reflect-pad 3x3, no bias / act
+            y = new_act(n, 2 * h, 2 * w, k, dev)
+            lib().call("hn_conv3x3_phase", ptr(x0), 4, n, h, w, c0, ld(x0), ptr(wp_eff), 4 * k, kp32(c0), ptr(b_eff), ACT_ELU, ptr(y), ld(y), k,
+                       ptr(z1), ld(z1) if z1 is not None else 0)
+        else:
+            y, _, _ = k_gemm_nt(x0, x1, 2, (n, 2 * h, 2 * w), wp_full, k, kp32(cin), 9, bias=bias, act=ACT_ELU, up=1)
         ctx.x0_is_elu, ctx.dy_is_dz = x0_is_elu, dy_is_dz
-        ctx.packs = (wt_eff, wt1)
+        ctx.packs = (wt_eff, wt1, wt_full)
         ctx.save_for_backward(x0, x1, y if not dy_is_dz else None)
         ctx.dims = (k, c0, c1)
         return y
@@ -1416,7 +1428,7 @@ class SegConvUp(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x0, x1, y = ctx.saved_tensors
-        wt_eff, wt1 = ctx.packs
+        wt_eff, wt1, wt_full = ctx.packs
         k, c0, c1 = ctx.dims
         n, h, w, _ = x0.shape
         dev = x0.device
@@ -1436,7 +1448,17 @@ class SegConvUp(torch.autograd.Function):
         T = _phase_matrix(dev)
         dw0 = (dw_eff.view(2, 2, k, c0, 3, 3).permute(2, 3, 0, 1, 4, 5).reshape(k * c0, 36) @ T).view(k, c0, 3, 3)
         dx0 = dx1 = None
-        if ctx.needs_input_grad[0]:
+        if not ctx.dgrad_phase:
+            # full-resolution data gradient for both operands at once (padded (2h+2) x (2w+2) grid), folded back per operand
+            dvp, _, _ = k_gemm_nt(dz, None, 3, (n, 2 * h + 2, 2 * w + 2), wt_full, c0 + c1, kp32(k), 9, c0=k, c1=0)
+            if ctx.needs_input_grad[0]:
+                dx0 = new_act(n, h, w, c0, dev)
+                yp = x0 if ctx.x0_is_elu else None
+                lib().call("hn_seg_fold", ptr(dvp), ld(dvp), 0, ptr(dx0), ld(dx0), ptr(yp), ld(yp) if yp is not None else 0, n, 2 * h, 2 * w, c0, 1)
+            if c1 and ctx.needs_input_grad[1]:
+                dx1 = new_act(n, 2 * h, 2 * w, c1, dev)
+                lib().call("hn_seg_fold", ptr(dvp), ld(dvp), c0, ptr(dx1), ld(dx1), None, 0, n, 2 * h, 2 * w, c1, 0)
+        elif ctx.needs_input_grad[0]:
             dvp = new_act(n, h + 2, w + 2, c0, dev)
             lib().call("hn_conv3x3_phase", ptr(dzs), 3, n, h + 2, w + 2, 4 * k, ld(dzs), ptr(wt_eff), c0, kp32(4 * k), None, ACT_NONE, ptr(dvp),
                        ld(dvp), k, None, 0)
@@ -1447,7 +1469,7 @@ class SegConvUp(torch.autograd.Function):
         if c1:
             dw1 = k_gemm_tn(x1, None, 2, (n, 2 * h, 2 * w), dz, k, kp32(c1), 9, c1, kh=3)
             dw = torch.cat([dw0, dw1], 1)
-            if ctx.needs_input_grad[1]:
+            if ctx.dgrad_phase and ctx.needs_input_grad[1]:
                 dvp1, _, _ = k_gemm_nt(dz, None, 3, (n, 2 * h + 2, 2 * w + 2), wt1, c1, kp32(k), 9, c0=k, c1=0)
                 dx1 = new_act(n, 2 * h, 2 * w, c1, dev)
                 lib().call("hn_seg_fold", ptr(dvp1), ld(dvp1), 0, ptr(dx1), ld(dx1), None, 0, n, 2 * h, 2 * w, c1, 0)
@@ -1455,6 +1477,8 @@ class SegConvUp(torch.autograd.Function):
 
 
 SEG_PHASE_UP = os.environ.get("HN_SEG_PHASE_UP", "1") != "0"
+SEG_FWD_PHASE = None        # None: per-layer heuristic; True / False force the forward form (tests)
+SEG_DGRAD_PHASE = None      # the same for the data gradient w.r.t. the up-sampled operand
 
 
 def seg_up_phase_ok(x0, x1, weight):

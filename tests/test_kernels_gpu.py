@@ -300,7 +300,8 @@ def test_seg_conv(K, c0, c1, cout, up, act, f32, n, h, w):
     (256, 112, 256, 1, 16, 32),      # decoder.3 (the dominant launch): 128-cout tiles, four K chunks per phase in the data gradient
     (64, 16, 64, 3, 10, 6),          # ragged tiles (output 10x6 low-res cells)
 ])
-def test_seg_conv_up_phase_form(K, c0, c1, cout, n, h, w):
+@pytest.mark.parametrize("fwd_phase,dgrad_phase", [(True, True), (False, True), (True, False), (None, None)])
+def test_seg_conv_up_phase_form(K, c0, c1, cout, n, h, w, fwd_phase, dgrad_phase):
     """ops.SegConvUp (phase form on the low-resolution grid, 4 of 9 taps per phase) == ELU(Conv3x3(reflect_pad(cat[up2(x0), x1])) + b):
     forward, both data gradients, weight / bias gradients.  h, w = LOW resolution of x0; the output is 2h x 2w."""
     x0 = rnd(n, c0, h, w)
@@ -312,8 +313,12 @@ def test_seg_conv_up_phase_form(K, c0, c1, cout, n, h, w):
     x1k = nhwc(x1).requires_grad_(True) if c1 else None
     wk, bk = wt.clone().requires_grad_(True), bs.clone().requires_grad_(True)
     assert K.seg_up_phase_ok(x0k, x1k, wk)
-    out = K.SegConvUp.apply(x0k, x1k, wk, bk, False, False)
-    out.backward(nhwc(upg))
+    K.SEG_FWD_PHASE, K.SEG_DGRAD_PHASE = fwd_phase, dgrad_phase          # every combination of forms is the same function
+    try:
+        out = K.SegConvUp.apply(x0k, x1k, wk, bk, False, False)
+        out.backward(nhwc(upg))
+    finally:
+        K.SEG_FWD_PHASE = K.SEG_DGRAD_PHASE = None
     x0r = x0.clone().requires_grad_(True)
     x1r = x1.clone().requires_grad_(True) if c1 else None
     wr, br = wt.clone().requires_grad_(True), bs.clone().requires_grad_(True)
