@@ -56,22 +56,46 @@ def synthetic_batch(cfgs, n, h, w, seed, device):
 
 
 def dominant_launch_roofline(net, n, h, w, iters=20):
-    """Time the largest seg-decoder launch (3x3 reflect conv over cat[up2(x), skip]: decoder.3 of the big cfg) with HIP events on the
-    stream it is launched on, and price it against the dense bf16 MFMA peak."""
+    """Time the largest seg-decoder launch with HIP events on the stream it is launched on, and price it against the dense bf16 MFMA peak.
+    decoder.3 of the big cfg = Conv3x3(reflect-pad(cat[up2(x 256 ch), P3 112 ch])) -> 256 @ (h/8) x (w/8).  Since round 2 its up-sampled
+    operand runs in PHASE form on the low-resolution grid (hn_conv3x3_phase: 4 of 9 taps per output phase, the skip operand's partial sum
+    arrives as a pre-activation addend): that launch is timed here.  `achieved` prices the ALGORITHMIC flops of the convolution it
+    replaces (2*N*H*W*Cout*C0*9, SURVEY 8(d) conv-MAC figure); `executed_tflops` is what the MFMA pipe actually ran (16/36 of it)."""
     from multitask_hydranet_amd import ops as K
+    from multitask_hydranet_amd._lib import lib
     P = net._idx
     wgt = P["segheader.decoder.3.conv.conv.weight"]
     cout, cin = wgt.shape[0], wgt.shape[1]
     c1 = net.fpn_num_filters
     c0 = cin - c1
-    hh, ww = h // 8, w // 8                                         # P3 resolution (stride 8)
+    hh, ww = h // 8, w // 8                                         # P3 resolution (stride 8) = output resolution
     dev = wgt.device
     x0 = torch.randn(n, hh // 2, ww // 2, c0, device=dev).to(torch.bfloat16)
     x1 = torch.randn(n, hh, ww, c1, device=dev).to(torch.bfloat16)
-    wp, _ = K.pack_conv_weight(wgt)
     bias = P["segheader.decoder.3.conv.conv.bias"]
     out = torch.empty(n, hh, ww, cout, device=dev, dtype=torch.bfloat16)
-    run = lambda: K.k_gemm_nt(x0, x1, 2, (n, hh, ww), wp, cout, K.kp32(cin), 9, bias=bias, act=K.ACT_ELU, out=out, up=1)
+    phase = K.seg_up_phase_ok(x0, x1, wgt)
+    if phase:
+        with torch.no_grad():
+            T = K._phase_matrix(dev)
+            w_eff = (wgt[:, :c0].reshape(cout * c0, 9) @ T.t()).view(cout, c0, 2, 2, 3, 3).permute(2, 3, 0, 1, 4, 5).reshape(4 * cout, c0, 3, 3).contiguous()
+            wpe, _ = K.pack_conv_weight(w_eff)
+            be = bias.detach().repeat(4)
+            wp1, _ = K.pack_conv_weight(wgt[:, c0:].detach().contiguous())
+            z1, _, _ = K.k_gemm_nt(x1, None, 2, (n, hh, ww), wp1, cout, K.kp32(c1), 9)
+        run = lambda: lib().call("hn_conv3x3_phase", x0.data_ptr(), 4, n, hh // 2, ww // 2, c0, c0, wpe.data_ptr(), 4 * cout, K.kp32(c0),
+                                 be.data_ptr(), K.ACT_ELU, out.data_ptr(), cout, cout, z1.data_ptr(), cout)
+        flops = 2.0 * n * hh * ww * cout * c0 * 9
+        executed = flops * 16.0 / 36.0
+        alg_bytes = 2.0 * (n * (hh // 2) * (ww // 2) * c0 + 2 * n * hh * ww * cout + 4 * cout * c0 * 9)
+        kname = "conv3x3_direct_kernel<128,false,false> phase form: seg decoder.3 up-sampled operand (256 ch @ %dx%d -> 4 phases x 256 @ %dx%d, " \
+                "+ skip addend, ELU), N=%d, fwd" % (hh // 2, ww // 2, hh, ww, n)
+    else:
+        wp, _ = K.pack_conv_weight(wgt)
+        run = lambda: K.k_gemm_nt(x0, x1, 2, (n, hh, ww), wp, cout, K.kp32(cin), 9, bias=bias, act=K.ACT_ELU, out=out, up=1)
+        flops = executed = 2.0 * n * hh * ww * cout * cin * 9
+        alg_bytes = 2.0 * (n * (hh // 2) * (ww // 2) * c0 + n * hh * ww * c1 + n * hh * ww * cout + cout * cin * 9)
+        kname = "conv3x3_direct_kernel<128,false,false> seg decoder.3 (reflect-pad 3x3 over cat[up2(x), skip], 368->256 @ %dx%d, N=%d) fwd" % (hh, ww, n)
     for _ in range(3):
         run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -82,20 +106,18 @@ def dominant_launch_roofline(net, n, h, w, iters=20):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
-    flops = 2.0 * n * hh * ww * cout * cin * 9
     ach = flops / (ms * 1e-3) / 1e12
-    alg_bytes = 2.0 * (n * (hh // 2) * (ww // 2) * c0 + n * hh * ww * c1 + n * hh * ww * cout + cout * cin * 9)
     return {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-            "traffic": measured_traffic(alg_bytes),
-            "kernel": "conv3x3_direct_kernel<128,false> seg decoder.3 (reflect-pad 3x3 over cat[up2(x), skip], 368->256 @ %dx%d, N=%d) fwd" % (hh, ww, n),
-            "launch_ms": round(ms, 4), "flop_per_launch": flops, "algorithmic_bytes_per_launch": alg_bytes}
+            "traffic": measured_traffic(alg_bytes), "kernel": kname, "launch_ms": round(ms, 4), "flop_per_launch": flops,
+            "executed_flop_per_launch": executed, "executed_tflops": round(executed / (ms * 1e-3) / 1e12, 2),
+            "frac_executed": round(executed / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), "algorithmic_bytes_per_launch": alg_bytes}
 
 
 def measured_traffic(alg_bytes):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r01_dominant_pmc.json: FETCH_SIZE
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r02_dominant_pmc.json: FETCH_SIZE
     doubled per the gfx950 correction + WRITE_SIZE, separate passes); None if the file is absent.  PMC counters cannot be read from
     inside this process, so the figure is the one measured with `rocprofv3 --pmc` on `bench.py --dominant-only`."""
-    path = os.path.join(ROOT, "profiles", "r01_dominant_pmc.json")
+    path = os.path.join(ROOT, "profiles", "r02_dominant_pmc.json")
     try:
         with open(path) as f:
             return json.load(f)["hbm_bytes_per_launch"]
