@@ -571,6 +571,8 @@ class HydraNet(nn.Module):
         """HydraNet.forward, model/model.py:159-198."""
         K.clear_pack_cache()
         params = {id(t) for t in self.parameters()}
+        if self._pack_plan is not None and not self._pack_plan.valid():
+            self._pack_plan = None                 # a parameter's storage was replaced: re-record the weights on this forward
         if self._pack_plan is not None and x.is_cuda:
             self._pack_plan.run()                  # every dense conv weight -> bf16 operands, one launch
         elif x.is_cuda:

@@ -134,7 +134,13 @@ class PackPlan:
             rows_.append([w.data_ptr(), wp.data_ptr(), wt.data_ptr(), cout, cin, taps, blk, 0])
             blk += (wp.numel() + wt.numel() + 255) // 256
         self.blocks = blk
+        self.ptrs = [w.data_ptr() for w in self.weights]
         self.table = torch.tensor(rows_, dtype=torch.int64).to(dev)
+
+    def valid(self):
+        """the device job table holds raw weight pointers: a parameter whose storage was swapped (`p.data = ...`, vector_to_parameters, a
+        device move) invalidates the plan (HydraNet.forward rebuilds it)"""
+        return all(w.data_ptr() == p_ and w.device == self.table.device for w, p_ in zip(self.weights, self.ptrs))
 
     def run(self):
         lib().call("hn_pack_weights_batched", ptr(self.table), len(self.weights), self.blocks)
