@@ -307,6 +307,8 @@ def main():
     net.check_finite = False                       # the reference's exit()-on-NaN guard is a host sync; checked once after the run instead
     net.lane_points_per_line = h // cfgs["lane"]["interval"]     # the reference default (160) raises IndexError at H=512
     broadcast_state(net)
+    if os.environ.get("HN_HEADS_SIDE") == "1":       # experiment hook: det + lane heads on a side stream (a hipGraph branch) next to the seg decoder
+        net.heads_on_side_stream = True
     if args.dominant_only:
         print(json.dumps(dominant_launch_roofline(net, args.batch, h, w, iters=args.steps)))
         return
