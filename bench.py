@@ -77,11 +77,8 @@ def dominant_launch_roofline(net, n, h, w, iters=20):
     phase = K.seg_up_phase_ok(x0, x1, wgt)
     if phase:
         with torch.no_grad():
-            T = K._phase_matrix(dev)
-            w_eff = (wgt[:, :c0].reshape(cout * c0, 9) @ T.t()).view(cout, c0, 2, 2, 3, 3).permute(2, 3, 0, 1, 4, 5).reshape(4 * cout, c0, 3, 3).contiguous()
-            wpe, _ = K.pack_conv_weight(w_eff)
-            be = bias.detach().repeat(4)
-            wp1, _ = K.pack_conv_weight(wgt[:, c0:].detach().contiguous())
+            wpe, _, be = K.pack_phase_weight(wgt, c0, bias)
+            wp1, _ = K.pack_conv_weight_slice(wgt, c0, c1)
             z1, _, _ = K.k_gemm_nt(x1, None, 2, (n, hh, ww), wp1, cout, K.kp32(c1), 9)
         run = lambda: lib().call("hn_conv3x3_phase", x0.data_ptr(), 4, n, hh // 2, ww // 2, c0, c0, wpe.data_ptr(), 4 * cout, K.kp32(c0),
                                  be.data_ptr(), K.ACT_ELU, out.data_ptr(), cout, cout, z1.data_ptr(), cout)

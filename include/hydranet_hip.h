@@ -28,6 +28,15 @@ typedef struct ihipStream_t* hipStream_t;
  * wt[Cin][taps][KP(Cout)], KP(x) = x rounded up to 32, zero filled.  Replaces the implicit weight cast of autocast convs. */
 int hn_gconv_pack_diag(const float* w, void* wk, void* wd, int C, hipStream_t stream);
 int hn_pack_weight(const float* w, void* wp, void* wt, int Cout, int Cin, int taps, hipStream_t stream);
+/* hn_pack_weight for a channel slice [ci0, ci0+Cin) of w [Cout][Cin_total][taps] (phase = 0), or (phase = 1, taps = 9) the PHASE-FORM
+ * effective weights of that slice: a 3x3 conv over a nearest-x2 up-sampled map (head_seg/segmentation.py:92-104: Upsample -> ReflectionPad2d
+ * -> Conv2d) evaluated on the low-resolution grid has 4*Cout outputs (one Cout-vector per output phase), each tap of which is the sum of
+ * the original taps that land on it: wp [4*Cout][9][KP(Cin)], wt [Cin][9][KP(4*Cout)], b_eff [4*Cout] (optional) = bias per phase. */
+int hn_pack_weight_ex(const float* w, void* wp, void* wt, int Cout, int Cin_total, int ci0, int Cin, int taps, int phase, const float* bias,
+                      float* b_eff, hipStream_t stream);
+/* the transpose: dw [K][C0+C1][3][3] (db [K], optional) from the effective-weight gradient dw_eff [4K][C0][3][3] (db_eff [4K]); channels
+ * [C0, C0+C1) are copied from the skip operand's own gradient dw1 [K][C1][3][3] */
+int hn_phase_fold(const float* dw_eff, const float* dw1, const float* db_eff, float* dw, float* db, int K, int C0, int C1, hipStream_t stream);
 /* every conv weight of a model in one launch: jobs = DEVICE table njobs x 8 int64 {w, wp, wt, Cout, Cin, taps, first_block, 0}, job j owns
  * ceil((Cout*taps*KP(Cin) + Cin*taps*KP(Cout)) / 256) consecutive blocks starting at first_block */
 int hn_pack_weights_batched(const long* jobs, int njobs, long total_blocks, hipStream_t stream);
@@ -211,7 +220,7 @@ int hn_bn_act_levels(const void* z, int ldz, const float* coef, int act, void* o
 int hn_bn_bwd_reduce_levels(const void* dout, int ldd, const void* z, int ldz, const void* y, int ldy, const float* coef, int act, int C,
                             long R, int nlev, const long* rows, float* pg, float* pgx, hipStream_t stream);
 int hn_bn_bwd_finalize_levels(const float* pg, const float* pgx, int div, int C, int nlev, const long* rows, const long* count,
-                              void* const* dgamma, void* const* dbeta, float* red, hipStream_t stream);
+                              void* const* dgamma, void* const* dbeta, float* red, float* zero_c, hipStream_t stream);
 int hn_bn_bwd_apply_levels(const void* dout, int ldd, const void* z, int ldz, const void* y, int ldy, const float* coef, const float* red,
                            int act, void* dz, int lddz, int C, int nlev, const long* rows, hipStream_t stream);
 
@@ -234,12 +243,13 @@ int hn_bn_apply_fused(const void* z, int ldz, long M, int C, const float* psum, 
 /* BatchNorm backward.  g = dout * act'(scale*z+shift), or dout * [y > 0] when the saved block output y is given (ReLU after the residual
  * add), or, with gate/dpool (SE, RB divides HW): g = (dout*gate[n][c] + dpool[n][c]/HW) * [scale*z+shift > 0] where dout is the gradient of
  * the gated tensor.  reduce: pg/pgx [ceil(M/RB)][C] partial sums of g and g*xhat.  apply: dz = scale*(g - mean g - xhat*mean(g*xhat)),
- * dgamma/dbeta written by row block 0, gout (optional) = g in bf16 (the residual branch's gradient). */
+ * dgamma/dbeta written by row block 0, gout (optional) = g in bf16 (the residual branch's gradient), zero_c (optional) = C zeros (the
+ * gradient of a conv bias that feeds this BatchNorm: written here instead of by a fill launch). */
 int hn_bn_bwd_reduce_fused(const void* dout, int ldd, const void* z, int ldz, const void* y, int ldy, const float* coef, int act,
                            const float* gate, const float* dpool, long HW, long M, int C, long RB, float* pg, float* pgx, hipStream_t stream);
 int hn_bn_bwd_apply_fused(const void* dout, int ldd, const void* z, int ldz, const void* y, int ldy, const float* coef, int act,
                           const float* gate, const float* dpool, long HW, const float* pg, const float* pgx, int P, long count, float* dgamma,
-                          float* dbeta, void* dz, int lddz, void* gout, int ldg, long M, int C, long RB, hipStream_t stream);
+                          float* dbeta, void* dz, int lddz, void* gout, int ldg, long M, int C, long RB, float* zero_c, hipStream_t stream);
 /* per-row-block channel sums / sums of squares [ceil(M/RB)][C] of a bf16 tensor (statistics of convs without a statistics epilogue) */
 int hn_col_stats_fused(const void* x, int ldx, long M, int C, long RB, float* psum, float* psq, hipStream_t stream);
 /* SE backward, first pass over (dbg = gradient of the gated tensor, z = pre-BN conv_block_2 output): b = relu(scale*z+shift),
@@ -343,6 +353,13 @@ int hn_preprocess_bgr(const void* src, int N, int Hs, int Ws, float* dst, int Hd
 int hn_seg_confusion(const long* pred, const void* target, int target_is_float, long M, int C, void* conf, hipStream_t stream);
 
 int hn_argmax_channels(const float* logits, int ldl, int C, long M, long* out, hipStream_t stream);
+
+/* HydraTrainer.cal_total_loss (model/train.py:192-203) in one launch: total = sum_g (sum_{i in g} x_i*w_i) * gw_g, left to right in fp32
+ * without fused multiply-add (the reference rounds after every mul / add); xs = HOST array of n <= 8 device pointers to fp32 scalars,
+ * w [n], gw [number of groups], grp [n] (non-decreasing group id per term) = HOST arrays.  out (optional) = total; grads (optional, needs
+ * gout = d loss / d total on the device) [n] = (gout * gw_g) * w_i. */
+int hn_weighted_sum(const void* const* xs, const float* w, const float* gw, const int* grp, int n, const float* gout, float* out, float* grads,
+                    hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -217,7 +217,7 @@ struct FBwd {
     const float* gate; const float* dpool; long HW;   // SE variant when gate != null (RB divides HW)
     float* pg; float* pgx;          // reduce: written [gridDim.y][C]; apply: read [P][C]
     int P; double count;
-    float* dgamma; float* dbeta;
+    float* dgamma; float* dbeta; float* zvec;   // zvec (optional): C zeros (the gradient of a conv bias that feeds this BatchNorm)
     bf16* dz; int lddz; bf16* gout; int ldg;
     long M; int C; long RB; int cw;
 };
@@ -235,7 +235,10 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(const FBwd p) {
             const double s1 = L.r1[0][tid], s2 = L.r2[0][tid];
             L.coef[4][tid] = (float)(s1 / p.count);
             L.coef[5][tid] = (float)(s2 / p.count);
-            if (blockIdx.y == 0) { p.dbeta[c0 + tid] = (float)s1; p.dgamma[c0 + tid] = (float)s2; }
+            if (blockIdx.y == 0) {
+                p.dbeta[c0 + tid] = (float)s1; p.dgamma[c0 + tid] = (float)s2;
+                if (p.zvec) p.zvec[c0 + tid] = 0.f;
+            }
         }
     }
     if (tid < nch) {
@@ -493,12 +496,12 @@ extern "C" int hn_bn_bwd_reduce_fused(const void* dout, int ldd, const void* z, 
 extern "C" int hn_bn_bwd_apply_fused(const void* dout, int ldd, const void* z, int ldz, const void* y, int ldy, const float* coef, int act,
                                      const float* gate, const float* dpool, long HW, const float* pg, const float* pgx, int P, long count,
                                      float* dgamma, float* dbeta, void* dz, int lddz, void* gout, int ldg, long M, int C, long RB,
-                                     hipStream_t st) {
+                                     float* zero_c, hipStream_t st) {
     FBwd p;
     const int rc = fill_bwd(p, dout, ldd, z, ldz, y, ldy, coef, act, gate, dpool, HW, (float*)pg, (float*)pgx, M, C, RB);
     if (rc) return rc;
     HN_CHECK_ARG(P > 0 && count > 0 && dgamma && dbeta && dz && (lddz & 7) == 0 && (!gout || (ldg & 7) == 0));
-    p.P = P; p.count = (double)count; p.dgamma = dgamma; p.dbeta = dbeta; p.dz = (bf16*)dz; p.lddz = lddz; p.gout = (bf16*)gout; p.ldg = ldg;
+    p.P = P; p.count = (double)count; p.dgamma = dgamma; p.dbeta = dbeta; p.zvec = zero_c; p.dz = (bf16*)dz; p.lddz = lddz; p.gout = (bf16*)gout; p.ldg = ldg;
     hipLaunchKernelGGL(fused_bwd_kernel<true>, fused_grid(M, C, RB), dim3(256), 0, st, p);
     HN_LAUNCH_CHECK();
 }

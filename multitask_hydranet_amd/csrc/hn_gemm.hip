@@ -1266,6 +1266,88 @@ __global__ void pack_w_kernel(const float* w, bf16* wp, bf16* wt, int Cout, int 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Phase-form effective weights of a 3x3 conv over a nearest-x2 up-sampled map (ops.py SegConvUp / SegOutUp): on the low-resolution grid the
+// conv has 4*Cout outputs, one Cout-vector per output phase (py,px):
+//   W_eff[(py*2+px)*Cout + o][c][dy][dx] = sum over the taps (ky,kx) whose up-sampled source falls on low-res offset (dy,dx)
+//   phase 0: k=0 -> d=0, k=1,2 -> d=1;   phase 1: k=0,1 -> d=1, k=2 -> d=2      (per axis; d = offset + 1)
+// phase_taps(p, d) = bit mask of the k that land on d.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned phase_taps(int p, int d) { return ((p ? 0x430u : 0x061u) >> (4 * d)) & 7u; }
+
+// value of the (virtual) weight tensor that is being packed: plain channel slice [ci0, ci0+Cin) of w[Cout][Cin_total][taps], or (phase)
+// the effective weights above (taps == 9, co in [0, 4*Cout))
+__device__ __forceinline__ float packed_w_value(const float* w, int Cout, int Cin_total, int ci0, int taps, int phase, int co, int ci, int tap) {
+    if (!phase) return w[((long)co * Cin_total + ci0 + ci) * taps + tap];
+    const int ph = co / Cout, o = co - ph * Cout;
+    const int dy = tap / 3, dx = tap - 3 * dy;
+    const unsigned my = phase_taps(ph >> 1, dy), mx = phase_taps(ph & 1, dx);
+    const float* wr = w + ((long)o * Cin_total + ci0 + ci) * 9;
+    float s = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+            if (((my >> ky) & 1u) && ((mx >> kx) & 1u)) s += wr[ky * 3 + kx];
+    return s;
+}
+
+// Wp[CoutE][taps][KPi] | Wt[Cin][taps][KPo] | b_eff[CoutE] (phase: the bias repeated per phase), CoutE = phase ? 4*Cout : Cout
+__global__ void pack_w_ex_kernel(const float* w, bf16* wp, bf16* wt, int Cout, int Cin_total, int ci0, int Cin, int taps, int phase, int KPi,
+                                 int KPo, const float* bias, float* b_eff) {
+    const int CoutE = phase ? 4 * Cout : Cout;
+    const long nf = (long)CoutE * taps * KPi;
+    const long nt = wt ? (long)Cin * taps * KPo : 0;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < nf) {
+        const int k = (int)(idx % KPi);
+        const long t = idx / KPi;
+        const int tap = (int)(t % taps);
+        const int co = (int)(t / taps);
+        wp[idx] = f2bf(k < Cin ? packed_w_value(w, Cout, Cin_total, ci0, taps, phase, co, k, tap) : 0.f);
+    } else if (idx < nf + nt) {
+        const long j = idx - nf;
+        const int k = (int)(j % KPo);
+        const long t = j / KPo;
+        const int tap = (int)(t % taps);
+        const int ci = (int)(t / taps);
+        wt[j] = f2bf(k < CoutE ? packed_w_value(w, Cout, Cin_total, ci0, taps, phase, k, ci, tap) : 0.f);
+    } else if (b_eff && idx < nf + nt + CoutE) {
+        const int co = (int)(idx - nf - nt);
+        b_eff[co] = bias[co % Cout];
+    }
+}
+
+// gradient of the 3x3 weights from the effective-weight gradient (the transpose of the map above), joined with the skip operand's part:
+//   dw[o][c][ky][kx] = c < C0 ? sum_{py,px} dw_eff[(py*2+px)*K + o][c][d(py,ky)][d(px,kx)] : dw1[o][c - C0][ky][kx]
+//   db[o] = sum_ph db_eff[ph*K + o]                                                   d(0,k) = k ? 1 : 0,  d(1,k) = k == 2 ? 2 : 1
+__global__ void phase_fold_kernel(const float* dw_eff, const float* dw1, const float* db_eff, float* dw, float* db, int K, int C0, int C1) {
+    const long total = (long)K * (C0 + C1) * 9;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < total) {
+        const int tap = (int)(idx % 9);
+        const long t = idx / 9;
+        const int c = (int)(t % (C0 + C1));
+        const int o = (int)(t / (C0 + C1));
+        if (c >= C0) {
+            dw[idx] = dw1[((long)o * C1 + (c - C0)) * 9 + tap];
+            return;
+        }
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        float s = 0.f;
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) {
+            const int py = ph >> 1, px = ph & 1;
+            const int dy = py ? (ky == 2 ? 2 : 1) : (ky ? 1 : 0), dx = px ? (kx == 2 ? 2 : 1) : (kx ? 1 : 0);
+            s += dw_eff[(((long)ph * K + o) * C0 + c) * 9 + dy * 3 + dx];
+        }
+        dw[idx] = s;
+    } else if (db && idx < total + K) {
+        const int o = (int)(idx - total);
+        db[o] = (db_eff[o] + db_eff[K + o]) + (db_eff[2 * K + o] + db_eff[3 * K + o]);
+    }
+}
+
 // all conv weights of a model in ONE launch: jobs[j] = {w, wp, wt, Cout, Cin, taps, first block, unused} (device int64 table, built once)
 __global__ void pack_w_batched_kernel(const long* jobs, int njobs) {
     int lo = 0, hi = njobs - 1;                                      // last job whose first block <= blockIdx.x
@@ -1681,6 +1763,29 @@ extern "C" int hn_pack_weights_batched(const long* jobs, int njobs, long total_b
 extern "C" int hn_gconv_pack_diag(const float* w, void* wk, void* wd, int C, hipStream_t st) {
     HN_CHECK_ARG(w && wk && wd && C > 0 && (C & 7) == 0);
     hipLaunchKernelGGL(gconv_pack_diag_kernel, dim3(cdiv((long)C * 576, 256)), dim3(256), 0, st, w, (bf16*)wk, (bf16*)wd, C);
+    HN_LAUNCH_CHECK();
+}
+
+/* packing of a channel slice [ci0, ci0+Cin) of w[Cout][Cin_total][taps] (phase = 0), or of the phase-form effective weights of that slice
+ * (phase = 1, taps = 9: wp [4*Cout][9][KP(Cin)], wt [Cin][9][KP(4*Cout)], b_eff [4*Cout] = bias repeated per phase, optional) */
+extern "C" int hn_pack_weight_ex(const float* w, void* wp, void* wt, int Cout, int Cin_total, int ci0, int Cin, int taps, int phase,
+                                 const float* bias, float* b_eff, hipStream_t st) {
+    HN_CHECK_ARG(w && wp && Cout > 0 && Cin > 0 && ci0 >= 0 && ci0 + Cin <= Cin_total && taps > 0 && (!phase || taps == 9) && (!b_eff || bias));
+    const int CoutE = phase ? 4 * Cout : Cout;
+    const int KPi = (Cin + 31) / 32 * 32, KPo = (CoutE + 31) / 32 * 32;
+    const long total = (long)CoutE * taps * KPi + (wt ? (long)Cin * taps * KPo : 0) + (b_eff ? CoutE : 0);
+    hipLaunchKernelGGL(pack_w_ex_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w, (bf16*)wp, (bf16*)wt, Cout, Cin_total, ci0, Cin, taps,
+                       phase, KPi, KPo, bias, b_eff);
+    HN_LAUNCH_CHECK();
+}
+
+/* dw [K][C0+C1][3][3] (and db [K], optional) from the effective-weight gradient dw_eff [4K][C0][3][3] (db_eff [4K]) and the skip operand's
+ * dw1 [K][C1][3][3] (C1 = 0: none) */
+extern "C" int hn_phase_fold(const float* dw_eff, const float* dw1, const float* db_eff, float* dw, float* db, int K, int C0, int C1,
+                             hipStream_t st) {
+    HN_CHECK_ARG(dw_eff && dw && K > 0 && C0 > 0 && C1 >= 0 && (C1 == 0 || dw1) && (!db || db_eff));
+    const long total = (long)K * (C0 + C1) * 9 + (db ? K : 0);
+    hipLaunchKernelGGL(phase_fold_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, dw_eff, dw1, db_eff, dw, db, K, C0, C1);
     HN_LAUNCH_CHECK();
 }
 

@@ -725,3 +725,47 @@ extern "C" int hn_nms_sorted(const float* boxes, int K, float iou_threshold, voi
     hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 0, st, (const unsigned long long*)mask, K, words, (unsigned char*)keep);
     HN_LAUNCH_CHECK();
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Weighted multitask loss sum (HydraTrainer.cal_total_loss, model/train.py:192-203) in one launch:
+//   total = sum_g ( sum_{i in g} x_i * w_i ) * gw_g        evaluated left to right in fp32, no fused multiply-add (the reference's separate
+//   mul / add kernels round after every operation); backward: dx_i = (gout * gw_g) * w_i
+// ---------------------------------------------------------------------------------------------------------
+#define HN_MAX_LOSS_TERMS 8
+struct WSum {
+    const float* x[HN_MAX_LOSS_TERMS]; float w[HN_MAX_LOSS_TERMS]; float gw[HN_MAX_LOSS_TERMS]; int grp[HN_MAX_LOSS_TERMS];
+    int n; const float* gout; float* out; float* grads;
+};
+__global__ void weighted_sum_kernel(const WSum p) {
+    if (threadIdx.x != 0) return;
+    if (p.out) {
+        float tot = 0.f;
+        int i = 0;
+        while (i < p.n) {
+            const int g = p.grp[i];
+            float s = __fmul_rn(p.x[i][0], p.w[i]);
+            for (++i; i < p.n && p.grp[i] == g; ++i) s = __fadd_rn(s, __fmul_rn(p.x[i][0], p.w[i]));
+            tot = __fadd_rn(tot, __fmul_rn(s, p.gw[g]));
+        }
+        p.out[0] = tot;
+    }
+    if (p.grads) {
+        const float go = p.gout[0];
+        for (int i = 0; i < p.n; ++i) p.grads[i] = __fmul_rn(__fmul_rn(go, p.gw[p.grp[i]]), p.w[i]);
+    }
+}
+/* xs: HOST array of n device pointers (one fp32 scalar each); w, gw, grp: HOST arrays (term weight, group weight indexed by group id, group
+ * id per term; terms of a group are consecutive); out (optional): the total; grads (optional, with gout): n gradients */
+extern "C" int hn_weighted_sum(const void* const* xs, const float* w, const float* gw, const int* grp, int n, const float* gout, float* out,
+                               float* grads, hipStream_t st) {
+    HN_CHECK_ARG(xs && w && gw && grp && n > 0 && n <= HN_MAX_LOSS_TERMS && (out || grads) && (!grads || gout));
+    WSum p = {};
+    for (int i = 0; i < n; ++i) {
+        HN_CHECK_ARG(xs[i] && grp[i] >= 0 && grp[i] < HN_MAX_LOSS_TERMS && (i == 0 || grp[i] >= grp[i - 1]));
+        p.x[i] = (const float*)xs[i]; p.w[i] = w[i]; p.grp[i] = grp[i];
+    }
+    for (int g = 0; g <= grp[n - 1]; ++g) p.gw[g] = gw[g];
+    p.n = n; p.gout = gout; p.out = out; p.grads = grads;
+    hipLaunchKernelGGL(weighted_sum_kernel, dim3(1), dim3(64), 0, st, p);
+    HN_LAUNCH_CHECK();
+}

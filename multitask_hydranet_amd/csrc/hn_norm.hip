@@ -463,6 +463,7 @@ struct FinLevels {
     const float* gamma[HN_MAX_LEVELS]; const float* beta[HN_MAX_LEVELS]; float* rm[HN_MAX_LEVELS]; float* rv[HN_MAX_LEVELS];
     float* dgamma[HN_MAX_LEVELS]; float* dbeta[HN_MAX_LEVELS];
     float* out;                  // fwd: coef [level][4][C]; bwd: red [level][2][C]
+    float* zero;                 // bwd (optional): C zeros written by level 0 (gradient of the conv bias that feeds these BatchNorms)
     const float* bias;           // fwd, ragged packing: the conv bias -- the (rows - count) alignment rows of a level hold exactly
                                  // bf16(bias[c]) (their conv input is zero), which is subtracted from the sums
 };
@@ -511,6 +512,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_levels_kernel(const FinLevel
             float* red = p.out + (long)lv * 2 * p.C;
             p.dbeta[lv][c] = (float)s1;
             p.dgamma[lv][c] = (float)s2;
+            if (p.zero && lv == 0) p.zero[c] = 0.f;
             red[c] = (float)(s1 / count);
             red[p.C + c] = (float)(s2 / count);
         }
@@ -936,12 +938,13 @@ extern "C" int hn_bn_finalize_levels(const float* psum, const float* psq, int di
 }
 /* red out: [nlev][2][C] = mean(g), mean(g*xhat); dgamma/dbeta: per-level fp32 [C] */
 extern "C" int hn_bn_bwd_finalize_levels(const float* pg, const float* pgx, int div, int C, int nlev, const long* rows, const long* count,
-                                         void* const* dgamma, void* const* dbeta, float* red, hipStream_t st) {
+                                         void* const* dgamma, void* const* dbeta, float* red, float* zero_c, hipStream_t st) {
     HN_CHECK_ARG(dgamma && dbeta && red);
     FinLevels p = {};
     const int rc = fill_fin(p, pg, pgx, div, C, nlev, rows, count);
     if (rc != HN_OK) return rc;
     p.out = red;
+    p.zero = zero_c;
     for (int l = 0; l < nlev; ++l) {
         HN_CHECK_ARG(dgamma[l] && dbeta[l]);
         p.dgamma[l] = (float*)dgamma[l]; p.dbeta[l] = (float*)dbeta[l];

@@ -652,7 +652,8 @@ class HydraNet(nn.Module):
         if self.train_detect:
             d = pred_dict["detection"]
             cl, rl = self.loss_detect(d["classification"], d["regression"], d["anchors"], gt_dict["gt_det"])
-            cl, rl = cl.mean(), rl.mean()
+            # the reference takes .mean() of the [1]-shaped batch means (model.py:226-227): a reshape for one element
+            cl, rl = (cl.reshape(()) if cl.numel() == 1 else cl.mean()), (rl.reshape(()) if rl.numel() == 1 else rl.mean())
             self._guard(cl, "cal det cls loss diverge!", allow_zero=True)
             self._guard(rl, "cal det reg loss diverge!", allow_zero=True)
             ld["loss_det_cls"], ld["loss_det_reg"] = cl, rl
@@ -669,6 +670,18 @@ class HydraNet(nn.Module):
     def total_loss(self, ld):
         """HydraTrainer.cal_total_loss, model/train.py:192-203."""
         c = self.cfgs
+        if all(isinstance(v, torch.Tensor) and v.is_cuda and v.dtype == torch.float32 for v in ld.values()):
+            groups = []                                      # one launch (fwd) + one (bwd) instead of ~22 scalar torch kernels
+            if self.train_seg:
+                groups.append((1.0, [(ld["loss_seg"], c["segment"]["segment_weight"])]))
+            if self.train_detect:
+                d = c["detection"]
+                groups.append((d["detection_weight"], [(ld["loss_det_cls"], d["loss_cls_weight"]), (ld["loss_det_reg"], d["loss_reg_weight"])]))
+            if self.train_lane:
+                l = c["lane"]
+                groups.append((l["lane_weight"], [(ld["loss_lane_cls_pos"], l["loss_cls_pos_weight"]),
+                                                  (ld["loss_lane_cls_neg"], l["loss_cls_neg_weight"]), (ld["loss_lane_loc"], l["loss_loc_weight"])]))
+            return K.weighted_loss_sum(groups)
         tot = 0.0
         if self.train_seg:
             tot = tot + ld["loss_seg"] * c["segment"]["segment_weight"]

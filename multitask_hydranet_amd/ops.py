@@ -160,6 +160,34 @@ def pack_conv_weight(w: torch.Tensor):
     return _cached("conv", w, make)
 
 
+def pack_conv_weight_slice(w: torch.Tensor, ci0: int, cin: int):
+    """pack_conv_weight of the input-channel slice w[:, ci0:ci0+cin] without materialising the slice"""
+    def make():
+        cout, taps = w.shape[0], w.shape[2] * w.shape[3]
+        wp = torch.empty((cout, taps * kp32(cin)), device=w.device, dtype=BF16)
+        wt = torch.empty((cin, taps * kp32(cout)), device=w.device, dtype=BF16)
+        lib().call("hn_pack_weight_ex", ptr(w), ptr(wp), ptr(wt), cout, w.shape[1], ci0, cin, taps, 0, None, None)
+        return wp, wt
+    return _cached(("slice", ci0, cin), w, make)
+
+
+def pack_phase_weight(w: torch.Tensor, c0: int, bias: torch.Tensor):
+    """phase-form effective weights of the first c0 input channels of a 3x3 conv over a nearest-x2 up-sampled map (SegConvUp / SegOutUp):
+    (wp_eff [4k, 9*KP(c0)], wt_eff [c0, 9*KP(4k)], b_eff [4k]) in one launch"""
+    def make():
+        k = w.shape[0]
+        wp = torch.empty((4 * k, 9 * kp32(c0)), device=w.device, dtype=BF16)
+        wt = torch.empty((c0, 9 * kp32(4 * k)), device=w.device, dtype=BF16)
+        b_eff = torch.empty((4 * k,), device=w.device, dtype=F32)
+        lib().call("hn_pack_weight_ex", ptr(w), ptr(wp), ptr(wt), k, w.shape[1], 0, c0, 9, 1, ptr(bias), ptr(b_eff))
+        return wp, wt, b_eff, bias, bias._version
+    v = _cached(("phase", c0), w, make)
+    if v[3] is not bias or v[4] != bias._version:               # the bias changed without the weight: repack
+        _PACK_CACHE.pop((("phase", c0), id(w)), None)
+        v = _cached(("phase", c0), w, make)
+    return v[0], v[1], v[2]
+
+
 def pack_gconv_weight(w: torch.Tensor, flip: int):
     def make():
         c = w.shape[0]
@@ -351,7 +379,7 @@ def k_bn_apply_fused(z, psum, psq, count, gamma, beta, eps, momentum, rm, rv, ac
     return out, coef, pool, rb
 
 
-def bn_backward_fused(dout, z, y, coef, act, count, want_g=False, gate=None, dpool=None, hw=0):
+def bn_backward_fused(dout, z, y, coef, act, count, want_g=False, gate=None, dpool=None, hw=0, zero_c=None):
     """BatchNorm(+activation) backward in two launches (reduce, apply with the finalize in its prologue): (dz, dgamma, dbeta, g|None).
     The two passes use their own row blocks: the reduce pass's block count is the number of partial rows the apply prologue folds."""
     n, h, w, c = z.shape
@@ -373,7 +401,7 @@ def bn_backward_fused(dout, z, y, coef, act, count, want_g=False, gate=None, dpo
     g = new_act(n, h, w, c, dev) if want_g else None
     lib().call("hn_bn_bwd_apply_fused", ptr(dout), ld(dout), ptr(z), ld(z), ptr(y), ld(y) if y is not None else 0, ptr(coef), act,
                ptr(gate), ptr(dpool), hw, ptr(pg), ptr(pgx), pr, count, ptr(dgamma), ptr(dbeta), ptr(dz), ld(dz), ptr(g),
-               ld(g) if g is not None else 0, m, c, rb_a)
+               ld(g) if g is not None else 0, m, c, rb_a, ptr(zero_c))
     return dz, dgamma, dbeta, g
 
 
@@ -468,8 +496,15 @@ class ConvBnAct(torch.autograd.Function):
         assert ctx.training, "backward through eval-mode BatchNorm is not part of the hot path"
         dout = dense(dout)
         kind, stride = ctx.kind, ctx.stride
-        dz, dgamma, dbeta, g = (bn_backward_fused if FUSED_BN else bn_backward)(dout, z, y, coef, ctx.act, ctx.count,
-                                                                                want_g=ctx.has_res and ctx.act != ACT_NONE)
+        # a conv bias that feeds BatchNorm has zero gradient: the zeros come out of the BN backward launch (no fill kernel)
+        dbias = torch.empty((z.shape[3],), device=z.device, dtype=F32) if ctx.has_bias else None
+        if FUSED_BN:
+            dz, dgamma, dbeta, g = bn_backward_fused(dout, z, y, coef, ctx.act, ctx.count, want_g=ctx.has_res and ctx.act != ACT_NONE,
+                                                     zero_c=dbias)
+        else:
+            dz, dgamma, dbeta, g = bn_backward(dout, z, y, coef, ctx.act, ctx.count, want_g=ctx.has_res and ctx.act != ACT_NONE)
+            if dbias is not None:
+                dbias = zeros((z.shape[3],), z.device)
         dres = None
         if ctx.has_res:
             dres = g if g is not None else dout
@@ -509,7 +544,6 @@ class ConvBnAct(torch.autograd.Function):
                     dx = zeros((n, hi, wi, cin), dev, BF16)
                     lib().call("hn_add_strided2", ptr(dx), ld(dx), ptr(dxs), ld(dxs), n, ho, wo, cin)
             dw = k_gemm_tn(x, None, 0 if stride == 1 else 1, (n, ho, wo), dz, cout, kp32(cin), 1, cin)
-        dbias = zeros((cout,), dev) if ctx.has_bias else None   # a bias feeding BatchNorm has zero gradient
         return dx, dw, dbias, dgamma, dbeta, None, None, None, dres, None, None, None, None, None, None
 
 
@@ -955,11 +989,10 @@ class HeadOut(torch.autograd.Function):
         dout = dout.contiguous()
         dev = dout.device
         ldz = pad8(cout)
-        dpw = zeros(pw_weight.shape, dev)
-        dbias = zeros((cout,), dev)
-        ddw = zeros(dw_weight.shape, dev) if has_dw else None
+        dpw = dbias = ddw = None                             # first level: the gradients themselves; further levels accumulate
         dfeats = []
         off = 0
+        acc = lambda tot, part: part if tot is None else tot.add_(part)
         for f, mid in zip(feats, mids):
             n, h, w, _ = f.shape
             m = n * h * w
@@ -968,11 +1001,11 @@ class HeadOut(torch.autograd.Function):
             lib().call("hn_head_grad", ptr(dout.view(-1)[base:]), ptr(yout.view(-1)[base:]) if yout is not None else None, h * w, img_stride,
                        ldc, cout, ptr(dz), ldz, m, 1 if act == ACT_SIGMOID else 0)
             ps, _, _ = k_col_stats(dz)
-            dbias += k_rows_reduce(ps, 1, ps.shape[0], ldz).view(-1)[:cout]
-            dpw += k_gemm_tn(mid, None, 0, (n, h, w), dz, cout, kp32(cin), 1, cin)
+            dbias = acc(dbias, k_rows_reduce(ps, 1, ps.shape[0], ldz).view(-1)[:cout])
+            dpw = acc(dpw, k_gemm_tn(mid, None, 0, (n, h, w), dz, cout, kp32(cin), 1, cin))
             dmid, _, _ = k_gemm_nt(dz, None, 0, (n, h, w), ctx.wt, cin, kp32(cout), 1, c0=ldz, c1=0)
             if has_dw:
-                ddw += k_dwconv_wgrad(f, dmid)
+                ddw = acc(ddw, k_dwconv_wgrad(f, dmid))
                 dfeats.append(k_dwconv(dmid, pack_dw_weight(dw_weight)[1]))
             else:
                 dfeats.append(dmid)
@@ -1249,14 +1282,14 @@ class TowerLayer(torch.autograd.Function):
         dgam = [torch.empty((cout,), device=dev, dtype=F32) for _ in range(nl)]
         dbet = [torch.empty((cout,), device=dev, dtype=F32) for _ in range(nl)]
         dga, dba = _ptr_array(dgam), _ptr_array(dbet)
+        dbias = torch.empty((cout,), device=dev, dtype=F32) if ctx.has_bias else None    # a bias feeding BatchNorm has zero gradient
         lib().call("hn_bn_bwd_finalize_levels", ptr(pg), ptr(pgx), r, cout, nl, ctypes.addressof(R), ctypes.addressof(CNT),
-                   ctypes.addressof(dga), ctypes.addressof(dba), ptr(red))
+                   ctypes.addressof(dga), ctypes.addressof(dba), ptr(red), ptr(dbias))
         dz = torch.empty_like(z)
         lib().call("hn_bn_bwd_apply_levels", ptr(dout), ld(dout), ptr(z), ld(z), None, 0, ptr(coef), ptr(red), act, ptr(dz), ld(dz), cout, nl,
                    ctypes.addressof(R))
         dd, _, _ = k_gemm_nt(dz, None, 0, (1, 1, total), wt, c, kp32(cout), 1)
         dpw = k_gemm_tn(d, None, 0, (1, 1, total), dz, cout, kp32(c), 1, c)
-        dbias = zeros((cout,), dev) if ctx.has_bias else None    # a bias feeding BatchNorm has zero gradient
         ddw = k_dwconv_wgrad_levels(x, dd, geom)
         dx = k_dwconv_levels(dd, wf, geom) if ctx.needs_input_grad[0] else None
         bn_grads = []
@@ -1350,10 +1383,7 @@ class SegOutUp(torch.autograd.Function):
         n, h, w, c = x.shape
         k = weight.shape[0]
         ctx.x_is_elu = x_is_elu
-        T = _phase_matrix(x.device)
-        w_eff = (weight.reshape(k * c, 9) @ T.t()).view(k, c, 2, 2, 3, 3).permute(2, 3, 0, 1, 4, 5).reshape(4 * k, c, 3, 3).contiguous()
-        b_eff = bias.repeat(4)
-        wp, wt = pack_conv_weight(w_eff)
+        wp, wt, b_eff = pack_phase_weight(weight, c, bias)
         out = torch.empty((n, 2 * h, 2 * w, k), device=x.device, dtype=F32)
         # img_stride = -k: the conv epilogue scatters phase (py, px) of low-res pixel (y, x) to output pixel (2y+py, 2x+px) itself
         k_gemm_nt(x, None, 4, (n, h, w), wp, 4 * k, kp32(c), 9, bias=b_eff, out=out, out_f32=True, ldc=4 * k, img_stride=-k)
@@ -1373,10 +1403,11 @@ class SegOutUp(torch.autograd.Function):
         dz = new_act(n, h, w, ldz, dev)
         lib().call("hn_space_to_depth", ptr(dy), ptr(dz), ldz, n, h, w, k)
         ps, _, _ = k_col_stats(dz)
-        dbias = k_rows_reduce(ps, 1, ps.shape[0], ldz).view(-1)[:4 * k].view(4, k).sum(0)
+        db_eff = k_rows_reduce(ps, 1, ps.shape[0], ldz)
         dw_eff = k_gemm_tn(x, None, 4, (n, h, w), dz, 4 * k, kp32(c), 9, c, kh=3)                       # [4k, c, 3, 3]
-        T = _phase_matrix(dev)
-        dw = (dw_eff.view(2, 2, k, c, 3, 3).permute(2, 3, 0, 1, 4, 5).reshape(k * c, 36) @ T).view(k, c, 3, 3)
+        dw = torch.empty((k, c, 3, 3), device=dev, dtype=F32)
+        dbias = torch.empty((k,), device=dev, dtype=F32)
+        lib().call("hn_phase_fold", ptr(dw_eff), None, ptr(db_eff), ptr(dw), ptr(dbias), k, c, 0)
         dx = None
         if ctx.needs_input_grad[0]:
             dvp, _, _ = k_gemm_nt(dz, None, 3, (n, h + 2, w + 2), ctx.wt, c, kp32(4 * k), 9, c0=ldz, c1=0)
@@ -1400,11 +1431,7 @@ class SegConvUp(torch.autograd.Function):
         k, cin = weight.shape[0], weight.shape[1]
         c1 = cin - c0
         dev = x0.device
-        T = _phase_matrix(dev)
-        w0 = weight[:, :c0].reshape(k * c0, 9)
-        w_eff = (w0 @ T.t()).view(k, c0, 2, 2, 3, 3).permute(2, 3, 0, 1, 4, 5).reshape(4 * k, c0, 3, 3).contiguous()
-        wp_eff, wt_eff = pack_conv_weight(w_eff)
-        b_eff = bias.repeat(4)
+        wp_eff, wt_eff, b_eff = pack_phase_weight(weight, c0, bias)
         z1 = wt1 = wt_full = None
         # Per-layer choice of form (measured, tools/bench_seg.py): the forward runs full-resolution when the skip operand is so narrow that its
         # own conv would be mostly K padding (decoder.5: 24 channels); the data gradient w.r.t. x0 runs full-resolution when the padded
@@ -1413,8 +1440,7 @@ class SegConvUp(torch.autograd.Function):
         tiles = n * ((h + 2 + 15) // 16) * ((w + 2 + 15) // 16) * ((c0 + 127) // 128)
         ctx.dgrad_phase = (tiles >= 448) if SEG_DGRAD_PHASE is None else SEG_DGRAD_PHASE
         if c1 and (fwd_phase or ctx.dgrad_phase):
-            w1 = weight[:, c0:].contiguous()
-            wp1, wt1 = pack_conv_weight(w1)
+            wp1, wt1 = pack_conv_weight_slice(weight, c0, c1)
         if not fwd_phase or not ctx.dgrad_phase:
             wp_full, wt_full = pack_conv_weight(weight)
         if fwd_phase:
@@ -1451,8 +1477,6 @@ class SegConvUp(torch.autograd.Function):
         ws = torch.empty((wsb.value // 4,), device=dev, dtype=F32)
         dw_eff = torch.empty((4 * k, c0, 3, 3), device=dev, dtype=F32)
         lib().call("hn_conv_gemm_tn_phase", ptr(x0), n, h, w, c0, ld(x0), ptr(dzs), ld(dzs), 4 * k, kp32(c0), k, ptr(ws), ptr(dw_eff))
-        T = _phase_matrix(dev)
-        dw0 = (dw_eff.view(2, 2, k, c0, 3, 3).permute(2, 3, 0, 1, 4, 5).reshape(k * c0, 36) @ T).view(k, c0, 3, 3)
         dx0 = dx1 = None
         if not ctx.dgrad_phase:
             # full-resolution data gradient for both operands at once (padded (2h+2) x (2w+2) grid), folded back per operand
@@ -1471,14 +1495,16 @@ class SegConvUp(torch.autograd.Function):
             dx0 = new_act(n, h, w, c0, dev)
             yp = x0 if ctx.x0_is_elu else None
             lib().call("hn_seg_fold", ptr(dvp), ld(dvp), 0, ptr(dx0), ld(dx0), ptr(yp), ld(yp) if yp is not None else 0, n, h, w, c0, 2)
-        dw = dw0
+        dw1 = None
         if c1:
             dw1 = k_gemm_tn(x1, None, 2, (n, 2 * h, 2 * w), dz, k, kp32(c1), 9, c1, kh=3)
-            dw = torch.cat([dw0, dw1], 1)
             if ctx.dgrad_phase and ctx.needs_input_grad[1]:
                 dvp1, _, _ = k_gemm_nt(dz, None, 3, (n, 2 * h + 2, 2 * w + 2), wt1, c1, kp32(k), 9, c0=k, c1=0)
                 dx1 = new_act(n, 2 * h, 2 * w, c1, dev)
                 lib().call("hn_seg_fold", ptr(dvp1), ld(dvp1), 0, ptr(dx1), ld(dx1), None, 0, n, 2 * h, 2 * w, c1, 0)
+        # effective-weight gradient mapped back to the 3x3 taps (the transpose of the phase map), joined with the skip operand's part
+        dw = torch.empty((k, c0 + c1, 3, 3), device=dev, dtype=F32)
+        lib().call("hn_phase_fold", ptr(dw_eff), ptr(dw1), None, ptr(dw), None, k, c0, c1)
         return dx0, dx1, dw, dbias, None, None
 
 
@@ -1565,3 +1591,46 @@ def lane_cls_loss_hip(cls_targets, cls_preds, negative_ratio=15, alpha=10.0):
 def lane_loc_loss_hip(pmask, positive_num, loc_targets, loc_preds, alpha=10.0, points_per_line=160):
     """cal_loss_regress (lanedetect_loss.py:57-78) incl. its hard-coded points_per_line = 160 default (x10 weights on columns 160/161)."""
     return LaneLocLoss.apply(pmask, positive_num, loc_targets, loc_preds, points_per_line, alpha)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# HydraTrainer.cal_total_loss (model/train.py:192-203) as one launch forward and one backward instead of ~22 scalar torch kernels.
+# --------------------------------------------------------------------------------------------------------------
+class WeightedLossSum(torch.autograd.Function):
+    """total = sum_g (sum_{i in g} x_i * w_i) * gw_g; meta = (w tuple, gw tuple, group-id tuple), xs = fp32 scalar device tensors"""
+
+    @staticmethod
+    def forward(ctx, meta, *xs):
+        w, gw, grp = meta
+        n = len(xs)
+        ctx.shapes = [x.shape for x in xs]
+        xs = [x.reshape(1) for x in xs]
+        assert all(x.dtype == F32 and x.is_cuda for x in xs)
+        out = torch.empty((1,), device=xs[0].device, dtype=F32)
+        ctx.host = (_ptr_array(xs), (ctypes.c_float * n)(*w), (ctypes.c_float * len(gw))(*gw), (ctypes.c_int * n)(*grp), n)
+        pa, wa, ga, ia, _ = ctx.host
+        lib().call("hn_weighted_sum", ctypes.addressof(pa), ctypes.addressof(wa), ctypes.addressof(ga), ctypes.addressof(ia), n, None, ptr(out), None)
+        ctx.keep = xs                                     # the pointer table refers to these
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        pa, wa, ga, ia, n = ctx.host
+        grads = torch.empty((n,), device=gout.device, dtype=F32)
+        g = gout.reshape(1)
+        if g.dtype != F32:
+            g = g.float()
+        lib().call("hn_weighted_sum", ctypes.addressof(pa), ctypes.addressof(wa), ctypes.addressof(ga), ctypes.addressof(ia), n, ptr(g), None, ptr(grads))
+        return (None, *[grads[i:i + 1].view(shape) for i, shape in enumerate(ctx.shapes)])
+
+
+def weighted_loss_sum(groups):
+    """groups = [(group weight, [(loss tensor, weight), ...]), ...] -> the reference's total loss, same association order"""
+    xs, w, gw, grp = [], [], [], []
+    for gi, (gweight, terms) in enumerate(groups):
+        gw.append(float(gweight))
+        for x, wi in terms:
+            xs.append(x)
+            w.append(float(wi))
+            grp.append(gi)
+    return WeightedLossSum.apply((tuple(w), tuple(gw), tuple(grp)), *xs)

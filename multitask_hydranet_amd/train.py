@@ -66,16 +66,9 @@ class HydraTrainer:
 
     # ------------------------------------------------------------------------------------------------------------------------------
     def cal_total_loss(self, loss_dict: Dict[str, torch.Tensor]):
-        """train.py:192-203"""
-        total = 0.0
-        if self.train_seg:
-            total = total + loss_dict["loss_seg"] * self.segment_weight
-        if self.train_detect:
-            total = total + (loss_dict["loss_det_cls"] * self.loss_cls_weight + loss_dict["loss_det_reg"] * self.loss_reg_weight) * self.detection_weight
-        if self.train_lane:
-            total = total + (loss_dict["loss_lane_cls_pos"] * self.loss_cls_pos_weight + loss_dict["loss_lane_cls_neg"] * self.loss_cls_neg_weight
-                             + loss_dict["loss_lane_loc"] * self.loss_loc_weight) * self.lane_weight
-        return total
+        """train.py:192-203: the weighted sum of the task losses (same weights, same association order); on the device it is one launch
+        (HydraNet.total_loss -> ops.WeightedLossSum)"""
+        return self.hydranet.total_loss(loss_dict)
 
     def to_gpu(self, batch_data: dict) -> dict:
         """train.py:228-239"""

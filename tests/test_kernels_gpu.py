@@ -356,6 +356,44 @@ def test_seg_out_phase_form(K, c, k, n, h, w):
     close(bk.grad, br.grad, GRAD_TOL, "dbias")
 
 
+@pytest.mark.parametrize("k,c0,c1", [(64, 64, 0), (64, 40, 24), (5, 64, 0), (128, 96, 112)])
+def test_phase_weight_pack_and_fold(K, k, c0, c1):
+    """hn_pack_weight_ex (phase form / channel slice) and hn_phase_fold against the definition W_eff = W @ T^T of ops._phase_matrix:
+    packed operands equal the plain packing of the materialised effective weights bit for bit when the tap sums are exact (bf16-valued
+    weights: at most 4 terms of 8 significant bits each), the fold is the transpose map."""
+    from multitask_hydranet_amd._lib import lib
+    w = rnd(k, c0 + c1, 3, 3, scale=0.25)
+    bias = rnd(k, scale=0.1)
+    T = K._phase_matrix(dev())
+    w_eff = (w[:, :c0].reshape(k * c0, 9) @ T.t()).view(k, c0, 2, 2, 3, 3).permute(2, 3, 0, 1, 4, 5).reshape(4 * k, c0, 3, 3).contiguous()
+    K.clear_pack_cache()
+    wp_ref, wt_ref = K.pack_conv_weight(w_eff)
+    wp, wt, b_eff = K.pack_phase_weight(w, c0, bias)
+    assert torch.equal(wp.view(-1), wp_ref.view(-1)) and torch.equal(wt.view(-1), wt_ref.view(-1))
+    assert torch.equal(b_eff, bias.repeat(4))
+    if c1:
+        w1 = w[:, c0:].contiguous()
+        a_ref, b_ref = K.pack_conv_weight(w1)
+        a, b = K.pack_conv_weight_slice(w, c0, c1)
+        assert torch.equal(a.view(-1), a_ref.view(-1)) and torch.equal(b.view(-1), b_ref.view(-1))
+    # cache: same tensors while weight and bias are unchanged, repacked after an in-place update of either
+    assert K.pack_phase_weight(w, c0, bias)[0] is wp
+    bias.add_(1.0)
+    assert torch.equal(K.pack_phase_weight(w, c0, bias)[2], bias.repeat(4))
+    dw_eff = torch.randn(4 * k, c0, 3, 3, device=dev())
+    dw1 = torch.randn(k, c1, 3, 3, device=dev()) if c1 else None
+    db_eff = torch.randn(4 * k, device=dev())
+    dw = torch.empty(k, c0 + c1, 3, 3, device=dev())
+    db = torch.empty(k, device=dev())
+    lib().call("hn_phase_fold", dw_eff.data_ptr(), dw1.data_ptr() if c1 else None, db_eff.data_ptr(), dw.data_ptr(), db.data_ptr(), k, c0, c1)
+    ref0 = (dw_eff.view(2, 2, k, c0, 3, 3).permute(2, 3, 0, 1, 4, 5).reshape(k * c0, 36).double() @ T.double()).view(k, c0, 3, 3)
+    torch.testing.assert_close(dw[:, :c0].double(), ref0, rtol=1e-6, atol=1e-6)
+    if c1:
+        assert torch.equal(dw[:, c0:], dw1)
+    torch.testing.assert_close(db.double(), db_eff.view(4, k).double().sum(0), rtol=1e-6, atol=1e-6)
+    K.clear_pack_cache()
+
+
 @pytest.mark.parametrize("with_dw,cout,k,act", [(True, 36, 4, 0), (True, 81, 9, 4), (False, 65, 65, 0), (False, 2, 2, 0)])
 def test_head_out(K, with_dw, cout, k, act):
     n, c = 2, 16
