@@ -130,11 +130,11 @@ int hn_maxpool_bwd(const void* in, int ldi, const void* dout, int ldd, void* dx,
                    int mode, hipStream_t stream);
 /* two-pass form of the same backward (arg-max bytes of every window in arg_ws = N*(H/2)*(W/2)*C bytes, then a gather per input pixel) */
 int hn_maxpool_bwd2(const void* in, int ldi, const void* dout, int ldd, void* dx, int ldx, const float* wscale, void* arg_ws, int N, int H,
-                    int W, int C, int mode, hipStream_t stream);
+                    int W, int C, int mode, int accumulate, hipStream_t stream);
 
 /* Nearest x2 up-sampling and its backward (F.interpolate / nn.Upsample, net/bifpn.py:43-46, head_lane/lanedetect.py:10-13). */
 int hn_up2_fwd(const void* in, int ldi, void* out, int ldo, int N, int H, int W, int C, hipStream_t stream);
-int hn_sum2x2(const void* g, int ldg, void* out, int ldo, const float* wscale, int N, int H, int W, int C, hipStream_t stream);
+int hn_sum2x2(const void* g, int ldg, void* out, int ldo, const float* wscale, int N, int H, int W, int C, int accumulate, hipStream_t stream);
 
 /* BiFPN fusion node out = swish(sum_i w[i]*T_i(in_i)) (net/bifpn.py:177-231); mode[i]: 0 absent, 1 same res, 2 nearest x2 of a
  * half-res map, 3 zero-pad-same max-pool of a double-res map.  w: 3 fp32 in device memory. */
@@ -143,9 +143,12 @@ int hn_fuse_weights(const float* praw, int nw, float eps, float* wn, hipStream_t
 int hn_fuse_dweights(const float* pw, int blocks, const float* praw, int nw, float eps, float* dp, hipStream_t stream);
 int hn_fuse_fwd(const void* const* in, const int* ld, const int* mode, const float* w, void* out, int ldo, int N, int H, int W, int C,
                 hipStream_t stream);
+/* `accumulate` / acc[i] = 1 in hn_fuse_bwd, hn_sum2x2 and hn_maxpool_bwd2: the destination already holds the gradient another consumer of
+ * the same tensor wrote (a BiFPN map feeds 2-3 nodes, net/bifpn.py:186-231) and this consumer's contribution is added in place (fp32 add,
+ * one bf16 rounding) -- the autograd engine's separate gradient-accumulation kernels disappear (ops.Share / ops.GradSlot). */
 int hn_fuse_bwd_blocks(int N, int H, int W, int C);
 int hn_fuse_bwd(const void* const* in, const int* ld, const int* mode, const float* w, const void* dout, int ldd, void* g, int ldg,
-                void* const* din, const int* ldin, float* pw, int N, int H, int W, int C, hipStream_t stream);
+                void* const* din, const int* ldin, const int* acc, float* pw, int N, int H, int W, int C, hipStream_t stream);
 
 /* Backward of ReflectionPad2d(1) (+ nearest x2, + channel split of the concat) for the seg decoder (head_seg/segmentation.py:40,92-99). */
 int hn_seg_fold(const void* dvp, int ldv, int c0, void* out, int ldo, const void* yprev, int ldy, int N, int H, int W, int C, int up,

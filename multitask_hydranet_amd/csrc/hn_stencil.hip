@@ -551,7 +551,7 @@ __global__ __launch_bounds__(256) void maxpool_arg_kernel(const bf16* in, int ld
     }
 }
 __global__ __launch_bounds__(256) void maxpool_bwd_arg_kernel(const unsigned char* arg, const bf16* dout, int ldd, bf16* dx, int ldx,
-                                                              const float* wscale, int N, int H, int W, int C, int mode) {
+                                                              const float* wscale, int N, int H, int W, int C, int mode, int accumulate) {
     const int C8 = C >> 3, Ho = H >> 1, Wo = W >> 1;
     const long total = (long)N * H * W * C8;
     const float ws = wscale ? *wscale : 1.0f;
@@ -579,10 +579,17 @@ __global__ __launch_bounds__(256) void maxpool_bwd_arg_kernel(const unsigned cha
                     if ((int)((a >> (8 * k)) & 0xff) == mine) acc[k] += bf2f(g[k]);
             }
         }
+        bf16* dst = dx + ((n * H + iy) * (long)W + ix) * ldx + cg * 8;
         bf16x8 v;
+        if (accumulate) {
+            const bf16x8 o = ld8(dst);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = f2bf(acc[k] * ws);
-        st8(dx + ((n * H + iy) * (long)W + ix) * ldx + cg * 8, v);
+            for (int k = 0; k < 8; ++k) v[k] = f2bf(fmaf(acc[k], ws, bf2f(o[k])));
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = f2bf(acc[k] * ws);
+        }
+        st8(dst, v);
     }
 }
 
@@ -601,7 +608,7 @@ __global__ __launch_bounds__(256) void up2_fwd_kernel(const bf16* in, int ldi, b
     }
 }
 __global__ __launch_bounds__(256) void sum2x2_kernel(const bf16* g, int ldg, bf16* out, int ldo, const float* wscale, int N, int H, int W,
-                                                     int C) {   // H, W = LOW resolution
+                                                     int C, int accumulate) {   // H, W = LOW resolution
     const int C8 = C >> 3;
     const long total = (long)N * H * W * C8;
     const float ws = wscale ? *wscale : 1.0f;
@@ -623,10 +630,17 @@ __global__ __launch_bounds__(256) void sum2x2_kernel(const bf16* g, int ldg, bf1
 #pragma unroll
                 for (int k = 0; k < 8; ++k) acc[k] += bf2f(v[k]);
             }
+        bf16* dst = out + ((n * H + y) * (long)W + x) * ldo + cg * 8;
         bf16x8 o;
+        if (accumulate) {
+            const bf16x8 prev = ld8(dst);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) o[k] = f2bf(acc[k] * ws);
-        st8(out + ((n * H + y) * (long)W + x) * ldo + cg * 8, o);
+            for (int k = 0; k < 8; ++k) o[k] = f2bf(fmaf(acc[k], ws, bf2f(prev[k])));
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = f2bf(acc[k] * ws);
+        }
+        st8(dst, o);
     }
 }
 
@@ -723,6 +737,7 @@ struct FuseBwd {
     const bf16* dout; int ldd;
     bf16* g; int ldg;
     bf16* din[3]; int ldin[3];      // only for mode 1 inputs (else null)
+    int acc[3];                     // 1: din[i] += (the tensor already holds the gradient of another consumer)
     float* pw;
 };
 __global__ __launch_bounds__(256) void fuse_bwd_kernel(const FuseBwd q) {
@@ -762,10 +777,17 @@ __global__ __launch_bounds__(256) void fuse_bwd_kernel(const FuseBwd q) {
             for (int k = 0; k < 8; ++k) dw[i] = fmaf(gg[k], v[i][k], dw[i]);
             if (p.mode[i] == 1 && q.din[i]) {
                 const float wi = p.w[i];
+                bf16* dst = q.din[i] + orow * q.ldin[i] + cg * 8;
                 bf16x8 o;
+                if (q.acc[i]) {
+                    const bf16x8 prev = ld8(dst);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) o[k] = f2bf(wi * gg[k]);
-                st8(q.din[i] + orow * q.ldin[i] + cg * 8, o);
+                    for (int k = 0; k < 8; ++k) o[k] = f2bf(fmaf(wi, gg[k], bf2f(prev[k])));
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) o[k] = f2bf(wi * gg[k]);
+                }
+                st8(dst, o);
             }
         }
     }
@@ -1070,12 +1092,12 @@ extern "C" int hn_maxpool_bwd(const void* in, int ldi, const void* dout, int ldd
 }
 /* two-pass form: arg_ws = N*(H/2)*(W/2)*C bytes of scratch (arg-max of every window); same results as hn_maxpool_bwd */
 extern "C" int hn_maxpool_bwd2(const void* in, int ldi, const void* dout, int ldd, void* dx, int ldx, const float* wscale, void* arg_ws,
-                               int N, int H, int W, int C, int mode, hipStream_t st) {
+                               int N, int H, int W, int C, int mode, int accumulate, hipStream_t st) {
     HN_CHECK_ARG(in && dout && dx && arg_ws && (C & 7) == 0 && ((ldi | ldd | ldx) & 7) == 0 && !(H & 1) && !(W & 1));
     hipLaunchKernelGGL(maxpool_arg_kernel, dim3(ew_grid((long)N * (H >> 1) * (W >> 1) * (C >> 3))), dim3(256), 0, st, (const bf16*)in, ldi,
                        (unsigned char*)arg_ws, N, H, W, C, mode);
     hipLaunchKernelGGL(maxpool_bwd_arg_kernel, dim3(ew_grid((long)N * H * W * (C >> 3))), dim3(256), 0, st, (const unsigned char*)arg_ws,
-                       (const bf16*)dout, ldd, (bf16*)dx, ldx, wscale, N, H, W, C, mode);
+                       (const bf16*)dout, ldd, (bf16*)dx, ldx, wscale, N, H, W, C, mode, accumulate);
     HN_LAUNCH_CHECK();
 }
 extern "C" int hn_up2_fwd(const void* in, int ldi, void* out, int ldo, int N, int H, int W, int C, hipStream_t st) {
@@ -1084,10 +1106,11 @@ extern "C" int hn_up2_fwd(const void* in, int ldi, void* out, int ldo, int N, in
                        N, H, W, C);
     HN_LAUNCH_CHECK();
 }
-extern "C" int hn_sum2x2(const void* g, int ldg, void* out, int ldo, const float* wscale, int N, int H, int W, int C, hipStream_t st) {
+extern "C" int hn_sum2x2(const void* g, int ldg, void* out, int ldo, const float* wscale, int N, int H, int W, int C, int accumulate,
+                         hipStream_t st) {
     HN_CHECK_ARG(g && out && (C & 7) == 0 && ((ldg | ldo) & 7) == 0);
     hipLaunchKernelGGL(sum2x2_kernel, dim3(ew_grid((long)N * H * W * (C >> 3))), dim3(256), 0, st, (const bf16*)g, ldg, (bf16*)out, ldo, wscale,
-                       N, H, W, C);
+                       N, H, W, C, accumulate);
     HN_LAUNCH_CHECK();
 }
 
@@ -1118,13 +1141,14 @@ extern "C" int hn_fuse_bwd_blocks(int N, int H, int W, int C) {
 }
 // pw: fp32 [hn_fuse_bwd_blocks][3]; reduce with hn_rows_reduce(pw, dw, 1, blocks, 3, 1)
 extern "C" int hn_fuse_bwd(const void* const* in, const int* ld, const int* mode, const float* w, const void* dout, int ldd, void* g,
-                           int ldg, void* const* din, const int* ldin, float* pw, int N, int H, int W, int C, hipStream_t st) {
+                           int ldg, void* const* din, const int* ldin, const int* acc, float* pw, int N, int H, int W, int C,
+                           hipStream_t st) {
     FuseBwd q;
     HN_CHECK_ARG(dout && g && pw && din && ldin && ((ldd | ldg) & 7) == 0);
     const int rc = fill_fuse(q.f, in, ld, mode, w, nullptr, 8, N, H, W, C);
     if (rc) return rc;
     q.dout = (const bf16*)dout; q.ldd = ldd; q.g = (bf16*)g; q.ldg = ldg; q.pw = pw;
-    for (int i = 0; i < 3; ++i) { q.din[i] = (bf16*)din[i]; q.ldin[i] = ldin[i]; }
+    for (int i = 0; i < 3; ++i) { q.din[i] = (bf16*)din[i]; q.ldin[i] = ldin[i]; q.acc[i] = acc ? acc[i] : 0; }
     hipLaunchKernelGGL(fuse_bwd_kernel, dim3(hn_fuse_bwd_blocks(N, H, W, C)), dim3(256), 0, st, q);
     HN_LAUNCH_CHECK();
 }

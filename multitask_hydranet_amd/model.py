@@ -401,9 +401,16 @@ class HydraNet(nn.Module):
     def _fusew(self, name):
         return self._idx[name]                      # raw fusion parameter; relu / normalisation happen inside the Fuse op
 
-    def _cell(self, p, inputs, first):
-        """BiFPN._forward_fast_attention, net/bifpn.py:156-233."""
+    # consumers of a cell's five inputs inside the cell (fusion nodes): P3 feeds one node, P4..P7 two each (net/bifpn.py:186-231)
+    CELL_IN_COUNTS = (1, 2, 2, 2, 2)
+
+    def _cell_shared(self, p, inputs, first, ext):
+        """BiFPN._forward_fast_attention, net/bifpn.py:156-233.  Every map with more than one consumer goes through ops.share(): the
+        fusion nodes accumulate its gradient in place inside their backward kernels instead of leaving k-1 additions per k-consumer
+        tensor to the autograd engine.  inputs: backbone features (first cell) or [(aliases, slot)] * 5 from the previous cell;
+        ext[l] = consumers of output level l outside this cell; returns [(aliases, slot)] * 5."""
         red = lambda nm, t: self._cba(t, p + nm + ".0.conv", p + nm + ".1", BN_FPN, act=ACT_NONE)
+        sh = K.share
         if first:
             if len(inputs) == 4:                       # 4 backbone stages (small cfg): P6 is pooled from P5 (net/bifpn.py:158-160)
                 p3, p4, p5 = inputs[-3:]
@@ -411,29 +418,49 @@ class HydraNet(nn.Module):
             else:                                      # 5 stages (big cfg): the last stage is P6 (net/bifpn.py:162-165)
                 p3, p4, p5, p6r = inputs[-4:]
                 p6_in = red("p6_down_channel", p6r)
-            p7_in = K.MaxPool.apply(p6_in, 0)
-            p3_in, p4_in, p5_in = red("p3_down_channel", p3), red("p4_down_channel", p4), red("p5_down_channel", p5)
+            (p6a, p6b, p6c), s6 = sh(p6_in, 3)         # two fusion nodes + the pool that makes P7
+            p7_in = K.MaxPool.apply(p6c, 0)
+            p3a, s3 = red("p3_down_channel", p3), None
+            (p4a, p4b), s4a, s4b = (red("p4_down_channel", p4), red("p4_down_channel_2", p4)), None, None
+            (p5a, p5b), s5a, s5b = (red("p5_down_channel", p5), red("p5_down_channel_2", p5)), None, None
         else:
-            p4 = p5 = None
-            p3_in, p4_in, p5_in, p6_in, p7_in = inputs
-        F = K.Fuse.apply
-        p6_up = self._sepconv(p + "conv6_up", F(self._fusew(p + "p6_w1"), 1, 2, 0, p6_in, p7_in, None))
-        p5_up = self._sepconv(p + "conv5_up", F(self._fusew(p + "p5_w1"), 1, 2, 0, p5_in, p6_up, None))
-        p4_up = self._sepconv(p + "conv4_up", F(self._fusew(p + "p4_w1"), 1, 2, 0, p4_in, p5_up, None))
-        p3_out = self._sepconv(p + "conv3_up", F(self._fusew(p + "p3_w1"), 1, 2, 0, p3_in, p4_up, None))
+            (p3a,), s3 = inputs[0]
+            (p4a, p4b), s4a = inputs[1]
+            (p5a, p5b), s5a = inputs[2]
+            (p6a, p6b), s6 = inputs[3]
+            s4b, s5b = s4a, s5a
         if first:
-            p4_in, p5_in = red("p4_down_channel_2", p4), red("p5_down_channel_2", p5)
-        p4_out = self._sepconv(p + "conv4_down", F(self._fusew(p + "p4_w2"), 1, 1, 3, p4_in, p4_up, p3_out))
-        p5_out = self._sepconv(p + "conv5_down", F(self._fusew(p + "p5_w2"), 1, 1, 3, p5_in, p5_up, p4_out))
-        p6_out = self._sepconv(p + "conv6_down", F(self._fusew(p + "p6_w2"), 1, 1, 3, p6_in, p6_up, p5_out))
-        p7_out = self._sepconv(p + "conv7_down", F(self._fusew(p + "p7_w2"), 1, 3, 0, p7_in, p6_out, None))
-        return p3_out, p4_out, p5_out, p6_out, p7_out
+            (p7a, p7b), s7 = sh(p7_in, 2)
+        else:
+            (p7a, p7b), s7 = inputs[4]
+        F = K.Fuse.apply
+        w = lambda nm: self._fusew(p + nm)
+        (u6a, u6b), t6 = sh(self._sepconv(p + "conv6_up", F(w("p6_w1"), 1, 2, 0, p6a, p7a, None, (s6, s7, None))), 2)
+        (u5a, u5b), t5 = sh(self._sepconv(p + "conv5_up", F(w("p5_w1"), 1, 2, 0, p5a, u6a, None, (s5a, t6, None))), 2)
+        (u4a, u4b), t4 = sh(self._sepconv(p + "conv4_up", F(w("p4_w1"), 1, 2, 0, p4a, u5a, None, (s4a, t5, None))), 2)
+        o3, q3 = sh(self._sepconv(p + "conv3_up", F(w("p3_w1"), 1, 2, 0, p3a, u4a, None, (s3, t4, None))), 1 + ext[0])
+        o4, q4 = sh(self._sepconv(p + "conv4_down", F(w("p4_w2"), 1, 1, 3, p4b, u4b, o3[0], (s4b, t4, q3))), 1 + ext[1])
+        o5, q5 = sh(self._sepconv(p + "conv5_down", F(w("p5_w2"), 1, 1, 3, p5b, u5b, o4[0], (s5b, t5, q4))), 1 + ext[2])
+        o6, q6 = sh(self._sepconv(p + "conv6_down", F(w("p6_w2"), 1, 1, 3, p6b, u6b, o5[0], (s6, t6, q5))), 1 + ext[3])
+        o7, q7 = sh(self._sepconv(p + "conv7_down", F(w("p7_w2"), 1, 3, 0, p7b, o6[0], None, (s7, q6, None))), ext[4])
+        return [(o3[1:], q3), (o4[1:], q4), (o5[1:], q5), (o6[1:], q6), (o7, q7)]
 
-    def _neck(self, feats):
+    def _cell(self, p, inputs, first):
+        """one BiFPN cell on plain tensors (the reference's module surface, per-segment tests): every output has one outside consumer"""
+        ins = list(inputs) if first else [K.share(t, c) for t, c in zip(inputs, self.CELL_IN_COUNTS)]
+        return tuple(a[0] for a, _ in self._cell_shared(p, ins, first, (1, 1, 1, 1, 1)))
+
+    def _neck_shared(self, feats, head_counts):
+        """-> per pyramid level a tuple of head_counts[l] aliases of the fused map (one per head that consumes it)"""
         x = list(feats)
         for k in range(self.fpn_cell_repeats):
-            x = self._cell(f"neck.bifpn.{k}.", x, k == 0)
-        return x
+            last = k == self.fpn_cell_repeats - 1
+            x = self._cell_shared(f"neck.bifpn.{k}.", x, k == 0, head_counts if last else self.CELL_IN_COUNTS)
+        return [aliases for aliases, _ in x]
+
+    def _neck(self, feats):
+        """BiFPN stack on plain tensors: the five fused maps"""
+        return [a[0] for a in self._neck_shared(feats, (1, 1, 1, 1, 1))]
 
     def _seg(self, feats_seg):
         """SegmentHeader.forward, head_seg/segmentation.py:84-105 -> fp32 logits, NCHW-shaped (channels-last memory)."""
@@ -587,7 +614,12 @@ class HydraNet(nn.Module):
 
     def _forward(self, x, mode):
         feats = self._backbone(x)
-        fused = self._neck(feats)
+        # consumers of every fused pyramid level among the heads: det towers (all five), seg decoder (P3..P5), lane fusion (P3..P6)
+        users = [[h for h, on, lv in (("det", self.train_detect, range(5)), ("seg", self.train_seg, range(3)), ("lane", self.train_lane, range(4)))
+                  if on and l in lv] for l in range(5)]
+        al = self._neck_shared(feats, tuple(max(len(u), 1) for u in users))
+        pick = lambda head: [al[l][users[l].index(head)] if head in users[l] else al[l][0] for l in range(5)]
+        fused_det, fused_seg, fused_lane = pick("det"), pick("seg"), pick("lane")
         out = {}
         seg = anchors = reg = cls = lane_cls = lane_reg = None
         # The detection and lane heads are chains of small launches that are independent of the (large) segmentation decoder: they run on a
@@ -600,14 +632,14 @@ class HydraNet(nn.Module):
             side.wait_stream(cur)
         with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
             if self.train_detect:
-                anchors, reg, cls = self._det(x, fused)
+                anchors, reg, cls = self._det(x, fused_det)
                 out["detection"] = {"anchors": anchors, "regression": reg, "classification": cls}
             if self.train_lane:
-                lane = self._lane(fused)
+                lane = self._lane(fused_lane)
                 out["lane"] = lane
                 lane_cls, lane_reg = lane["predict_cls"], lane["predict_loc"]
         if self.train_seg:
-            seg = self._seg([feats[0], fused[0], fused[1], fused[2]])
+            seg = self._seg([feats[0], fused_seg[0], fused_seg[1], fused_seg[2]])
             out["seg"] = seg
         if side is not None:
             cur.wait_stream(side)

@@ -806,11 +806,13 @@ def k_maxpool(x, mode, out=None):
     return out
 
 
-def k_maxpool_bwd(x, dout, mode, wscale=None):
+def k_maxpool_bwd(x, dout, mode, wscale=None, into=None, accumulate=False):
+    """into: destination of x's shape (default: a new tensor); accumulate: add to what `into` already holds (GradSlot)"""
     n, h, w, c = x.shape
-    dx = new_act(n, h, w, c, x.device)
+    dx = new_act(n, h, w, c, x.device) if into is None else into
     arg = torch.empty((n * (h // 2) * (w // 2) * c,), device=x.device, dtype=torch.uint8)
-    lib().call("hn_maxpool_bwd2", ptr(x), ld(x), ptr(dout), ld(dout), ptr(dx), ld(dx), ptr(wscale), ptr(arg), n, h, w, c, mode)
+    lib().call("hn_maxpool_bwd2", ptr(x), ld(x), ptr(dout), ld(dout), ptr(dx), ld(dx), ptr(wscale), ptr(arg), n, h, w, c, mode,
+               1 if accumulate else 0)
     return dx
 
 
@@ -837,11 +839,55 @@ def _fuse_args(ins, modes):
     return arr_p, arr_l, arr_m
 
 
-class Fuse(torch.autograd.Function):
-    """out = swish(w0*T0(a) + w1*T1(b) [+ w2*T2(c)]), w = relu(p)/(sum relu(p) + 1e-4) from the raw fusion parameter p (2 or 3 values)."""
+class GradSlot:
+    """Where the consumers of one multi-consumer tensor meet in backward: the first consumer to run allocates `buf` and stores its
+    contribution, the later ones add theirs in place inside their own kernels.  Share.backward hands `buf` to the producer."""
+    __slots__ = ("buf",)
+
+    def __init__(self):
+        self.buf = None
+
+
+class Share(torch.autograd.Function):
+    """Identity with n aliases, one per consumer of x (a BiFPN map feeds 2-3 fusion nodes, net/bifpn.py:186-231).  Consumers that were
+    given the slot accumulate their input gradient into slot.buf inside their own backward kernels and return None for this input;
+    consumers that do not know about slots return a gradient as usual and it is added here with one elementwise launch.  Without this
+    node the autograd engine sums the k gradients of a k-consumer tensor with k-1 separate ATen add kernels (54 per step)."""
 
     @staticmethod
-    def forward(ctx, praw, m0, m1, m2, a, b, c):
+    def forward(ctx, x, slot, n):
+        ctx.slot = slot
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        buf, ctx.slot.buf = ctx.slot.buf, None
+        for g in grads:
+            if g is None:
+                continue
+            if buf is None:
+                buf = dense(g)
+            else:
+                g = dense(g)
+                k_eltwise(0, buf, g, out=buf)
+        return buf, None, None
+
+
+def share(x, n):
+    """-> (aliases, slot) for a tensor with n consumers; n == 1: the tensor itself and no slot"""
+    if n <= 1 or not x.requires_grad:
+        return (x,) * max(n, 1), None
+    slot = GradSlot()
+    return Share.apply(x, slot, n), slot
+
+
+class Fuse(torch.autograd.Function):
+    """out = swish(w0*T0(a) + w1*T1(b) [+ w2*T2(c)]), w = relu(p)/(sum relu(p) + 1e-4) from the raw fusion parameter p (2 or 3 values).
+    slots (optional): one GradSlot | None per input -- the gradient of a slotted input is accumulated into slot.buf (see Share)."""
+
+    @staticmethod
+    def forward(ctx, praw, m0, m1, m2, a, b, c, slots=None):
         ins = [a, b, c]
         modes = [m0, m1, m2]
         n, h, wd, ch = a.shape                        # input 0 is always at the output resolution (mode 1)
@@ -853,6 +899,7 @@ class Fuse(torch.autograd.Function):
         ap, al, am = _fuse_args(ins, modes)
         lib().call("hn_fuse_fwd", ctypes.addressof(ap), ctypes.addressof(al), ctypes.addressof(am), ptr(w), ptr(out), ld(out), n, h, wd, ch)
         ctx.modes = modes
+        ctx.slots = slots if slots is not None else (None, None, None)
         ctx.save_for_backward(praw, w, *[t for t in ins if t is not None])
         return out
 
@@ -860,31 +907,41 @@ class Fuse(torch.autograd.Function):
     def backward(ctx, dout):
         praw, w = ctx.saved_tensors[0], ctx.saved_tensors[1]
         rest = list(ctx.saved_tensors[2:])
-        modes = ctx.modes
+        modes, slots = ctx.modes, ctx.slots
         ins = [rest.pop(0) if m else None for m in modes]
         dout = dense(dout)
         n, h, wd, ch = dout.shape
         dev = dout.device
         g = new_act(n, h, wd, ch, dev)
-        dins = [new_act(n, h, wd, ch, dev) if m == 1 else None for m in modes]
+        # destination of every input gradient: a fresh tensor, or the slot's buffer (first consumer: allocate + store, later: accumulate)
+        dst, accum = [None] * 3, [0] * 3
+        for i, m in enumerate(modes):
+            if not m:
+                continue
+            s = slots[i]
+            if s is not None and s.buf is not None:
+                dst[i], accum[i] = s.buf, 1
+            else:
+                dst[i] = new_act(*ins[i].shape, dev)
+                if s is not None:
+                    s.buf = dst[i]
         ap, al, am = _fuse_args(ins, modes)
-        dp_ = (ctypes.c_void_p * 3)(*[ptr(t) if t is not None else None for t in dins])
-        dl = (ctypes.c_int * 3)(*[ld(t) if t is not None else 0 for t in dins])
+        dp_ = (ctypes.c_void_p * 3)(*[ptr(dst[i]) if modes[i] == 1 else None for i in range(3)])
+        dl = (ctypes.c_int * 3)(*[ld(dst[i]) if modes[i] == 1 else 0 for i in range(3)])
+        da = (ctypes.c_int * 3)(*accum)
         blocks = lib().query("hn_fuse_bwd_blocks", n, h, wd, ch)
         pw = torch.empty((blocks, 3), device=dev, dtype=F32)
         lib().call("hn_fuse_bwd", ctypes.addressof(ap), ctypes.addressof(al), ctypes.addressof(am), ptr(w), ptr(dout), ld(dout), ptr(g), ld(g),
-                   ctypes.addressof(dp_), ctypes.addressof(dl), ptr(pw), n, h, wd, ch)
+                   ctypes.addressof(dp_), ctypes.addressof(dl), ctypes.addressof(da), ptr(pw), n, h, wd, ch)
         dpraw = torch.empty_like(praw)
         lib().call("hn_fuse_dweights", ptr(pw), blocks, ptr(praw), praw.numel(), 1e-4, ptr(dpraw))
         for i, m in enumerate(modes):
             if m == 2:                                               # nearest x2 of a half-res input: 2x2 sum of g
-                t = ins[i]
-                d = new_act(*t.shape, dev)
-                lib().call("hn_sum2x2", ptr(g), ld(g), ptr(d), ld(d), ptr(w[i]), n, h // 2, wd // 2, ch)
-                dins[i] = d
+                lib().call("hn_sum2x2", ptr(g), ld(g), ptr(dst[i]), ld(dst[i]), ptr(w[i]), n, h // 2, wd // 2, ch, accum[i])
             elif m == 3:                                             # zero-pad-same max pool of a double-res input
-                dins[i] = k_maxpool_bwd(ins[i], g, 0, wscale=w[i])
-        return dpraw, None, None, None, dins[0], dins[1], dins[2]
+                k_maxpool_bwd(ins[i], g, 0, wscale=w[i], into=dst[i], accumulate=bool(accum[i]))
+        dins = [None if (slots[i] is not None or not modes[i]) else dst[i] for i in range(3)]
+        return dpraw, None, None, None, dins[0], dins[1], dins[2], None
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -1040,7 +1097,7 @@ class LaneConcat(torch.autograd.Function):
         d4 = k_maxpool_bwd(p4, dout[..., c:2 * c], 1)
         d5 = k_eltwise(2, dout[..., 2 * c:3 * c], alpha=1.0)
         d6 = new_act(n, h // 2, w // 2, c, dout.device)
-        lib().call("hn_sum2x2", ptr(dout[..., 3 * c:]), ld(dout), ptr(d6), ld(d6), None, n, h // 2, w // 2, c)
+        lib().call("hn_sum2x2", ptr(dout[..., 3 * c:]), ld(dout), ptr(d6), ld(d6), None, n, h // 2, w // 2, c, 0)
         return d3, d4, d5, d6
 
 

@@ -204,6 +204,45 @@ def test_maxpool(K, mode, c, n, h, w):
     close(nchw(xk.grad), xr.grad, 1e-2, "dx")          # only bf16 rounding of summed routed gradients
 
 
+@pytest.mark.parametrize("order", [0, 1])
+def test_shared_gradient_slots(K, order):
+    """ops.share / GradSlot: a map consumed by three fusion nodes (as the identity input of one, up-sampled into a second, max-pooled into
+    a third) plus one consumer that knows nothing about slots gets the SAME gradient as when the autograd engine sums the four
+    contributions itself (in-place fp32 accumulation rounds once per consumer, the engine's bf16 adds as well: bf16-level tolerance)."""
+    n, c, h, w = 2, 16, 8, 12
+    x = rnd(n, c, h, w)                      # the shared map
+    a_hi, b_hi = rnd(n, c, 2 * h, 2 * w), rnd(n, c, 2 * h, 2 * w)      # double-resolution node: x enters up-sampled (mode 2)
+    a_lo = rnd(n, c, h // 2, w // 2)                                  # half-resolution node: x enters max-pooled (mode 3)
+    b_same = rnd(n, c, h, w)
+    ps = [torch.rand(2, device=dev()) + 0.2, torch.rand(3, device=dev()) + 0.2, torch.rand(2, device=dev()) + 0.2]
+    ups = [rnd(n, c, h, w), rnd(n, c, 2 * h, 2 * w), rnd(n, c, h // 2, w // 2), rnd(n, c, h, w)]
+
+    def run(shared):
+        xk = nhwc(x).requires_grad_(True)
+        if shared:
+            (x0, x1, x2, x3), slot = K.share(xk, 4)
+        else:
+            (x0, x1, x2, x3), slot = (xk,) * 4, None
+        pk = [p.clone().requires_grad_(True) for p in ps]
+        nodes = [lambda: K.Fuse.apply(pk[0], 1, 1, 0, x0, nhwc(b_same), None, (slot, None, None)),
+                 lambda: K.Fuse.apply(pk[1], 1, 1, 2, nhwc(a_hi), nhwc(b_hi), x1, (None, None, slot)),
+                 lambda: K.Fuse.apply(pk[2], 1, 3, 0, nhwc(a_lo), x2, None, (None, slot, None))]
+        outs = [None] * 3
+        for i in ([0, 1, 2] if order == 0 else [2, 0, 1]):      # backward visits the nodes in reverse creation order
+            outs[i] = nodes[i]()
+        plain = x3 * 0.5                                        # a consumer without slot support: its gradient is added by Share.backward
+        loss = sum((o.float() * nhwc(u).float()).sum() for o, u in zip(outs, ups[:3])) + (plain.float() * nhwc(ups[3]).float()).sum()
+        loss.backward()
+        assert slot is None or slot.buf is None, "Share.backward hands the buffer over and resets the slot"
+        return xk.grad.float(), [p.grad.clone() for p in pk]
+
+    g_ref, pg_ref = run(False)
+    g, pg = run(True)
+    close(g, g_ref, 1e-2, "shared dx")
+    for a, b in zip(pg, pg_ref):
+        close(a, b, 1e-3, "fusion parameter gradients")
+
+
 @pytest.mark.parametrize("modes", [(1, 2, 0), (1, 1, 3), (1, 3, 0)])
 def test_bifpn_fuse(K, modes):
     n, c, h, w = 2, 16, 8, 12
