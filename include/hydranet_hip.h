@@ -70,11 +70,14 @@ int hn_direct_stat_rows(int n_img, int H, int W);
  * operand path (net/anynet.py:67-70: conv_block_3 consumes SE(relu(bn2(conv_block_2)))), nothing materialised; and (b) an addend for the
  * staged bf16 epilogue: out = bf16(bf16(acc) + addend[pixel][cout]) (the residual-gradient add of an XBlock's conv_block_1 dgrad); with
  * ld_add < 0 the addend (row stride -ld_add) goes in BEFORE the activation: out = act(acc + bias + addend) -- inference with folded
- * BatchNorm: conv_block_3 + identity branch + ReLU of an XBlock in one launch (net/anynet.py:70-76). */
+ * BatchNorm: conv_block_3 + identity branch + ReLU of an XBlock in one launch (net/anynet.py:70-76).  add_mode 1 (mode 0, ld_add > 0,
+ * even H, W): the addend lives on the stride-2 sub-grid [N][H/2][W/2] and is added at even (y, x) only -- the data gradient of a
+ * stride-2 XBlock's shortcut conv joins the data gradient of its conv_block_1 (both read the same input, net/anynet.py:65-76) without a
+ * zero-filled full-resolution tensor and a separate addition. */
 int hn_conv_gemm_nt_ex(const void* x0, const void* x1, int mode, int n_img, int H, int W, int C0, int C1, int ld0, int ld1, int up, long M,
                        const void* w, int Nout, int KP, int taps, const float* bias, int act, void* out, int out_f32, int ldc, long rpi,
                        long img_stride, float* psum, float* psq, const float* xscale, const float* xshift, const float* xgate, long xhw,
-                       int xact, const void* addend, int ld_add, hipStream_t stream);
+                       int xact, const void* addend, int ld_add, int add_mode, hipStream_t stream);
 /* tuning hook for tools/: force the cout tile (16/32/64/128) and LDS ring depth (2..4) of later hn_conv_gemm_nt launches; 0 = automatic */
 int hn_debug_nt_config(int bc, int r);
 /* tools/ A/B hook: 1 = software-pipelined direct 3x3 kernel (one workgroup per CU, weight ring of 3 + 2 patch buffers), 0 (default, faster

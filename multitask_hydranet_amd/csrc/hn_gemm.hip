@@ -143,6 +143,8 @@ struct GemmNT {
     // taps ky in {py, py+1}, kx in {px, px+1}, so 4 of the 9 taps are visited (2.25x fewer MACs than convolving the up-sampled map):
     //   phase_mode 1 (forward): the cout tile's phase = cout / phase_span;  2 (data gradient, mode 3): the K chunk's phase = channel / phase_span
     int phase_mode, phase_span;
+    int add_s2;                       // 1: the addend lives on the stride-2 sub-grid [N][H/2][W/2] and is added at even (y, x) only (the data
+                                      //    gradient of a stride-2 1x1 conv joining the gradient of a full-resolution 1x1 conv of the same input)
     int add_pre;                      // 1: the addend goes in BEFORE the activation: out = act(acc + bias + addend) (inference: folded
                                       // BatchNorm + identity branch + ReLU of an XBlock in conv_block_3's epilogue)
 };
@@ -514,9 +516,20 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
                     orow = (long)im * p.img_stride + (long)((unsigned)pix - im * (unsigned)p.rpi) * p.ldc;
                 }
                 if (p.addend && !p.add_pre) {
-                    const bf16x8 a = ld8(p.addend + pix * p.ld_add + co);
+                    long arow = pix;
+                    bool has = true;
+                    if (p.add_s2) {
+                        const unsigned W = (unsigned)p.x.W, H = (unsigned)p.x.H;
+                        const unsigned x = (unsigned)pix % W, t = (unsigned)pix / W;
+                        const unsigned y = t % H, n = t / H;
+                        has = !((x | y) & 1u);
+                        arow = ((long)n * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1);
+                    }
+                    if (has) {
+                        const bf16x8 a = ld8(p.addend + arow * p.ld_add + co);
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = f2bf(bf2f(v[k]) + bf2f(a[k]));
+                        for (int k = 0; k < 8; ++k) v[k] = f2bf(bf2f(v[k]) + bf2f(a[k]));
+                    }
                 }
                 *reinterpret_cast<bf16x8*>(outp + orow + co) = v;
             }
@@ -1479,23 +1492,23 @@ extern "C" int hn_nt_stat_rows(long M, int Nout) {               // one partial 
 static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img, int H, int W, int C0, int C1, int ld0, int ld1,
                              int up, long M, const void* w, int Nout, int KP, int taps, const float* bias, int act, void* out,
                              int out_f32, int ldc, long rpi, long img_stride, float* psum, float* psq, const float* xscale,
-                             const float* xshift, const float* xgate, long xhw, int xact, const void* addend, int ld_add, int phase_mode,
-                             int phase_span, hipStream_t st);
+                             const float* xshift, const float* xgate, long xhw, int xact, const void* addend, int ld_add, int add_mode,
+                             int phase_mode, int phase_span, hipStream_t st);
 
 extern "C" int hn_conv_gemm_nt(const void* x0, const void* x1, int mode, int n_img, int H, int W, int C0, int C1, int ld0, int ld1,
                                int up, long M, const void* w, int Nout, int KP, int taps, const float* bias, int act, void* out,
                                int out_f32, int ldc, long rpi, long img_stride, float* psum, float* psq, hipStream_t st) {
     return conv_gemm_nt_impl(x0, x1, mode, n_img, H, W, C0, C1, ld0, ld1, up, M, w, Nout, KP, taps, bias, act, out, out_f32, ldc, rpi,
-                             img_stride, psum, psq, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, 0, 0, st);
+                             img_stride, psum, psq, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, 0, 0, 0, st);
 }
 
 extern "C" int hn_conv_gemm_nt_ex(const void* x0, const void* x1, int mode, int n_img, int H, int W, int C0, int C1, int ld0, int ld1,
                                   int up, long M, const void* w, int Nout, int KP, int taps, const float* bias, int act, void* out,
                                   int out_f32, int ldc, long rpi, long img_stride, float* psum, float* psq, const float* xscale,
                                   const float* xshift, const float* xgate, long xhw, int xact, const void* addend, int ld_add,
-                                  hipStream_t st) {
+                                  int add_mode, hipStream_t st) {
     return conv_gemm_nt_impl(x0, x1, mode, n_img, H, W, C0, C1, ld0, ld1, up, M, w, Nout, KP, taps, bias, act, out, out_f32, ldc, rpi,
-                             img_stride, psum, psq, xscale, xshift, xgate, xhw, xact, addend, ld_add, 0, 0, st);
+                             img_stride, psum, psq, xscale, xshift, xgate, xhw, xact, addend, ld_add, add_mode, 0, 0, st);
 }
 
 /* Phase form of Conv3x3(ReflectionPad2d(1)(nearest_up2(x0))) on the low-resolution grid (head_seg/segmentation.py:92-104 decoder blocks
@@ -1509,18 +1522,18 @@ extern "C" int hn_conv3x3_phase(const void* x0, int mode, int n_img, int H, int 
     if (mode == 4) {
         HN_CHECK_ARG(Nout == 4 * k && (k % 64 == 0) && (!addend || (ld_add & 3) == 0));
         return conv_gemm_nt_impl(x0, nullptr, 4, n_img, H, W, C0, 0, ld0, 0, 0, (long)n_img * H * W, w, Nout, KP, 9, bias, act, out, 0, ldc, 0,
-                                 -(long)k, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, addend, -ld_add, 1, k, st);
+                                 -(long)k, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, addend, -ld_add, 0, 1, k, st);
     }
     HN_CHECK_ARG(C0 == 4 * k && (k % 64 == 0) && !addend);
     return conv_gemm_nt_impl(x0, nullptr, 3, n_img, H, W, C0, 0, ld0, 0, 0, (long)n_img * H * W, w, Nout, KP, 9, bias, act, out, 0, ldc, 0, 0,
-                             nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, 2, k, st);
+                             nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, 0, 2, k, st);
 }
 
 static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img, int H, int W, int C0, int C1, int ld0, int ld1,
                              int up, long M, const void* w, int Nout, int KP, int taps, const float* bias, int act, void* out,
                              int out_f32, int ldc, long rpi, long img_stride, float* psum, float* psq, const float* xscale,
-                             const float* xshift, const float* xgate, long xhw, int xact, const void* addend, int ld_add, int phase_mode,
-                             int phase_span, hipStream_t st) {
+                             const float* xshift, const float* xgate, long xhw, int xact, const void* addend, int ld_add, int add_mode,
+                             int phase_mode, int phase_span, hipStream_t st) {
     HN_CHECK_ARG(x0 && w && out && M > 0 && Nout > 0 && KP > 0 && (KP & 31) == 0 && taps >= 1 && taps <= 9);
     // operand transform: plain / stride-2 row gathers, bf16 output; addend: staged bf16 epilogue only (aligned rows, no per-image mapping)
     HN_CHECK_ARG(!xscale || (xshift && mode <= 1 && !out_f32 && C1 == 0 && (!xgate || xhw > 0)));
@@ -1544,6 +1557,9 @@ static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img
     p.d2s = 0;
     p.xscale = xscale; p.xshift = xshift; p.xgate = xgate; p.xhw = xhw; p.xact = xact;
     p.addend = (const bf16*)addend; p.ld_add = ld_add < 0 ? -ld_add : ld_add; p.add_pre = ld_add < 0 ? 1 : 0;
+    HN_CHECK_ARG(add_mode == 0 || (add_mode == 1 && addend && ld_add > 0 && mode == 0 && !(H & 1) && !(W & 1) && (long)n_img * H * W == M &&
+                                   M < (1L << 32)));
+    p.add_s2 = add_mode;
     p.phase_mode = phase_mode; p.phase_span = phase_span;
     if (img_stride < 0) {                                            // mode 4: -img_stride = channels per depth-to-space output pixel
         HN_CHECK_ARG(p.x.clamp == 1 && (out_f32 || phase_mode == 1) && rpi == 0 && !psum && Nout == 4 * (int)(-img_stride));

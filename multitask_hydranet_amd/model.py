@@ -367,9 +367,10 @@ class HydraNet(nn.Module):
             return self._cba(b, q + "conv_block_3.0", q + "conv_block_3.1", BN_STD, res=s, act=ACT_RELU)
         if K.xblock_fusable(x, P[q + "conv_block_1.0.weight"], stride, has_se, has_sc):     # one autograd node, 9 + 21 launches
             bn = [self._bn(q + f"conv_block_{i}.1")[:4] for i in (1, 2, 3)]
+            sc = (P[q + "shortcut.0.weight"], *self._bn(q + "shortcut.1")[:4]) if has_sc else ()
             return K.XBlockFn.apply(x, P[q + "conv_block_1.0.weight"], *bn[0], P[q + "conv_block_2.0.weight"], *bn[1],
                                     P[q + "se.1.weight"], P[q + "se.1.bias"], P[q + "se.3.weight"], P[q + "se.3.bias"],
-                                    P[q + "conv_block_3.0.weight"], *bn[2], BN_STD["eps"], BN_STD["momentum"], self.training)
+                                    P[q + "conv_block_3.0.weight"], *bn[2], BN_STD["eps"], BN_STD["momentum"], self.training, stride, *sc)
         a = self._cba(x, q + "conv_block_1.0", q + "conv_block_1.1", BN_STD, act=ACT_RELU)
         b = self._cba(a, q + "conv_block_2.0", q + "conv_block_2.1", BN_STD, kind="g3x3", stride=stride, act=ACT_RELU)
         if (q + "se.1.weight") in P:

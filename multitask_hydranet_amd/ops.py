@@ -223,10 +223,10 @@ def pack_dw_weight(w: torch.Tensor):
 # raw kernel wrappers (no autograd)
 # --------------------------------------------------------------------------------------------------------------
 def k_gemm_nt(x0, x1, mode, grid, wp, nout, kp, taps, bias=None, act=ACT_NONE, out=None, out_f32=False, up=0, stats=False,
-              c0=None, c1=None, rpi=0, img_stride=0, ldc=None, xform=None, addend=None, add_pre=False):
+              c0=None, c1=None, rpi=0, img_stride=0, ldc=None, xform=None, addend=None, add_pre=False, add_s2=False):
     """grid = (N, H, W) of the OUTPUT pixel grid.  Returns (out, psum, psq).
     xform = (scale, shift, gate | None, rows_per_image, act): operand transform of hn_conv_gemm_nt_ex; addend: bf16 tensor added in the
-    epilogue (same rows / channels as the output)."""
+    epilogue (same rows / channels as the output; add_s2: the addend lives on the stride-2 sub-grid and is added at even (y, x))."""
     n, h, w = grid
     m = n * h * w
     dev = x0.device
@@ -249,7 +249,7 @@ def k_gemm_nt(x0, x1, mode, grid, wp, nout, kp, taps, bias=None, act=ACT_NONE, o
         lib().call("hn_conv_gemm_nt_ex", ptr(x0), ptr(x1), mode, n, h, w, c0, c1, ld(x0), ld(x1) if x1 is not None else 0, up, m,
                    ptr(wp), nout, kp, taps, ptr(bias), act, ptr(out), 1 if out_f32 else 0, ldc, rpi, img_stride, ptr(psum), ptr(psq),
                    ptr(xs), ptr(xh), ptr(xg), xhw, xact, ptr(addend),
-                   (-ld(addend) if add_pre else ld(addend)) if addend is not None else 0)
+                   (-ld(addend) if add_pre else ld(addend)) if addend is not None else 0, 1 if add_s2 else 0)
     return out, psum, psq
 
 
@@ -568,18 +568,32 @@ XBLOCK_XF_GEMM = os.environ.get("HN_XBLOCK_XF", "0") == "1"
 
 
 class XBlockFn(torch.autograd.Function):
+    """stride 1 without shortcut: the identity blocks; stride 2 (or a channel change) with the projection shortcut conv + BN
+    (ws, gs, bs, rms, rvs): the first block of every stage.  There the grouped conv runs on the stride-2 stencil kernels, and the data
+    gradient of the shortcut (a stride-2 row gather) joins conv_block_1's data gradient in that GEMM's epilogue (add_s2): x has ONE
+    consumer node, no zero-filled full-resolution tensor, no separate additions."""
+
     @staticmethod
-    def forward(ctx, x, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, sw1, sb1, sw2, sb2, w3, g3, b3, rm3, rv3, eps, momentum, training):
-        n, h, w, c = x.shape
-        m, hw = n * h * w, h * w
+    def forward(ctx, x, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, sw1, sb1, sw2, sb2, w3, g3, b3, rm3, rv3, eps, momentum, training,
+                stride=1, ws=None, gs=None, bs=None, rms=None, rvs=None):
+        n, h, w, cin = x.shape
+        c = w1.shape[0]
+        ho, wo = h // stride, w // stride
+        m_in, m, hw = n * h * w, n * ho * wo, ho * wo
         cs = sw1.shape[0]
         dev = x.device
-        grid = (n, h, w)
+        grid = (n, ho, wo)
         wp1, wt1 = pack_conv_weight(w1)
-        z1, ps, pq = k_gemm_nt(x, None, 0, grid, wp1, c, kp32(c), 1, stats=training)
-        a, coef1, _, _ = k_bn_apply_fused(z1, ps, pq, m, g1, b1, eps, momentum, rm1, rv1, ACT_RELU, training=training)
-        wk2, wd2 = pack_gconv_diag(w2)
-        z2, ps, pq = k_gemm_nt(a, None, 5, grid, wk2, c, 64, 9, stats=training)
+        z1, ps, pq = k_gemm_nt(x, None, 0, (n, h, w), wp1, c, kp32(cin), 1, stats=training)
+        a, coef1, _, _ = k_bn_apply_fused(z1, ps, pq, m_in, g1, b1, eps, momentum, rm1, rv1, ACT_RELU, training=training)
+        if stride == 1:
+            wk2, wd2 = pack_gconv_diag(w2)
+            z2, ps, pq = k_gemm_nt(a, None, 5, grid, wk2, c, 64, 9, stats=training)
+        else:
+            wk2, wd2 = pack_gconv_weight(w2, 0)
+            z2 = new_act(n, ho, wo, c, dev)
+            lib().call("hn_gconv_fwd", ptr(a), ld(a), ptr(wk2), ptr(z2), ld(z2), n, h, w, c, stride)
+            ps, pq = k_col_stats_fused(z2) if training else (None, None)
         _, coef2, pool, rb = k_bn_apply_fused(z2, ps, pq, m, g2, b2, eps, momentum, rm2, rv2, ACT_RELU, want_out=False, pool_align=hw,
                                               training=training)
         pooled = torch.empty((n, c), device=dev, dtype=F32)
@@ -594,31 +608,39 @@ class XBlockFn(torch.autograd.Function):
         else:                   # second pass over z2: bg = relu(bn2(z2)) * gate, kept for conv_block_3's weight gradient
             bg, _, _, _ = k_bn_apply_fused(z2, None, None, m, g2, b2, eps, momentum, None, None, ACT_RELU, coef=coef2, gate=gate, hw=hw)
             z3, ps, pq = k_gemm_nt(bg, None, 0, grid, wp3, c, kp32(c), 1, stats=training)
-        out, coef3, _, _ = k_bn_apply_fused(z3, ps, pq, m, g3, b3, eps, momentum, rm3, rv3, ACT_RELU, res=x, training=training)
-        ctx.training = training
-        ctx.packs = (wt1, wd2, wt3)
-        ctx.save_for_backward(x, z1, a, z2, z3, out, coef1, coef2, coef3, pooled, hid, gate, sw1, sw2, bg)
+        zs = coefs = wts = None
+        res = x
+        if ws is not None:      # projection shortcut: 1x1 conv (stride-2 row gather) + BatchNorm, no activation
+            wps, wts = pack_conv_weight(ws)
+            zs, pss, pqs = k_gemm_nt(x, None, 0 if stride == 1 else 1, grid, wps, c, kp32(cin), 1, stats=training)
+            res, coefs, _, _ = k_bn_apply_fused(zs, pss, pqs, m, gs, bs, eps, momentum, rms, rvs, ACT_NONE, training=training)
+        out, coef3, _, _ = k_bn_apply_fused(z3, ps, pq, m, g3, b3, eps, momentum, rm3, rv3, ACT_RELU, res=res, training=training)
+        ctx.training, ctx.stride = training, stride
+        ctx.packs = (wt1, wd2, wt3, wts)
+        ctx.save_for_backward(x, z1, a, z2, z3, out, coef1, coef2, coef3, pooled, hid, gate, sw1, sw2, bg, zs, coefs)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, z1, a, z2, z3, out, coef1, coef2, coef3, pooled, hid, gate, sw1, sw2, bg = ctx.saved_tensors
+        x, z1, a, z2, z3, out, coef1, coef2, coef3, pooled, hid, gate, sw1, sw2, bg, zs, coefs = ctx.saved_tensors
         assert ctx.training, "backward through eval-mode BatchNorm is not part of the hot path"
-        wt1, wd2, wt3 = ctx.packs
+        wt1, wd2, wt3, wts = ctx.packs
+        stride = ctx.stride
         dout = dense(dout)
-        n, h, w, c = x.shape
-        m, hw = n * h * w, h * w
+        n, h, w, cin = x.shape
+        _, ho, wo, c = z2.shape
+        m_in, m, hw = n * h * w, n * ho * wo, ho * wo
         cs = sw1.shape[0]
         dev = x.device
-        grid = (n, h, w)
-        # out = relu(bn3(z3) + x): g = dout * [out > 0] is also the gradient of the identity branch
+        grid = (n, ho, wo)
+        # out = relu(bn3(z3) + shortcut): g = dout * [out > 0] is also the gradient of the shortcut branch
         dz3, dg3, db3, g = bn_backward_fused(dout, z3, out, coef3, ACT_RELU, m, want_g=True)
         dbg, _, _ = k_gemm_nt(dz3, None, 0, grid, wt3, c, kp32(c), 1)
         # one pass over (dbg, z2): gate-gradient partials and the gated operand bg = relu(bn2(z2)) * gate of conv_block_3's wgrad
         rb = lib().query("hn_fused_row_block", m, c, hw, 0, 1)
         make_bg = bg is None
         if make_bg:
-            bg = new_act(n, h, w, c, dev)
+            bg = new_act(n, ho, wo, c, dev)
         pdot = torch.empty(((m + rb - 1) // rb, c), device=dev, dtype=F32)
         lib().call("hn_se_bwd_reduce_fused", ptr(dbg), ld(dbg), ptr(z2), ld(z2), ptr(coef2), ptr(gate), hw, ptr(bg) if make_bg else None,
                    ld(bg), ptr(pdot), m, c, rb)
@@ -632,15 +654,30 @@ class XBlockFn(torch.autograd.Function):
                    ptr(dpool), ptr(dsw1), ptr(dsb1), ptr(dsw2), ptr(dsb2), n, c, cs)
         # BN2 backward with the SE data path folded in: g2 = (dbg * gate + dpool / HW) * [bn2(z2) > 0]
         dz2, dg2, db2, _ = bn_backward_fused(dbg, z2, None, coef2, ACT_RELU, m, gate=gate, dpool=dpool, hw=hw)
-        da, _, _ = k_gemm_nt(dz2, None, 5, grid, wd2, c, 64, 9)
-        dw2 = k_gemm_tn(a, None, 5, grid, dz2, c, 64, 9, 8, kh=3)
-        dz1, dg1, db1, _ = bn_backward_fused(da, z1, None, coef1, ACT_RELU, m)
+        if stride == 1:
+            da, _, _ = k_gemm_nt(dz2, None, 5, grid, wd2, c, 64, 9)
+            dw2 = k_gemm_tn(a, None, 5, grid, dz2, c, 64, 9, 8, kh=3)
+        else:
+            da = new_act(n, h, w, c, dev)
+            lib().call("hn_gconv_dgrad_s2", ptr(dz2), ld(dz2), ptr(wd2), ptr(da), ld(da), n, h, w, c)
+            chunks = lib().query("hn_wgrad_chunks", m, (c // 8) * 9)
+            part = torch.empty((chunks, c * 72), device=dev, dtype=F32)
+            lib().call("hn_gconv_wgrad", ptr(a), ld(a), ptr(dz2), ld(dz2), ptr(part), n, h, w, c, stride)
+            dw2 = k_rows_reduce(part, 1, chunks, c * 72).view(c, 8, 3, 3)
+        dz1, dg1, db1, _ = bn_backward_fused(da, z1, None, coef1, ACT_RELU, m_in)
+        dws = dgs = dbs = None
+        addend, add_s2 = g, False                               # identity block: + gradient of the identity branch
+        if zs is not None:
+            dzs, dgs, dbs, _ = bn_backward_fused(g, zs, None, coefs, ACT_NONE, m)
+            addend, _, _ = k_gemm_nt(dzs, None, 0, grid, wts, cin, kp32(c), 1)           # shortcut data gradient on the output grid
+            add_s2 = stride == 2
+            dws = k_gemm_tn(x, None, 0 if stride == 1 else 1, grid, dzs, c, kp32(cin), 1, cin)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx, _, _ = k_gemm_nt(dz1, None, 0, grid, wt1, c, kp32(c), 1, addend=g)      # + gradient of the identity branch
-        dw1 = k_gemm_tn(x, None, 0, grid, dz1, c, kp32(c), 1, c)
+            dx, _, _ = k_gemm_nt(dz1, None, 0, (n, h, w), wt1, cin, kp32(c), 1, addend=addend, add_s2=add_s2)
+        dw1 = k_gemm_tn(x, None, 0, (n, h, w), dz1, c, kp32(cin), 1, cin)
         return (dx, dw1, dg1, db1, None, None, dw2, dg2, db2, None, None, dsw1, dsb1, dsw2, dsb2, dw3, dg3, db3, None, None,
-                None, None, None)
+                None, None, None, None, dws, dgs, dbs, None, None)
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -707,10 +744,13 @@ def se_gate_infer(b, w1, b1, w2, b2):
 
 
 def xblock_fusable(x, w1, stride, has_se, has_shortcut):
-    """the fused node covers the stride-1 identity blocks with SE whose channel count is a multiple of 8 (every non-first block of a stage)"""
-    return (FUSED_XBLOCK and FUSED_BN and GCONV_MFMA and x.is_cuda and stride == 1 and has_se and not has_shortcut
-            and w1.shape[0] == w1.shape[1] and w1.shape[0] % 8 == 0 and (x.shape[1] * x.shape[2]) % 128 == 0
-            and 3 * kp32(w1.shape[0]) * 4 <= 32768)
+    """the fused node covers XBlocks with SE whose channel counts are multiples of 8 and whose output grid is a multiple of 128 pixels:
+    the stride-1 identity blocks and the stride-2 first block of a stage (projection shortcut)"""
+    cout, cin = w1.shape[0], w1.shape[1]
+    ho, wo = x.shape[1] // stride, x.shape[2] // stride
+    shape_ok = (stride == 1 and not has_shortcut and cout == cin) or (stride == 2 and has_shortcut and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0)
+    return (FUSED_XBLOCK and FUSED_BN and GCONV_MFMA and x.is_cuda and has_se and shape_ok and cout % 8 == 0 and cin % 8 == 0
+            and (ho * wo) % 128 == 0 and 3 * kp32(cout) * 4 <= 32768 and x.shape[0] * x.shape[1] * x.shape[2] < (1 << 31))
 
 
 # --------------------------------------------------------------------------------------------------------------
