@@ -116,9 +116,10 @@ int hn_dwconv_fwd(const void* in, int ldi, const void* wk, void* out, int ldo, i
 /* level-packed form: rows of nlev (<= 5) pyramid levels [N,H[l],W[l],C] stacked in one tensor, one launch (the det-head towers apply the
  * same SeparableConvBlock to every level, head_detect/detection.py:30-35,67-72) */
 /* row_align (>= 1): every level starts on a multiple of row_align rows ("ragged" packing: levels whose row count is not a multiple of the
- * 128-row GEMM / BatchNorm blocks are padded; this kernel writes ZEROS to the alignment rows so downstream sums can be corrected exactly) */
+ * 128-row GEMM / BatchNorm blocks are padded; this kernel writes ZEROS to the alignment rows so downstream sums can be corrected exactly).
+ * accumulate = 1: out += (used as the data gradient of a packed map that feeds both det towers: the second tower adds in place). */
 int hn_dwconv_fwd_levels(const void* in, int ldi, const void* wk, void* out, int ldo, int N, int C, int nlev, const int* H, const int* W,
-                         int row_align, hipStream_t stream);
+                         int row_align, int accumulate, hipStream_t stream);
 /* partial rows of hn_dwconv_wgrad*: strips = sum over levels of N * H * ceil(W / 4) (the kernel walks 4-pixel strips) */
 long hn_dwconv_wgrad_blocks(long strips, int C);
 int hn_dwconv_wgrad(const void* x, int ldx, const void* dz, int ldz, float* part, int N, int H, int W, int C, hipStream_t stream);

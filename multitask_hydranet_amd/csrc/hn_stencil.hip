@@ -277,13 +277,14 @@ __global__ void gconv_pack_kernel(const float* w, bf16* wk, bf16* wd, int G, int
 // depthwise 3x3, stride 1, zero pad 1.  Packed weights wk[tap][C] bf16.  Thread = 8 channels x strip of 4 pixels.
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const bf16* in, int ldi, const bf16* wk, bf16* out, int ldo, int N, int C,
-                                                         const Levels L) {
+                                                         const Levels L, int accumulate) {
     const int C8 = C >> 3;
     long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= L.work_off[L.n]) {
         // ragged level packing: every level is padded to a multiple of the row alignment; the work items behind the real ones ZERO those
         // alignment rows, so that downstream GEMMs see exact zeros there (their BatchNorm statistics are corrected analytically)
         idx -= L.work_off[L.n];
+        if (accumulate) return;                                        // the first writer already zeroed the alignment rows
         for (int l = 0; l < L.n; ++l) {
             const long real = (long)N * L.H[l] * L.W[l];
             const long pad = L.row_off[l + 1] - L.row_off[l] - real;
@@ -335,10 +336,17 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const bf16* in, int ldi
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         if (ox0 + p >= W) break;
+        bf16* dst = out + ((n * H + oy) * (long)W + ox0 + p) * ldo + cg * 8;
         bf16x8 v;
+        if (accumulate) {                                              // a second consumer's gradient of the same tensor (ops.GradSlot)
+            const bf16x8 prev = ld8(dst);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = f2bf(acc[p][k]);
-        st8(out + ((n * H + oy) * (long)W + ox0 + p) * ldo + cg * 8, v);
+            for (int k = 0; k < 8; ++k) v[k] = f2bf(acc[p][k] + bf2f(prev[k]));
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = f2bf(acc[p][k]);
+        }
+        st8(dst, v);
     }
 }
 
@@ -1024,14 +1032,15 @@ static int fill_levels(Levels& L, int N, int nlev, const int* H, const int* W, i
     }
     return HN_OK;
 }
-static int dwconv_fwd_launch(const void* in, int ldi, const void* wk, void* out, int ldo, int N, int C, Levels& L, hipStream_t st) {
+static int dwconv_fwd_launch(const void* in, int ldi, const void* wk, void* out, int ldo, int N, int C, Levels& L, hipStream_t st,
+                             int accumulate = 0) {
     HN_CHECK_ARG(in && wk && out && (C & 7) == 0 && ((ldi | ldo) & 7) == 0);
     L.work_off[0] = 0;
     for (int l = 0; l < L.n; ++l) L.work_off[l + 1] = L.work_off[l] + (long)N * L.H[l] * ((L.W[l] + 3) >> 2) * (C >> 3);
     long pad_items = 0;
     for (int l = 0; l < L.n; ++l) pad_items += (L.row_off[l + 1] - L.row_off[l] - (long)N * L.H[l] * L.W[l]) * (C >> 3);
     hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(cdiv(L.work_off[L.n] + pad_items, 256)), dim3(256), 0, st, (const bf16*)in, ldi, (const bf16*)wk, (bf16*)out,
-                       ldo, N, C, L);
+                       ldo, N, C, L, accumulate);
     HN_LAUNCH_CHECK();
 }
 extern "C" int hn_dwconv_fwd(const void* in, int ldi, const void* wk, void* out, int ldo, int N, int H, int W, int C, hipStream_t st) {
@@ -1040,10 +1049,10 @@ extern "C" int hn_dwconv_fwd(const void* in, int ldi, const void* wk, void* out,
     return rc != HN_OK ? rc : dwconv_fwd_launch(in, ldi, wk, out, ldo, N, C, L, st);
 }
 extern "C" int hn_dwconv_fwd_levels(const void* in, int ldi, const void* wk, void* out, int ldo, int N, int C, int nlev, const int* H,
-                                    const int* W, int row_align, hipStream_t st) {
+                                    const int* W, int row_align, int accumulate, hipStream_t st) {
     Levels L;
     const int rc = fill_levels(L, N, nlev, H, W, row_align);
-    return rc != HN_OK ? rc : dwconv_fwd_launch(in, ldi, wk, out, ldo, N, C, L, st);
+    return rc != HN_OK ? rc : dwconv_fwd_launch(in, ldi, wk, out, ldo, N, C, L, st, accumulate);
 }
 // number of partial rows (= blocks) of hn_dwconv_wgrad; part is fp32 [blocks][C*9], reduce with hn_rows_reduce(part, dw, 1, blocks, C*9, 1)
 // partial rows (= blocks) of hn_dwconv_wgrad* for `strips` = sum over levels of N * H * ceil(W / 4) four-pixel strips; part is fp32

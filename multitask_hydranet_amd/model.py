@@ -352,6 +352,8 @@ class HydraNet(nn.Module):
         if f is not None and x.dim() == 4 and x.dtype == torch.bfloat16:
             return K.conv_infer(x, f[0], f[1], P[conv + ".weight"].shape[0], kw.get("kind", "1x1"), kw.get("stride", 1), kw.get("act", ACT_NONE),
                                 kw.get("res"))
+        if not x.requires_grad:
+            kw.pop("slot", None)
         return K.conv_bn_act(x, P[conv + ".weight"], P.get(conv + ".bias"), self._bn(bn), training=self.training, **bnkw, **kw)
 
     def _xblock(self, q, x, stride):
@@ -383,6 +385,11 @@ class HydraNet(nn.Module):
 
     def _backbone(self, x):
         """AnyNetX.forward, net/anynet.py:136-145: x NCHW fp32 -> list of NHWC bf16 stage outputs."""
+        return [a[0] for a, _ in self._backbone_shared(x, (1,) * len(self.depths))]
+
+    def _backbone_shared(self, x, ext):
+        """-> per stage (aliases, slot): ext[k] aliases of the stage output for its consumers OUTSIDE the backbone (BiFPN input convs, the seg
+        decoder's skip operand); the next stage takes one more alias.  Consumers that know the slot add their gradient in place (ops.share)."""
         p = "backbone.net."
         x = x.contiguous().float()
         t = self._cba(x, p + "stem.conv", p + "stem.bn", BN_STD, kind="stem", act=ACT_RELU)
@@ -390,7 +397,11 @@ class HydraNet(nn.Module):
         for k, d in enumerate(self.depths):
             for i in range(d):
                 t = self._xblock(f"{p}stage_{k}.blocks.block_{i}.", t, self.backbone_stride if i == 0 else 1)
-            feats.append(t)
+            last = k == len(self.depths) - 1
+            al, slot = K.share(t, ext[k] + (0 if last else 1))
+            feats.append((al[:ext[k]], slot))
+            if not last:
+                t = al[-1]
         return feats
 
     def _sepconv(self, name, x, act=ACT_NONE):
@@ -410,20 +421,20 @@ class HydraNet(nn.Module):
         fusion nodes accumulate its gradient in place inside their backward kernels instead of leaving k-1 additions per k-consumer
         tensor to the autograd engine.  inputs: backbone features (first cell) or [(aliases, slot)] * 5 from the previous cell;
         ext[l] = consumers of output level l outside this cell; returns [(aliases, slot)] * 5."""
-        red = lambda nm, t: self._cba(t, p + nm + ".0.conv", p + nm + ".1", BN_FPN, act=ACT_NONE)
+        red = lambda nm, src, i: self._cba(src[0][i], p + nm + ".0.conv", p + nm + ".1", BN_FPN, act=ACT_NONE, slot=src[1])
         sh = K.share
-        if first:
+        if first:                                      # inputs: (aliases, slot) per backbone stage, see first_cell_counts()
             if len(inputs) == 4:                       # 4 backbone stages (small cfg): P6 is pooled from P5 (net/bifpn.py:158-160)
                 p3, p4, p5 = inputs[-3:]
-                p6_in = K.MaxPool.apply(red("p5_to_p6", p5), 0)
+                p6_in = K.MaxPool.apply(red("p5_to_p6", p5, 2), 0)
             else:                                      # 5 stages (big cfg): the last stage is P6 (net/bifpn.py:162-165)
                 p3, p4, p5, p6r = inputs[-4:]
-                p6_in = red("p6_down_channel", p6r)
+                p6_in = red("p6_down_channel", p6r, 0)
             (p6a, p6b, p6c), s6 = sh(p6_in, 3)         # two fusion nodes + the pool that makes P7
             p7_in = K.MaxPool.apply(p6c, 0)
-            p3a, s3 = red("p3_down_channel", p3), None
-            (p4a, p4b), s4a, s4b = (red("p4_down_channel", p4), red("p4_down_channel_2", p4)), None, None
-            (p5a, p5b), s5a, s5b = (red("p5_down_channel", p5), red("p5_down_channel_2", p5)), None, None
+            p3a, s3 = red("p3_down_channel", p3, 0), None
+            (p4a, p4b), s4a, s4b = (red("p4_down_channel", p4, 0), red("p4_down_channel_2", p4, 1)), None, None
+            (p5a, p5b), s5a, s5b = (red("p5_down_channel", p5, 0), red("p5_down_channel_2", p5, 1)), None, None
         else:
             (p3a,), s3 = inputs[0]
             (p4a, p4b), s4a = inputs[1]
@@ -446,13 +457,24 @@ class HydraNet(nn.Module):
         o7, q7 = sh(self._sepconv(p + "conv7_down", F(w("p7_w2"), 1, 3, 0, p7b, o6[0], None, (s7, q6, None))), ext[4])
         return [(o3[1:], q3), (o4[1:], q4), (o5[1:], q5), (o6[1:], q6), (o7, q7)]
 
+    def first_cell_counts(self):
+        """consumers of every backbone stage output inside the first BiFPN cell (its 1x1 input convs, net/bifpn.py:156-197)"""
+        n = len(self.depths)
+        cnt = [0] * n
+        if n == 4:
+            cnt[-3:] = [1, 2, 3]                       # P3; P4 (two input convs); P5 (two input convs + p5_to_p6)
+        else:
+            cnt[-4:] = [1, 2, 2, 1]
+        return cnt
+
     def _cell(self, p, inputs, first):
         """one BiFPN cell on plain tensors (the reference's module surface, per-segment tests): every output has one outside consumer"""
-        ins = list(inputs) if first else [K.share(t, c) for t, c in zip(inputs, self.CELL_IN_COUNTS)]
+        ins = [((t, t, t), None) for t in inputs] if first else [K.share(t, c) for t, c in zip(inputs, self.CELL_IN_COUNTS)]
         return tuple(a[0] for a, _ in self._cell_shared(p, ins, first, (1, 1, 1, 1, 1)))
 
     def _neck_shared(self, feats, head_counts):
-        """-> per pyramid level a tuple of head_counts[l] aliases of the fused map (one per head that consumes it)"""
+        """feats: (aliases, slot) per backbone stage (first_cell_counts() aliases each) -> per pyramid level a tuple of head_counts[l]
+        aliases of the fused map (one per head that consumes it)"""
         x = list(feats)
         for k in range(self.fpn_cell_repeats):
             last = k == self.fpn_cell_repeats - 1
@@ -461,7 +483,7 @@ class HydraNet(nn.Module):
 
     def _neck(self, feats):
         """BiFPN stack on plain tensors: the five fused maps"""
-        return [a[0] for a in self._neck_shared(feats, (1, 1, 1, 1, 1))]
+        return [a[0] for a in self._neck_shared([((t, t, t), None) for t in feats], (1, 1, 1, 1, 1))]
 
     def _seg(self, feats_seg):
         """SegmentHeader.forward, head_seg/segmentation.py:84-105 -> fp32 logits, NCHW-shaped (channels-last memory)."""
@@ -549,7 +571,7 @@ class HydraNet(nn.Module):
         return K.HeadOut.apply(P[p + "header.depthwise_conv.conv.weight"], P[p + "header.pointwise_conv.conv.weight"],
                                P[p + "header.pointwise_conv.conv.bias"], k, act, *outs)
 
-    def _det_tower_packed(self, p, xp, geom, k, act):
+    def _det_tower_packed(self, p, xp, geom, k, act, slot=None):
         """Regressor / Classifier on level-packed rows: one launch per op for all five levels (ops.TowerLayer)."""
         P = self._idx
         layers = self.cfgs["detection"]["box_class_repeats"]
@@ -561,7 +583,7 @@ class HydraNet(nn.Module):
                 bn += [g, b, rm, rv]
             f = K.TowerLayer.apply(f, P[f"{p}conv_list.{i}.depthwise_conv.conv.weight"], P[f"{p}conv_list.{i}.pointwise_conv.conv.weight"],
                                    P.get(f"{p}conv_list.{i}.pointwise_conv.conv.bias"), geom, ACT_SWISH, BN_FPN["eps"], BN_FPN["momentum"],
-                                   self.training, *bn)
+                                   self.training, slot if i == 0 else None, *bn)
         return K.HeadOutPacked.apply(P[p + "header.depthwise_conv.conv.weight"], P[p + "header.pointwise_conv.conv.weight"],
                                      P[p + "header.pointwise_conv.conv.bias"], k, act, geom, f)
 
@@ -570,9 +592,9 @@ class HydraNet(nn.Module):
         ncls = self.cfgs["detection"]["num_classes"]
         if self.pack_det_levels and K.levels_packable(fused):
             geom = (fused[0].shape[0], tuple(f.shape[1] for f in fused), tuple(f.shape[2] for f in fused))
-            xp = K.PackLevels.apply(*fused)
-            reg = self._det_tower_packed("detectheader.regressor.", xp, geom, 4, ACT_NONE)
-            cls = self._det_tower_packed("detectheader.classifier.", xp, geom, ncls, ACT_SIGMOID)
+            (xr, xc), slot = K.share(K.PackLevels.apply(*fused), 2)       # both towers read the packed map
+            reg = self._det_tower_packed("detectheader.regressor.", xr, geom, 4, ACT_NONE, slot)
+            cls = self._det_tower_packed("detectheader.classifier.", xc, geom, ncls, ACT_SIGMOID, slot)
         else:
             reg = self._det_tower("detectheader.regressor.", fused, 4, ACT_NONE)
             cls = self._det_tower("detectheader.classifier.", fused, ncls, ACT_SIGMOID)
@@ -583,11 +605,12 @@ class HydraNet(nn.Module):
         P = self._idx
         stride = self.cfgs["lane"]["anchor_stride"]
         assert stride == 32, "only the stride-32 lane fusion of the shipped cfgs is on the hot path"
-        fl = K.LaneConcat.apply(fused[0], fused[1], fused[2], fused[3])
+        fl, slot = K.share(K.LaneConcat.apply(fused[0], fused[1], fused[2], fused[3]), 3)      # three branches read the fused map
+        fl = list(fl)
 
         def branch(nm):
             q = f"laneheader.{nm}."
-            t = self._cba(fl, q + "0", q + "1", BN_STD, act=ACT_RELU)
+            t = self._cba(fl.pop(), q + "0", q + "1", BN_STD, act=ACT_RELU, slot=slot)
             w = P[q + "3.weight"]
             return K.HeadOut.apply(None, w, P[q + "3.bias"], w.shape[0], ACT_NONE, t)
         cls = branch("conv_cls_conv")
@@ -614,7 +637,11 @@ class HydraNet(nn.Module):
                     self._pack_plan = K.PackPlan(log)
 
     def _forward(self, x, mode):
-        feats = self._backbone(x)
+        neck_cnt = self.first_cell_counts()
+        seg_skip = 1 if self.train_seg else 0          # the seg decoder's last skip operand is the stage-0 output
+        bb = self._backbone_shared(x, tuple(c + (seg_skip if k == 0 else 0) for k, c in enumerate(neck_cnt)))
+        feats = [(a[(seg_skip if k == 0 else 0):], s) for k, (a, s) in enumerate(bb)]      # what the neck sees
+        feat0_seg = bb[0][0][0] if seg_skip else None
         # consumers of every fused pyramid level among the heads: det towers (all five), seg decoder (P3..P5), lane fusion (P3..P6)
         users = [[h for h, on, lv in (("det", self.train_detect, range(5)), ("seg", self.train_seg, range(3)), ("lane", self.train_lane, range(4)))
                   if on and l in lv] for l in range(5)]
@@ -640,7 +667,7 @@ class HydraNet(nn.Module):
                 out["lane"] = lane
                 lane_cls, lane_reg = lane["predict_cls"], lane["predict_loc"]
         if self.train_seg:
-            seg = self._seg([feats[0], fused_seg[0], fused_seg[1], fused_seg[2]])
+            seg = self._seg([feat0_seg, fused_seg[0], fused_seg[1], fused_seg[2]])
             out["seg"] = seg
         if side is not None:
             cur.wait_stream(side)

@@ -436,9 +436,10 @@ class ConvBnAct(torch.autograd.Function):
     """out = act(BN(conv(x) [+ conv_bias]) [+ res]).  kind: "1x1", "g3x3", "stem"."""
 
     @staticmethod
-    def forward(ctx, x, weight, conv_bias, gamma, beta, rm, rv, nbt, res, kind, stride, act, eps, momentum, training):
+    def forward(ctx, x, weight, conv_bias, gamma, beta, rm, rv, nbt, res, kind, stride, act, eps, momentum, training, slot=None):
         dev = x.device
         cout = weight.shape[0]
+        ctx.slot = slot if (kind == "1x1" and stride == 1) else None     # GradSlot of x (see Share): dgrad accumulates in its GEMM epilogue
         if kind == "stem":
             n, _, hi, wi = x.shape
             ho, wo = hi // 2, wi // 2
@@ -536,7 +537,14 @@ class ConvBnAct(torch.autograd.Function):
         else:
             _, hi, wi, cin = x.shape
             wp, wt = ctx.packs
-            if ctx.needs_input_grad[0]:
+            if ctx.needs_input_grad[0] and ctx.slot is not None:
+                # x has other consumers: the first one to run stores its data gradient, the others add theirs in the GEMM epilogue (in place)
+                sl = ctx.slot
+                if sl.buf is None:
+                    sl.buf, _, _ = k_gemm_nt(dz, None, 0, (n, ho, wo), wt, cin, kp32(cout), 1)
+                else:
+                    k_gemm_nt(dz, None, 0, (n, ho, wo), wt, cin, kp32(cout), 1, addend=sl.buf, out=sl.buf)
+            elif ctx.needs_input_grad[0]:
                 dxs, _, _ = k_gemm_nt(dz, None, 0, (n, ho, wo), wt, cin, kp32(cout), 1)
                 if stride == 1:
                     dx = dxs
@@ -544,12 +552,12 @@ class ConvBnAct(torch.autograd.Function):
                     dx = zeros((n, hi, wi, cin), dev, BF16)
                     lib().call("hn_add_strided2", ptr(dx), ld(dx), ptr(dxs), ld(dxs), n, ho, wo, cin)
             dw = k_gemm_tn(x, None, 0 if stride == 1 else 1, (n, ho, wo), dz, cout, kp32(cin), 1, cin)
-        return dx, dw, dbias, dgamma, dbeta, None, None, None, dres, None, None, None, None, None, None
+        return dx, dw, dbias, dgamma, dbeta, None, None, None, dres, None, None, None, None, None, None, None
 
 
-def conv_bn_act(x, weight, conv_bias, bn, res=None, kind="1x1", stride=1, act=ACT_NONE, eps=1e-5, momentum=0.1, training=True):
+def conv_bn_act(x, weight, conv_bias, bn, res=None, kind="1x1", stride=1, act=ACT_NONE, eps=1e-5, momentum=0.1, training=True, slot=None):
     gamma, beta, rm, rv, nbt = bn
-    return ConvBnAct.apply(x, weight, conv_bias, gamma, beta, rm, rv, nbt, res, kind, stride, act, eps, momentum, training)
+    return ConvBnAct.apply(x, weight, conv_bias, gamma, beta, rm, rv, nbt, res, kind, stride, act, eps, momentum, training, slot)
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -1286,11 +1294,12 @@ def level_views(packed, geom):
     return out
 
 
-def k_dwconv_levels(x, wk, geom):
+def k_dwconv_levels(x, wk, geom, into=None):
+    """into: an existing tensor the result is ADDED to (GradSlot accumulation of a data gradient)"""
     nl, H, W, _, _ = _geom_arrays(geom)
-    out = torch.empty_like(x)
+    out = torch.empty_like(x) if into is None else into
     lib().call("hn_dwconv_fwd_levels", ptr(x), ld(x), ptr(wk), ptr(out), ld(out), geom[0], x.shape[3], nl, ctypes.addressof(H),
-               ctypes.addressof(W), LEVEL_ALIGN)
+               ctypes.addressof(W), LEVEL_ALIGN, 0 if into is None else 1)
     return out
 
 
@@ -1327,8 +1336,9 @@ class TowerLayer(torch.autograd.Function):
     """out = act(BN_level(pointwise(depthwise(x)) + bias)) on level-packed rows; bn = nlev x (gamma, beta, running_mean, running_var)."""
 
     @staticmethod
-    def forward(ctx, x, dw_w, pw_w, pw_b, geom, act, eps, momentum, training, *bn):
+    def forward(ctx, x, dw_w, pw_w, pw_b, geom, act, eps, momentum, training, slot, *bn):
         nl, H, W, R, CNT = _geom_arrays(geom)
+        ctx.slot = slot                                     # GradSlot of x (the packed map feeds both towers), see Share
         total, c = x.shape[2], x.shape[3]
         cout = pw_w.shape[0]
         dev = x.device
@@ -1388,11 +1398,19 @@ class TowerLayer(torch.autograd.Function):
         dd, _, _ = k_gemm_nt(dz, None, 0, (1, 1, total), wt, c, kp32(cout), 1)
         dpw = k_gemm_tn(d, None, 0, (1, 1, total), dz, cout, kp32(c), 1, c)
         ddw = k_dwconv_wgrad_levels(x, dd, geom)
-        dx = k_dwconv_levels(dd, wf, geom) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0] and ctx.slot is not None:
+            sl = ctx.slot
+            if sl.buf is None:
+                sl.buf = k_dwconv_levels(dd, wf, geom)
+            else:
+                k_dwconv_levels(dd, wf, geom, into=sl.buf)
+        elif ctx.needs_input_grad[0]:
+            dx = k_dwconv_levels(dd, wf, geom)
         bn_grads = []
         for l in range(nl):
             bn_grads += [dgam[l], dbet[l], None, None]
-        return (dx, ddw, dpw, dbias, None, None, None, None, None, *bn_grads)
+        return (dx, ddw, dpw, dbias, None, None, None, None, None, None, *bn_grads)
 
 
 class HeadOutPacked(torch.autograd.Function):
