@@ -323,16 +323,18 @@ def main():
     if exchange:
         reducer = make_reducer()
 
+    one = torch.ones((), device=dev)                # d loss / d loss, allocated once (loss.backward() alone fills a fresh one every step)
+
     def fwd_bwd():
         if args.backbone_only:
             feats = net._backbone(batch["image"])
             loss = sum(f.float().mean() for f in feats)
-            loss.backward()
+            loss.backward(one)
             return loss
         out = net(batch["image"])
         ld = net.cal_loss(out, batch)
         loss = net.total_loss(ld)
-        loss.backward()
+        loss.backward(one)
         return loss
 
     graph = None

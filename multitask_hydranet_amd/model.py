@@ -608,14 +608,15 @@ class HydraNet(nn.Module):
         fl, slot = K.share(K.LaneConcat.apply(fused[0], fused[1], fused[2], fused[3]), 3)      # three branches read the fused map
         fl = list(fl)
 
-        def branch(nm):
+        def trunk(nm):
             q = f"laneheader.{nm}."
-            t = self._cba(fl.pop(), q + "0", q + "1", BN_STD, act=ACT_RELU, slot=slot)
-            w = P[q + "3.weight"]
-            return K.HeadOut.apply(None, w, P[q + "3.bias"], w.shape[0], ACT_NONE, t)
-        cls = branch("conv_cls_conv")
-        up, down = branch("conv_up_conv"), branch("conv_down_conv")
-        return dict(predict_cls=cls, predict_loc=torch.cat([down, up], -1))
+            return self._cba(fl.pop(), q + "0", q + "1", BN_STD, act=ACT_RELU, slot=slot), P[q + "3.weight"], P[q + "3.bias"]
+        t, w, b = trunk("conv_cls_conv")
+        cls = K.HeadOut.apply(None, w, b, w.shape[0], ACT_NONE, t)
+        tu, wu, bu = trunk("conv_up_conv")
+        td, wd, bd = trunk("conv_down_conv")
+        # predict_loc = cat([down, up], -1) (lanedetect.py:93): the two 1x1 convs write side by side into one tensor
+        return dict(predict_cls=cls, predict_loc=K.HeadOutCat.apply(wd, bd, wu, bu, td, tu))
 
     # ------------------------------------------------------------------------------------------------------
     def forward(self, x, mode="train"):

@@ -1118,6 +1118,49 @@ class HeadOut(torch.autograd.Function):
         return (ddw, dpw, dbias, None, None, *dfeats)
 
 
+class HeadOutCat(torch.autograd.Function):
+    """cat([1x1(ta; wa, ba), 1x1(tb; wb, bb)], -1) as fp32 [N, H*W, ca + cb]: both branch outputs are written side by side by their GEMM
+    epilogues (channel offset + row stride), so neither the concat (head_lane/lanedetect.py:93: cat([down, up], 1)) nor the slicing of
+    its gradient exist as separate kernels."""
+
+    @staticmethod
+    def forward(ctx, wa, ba, wb, bb, ta, tb):
+        n, h, w, _ = ta.shape
+        ca, cb = wa.shape[0], wb.shape[0]
+        ldc = ca + cb
+        out = torch.empty((n, h * w, ldc), device=ta.device, dtype=F32)
+        wts = []
+        for wgt, bias, t, off in ((wa, ba, ta, 0), (wb, bb, tb, ca)):
+            wp, wt = pack_conv_weight(wgt)
+            wts.append(wt)
+            k_gemm_nt(t, None, 0, (n, h, w), wp, wgt.shape[0], kp32(wgt.shape[1]), 1, bias=bias, out=out.view(-1)[off:], out_f32=True,
+                      ldc=ldc, rpi=h * w, img_stride=h * w * ldc)
+        ctx.wts = wts
+        ctx.save_for_backward(ta, tb, wa, wb)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ta, tb, wa, wb = ctx.saved_tensors
+        n, h, w, _ = ta.shape
+        ca, cb = wa.shape[0], wb.shape[0]
+        ldc = ca + cb
+        dout = dout.contiguous()
+        dev = dout.device
+        res = []
+        for wgt, wt, t, off in ((wa, ctx.wts[0], ta, 0), (wb, ctx.wts[1], tb, ca)):
+            cout, cin = wgt.shape[0], wgt.shape[1]
+            ldz = pad8(cout)
+            dz = new_act(n, h, w, ldz, dev)
+            lib().call("hn_head_grad", ptr(dout.view(-1)[off:]), None, h * w, h * w * ldc, ldc, cout, ptr(dz), ldz, n * h * w, 0)
+            ps, _, _ = k_col_stats(dz)
+            dbias = k_rows_reduce(ps, 1, ps.shape[0], ldz).view(-1)[:cout]
+            dwgt = k_gemm_tn(t, None, 0, (n, h, w), dz, cout, kp32(cin), 1, cin)
+            dt, _, _ = k_gemm_nt(dz, None, 0, (n, h, w), wt, cin, kp32(cout), 1, c0=ldz, c1=0)
+            res.append((dwgt, dbias, dt))
+        return res[0][0], res[0][1], res[1][0], res[1][1], res[0][2], res[1][2]
+
+
 # --------------------------------------------------------------------------------------------------------------
 # lane-head input fusion: cat[mp(mp(P3)), mp(P4), P5, up2(P6)] with nn.MaxPool2d(3,2,1)   (head_lane/lanedetect.py:76-80)
 # --------------------------------------------------------------------------------------------------------------

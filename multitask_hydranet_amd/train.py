@@ -56,6 +56,7 @@ class HydraTrainer:
         self.optimizer = torch.optim.Adam(self.hydranet.parameters(), self.lr, weight_decay=self.weight_decay)
         self.scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(self.optimizer, self.total_iters, eta_min=1e-8)     # iteration based
 
+        self._one = torch.ones((), device=self.device)            # root gradient, allocated once
         s, d, l = cfgs["segment"], cfgs["detection"], cfgs["lane"]
         self.segment_weight = s["segment_weight"]
         self.loss_cls_weight, self.loss_reg_weight, self.detection_weight = d["loss_cls_weight"], d["loss_reg_weight"], d["detection_weight"]
@@ -91,7 +92,7 @@ class HydraTrainer:
         loss_dict.update({"total_loss": loss_total})
         # gradients accumulate straight into the exchange buckets after the first step: zero them in place instead of dropping them
         self.optimizer.zero_grad(set_to_none=self.reducer is None)
-        loss_total.backward()
+        loss_total.backward(self._one)
         if self.reducer is not None:
             self.reducer.finish()
         self.optimizer.step()

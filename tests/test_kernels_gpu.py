@@ -433,6 +433,29 @@ def test_phase_weight_pack_and_fold(K, k, c0, c1):
     K.clear_pack_cache()
 
 
+@pytest.mark.parametrize("ca,cb", [(65, 65), (8, 3)])
+def test_head_out_cat(K, ca, cb):
+    """ops.HeadOutCat == cat([conv1x1(ta), conv1x1(tb)], channel) flattened to [N, H*W, ca+cb] (lane location head, lanedetect.py:86-93)"""
+    n, c, h, w = 2, 48, 4, 6
+    ta, tb = rnd(n, c, h, w), rnd(n, c, h, w)
+    wa, wb = rnd(ca, c, 1, 1, scale=0.2), rnd(cb, c, 1, 1, scale=0.2)
+    ba, bb = rnd(ca, scale=0.1), rnd(cb, scale=0.1)
+    ak, bk = nhwc(ta).requires_grad_(True), nhwc(tb).requires_grad_(True)
+    prm = [t.clone().requires_grad_(True) for t in (wa, ba, wb, bb)]
+    out = K.HeadOutCat.apply(*prm, ak, bk)
+    up = torch.randn_like(out)
+    out.backward(up)
+    ar, br = ta.clone().requires_grad_(True), tb.clone().requires_grad_(True)
+    ref_p = [t.clone().requires_grad_(True) for t in (wa, ba, wb, bb)]
+    y = torch.cat([F.conv2d(ar, ref_p[0], ref_p[1]), F.conv2d(br, ref_p[2], ref_p[3])], 1).permute(0, 2, 3, 1).reshape(n, h * w, ca + cb)
+    y.backward(up)
+    close(out, y, ACT_TOL, "out")
+    close(nchw(ak.grad), ar.grad, GRAD_TOL, "dta")
+    close(nchw(bk.grad), br.grad, GRAD_TOL, "dtb")
+    for got, ref, nm in zip(prm, ref_p, ("dwa", "dba", "dwb", "dbb")):
+        close(got.grad, ref.grad, GRAD_TOL, nm)
+
+
 @pytest.mark.parametrize("with_dw,cout,k,act", [(True, 36, 4, 0), (True, 81, 9, 4), (False, 65, 65, 0), (False, 2, 2, 0)])
 def test_head_out(K, with_dw, cout, k, act):
     n, c = 2, 16
