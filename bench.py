@@ -257,6 +257,8 @@ def main():
     ap.add_argument("--cfg", default=os.path.join(ROOT, "cfgs", "hydranet_big.yml"))
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one captured hipGraph per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-optimizer", action="store_true", help="skip the separate Adam-step timing (profiling runs: keeps the optimizer's "
+                    "state initialisation and multi-tensor kernels out of the kernel statistics)")
     ap.add_argument("--backbone-only", action="store_true", help="BASELINE config[1]: backbone fwd+bwd, loss = sum of feature means")
     ap.add_argument("--dominant-only", action="store_true", help="launch only the dominant kernel (for rocprofv3 --pmc passes) and exit")
     ap.add_argument("--infer", action="store_true", help="BASELINE config 5: eval-mode deploy forward with folded BatchNorm, hipGraph-captured "
@@ -453,15 +455,17 @@ def main():
         ms_step = dt / args.steps * 1e3
         value = args.batch * world * args.steps / dt
         # optimizer step, reported separately (Adam as in model/train.py:147)
-        opt = torch.optim.Adam(net.parameters(), 1e-5, weight_decay=1e-8)
-        for _ in range(2):
-            opt.step()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(5):
-            opt.step()
-        torch.cuda.synchronize()
-        ms_opt = (time.perf_counter() - t1) / 5 * 1e3
+        ms_opt = None
+        if not args.no_optimizer:
+            opt = torch.optim.Adam(net.parameters(), 1e-5, weight_decay=1e-8)
+            for _ in range(2):
+                opt.step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                opt.step()
+            torch.cuda.synchronize()
+            ms_opt = (time.perf_counter() - t1) / 5 * 1e3
         scale = (h * w) / (512.0 * 1024.0)
         gflop_img = 3 * FWD_GFLOP_PER_IMG_512x1024 * scale * (12.02 / 81.13 if args.backbone_only else 1.0)
         res = {
@@ -472,7 +476,7 @@ def main():
                        + ", big cfg, fwd+loss+bwd", "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "resolution": "3x%dx%d" % (h, w), "parallelism": "dp%d" % world, "hipgraph": graph is not None,
                        "grad_allreduce": None if reducer is None else ("%s backend: " % backend) + reducer.describe()},
-            "ms_optimizer_step": round(ms_opt, 3), "loss": round(loss_val, 4),
+            "ms_optimizer_step": round(ms_opt, 3) if ms_opt is not None else None, "loss": round(loss_val, 4),
             "model_tflops": round(value * gflop_img / 1e3, 2),
             # SURVEY 8(d) segment-wise roofline of the whole step (seg decoder on MFMA, everything else on HBM): 0.177 ms/img at 512x1024
             "step_roofline": {"floor_ms_per_img": round(0.177 * scale, 4), "frac": round(value / world * 0.177e-3 * scale, 4)},
