@@ -667,16 +667,18 @@ __global__ __launch_bounds__(256) void se_fc_rows_kernel(const float* W, const f
 }
 
 // out[n][o] = mask(o) * sum_i W[i][o] * f(in)[n][i]   (contraction over the ROW index of W: coalesced over o).
-// block = 64 outputs x 4 partitions of i.  pre: 0 = in as is, 1 = in * g * (1 - g) with g = aux[n][i] (sigmoid', result also stored to
+// block = 16 outputs x 64 partitions of i (a workgroup streams its weight slab at only ~30 GB/s, so the slabs are kept small and many:
+// 64-output tiles took 12.7 us per launch at stage 4).  pre: 0 = in as is, 1 = in * g * (1 - g) with g = aux[n][i] (sigmoid', result also stored to
 // `store`).  post: 0 none, 1 = zero where aux2[n][o] <= 0 (ReLU').
 // S > 0: `in` holds S partial rows per image (summed on the fly: the SE gate gradient from the per-row-block sums of hn_se_bwd_reduce_fused)
-__global__ __launch_bounds__(1024) void se_fc_cols_kernel(const float* W, const float* in, const float* aux, float* store, const float* aux2,
-                                                          float* out, int N, int O, int I, int pre, int post, int S) {
-    __shared__ float red[16][64];
-    const int ox = threadIdx.x & 63, part = threadIdx.x >> 6;         // 64 outputs x 16 partitions of the contraction
-    const int o = blockIdx.x * 64 + ox, n = blockIdx.y;
+template <int PARTS>
+__global__ __launch_bounds__(16 * PARTS) void se_fc_cols_kernel(const float* W, const float* in, const float* aux, float* store, const float* aux2,
+                                                                float* out, int N, int O, int I, int pre, int post, int S) {
+    __shared__ float red[PARTS][17];
+    const int ox = threadIdx.x & 15, part = threadIdx.x >> 4;         // 16 outputs x PARTS partitions of the contraction
+    const int o = blockIdx.x * 16 + ox, n = blockIdx.y;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    const int i0 = (int)((long)I * part / 16), i1 = (int)((long)I * (part + 1) / 16);
+    const int i0 = (int)((long)I * part / PARTS), i1 = (int)((long)I * (part + 1) / PARTS);
     const float* inr = in + (long)n * (S > 0 ? S : 1) * I;
     const float* auxr = aux ? aux + (long)n * I : nullptr;
     const bool ov = o < O;
@@ -709,38 +711,44 @@ __global__ __launch_bounds__(1024) void se_fc_cols_kernel(const float* W, const 
     if (part == 0 && ov) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) t += red[k][ox];
+        for (int k = 0; k < PARTS; ++k) t += red[k][ox];
         if (post && aux2[(long)n * O + o] <= 0.f) t = 0.f;
         out[(long)n * O + o] = t;
     }
 }
 
-// parameter gradients (sum over the N images): dW2[c][j] = sum dpre2[n][c] hid[n][j]; db2 = sum dpre2; dW1[j][c] = sum dpre1[n][j] pooled[n][c]
-__global__ void se_mlp_wgrad_kernel(const float* dpre2, const float* dpre1, const float* hid, const float* pooled, float* dw1, float* db1,
-                                    float* dw2, float* db2, int N, int C, int Cs) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long n2 = (long)C * Cs;
-    if (idx < n2) {
-        const int c = (int)(idx / Cs), j = (int)(idx - (long)c * Cs);
-        float s = 0.f;
-        for (int n = 0; n < N; ++n) s += dpre2[(long)n * C + c] * hid[(long)n * Cs + j];
-        dw2[idx] = s;
-    } else if (idx < 2 * n2) {
-        const long k = idx - n2;
-        const int j = (int)(k / C), c = (int)(k - (long)j * C);
-        float s = 0.f;
-        for (int n = 0; n < N; ++n) s += dpre1[(long)n * Cs + j] * pooled[(long)n * C + c];
-        dw1[k] = s;
-    } else if (idx < 2 * n2 + C) {
-        const int c = (int)(idx - 2 * n2);
-        float s = 0.f;
-        for (int n = 0; n < N; ++n) s += dpre2[(long)n * C + c];
-        db2[c] = s;
-    } else if (idx < 2 * n2 + C + Cs) {
-        const int j = (int)(idx - 2 * n2 - C);
-        float s = 0.f;
-        for (int n = 0; n < N; ++n) s += dpre1[(long)n * Cs + j];
-        db1[j] = s;
+// parameter gradients (sums over the N images) as outer-product tiles on the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32): D[i][j] = sum_n P[n][i] * Q[n][j]
+//   job 0: dW2[c][j] = sum dpre2[n][c] hid[n][j]  (+ db2[c] = sum dpre2[n][c] from the j-tile 0 waves)
+//   job 1: dW1[j][c] = sum dpre1[n][j] pooled[n][c]  (+ db1[j])
+// one wave per 16x16 tile, 4 waves per workgroup
+struct SeOuter { const float* P; int PI; const float* Q; int QJ; float* D; float* dbias; int tiles_j; int tiles; };
+__global__ __launch_bounds__(256) void se_mlp_wgrad_kernel(const SeOuter j0, const SeOuter j1, int N) {
+    const int lane = threadIdx.x & 63;
+    int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const SeOuter& jb = tile < j0.tiles ? j0 : j1;
+    if (tile >= j0.tiles) tile -= j0.tiles;
+    if (tile >= jb.tiles) return;
+    const int ti = tile / jb.tiles_j, tj = tile - ti * jb.tiles_j;
+    const int r = lane & 15, kk = lane >> 4;
+    const int i = ti * 16 + r, j = tj * 16 + r;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float colsum = 0.f;
+    for (int n0 = 0; n0 < N; n0 += 4) {
+        const int n = n0 + kk;
+        const float a = (n < N && i < jb.PI) ? jb.P[(long)n * jb.PI + i] : 0.f;
+        const float b = (n < N && j < jb.QJ) ? jb.Q[(long)n * jb.QJ + j] : 0.f;
+        colsum += a;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int oi = ti * 16 + 4 * kk + q;
+        if (oi < jb.PI && j < jb.QJ) jb.D[(long)oi * jb.QJ + j] = acc[q];
+    }
+    if (tj == 0) {                                                    // the bias gradient: sum over the images of P[n][i]
+        colsum += __shfl_xor(colsum, 16);
+        colsum += __shfl_xor(colsum, 32);
+        if (kk == 0 && i < jb.PI) jb.dbias[i] = colsum;
     }
 }
 
@@ -1037,11 +1045,14 @@ static int se_mlp_bwd_impl(const float* dgate, int S, const float* gate, const f
                            hipStream_t st) {
     HN_CHECK_ARG(dgate && gate && hid && pooled && w1 && w2 && dpre2 && dpre1 && dpool && dw1 && db1 && dw2 && db2 && N > 0 && C > 0 && Cs > 0);
     // dpre1[n][j] = [hid > 0] * sum_c W2[c][j] * (dgate * g (1-g))[n][c]        (also stores dpre2)
-    hipLaunchKernelGGL(se_fc_cols_kernel, dim3(cdiv(Cs, 64), N), dim3(1024), 0, st, w2, dgate, gate, dpre2, hid, dpre1, N, Cs, C, 1, 1, S);
+    // (contraction over C: 64 partitions; over Cs = C/4 below: 16)
+    hipLaunchKernelGGL(se_fc_cols_kernel<64>, dim3(cdiv(Cs, 16), N), dim3(1024), 0, st, w2, dgate, gate, dpre2, hid, dpre1, N, Cs, C, 1, 1, S);
     // dpool[n][c] = sum_j W1[j][c] * dpre1[n][j]
-    hipLaunchKernelGGL(se_fc_cols_kernel, dim3(cdiv(C, 64), N), dim3(1024), 0, st, w1, (const float*)dpre1, (const float*)nullptr,
+    hipLaunchKernelGGL(se_fc_cols_kernel<16>, dim3(cdiv(C, 16), N), dim3(256), 0, st, w1, (const float*)dpre1, (const float*)nullptr,
                        (float*)nullptr, (const float*)nullptr, dpool, N, C, Cs, 0, 0, 0);
-    const long total = 2L * C * Cs + C + Cs;
-    hipLaunchKernelGGL(se_mlp_wgrad_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, dpre2, dpre1, hid, pooled, dw1, db1, dw2, db2, N, C, Cs);
+    const int tc = cdiv(C, 16), ts = cdiv(Cs, 16);
+    const SeOuter j0 = {dpre2, C, hid, Cs, dw2, db2, ts, tc * ts};
+    const SeOuter j1 = {dpre1, Cs, pooled, C, dw1, db1, tc, tc * ts};
+    hipLaunchKernelGGL(se_mlp_wgrad_kernel, dim3(cdiv(2L * tc * ts, 4)), dim3(256), 0, st, j0, j1, N);
     HN_LAUNCH_CHECK();
 }
