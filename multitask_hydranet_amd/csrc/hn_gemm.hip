@@ -1193,8 +1193,19 @@ __global__ __launch_bounds__(512) void wgrad_reduce_kernel(const float* part, fl
     const long cols = (long)Nout * Ktot;
     const long col = (long)blockIdx.x * 32 + tx;
     float s = 0.f;
-    if (col < cols)
-        for (int k = ty; k < splits; k += 16) s += part[(long)k * cols + col];
+    if (col < cols) {
+        // a dependent global-load round costs ~1 us at this occupancy: four independent loads per round
+        int k = ty;
+        float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (; k + 48 < splits; k += 64) {
+            s += part[(long)k * cols + col];
+            s1 += part[(long)(k + 16) * cols + col];
+            s2 += part[(long)(k + 32) * cols + col];
+            s3 += part[(long)(k + 48) * cols + col];
+        }
+        for (; k < splits; k += 16) s += part[(long)k * cols + col];
+        s = (s + s1) + (s2 + s3);
+    }
     red[ty][tx] = s;
     __syncthreads();
     if (ty == 0 && col < cols) {
@@ -1215,7 +1226,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* part, f
     const long col = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (col >= cols) return;
     f32x4 s = *reinterpret_cast<const f32x4*>(part + col);
-#pragma unroll 4
+#pragma unroll 8
     for (int k = 1; k < splits; ++k) s += *reinterpret_cast<const f32x4*>(part + (long)k * cols + col);
     const int co = (int)(col / Ktot);
     const int r = (int)(col - (long)co * Ktot);
@@ -1567,7 +1578,7 @@ static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img
         p.img_stride = 0;
     }
     if (mode >= 2 && (!psum || p.x.diag) && !rpi) {      // statistics epilogue: grouped convs only (one partial row per 16x16 patch)
-        int bc = p.x.diag ? 64 : (Nout <= 16 ? 16 : (Nout <= 64 ? 64 : 128));
+        int bc = p.x.diag ? 64 : (Nout <= 16 ? 16 : (Nout <= 32 ? 32 : (Nout <= 64 ? 64 : 128)));
         if (phase_mode == 1 && phase_span < bc) bc = 64;            // a cout tile must lie inside one phase
         dim3 grid((unsigned)(cdiv(Nout, bc) * cdiv(W, 16) * cdiv(H, 16) * n_img));
         // software-pipelined variant (one workgroup per CU, 3 weight tiles + 2 patch buffers): the bf16 launches with >= 64 couts per tile
@@ -1577,6 +1588,7 @@ static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img
         // > 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel (done on the first, un-captured call)
         static std::atomic<unsigned long long> optin{0};
         if (!lds_optin(optin, {(const void*)conv3x3_direct_kernel<16, true, false>, (const void*)conv3x3_direct_kernel<16, false, false>,
+                               (const void*)conv3x3_direct_kernel<32, true, false>, (const void*)conv3x3_direct_kernel<32, false, false>,
                                (const void*)conv3x3_direct_kernel<64, true, false>, (const void*)conv3x3_direct_kernel<64, false, false>,
                                (const void*)conv3x3_direct_kernel<128, true, false>, (const void*)conv3x3_direct_kernel<128, false, false>,
                                (const void*)conv3x3_direct_kernel<64, false, true>, (const void*)conv3x3_direct_kernel<128, false, true>}))
@@ -1591,7 +1603,7 @@ static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img
             if (out_f32) hipLaunchKernelGGL((conv3x3_direct_kernel<BC_, true, false>), grid, dim3(512), lds, st, p); \
             else hipLaunchKernelGGL((conv3x3_direct_kernel<BC_, false, false>), grid, dim3(512), lds, st, p); \
         }
-        DIRECT_CASE(16) DIRECT_CASE(64) DIRECT_CASE(128)
+        DIRECT_CASE(16) DIRECT_CASE(32) DIRECT_CASE(64) DIRECT_CASE(128)
 #undef DIRECT_CASE
         HN_LAUNCH_CHECK();
     }
@@ -1637,6 +1649,7 @@ static void tn_tiles(int Nout, int KP, int& bc, int& bn) {
 static bool use_patch_wgrad(int mode, int Nout, int KP) { return mode == 2 && KP >= 64; }
 static void patch_tiles(int Nout, int& bc, int& ci, int& ksplit) {
     if (Nout <= 16) { bc = 16; ci = 64; ksplit = 2; }
+    else if (Nout <= 32) { bc = 32; ci = 128; ksplit = 1; }          // the 4-phase 5-class output conv: 20 couts
     else if (Nout <= 64) { bc = 64; ci = 128; ksplit = 1; }
     else { bc = 128; ci = 64; ksplit = 1; }
 }
@@ -1724,7 +1737,8 @@ static int conv_gemm_tn_impl(const void* x0, const void* x1, int mode, int n_img
     if (use_patch_wgrad(mode, Nout, KP)) {
         static std::atomic<unsigned long long> optin{0};
         if (!lds_optin(optin, {(const void*)wgrad3x3_patch_kernel<128, 64>, (const void*)wgrad3x3_patch_kernel<64, 128>,
-                               (const void*)wgrad3x3_patch_kernel<16, 64>, (const void*)wgrad3x3_patch_kernel<64, 64>}))
+                               (const void*)wgrad3x3_patch_kernel<16, 64>, (const void*)wgrad3x3_patch_kernel<64, 64>,
+                               (const void*)wgrad3x3_patch_kernel<32, 128>}))
             return HN_ERR_LAUNCH;
         int pbc, pci, ksplit;
         patch_tiles(Nout, pbc, pci, ksplit);
@@ -1738,6 +1752,7 @@ static int conv_gemm_tn_impl(const void* x0, const void* x1, int mode, int n_img
         if (grouped) hipLaunchKernelGGL((wgrad3x3_patch_kernel<64, 64>), grid, dim3(512), lds, st, p, (int)rps, patches);
         else if (pbc == 128) hipLaunchKernelGGL((wgrad3x3_patch_kernel<128, 64>), grid, dim3(512), lds, st, p, (int)rps, patches);
         else if (pbc == 64) hipLaunchKernelGGL((wgrad3x3_patch_kernel<64, 128>), grid, dim3(512), lds, st, p, (int)rps, patches);
+        else if (pbc == 32) hipLaunchKernelGGL((wgrad3x3_patch_kernel<32, 128>), grid, dim3(512), lds, st, p, (int)rps, patches);
         else hipLaunchKernelGGL((wgrad3x3_patch_kernel<16, 64>), grid, dim3(512), lds, st, p, (int)rps, patches);
         if (hipGetLastError() != hipSuccess) return HN_ERR_LAUNCH;
         const long cols = (long)Nout * taps * KP;
