@@ -147,6 +147,9 @@ int hn_fuse_weights(const float* praw, int nw, float eps, float* wn, hipStream_t
 int hn_fuse_dweights(const float* pw, int blocks, const float* praw, int nw, float eps, float* dp, hipStream_t stream);
 int hn_fuse_fwd(const void* const* in, const int* ld, const int* mode, const float* w, void* out, int ldo, int N, int H, int W, int C,
                 hipStream_t stream);
+/* the same with the normalisation of the raw fusion parameters inside the kernel (wn [3] is written for the backward pass) */
+int hn_fuse_fwd_raw(const void* const* in, const int* ld, const int* mode, const float* praw, int nw, float eps, float* wn, void* out, int ldo,
+                    int N, int H, int W, int C, hipStream_t stream);
 /* `accumulate` / acc[i] = 1 in hn_fuse_bwd, hn_sum2x2 and hn_maxpool_bwd2: the destination already holds the gradient another consumer of
  * the same tensor wrote (a BiFPN map feeds 2-3 nodes, net/bifpn.py:186-231) and this consumer's contribution is added in place (fp32 add,
  * one bf16 rounding) -- the autograd engine's separate gradient-accumulation kernels disappear (ops.Share / ops.GradSlot). */

@@ -677,6 +677,7 @@ __global__ __launch_bounds__(256) void sum2x2_kernel(const bf16* g, int ldg, bf1
 // ---------------------------------------------------------------------------------------------------------
 struct Fuse {
     const bf16* in[3]; int ld[3]; int mode[3];
+    const float* praw; int nw; float eps; float* wn;   // praw != null: the kernel normalises the raw fusion parameters itself (and stores wn)
     const float* w;
     bf16* out; int ldo;
     int N, H, W, C;       // output resolution
@@ -698,6 +699,18 @@ __device__ __forceinline__ void fuse_gather(const Fuse& p, int i, long n, int y,
 __global__ __launch_bounds__(256) void fuse_fwd_kernel(const Fuse p) {
     const int C8 = p.C >> 3;
     const long total = (long)p.N * p.H * p.W * C8;
+    float wv[3];
+    if (p.praw) {                      // w = relu(p) / (sum relu(p) + eps), net/bifpn.py:179-180 (no separate one-thread launch)
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { wv[i] = i < p.nw ? fmaxf(p.praw[i], 0.f) : 0.f; sum += wv[i]; }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) wv[i] = wv[i] / (sum + p.eps);
+        if (blockIdx.x == 0 && threadIdx.x < 3) p.wn[threadIdx.x] = wv[threadIdx.x];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) wv[i] = p.w[i];
+    }
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int cg = (int)(idx % C8);
         long t = idx / C8;
@@ -713,7 +726,7 @@ __global__ __launch_bounds__(256) void fuse_fwd_kernel(const Fuse p) {
             if (!p.mode[i]) continue;
             float v[8];
             fuse_gather(p, i, n, y, x, cg * 8, v);
-            const float wi = p.w[i];
+            const float wi = wv[i];
 #pragma unroll
             for (int k = 0; k < 8; ++k) acc[k] = fmaf(wi, v[k], acc[k]);
         }
@@ -1144,13 +1157,14 @@ extern "C" int hn_sum2x2(const void* g, int ldg, void* out, int ldo, const float
 
 static int fill_fuse(Fuse& f, const void* const* in, const int* ld, const int* mode, const float* w, void* out, int ldo, int N, int H,
                      int W, int C) {
-    HN_CHECK_ARG(in && ld && mode && w && (C & 7) == 0 && (ldo & 7) == 0);
+    HN_CHECK_ARG(in && ld && mode && (C & 7) == 0 && (ldo & 7) == 0);
     for (int i = 0; i < 3; ++i) {
         f.in[i] = (const bf16*)in[i]; f.ld[i] = ld[i]; f.mode[i] = mode[i];
         HN_CHECK_ARG(mode[i] >= 0 && mode[i] <= 3 && (mode[i] == 0 || (in[i] && (ld[i] & 7) == 0)));
         HN_CHECK_ARG(mode[i] != 2 || (!(H & 1) && !(W & 1)));
     }
     f.w = w; f.out = (bf16*)out; f.ldo = ldo; f.N = N; f.H = H; f.W = W; f.C = C;
+    f.praw = nullptr; f.nw = 0; f.eps = 0.f; f.wn = nullptr;
     return HN_OK;
 }
 extern "C" int hn_fuse_fwd(const void* const* in, const int* ld, const int* mode, const float* w, void* out, int ldo, int N, int H, int W,
@@ -1159,6 +1173,18 @@ extern "C" int hn_fuse_fwd(const void* const* in, const int* ld, const int* mode
     HN_CHECK_ARG(out);
     const int rc = fill_fuse(f, in, ld, mode, w, out, ldo, N, H, W, C);
     if (rc) return rc;
+    hipLaunchKernelGGL(fuse_fwd_kernel, dim3(ew_grid((long)N * H * W * (C >> 3))), dim3(256), 0, st, f);
+    HN_LAUNCH_CHECK();
+}
+/* hn_fuse_fwd with the weight normalisation inside: praw = the nw (2 or 3) raw fusion parameters, wn [3] receives relu(p)/(sum relu(p)+eps)
+ * (kept for the backward pass) */
+extern "C" int hn_fuse_fwd_raw(const void* const* in, const int* ld, const int* mode, const float* praw, int nw, float eps, float* wn,
+                               void* out, int ldo, int N, int H, int W, int C, hipStream_t st) {
+    Fuse f;
+    HN_CHECK_ARG(out && praw && wn && nw >= 1 && nw <= 3);
+    const int rc = fill_fuse(f, in, ld, mode, nullptr, out, ldo, N, H, W, C);
+    if (rc) return rc;
+    f.praw = praw; f.nw = nw; f.eps = eps; f.wn = wn;
     hipLaunchKernelGGL(fuse_fwd_kernel, dim3(ew_grid((long)N * H * W * (C >> 3))), dim3(256), 0, st, f);
     HN_LAUNCH_CHECK();
 }

@@ -942,10 +942,10 @@ class Fuse(torch.autograd.Function):
         assert m0 == 1
         dev = a.device
         w = torch.empty((3,), device=dev, dtype=F32)
-        lib().call("hn_fuse_weights", ptr(praw), praw.numel(), 1e-4, ptr(w))
         out = new_act(n, h, wd, ch, dev)
         ap, al, am = _fuse_args(ins, modes)
-        lib().call("hn_fuse_fwd", ctypes.addressof(ap), ctypes.addressof(al), ctypes.addressof(am), ptr(w), ptr(out), ld(out), n, h, wd, ch)
+        lib().call("hn_fuse_fwd_raw", ctypes.addressof(ap), ctypes.addressof(al), ctypes.addressof(am), ptr(praw), praw.numel(), 1e-4, ptr(w),
+                   ptr(out), ld(out), n, h, wd, ch)
         ctx.modes = modes
         ctx.slots = slots if slots is not None else (None, None, None)
         ctx.save_for_backward(praw, w, *[t for t in ins if t is not None])
