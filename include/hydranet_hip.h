@@ -37,9 +37,11 @@ int hn_pack_weight_ex(const float* w, void* wp, void* wt, int Cout, int Cin_tota
 /* the transpose: dw [K][C0+C1][3][3] (db [K], optional) from the effective-weight gradient dw_eff [4K][C0][3][3] (db_eff [4K]); channels
  * [C0, C0+C1) are copied from the skip operand's own gradient dw1 [K][C1][3][3] */
 int hn_phase_fold(const float* dw_eff, const float* dw1, const float* db_eff, float* dw, float* db, int K, int C0, int C1, hipStream_t stream);
-/* every conv weight of a model in one launch: jobs = DEVICE table njobs x 8 int64 {w, wp, wt, Cout, Cin, taps, first_block, 0}, job j owns
- * ceil((Cout*taps*KP(Cin) + Cin*taps*KP(Cout)) / 256) consecutive blocks starting at first_block */
-int hn_pack_weights_batched(const long* jobs, int njobs, long total_blocks, hipStream_t stream);
+/* every conv weight of a model in one launch: jobs = DEVICE table njobs x 8 int64 {w, wp, wt, Cout, Cin, taps, first_block, ci_tiles}; job j
+ * owns one block per 32 x 32 (cout, cin) tile -- (KP(Cout)/32) * ci_tiles blocks with ci_tiles = KP(Cin)/32 -- starting at first_block;
+ * the tile passes through LDS so that both operand layouts are written in contiguous runs.  taps = 1 or 9.  block_job (optional, DEVICE
+ * int32 [total_blocks]) = job index of every block (otherwise each block searches the table). */
+int hn_pack_weights_batched(const long* jobs, int njobs, long total_blocks, const int* block_job, hipStream_t stream);
 
 /* out[pixel][cout] = act(bias[cout] + sum_{tap,c} X(pixel, tap)[c] * w[cout][tap][c]); X is gathered on the fly:
  *   mode 0: X = x0 rows (1x1 conv; also every dgrad of a 1x1 conv)            nn.Conv2d k=1: net/anynet.py:29-33,52-60;

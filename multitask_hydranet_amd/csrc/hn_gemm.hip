@@ -1372,36 +1372,59 @@ __global__ void phase_fold_kernel(const float* dw_eff, const float* dw1, const f
     }
 }
 
-// all conv weights of a model in ONE launch: jobs[j] = {w, wp, wt, Cout, Cin, taps, first block, unused} (device int64 table, built once)
-__global__ void pack_w_batched_kernel(const long* jobs, int njobs) {
-    int lo = 0, hi = njobs - 1;                                      // last job whose first block <= blockIdx.x
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (jobs[mid * 8 + 6] <= (long)blockIdx.x) lo = mid; else hi = mid - 1;
+// all conv weights of a model in ONE launch: jobs[j] = {w, wp, wt, Cout, Cin, taps, first block, ci tiles} (device int64 table, built once).
+// One workgroup = one 32-cout x 32-cin tile with all its taps, staged through LDS so that BOTH layouts are written in contiguous runs:
+// the transposed operand Wt[ci][tap][co] read column-wise from global memory costs a 64-byte sector per 4-byte element (310 us per step
+// for the 43 M parameters of the big cfg against ~60 us of HBM time).
+template <int TAPS>
+__device__ __forceinline__ void pack_tile(const float* w, bf16* wp, bf16* wt, int Cout, int Cin, int co0, int ci0, bf16* tile) {
+    constexpr int row = 32 * TAPS, ldt = row + 2;                     // tile[r][c * TAPS + tap] (bf16: 18.5 KB for 3x3 -> 8 workgroups per CU)
+    const int KPi = (Cin + 31) / 32 * 32, KPo = (Cout + 31) / 32 * 32;
+    const int tid = threadIdx.x;
+#pragma unroll 4
+    for (int e = tid; e < 32 * row; e += 256) {
+        const int r = e / row, x = e - r * row;
+        const int co = co0 + r, ci = ci0 + x / TAPS;
+        tile[r * ldt + x] = f2bf((co < Cout && ci < Cin) ? w[((long)co * Cin + ci0) * TAPS + x] : 0.f);
+    }
+    __syncthreads();
+    // forward operand Wp[co][tap][KPi]: 32 consecutive ci per (co, tap)
+#pragma unroll 4
+    for (int e = tid; e < 32 * row; e += 256) {
+        const int c = e & 31, rt = e >> 5, tap = rt % TAPS, r = rt / TAPS;
+        if (co0 + r < Cout) wp[((long)(co0 + r) * TAPS + tap) * KPi + ci0 + c] = tile[r * ldt + c * TAPS + tap];
+    }
+    // data-gradient operand Wt[ci][tap][KPo]: 32 consecutive co per (ci, tap)
+    if (wt) {
+#pragma unroll 4
+        for (int e = tid; e < 32 * row; e += 256) {
+            const int r = e & 31, ct = e >> 5, tap = ct % TAPS, c = ct / TAPS;
+            if (ci0 + c < Cin) wt[((long)(ci0 + c) * TAPS + tap) * KPo + co0 + r] = tile[r * ldt + c * TAPS + tap];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_w_batched_kernel(const long* jobs, int njobs, const int* block_job) {
+    __shared__ bf16 tile[32 * (32 * 9 + 2)];
+    int lo = 0;
+    if (block_job) {
+        lo = block_job[blockIdx.x];                                   // one load instead of a 7-step dependent search per workgroup
+    } else {
+        int hi = njobs - 1;                                           // last job whose first block <= blockIdx.x
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (jobs[mid * 8 + 6] <= (long)blockIdx.x) lo = mid; else hi = mid - 1;
+        }
     }
     const long* jb = jobs + lo * 8;
     const float* w = reinterpret_cast<const float*>(jb[0]);
     bf16* wp = reinterpret_cast<bf16*>(jb[1]);
     bf16* wt = reinterpret_cast<bf16*>(jb[2]);
-    const int Cout = (int)jb[3], Cin = (int)jb[4], taps = (int)jb[5];
-    const int KPi = (Cin + 31) / 32 * 32, KPo = (Cout + 31) / 32 * 32;
-    const long nf = (long)Cout * taps * KPi;
-    const long nt = wt ? (long)Cin * taps * KPo : 0;
-    const long idx = ((long)blockIdx.x - jb[6]) * blockDim.x + threadIdx.x;
-    if (idx < nf) {
-        const int k = (int)(idx % KPi);
-        const long t = idx / KPi;
-        const int tap = (int)(t % taps);
-        const int co = (int)(t / taps);
-        wp[idx] = f2bf(k < Cin ? w[((long)co * Cin + k) * taps + tap] : 0.f);
-    } else if (idx < nf + nt) {
-        const long j = idx - nf;
-        const int k = (int)(j % KPo);
-        const long t = j / KPo;
-        const int tap = (int)(t % taps);
-        const int ci = (int)(t / taps);
-        wt[j] = f2bf(k < Cout ? w[((long)k * Cin + ci) * taps + tap] : 0.f);
-    }
+    const int Cout = (int)jb[3], Cin = (int)jb[4], taps = (int)jb[5], tiles_ci = (int)jb[7];
+    const int t = (int)((long)blockIdx.x - jb[6]);
+    const int co0 = (t / tiles_ci) * 32, ci0 = (t % tiles_ci) * 32;
+    if (taps == 1) pack_tile<1>(w, wp, wt, Cout, Cin, co0, ci0, tile);
+    else if (taps == 9) pack_tile<9>(w, wp, wt, Cout, Cin, co0, ci0, tile);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1781,11 +1804,12 @@ static int conv_gemm_tn_impl(const void* x0, const void* x1, int mode, int n_img
     HN_LAUNCH_CHECK();
 }
 
-/* jobs: DEVICE table of njobs x 8 int64 {w, wp, wt, Cout, Cin, taps, first_block, 0}; job j owns blocks [first_block_j, first_block_{j+1})
- * of 256 threads, ceil((Cout*taps*KP(Cin) + Cin*taps*KP(Cout)) / 256) each; total_blocks = their sum. */
-extern "C" int hn_pack_weights_batched(const long* jobs, int njobs, long total_blocks, hipStream_t st) {
+/* jobs: DEVICE table of njobs x 8 int64 {w, wp, wt, Cout, Cin, taps, first_block, ci_tiles}; job j owns blocks [first_block_j,
+ * first_block_{j+1}) of 256 threads, one per 32 x 32 (cout, cin) tile: (KP(Cout)/32) * ci_tiles with ci_tiles = KP(Cin)/32; total_blocks =
+ * their sum.  taps <= 9. */
+extern "C" int hn_pack_weights_batched(const long* jobs, int njobs, long total_blocks, const int* block_job, hipStream_t st) {
     HN_CHECK_ARG(jobs && njobs > 0 && total_blocks > 0);
-    hipLaunchKernelGGL(pack_w_batched_kernel, dim3((unsigned)total_blocks), dim3(256), 0, st, jobs, njobs);
+    hipLaunchKernelGGL(pack_w_batched_kernel, dim3((unsigned)total_blocks), dim3(256), 0, st, jobs, njobs, block_job);
     HN_LAUNCH_CHECK();
 }
 

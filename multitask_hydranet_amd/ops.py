@@ -124,18 +124,22 @@ class PackPlan:
         self.weights = list(weights)
         dev = self.weights[0].device
         self.packs = []
-        rows_, blk = [], 0
+        rows_, blk, owner = [], 0, []
         for w in self.weights:
             cout, cin = w.shape[0], w.shape[1]
             taps = w.shape[2] * w.shape[3]
             wp = torch.empty((cout, taps * kp32(cin)), device=dev, dtype=BF16)
             wt = torch.empty((cin, taps * kp32(cout)), device=dev, dtype=BF16)
             self.packs.append((wp, wt))
-            rows_.append([w.data_ptr(), wp.data_ptr(), wt.data_ptr(), cout, cin, taps, blk, 0])
-            blk += (wp.numel() + wt.numel() + 255) // 256
+            assert taps in (1, 9)
+            rows_.append([w.data_ptr(), wp.data_ptr(), wt.data_ptr(), cout, cin, taps, blk, kp32(cin) // 32])
+            nb = (kp32(cout) // 32) * (kp32(cin) // 32)               # one workgroup per 32 x 32 (cout, cin) tile
+            owner += [len(rows_) - 1] * nb
+            blk += nb
         self.blocks = blk
         self.ptrs = [w.data_ptr() for w in self.weights]
         self.table = torch.tensor(rows_, dtype=torch.int64).to(dev)
+        self.block_job = torch.tensor(owner, dtype=torch.int32).to(dev)
 
     def valid(self):
         """the device job table holds raw weight pointers: a parameter whose storage was swapped (`p.data = ...`, vector_to_parameters, a
@@ -143,7 +147,7 @@ class PackPlan:
         return all(w.data_ptr() == p_ and w.device == self.table.device for w, p_ in zip(self.weights, self.ptrs))
 
     def run(self):
-        lib().call("hn_pack_weights_batched", ptr(self.table), len(self.weights), self.blocks)
+        lib().call("hn_pack_weights_batched", ptr(self.table), len(self.weights), self.blocks, ptr(self.block_job))
         for w, pk in zip(self.weights, self.packs):
             _PACK_CACHE[("conv", id(w))] = (w, w._version, pk)
 

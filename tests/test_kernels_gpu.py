@@ -395,6 +395,29 @@ def test_seg_out_phase_form(K, c, k, n, h, w):
     close(bk.grad, br.grad, GRAD_TOL, "dbias")
 
 
+def test_pack_plan_matches_single_packs(K):
+    """ops.PackPlan (every conv weight in one launch, 32x32 tiles through LDS) writes bit for bit what hn_pack_weight writes one by one:
+    1x1 and 3x3 weights, channel counts that are not multiples of 32 (zero padding of both operand layouts)."""
+    shapes = [(24, 32, 1), (152, 64, 1), (936, 368, 1), (65, 448, 1), (5, 64, 3), (256, 368, 3), (36, 112, 1), (64, 8, 3)]
+    ws = [rnd(co, ci, k, k) for co, ci, k in shapes]
+    K.clear_pack_cache()
+    ref = []
+    for w in ws:
+        wp, wt = K.pack_conv_weight(w)
+        ref.append((wp.clone(), wt.clone()))
+    K.clear_pack_cache()
+    plan = K.PackPlan(ws)
+    for wp, wt in plan.packs:                      # poison: every element (padding included) must be rewritten
+        wp.fill_(7.0)
+        wt.fill_(7.0)
+    plan.run()
+    for (wp, wt), (rp, rt), shp in zip(plan.packs, ref, shapes):
+        assert torch.equal(wp, rp), shp
+        assert torch.equal(wt, rt), shp
+    assert K.pack_conv_weight(ws[2])[0] is plan.packs[2][0]           # run() primes the cache
+    K.clear_pack_cache()
+
+
 @pytest.mark.parametrize("k,c0,c1", [(64, 64, 0), (64, 40, 24), (5, 64, 0), (128, 96, 112)])
 def test_phase_weight_pack_and_fold(K, k, c0, c1):
     """hn_pack_weight_ex (phase form / channel slice) and hn_phase_fold against the definition W_eff = W @ T^T of ops._phase_matrix:
