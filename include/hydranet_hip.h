@@ -308,6 +308,12 @@ int hn_seg_loss_fwd(const float* logits, int ldl, int C, const void* target, int
                     long HW, int use_topk, long k, void* ws, float* out, hipStream_t stream);
 int hn_seg_loss_bwd(const float* logits, int ldl, int C, const void* target, int target_is_float, const float* cw, int ignore_index, int N,
                     long HW, int use_topk, long k, const void* ws, const float* gout, float* dlogits, int ldd, hipStream_t stream);
+/* the same gradient in the layout the phase-form 5-class output conv's backward consumes (hn_space_to_depth of dlogits, rounded to bf16):
+ * dz bf16 [N][H/2][W/2][ldz], channel (py*2+px)*C + c of low-res pixel (y, x) = dlogits(2y+py, 2x+px, c), zeros in [4C, ldz) -- the fp32
+ * dlogits tensor and the pass over it are skipped (head_seg/segmentation.py:101-104 -> segmentation_loss.py:48-65 chain) */
+int hn_seg_loss_bwd_s2d(const float* logits, int ldl, int C, const void* target, int target_is_float, const float* class_weights,
+                        int ignore_index, int N, int H, int W, int use_topk, long k, const void* ws, const float* gout, void* dz, int ldz,
+                        hipStream_t stream);
 /* Detection loss (FocalLoss.forward, head_detect/detection_loss.py:132-267): cls fp32 [N][A][K] (post-sigmoid), reg [N][A][4], anchors
  * [A][4] (y1,x1,y2,x2), ann [N][Mx][5] (x1,y1,x2,y2,class; rows with class -1 are padding).  out[0] / out[1] = batch-mean classification /
  * regression loss.  assign: int16 [N][A]; part: fp32 [N][hn_det_loss_blocks(A)][3]; npos: fp32 [N] (all written by fwd, read by bwd). */

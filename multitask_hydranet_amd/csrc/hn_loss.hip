@@ -198,6 +198,52 @@ __global__ __launch_bounds__(256) void seg_ce_bwd_kernel(const float* logits, in
     }
 }
 
+// the same gradient written straight into the operand the phase-form output conv's backward consumes (ops.SegOutUp): bf16
+// [N][H/2][W/2][ldz], channel (py*2+px)*C + c of low-res pixel (y, x) = dlogits(2y+py, 2x+px, c), zeros in [4C, ldz).  One thread per
+// low-res pixel writes one contiguous row; the fp32 dlogits tensor (168 MB at 16 x 512 x 1024 x 5) and the separate space-to-depth pass
+// over it are never materialised.
+__global__ __launch_bounds__(256) void seg_ce_bwd_s2d_kernel(const float* logits, int ldl, int C, const void* target, int target_is_float,
+                                                             const float* cw, int ignore_index, int H, int W, long M4, const float* loss,
+                                                             const SelState* st, const unsigned int* ties, int use_topk, const float* gout,
+                                                             float inv_denom, bf16* dz, int ldz) {
+    const float gs = gout[0] * inv_denom;
+    const int h = H >> 1, w = W >> 1;
+    const long HW = (long)H * W;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < M4; q += (long)gridDim.x * 256) {
+        const int x = (int)(q % w);
+        const long t = q / w;
+        const int y = (int)(t % h);
+        const int n = (int)(t / h);
+        bf16* d = dz + q * ldz;
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) {
+            const long m = (long)n * HW + (long)(2 * y + (ph >> 1)) * W + 2 * x + (ph & 1);
+            const int yy = target_is_float ? (int)reinterpret_cast<const float*>(target)[m] : (int)reinterpret_cast<const long*>(target)[m];
+            float sel = 0.f;
+            if (yy != ignore_index && yy >= 0 && yy < C) {
+                sel = 1.f;
+                if (use_topk) {
+                    const unsigned int u = __float_as_uint(loss[m]), thr = st[n].prefix;
+                    if (u < thr) sel = 0.f;
+                    else if (u == thr) sel = (float)st[n].remaining / (float)(ties[n] > 0 ? ties[n] : 1u);
+                }
+            }
+            if (sel == 0.f) {
+                for (int c = 0; c < C; ++c) d[ph * C + c] = f2bf(0.f);
+                continue;
+            }
+            const float* row = logits + m * ldl;
+            float mx = row[0];
+            for (int c = 1; c < C; ++c) mx = fmaxf(mx, row[c]);
+            float e[HN_SEG_MAXC], se = 0.f;
+            for (int c = 0; c < C; ++c) { e[c] = __expf(row[c] - mx); se += e[c]; }
+            const float k = gs * sel * cw[yy] / se;
+            for (int c = 0; c < C; ++c) d[ph * C + c] = f2bf(k * e[c] - (c == yy ? gs * sel * cw[yy] : 0.f));
+        }
+        for (int c = 4 * C; c < ldz; ++c) d[c] = f2bf(0.f);
+    }
+}
+
 // number of elements exactly at the threshold, per image (for the tie share in backward): it is hist level-2 bin = prefix&1023, saved
 // by the select kernel before clearing; simpler: count again
 __global__ __launch_bounds__(256) void seg_count_ties_kernel(const float* loss, long HW, long M, const SelState* st, unsigned int* ties) {
@@ -440,6 +486,26 @@ extern "C" int hn_seg_loss_bwd(const float* logits, int ldl, int C, const void* 
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(seg_ce_bwd_kernel, dim3(blocks), dim3(256), 0, st, logits, ldl, C, target, target_is_float, cw, ignore_index, HW, M, loss,
                        state, ties, use_topk, gout, (float)(1.0 / denom), dlogits, ldd);
+    HN_LAUNCH_CHECK();
+}
+
+/* hn_seg_loss_bwd writing the space-to-depth bf16 operand of the phase-form output conv's backward instead of fp32 dlogits:
+ * dz [N][H/2][W/2][ldz], ldz >= 4*C (see seg_ce_bwd_s2d_kernel); H, W even */
+extern "C" int hn_seg_loss_bwd_s2d(const float* logits, int ldl, int C, const void* target, int target_is_float, const float* cw,
+                                   int ignore_index, int N, int H, int W, int use_topk, long k, const void* ws, const float* gout, void* dz,
+                                   int ldz, hipStream_t st) {
+    HN_CHECK_ARG(logits && target && cw && ws && gout && dz && C >= 1 && C <= HN_SEG_MAXC && N > 0 && H > 0 && W > 0 && !(H & 1) && !(W & 1) &&
+                 ldz >= 4 * C);
+    const long HW = (long)H * W, M = (long)N * HW;
+    const char* w = (const char*)ws;
+    const float* loss = (const float*)w;
+    const SelState* state = (const SelState*)(w + M * 4 + (long)N * 2048 * 4);
+    const unsigned int* ties = (const unsigned int*)(w + M * 4 + (long)N * 2048 * 4 + (long)N * 8);
+    const double denom = use_topk ? (double)N * (double)k : (double)M;
+    long blocks = (M / 4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(seg_ce_bwd_s2d_kernel, dim3(blocks), dim3(256), 0, st, logits, ldl, C, target, target_is_float, cw, ignore_index, H, W,
+                       M / 4, loss, state, ties, use_topk, gout, (float)(1.0 / denom), (bf16*)dz, ldz);
     HN_LAUNCH_CHECK();
 }
 

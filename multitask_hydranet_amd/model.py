@@ -504,7 +504,10 @@ class HydraNet(nn.Module):
                 x = K.SegConv.apply(x, skip, wgt, P[f"{p}{2 * i + 1}.conv.conv.bias"], 1, ACT_ELU, False, fuse, fuse)
         last = 2 * n
         if self.seg_phase_output:          # final 3x3 over the up-sampled map as a 4-phase conv on the low-resolution grid (ops.SegOutUp)
-            y = K.SegOutUp.apply(x, P[f"{p}{last}.conv.weight"], P[f"{p}{last}.conv.bias"], fuse)
+            # the loss may hand its gradient over in this node's operand form (no fp32 dlogits tensor): see _seg_loss
+            slot = K.GradSlot() if (x.requires_grad and self.training) else None
+            y = K.SegOutUp.apply(x, P[f"{p}{last}.conv.weight"], P[f"{p}{last}.conv.bias"], fuse, slot)
+            self._seg_grad_slot = (slot, y.data_ptr(), tuple(y.shape)) if slot is not None else None
         else:
             y = K.SegConv.apply(x, None, P[f"{p}{last}.conv.weight"], P[f"{p}{last}.conv.bias"], 1, ACT_NONE, True, fuse, False)
         return y.permute(0, 3, 1, 2)
@@ -695,7 +698,11 @@ class HydraNet(nn.Module):
         if use_focal:                                   # small-cfg variant (a few elementwise device ops on the HIP logits), not benchmarked
             # the reference always hands gt_seg.long() to the loss (model.py:212); to_gpu delivers float32 class ids
             return L.seg_loss(logits, target.long(), self._seg_class_weight, use_top_k, ratio, use_focal)
-        return K.seg_loss_hip(logits, target, self._seg_class_weight, use_top_k, ratio)      # no CPU fallback: raises off-device
+        slot = None
+        key = getattr(self, "_seg_grad_slot", None)
+        if key is not None and logits.data_ptr() == key[1] and tuple(logits.permute(0, 2, 3, 1).shape) == key[2]:
+            slot, self._seg_grad_slot = key[0], None                  # this forward's own "seg" output, consumed once
+        return K.seg_loss_hip(logits, target, self._seg_class_weight, use_top_k, ratio, slot=slot)      # no CPU fallback: raises off-device
 
     def _guard(self, value, what, allow_zero=False):
         if self.check_finite and ((not allow_zero and value == 0) or not torch.isfinite(value)):

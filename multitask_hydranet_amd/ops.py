@@ -1203,9 +1203,13 @@ class SegLoss(torch.autograd.Function):
     """logits: fp32 NHWC [N, H, W, C] (dense rows); target: [N, H, W] int64 or float32 class ids."""
 
     @staticmethod
-    def forward(ctx, logits, target, class_weights, use_top_k, top_k_ratio, ignore_index):
+    def forward(ctx, logits, target, class_weights, use_top_k, top_k_ratio, ignore_index, slot=None):
+        """slot (GradSlot of the producing SegOutUp node): the gradient is handed over as that node's space-to-depth bf16 operand
+        (hn_seg_loss_bwd_s2d) instead of an fp32 dlogits tensor"""
         n, h, w, c = logits.shape
         hw = h * w
+        ctx.slot = slot if (slot is not None and h % 2 == 0 and w % 2 == 0) else None
+        ctx.hw_dims = (h, w)
         k = int(top_k_ratio * hw) if use_top_k else hw
         dev = logits.device
         ws = torch.empty((lib().query("hn_seg_loss_ws_bytes", n, hw),), device=dev, dtype=torch.uint8)
@@ -1222,19 +1226,27 @@ class SegLoss(torch.autograd.Function):
     def backward(ctx, gout):
         logits, target, cw, ws = ctx.saved_tensors
         n, hw, c, tf, topk, k, ign = ctx.meta
-        dl = torch.empty_like(logits)
         g = gout.contiguous().to(F32).view(1)
+        if ctx.slot is not None and ctx.slot.buf is None:
+            h, w = ctx.hw_dims
+            dz = new_act(n, h // 2, w // 2, pad8(4 * c), logits.device)
+            lib().call("hn_seg_loss_bwd_s2d", ptr(logits), logits.stride(2), c, ptr(target), tf, ptr(cw), ign, n, h, w, topk, k, ptr(ws), ptr(g),
+                       ptr(dz), ld(dz))
+            ctx.slot.buf = dz
+            return None, None, None, None, None, None, None
+        dl = torch.empty_like(logits)
         lib().call("hn_seg_loss_bwd", ptr(logits), logits.stride(2), c, ptr(target), tf, ptr(cw), ign, n, hw, topk, k, ptr(ws), ptr(g),
                    ptr(dl), dl.stride(2))
-        return dl, None, None, None, None, None
+        return dl, None, None, None, None, None, None
 
 
-def seg_loss_hip(seg_nchw, target, class_weights, use_top_k, top_k_ratio, ignore_index=255):
-    """seg_nchw: the module's "seg" output (fp32, NCHW-shaped view of NHWC memory)."""
+def seg_loss_hip(seg_nchw, target, class_weights, use_top_k, top_k_ratio, ignore_index=255, slot=None):
+    """seg_nchw: the module's "seg" output (fp32, NCHW-shaped view of NHWC memory).  slot: GradSlot of the SegOutUp node that produced
+    exactly this tensor (HydraNet passes it when its own cal_loss consumes its own "seg" output)."""
     logits = seg_nchw.permute(0, 2, 3, 1)
     if not logits.is_contiguous():
-        logits = logits.contiguous()
-    return SegLoss.apply(logits, target.contiguous(), class_weights, use_top_k, top_k_ratio, ignore_index)
+        logits, slot = logits.contiguous(), None
+    return SegLoss.apply(logits, target.contiguous(), class_weights, use_top_k, top_k_ratio, ignore_index, slot)
 
 
 def argmax_channels(seg_nchw):
@@ -1541,10 +1553,13 @@ class SegOutUp(torch.autograd.Function):
     """logits[N, 2h, 2w, k] (fp32) = Conv3x3(ReflectionPad2d(1)(nearest_up2(x))) + bias, x [N, h, w, c] bf16."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, x_is_elu=False):
+    def forward(ctx, x, weight, bias, x_is_elu=False, slot=None):
+        """slot: GradSlot through which the loss may deliver the gradient already in this node's space-to-depth bf16 operand form"""
         n, h, w, c = x.shape
         k = weight.shape[0]
         ctx.x_is_elu = x_is_elu
+        ctx.slot = slot
+        ctx.set_materialize_grads(False)
         wp, wt, b_eff = pack_phase_weight(weight, c, bias)
         out = torch.empty((n, 2 * h, 2 * w, k), device=x.device, dtype=F32)
         # img_stride = -k: the conv epilogue scatters phase (py, px) of low-res pixel (y, x) to output pixel (2y+py, 2x+px) itself
@@ -1560,10 +1575,16 @@ class SegOutUp(torch.autograd.Function):
         n, h, w, c = x.shape
         k = ctx.k
         dev = x.device
-        dy = dy.contiguous()
         ldz = pad8(4 * k)
-        dz = new_act(n, h, w, ldz, dev)
-        lib().call("hn_space_to_depth", ptr(dy), ptr(dz), ldz, n, h, w, k)
+        dz = None
+        if ctx.slot is not None and ctx.slot.buf is not None:          # delivered by SegLoss.backward in operand form
+            dz, ctx.slot.buf = ctx.slot.buf, None
+        if dy is not None:
+            d2 = new_act(n, h, w, ldz, dev)
+            lib().call("hn_space_to_depth", ptr(dy.contiguous()), ptr(d2), ldz, n, h, w, k)
+            dz = d2 if dz is None else k_eltwise(0, dz, d2)
+        if dz is None:
+            return None, None, None, None, None
         ps, _, _ = k_col_stats(dz)
         db_eff = k_rows_reduce(ps, 1, ps.shape[0], ldz)
         dw_eff = k_gemm_tn(x, None, 4, (n, h, w), dz, 4 * k, kp32(c), 9, c, kh=3)                       # [4k, c, 3, 3]
@@ -1576,7 +1597,7 @@ class SegOutUp(torch.autograd.Function):
             dx = new_act(n, h, w, c, dev)
             yp = x if ctx.x_is_elu else None
             lib().call("hn_seg_fold", ptr(dvp), ld(dvp), 0, ptr(dx), ld(dx), ptr(yp), ld(yp) if yp is not None else 0, n, h, w, c, 2)
-        return dx, dw, dbias, None
+        return dx, dw, dbias, None, None
 
 
 class SegConvUp(torch.autograd.Function):

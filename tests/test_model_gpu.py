@@ -408,6 +408,44 @@ def test_focal_seg_loss_takes_float_class_ids():
 
 
 @pytest.mark.gpu
+def test_seg_loss_gradient_handover_is_bit_identical(env):
+    """HydraNet.cal_loss on the module's own "seg" output hands the CE gradient to the phase-form output conv in its space-to-depth bf16
+    operand form (hn_seg_loss_bwd_s2d through a GradSlot: no fp32 dlogits tensor, no space-to-depth pass).  Same roundings at the same
+    places: every seg-decoder gradient must be bit-identical to the plain dlogits path; a second consumer of the logits is added on top."""
+    z, cfgs, net, batch, oracle, sd = env
+    net.load_state_dict(sd)
+    net.train()
+    x = batch["image"].to("cuda:0")
+    gt = batch["gt_seg"].to("cuda:0")
+    names = [n for n, _ in net.named_parameters() if n.startswith("segheader.")]
+    P = dict(net.named_parameters())
+
+    def run(handover, extra):
+        for p_ in net.parameters():
+            p_.grad = None
+        out = net(x)
+        assert net._seg_grad_slot is not None
+        if not handover:
+            net._seg_grad_slot = None
+        loss = net.loss_seg(out["seg"], gt)
+        if extra:
+            loss = loss + out["seg"].square().mean()                  # a consumer that knows nothing about the slot
+        loss.backward()
+        return float(loss), {n: P[n].grad.clone() for n in names}
+
+    for extra in (False, True):
+        l0, g0 = run(False, extra)
+        l1, g1 = run(True, extra)
+        assert l0 == l1
+        for n in names:
+            if extra:
+                # two bf16-rounded operands summed instead of one rounding of the fp32 sum: max-norm 2e-2
+                assert float((g1[n] - g0[n]).abs().max()) <= 2e-2 * float(g0[n].abs().max()) + 1e-12, n
+            else:
+                assert torch.equal(g0[n], g1[n]), n
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cin,c,n,h,w", [(32, 24, 2, 32, 48), (64, 152, 4, 32, 64), (368, 936, 4, 16, 32)])
 def test_xblock_stride2_fused_node_equals_unfused_composition(cin, c, n, h, w):
     """The first block of a stage (stride 2, projection shortcut conv + BN, net/anynet.py:55-76) as ONE XBlockFn node -- stride-2 grouped
