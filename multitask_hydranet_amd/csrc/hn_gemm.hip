@@ -590,38 +590,34 @@ __global__ __launch_bounds__(512, PIPE ? 2 : 4) void conv3x3_direct_kernel(const
     };
     const int xc0 = xs.diag ? c_blk : 0;                              // first input channel of chunk 0
 
-    // patch pieces owned by this thread: e = tid + 512 i -> patch pixel e>>3, PHYSICAL piece e&7 (logical = physical ^ (pixel&7))
-    int spix0[XL], spix1[XL];
-    int ssub[XL];
+    // patch pieces owned by this thread: e = tid + 512 i -> patch pixel e>>3, PHYSICAL piece e&7 (logical = physical ^ (pixel&7)).
+    // One register per piece: the source pixel as (gy << 16 | gx) in full-resolution coordinates (-1: outside / zero); the row index in
+    // either operand and the channel sub-offset are recomputed when the load is issued (this kernel sits at the 128-VGPR limit of two
+    // co-resident workgroups: three registers per piece cost 12 spilled VGPRs = 52 B/lane of scratch traffic).
+    int spack[XL];
 #pragma unroll
     for (int i = 0; i < XL; ++i) {
-        const int e = tid + 512 * i;
-        const int pp = e >> 3;
-        ssub[i] = (((e & 7) ^ (pp & 7)) << 3);
-        spix0[i] = -1;
-        spix1[i] = -1;
+        const int pp = (tid + 512 * i) >> 3;
+        spack[i] = -1;
         if (pp < PPIX) {
             const int py = pp / 18, px = pp - py * 18;
             int gy = oy0 + org + py, gx = ox0 + org + px;
             if (xs.mode == 2) {
                 gy = border_idx(gy, xs.Hi, xs.clamp);
                 gx = border_idx(gx, xs.Wi, xs.clamp);
-                if (gy >= 0 && gx >= 0) {                             // (negative only for pixels that feed no in-image output)
-                    spix0[i] = (n * (xs.Hi >> xs.up) + (gy >> xs.up)) * (xs.Wi >> xs.up) + (gx >> xs.up);
-                    if (xs.C1) spix1[i] = (n * xs.Hi + gy) * xs.Wi + gx;
-                }
+                if (gy >= 0 && gx >= 0) spack[i] = (gy << 16) | gx;   // (negative only for pixels that feed no in-image output)
             } else if (gy >= 0 && gy < xs.Hi && gx >= 0 && gx < xs.Wi) {
-                spix0[i] = (n * xs.Hi + gy) * xs.Wi + gx;
+                spack[i] = (gy << 16) | gx;
             }
         }
     }
     // weight pieces: row = (tid>>3) + 64 i, physical piece tid&7
     const int wsub = (((tid & 7) ^ ((tid >> 3) & 7)) << 3);
-    long wrow[WL];
+    int wrow[WL];                                                      // element offset of the thread's weight row (32-bit: Nout * 9 * KP < 2^31)
 #pragma unroll
     for (int i = 0; i < WL; ++i) {
         const int co = c_blk + (tid >> 3) + 64 * i;
-        wrow[i] = ((tid >> 3) + 64 * i < BC && co < p.Nout) ? (long)co * Ktot + wsub : -1;
+        wrow[i] = ((tid >> 3) + 64 * i < BC && co < p.Nout) ? co * Ktot + wsub : -1;
     }
 
     f32x4 acc[TC][TP];
@@ -674,11 +670,15 @@ __global__ __launch_bounds__(512, PIPE ? 2 : 4) void conv3x3_direct_kernel(const
 #pragma unroll
         for (int i = 0; i < XL; ++i) {
             if (PIPE || 512 * i + 64 * wave < PPIX * 8) {              // PIPE: every wave issues all XL rounds (padded buffer)
-                const int c = xc0 + k0 + ssub[i];
+                const int e = tid + 512 * i;
+                const int c = xc0 + k0 + ((((e & 7) ^ ((e >> 3) & 7))) << 3);
                 const bf16* src = g_zero_piece;
-                if (c < Ctot) {
-                    if (c < xs.C0) { if (spix0[i] >= 0) src = xs.x0 + c + (long)spix0[i] * xs.ld0; }
-                    else if (spix1[i] >= 0) src = xs.x1 + (c - xs.C0) + (long)spix1[i] * xs.ld1;
+                int pk = spack[i];
+                asm volatile("" : "+v"(pk));                          // keep the 64-bit row pointers out of loop-invariant registers
+                if (c < Ctot && pk >= 0) {
+                    const int gy = pk >> 16, gx = pk & 0xffff;
+                    if (c < xs.C0) src = xs.x0 + c + (long)((n * (xs.Hi >> xs.up) + (gy >> xs.up)) * (xs.Wi >> xs.up) + (gx >> xs.up)) * xs.ld0;
+                    else src = xs.x1 + (c - xs.C0) + (long)((n * xs.Hi + gy) * xs.Wi + gx) * xs.ld1;
                 }
                 glds16(src, sX + (512 * i + 64 * wave) * 16);
             }
@@ -724,21 +724,7 @@ __global__ __launch_bounds__(512, PIPE ? 2 : 4) void conv3x3_direct_kernel(const
                     glds16(src, sW + (wave * 8 + 64 * i) * 128);
                 }
             }
-            if (ti == 0) {
-                char* sX = sXb + (XBUFS == 2 ? (chunk & 1) : 0) * XBYTES;
-#pragma unroll
-                for (int i = 0; i < XL; ++i) {
-                    if (512 * i + 64 * wave < PPIX * 8) {             // wave-uniform: this 1 KiB run starts inside the patch
-                        const int c = xc0 + k0 + ssub[i];
-                        const bf16* src = g_zero_piece;
-                        if (c < Ctot) {
-                            if (c < xs.C0) { if (spix0[i] >= 0) src = xs.x0 + c + (long)spix0[i] * xs.ld0; }
-                            else if (spix1[i] >= 0) src = xs.x1 + (c - xs.C0) + (long)spix1[i] * xs.ld1;
-                        }
-                        glds16(src, sX + (512 * i + 64 * wave) * 16);
-                    }
-                }
-            }
+            if (ti == 0) issue_x(chunk);
         }
         if (it > 0 && !boundary) compute(it - 1);
     }
