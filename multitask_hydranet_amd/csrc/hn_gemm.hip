@@ -772,6 +772,14 @@ __global__ __launch_bounds__(512, PIPE ? 2 : 4) void conv3x3_direct_kernel(const
     // epilogue: bias, activation (one uniform branch per 4 values, in place on the accumulators: no second copy of the wave tile in
     // registers), store 4 consecutive couts per lane
     const int ox = ox0 + (lane & 15);
+    // phase form, bf16: the depth-to-space scatter writes 8 bytes per lane 1 KiB apart; partial-line writes make L2 fetch every output
+    // line before merging (measured: FETCH_SIZE +124 MB, WRITE_SIZE +28 MB on a 67 MB output).  The finished bf16 tile is staged in LDS
+    // ([256 px][BC], 16-byte pieces XOR-swizzled by the pixel) and leaves as whole BC*2-byte runs per output pixel.
+    // The same holds for every bf16 output of this kernel (8 bytes per lane, one row stride apart): all of them are staged.
+    const bool stage_d2s = !OUT_F32 && (p.ldc & 7) == 0 && (p.Nout & 7) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0 && BC >= 64 &&
+                           (!p.d2s || ((p.d2s & 7) == 0 && c_blk + BC <= p.Nout));
+    char* stage = smem;
+    if (stage_d2s) __syncthreads();                                   // every wave is done with the operand buffers
 #pragma unroll
     for (int i = 0; i < TC; ++i) {
         const int co0 = c_blk + wc * WCO + i * 16 + (lane >> 4) * 4;
@@ -793,13 +801,20 @@ __global__ __launch_bounds__(512, PIPE ? 2 : 4) void conv3x3_direct_kernel(const
                     const int ph = co0 / p.d2s, oc = co0 - ph * p.d2s;
                     const long opix = ((long)(n * 2 * xs.H + 2 * oy + (ph >> 1)) * (2 * xs.W) + 2 * ox + (ph & 1));
                     if (p.addend) {
+                        // (plain load: the four cout sub-tiles of a lane touch the same 128-byte lines one after the other -- a
+                        // non-temporal load re-fetched them from memory every time: 2x FETCH_SIZE, 128 -> 178 us)
                         const bf16x4 a = *reinterpret_cast<const bf16x4*>(p.addend + opix * p.ld_add + oc);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] += bf2f(a[r]);
                     }
                     act_fwd_n(v, p.act);
                     bf16x4 tv = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-                    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.out) + opix * p.ldc + oc) = tv;
+                    if (stage_d2s) {
+                        const int pl = (wp * ROWS + j) * 16 + (lane & 15), cl = wc * WCO + i * 16 + (lane >> 4) * 4;
+                        *reinterpret_cast<bf16x4*>(stage + pl * (BC * 2) + ((((cl >> 3) ^ pl) & (BC / 8 - 1)) << 4) + (cl & 7) * 2) = tv;
+                    } else {
+                        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.out) + opix * p.ldc + oc) = tv;
+                    }
                 }
                 continue;
             }
@@ -823,13 +838,34 @@ __global__ __launch_bounds__(512, PIPE ? 2 : 4) void conv3x3_direct_kernel(const
                 }
             } else {
                 bf16* o = reinterpret_cast<bf16*>(p.out) + orow + co0;
-                if (co0 + 3 < p.Nout && (reinterpret_cast<uintptr_t>(o) & 7) == 0) {
+                if (stage_d2s) {
+                    bf16x4 tv = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                    const int pl = (wp * ROWS + j) * 16 + (lane & 15), cl = wc * WCO + i * 16 + (lane >> 4) * 4;
+                    *reinterpret_cast<bf16x4*>(stage + pl * (BC * 2) + ((((cl >> 3) ^ pl) & (BC / 8 - 1)) << 4) + (cl & 7) * 2) = tv;
+                } else if (co0 + 3 < p.Nout && (reinterpret_cast<uintptr_t>(o) & 7) == 0) {
                     bf16x4 tv = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
                     *reinterpret_cast<bf16x4*>(o) = tv;
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) if (co0 + r < p.Nout) o[r] = f2bf(v[r]);
                 }
+            }
+        }
+    }
+    if (stage_d2s) {
+        __syncthreads();
+        constexpr int NPC = BC / 8;                                   // 16-byte pieces per output pixel
+        const int ph = p.d2s ? c_blk / p.d2s : 0, oc0 = p.d2s ? c_blk - ph * p.d2s : c_blk;    // (d2s: the whole cout tile lies in one phase)
+        bf16* outp = reinterpret_cast<bf16*>(p.out);
+#pragma unroll 2
+        for (int idx = tid; idx < 256 * NPC; idx += 512) {
+            const int pl = idx / NPC, pc = idx - pl * NPC;
+            const int oy = oy0 + (pl >> 4), oxx = ox0 + (pl & 15);
+            if (oy < xs.H && oxx < xs.W && c_blk + pc * 8 < p.Nout) {
+                const long opix = p.d2s ? ((long)(n * 2 * xs.H + 2 * oy + (ph >> 1)) * (2 * xs.W) + 2 * oxx + (ph & 1))
+                                        : ((long)(n * xs.H + oy) * xs.W + oxx);
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(stage + pl * (BC * 2) + (((pc ^ pl) & (NPC - 1)) << 4));
+                *reinterpret_cast<bf16x8*>(outp + opix * p.ldc + oc0 + pc * 8) = v;
             }
         }
     }
