@@ -778,8 +778,12 @@ __global__ __launch_bounds__(512, PIPE ? 2 : 4) void conv3x3_direct_kernel(const
     // The same holds for every bf16 output of this kernel (8 bytes per lane, one row stride apart): all of them are staged.
     const bool stage_d2s = !OUT_F32 && (p.ldc & 7) == 0 && (p.Nout & 7) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0 && BC >= 64 &&
                            (!p.d2s || ((p.d2s & 7) == 0 && c_blk + BC <= p.Nout));
+    // fp32 depth-to-space output (the 5-class logits): 4-byte stores scattered over four output pixels per lane; the 32 x 32-pixel x k
+    // output tile is assembled in LDS and written as contiguous rows of 32*k floats
+    const bool stage_f32 = OUT_F32 && p.d2s && c_blk == 0 && p.Nout <= BC && 32 * 32 * p.d2s * 4 <= 32768 && ((2 * xs.W * p.d2s) & 3) == 0 &&
+                           ((32 * p.d2s) & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0;
     char* stage = smem;
-    if (stage_d2s) __syncthreads();                                   // every wave is done with the operand buffers
+    if (stage_d2s || stage_f32) __syncthreads();                      // every wave is done with the operand buffers
 #pragma unroll
     for (int i = 0; i < TC; ++i) {
         const int co0 = c_blk + wc * WCO + i * 16 + (lane >> 4) * 4;
@@ -826,7 +830,12 @@ __global__ __launch_bounds__(512, PIPE ? 2 : 4) void conv3x3_direct_kernel(const
                     const int c = co0 + r;
                     if (c < p.Nout) {
                         const int ph = c / p.d2s, oc = c - ph * p.d2s;
-                        ob[((long)(n * 2 * xs.H + 2 * oy + (ph >> 1)) * (2 * xs.W) + 2 * ox + (ph & 1)) * p.d2s + oc] = v[r];
+                        if (stage_f32) {                               // tile-local: row 2*ly + py, column (2*lx + px) * k + oc
+                            const int ly = wp * ROWS + j, lx = lane & 15;
+                            reinterpret_cast<float*>(stage)[(2 * ly + (ph >> 1)) * (32 * p.d2s) + (2 * lx + (ph & 1)) * p.d2s + oc] = v[r];
+                        } else {
+                            ob[((long)(n * 2 * xs.H + 2 * oy + (ph >> 1)) * (2 * xs.W) + 2 * ox + (ph & 1)) * p.d2s + oc] = v[r];
+                        }
                     }
                 }
             } else if (OUT_F32) {
@@ -849,6 +858,22 @@ __global__ __launch_bounds__(512, PIPE ? 2 : 4) void conv3x3_direct_kernel(const
 #pragma unroll
                     for (int r = 0; r < 4; ++r) if (co0 + r < p.Nout) o[r] = f2bf(v[r]);
                 }
+            }
+        }
+    }
+    if (stage_f32) {
+        __syncthreads();
+        const int rowf = 32 * p.d2s, row4 = rowf >> 2;                // floats / float4 per tile row
+        float* ob = reinterpret_cast<float*>(p.out);
+        for (int idx = tid; idx < 32 * row4; idx += 512) {
+            const int Y = idx / row4, q4 = idx - Y * row4;
+            const int gy = 2 * oy0 + Y;
+            const int valid = (2 * xs.W - 2 * ox0) * p.d2s;           // floats of this row that lie inside the image
+            if (gy < 2 * xs.H && q4 * 4 < valid) {
+                float* dst = ob + ((long)(n * 2 * xs.H + gy) * (2 * xs.W) + 2 * ox0) * p.d2s + q4 * 4;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(stage) + Y * rowf + q4 * 4);
+                if (q4 * 4 + 4 <= valid) *reinterpret_cast<f32x4*>(dst) = v;
+                else for (int k = 0; q4 * 4 + k < valid; ++k) dst[k] = v[k];
             }
         }
     }
