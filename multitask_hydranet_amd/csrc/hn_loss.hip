@@ -46,6 +46,56 @@ __global__ __launch_bounds__(256) void seg_ce_fwd_kernel(const float* logits, in
     }
 }
 
+// compile-time class count, four consecutive pixels per thread: 4*CT contiguous floats = CT float4 loads, float4 targets, float4 loss store
+template <int CT>
+__global__ __launch_bounds__(256) void seg_ce_fwd_vec_kernel(const float* logits, const float* target, const float* cw, int ignore_index,
+                                                             long HW, long M, float* loss, unsigned int* hist) {
+    __shared__ unsigned int sh[2048];
+    const bool do_hist = hist != nullptr;
+    if (do_hist) {
+        for (int i = threadIdx.x; i < 2048; i += 256) sh[i] = 0;
+        __syncthreads();
+    }
+    const int bpi = gridDim.x / (int)(M / HW);
+    const int n = blockIdx.x / bpi, b = blockIdx.x - n * bpi;
+    const long per = ((HW / 4 + bpi - 1) / bpi) * 4;                  // pixels per block, a multiple of 4 (HW % 4 == 0)
+    const long p0 = (long)n * HW + b * per;
+    long p1 = p0 + per;
+    if (p1 > (long)(n + 1) * HW) p1 = (long)(n + 1) * HW;
+    for (long m = p0 + 4 * threadIdx.x; m < p1; m += 1024) {
+        float lg[4 * CT];
+        const f32x4* row = reinterpret_cast<const f32x4*>(logits + m * CT);
+#pragma unroll
+        for (int k = 0; k < CT; ++k) { const f32x4 v = row[k]; lg[4 * k] = v[0]; lg[4 * k + 1] = v[1]; lg[4 * k + 2] = v[2]; lg[4 * k + 3] = v[3]; }
+        const f32x4 tg = *reinterpret_cast<const f32x4*>(target + m);
+        f32x4 lo;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int y = (int)tg[u];
+            float l = 0.f;
+            if (y != ignore_index && y >= 0 && y < CT) {
+                const float* r = &lg[u * CT];
+                float mx = r[0];
+#pragma unroll
+                for (int c = 1; c < CT; ++c) mx = fmaxf(mx, r[c]);
+                float se = 0.f, ry = 0.f;
+#pragma unroll
+                for (int c = 0; c < CT; ++c) { se += __expf(r[c] - mx); ry = c == y ? r[c] : ry; }
+                l = cw[y] * (mx + __logf(se) - ry);
+                if (l < 0.f) l = 0.f;
+            }
+            lo[u] = l;
+            if (do_hist) atomicAdd(&sh[__float_as_uint(l) >> 21], 1u);
+        }
+        *reinterpret_cast<f32x4*>(loss + m) = lo;
+    }
+    if (do_hist) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2048; i += 256)
+            if (sh[i]) atomicAdd(&hist[(long)n * 2048 + i], sh[i]);
+    }
+}
+
 // radix-select state per image: prefix (bits fixed so far), remaining rank r (how many of the still-ambiguous bin are needed)
 struct SelState { unsigned int prefix; unsigned int remaining; };
 
@@ -527,8 +577,13 @@ extern "C" int hn_seg_loss_fwd(const float* logits, int ldl, int C, const void* 
         const long words = (long)N * 2048 + (long)N * 3;
         hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, hist, words);
     }
-    hipLaunchKernelGGL(seg_ce_fwd_kernel, dim3(blocks), dim3(256), 0, st, logits, ldl, C, target, target_is_float, cw, ignore_index, HW, M, loss,
-                       use_topk ? hist : (unsigned int*)nullptr);
+    if (C == 5 && ldl == 5 && target_is_float && (HW & 3) == 0 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(target) & 15) == 0)
+        hipLaunchKernelGGL(seg_ce_fwd_vec_kernel<5>, dim3(blocks), dim3(256), 0, st, logits, (const float*)target, cw, ignore_index, HW, M, loss,
+                           use_topk ? hist : (unsigned int*)nullptr);
+    else
+        hipLaunchKernelGGL(seg_ce_fwd_kernel, dim3(blocks), dim3(256), 0, st, logits, ldl, C, target, target_is_float, cw, ignore_index, HW, M,
+                           loss, use_topk ? hist : (unsigned int*)nullptr);
     if (use_topk) {
         hipLaunchKernelGGL(seg_select_kernel, dim3(N), dim3(64), 0, st, hist, state, 0, (unsigned int)k);
         hipLaunchKernelGGL(seg_hist_kernel, dim3(blocks), dim3(256), 0, st, loss, HW, M, state, 1, hist);
