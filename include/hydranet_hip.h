@@ -42,6 +42,11 @@ int hn_phase_fold(const float* dw_eff, const float* dw1, const float* db_eff, fl
  * the tile passes through LDS so that both operand layouts are written in contiguous runs.  taps = 1 or 9.  block_job (optional, DEVICE
  * int32 [total_blocks]) = job index of every block (otherwise each block searches the table). */
 int hn_pack_weights_batched(const long* jobs, int njobs, long total_blocks, const int* block_job, hipStream_t stream);
+/* the remaining per-step packs of a model (depthwise taps = hn_dw_pack, grouped-conv stencil operands = hn_gconv_pack, block-diagonal MFMA
+ * operands = hn_gconv_pack_diag, channel-slice / phase-form packs = hn_pack_weight_ex) in one launch: jobs = DEVICE table njobs x 16 int64
+ * {w, out0, out1, out2, bias, kind 1..4, first_block, p0..p5, 0, 0, 0} with the parameters of the single-weight entry point of that kind,
+ * one thread per output element; block_job = DEVICE int32 [total_blocks] */
+int hn_pack_small_batched(const long* jobs, const int* block_job, long total_blocks, hipStream_t stream);
 
 /* out[pixel][cout] = act(bias[cout] + sum_{tap,c} X(pixel, tap)[c] * w[cout][tap][c]); X is gathered on the fly:
  *   mode 0: X = x0 rows (1x1 conv; also every dgrad of a 1x1 conv)            nn.Conv2d k=1: net/anynet.py:29-33,52-60;

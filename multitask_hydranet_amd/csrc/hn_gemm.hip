@@ -1474,6 +1474,76 @@ __global__ __launch_bounds__(256) void pack_w_batched_kernel(const long* jobs, i
     else if (taps == 9) pack_tile<9>(w, wp, wt, Cout, Cin, co0, ci0, tile);
 }
 
+// The remaining per-step weight packs of a model in ONE launch (they were ~70 launches of 4-16 us: depthwise taps, grouped-conv stencil
+// and block-diagonal operands, phase-form / channel-slice packs).  jobs[j] = 16 int64:
+//   {w, out0, out1, out2, bias, kind, first_block, p0, p1, p2, p3, p4, p5, 0, 0, 0}; one thread per output element, 256 per block.
+//   kind 1: depthwise [C][1][3][3] -> out0 = wk[tap][C], out1 = wkf[8-tap][C]                              p0 = C
+//   kind 2: grouped [C][8][3][3] -> stencil operands out0 = wk[tap][i][G][o], out1 = wd[tap'][o][G][i]      p0 = G, p1 = flip
+//   kind 3: grouped -> block-diagonal MFMA operands out0 = wk, out1 = wd [C][9][64]                        p0 = C
+//   kind 4: hn_pack_weight_ex (channel slice / phase form): out0 = wp, out1 = wt, out2 = b_eff             p0..p5 = Cout, Cin_total, ci0, Cin, taps, phase
+__global__ __launch_bounds__(256) void pack_small_batched_kernel(const long* jobs, const int* block_job) {
+    const long* jb = jobs + (long)block_job[blockIdx.x] * 16;
+    const float* w = reinterpret_cast<const float*>(jb[0]);
+    bf16* o0 = reinterpret_cast<bf16*>(jb[1]);
+    bf16* o1 = reinterpret_cast<bf16*>(jb[2]);
+    const int kind = (int)jb[5];
+    const long idx = ((long)blockIdx.x - jb[6]) * 256 + threadIdx.x;
+    if (kind == 1) {
+        const int C = (int)jb[7];
+        if (idx >= 9L * C) return;
+        const int c = (int)(idx % C), tap = (int)(idx / C);
+        const bf16 v = f2bf(w[c * 9 + tap]);
+        o0[idx] = v;
+        if (o1) o1[(8 - tap) * C + c] = v;
+    } else if (kind == 2) {
+        const int G = (int)jb[7], flip = (int)jb[8];
+        if (idx >= (long)G * 576) return;
+        const int b = (int)(idx & 7);
+        long t = idx >> 3;
+        const int g = (int)(t % G);
+        t /= G;
+        const int a = (int)(t & 7), tap = (int)(t >> 3);
+        o0[idx] = f2bf(w[((long)(g * 8 + b) * 8 + a) * 9 + tap]);
+        if (o1) o1[idx] = f2bf(w[((long)(g * 8 + a) * 8 + b) * 9 + (flip ? 8 - tap : tap)]);
+    } else if (kind == 3) {
+        const int C = (int)jb[7];
+        if (idx >= (long)C * 576) return;
+        const int j = (int)(idx & 63), tap = (int)((idx >> 6) % 9), co = (int)(idx / 576);
+        const int gl = (co & 63) >> 3;
+        float a = 0.f, b = 0.f;
+        if ((j >> 3) == gl) {
+            a = w[((long)co * 8 + (j & 7)) * 9 + tap];
+            const int cosrc = (co & ~63) + j;
+            if (cosrc < C) b = w[((long)cosrc * 8 + (co & 7)) * 9 + (8 - tap)];
+        }
+        o0[idx] = f2bf(a);
+        o1[idx] = f2bf(b);
+    } else if (kind == 4) {
+        const int Cout = (int)jb[7], Cin_total = (int)jb[8], ci0 = (int)jb[9], Cin = (int)jb[10], taps = (int)jb[11], phase = (int)jb[12];
+        float* b_eff = reinterpret_cast<float*>(jb[3]);
+        const float* bias = reinterpret_cast<const float*>(jb[4]);
+        const int CoutE = phase ? 4 * Cout : Cout;
+        const int KPi = (Cin + 31) / 32 * 32, KPo = (CoutE + 31) / 32 * 32;
+        const long nf = (long)CoutE * taps * KPi;
+        const long nt = o1 ? (long)Cin * taps * KPo : 0;
+        if (idx < nf) {
+            const int k = (int)(idx % KPi);
+            const long t = idx / KPi;
+            const int tap = (int)(t % taps), co = (int)(t / taps);
+            o0[idx] = f2bf(k < Cin ? packed_w_value(w, Cout, Cin_total, ci0, taps, phase, co, k, tap) : 0.f);
+        } else if (idx < nf + nt) {
+            const long j = idx - nf;
+            const int k = (int)(j % KPo);
+            const long t = j / KPo;
+            const int tap = (int)(t % taps), ci = (int)(t / taps);
+            o1[j] = f2bf(k < CoutE ? packed_w_value(w, Cout, Cin_total, ci0, taps, phase, k, ci, tap) : 0.f);
+        } else if (b_eff && idx < nf + nt + CoutE) {
+            const int co = (int)(idx - nf - nt);
+            b_eff[co] = bias[co % Cout];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
@@ -1857,6 +1927,14 @@ static int conv_gemm_tn_impl(const void* x0, const void* x1, int mode, int n_img
 extern "C" int hn_pack_weights_batched(const long* jobs, int njobs, long total_blocks, const int* block_job, hipStream_t st) {
     HN_CHECK_ARG(jobs && njobs > 0 && total_blocks > 0);
     hipLaunchKernelGGL(pack_w_batched_kernel, dim3((unsigned)total_blocks), dim3(256), 0, st, jobs, njobs, block_job);
+    HN_LAUNCH_CHECK();
+}
+
+/* every other per-step weight pack of a model in one launch: jobs = DEVICE table njobs x 16 int64 (see pack_small_batched_kernel),
+ * block_job = DEVICE int32 [total_blocks] job index of every 256-thread block */
+extern "C" int hn_pack_small_batched(const long* jobs, const int* block_job, long total_blocks, hipStream_t st) {
+    HN_CHECK_ARG(jobs && block_job && total_blocks > 0);
+    hipLaunchKernelGGL(pack_small_batched_kernel, dim3((unsigned)total_blocks), dim3(256), 0, st, jobs, block_job);
     HN_LAUNCH_CHECK();
 }
 

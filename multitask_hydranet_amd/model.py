@@ -636,7 +636,7 @@ class HydraNet(nn.Module):
             return self._forward(x, mode)
         finally:
             if self._pack_plan is None and x.is_cuda:
-                log = [w for w in K.stop_pack_log() if id(w) in params]
+                log = [e for e in K.stop_pack_log() if id(e[1]) in params]
                 if log:
                     self._pack_plan = K.PackPlan(log)
 

@@ -92,7 +92,7 @@ def clear_pack_cache():
 _PACK_LOG = None            # when a list: conv weights packed one by one are recorded here (HydraNet builds its PackPlan from it)
 
 
-def _cached(key, w: torch.Tensor, make):
+def _cached(key, w: torch.Tensor, make, meta=None):
     # the entry keeps a strong reference to the weight tensor, so its id() cannot be recycled while the entry lives
     k = (key, id(w))
     hit = _PACK_CACHE.get(k)
@@ -100,8 +100,8 @@ def _cached(key, w: torch.Tensor, make):
         return hit[2]
     v = make()
     _PACK_CACHE[k] = (w, w._version, v)
-    if _PACK_LOG is not None and key == "conv":
-        _PACK_LOG.append(w)
+    if _PACK_LOG is not None:
+        _PACK_LOG.append((key, w, meta))
     return v
 
 
@@ -117,39 +117,102 @@ def stop_pack_log():
 
 
 class PackPlan:
-    """bf16 operand packing of every dense conv weight of a model in ONE launch per step (118 launches one by one for the big cfg).
-    Owns persistent packed buffers; run() refreshes them and primes the pack cache so that pack_conv_weight() hits."""
+    """Every per-step weight pack of a model in TWO launches (the big cfg needed ~190 one by one): dense conv weights go through the tiled
+    transposing kernel (hn_pack_weights_batched), everything else -- depthwise taps, grouped-conv stencil / block-diagonal operands,
+    channel-slice and phase-form packs -- through one elementwise launch (hn_pack_small_batched).  Built from the pack log of a forward:
+    entries (key, weight, meta) as recorded by _cached().  Owns persistent packed buffers; run() refreshes them and primes the pack cache
+    so that the pack_*() helpers hit."""
 
-    def __init__(self, weights):
-        self.weights = list(weights)
-        dev = self.weights[0].device
-        self.packs = []
-        rows_, blk, owner = [], 0, []
-        for w in self.weights:
-            cout, cin = w.shape[0], w.shape[1]
-            taps = w.shape[2] * w.shape[3]
-            wp = torch.empty((cout, taps * kp32(cin)), device=dev, dtype=BF16)
-            wt = torch.empty((cin, taps * kp32(cout)), device=dev, dtype=BF16)
-            self.packs.append((wp, wt))
-            assert taps in (1, 9)
-            rows_.append([w.data_ptr(), wp.data_ptr(), wt.data_ptr(), cout, cin, taps, blk, kp32(cin) // 32])
-            nb = (kp32(cout) // 32) * (kp32(cin) // 32)               # one workgroup per 32 x 32 (cout, cin) tile
-            owner += [len(rows_) - 1] * nb
-            blk += nb
-        self.blocks = blk
-        self.ptrs = [w.data_ptr() for w in self.weights]
-        self.table = torch.tensor(rows_, dtype=torch.int64).to(dev)
-        self.block_job = torch.tensor(owner, dtype=torch.int32).to(dev)
+    def __init__(self, log):
+        seen, entries = set(), []
+        for key, w, meta in log:
+            if (key, id(w)) not in seen:
+                seen.add((key, id(w)))
+                entries.append((key, w, meta))
+        self.entries = entries
+        dev = entries[0][1].device
+        self.values = []                                   # cache value per entry (tuple of tensors [+ bias bookkeeping for phase packs])
+        dense_rows, dense_owner, dblk = [], [], 0
+        small_rows, small_owner = [], []
+        sblk = [0]
+
+        def small(row, elements):
+            nb = (elements + 255) // 256
+            row[6] = sblk[0]
+            small_rows.append(row + [0] * (16 - len(row)))
+            small_owner.extend([len(small_rows) - 1] * nb)
+            sblk[0] += nb
+
+        for key, w, meta in entries:
+            kind = key[0] if isinstance(key, tuple) else key
+            if kind == "conv":
+                cout, cin = w.shape[0], w.shape[1]
+                taps = w.shape[2] * w.shape[3]
+                assert taps in (1, 9)
+                wp = torch.empty((cout, taps * kp32(cin)), device=dev, dtype=BF16)
+                wt = torch.empty((cin, taps * kp32(cout)), device=dev, dtype=BF16)
+                dense_rows.append([w.data_ptr(), wp.data_ptr(), wt.data_ptr(), cout, cin, taps, dblk, kp32(cin) // 32])
+                nb = (kp32(cout) // 32) * (kp32(cin) // 32)               # one workgroup per 32 x 32 (cout, cin) tile
+                dense_owner += [len(dense_rows) - 1] * nb
+                dblk += nb
+                self.values.append((wp, wt))
+            elif kind == "dw":
+                c = w.shape[0]
+                wk, wf = torch.empty((9 * c,), device=dev, dtype=BF16), torch.empty((9 * c,), device=dev, dtype=BF16)
+                small([w.data_ptr(), wk.data_ptr(), wf.data_ptr(), 0, 0, 1, 0, c], 9 * c)
+                self.values.append((wk, wf))
+            elif kind == "g":
+                c, flip = w.shape[0], key[1]
+                wk, wd = torch.empty((72 * c,), device=dev, dtype=BF16), torch.empty((72 * c,), device=dev, dtype=BF16)
+                small([w.data_ptr(), wk.data_ptr(), wd.data_ptr(), 0, 0, 2, 0, c // 8, flip], 72 * c)
+                self.values.append((wk, wd))
+            elif kind == "gdiag":
+                c = w.shape[0]
+                wk, wd = torch.empty((c, 576), device=dev, dtype=BF16), torch.empty((c, 576), device=dev, dtype=BF16)
+                small([w.data_ptr(), wk.data_ptr(), wd.data_ptr(), 0, 0, 3, 0, c], 576 * c)
+                self.values.append((wk, wd))
+            elif kind in ("slice", "phase"):
+                cout, cin_total, taps = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
+                phase = 1 if kind == "phase" else 0
+                ci0, cin = (0, key[1]) if phase else (key[1], key[2])
+                coute = 4 * cout if phase else cout
+                wp = torch.empty((coute, taps * kp32(cin)), device=dev, dtype=BF16)
+                wt = torch.empty((cin, taps * kp32(coute)), device=dev, dtype=BF16)
+                b_eff = torch.empty((coute,), device=dev, dtype=F32) if phase else None
+                bias = meta if phase else None
+                small([w.data_ptr(), wp.data_ptr(), wt.data_ptr(), b_eff.data_ptr() if phase else 0, bias.data_ptr() if phase else 0, 4, 0,
+                       cout, cin_total, ci0, cin, taps, phase], wp.numel() + wt.numel() + (coute if phase else 0))
+                self.values.append((wp, wt, b_eff, bias) if phase else (wp, wt))
+            else:
+                raise KeyError(key)
+        self.dense_blocks, self.small_blocks = dblk, sblk[0]
+        mk = lambda rows_, dt: torch.tensor(rows_, dtype=dt).to(dev) if rows_ else None
+        self.dense_table, self.dense_owner = mk(dense_rows, torch.int64), mk(dense_owner, torch.int32)
+        self.small_table, self.small_owner = mk(small_rows, torch.int64), mk(small_owner, torch.int32)
+        self.n_dense = len(dense_rows)
+        self.device = dev
+        self.ptrs = [(w.data_ptr(), meta.data_ptr() if isinstance(meta, torch.Tensor) else 0) for _, w, meta in entries]
+
+    @property
+    def packs(self):
+        """(wp, wt) of the dense conv weights, in log order (tests)"""
+        return [v for (key, _, _), v in zip(self.entries, self.values) if key == "conv"]
 
     def valid(self):
-        """the device job table holds raw weight pointers: a parameter whose storage was swapped (`p.data = ...`, vector_to_parameters, a
+        """the device job tables hold raw weight pointers: a parameter whose storage was swapped (`p.data = ...`, vector_to_parameters, a
         device move) invalidates the plan (HydraNet.forward rebuilds it)"""
-        return all(w.data_ptr() == p_ and w.device == self.table.device for w, p_ in zip(self.weights, self.ptrs))
+        return all(w.data_ptr() == p_[0] and w.device == self.device and (not isinstance(meta, torch.Tensor) or meta.data_ptr() == p_[1])
+                   for (_, w, meta), p_ in zip(self.entries, self.ptrs))
 
     def run(self):
-        lib().call("hn_pack_weights_batched", ptr(self.table), len(self.weights), self.blocks, ptr(self.block_job))
-        for w, pk in zip(self.weights, self.packs):
-            _PACK_CACHE[("conv", id(w))] = (w, w._version, pk)
+        if self.dense_table is not None:
+            lib().call("hn_pack_weights_batched", ptr(self.dense_table), self.n_dense, self.dense_blocks, ptr(self.dense_owner))
+        if self.small_table is not None:
+            lib().call("hn_pack_small_batched", ptr(self.small_table), ptr(self.small_owner), self.small_blocks)
+        for (key, w, meta), v in zip(self.entries, self.values):
+            if isinstance(key, tuple) and key[0] == "phase":
+                v = (v[0], v[1], v[2], meta, meta._version)
+            _PACK_CACHE[(key, id(w))] = (w, w._version, v)
 
 
 def pack_conv_weight(w: torch.Tensor):
@@ -185,10 +248,10 @@ def pack_phase_weight(w: torch.Tensor, c0: int, bias: torch.Tensor):
         b_eff = torch.empty((4 * k,), device=w.device, dtype=F32)
         lib().call("hn_pack_weight_ex", ptr(w), ptr(wp), ptr(wt), k, w.shape[1], 0, c0, 9, 1, ptr(bias), ptr(b_eff))
         return wp, wt, b_eff, bias, bias._version
-    v = _cached(("phase", c0), w, make)
+    v = _cached(("phase", c0), w, make, meta=bias)
     if v[3] is not bias or v[4] != bias._version:               # the bias changed without the weight: repack
         _PACK_CACHE.pop((("phase", c0), id(w)), None)
-        v = _cached(("phase", c0), w, make)
+        v = _cached(("phase", c0), w, make, meta=bias)
     return v[0], v[1], v[2]
 
 

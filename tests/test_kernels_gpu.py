@@ -396,25 +396,37 @@ def test_seg_out_phase_form(K, c, k, n, h, w):
 
 
 def test_pack_plan_matches_single_packs(K):
-    """ops.PackPlan (every conv weight in one launch, 32x32 tiles through LDS) writes bit for bit what hn_pack_weight writes one by one:
-    1x1 and 3x3 weights, channel counts that are not multiples of 32 (zero padding of both operand layouts)."""
+    """ops.PackPlan (every per-step weight pack of a model in two launches) writes bit for bit what the single-weight entry points write:
+    dense 1x1 / 3x3 weights through the tiled transposing kernel (channel counts that are not multiples of 32: zero padding of both
+    operand layouts), depthwise taps, grouped-conv stencil and block-diagonal operands, channel-slice and phase-form packs through the
+    elementwise kernel."""
     shapes = [(24, 32, 1), (152, 64, 1), (936, 368, 1), (65, 448, 1), (5, 64, 3), (256, 368, 3), (36, 112, 1), (64, 8, 3)]
     ws = [rnd(co, ci, k, k) for co, ci, k in shapes]
+    dw = [rnd(112, 1, 3, 3), rnd(36, 1, 3, 3)]
+    gw = [rnd(24, 8, 3, 3), rnd(152, 8, 3, 3)]
+    seg_w, seg_b = rnd(64, 88, 3, 3), rnd(64)
     K.clear_pack_cache()
-    ref = []
-    for w in ws:
-        wp, wt = K.pack_conv_weight(w)
-        ref.append((wp.clone(), wt.clone()))
+    K.start_pack_log()
+    ref = [K.pack_conv_weight(w) for w in ws] + [K.pack_dw_weight(w) for w in dw] + [K.pack_gconv_weight(gw[0], 0), K.pack_gconv_weight(gw[1], 1)]
+    ref += [K.pack_gconv_diag(w) for w in gw] + [K.pack_conv_weight_slice(seg_w, 64, 24), K.pack_phase_weight(seg_w, 64, seg_b)]
+    ref = [tuple(t.clone() for t in r) for r in ref]
+    log = K.stop_pack_log()
+    assert len(log) == len(ref)
     K.clear_pack_cache()
-    plan = K.PackPlan(ws)
-    for wp, wt in plan.packs:                      # poison: every element (padding included) must be rewritten
-        wp.fill_(7.0)
-        wt.fill_(7.0)
+    plan = K.PackPlan(log)
+    for v in plan.values:                          # poison: every element (padding included) must be rewritten
+        for t in v[:3]:
+            if t is not None:
+                t.fill_(7.0)
     plan.run()
-    for (wp, wt), (rp, rt), shp in zip(plan.packs, ref, shapes):
-        assert torch.equal(wp, rp), shp
-        assert torch.equal(wt, rt), shp
+    for (key, _, _), v, r in zip(plan.entries, plan.values, ref):
+        for got, want in zip(v[:len(r)], r):
+            assert torch.equal(got.view(-1), want.view(-1)), key
     assert K.pack_conv_weight(ws[2])[0] is plan.packs[2][0]           # run() primes the cache
+    assert K.pack_dw_weight(dw[0])[0] is plan.values[len(ws)][0]
+    assert K.pack_phase_weight(seg_w, 64, seg_b)[2] is plan.values[-1][2]
+    seg_b.add_(1.0)                                                   # a changed bias is noticed (repacked outside the plan)
+    assert torch.equal(K.pack_phase_weight(seg_w, 64, seg_b)[2], seg_b.repeat(4))
     K.clear_pack_cache()
 
 
