@@ -29,6 +29,18 @@ PEAK_HBM_GBS = 8000.0
 FWD_GFLOP_PER_IMG_512x1024 = 81.13   # BASELINE.md section 3 (conv MACs x 2); fwd+bwd = 3x
 
 
+def emit(res):
+    """the JSON line must be the LAST line on stdout: RCCL leaves a version banner in the C stdio buffer (printed at exit when stdout is a
+    pipe), so the C streams are flushed first"""
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:       # noqa: BLE001
+        pass
+    print(json.dumps(res), flush=True)
+
+
 def synthetic_batch(cfgs, n, h, w, seed, device):
     """SURVEY.md section 8(d) synthetic inputs (same recipe as oracle.synthetic_batch, restated so the product path never imports oracle/)."""
     g = torch.Generator().manual_seed(seed)
@@ -244,7 +256,7 @@ def infer_bench(args, net, cfgs, h, w, dev, rank, world):
         res["roofline"] = dominant_launch_roofline(net, args.batch, h, w)
     except Exception as e:      # noqa: BLE001
         res["roofline"] = {"error": repr(e)}
-    print(json.dumps(res))
+    emit(res)
 
 
 def main():
@@ -490,7 +502,7 @@ def main():
                 res["cpu_baseline"] = cpu_baseline(yaml.safe_load(open(args.cfg)) | {"dataloader": cfgs["dataloader"]}, h, w)
             except Exception as e:  # noqa: BLE001
                 res["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(res))
+        emit(res)
     if exchange:
         dist.destroy_process_group()
 

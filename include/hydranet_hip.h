@@ -45,7 +45,8 @@ int hn_pack_weights_batched(const long* jobs, int njobs, long total_blocks, cons
 /* the remaining per-step packs of a model (depthwise taps = hn_dw_pack, grouped-conv stencil operands = hn_gconv_pack, block-diagonal MFMA
  * operands = hn_gconv_pack_diag, channel-slice / phase-form packs = hn_pack_weight_ex) in one launch: jobs = DEVICE table njobs x 16 int64
  * {w, out0, out1, out2, bias, kind 1..4, first_block, p0..p5, 0, 0, 0} with the parameters of the single-weight entry point of that kind,
- * one thread per output element; block_job = DEVICE int32 [total_blocks] */
+ * one thread per output element; block_job = DEVICE int32 [total_blocks].  Kind 3 writes only the 8 x 8 diagonal blocks of the block-diagonal
+ * operands: the caller's (persistent) buffers must have been zero-filled once. */
 int hn_pack_small_batched(const long* jobs, const int* block_job, long total_blocks, hipStream_t stream);
 
 /* out[pixel][cout] = act(bias[cout] + sum_{tap,c} X(pixel, tap)[c] * w[cout][tap][c]); X is gathered on the fly:

@@ -1479,7 +1479,7 @@ __global__ __launch_bounds__(256) void pack_w_batched_kernel(const long* jobs, i
 //   {w, out0, out1, out2, bias, kind, first_block, p0, p1, p2, p3, p4, p5, 0, 0, 0}; one thread per output element, 256 per block.
 //   kind 1: depthwise [C][1][3][3] -> out0 = wk[tap][C], out1 = wkf[8-tap][C]                              p0 = C
 //   kind 2: grouped [C][8][3][3] -> stencil operands out0 = wk[tap][i][G][o], out1 = wd[tap'][o][G][i]      p0 = G, p1 = flip
-//   kind 3: grouped -> block-diagonal MFMA operands out0 = wk, out1 = wd [C][9][64]                        p0 = C
+//   kind 3: grouped -> the DIAGONAL blocks of the block-diagonal MFMA operands out0 = wk, out1 = wd [C][9][64] (buffers zero-filled by the owner)   p0 = C
 //   kind 4: hn_pack_weight_ex (channel slice / phase form): out0 = wp, out1 = wt, out2 = b_eff             p0..p5 = Cout, Cin_total, ci0, Cin, taps, phase
 __global__ __launch_bounds__(256) void pack_small_batched_kernel(const long* jobs, const int* block_job) {
     const long* jb = jobs + (long)block_job[blockIdx.x] * 16;
@@ -1506,18 +1506,17 @@ __global__ __launch_bounds__(256) void pack_small_batched_kernel(const long* job
         o0[idx] = f2bf(w[((long)(g * 8 + b) * 8 + a) * 9 + tap]);
         if (o1) o1[idx] = f2bf(w[((long)(g * 8 + a) * 8 + b) * 9 + (flip ? 8 - tap : tap)]);
     } else if (kind == 3) {
+        // only the 8 x 8 diagonal blocks: the caller's persistent buffers were zero-filled once and the off-diagonal 7/8 never change
         const int C = (int)jb[7];
-        if (idx >= (long)C * 576) return;
-        const int j = (int)(idx & 63), tap = (int)((idx >> 6) % 9), co = (int)(idx / 576);
-        const int gl = (co & 63) >> 3;
-        float a = 0.f, b = 0.f;
-        if ((j >> 3) == gl) {
-            a = w[((long)co * 8 + (j & 7)) * 9 + tap];
-            const int cosrc = (co & ~63) + j;
-            if (cosrc < C) b = w[((long)cosrc * 8 + (co & 7)) * 9 + (8 - tap)];
-        }
-        o0[idx] = f2bf(a);
-        o1[idx] = f2bf(b);
+        if (idx >= (long)C * 72) return;
+        const int i = (int)(idx & 7), tap = (int)((idx >> 3) % 9), co = (int)(idx / 72);
+        const int gl = (co & 63) >> 3, j = gl * 8 + i;
+        const float a = w[((long)co * 8 + i) * 9 + tap];
+        const int cosrc = (co & ~63) + j;
+        const float b = cosrc < C ? w[((long)cosrc * 8 + (co & 7)) * 9 + (8 - tap)] : 0.f;
+        const long dst = ((long)co * 9 + tap) * 64 + j;
+        o0[dst] = f2bf(a);
+        o1[dst] = f2bf(b);
     } else if (kind == 4) {
         const int Cout = (int)jb[7], Cin_total = (int)jb[8], ci0 = (int)jb[9], Cin = (int)jb[10], taps = (int)jb[11], phase = (int)jb[12];
         float* b_eff = reinterpret_cast<float*>(jb[3]);

@@ -168,8 +168,9 @@ class PackPlan:
                 self.values.append((wk, wd))
             elif kind == "gdiag":
                 c = w.shape[0]
-                wk, wd = torch.empty((c, 576), device=dev, dtype=BF16), torch.empty((c, 576), device=dev, dtype=BF16)
-                small([w.data_ptr(), wk.data_ptr(), wd.data_ptr(), 0, 0, 3, 0, c], 576 * c)
+                # zero-filled ONCE: the batched kernel rewrites only the 8 x 8 diagonal blocks (1/8 of the operand) every step
+                wk, wd = torch.zeros((c, 576), device=dev, dtype=BF16), torch.zeros((c, 576), device=dev, dtype=BF16)
+                small([w.data_ptr(), wk.data_ptr(), wd.data_ptr(), 0, 0, 3, 0, c], 72 * c)
                 self.values.append((wk, wd))
             elif kind in ("slice", "phase"):
                 cout, cin_total, taps = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
