@@ -1284,6 +1284,42 @@ __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* part, f
         if (ci + j < Cin) d[(long)j * taps] = s[j];
 }
 
+// 3x3 weights: the partial slabs are [co][tap][KP] (ci contiguous), PyTorch wants [co][ci][3][3] (tap contiguous).  Writing that
+// transposition straight from registers is a 4-byte store every 36 bytes: the 2048 x 512 x 9 phase-form gradient of decoder.1 (37.7 MB)
+// cost 375 MB of WRITE_SIZE and 100 us.  One workgroup = one cout x 64 input channels x 9 taps: coalesced partial reads per tap, the
+// [64][9] result tile is turned in LDS and leaves as contiguous float4 runs.
+__global__ __launch_bounds__(256) void wgrad_reduce9_kernel(const float* part, float* dw, int splits, int Nout, int Cin, int KP) {
+    // 64 input channels x 4 split lanes per workgroup (the splits are walked four at a time per lane: 36 loads in flight)
+    __shared__ float tile[4][64 * 9 + 4];
+    const long Ktot = 9L * KP, cols = (long)Nout * Ktot;
+    const int co = blockIdx.y, ci0 = blockIdx.x * 64, cl = threadIdx.x & 63, kl = threadIdx.x >> 6, ci = ci0 + cl;
+    float s[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) s[t] = 0.f;
+    if (ci < Cin) {
+        const float* src = part + (long)co * Ktot + ci;
+#pragma unroll 4
+        for (int k = kl; k < splits; k += 4) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) s[t] += src[(long)k * cols + (long)t * KP];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) tile[kl][cl * 9 + t] = s[t];
+    __syncthreads();
+    const int nci = Cin - ci0 < 64 ? Cin - ci0 : 64;                   // input channels of this block
+    float* dst = dw + ((long)co * Cin + ci0) * 9;                      // nci * 9 contiguous floats
+    const int total = nci * 9;
+    const bool al = (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
+    for (int e = threadIdx.x * 4; e < total; e += 1024) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = e + j < total ? (tile[0][e + j] + tile[1][e + j]) + (tile[2][e + j] + tile[3][e + j]) : 0.f;
+        if (al && e + 4 <= total) *reinterpret_cast<f32x4*>(dst + e) = (f32x4){v[0], v[1], v[2], v[3]};
+        else for (int j = 0; j < 4 && e + j < total; ++j) dst[e + j] = v[j];
+    }
+}
+
 // grouped conv (group width 8) weight gradient from the block-diagonal slabs: dw[co][i][tap] = sum_split part[split][co][tap*64 + ((co&63)>>3)*8 + i]
 __global__ void gconv_diag_extract_kernel(const float* part, float* dw, int splits, int C) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1897,6 +1933,8 @@ static int conv_gemm_tn_impl(const void* x0, const void* x1, int mode, int n_img
         const long cols = (long)Nout * taps * KP;
         if (grouped)
             hipLaunchKernelGGL(gconv_diag_extract_kernel, dim3(cdiv(Nout * 72, 256)), dim3(256), 0, st, workspace, dw, splits, Nout);
+        else if (taps == 9 && splits <= 64)
+            hipLaunchKernelGGL(wgrad_reduce9_kernel, dim3(cdiv(C0 + C1, 64), Nout), dim3(256), 0, st, workspace, dw, splits, Nout, C0 + C1, KP);
         else if (splits <= 128 && cols >= 65536)
             hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(cdiv(cols / 4, 256)), dim3(256), 0, st, workspace, dw, splits, Nout, C0 + C1, KP, taps);
         else
