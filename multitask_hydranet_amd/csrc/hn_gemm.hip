@@ -1824,8 +1824,8 @@ static void tn_tiles(int Nout, int KP, int& bc, int& bn) {
 static bool use_patch_wgrad(int mode, int Nout, int KP) { return mode == 2 && KP >= 64; }
 static void patch_tiles(int Nout, int& bc, int& ci, int& ksplit) {
     if (Nout <= 16) { bc = 16; ci = 64; ksplit = 2; }
-    else if (Nout <= 32) { bc = 32; ci = 128; ksplit = 1; }          // the 4-phase 5-class output conv: 20 couts
-    else if (Nout <= 64) { bc = 64; ci = 128; ksplit = 1; }
+    else if (Nout <= 32) { bc = 32; ci = 64; ksplit = 2; }           // the 4-phase 5-class output conv: 20 couts (62 KB LDS: 2 workgroups per CU)
+    else if (Nout <= 64) { bc = 64; ci = 64; ksplit = 2; }           // 78 KB LDS: two workgroups per CU (ci = 128: 124 KB, one)
     else { bc = 128; ci = 64; ksplit = 1; }
 }
 
@@ -1850,10 +1850,12 @@ static int wgrad_plan_impl(int mode, int n_img, int H, int W, long M, int Nout, 
         int bc, ci, ksplit;
         patch_tiles(Nout, bc, ci, ksplit);
         if (grouped) { bc = 64; ci = 64; ksplit = 2; }
-        if (phase_span && phase_span < bc) { bc = 64; ci = 128; ksplit = 1; }      // a cout tile must lie inside one phase
+        if (phase_span && phase_span < bc) { bc = 64; ci = 64; ksplit = 2; }      // a cout tile must lie inside one phase
         const long tiles = (long)cdiv(Nout, bc) * cdiv(KP, ci);
         const long patches = (long)n_img * cdiv(H, 8) * cdiv(W, 16);
         long want = (256 + tiles - 1) / tiles;          // one workgroup per CU in total: every split costs a full fp32 slab of dW (write + reduce)
+        // ... unless the slab is small: then two workgroups per CU (where their LDS fits) hide each other's DMA waits
+        if (bc <= 64 && 2 * want * ksplit * (long)Nout * taps * KP * 4 <= (64L << 20)) want *= 2;
         if (want > patches / 2) want = patches / 2;
         if (want < 1) want = 1;
         const long pps = (patches + want - 1) / want;
@@ -1913,12 +1915,12 @@ static int conv_gemm_tn_impl(const void* x0, const void* x1, int mode, int n_img
         static std::atomic<unsigned long long> optin{0};
         if (!lds_optin(optin, {(const void*)wgrad3x3_patch_kernel<128, 64>, (const void*)wgrad3x3_patch_kernel<64, 128>,
                                (const void*)wgrad3x3_patch_kernel<16, 64>, (const void*)wgrad3x3_patch_kernel<64, 64>,
-                               (const void*)wgrad3x3_patch_kernel<32, 128>}))
+                               (const void*)wgrad3x3_patch_kernel<32, 64>}))
             return HN_ERR_LAUNCH;
         int pbc, pci, ksplit;
         patch_tiles(Nout, pbc, pci, ksplit);
         if (grouped) { pbc = 64; pci = 64; ksplit = 2; }
-        if (phase_span && phase_span < pbc) { pbc = 64; pci = 128; ksplit = 1; }
+        if (phase_span && phase_span < pbc) { pbc = 64; pci = 64; ksplit = 2; }
         p.gy = cdiv(Nout, pbc);
         const int patches = n_img * cdiv(H, 8) * cdiv(W, 16);
         dim3 grid((unsigned)(cdiv(KP, pci) * p.gy * (splits / ksplit)));
@@ -1926,8 +1928,8 @@ static int conv_gemm_tn_impl(const void* x0, const void* x1, int mode, int n_img
         const size_t lds = 2 * ((size_t)((128 * pbc * 2 + 1023) / 1024 * 1024) + xb);
         if (grouped) hipLaunchKernelGGL((wgrad3x3_patch_kernel<64, 64>), grid, dim3(512), lds, st, p, (int)rps, patches);
         else if (pbc == 128) hipLaunchKernelGGL((wgrad3x3_patch_kernel<128, 64>), grid, dim3(512), lds, st, p, (int)rps, patches);
-        else if (pbc == 64) hipLaunchKernelGGL((wgrad3x3_patch_kernel<64, 128>), grid, dim3(512), lds, st, p, (int)rps, patches);
-        else if (pbc == 32) hipLaunchKernelGGL((wgrad3x3_patch_kernel<32, 128>), grid, dim3(512), lds, st, p, (int)rps, patches);
+        else if (pbc == 64) hipLaunchKernelGGL((wgrad3x3_patch_kernel<64, 64>), grid, dim3(512), lds, st, p, (int)rps, patches);
+        else if (pbc == 32) hipLaunchKernelGGL((wgrad3x3_patch_kernel<32, 64>), grid, dim3(512), lds, st, p, (int)rps, patches);
         else hipLaunchKernelGGL((wgrad3x3_patch_kernel<16, 64>), grid, dim3(512), lds, st, p, (int)rps, patches);
         if (hipGetLastError() != hipSuccess) return HN_ERR_LAUNCH;
         const long cols = (long)Nout * taps * KP;
