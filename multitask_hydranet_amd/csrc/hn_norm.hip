@@ -638,6 +638,7 @@ __global__ void cast_f32_kernel(const bf16* src, int lds_, float* dst, int ldo, 
 // out[n][o] = act(bias[o] + sum_i W[o][i] * in[n][i]) : one wave per (n, o), lanes stride the contraction (coalesced weight rows)
 // S > 0: `in` holds S partial rows per image (in[n][i] = alpha * sum_j part[(n*S + j)][i], e.g. the SE squeeze from the per-row-block
 // channel sums of hn_bn_apply_fused); the o == 0 wave also stores the assembled vector to `store` [N][I] (kept for the backward pass).
+template <bool FOLD>   // FOLD: `in` holds S >= 1 partial rows per image (register-heavy path); else one dense row
 __global__ __launch_bounds__(256) void se_fc_rows_kernel(const float* W, const float* bias, const float* in, float* out, int N, int O, int I,
                                                          int act, int S, float alpha, float* store) {
     const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -646,18 +647,41 @@ __global__ __launch_bounds__(256) void se_fc_rows_kernel(const float* W, const f
     const int n = (int)(wid / O), o = (int)(wid - (long)n * O);
     const float* wr = W + (long)o * I;
     float s = 0.f;
-    if (S > 0) {
-        const float* pr = in + (long)n * S * I;
-        for (int i = lane; i < I; i += 64) {
-            float v = 0.f;
-            for (int j = 0; j < S; ++j) v += pr[(long)j * I + i];
-            v *= alpha;
-            if (store && o == 0) store[(long)n * I + i] = v;
-            s += wr[i] * v;
-        }
-    } else {
+    if (!FOLD) {
         const float* xr = in + (long)n * I;
         for (int i = lane; i < I; i += 64) s += wr[i] * xr[i];
+    } else
+    // a lane owns elements lane, lane + 64, ... (<= 16 per round of 1024): their loads are issued together
+    // (the nested "for i { for j < S }" form made every load wait for the previous one: 20 us at stage 4, S = 4)
+    for (int base = 0; base < I; base += 1024) {
+        float v[16], wv[16];
+        const float* xr = in + (long)n * S * I + base + lane;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const bool ok = base + lane + 64 * k < I;
+            v[k] = ok ? xr[64 * k] : 0.f;
+            wv[k] = ok ? wr[base + lane + 64 * k] : 0.f;
+        }
+        // the partial rows were just written by another kernel (another XCD's L2): every dependent round is a trip to memory (~2 us), so
+        // four rows (64 loads) are in flight per round
+        for (int j0 = 1; j0 < S; j0 += 4) {
+            float t[4][16];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    t[jj][k] = (j0 + jj < S && base + lane + 64 * k < I) ? xr[(long)(j0 + jj) * I + 64 * k] : 0.f;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) v[k] += t[jj][k];
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            v[k] *= alpha;
+            if (store && o == 0 && base + lane + 64 * k < I) store[(long)n * I + base + lane + 64 * k] = v[k];
+            s += wv[k] * v[k];
+        }
     }
     s = wave_sum(s);
     if (lane == 0) {
@@ -682,29 +706,36 @@ __global__ __launch_bounds__(16 * PARTS) void se_fc_cols_kernel(const float* W, 
     const float* inr = in + (long)n * (S > 0 ? S : 1) * I;
     const float* auxr = aux ? aux + (long)n * I : nullptr;
     const bool ov = o < O;
-    auto val = [&](int i) {
-        float v = inr[i];
-        for (int j = 1; j < S; ++j) v += inr[(long)j * I + i];
+    // the partition's elements (<= 16 per round) are loaded together, one round per partial row, before the first multiply
+    for (int ib = i0; ib < i1; ib += 16) {
+        float v[16], wv[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const bool ok = ib + k < i1;
+            v[k] = ok ? inr[ib + k] : 0.f;
+            wv[k] = (ok && ov) ? W[(long)(ib + k) * O + o] : 0.f;
+        }
+        for (int j = 1; j < S; ++j)
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (ib + k < i1) v[k] += inr[(long)j * I + ib + k];
         if (pre) {
-            const float g = auxr[i];
-            v *= g * (1.f - g);
-            if (store && blockIdx.x == 0 && ox == 0) store[(long)n * I + i] = v;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                if (ib + k < i1) {
+                    const float g = auxr[ib + k];
+                    v[k] *= g * (1.f - g);
+                    if (store && blockIdx.x == 0 && ox == 0) store[(long)n * I + ib + k] = v[k];
+                }
+            }
         }
-        return v;
-    };
-    int i = i0;
-    for (; i + 4 <= i1; i += 4) {                                      // four independent loads in flight
-        const float v0 = val(i), v1 = val(i + 1), v2 = val(i + 2), v3 = val(i + 3);
-        if (ov) {
-            s0 += W[(long)i * O + o] * v0;
-            s1 += W[(long)(i + 1) * O + o] * v1;
-            s2 += W[(long)(i + 2) * O + o] * v2;
-            s3 += W[(long)(i + 3) * O + o] * v3;
+#pragma unroll
+        for (int k = 0; k < 16; k += 4) {
+            s0 += wv[k] * v[k];
+            s1 += wv[k + 1] * v[k + 1];
+            s2 += wv[k + 2] * v[k + 2];
+            s3 += wv[k + 3] * v[k + 3];
         }
-    }
-    for (; i < i1; ++i) {
-        const float v = val(i);
-        if (ov) s0 += W[(long)i * O + o] * v;
     }
     red[part][ox] = (s0 + s1) + (s2 + s3);
     __syncthreads();
@@ -1007,9 +1038,9 @@ extern "C" int hn_cast_bf16_to_f32(const void* src, int lds_, float* dst, int ld
 extern "C" int hn_se_mlp_fwd(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2, float* hid, float* gate,
                              int N, int C, int Cs, hipStream_t st) {
     HN_CHECK_ARG(pooled && w1 && b1 && w2 && b2 && hid && gate && N > 0 && C > 0 && Cs > 0);
-    hipLaunchKernelGGL(se_fc_rows_kernel, dim3(cdiv((long)N * Cs, 4)), dim3(256), 0, st, w1, b1, pooled, hid, N, Cs, C, HN_ACT_RELU, 0, 1.f,
+    hipLaunchKernelGGL(se_fc_rows_kernel<false>, dim3(cdiv((long)N * Cs, 4)), dim3(256), 0, st, w1, b1, pooled, hid, N, Cs, C, HN_ACT_RELU, 0, 1.f,
                        (float*)nullptr);
-    hipLaunchKernelGGL(se_fc_rows_kernel, dim3(cdiv((long)N * C, 4)), dim3(256), 0, st, w2, b2, (const float*)hid, gate, N, C, Cs,
+    hipLaunchKernelGGL(se_fc_rows_kernel<false>, dim3(cdiv((long)N * C, 4)), dim3(256), 0, st, w2, b2, (const float*)hid, gate, N, C, Cs,
                        HN_ACT_SIGMOID, 0, 1.f, (float*)nullptr);
     HN_LAUNCH_CHECK();
 }
@@ -1018,9 +1049,9 @@ extern "C" int hn_se_mlp_fwd(const float* pooled, const float* w1, const float* 
 extern "C" int hn_se_mlp_fwd_parts(const float* pool_part, int S, float alpha, const float* w1, const float* b1, const float* w2, const float* b2,
                                    float* pooled, float* hid, float* gate, int N, int C, int Cs, hipStream_t st) {
     HN_CHECK_ARG(pool_part && S > 0 && w1 && b1 && w2 && b2 && pooled && hid && gate && N > 0 && C > 0 && Cs > 0);
-    hipLaunchKernelGGL(se_fc_rows_kernel, dim3(cdiv((long)N * Cs, 4)), dim3(256), 0, st, w1, b1, pool_part, hid, N, Cs, C, HN_ACT_RELU, S,
+    hipLaunchKernelGGL(se_fc_rows_kernel<true>, dim3(cdiv((long)N * Cs, 4)), dim3(256), 0, st, w1, b1, pool_part, hid, N, Cs, C, HN_ACT_RELU, S,
                        alpha, pooled);
-    hipLaunchKernelGGL(se_fc_rows_kernel, dim3(cdiv((long)N * C, 4)), dim3(256), 0, st, w2, b2, (const float*)hid, gate, N, C, Cs,
+    hipLaunchKernelGGL(se_fc_rows_kernel<false>, dim3(cdiv((long)N * C, 4)), dim3(256), 0, st, w2, b2, (const float*)hid, gate, N, C, Cs,
                        HN_ACT_SIGMOID, 0, 1.f, (float*)nullptr);
     HN_LAUNCH_CHECK();
 }
