@@ -715,10 +715,18 @@ __global__ __launch_bounds__(16 * PARTS) void se_fc_cols_kernel(const float* W, 
             v[k] = ok ? inr[ib + k] : 0.f;
             wv[k] = (ok && ov) ? W[(long)(ib + k) * O + o] : 0.f;
         }
-        for (int j = 1; j < S; ++j)
+        for (int j0 = 1; j0 < S; j0 += 4) {                            // four partial rows per round (fresh data: a trip to memory per round)
+            float t[4][16];
 #pragma unroll
-            for (int k = 0; k < 16; ++k)
-                if (ib + k < i1) v[k] += inr[(long)j * I + ib + k];
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    t[jj][k] = (j0 + jj < S && ib + k < i1) ? inr[(long)(j0 + jj) * I + ib + k] : 0.f;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) v[k] += t[jj][k];
+        }
         if (pre) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
