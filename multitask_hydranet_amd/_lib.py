@@ -85,7 +85,8 @@ class _Lib:
             raise HipKernelError(
                 f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU / eager fallback for the HydraNet hot path)")
-        self._dll = ctypes.CDLL(SO_PATH)
+        # HN_LIB_AB: tools-only hook for same-box A/B measurements of two builds (an alternate in-tree .so with the same ABI)
+        self._dll = ctypes.CDLL(os.environ.get("HN_LIB_AB") or SO_PATH)
         self._sig = parse_header()
         self._fn = {}
         for name, (ret, args, has_stream) in self._sig.items():
