@@ -318,6 +318,11 @@ def main():
     net.check_finite = False                       # the reference's exit()-on-NaN guard is a host sync; checked once after the run instead
     net.lane_points_per_line = h // cfgs["lane"]["interval"]     # the reference default (160) raises IndexError at H=512
     broadcast_state(net)
+    if os.environ.get("HN_KNOBS"):                   # tools/ sweeps: "id=value,id=value" -> hn_debug_knob
+        from multitask_hydranet_amd._lib import lib
+        for kv in os.environ["HN_KNOBS"].split(","):
+            k, v = kv.split("=")
+            lib().query("hn_debug_knob", int(k), int(v))
     if os.environ.get("HN_HEADS_SIDE") == "1":       # experiment hook: det + lane heads on a side stream (a hipGraph branch) next to the seg decoder
         net.heads_on_side_stream = True
     if args.dominant_only:

@@ -92,6 +92,9 @@ int hn_debug_nt_config(int bc, int r);
  * on every measured shape) = the two-workgroups-per-CU double-buffer form */
 int hn_debug_direct_pipe(int on);
 int hn_debug_tn_config(int bc, int bn, int splits);
+/* tools/ sweep hook: heuristic constants (0 TN split target, 1 TN minimum rows per split, 2 / 3 fused-BatchNorm row-block targets, 4 / 5 pixel
+ * thresholds of the 64x64 GEMM tile); the defaults are the shipped heuristics */
+int hn_debug_knob(int id, long value);
 
 /* wgrad: dw[Cout][Cin][taps] (PyTorch layout, fp32) = sum_pixel dz[pixel][cout] * X(pixel, tap)[c]; X modes 0..2 as above.
  * dz rows must be zero padded up to ldz >= Nout rounded up to 8.  workspace: fp32, size from hn_wgrad_plan.

@@ -33,6 +33,9 @@ __device__ __forceinline__ bf16x8 zero8() {
 }
 
 // activation codes shared by the C-ABI
+// tuning knobs for tools/ sweeps (hn_debug_knob; defaults = the shipped heuristics): 0 TN split target (workgroups), 1 TN minimum rows per
+// split, 2 fused-BatchNorm apply-pass target workgroups, 3 fused reduce-pass row-block divisor, 4 / 5 pixel thresholds of the 64x64 GEMM tile
+extern long g_hn_knob[8];
 #define HN_ACT_NONE 0
 #define HN_ACT_RELU 1
 #define HN_ACT_SWISH 2

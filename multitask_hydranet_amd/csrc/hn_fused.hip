@@ -437,9 +437,9 @@ extern "C" long hn_fused_row_block(long M, int C, long align, int P, int kind) {
     long RB;
     if (kind == 1) {
         RB = 128;
-        while (RB * 512 < M) RB <<= 1;
+        while (RB * g_hn_knob[3] < M) RB <<= 1;
     } else {
-        const long want = (M * chunk_count(C) + 1023) / 1024;
+        const long want = (M * chunk_count(C) + g_hn_knob[2] - 1) / g_hn_knob[2];
         RB = 32;
         while (RB < want && RB < 1024) RB <<= 1;
         if (P > 128 && RB < 128) RB = 128;

@@ -1666,7 +1666,9 @@ static int pick_bc(int Nout) {
 
 // Few pixel rows x wide cout (the deep backbone stages: 2048...8192 rows, 376/936 channels): 64x64 tiles give >= 2 workgroups per CU,
 // which overlap each other's load / wait / MFMA phases (a 64x128 tiling leaves one workgroup per CU waiting on its own loads).
-static bool small_tile(long M, int Nout) { return !g_nt_force_bc && Nout > 64 && (M <= 8192 || (M <= 32768 && Nout <= 128)); }
+long g_hn_knob[8] = {1024, 256, 1024, 512, 8192, 32768, 0, 0};
+extern "C" int hn_debug_knob(int id, long value) { if (id < 0 || id >= 8) return HN_ERR_ARG; g_hn_knob[id] = value; return HN_OK; }
+static bool small_tile(long M, int Nout) { return !g_nt_force_bc && Nout > 64 && (M <= g_hn_knob[4] || (M <= g_hn_knob[5] && Nout <= 128)); }
 
 // partial statistic rows of a mode-5 (grouped 3x3 on the direct kernel) launch: one per 16x16 output patch
 extern "C" int hn_direct_stat_rows(int n_img, int H, int W) { return n_img * cdiv(H, 16) * cdiv(W, 16); }
@@ -1867,8 +1869,8 @@ static int wgrad_plan_impl(int mode, int n_img, int H, int W, long M, int Nout, 
     int bc, bn;
     tn_tiles(Nout, KP, bc, bn);
     const long tiles = (long)cdiv(Nout, bc) * cdiv(KP, bn) * taps;
-    long want = (1024 + tiles - 1) / tiles;                 // ~4 workgroups per CU in total
-    const long max_splits = (M + 255) / 256;                // at least 256 rows per split
+    long want = (g_hn_knob[0] + tiles - 1) / tiles;         // ~4 workgroups per CU in total
+    const long max_splits = (M + g_hn_knob[1] - 1) / g_hn_knob[1];   // at least 256 rows per split
     if (want > max_splits) want = max_splits;
     if (g_tn_force_splits) want = g_tn_force_splits;
     if (want < 1) want = 1;
