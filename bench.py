@@ -386,7 +386,8 @@ def main():
 
     if use_graph:
         try:
-            if reducer is not None and not args.exchange_after_replay:
+            # (only RCCL collectives can be captured: the gloo test hook exchanges after the replay)
+            if reducer is not None and not args.exchange_after_replay and backend == "nccl":
                 try:
                     graph, static_loss = capture(with_hooks=True)
                     reducer.adopt_bucket_grads()
@@ -492,7 +493,8 @@ def main():
             "config": {"workload": ("RegNetY backbone only" if args.backbone_only else "full HydraNet (backbone + BiFPN + seg/det/lane heads + multitask loss)")
                        + ", big cfg, fwd+loss+bwd", "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "resolution": "3x%dx%d" % (h, w), "parallelism": "dp%d" % world, "hipgraph": graph is not None,
-                       "grad_allreduce": None if reducer is None else ("%s backend: " % backend) + reducer.describe()},
+                       "grad_allreduce": None if reducer is None else ("%s backend: " % backend) + reducer.describe(
+                           after_replay=graph is not None and not in_graph_exchange)},
             "ms_optimizer_step": round(ms_opt, 3) if ms_opt is not None else None, "loss": round(loss_val, 4),
             "model_tflops": round(value * gflop_img / 1e3, 2),
             # SURVEY 8(d) segment-wise roofline of the whole step (seg decoder on MFMA, everything else on HBM): 0.177 ms/img at 512x1024

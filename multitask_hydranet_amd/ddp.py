@@ -221,9 +221,10 @@ class GradReducer:
             h.remove()
         self._hooks = []
 
-    def describe(self) -> str:
+    def describe(self, after_replay: bool = False) -> str:
         how = "captured inside the hipGraph on a side stream, overlapped with backward" if self.captured else \
-              ("on a side stream from autograd hooks, overlapped with backward" if self.stream is not None else "after backward")
+              ("after each hipGraph replay (reduce_now, not overlapped)" if after_replay else
+               ("on a side stream from autograd hooks, overlapped with backward" if self.stream is not None else "after backward"))
         return "%d buckets (%s payload, %s) %s" % (len(self.buckets), str(self.payload_dtype).replace("torch.", ""),
                                                     "ncclAvg" if self._avg else "sum + scale", how)
 
