@@ -359,6 +359,7 @@ def main():
     graph = None
     static_loss = None
     in_graph_exchange = False
+    capture_failed = False
 
     def capture(with_hooks):
         """two eager warm-up steps on a side stream, then the capture.  with_hooks: the reducer's autograd hooks stay armed, so every
@@ -387,20 +388,27 @@ def main():
     if use_graph:
         try:
             # (only RCCL collectives can be captured: the gloo test hook exchanges after the replay)
-            if reducer is not None and not args.exchange_after_replay and backend == "nccl":
+            if reducer is not None and not args.exchange_after_replay and (backend == "nccl" or os.environ.get("HN_BENCH_TRY_CAPTURE") == "1"):
                 try:
                     graph, static_loss = capture(with_hooks=True)
                     reducer.adopt_bucket_grads()
                     reducer.remove()
                     in_graph_exchange = reducer.captured
                 except Exception as e:              # noqa: BLE001  (an RCCL build that cannot be captured)
+                    # a capture that failed half-way leaves PyTorch's graph bookkeeping unusable for a second capture in this process
+                    # ("Cannot register the state during capturing stage"): run eager launches with the overlapped hook exchange instead
                     if rank == 0:
-                        print("capturing the all-reduce inside the hipGraph failed (%r): exchanging after the replay instead" % (e,), file=sys.stderr)
-                    torch.cuda.synchronize()
+                        print("capturing the all-reduce inside the hipGraph failed (%r): eager launches with the hook exchange instead" % (e,),
+                              file=sys.stderr)
+                    try:
+                        torch.cuda.synchronize()
+                    except Exception:               # noqa: BLE001  (a capture that could not be ended keeps its stream in capture mode)
+                        pass
                     graph = None
+                    capture_failed = True
                     reducer.remove()
                     reducer = make_reducer()
-            if graph is None:
+            if graph is None and not capture_failed:
                 if reducer is not None:
                     reducer.remove()                # no hooks during this capture; gradients are exchanged right after each replay
                 graph, static_loss = capture(with_hooks=False)
