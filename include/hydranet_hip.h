@@ -192,6 +192,11 @@ int hn_space_to_depth_bf16(const void* in, int ldi, void* out, int N, int h, int
  * hn_conv_gemm_tn_phase: gradient of W_eff (fp32 [4k][C0][3][3], zeros at unused taps) from x0 and the space-to-depth output gradient. */
 int hn_conv3x3_phase(const void* x0, int mode, int n_img, int H, int W, int C0, int ld0, const void* w, int Nout, int KP, const float* bias,
                      int act, void* out, int ldc, int k, const void* addend, int ld_add, hipStream_t stream);
+/* deploy forward of the seg head's output layer: Conv3x3(ReflectionPad2d(1)(nearest_up2(x0))) (head_seg/segmentation.py:101-104, phase
+ * form: w = effective weights [4k][9][KP] from hn_pack_weight_ex, bias [4k]) fused with torch.argmax over the k classes
+ * (model/model.py:197): mask int64 [N][2H][2W], first maximum wins; the fp32 logits are never written.  C0 <= 64, 4k <= 32. */
+int hn_conv3x3_out_argmax(const void* x0, int n_img, int H, int W, int C0, int ld0, const void* w, int k, int KP, const float* bias, long* mask,
+                          hipStream_t stream);
 int hn_wgrad_plan_phase(int n_img, int H, int W, int Nout, int KP, int phase_span, int* splits, long* rows_per_split, long* ws_bytes);
 int hn_conv_gemm_tn_phase(const void* x0, int n_img, int H, int W, int C0, int ld0, const void* dz, int ldz, int Nout, int KP, int phase_span,
                           float* workspace, float* dw, hipStream_t stream);

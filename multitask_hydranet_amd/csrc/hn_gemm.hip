@@ -145,6 +145,8 @@ struct GemmNT {
     int phase_mode, phase_span;
     int add_s2;                       // 1: the addend lives on the stride-2 sub-grid [N][H/2][W/2] and is added at even (y, x) only (the data
                                       //    gradient of a stride-2 1x1 conv joining the gradient of a full-resolution 1x1 conv of the same input)
+    long* amax;                       // fp32 depth-to-space output mode only: write arg-max over the d2s classes (int64 per output pixel, first
+                                      // maximum wins) instead of the logits (deploy forward: model/model.py:197 only needs the mask)
     int add_pre;                      // 1: the addend goes in BEFORE the activation: out = act(acc + bias + addend) (inference: folded
                                       // BatchNorm + identity branch + ReLU of an XBlock in conv_block_3's epilogue)
 };
@@ -861,7 +863,23 @@ __global__ __launch_bounds__(512, PIPE ? 2 : 4) void conv3x3_direct_kernel(const
             }
         }
     }
-    if (stage_f32) {
+    if (p.amax && !stage_f32) return;                                // (the host entry point guarantees the staged path)
+    if (stage_f32 && p.amax) {
+        __syncthreads();
+        const int rowf = 32 * p.d2s;
+        for (int idx = tid; idx < 32 * 32; idx += 512) {              // one output pixel per thread: arg-max of its d2s logits in the tile
+            const int Y = idx >> 5, X = idx & 31;
+            const int gy = 2 * oy0 + Y, gx = 2 * ox0 + X;
+            if (gy < 2 * xs.H && gx < 2 * xs.W) {
+                const float* r = reinterpret_cast<const float*>(stage) + Y * rowf + X * p.d2s;
+                float best = r[0];
+                int arg = 0;
+                for (int c = 1; c < p.d2s; ++c)
+                    if (r[c] > best) { best = r[c]; arg = c; }
+                p.amax[(long)(n * 2 * xs.H + gy) * (2 * xs.W) + gx] = arg;
+            }
+        }
+    } else if (stage_f32) {
         __syncthreads();
         const int rowf = 32 * p.d2s, row4 = rowf >> 2;                // floats / float4 per tile row
         float* ob = reinterpret_cast<float*>(p.out);
@@ -1677,6 +1695,7 @@ extern "C" int hn_nt_stat_rows(long M, int Nout) {               // one partial 
     return small_tile(M, Nout) ? cdiv(M, 64) : cdiv(M, 128);
 }
 
+static thread_local long* g_next_amax = nullptr;    // set by hn_conv3x3_out_argmax for the launch it makes (same thread, same call)
 static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img, int H, int W, int C0, int C1, int ld0, int ld1,
                              int up, long M, const void* w, int Nout, int KP, int taps, const float* bias, int act, void* out,
                              int out_f32, int ldc, long rpi, long img_stride, float* psum, float* psq, const float* xscale,
@@ -1704,6 +1723,21 @@ extern "C" int hn_conv_gemm_nt_ex(const void* x0, const void* x1, int mode, int 
  * pre-activation partial result of the full-resolution skip operand at the output's layout) or mode 3 (data gradient on the padded
  * low-resolution grid; x0 = space-to-depth gradient [N][H][W][4*k], w = transposed effective weights).  Only the 4 non-zero taps of each
  * phase are visited. */
+/* The 4-phase k-class output conv of the seg head (head_seg/segmentation.py:101-104) fused with the deploy arg-max (model/model.py:197):
+ * x0 [N][H][W][C0] bf16, w = phase-form effective weights [4k][9][KP], bias [4k]; mask int64 [N][2H][2W] = arg-max over the k logits of
+ * every output pixel (first maximum wins).  The fp32 logits are never written (1.4 GB at 32 x 1152 x 1920 x 5). */
+extern "C" int hn_conv3x3_out_argmax(const void* x0, int n_img, int H, int W, int C0, int ld0, const void* w, int k, int KP, const float* bias,
+                                     long* mask, hipStream_t st) {
+    HN_CHECK_ARG(mask && k >= 1 && 4 * k <= 32 && 32 * 32 * k * 4 <= 32768 && KP == 64 && C0 <= 64 && ((2 * W * k) & 3) == 0 && ((32 * k) & 3) == 0 &&
+                 (reinterpret_cast<uintptr_t>(mask) & 15) == 0);
+    g_next_amax = mask;
+    // (out is only used for its alignment test; nothing is written to it)
+    const int rc = conv_gemm_nt_impl(x0, nullptr, 4, n_img, H, W, C0, 0, ld0, 0, 0, (long)n_img * H * W, w, 4 * k, KP, 9, bias, HN_ACT_NONE,
+                                     (void*)mask, 1, 4 * k, 0, -(long)k, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, 0, 0, 0, st);
+    g_next_amax = nullptr;
+    return rc;
+}
+
 extern "C" int hn_conv3x3_phase(const void* x0, int mode, int n_img, int H, int W, int C0, int ld0, const void* w, int Nout, int KP,
                                 const float* bias, int act, void* out, int ldc, int k, const void* addend, int ld_add, hipStream_t st) {
     HN_CHECK_ARG((mode == 4 || mode == 3) && k > 0 && (k & 3) == 0);
@@ -1749,6 +1783,8 @@ static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img
                                    M < (1L << 32)));
     p.add_s2 = add_mode;
     p.phase_mode = phase_mode; p.phase_span = phase_span;
+    p.amax = g_next_amax;
+    g_next_amax = nullptr;
     if (img_stride < 0) {                                            // mode 4: -img_stride = channels per depth-to-space output pixel
         HN_CHECK_ARG(p.x.clamp == 1 && (out_f32 || phase_mode == 1) && rpi == 0 && !psum && Nout == 4 * (int)(-img_stride));
         p.d2s = (int)(-img_stride);

@@ -485,8 +485,9 @@ class HydraNet(nn.Module):
         """BiFPN stack on plain tensors: the five fused maps"""
         return [a[0] for a in self._neck_shared([((t, t, t), None) for t in feats], (1, 1, 1, 1, 1))]
 
-    def _seg(self, feats_seg):
-        """SegmentHeader.forward, head_seg/segmentation.py:84-105 -> fp32 logits, NCHW-shaped (channels-last memory)."""
+    def _seg(self, feats_seg, want_mask=False):
+        """SegmentHeader.forward, head_seg/segmentation.py:84-105 -> fp32 logits, NCHW-shaped (channels-last memory); want_mask (deploy mode
+        under no_grad): the int64 arg-max mask straight from the output conv's epilogue instead (the logits are never materialised)."""
         P = self._idx
         n = len(feats_seg)
         x = feats_seg[-1]
@@ -503,6 +504,8 @@ class HydraNet(nn.Module):
             else:
                 x = K.SegConv.apply(x, skip, wgt, P[f"{p}{2 * i + 1}.conv.conv.bias"], 1, ACT_ELU, False, fuse, fuse)
         last = 2 * n
+        if want_mask and self.seg_phase_output and K.seg_out_argmax_ok(x, P[f"{p}{last}.conv.weight"]):
+            return K.seg_out_argmax(x, P[f"{p}{last}.conv.weight"], P[f"{p}{last}.conv.bias"])
         if self.seg_phase_output:          # final 3x3 over the up-sampled map as a 4-phase conv on the low-resolution grid (ops.SegOutUp)
             # the loss may hand its gradient over in this node's operand form (no fp32 dlogits tensor): see _seg_loss
             slot = K.GradSlot() if (x.requires_grad and self.training) else None
@@ -670,8 +673,11 @@ class HydraNet(nn.Module):
                 lane = self._lane(fused_lane)
                 out["lane"] = lane
                 lane_cls, lane_reg = lane["predict_cls"], lane["predict_loc"]
+        seg_mask = None
         if self.train_seg:
-            seg = self._seg([feat0_seg, fused_seg[0], fused_seg[1], fused_seg[2]])
+            seg = self._seg([feat0_seg, fused_seg[0], fused_seg[1], fused_seg[2]], want_mask=(mode == "deploy" and not torch.is_grad_enabled()))
+            if seg.dtype == torch.int64:                   # deploy + no_grad: the output conv already took the arg-max
+                seg_mask, seg = seg, None
             out["seg"] = seg
         if side is not None:
             cur.wait_stream(side)
@@ -681,7 +687,7 @@ class HydraNet(nn.Module):
         self._flush_nbt()
         if mode != "deploy":
             return out
-        dep = (K.argmax_channels(seg), anchors, reg, cls, lane_cls, lane_reg)
+        dep = (seg_mask if seg_mask is not None else K.argmax_channels(seg), anchors, reg, cls, lane_cls, lane_reg)
         if self.deploy_postprocess is not None and self.train_detect:
             # decode + clip + threshold + class-offset NMS + gather on the device, same stream, no host round trip;
             # a 7th element (dict of device tensors: rois / class_ids / scores [N, cap, ...], kept / total [N]) follows the reference's 6-tuple

@@ -1664,6 +1664,22 @@ class SegOutUp(torch.autograd.Function):
         return dx, dw, dbias, None, None
 
 
+def seg_out_argmax(x, weight, bias):
+    """deploy forward of the seg output layer fused with the arg-max over the classes (model/model.py:197): int64 mask [N, 2h, 2w]; the fp32
+    logits are never written.  No gradient (inference only)."""
+    n, h, w, c = x.shape
+    k = weight.shape[0]
+    wp, _, b_eff = pack_phase_weight(weight, c, bias)
+    mask = torch.empty((n, 2 * h, 2 * w), device=x.device, dtype=torch.int64)
+    lib().call("hn_conv3x3_out_argmax", ptr(x), n, h, w, c, ld(x), ptr(wp), k, kp32(c), ptr(b_eff), ptr(mask))
+    return mask
+
+
+def seg_out_argmax_ok(x, weight):
+    k, c = weight.shape[0], x.shape[3]
+    return x.is_cuda and not torch.is_grad_enabled() and 4 * k <= 32 and kp32(c) == 64 and (x.shape[2] * k) % 2 == 0
+
+
 class SegConvUp(torch.autograd.Function):
     """y [N, 2h, 2w, k] = ELU(Conv3x3(ReflectionPad2d(1)(cat[nearest_up2(x0), x1])) + bias) in PHASE form (decoder blocks 1/3/5/7,
     head_seg/segmentation.py:92-100).  The up-sampled operand is convolved on its own low-resolution grid with the effective weights of

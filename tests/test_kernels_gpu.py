@@ -493,6 +493,23 @@ def test_head_out_cat(K, ca, cb):
         close(got.grad, ref.grad, GRAD_TOL, nm)
 
 
+@pytest.mark.parametrize("c,k,n,h,w", [(64, 5, 2, 8, 12), (64, 5, 1, 20, 36), (64, 3, 2, 16, 18), (48, 8, 1, 4, 6)])
+def test_seg_out_argmax_fused(K, c, k, n, h, w):
+    """hn_conv3x3_out_argmax (deploy: the output conv's epilogue takes the arg-max over the classes, the logits are never written) ==
+    arg-max of the logits SegOutUp writes, bit for bit (same accumulation, first maximum wins); h, w = INPUT size."""
+    x = nhwc(rnd(n, c, h, w))
+    wt = rnd(k, c, 3, 3, scale=(9 * c) ** -0.5)
+    bs = rnd(k, scale=0.1)
+    with torch.no_grad():
+        assert K.seg_out_argmax_ok(x, wt)
+        logits = K.SegOutUp.apply(x, wt, bs)
+        want = K.argmax_channels(logits.permute(0, 3, 1, 2))
+        got = K.seg_out_argmax(x, wt, bs)
+    assert got.dtype == torch.int64 and got.shape == (n, 2 * h, 2 * w)
+    assert torch.equal(got, want)
+    assert torch.equal(want, torch.argmax(logits, dim=3))
+
+
 @pytest.mark.parametrize("with_dw,cout,k,act", [(True, 36, 4, 0), (True, 81, 9, 4), (False, 65, 65, 0), (False, 2, 2, 0)])
 def test_head_out(K, with_dw, cout, k, act):
     n, c = 2, 16
