@@ -340,6 +340,9 @@ def main():
     net.check_finite = False                       # the reference's exit()-on-NaN guard is a host sync; checked once after the run instead
     net.lane_points_per_line = h // cfgs["lane"]["interval"]     # the reference default (160) raises IndexError at H=512
     broadcast_state(net)
+    if os.environ.get("HN_TN"):                      # tools/ sweeps: "bc,bn,splits" -> hn_debug_tn_config
+        from multitask_hydranet_amd._lib import lib
+        lib().query("hn_debug_tn_config", *[int(v) for v in os.environ["HN_TN"].split(",")])
     if os.environ.get("HN_KNOBS"):                   # tools/ sweeps: "id=value,id=value" -> hn_debug_knob
         from multitask_hydranet_amd._lib import lib
         for kv in os.environ["HN_KNOBS"].split(","):
