@@ -178,8 +178,11 @@ int hn_seg_fold(const void* dvp, int ldv, int c0, void* out, int ldo, const void
 int hn_depth_to_space(const float* in, int ldi, float* out, int N, int h, int w, int k, hipStream_t stream);
 int hn_space_to_depth(const float* dy, void* out, int ldo, int N, int h, int w, int k, hipStream_t stream);
 
-/* bf16 form: in [N][2h][2w][k] (row stride ldi) -> out [N][h][w][4k], phase-major channels (the operand layout of the phase-form convs) */
-int hn_space_to_depth_bf16(const void* in, int ldi, void* out, int N, int h, int w, int k, hipStream_t stream);
+/* bf16 form: in [N][2h][2w][k] (row stride ldi) -> out [N][h][w][4k], phase-major channels (the operand layout of the phase-form convs);
+ * psum (optional, fp32 [hn_space_to_depth_blocks][k], needs 256 % (k/2) == 0): per-block channel sums of the tensor on its way through =
+ * partial rows of the conv's bias gradient (head_seg/segmentation.py:60-67 ConvBlock bias), reduce with hn_rows_reduce */
+int hn_space_to_depth_blocks(int N, int h, int w, int k);
+int hn_space_to_depth_bf16(const void* in, int ldi, void* out, int N, int h, int w, int k, float* psum, hipStream_t stream);
 
 /* Phase form of Conv3x3(ReflectionPad2d(1)(nearest_up2(x0))) (head_seg/segmentation.py:92-104, decoder blocks 1/3/5/7) on the LOW-resolution
  * grid: effective weights W_eff[(py,px,o)][c][dy][dx] = sum of the original taps that land on low-res offset (dy, dx) for output phase

@@ -928,9 +928,16 @@ __global__ void space_to_depth_kernel(const float* dy, bf16* out, int ldo, int N
 }
 
 // bf16 [N][2h][2w][k] (row stride ldi) -> bf16 [N][h][w][4k]: channel (py*2+px)*k + o of low-res pixel (y, x) = in(2y+py, 2x+px, o); 16-byte pieces
-__global__ void space_to_depth_bf16_kernel(const bf16* in, int ldi, bf16* out, int N, int h, int w, int k) {
+// psum (optional, [gridDim.x][k] fp32): per-block channel sums of the tensor that passes through -- the bias gradient of the conv whose dz
+// this is, for free (a separate column reduction re-read the 268 MB full-resolution dz of decoder.7).  Needs 256 % (4 * k/8) == 0: then a
+// thread keeps one channel group for the whole grid-stride loop.
+__global__ __launch_bounds__(256) void space_to_depth_bf16_kernel(const bf16* in, int ldi, bf16* out, int N, int h, int w, int k, float* psum) {
+    __shared__ float red[256][9];
     const int k8 = k >> 3;
     const long total = (long)N * h * w * 4 * k8;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int c8 = (int)(idx % (4 * k8));
         long t = idx / (4 * k8);
@@ -941,6 +948,21 @@ __global__ void space_to_depth_bf16_kernel(const bf16* in, int ldi, bf16* out, i
         const int ph = c8 / k8, o = (c8 - ph * k8) * 8;
         const bf16x8 v = ld8(in + ((n * 2 * h + 2 * y + (ph >> 1)) * (long)(2 * w) + 2 * x + (ph & 1)) * ldi + o);
         st8(out + idx * 8, v);
+        if (psum) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += bf2f(v[j]);
+        }
+    }
+    if (psum) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[threadIdx.x][j] = acc[j];
+        __syncthreads();
+        for (int c = threadIdx.x; c < k; c += 256) {                  // channel c: threads t with (t % (4*k8)) % k8 == c / 8 hold its group
+            const int g = c >> 3, j = c & 7;
+            float s = 0.f;
+            for (int t = g; t < 256; t += k8) s += red[t][j];
+            psum[(long)blockIdx.x * k + c] = s;
+        }
     }
 }
 
@@ -1229,10 +1251,13 @@ extern "C" int hn_space_to_depth(const float* dy, void* out, int ldo, int N, int
     HN_LAUNCH_CHECK();
 }
 
-extern "C" int hn_space_to_depth_bf16(const void* in, int ldi, void* out, int N, int h, int w, int k, hipStream_t st) {
+extern "C" int hn_space_to_depth_blocks(int N, int h, int w, int k) { return ew_grid((long)N * h * w * 4 * (k >> 3)); }
+/* psum (optional): fp32 [hn_space_to_depth_blocks(N,h,w,k)][k] per-block channel sums of the tensor (needs 256 % (k/2) == 0: k = 64 ... 512) */
+extern "C" int hn_space_to_depth_bf16(const void* in, int ldi, void* out, int N, int h, int w, int k, float* psum, hipStream_t st) {
     HN_CHECK_ARG(in && out && N > 0 && h > 0 && w > 0 && k > 0 && (k & 7) == 0 && (ldi & 7) == 0);
-    hipLaunchKernelGGL(space_to_depth_bf16_kernel, dim3(ew_grid((long)N * h * w * 4 * (k >> 3))), dim3(256), 0, st, (const bf16*)in, ldi,
-                       (bf16*)out, N, h, w, k);
+    HN_CHECK_ARG(!psum || 256 % (4 * (k >> 3)) == 0);
+    hipLaunchKernelGGL(space_to_depth_bf16_kernel, dim3(hn_space_to_depth_blocks(N, h, w, k)), dim3(256), 0, st, (const bf16*)in, ldi,
+                       (bf16*)out, N, h, w, k, psum);
     HN_LAUNCH_CHECK();
 }
 

@@ -1729,11 +1729,17 @@ class SegConvUp(torch.autograd.Function):
         dev = x0.device
         dy = dense(dy)
         dz = dy if ctx.dy_is_dz else k_eltwise(1, dy, y, act=ACT_ELU)
-        ps, _, _ = k_col_stats(dz)
-        dbias = k_rows_reduce(ps, 1, ps.shape[0], k).view(-1)
-        # space-to-depth gradient: the operand of both low-resolution contractions
+        # space-to-depth gradient: the operand of both low-resolution contractions; the bias gradient (channel sums of dz) comes out of
+        # the same pass as per-block partial rows
         dzs = new_act(n, h, w, 4 * k, dev)
-        lib().call("hn_space_to_depth_bf16", ptr(dz), ld(dz), ptr(dzs), n, h, w, k)
+        if 256 % (k // 2) == 0:
+            pb = lib().query("hn_space_to_depth_blocks", n, h, w, k)
+            ps = torch.empty((pb, k), device=dev, dtype=F32)
+            lib().call("hn_space_to_depth_bf16", ptr(dz), ld(dz), ptr(dzs), n, h, w, k, ptr(ps))
+        else:
+            ps, _, _ = k_col_stats(dz)
+            lib().call("hn_space_to_depth_bf16", ptr(dz), ld(dz), ptr(dzs), n, h, w, k, None)
+        dbias = k_rows_reduce(ps, 1, ps.shape[0], k).view(-1)
         # effective-weight gradient (zeros at the taps a phase does not use), mapped back to the 3x3 weights by the phase matrix
         splits, rps, wsb = ctypes.c_int(), ctypes.c_long(), ctypes.c_long()
         lib().query("hn_wgrad_plan_phase", n, h, w, 4 * k, kp32(c0), k, ctypes.addressof(splits), ctypes.addressof(rps), ctypes.addressof(wsb))
