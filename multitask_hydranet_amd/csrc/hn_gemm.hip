@@ -151,14 +151,18 @@ struct GemmNT {
                                       // BatchNorm + identity branch + ReLU of an XBlock in conv_block_3's epilogue)
 };
 
-template <int BC, int BP, int WGC, int WGP, bool OUT_F32, int R, bool XF = false>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
+// KG = 2: 512 threads = two independent 4-wave groups that walk alternate K stages (their own LDS stages, common barriers) and meet in LDS
+// before the epilogue: half the barrier-separated K steps per workgroup for the small-M GEMMs of the deep stages, whose 15-step K loop is
+// pure latency (one or two workgroups per CU).
+template <int BC, int BP, int WGC, int WGP, bool OUT_F32, int R, bool XF = false, int KG = 1>
+__global__ __launch_bounds__(256 * KG) void gemm_nt_kernel(const GemmNT p) {
     static_assert(!XF || R == 2, "the register-staged operand transform is written for the double buffer");
+    static_assert(KG == 1 || (!XF && R == 2), "the K-group form is written for the plain double buffer");
     constexpr int WC = BC / WGC, WP = BP / WGP, TC = WC / 16, TP = WP / 16;
     constexpr int XR = BP / 32, WR = (BC + 31) / 32;
     constexpr int STAGE = (BC + BP) * 128;                        // one K stage (64 k) of both operands
     extern __shared__ __attribute__((aligned(16))) char smem[];   // R stages, ONE array (keeps the compiler's LDS-DMA waits minimal)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x & 255, kg = threadIdx.x >> 8, lane = tid & 63, wave = tid >> 6;   // (thread / wave index inside the K group)
     const int wc = wave / WGP, wp = wave % WGP;
     const int ncy = (p.Nout + BC - 1) / BC;                       // cout tiles: fastest logical index => they share the pixel tile in L2
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
     // LDS-DMA staging: a wave instruction writes 64 x 16 B = 8 consecutive tile rows (lane-linear).  Thread t owns PHYSICAL piece t&7 of
     // rows (t>>3) + 32 i; the XOR swizzle is applied on the SOURCE side: it fetches logical piece (t&7) ^ (row&7).
     const int r0 = tid >> 3, lp = (tid & 7) ^ (r0 & 7), half = lp >> 2, sub = (lp & 3) * 8;
-    const int kc = p.KP >> 5, Q = p.taps * kc, S = (Q + 1) >> 1;
+    const int kc = p.KP >> 5, Q = p.taps * kc, S = (((Q + 1) >> 1) + KG - 1) / KG;       // S = K steps of this workgroup (KG stages each)
     const int Ktot = p.taps * p.KP;
 
     int xn[XR], xy[XR], xx[XR];
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
 
     // 3x3 modes: the source coordinates of a tap are separable in (oy, ky) and (ox, kx), so they are tabulated once per block in LDS:
     //   ty0[ky][oy], tx0[kx][ox] in x0's grid (reflected, >> up for mode 2; -1 = outside for mode 3); ty1/tx1 in x1's full-res grid
-    int* ty0 = reinterpret_cast<int*>(smem + R * STAGE);
+    int* ty0 = reinterpret_cast<int*>(smem + R * KG * STAGE);
     int* tx0 = ty0 + 3 * p.x.H;
     int* ty1 = tx0 + 3 * p.x.W;
     int* tx1 = ty1 + 3 * p.x.H;
@@ -210,7 +214,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
     }
     const int hh0 = p.x.mode == 2 ? p.x.Hi >> p.x.up : p.x.Hi, ww0 = p.x.mode == 2 ? p.x.Wi >> p.x.up : p.x.Wi;
 
-    int tap = half / kc, cidx = half - tap * kc;   // chunk q = 2*stage + half -> (tap, cidx)
+    int tap = (2 * kg + half) / kc, cidx = (2 * kg + half) - tap * kc;   // chunk q = 2*stage + half -> (tap, cidx); group kg owns stages it*KG + kg
     const int Ctot = p.x.C0 + p.x.C1;
     int pix0[XR], pix1[XR];                        // per-row source PIXEL index for the current tap (-1 = zeros); pixels fit int32
     auto retap = [&]() {
@@ -262,7 +266,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
     bool xval[XF ? XR : 1];
     int xch = 0;
     // per-channel coefficients (scale, shift, gate of the tile's image: xhw is a multiple of BP) staged in LDS once, behind the ring
-    float* xcoef = reinterpret_cast<float*>(smem + R * STAGE);
+    float* xcoef = reinterpret_cast<float*>(smem + R * KG * STAGE);
     if (XF) {
         const long img = p.xgate ? p_blk / p.xhw : 0;
         for (int i = tid; i < p.KP; i += 256) {
@@ -283,9 +287,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
         }
         bool xcv = false;
         if (it < S) {
-            char* sW = smem + (it % R) * STAGE;
+            char* sW = smem + ((it % R) * KG + kg) * STAGE;
             char* sX = sW + BC * 128;
-            const int q = 2 * it + half;
+            const int q = 2 * (it * KG + kg) + half;
             const bool qv = q < Q;
             const int c = cidx * 32 + sub;
             const bool from0 = c < p.x.C0;
@@ -318,7 +322,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
                 }
             }
             if (qv) {
-                cidx += 2;
+                cidx += 2 * KG;
                 if (cidx >= kc) {
                     while (cidx >= kc) { cidx -= kc; ++tap; }
                     if (tap < p.taps) retap();
@@ -326,7 +330,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
             }
         }
         if (it >= R - 1) {
-            const char* sW = smem + ((it - (R - 1)) % R) * STAGE;
+            const char* sW = smem + (((it - (R - 1)) % R) * KG + kg) * STAGE;
             const char* sX = sW + BC * 128;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -376,6 +380,27 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
         }
     }
 
+    if (KG == 2) {                                                // the two K groups meet: group 1 hands its partial tile over and retires
+        __syncthreads();
+        float* hand = reinterpret_cast<float*>(smem);              // [256 threads][TC*TP*4], lane-contiguous
+        if (kg == 1) {
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int j = 0; j < TP; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) hand[((i * TP + j) * 4 + r) * 256 + tid] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (kg == 1) return;
+#pragma unroll
+        for (int i = 0; i < TC; ++i)
+#pragma unroll
+            for (int j = 0; j < TP; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] += hand[((i * TP + j) * 4 + r) * 256 + tid];
+        // (the epilogue's own leading barrier, when it stages through LDS, now only involves the surviving group)
+    }
     // ---- epilogue: bias, activation, optional BN partial statistics; store.  bf16 outputs whose rows are 16-B aligned go through an
     // LDS tile ([BP][BC], 16-B pieces XOR-swizzled by the pixel row) so that every wave writes whole contiguous row segments; the
     // remaining cases (fp32 head outputs, ragged Nout) store 4 consecutive couts per lane directly.
@@ -1619,18 +1644,19 @@ static XSrc make_xsrc(const void* x0, const void* x1, int mode, int n_img, int H
     return s;
 }
 
-template <int BC, int BP, int WGC, int WGP, int R>
+template <int BC, int BP, int WGC, int WGP, int R, int KG = 1>
 static int launch_nt_r(const GemmNT& p, int out_f32, hipStream_t st) {
     dim3 grid(cdiv(p.x.M, BP) * cdiv(p.Nout, BC));
     const size_t tables = p.x.mode >= 2 ? (size_t)(3 * p.x.H + 3 * p.x.W) * 4 * (p.x.C1 ? 2 : 1) : 0;
-    const size_t lds = (size_t)(BC + BP) * 128 * R + tables;
+    const size_t lds = (size_t)(BC + BP) * 128 * R * KG + tables;
     if (lds > 64 * 1024) {
         static std::atomic<unsigned long long> optin{0};             // one per instantiation, one bit per device
-        if (!lds_optin(optin, {(const void*)gemm_nt_kernel<BC, BP, WGC, WGP, true, R>, (const void*)gemm_nt_kernel<BC, BP, WGC, WGP, false, R>}))
+        if (!lds_optin(optin, {(const void*)gemm_nt_kernel<BC, BP, WGC, WGP, true, R, false, KG>,
+                               (const void*)gemm_nt_kernel<BC, BP, WGC, WGP, false, R, false, KG>}))
             return HN_ERR_LAUNCH;
     }
-    if (out_f32) hipLaunchKernelGGL((gemm_nt_kernel<BC, BP, WGC, WGP, true, R>), grid, dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((gemm_nt_kernel<BC, BP, WGC, WGP, false, R>), grid, dim3(256), lds, st, p);
+    if (out_f32) hipLaunchKernelGGL((gemm_nt_kernel<BC, BP, WGC, WGP, true, R, false, KG>), grid, dim3(256 * KG), lds, st, p);
+    else hipLaunchKernelGGL((gemm_nt_kernel<BC, BP, WGC, WGP, false, R, false, KG>), grid, dim3(256 * KG), lds, st, p);
     HN_LAUNCH_CHECK();
 }
 
@@ -1829,7 +1855,11 @@ static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img
             default: return launch_nt_xf<128, 128, 2, 2>(p, st);
         }
     }
-    if (small_tile(M, Nout)) return launch_nt<64, 64, 2, 2, 4>(p, out_f32, st);
+    if (small_tile(M, Nout)) {
+        // 1x1 convs of the deep stages: two K groups per workgroup when the K loop is long enough to split (knob 6 = 0 turns it off)
+        if (mode <= 1 && taps == 1 && KP >= 256 && g_hn_knob[6] == 0 && !g_nt_force_r) return launch_nt_r<64, 64, 2, 2, 2, 2>(p, out_f32, st);
+        return launch_nt<64, 64, 2, 2, 4>(p, out_f32, st);
+    }
     switch (pick_bc(Nout)) {
         case 16: return launch_nt<16, 128, 1, 4, 2>(p, out_f32, st);
         case 32: return launch_nt<32, 128, 1, 4, 4>(p, out_f32, st);
