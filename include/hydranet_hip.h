@@ -137,6 +137,12 @@ int hn_dwconv_wgrad(const void* x, int ldx, const void* dz, int ldz, float* part
 /* level-packed: part is fp32 [hn_dwconv_wgrad_blocks(total pixels, C)][C*9] */
 int hn_dwconv_wgrad_levels(const void* x, int ldx, const void* dz, int ldz, float* part, int N, int C, int nlev, const int* H, const int* W,
                            int row_align, hipStream_t stream);
+/* depthwise 3x3 backward in one pass over (dz, x): dx (optional; `accumulate`: added to an existing tensor) = conv(dz, flipped weights wf
+ * [9][C] bf16) and the weight-gradient partial rows part [hn_dwconv_bwd_blocks(strips, C)][C*9] (strips = sum over levels of
+ * N * H * ceil(W / 4)); reduce with hn_rows_reduce.  Reference: the backward of SeparableConvBlock.depthwise_conv (net/common.py:91-92,104). */
+long hn_dwconv_bwd_blocks(long strips, int C);
+int hn_dwconv_bwd_levels(const void* dz, int ldz, const void* x, int ldx, const void* wf, void* dx, int lddx, float* part, int N, int C,
+                         int nlev, const int* H, const int* W, int row_align, int accumulate, hipStream_t stream);
 
 /* 3x3/s2 max pools: mode 0 = zero pad right/bottom, zeros take part in the max (MaxPool2dStaticSamePadding, net/common.py:138-151);
  * mode 1 = nn.MaxPool2d(3,2,1) (head_lane/lanedetect.py:40).  Backward recomputes the arg-max (first maximum wins). */

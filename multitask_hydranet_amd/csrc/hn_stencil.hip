@@ -458,6 +458,149 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const bf16* x, int ld
     }
 }
 
+// Backward of the depthwise conv in ONE pass over (dz, x): the data gradient dx[q] = sum_t wf[t] * dz[q + t - 1] (wf = flipped weights)
+// and the weight gradient dw[ky][kx] = sum_q x[q] * dz[q - (ky-1, kx-1)] read the SAME 3x3 neighbourhood of dz around q, so the 3x6
+// window of a 4-pixel strip serves 36 products for dx and 36 for dw.  Thread = 4 channels (8-byte loads: with 8 channels the window, the
+// 72 accumulators and 22 addresses do not fit 256 registers) x `spl` consecutive strips; dx leaves per strip, the 36 weight-gradient
+// accumulators are summed over the block's lanes through LDS once at the end (one partial row per block).  Separate launches read dz
+// twice and pay the lane reduction for two strips of work: 43 + 26 us on the packed det map.  Blocks behind the real ones zero the
+// alignment rows of dx (ragged level packing), as the forward kernel does.
+__device__ __forceinline__ bf16x4 ld4(const bf16* p) { return *reinterpret_cast<const bf16x4*>(p); }
+__device__ __forceinline__ bf16x4 zero4() { bf16x4 z; z[0] = z[1] = z[2] = z[3] = (bf16)0.0f; return z; }
+
+__global__ __launch_bounds__(256) void dwconv_bwd_kernel(const bf16* dz, int ldz, const bf16* x, int ldx, const bf16* wf, bf16* dx, int lddx,
+                                                         float* part, int N, int C, int spl, long blocks, const Levels L, int accumulate) {
+    extern __shared__ float red[];                                    // [256][37] lane sums, then [9][C] fp32 flipped weights
+    float* wl = red + 256 * 37;
+    const int C4 = C >> 2;
+    const int tid = threadIdx.x;
+    if ((long)blockIdx.x >= blocks) {
+        const int C8 = C >> 3;
+        long idx = ((long)blockIdx.x - blocks) * 256 + tid;
+        for (int l = 0; l < L.n; ++l) {
+            const long real = (long)N * L.H[l] * L.W[l];
+            const long pad = L.row_off[l + 1] - L.row_off[l] - real;
+            if (idx < pad * C8) {
+                st8(dx + (L.row_off[l] + real + idx / C8) * lddx + (idx % C8) * 8, zero8());
+                return;
+            }
+            idx -= pad * C8;
+        }
+        return;
+    }
+    const int lanes = 256 / C4;
+    const int cg = tid % C4, lane = tid / C4;
+    const bool active = lane < lanes;
+    const long total = L.work_off[L.n];                               // strips
+    const long s0 = ((long)blockIdx.x * lanes + lane) * spl;
+    long s1 = s0 + spl;
+    if (s1 > total) s1 = total;
+    float acc[9][4];
+#pragma unroll
+    for (int tq = 0; tq < 9; ++tq)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[tq][k] = 0.f;
+    if (dx) {
+        for (int i = tid; i < 9 * C; i += 256) wl[i] = bf2f(wf[i]);
+        __syncthreads();
+    }
+    if (active) {
+        int lv = 0;
+        for (long sidx = s0; sidx < s1; ++sidx) {
+            while (lv + 1 < L.n && sidx >= L.work_off[lv + 1]) ++lv;
+            const int H = L.H[lv], W = L.W[lv], strips = (W + 3) >> 2;
+            const long ls = sidx - L.work_off[lv];
+            const int sx = (int)(ls % strips);
+            const long t1 = ls / strips;
+            const int oy = (int)(t1 % H);
+            const long n = t1 / H;
+            const int ox0 = sx * 4;
+            const bf16* zl = dz + L.row_off[lv] * ldz + cg * 4;
+            const bf16* xl = x + L.row_off[lv] * ldx + cg * 4;
+            bf16x4 zw[3][6], xv[4];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int iy = oy + r - 1;
+                const int iyc = iy < 0 ? 0 : (iy >= H ? H - 1 : iy);
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    const int ix = ox0 + c - 1;
+                    const int ixc = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
+                    zw[r][c] = ld4(zl + ((n * H + iyc) * (long)W + ixc) * ldz);
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int ox = ox0 + p;
+                xv[p] = ld4(xl + ((n * H + oy) * (long)W + (ox < W ? ox : W - 1)) * ldx);
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                if (ox0 + p >= W) xv[p] = zero4();
+            float da[4][4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) da[p][k] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int iy = oy + r - 1;
+                const bool rok = iy >= 0 && iy < H;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    const int ix = ox0 + c - 1;
+                    if (!(rok && ix >= 0 && ix < W)) zw[r][c] = zero4();
+                }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    if (dx) {
+                        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wl + (r * 3 + j) * C + cg * 4);
+#pragma unroll
+                        for (int p = 0; p < 4; ++p)
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) da[p][k] = fmaf(bf2f(zw[r][p + j][k]), w0[k], da[p][k]);
+                    }
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            acc[8 - (r * 3 + j)][k] = fmaf(bf2f(xv[p][k]), bf2f(zw[r][p + j][k]), acc[8 - (r * 3 + j)][k]);
+                }
+            }
+            if (dx) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    if (ox0 + p >= W) break;
+                    bf16* dst = dx + (L.row_off[lv] + (n * H + oy) * (long)W + ox0 + p) * lddx + cg * 4;
+                    bf16x4 v;
+                    if (accumulate) {
+                        const bf16x4 prev = ld4(dst);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] = f2bf(da[p][k] + bf2f(prev[k]));
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] = f2bf(da[p][k]);
+                    }
+                    *reinterpret_cast<bf16x4*>(dst) = v;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int tq = 0; tq < 9; ++tq)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[tid * 37 + tq * 4 + k] = active ? acc[tq][k] : 0.f;
+    __syncthreads();
+    float* dst = part + (long)blockIdx.x * C * 9;
+    for (int o = tid; o < C4 * 36; o += 256) {
+        const int g = o / 36, v = o - g * 36;
+        float sum = 0.f;
+        for (int l = 0; l < lanes; ++l) sum += red[(l * C4 + g) * 37 + v];
+        const int tq = v >> 2, k = v & 3;
+        dst[(long)(g * 4 + k) * 9 + tq] = sum;
+    }
+}
+
 // fp32 [C][1][3][3] -> wk[tap][C] and flipped wkf[8 - tap][C]
 __global__ void dw_pack_kernel(const float* w, bf16* wk, bf16* wkf, int C) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1138,6 +1281,39 @@ extern "C" int hn_dwconv_wgrad_levels(const void* x, int ldx, const void* dz, in
     Levels L;
     const int rc = fill_levels(L, N, nlev, H, W, row_align);
     return rc != HN_OK ? rc : dwconv_wgrad_launch(x, ldx, dz, ldz, part, N, C, L, st);
+}
+
+// one-pass backward of the depthwise conv (data gradient + weight-gradient partial rows): blocks / launch
+extern "C" long hn_dwconv_bwd_blocks(long strips, int C) {
+    const int lanes = 256 / (C >> 2);
+    long spl = (strips + 767L * lanes) / (768L * lanes);          // ~768 blocks: three co-resident per CU, the lane reduction amortised
+    if (spl < 2) spl = 2;
+    return (strips + spl * lanes - 1) / (spl * lanes);
+}
+extern "C" int hn_dwconv_bwd_levels(const void* dz, int ldz, const void* x, int ldx, const void* wf, void* dx, int lddx, float* part, int N, int C,
+                                    int nlev, const int* H, const int* W, int row_align, int accumulate, hipStream_t st) {
+    Levels L;
+    const int rc = fill_levels(L, N, nlev, H, W, row_align);
+    if (rc != HN_OK) return rc;
+    HN_CHECK_ARG(dz && x && part && (!dx || wf) && (C & 7) == 0 && C >= 8 && C <= 1024 && ((ldz | ldx) & 7) == 0 && (!dx || (lddx & 7) == 0));
+    L.work_off[0] = 0;
+    for (int l = 0; l < L.n; ++l) L.work_off[l + 1] = L.work_off[l] + (long)N * L.H[l] * ((L.W[l] + 3) >> 2);
+    const long strips = L.work_off[L.n];
+    const int lanes = 256 / (C >> 2);
+    const long blocks = hn_dwconv_bwd_blocks(strips, C);
+    const int spl = (int)((strips + blocks * lanes - 1) / (blocks * lanes));
+    long pad_items = 0;
+    if (dx && !accumulate)
+        for (int l = 0; l < L.n; ++l) pad_items += (L.row_off[l + 1] - L.row_off[l] - (long)N * L.H[l] * L.W[l]) * (C >> 3);
+    const size_t lds = (256 * 37 + 9 * (size_t)C) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)dwconv_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((256 * 37 + 9 * 1024) * sizeof(float))) != hipSuccess) return HN_ERR_LAUNCH;
+        attr = true;
+    }
+    hipLaunchKernelGGL(dwconv_bwd_kernel, dim3((unsigned)(blocks + cdiv(pad_items, 256))), dim3(256), lds, st, (const bf16*)dz, ldz, (const bf16*)x,
+                       ldx, (const bf16*)wf, (bf16*)dx, lddx, part, N, C, spl, blocks, L, accumulate);
+    HN_LAUNCH_CHECK();
 }
 
 extern "C" int hn_maxpool_fwd(const void* in, int ldi, void* out, int ldo, int N, int H, int W, int C, int mode, hipStream_t st) {

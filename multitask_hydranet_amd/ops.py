@@ -896,6 +896,28 @@ def k_dwconv_wgrad(x, dz):
     return k_rows_reduce(part, 1, chunks, c * 9).view(c, 1, 3, 3)
 
 
+def k_dwconv_bwd(dz, x, wf, geom=None, want_dx=True, into=None):
+    """depthwise 3x3 backward in one launch (+ the partial-row reduce): (dx | None, dweight [C,1,3,3]).  geom: level-packed tensors;
+    into: an existing tensor dx is ADDED to (GradSlot accumulation)."""
+    c = x.shape[3]
+    if geom is None:
+        n, h, w, _ = x.shape
+        H, W, nl, align = (ctypes.c_int * 1)(h), (ctypes.c_int * 1)(w), 1, 1
+        strips = n * h * ((w + 3) // 4)
+    else:
+        nl, H, W, _, _ = _geom_arrays(geom)
+        n, align = geom[0], LEVEL_ALIGN
+        strips = sum(n * hh * ((ww + 3) // 4) for hh, ww in zip(geom[1], geom[2]))
+    blocks = lib().query("hn_dwconv_bwd_blocks", strips, c)
+    part = torch.empty((blocks, c * 9), device=x.device, dtype=F32)
+    dx = None
+    if want_dx:
+        dx = torch.empty_like(dz) if into is None else into
+    lib().call("hn_dwconv_bwd_levels", ptr(dz), ld(dz), ptr(x), ld(x), ptr(wf), ptr(dx), ld(dx) if dx is not None else 0, ptr(part), n, c, nl,
+               ctypes.addressof(H), ctypes.addressof(W), align, 0 if into is None else 1)
+    return dx, k_rows_reduce(part, 1, blocks, c * 9).view(c, 1, 3, 3)
+
+
 class DwConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight):
@@ -907,8 +929,7 @@ class DwConv(torch.autograd.Function):
     def backward(ctx, dout):
         x, wf = ctx.saved_tensors
         dout = dense(dout)
-        dx = k_dwconv(dout, wf) if ctx.needs_input_grad[0] else None
-        return dx, k_dwconv_wgrad(x, dout)
+        return k_dwconv_bwd(dout, x, wf, want_dx=ctx.needs_input_grad[0])
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -1178,8 +1199,9 @@ class HeadOut(torch.autograd.Function):
             dpw = acc(dpw, k_gemm_tn(mid, None, 0, (n, h, w), dz, cout, kp32(cin), 1, cin))
             dmid, _, _ = k_gemm_nt(dz, None, 0, (n, h, w), ctx.wt, cin, kp32(cout), 1, c0=ldz, c1=0)
             if has_dw:
-                ddw = acc(ddw, k_dwconv_wgrad(f, dmid))
-                dfeats.append(k_dwconv(dmid, pack_dw_weight(dw_weight)[1]))
+                df, dwl = k_dwconv_bwd(dmid, f, pack_dw_weight(dw_weight)[1])
+                ddw = acc(ddw, dwl)
+                dfeats.append(df)
             else:
                 dfeats.append(dmid)
             off += h * w
@@ -1520,16 +1542,15 @@ class TowerLayer(torch.autograd.Function):
                    ctypes.addressof(R))
         dd, _, _ = k_gemm_nt(dz, None, 0, (1, 1, total), wt, c, kp32(cout), 1)
         dpw = k_gemm_tn(d, None, 0, (1, 1, total), dz, cout, kp32(c), 1, c)
-        ddw = k_dwconv_wgrad_levels(x, dd, geom)
         dx = None
         if ctx.needs_input_grad[0] and ctx.slot is not None:
             sl = ctx.slot
             if sl.buf is None:
-                sl.buf = k_dwconv_levels(dd, wf, geom)
+                sl.buf, ddw = k_dwconv_bwd(dd, x, wf, geom)
             else:
-                k_dwconv_levels(dd, wf, geom, into=sl.buf)
-        elif ctx.needs_input_grad[0]:
-            dx = k_dwconv_levels(dd, wf, geom)
+                _, ddw = k_dwconv_bwd(dd, x, wf, geom, into=sl.buf)
+        else:
+            dx, ddw = k_dwconv_bwd(dd, x, wf, geom, want_dx=ctx.needs_input_grad[0])
         bn_grads = []
         for l in range(nl):
             bn_grads += [dgam[l], dbet[l], None, None]
@@ -1584,8 +1605,7 @@ class HeadOutPacked(torch.autograd.Function):
         dbias = k_rows_reduce(ps, 1, ps.shape[0], ldz).view(-1)[:cout]
         dpw = k_gemm_tn(mid, None, 0, (1, 1, total), dz, cout, kp32(cin), 1, cin)
         dmid, _, _ = k_gemm_nt(dz, None, 0, (1, 1, total), wt, cin, kp32(cout), 1, c0=ldz, c1=0)
-        ddw = k_dwconv_wgrad_levels(x, dmid, geom)
-        dx = k_dwconv_levels(dmid, wf, geom)
+        dx, ddw = k_dwconv_bwd(dmid, x, wf, geom)
         return ddw, dpw, dbias, None, None, None, dx
 
 

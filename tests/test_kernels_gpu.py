@@ -683,3 +683,44 @@ def test_device_nms_bit_exact_vs_oracle(K, k, spread):
         ref = O.nms_greedy(boxes.cpu(), scores.cpu(), thr)
         assert torch.equal(dev_keep, ref), (k, thr)
         assert 0 < len(ref) <= k
+
+
+@pytest.mark.parametrize("c,n,hs,ws", [(112, 2, (8,), (12,)), (16, 1, (5,), (5,)), (112, 16, (64,), (128,)), (64, 3, (7,), (9,)),
+                                       (112, 4, (20, 10, 5, 3, 2), (20, 10, 5, 3, 2)), (112, 16, (64, 32, 16, 8, 4), (128, 64, 32, 16, 8))])
+def test_depthwise_backward_one_pass(K, c, n, hs, ws):
+    """hn_dwconv_bwd_levels (data + weight gradient from one pass over (dz, x)) against the separate launches: dx bit-identical (same
+    products in the same order), dweight to fp32 summation order; ragged level packing (alignment rows zeroed) and accumulation."""
+    geom = (n, list(hs), list(ws)) if len(hs) > 1 else None
+    wt = rnd(c, 1, 3, 3, scale=0.3)
+    _, wf = K.pack_dw_weight(wt)
+    if geom is None:
+        x, dz = nhwc(rnd(n, c, hs[0], ws[0])), nhwc(rnd(n, c, hs[0], ws[0]))
+        dx_ref, dw_ref = K.k_dwconv(dz, wf), K.k_dwconv_wgrad(x, dz)
+    else:
+        rows_ = sum(K._pad_rows(n * h * w) for h, w in zip(hs, ws))
+        x = (torch.randn(1, 1, rows_, c, device=dev())).bfloat16()
+        dz = (torch.randn(1, 1, rows_, c, device=dev())).bfloat16()
+        dx_ref, dw_ref = K.k_dwconv_levels(dz, wf, geom), K.k_dwconv_wgrad_levels(x, dz, geom)
+    dx, dw = K.k_dwconv_bwd(dz, x, wf, geom)
+    assert torch.equal(dx, dx_ref)
+    close(dw, dw_ref, 1e-4, "dweight")
+    base = torch.randn_like(dx.float()).bfloat16()
+    got = base.clone()
+    K.k_dwconv_bwd(dz, x, wf, geom, into=got)
+    if geom is None:
+        want = (dx_ref.float() + base.float()).bfloat16()
+        # the accumulate path adds the fp32 sum to the stored bf16 value: one rounding, not two
+        assert float((got.float() - want.float()).abs().max()) <= 2e-2 * float(want.float().abs().max())
+    else:
+        want = base.clone()
+        K.k_dwconv_levels(dz, wf, geom, into=want)
+        assert torch.equal(got, want)
+    none_dx, dw2 = K.k_dwconv_bwd(dz, x, wf, geom, want_dx=False)
+    assert none_dx is None and torch.equal(dw2, dw)
+    # against the fp32 definition
+    if geom is None:
+        xr = nchw(x).clone().requires_grad_(True)
+        wr = wt.clone().requires_grad_(True)
+        F.conv2d(xr, wr, None, 1, 1, 1, c).backward(nchw(dz))
+        close(nchw(dx), xr.grad, GRAD_TOL, "dx vs torch")
+        close(dw, wr.grad, GRAD_TOL, "dw vs torch")
