@@ -174,6 +174,16 @@ int hn_fuse_bwd_blocks(int N, int H, int W, int C);
 int hn_fuse_bwd(const void* const* in, const int* ld, const int* mode, const float* w, const void* dout, int ldd, void* g, int ldg,
                 void* const* din, const int* ldin, const int* acc, float* pw, int N, int H, int W, int C, hipStream_t stream);
 
+/* Data gradient of a 3x3 conv over a reflection-padded (clamp = 0: ConvBlock / Conv3x3, head_seg/segmentation.py:40-58) or, in phase form,
+ * replicate-padded (clamp = 1) input, written straight to the unpadded gradient: dx [N][H][W][Nout] (row stride ldo) = fold(full
+ * correlation of dz with the transposed weights) [* ELU'(yprev)].  Replaces hn_conv_gemm_nt(mode 3) on the padded grid + hn_seg_fold:
+ * the conv epilogue writes the interior of the padded grid in place and the one-pixel ring to `ring`
+ * [N][hn_fold_ring_rows(H, W)][Nout] bf16; a border fix-up adds the ring to the 2 (H + W) pixels per image it mirrors onto.
+ * phase_k = 0: dz [N][H][W][Cz], wt [Nout][9][KP];  phase_k > 0: dz = space-to-depth gradient [N][H][W][4 k], wt = transposed effective
+ * weights.  HN_ERR_UNSUPPORTED (3) unless Nout % 8 == 0, Nout > 32, H, W >= 4 -- callers keep the two-pass path for those shapes. */
+long hn_fold_ring_rows(int H, int W);
+int hn_conv3x3_dgrad_fold(const void* dz, int ldz, int Cz, int n_img, int H, int W, const void* wt, int Nout, int KP, int phase_k, int clamp,
+                          void* out, int ldo, const void* yprev, int ldy, void* ring, hipStream_t stream);
 /* Backward of ReflectionPad2d(1) (+ nearest x2, + channel split of the concat) for the seg decoder (head_seg/segmentation.py:40,92-99). */
 int hn_seg_fold(const void* dvp, int ldv, int c0, void* out, int ldo, const void* yprev, int ldy, int N, int H, int W, int C, int up,
                 hipStream_t stream);

@@ -9,6 +9,7 @@
 // head_lane/lanedetect.py:45-64) and the segmentation decoder's ReflectionPad2d(1)+Conv2d(3)+upsample+cat
 // (head_seg/segmentation.py:32-48,84-105).
 #include "hn_common.h"
+#include <climits>
 
 struct XSrc {
     const bf16* x0;
@@ -149,6 +150,13 @@ struct GemmNT {
                                       // maximum wins) instead of the logits (deploy forward: model/model.py:197 only needs the mask)
     int add_pre;                      // 1: the addend goes in BEFORE the activation: out = act(acc + bias + addend) (inference: folded
                                       // BatchNorm + identity branch + ReLU of an XBlock in conv_block_3's epilogue)
+    // Direct 3x3 kernel, mode 3 (data gradient on the padded (H+2) x (W+2) grid), staged bf16 epilogue: fold = 1 writes the INTERIOR of
+    // the padded grid straight to the unpadded gradient out [N][H][W] (row stride ldc), multiplied by ELU'(fold_y) when the producer's
+    // ELU output is given, and the one-pixel RING to ring [N][2 (W+2) + 2 H][Nout] (top row, bottom row, left column, right column);
+    // seg_ring_fix_kernel then adds the ring to the border pixels it reflects / clamps onto.  No padded tensor, no full fold pass.
+    int fold;
+    bf16* ring;
+    const bf16* fold_y; int ld_fy;
 };
 
 // KG = 2: 512 threads = two independent 4-wave groups that walk alternate K stages (their own LDS stages, common barriers) and meet in LDS
@@ -925,6 +933,47 @@ __global__ __launch_bounds__(512, PIPE ? 2 : 4) void conv3x3_direct_kernel(const
         constexpr int NPC = BC / 8;                                   // 16-byte pieces per output pixel
         const int ph = p.d2s ? c_blk / p.d2s : 0, oc0 = p.d2s ? c_blk - ph * p.d2s : c_blk;    // (d2s: the whole cout tile lies in one phase)
         bf16* outp = reinterpret_cast<bf16*>(p.out);
+        if (p.fold) {
+            constexpr int ITER = 256 * NPC / 512;
+            const int H = xs.H - 2, W = xs.W - 2;
+            const int pc = tid % NPC, c = c_blk + pc * 8;             // (512 % NPC == 0: a thread keeps its 8-channel piece)
+            long dst[ITER];                                           // element offset in out (>= 0) or -(ring offset) - 1; LONG_MIN: nothing
+            bf16x8 yv[ITER];
+#pragma unroll
+            for (int i = 0; i < ITER; ++i) {
+                const int pl = (tid + 512 * i) / NPC;
+                const int oy = oy0 + (pl >> 4), oxx = ox0 + (pl & 15);
+                const int iy = oy - 1, ix = oxx - 1;
+                dst[i] = LONG_MIN;
+                yv[i] = zero8();
+                if (oy < xs.H && oxx < xs.W && c < p.Nout) {
+                    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+                        const long pix = (long)(n * H + iy) * W + ix;
+                        dst[i] = pix * p.ldc + c;
+                        if (p.fold_y) yv[i] = ld8(p.fold_y + pix * p.ld_fy + c);
+                    } else {
+                        const int r = oy == 0 ? oxx : (oy == H + 1 ? xs.W + oxx : (oxx == 0 ? 2 * xs.W + iy : 2 * xs.W + H + iy));
+                        dst[i] = -(((long)n * (2 * xs.W + 2 * H) + r) * p.Nout + c) - 1;
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < ITER; ++i) {
+                if (dst[i] == LONG_MIN) continue;
+                const int pl = (tid + 512 * i) / NPC;
+                bf16x8 v = *reinterpret_cast<const bf16x8*>(stage + pl * (BC * 2) + (((pc ^ pl) & (NPC - 1)) << 4));
+                if (dst[i] >= 0) {
+                    if (p.fold_y) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) { const float yy = bf2f(yv[i][k]), f = bf2f(v[k]); v[k] = f2bf(yy > 0.f ? f : f * (yy + 1.0f)); }
+                    }
+                    *reinterpret_cast<bf16x8*>(outp + dst[i]) = v;
+                } else {
+                    *reinterpret_cast<bf16x8*>(p.ring - dst[i] - 1) = v;
+                }
+            }
+            return;
+        }
 #pragma unroll 2
         for (int idx = tid; idx < 256 * NPC; idx += 512) {
             const int pl = idx / NPC, pc = idx - pl * NPC;
@@ -1721,6 +1770,8 @@ extern "C" int hn_nt_stat_rows(long M, int Nout) {               // one partial 
     return small_tile(M, Nout) ? cdiv(M, 64) : cdiv(M, 128);
 }
 
+struct NextFold { bf16* ring; const bf16* y; int ldy; };
+static thread_local NextFold g_next_fold = {nullptr, nullptr, 0};   // set by hn_conv3x3_dgrad_fold for the launch it makes
 static thread_local long* g_next_amax = nullptr;    // set by hn_conv3x3_out_argmax for the launch it makes (same thread, same call)
 static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img, int H, int W, int C0, int C1, int ld0, int ld1,
                              int up, long M, const void* w, int Nout, int KP, int taps, const float* bias, int act, void* out,
@@ -1811,6 +1862,7 @@ static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img
     p.phase_mode = phase_mode; p.phase_span = phase_span;
     p.amax = g_next_amax;
     g_next_amax = nullptr;
+    p.fold = g_next_fold.ring ? 1 : 0; p.ring = g_next_fold.ring; p.fold_y = g_next_fold.y; p.ld_fy = g_next_fold.ldy;
     if (img_stride < 0) {                                            // mode 4: -img_stride = channels per depth-to-space output pixel
         HN_CHECK_ARG(p.x.clamp == 1 && (out_f32 || phase_mode == 1) && rpi == 0 && !psum && Nout == 4 * (int)(-img_stride));
         p.d2s = (int)(-img_stride);
@@ -1866,6 +1918,88 @@ static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img
         case 64: return launch_nt<64, 128, 2, 2, 4>(p, out_f32, st);
         default: return launch_nt<128, 128, 2, 2, 4>(p, out_f32, st);
     }
+}
+
+// Border fix-up of a folded data gradient (GemmNT::fold): the gradient of a reflection- (clamp = 0) or replicate-padded (clamp = 1) input
+// collects, besides its own position of the padded grid, the padded ring positions that mirror / clamp onto it:
+//   reflect: rows 1 and H-2 take padded rows 0 and H+1 (columns alike);  clamp: rows 0 and H-1.
+// Thread = 8 channels of one border target pixel (2 W + 2 (H - 2) per image); out += ring sum * ELU'(y).
+__global__ __launch_bounds__(256) void seg_ring_fix_kernel(bf16* out, int ldo, const bf16* ring, const bf16* y, int ldy, int N, int H, int W,
+                                                           int C, int clamp) {
+    const int C8 = C >> 3, T = 2 * W + 2 * (H - 2), R = 2 * (W + 2) + 2 * H;
+    const long total = (long)N * T * C8;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int cg = (int)(idx % C8);
+    long t = idx / C8;
+    const int tt = (int)(t % T);
+    const int n = (int)(t / T);
+    const int ry0 = clamp ? 0 : 1, ry1 = clamp ? H - 1 : H - 2, rx0 = clamp ? 0 : 1, rx1 = clamp ? W - 1 : W - 2;
+    int yy, xx;
+    if (tt < W) { yy = ry0; xx = tt; }
+    else if (tt < 2 * W) { yy = ry1; xx = tt - W; }
+    else {
+        int j = tt - 2 * W;
+        xx = rx0;
+        if (j >= H - 2) { j -= H - 2; xx = rx1; }
+        yy = j + (j >= ry0 ? 1 : 0);
+        if (yy >= ry1) ++yy;
+    }
+    int ya[3], xa[3], ny = 0, nx = 0;
+    ya[ny++] = yy + 1; xa[nx++] = xx + 1;
+    if (yy == ry0) ya[ny++] = 0;
+    if (yy == ry1) ya[ny++] = H + 1;
+    if (xx == rx0) xa[nx++] = 0;
+    if (xx == rx1) xa[nx++] = W + 1;
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    const bf16* rg = ring + (long)n * R * C + cg * 8;
+    for (int a = 0; a < ny; ++a)
+        for (int b = 0; b < nx; ++b) {
+            if (a == 0 && b == 0) continue;                           // the pixel's own position: written by the conv epilogue
+            const int pa = ya[a], pb = xa[b];
+            const int r = pa == 0 ? pb : (pa == H + 1 ? (W + 2) + pb : (pb == 0 ? 2 * (W + 2) + pa - 1 : 2 * (W + 2) + H + pa - 1));
+            const bf16x8 v = ld8(rg + (long)r * C);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += bf2f(v[k]);
+        }
+    const long pix = (long)(n * H + yy) * W + xx;
+    bf16* o = out + pix * ldo + cg * 8;
+    bf16x8 cur = ld8(o);
+    if (y) {
+        const bf16x8 yv = ld8(y + pix * ldy + cg * 8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const float e = bf2f(yv[k]); acc[k] = e > 0.f ? acc[k] : acc[k] * (e + 1.0f); }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cur[k] = f2bf(bf2f(cur[k]) + acc[k]);
+    st8(o, cur);
+}
+
+extern "C" long hn_fold_ring_rows(int H, int W) { return 2L * (W + 2) + 2L * H; }
+
+/* Data gradient of a 3x3 conv over a reflection-padded (clamp = 0) or, in phase form, replicate-padded (clamp = 1) input, written
+ * straight to the unpadded gradient: dx [N][H][W][Nout] (row stride ldo) = fold(full correlation of dz with the transposed weights)
+ * [* ELU'(yprev)] -- the padded-grid tensor and the fold pass of hn_conv_gemm_nt(mode 3) + hn_seg_fold in two launches (conv with a
+ * folding epilogue + a border fix-up over 2 (H + W) pixels per image).  phase_k = 0: dz [N][H][W][Cz], wt [Nout][9][KP];  phase_k > 0:
+ * dz = space-to-depth gradient [N][H][W][4 k] of a phase-form conv, wt = its transposed effective weights (4 taps per phase).
+ * ring: scratch [N][hn_fold_ring_rows(H, W)][Nout] bf16.  Needs Nout % 8 == 0, Nout > 32, H, W >= 4 (else HN_ERR_UNSUPPORTED). */
+extern "C" int hn_conv3x3_dgrad_fold(const void* dz, int ldz, int Cz, int n_img, int H, int W, const void* wt, int Nout, int KP, int phase_k,
+                                     int clamp, void* out, int ldo, const void* yprev, int ldy, void* ring, hipStream_t st) {
+    HN_CHECK_ARG(dz && wt && out && ring && n_img > 0 && (ldo & 7) == 0 && (!yprev || (ldy & 7) == 0) && (clamp == 0 || clamp == 1));
+    HN_CHECK_ARG(phase_k == 0 || (Cz == 4 * phase_k && phase_k % 64 == 0));
+    if ((Nout & 7) || Nout <= 32 || H < 4 || W < 4 || g_direct_pipe || (reinterpret_cast<uintptr_t>(out) & 15)) return HN_ERR_UNSUPPORTED;
+    g_next_fold = {(bf16*)ring, (const bf16*)yprev, ldy};
+    const int rc = conv_gemm_nt_impl(dz, nullptr, 3, n_img, H + 2, W + 2, Cz, 0, ldz, 0, 0, (long)n_img * (H + 2) * (W + 2), wt, Nout, KP, 9,
+                                     nullptr, HN_ACT_NONE, out, 0, ldo, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, 0,
+                                     phase_k ? 2 : 0, phase_k, st);
+    g_next_fold = {nullptr, nullptr, 0};
+    if (rc != HN_OK) return rc;
+    const long total = (long)n_img * (2 * W + 2 * (H - 2)) * (Nout >> 3);
+    hipLaunchKernelGGL(seg_ring_fix_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, (bf16*)out, ldo, (const bf16*)ring, (const bf16*)yprev, ldy,
+                       n_img, H, W, Nout, clamp);
+    HN_LAUNCH_CHECK();
 }
 
 template <int BC, int BN, int WGC, int WGN>

@@ -1084,6 +1084,28 @@ class Fuse(torch.autograd.Function):
 # --------------------------------------------------------------------------------------------------------------
 # segmentation decoder block: y = act(conv3x3(reflect_pad(cat[up2(x0)|x0, x1])) + bias)
 # --------------------------------------------------------------------------------------------------------------
+SEG_FOLD_DIRECT = os.environ.get("HN_SEG_FOLD_DIRECT", "1") != "0"
+
+
+SEG_FOLD_MIN_ELEMS = 1 << 24   # measured (step trace, N = 16): the folding epilogue wins 130 / 45 / 19 / 11 us on the 134M / 67M / 33M / 17M-element
+                               # gradients and loses 2...26 us on the <= 8M-element ones (a few hundred workgroups cannot hide the extra loads)
+
+
+def dgrad_fold_ok(nout, h, w, n=None):
+    """shapes hn_conv3x3_dgrad_fold covers (the staged bf16 epilogue of the 64 / 128-cout tiles); with n: and where it pays"""
+    return SEG_FOLD_DIRECT and nout % 8 == 0 and nout > 32 and h >= 4 and w >= 4 and (n is None or n * h * w * nout >= SEG_FOLD_MIN_ELEMS)
+
+
+def k_dgrad_fold(dz, wt, n, h, w, nout, kp, phase_k, clamp, yprev):
+    """dx [N,h,w,nout] = folded data gradient (* ELU'(yprev)): conv with a folding epilogue + border fix-up, no padded-grid tensor"""
+    dev = dz.device
+    dx = new_act(n, h, w, nout, dev)
+    ring = torch.empty((n, lib().query("hn_fold_ring_rows", h, w), nout), device=dev, dtype=BF16)
+    lib().call("hn_conv3x3_dgrad_fold", ptr(dz), ld(dz), dz.shape[3], n, h, w, ptr(wt), nout, kp, phase_k, clamp, ptr(dx), ld(dx),
+               ptr(yprev), ld(yprev) if yprev is not None else 0, ptr(ring))
+    return dx
+
+
 class SegConv(torch.autograd.Function):
     """ConvBlock / Conv3x3 of the seg decoder.  Along the decoder chain every x0 is the ELU output of the previous block and has no other
     consumer, so ELU' of the previous block is applied where this block folds its data gradient (x0_is_elu: hn_seg_fold multiplies by
@@ -1128,8 +1150,12 @@ class SegConv(torch.autograd.Function):
             dbias = dbias[:cout] + 0.0                               # owning copy by a kernel (a clone would be a memcpy node in the graph)
         dw = k_gemm_tn(x0, x1, 2, (n, h, w), dz, cout, kp32(cin), 9, cin, up=up, kh=3)
         # data gradient on the padded (H+2)x(W+2) grid, then fold the reflection / up-sampling / concat back
-        dvp, _, _ = k_gemm_nt(dz, None, 3, (n, h + 2, w + 2), ctx.wt, cin, kp32(cout), 9, c0=dz.shape[3], c1=0)
         dx0 = dx1 = None
+        if not up and not ctx.has_x1 and dgrad_fold_ok(c0, h, w, n):
+            if ctx.needs_input_grad[0]:
+                dx0 = k_dgrad_fold(dz, ctx.wt, n, h, w, c0, kp32(cout), 0, 0, x0 if ctx.x0_is_elu else None)
+            return dx0, dx1, dw, dbias, None, None, None, None, None
+        dvp, _, _ = k_gemm_nt(dz, None, 3, (n, h + 2, w + 2), ctx.wt, cin, kp32(cout), 9, c0=dz.shape[3], c1=0)
         if ctx.needs_input_grad[0]:
             dx0 = new_act(n, h0, w0, c0, dev)
             yp = x0 if ctx.x0_is_elu else None
@@ -1677,10 +1703,13 @@ class SegOutUp(torch.autograd.Function):
         lib().call("hn_phase_fold", ptr(dw_eff), None, ptr(db_eff), ptr(dw), ptr(dbias), k, c, 0)
         dx = None
         if ctx.needs_input_grad[0]:
-            dvp, _, _ = k_gemm_nt(dz, None, 3, (n, h + 2, w + 2), ctx.wt, c, kp32(4 * k), 9, c0=ldz, c1=0)
-            dx = new_act(n, h, w, c, dev)
             yp = x if ctx.x_is_elu else None
-            lib().call("hn_seg_fold", ptr(dvp), ld(dvp), 0, ptr(dx), ld(dx), ptr(yp), ld(yp) if yp is not None else 0, n, h, w, c, 2)
+            if dgrad_fold_ok(c, h, w, n):
+                dx = k_dgrad_fold(dz, ctx.wt, n, h, w, c, kp32(4 * k), 0, 1, yp)
+            else:
+                dvp, _, _ = k_gemm_nt(dz, None, 3, (n, h + 2, w + 2), ctx.wt, c, kp32(4 * k), 9, c0=ldz, c1=0)
+                dx = new_act(n, h, w, c, dev)
+                lib().call("hn_seg_fold", ptr(dvp), ld(dvp), 0, ptr(dx), ld(dx), ptr(yp), ld(yp) if yp is not None else 0, n, h, w, c, 2)
         return dx, dw, dbias, None, None
 
 
@@ -1777,6 +1806,8 @@ class SegConvUp(torch.autograd.Function):
             if c1 and ctx.needs_input_grad[1]:
                 dx1 = new_act(n, 2 * h, 2 * w, c1, dev)
                 lib().call("hn_seg_fold", ptr(dvp), ld(dvp), c0, ptr(dx1), ld(dx1), None, 0, n, 2 * h, 2 * w, c1, 0)
+        elif ctx.needs_input_grad[0] and dgrad_fold_ok(c0, h, w, n):
+            dx0 = k_dgrad_fold(dzs, wt_eff, n, h, w, c0, kp32(4 * k), k, 1, x0 if ctx.x0_is_elu else None)
         elif ctx.needs_input_grad[0]:
             dvp = new_act(n, h + 2, w + 2, c0, dev)
             lib().call("hn_conv3x3_phase", ptr(dzs), 3, n, h + 2, w + 2, 4 * k, ld(dzs), ptr(wt_eff), c0, kp32(4 * k), None, ACT_NONE, ptr(dvp),

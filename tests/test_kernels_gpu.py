@@ -724,3 +724,46 @@ def test_depthwise_backward_one_pass(K, c, n, hs, ws):
         F.conv2d(xr, wr, None, 1, 1, 1, c).backward(nchw(dz))
         close(nchw(dx), xr.grad, GRAD_TOL, "dx vs torch")
         close(dw, wr.grad, GRAD_TOL, "dw vs torch")
+
+
+@pytest.mark.parametrize("n,h,w,cz,nout,clamp,elu", [
+    (2, 16, 16, 64, 64, 0, True), (1, 4, 4, 64, 64, 0, False), (3, 5, 7, 128, 112, 0, True), (2, 33, 18, 64, 256, 0, True),
+    (2, 16, 32, 24, 64, 1, True), (1, 4, 5, 24, 64, 1, False), (2, 128, 256, 24, 64, 1, True), (2, 31, 47, 256, 128, 0, False),
+])
+def test_dgrad_fold_direct_vs_padded_grid_and_fold(K, n, h, w, cz, nout, clamp, elu):
+    """hn_conv3x3_dgrad_fold (folding epilogue + ring fix-up) against hn_conv_gemm_nt(mode 3) on the padded grid + hn_seg_fold: identical
+    away from the border (same bf16 values through the same operations), one extra bf16 rounding on the 2 (H + W) border pixels."""
+    from multitask_hydranet_amd._lib import lib
+    dz = nhwc(rnd(n, cz, h, w))
+    wgt = rnd(cz, nout, 3, 3, scale=0.2)                     # forward weight [cout = cz][cin = nout]
+    _, wt = K.pack_conv_weight(wgt)
+    yp = nhwc(rnd(n, nout, h, w)) if elu else None
+    kp = K.kp32(cz)
+    dvp, _, _ = K.k_gemm_nt(dz, None, 3, (n, h + 2, w + 2), wt, nout, kp, 9, c0=cz, c1=0)
+    ref = K.new_act(n, h, w, nout, dev())
+    lib().call("hn_seg_fold", K.ptr(dvp), K.ld(dvp), 0, K.ptr(ref), K.ld(ref), K.ptr(yp), K.ld(yp) if yp is not None else 0, n, h, w, nout,
+               2 if clamp else 0)
+    assert K.dgrad_fold_ok(nout, h, w)
+    got = K.k_dgrad_fold(dz, wt, n, h, w, nout, kp, 0, clamp, yp)
+    inner = (slice(None), slice(2, h - 2), slice(2, w - 2))
+    if h > 4 and w > 4:
+        assert torch.equal(got[inner], ref[inner])
+    close(got, ref, 1e-2, "folded dgrad")
+
+
+@pytest.mark.parametrize("n,h,w,k,c0", [(2, 16, 16, 64, 64), (1, 8, 12, 64, 128), (2, 20, 36, 128, 256)])
+def test_dgrad_fold_direct_phase_form(K, n, h, w, k, c0):
+    """the same for the phase-form data gradient (space-to-depth gradient operand, 4 taps per phase, replicate-padding fold)"""
+    from multitask_hydranet_amd._lib import lib
+    wgt = rnd(k, c0, 3, 3, scale=0.1)
+    _, wt_eff, _ = K.pack_phase_weight(wgt, c0, rnd(k))
+    dzs = nhwc(rnd(n, 4 * k, h, w))
+    yp = nhwc(rnd(n, c0, h, w))
+    dvp = K.new_act(n, h + 2, w + 2, c0, dev())
+    lib().call("hn_conv3x3_phase", K.ptr(dzs), 3, n, h + 2, w + 2, 4 * k, K.ld(dzs), K.ptr(wt_eff), c0, K.kp32(4 * k), None, 0, K.ptr(dvp),
+               K.ld(dvp), k, None, 0)
+    ref = K.new_act(n, h, w, c0, dev())
+    lib().call("hn_seg_fold", K.ptr(dvp), K.ld(dvp), 0, K.ptr(ref), K.ld(ref), K.ptr(yp), K.ld(yp), n, h, w, c0, 2)
+    got = K.k_dgrad_fold(dzs, wt_eff, n, h, w, c0, K.kp32(4 * k), k, 1, yp)
+    assert torch.equal(got[:, 2:h - 2, 2:w - 2], ref[:, 2:h - 2, 2:w - 2])
+    close(got, ref, 1e-2, "folded phase dgrad")
