@@ -2023,8 +2023,11 @@ static void tn_tiles(int Nout, int KP, int& bc, int& bn) {
     if (bc == 16 && bn < 64) bn = 64;                       // 4 waves need >= 16 columns each
 }
 
-static bool use_patch_wgrad(int mode, int Nout, int KP) { return mode == 2 && KP >= 64; }
-static void patch_tiles(int Nout, int& bc, int& ci, int& ksplit) {
+// (KP = 32, the 24-channel skip operand of decoder.5: nine tap-parallel row-gather workgroups re-read dZ nine times -- 173 us; the
+// patch kernel reads it once: 95 us with half of a 64-channel patch zero-filled, 69 us with the 32-channel patch)
+static bool use_patch_wgrad(int mode, int Nout, int KP) { return mode == 2 && KP >= 32; }
+static void patch_tiles(int Nout, int KP, int& bc, int& ci, int& ksplit) {
+    if (KP <= 32 && Nout > 64) { bc = 128; ci = 32; ksplit = 2; return; }
     if (Nout <= 16) { bc = 16; ci = 64; ksplit = 2; }
     else if (Nout <= 32) { bc = 32; ci = 64; ksplit = 2; }           // the 4-phase 5-class output conv: 20 couts (62 KB LDS: 2 workgroups per CU)
     else if (Nout <= 64) { bc = 64; ci = 64; ksplit = 2; }           // 78 KB LDS: two workgroups per CU (ci = 128: 124 KB, one)
@@ -2050,7 +2053,7 @@ static int wgrad_plan_impl(int mode, int n_img, int H, int W, long M, int Nout, 
     if (mode == 4 || mode == 5) mode = 2;
     if (use_patch_wgrad(mode, Nout, KP)) {
         int bc, ci, ksplit;
-        patch_tiles(Nout, bc, ci, ksplit);
+        patch_tiles(Nout, KP, bc, ci, ksplit);
         if (grouped) { bc = 64; ci = 64; ksplit = 2; }
         if (phase_span && phase_span < bc) { bc = 64; ci = 64; ksplit = 2; }      // a cout tile must lie inside one phase
         const long tiles = (long)cdiv(Nout, bc) * cdiv(KP, ci);
@@ -2117,10 +2120,10 @@ static int conv_gemm_tn_impl(const void* x0, const void* x1, int mode, int n_img
         static std::atomic<unsigned long long> optin{0};
         if (!lds_optin(optin, {(const void*)wgrad3x3_patch_kernel<128, 64>, (const void*)wgrad3x3_patch_kernel<64, 128>,
                                (const void*)wgrad3x3_patch_kernel<16, 64>, (const void*)wgrad3x3_patch_kernel<64, 64>,
-                               (const void*)wgrad3x3_patch_kernel<32, 64>}))
+                               (const void*)wgrad3x3_patch_kernel<32, 64>, (const void*)wgrad3x3_patch_kernel<128, 32>}))
             return HN_ERR_LAUNCH;
         int pbc, pci, ksplit;
-        patch_tiles(Nout, pbc, pci, ksplit);
+        patch_tiles(Nout, KP, pbc, pci, ksplit);
         if (grouped) { pbc = 64; pci = 64; ksplit = 2; }
         if (phase_span && phase_span < pbc) { pbc = 64; pci = 64; ksplit = 2; }
         p.gy = cdiv(Nout, pbc);
@@ -2129,6 +2132,7 @@ static int conv_gemm_tn_impl(const void* x0, const void* x1, int mode, int n_img
         const size_t xb = (size_t)((180 * (pci / 8) + 511) / 512) * 512 * 16;
         const size_t lds = 2 * ((size_t)((128 * pbc * 2 + 1023) / 1024 * 1024) + xb);
         if (grouped) hipLaunchKernelGGL((wgrad3x3_patch_kernel<64, 64>), grid, dim3(512), lds, st, p, (int)rps, patches);
+        else if (pbc == 128 && pci == 32) hipLaunchKernelGGL((wgrad3x3_patch_kernel<128, 32>), grid, dim3(512), lds, st, p, (int)rps, patches);
         else if (pbc == 128) hipLaunchKernelGGL((wgrad3x3_patch_kernel<128, 64>), grid, dim3(512), lds, st, p, (int)rps, patches);
         else if (pbc == 64) hipLaunchKernelGGL((wgrad3x3_patch_kernel<64, 64>), grid, dim3(512), lds, st, p, (int)rps, patches);
         else if (pbc == 32) hipLaunchKernelGGL((wgrad3x3_patch_kernel<32, 64>), grid, dim3(512), lds, st, p, (int)rps, patches);
