@@ -178,11 +178,12 @@ class PackPlan:
                 ci0, cin = (0, key[1]) if phase else (key[1], key[2])
                 coute = 4 * cout if phase else cout
                 wp = torch.empty((coute, taps * kp32(cin)), device=dev, dtype=BF16)
-                wt = torch.empty((cin, taps * kp32(coute)), device=dev, dtype=BF16)
+                wt = torch.empty((cin, taps * kp32(coute)), device=dev, dtype=BF16) if (not phase or key[2]) else None
                 b_eff = torch.empty((coute,), device=dev, dtype=F32) if phase else None
                 bias = meta if phase else None
-                small([w.data_ptr(), wp.data_ptr(), wt.data_ptr(), b_eff.data_ptr() if phase else 0, bias.data_ptr() if phase else 0, 4, 0,
-                       cout, cin_total, ci0, cin, taps, phase], wp.numel() + wt.numel() + (coute if phase else 0))
+                small([w.data_ptr(), wp.data_ptr(), wt.data_ptr() if wt is not None else 0, b_eff.data_ptr() if phase else 0,
+                       bias.data_ptr() if phase else 0, 4, 0, cout, cin_total, ci0, cin, taps, phase],
+                      wp.numel() + (wt.numel() if wt is not None else 0) + (coute if phase else 0))
                 self.values.append((wp, wt, b_eff, bias) if phase else (wp, wt))
             else:
                 raise KeyError(key)
@@ -239,20 +240,23 @@ def pack_conv_weight_slice(w: torch.Tensor, ci0: int, cin: int):
     return _cached(("slice", ci0, cin), w, make)
 
 
-def pack_phase_weight(w: torch.Tensor, c0: int, bias: torch.Tensor):
+def pack_phase_weight(w: torch.Tensor, c0: int, bias: torch.Tensor, want_wt: bool = True):
     """phase-form effective weights of the first c0 input channels of a 3x3 conv over a nearest-x2 up-sampled map (SegConvUp / SegOutUp):
-    (wp_eff [4k, 9*KP(c0)], wt_eff [c0, 9*KP(4k)], b_eff [4k]) in one launch"""
+    (wp_eff [4k, 9*KP(c0)], wt_eff [c0, 9*KP(4k)] | None, b_eff [4k]) in one launch.  want_wt = False: the layer's data gradient does not
+    run in phase form (decoder.1: the transposed operand alone was 9.4 M scattered-read elements of the per-step pack)."""
+    key = ("phase", c0, 1 if want_wt else 0)
+
     def make():
         k = w.shape[0]
         wp = torch.empty((4 * k, 9 * kp32(c0)), device=w.device, dtype=BF16)
-        wt = torch.empty((c0, 9 * kp32(4 * k)), device=w.device, dtype=BF16)
+        wt = torch.empty((c0, 9 * kp32(4 * k)), device=w.device, dtype=BF16) if want_wt else None
         b_eff = torch.empty((4 * k,), device=w.device, dtype=F32)
         lib().call("hn_pack_weight_ex", ptr(w), ptr(wp), ptr(wt), k, w.shape[1], 0, c0, 9, 1, ptr(bias), ptr(b_eff))
         return wp, wt, b_eff, bias, bias._version
-    v = _cached(("phase", c0), w, make, meta=bias)
+    v = _cached(key, w, make, meta=bias)
     if v[3] is not bias or v[4] != bias._version:               # the bias changed without the weight: repack
-        _PACK_CACHE.pop((("phase", c0), id(w)), None)
-        v = _cached(("phase", c0), w, make, meta=bias)
+        _PACK_CACHE.pop((key, id(w)), None)
+        v = _cached(key, w, make, meta=bias)
     return v[0], v[1], v[2]
 
 
@@ -1743,7 +1747,6 @@ class SegConvUp(torch.autograd.Function):
         k, cin = weight.shape[0], weight.shape[1]
         c1 = cin - c0
         dev = x0.device
-        wp_eff, wt_eff, b_eff = pack_phase_weight(weight, c0, bias)
         z1 = wt1 = wt_full = None
         # Per-layer choice of form (measured, tools/bench_seg.py): the forward runs full-resolution when the skip operand is so narrow that its
         # own conv would be mostly K padding (decoder.5: 24 channels); the data gradient w.r.t. x0 runs full-resolution when the padded
@@ -1751,6 +1754,7 @@ class SegConvUp(torch.autograd.Function):
         fwd_phase = (c1 == 0 or c1 >= 32) if SEG_FWD_PHASE is None else SEG_FWD_PHASE
         tiles = n * ((h + 2 + 15) // 16) * ((w + 2 + 15) // 16) * ((c0 + 127) // 128)
         ctx.dgrad_phase = (tiles >= 448) if SEG_DGRAD_PHASE is None else SEG_DGRAD_PHASE
+        wp_eff, wt_eff, b_eff = pack_phase_weight(weight, c0, bias, want_wt=ctx.dgrad_phase)
         if c1 and (fwd_phase or ctx.dgrad_phase):
             wp1, wt1 = pack_conv_weight_slice(weight, c0, c1)
         if not fwd_phase or not ctx.dgrad_phase:
