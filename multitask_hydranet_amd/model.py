@@ -510,9 +510,11 @@ class HydraNet(nn.Module):
             # the loss may hand its gradient over in this node's operand form (no fp32 dlogits tensor): see _seg_loss
             slot = K.GradSlot() if (x.requires_grad and self.training) else None
             y = K.SegOutUp.apply(x, P[f"{p}{last}.conv.weight"], P[f"{p}{last}.conv.bias"], fuse, slot)
-            self._seg_grad_slot = (slot, y.data_ptr(), tuple(y.shape)) if slot is not None else None
-        else:
-            y = K.SegConv.apply(x, None, P[f"{p}{last}.conv.weight"], P[f"{p}{last}.conv.bias"], 1, ACT_NONE, True, fuse, False)
+            out = y.permute(0, 3, 1, 2)
+            # identified by the returned tensor OBJECT (weak reference): an address + shape match can be a recycled allocation
+            self._seg_grad_slot = (slot, weakref.ref(out)) if slot is not None else None
+            return out
+        y = K.SegConv.apply(x, None, P[f"{p}{last}.conv.weight"], P[f"{p}{last}.conv.bias"], 1, ACT_NONE, True, fuse, False)
         return y.permute(0, 3, 1, 2)
 
     def anchors_for(self, h, w, device):
@@ -706,8 +708,10 @@ class HydraNet(nn.Module):
             return L.seg_loss(logits, target.long(), self._seg_class_weight, use_top_k, ratio, use_focal)
         slot = None
         key = getattr(self, "_seg_grad_slot", None)
-        if key is not None and logits.data_ptr() == key[1] and tuple(logits.permute(0, 2, 3, 1).shape) == key[2]:
-            slot, self._seg_grad_slot = key[0], None                  # this forward's own "seg" output, consumed once
+        if key is not None:
+            self._seg_grad_slot = None                                # consumed (or dropped) by the first loss call after the forward
+            if key[1]() is logits:
+                slot = key[0]                                         # this forward's own "seg" output
         return K.seg_loss_hip(logits, target, self._seg_class_weight, use_top_k, ratio, slot=slot)      # no CPU fallback: raises off-device
 
     def _guard(self, value, what, allow_zero=False):
