@@ -1000,6 +1000,8 @@ struct GemmTN {
     int gy;           // number of cout tiles
     int phase_span;   // patch wgrad of a phase-form conv (see GemmNT::phase_mode): couts per phase; the cout tile's phase only has
                       // non-zero effective weights on 4 of the 9 taps, the other five are skipped (their slab entries stay zero)
+    float* bias_part; // patch wgrad only (optional): [slabs][Nout] per-slab column sums of dZ (= the conv's bias gradient), accumulated by
+                      // one extra MFMA per k-step against an all-ones operand while the dZ fragments are in registers anyway
 };
 
 // LDS image of a pixel-major tile: rows of COLS bf16, UNPADDED (LDS-DMA writes lane-linear 1 KiB runs), 16-byte pieces XOR-swizzled so
@@ -1224,6 +1226,15 @@ __global__ __launch_bounds__(512) void wgrad3x3_patch_kernel(const GemmTN p, int
     for (int i = 0; i < TC; ++i)
 #pragma unroll
         for (int t = 0; t < 9; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // bias gradient: the first input-channel tile's wn == 0 waves also multiply their dZ fragments with ones (every output column of
+    // that MFMA is the fragment's pixel sum)
+    const bool do_bias = p.bias_part && bx == 0 && wn == 0;
+    f32x4 accb[TC];
+#pragma unroll
+    for (int i = 0; i < TC; ++i) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ones[k] = (bf16)1.0f;
     unsigned tapmask = 0x1ffu;
     if (p.phase_span) {
         const int ph = c_blk / p.phase_span, py = ph >> 1, px = ph & 1;
@@ -1292,6 +1303,10 @@ __global__ __launch_bounds__(512) void wgrad3x3_patch_kernel(const GemmTN p, int
                     const trv4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(sZ + rhi * (BC * 2) + tn_swz<BC>(rhi, piece) * 16 + (pp & 1) * 8));
                     a[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
+                if (do_bias) {
+#pragma unroll
+                    for (int i = 0; i < TC; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], ones, accb[i], 0, 0, 0);
+                }
                 const int bpiece = (wn * 16) / 8 + (pp >> 1);
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
@@ -1309,6 +1324,16 @@ __global__ __launch_bounds__(512) void wgrad3x3_patch_kernel(const GemmTN p, int
     }
     const int Ktot = 9 * p.KP;
     float* part = p.part + ((long)bz * KSPLIT + wk) * p.Nout * Ktot;       // each k-split wave group owns its own partial slab
+    if (do_bias && (lane & 15) == 0) {
+        float* bp = p.bias_part + ((long)bz * KSPLIT + wk) * p.Nout;
+#pragma unroll
+        for (int i = 0; i < TC; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = c_blk + wc * WCO + i * 16 + (lane >> 4) * 4 + r;
+                if (co < p.Nout) bp[co] = accb[i][r];
+            }
+    }
     const int ci = ci_out0 + wn * 16 + (lane & 15);
     if (ci < p.KP) {
 #pragma unroll
@@ -1323,9 +1348,30 @@ __global__ __launch_bounds__(512) void wgrad3x3_patch_kernel(const GemmTN p, int
     }
 }
 
+// dbias[co] = sum over the slabs of bias_part[slab][co]: done by the first ceil(Nout / 64) workgroups of whichever reduce kernel follows
+// the patch wgrad (64 channels x nthreads / 64 slab lanes, fixed-order LDS fold), before their own columns
+__device__ __forceinline__ void reduce_bias_cols(const float* bp, float* db, int slabs, int Nout, int blk, int nthreads) {
+    __shared__ float rb[8][64];
+    if (!bp || blk * 64 >= Nout) return;                              // workgroup-uniform
+    const int c = blk * 64 + (threadIdx.x & 63), l = threadIdx.x >> 6, nl = nthreads >> 6;
+    float s = 0.f;
+    if (c < Nout)
+        for (int k = l; k < slabs; k += nl) s += bp[(long)k * Nout + c];
+    rb[l][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (l == 0 && c < Nout) {
+        float t = 0.f;
+        for (int k = 0; k < nl; ++k) t += rb[k][threadIdx.x & 63];
+        db[c] = t;
+    }
+    __syncthreads();
+}
+
 // dW[co][ci][tap] (PyTorch [Cout][Cin][kh][kw] order) = sum_split part[split][co][tap*KP + ci].
 // block = 32 consecutive partial columns x 16 split lanes: coalesced rows, LDS tree over the lanes.
-__global__ __launch_bounds__(512) void wgrad_reduce_kernel(const float* part, float* dw, int splits, int Nout, int Cin, int KP, int taps) {
+__global__ __launch_bounds__(512) void wgrad_reduce_kernel(const float* part, float* dw, int splits, int Nout, int Cin, int KP, int taps,
+                                                            const float* bias_part = nullptr, float* dbias = nullptr) {
+    reduce_bias_cols(bias_part, dbias, splits, Nout, blockIdx.x, 512);
     __shared__ float red[16][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const long Ktot = (long)taps * KP;
@@ -1359,7 +1405,9 @@ __global__ __launch_bounds__(512) void wgrad_reduce_kernel(const float* part, fl
 }
 
 // few splits, many columns (the wide deep layers): thread = 4 consecutive columns, float4 loads, splits walked serially
-__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* part, float* dw, int splits, int Nout, int Cin, int KP, int taps) {
+__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* part, float* dw, int splits, int Nout, int Cin, int KP, int taps,
+                                                             const float* bias_part = nullptr, float* dbias = nullptr) {
+    reduce_bias_cols(bias_part, dbias, splits, Nout, blockIdx.x, 256);
     const long Ktot = (long)taps * KP;
     const long cols = (long)Nout * Ktot;
     const long col = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -1380,7 +1428,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* part, f
 // transposition straight from registers is a 4-byte store every 36 bytes: the 2048 x 512 x 9 phase-form gradient of decoder.1 (37.7 MB)
 // cost 375 MB of WRITE_SIZE and 100 us.  One workgroup = one cout x 64 input channels x 9 taps: coalesced partial reads per tap, the
 // [64][9] result tile is turned in LDS and leaves as contiguous float4 runs.
-__global__ __launch_bounds__(256) void wgrad_reduce9_kernel(const float* part, float* dw, int splits, int Nout, int Cin, int KP) {
+__global__ __launch_bounds__(256) void wgrad_reduce9_kernel(const float* part, float* dw, int splits, int Nout, int Cin, int KP,
+                                                             const float* bias_part = nullptr, float* dbias = nullptr) {
+    reduce_bias_cols(bias_part, dbias, splits, Nout, blockIdx.y * gridDim.x + blockIdx.x, 256);
     // 64 input channels x 4 split lanes per workgroup (the splits are walked four at a time per lane: 36 loads in flight)
     __shared__ float tile[4][64 * 9 + 4];
     const long Ktot = 9L * KP, cols = (long)Nout * Ktot;
@@ -2066,7 +2116,7 @@ static int wgrad_plan_impl(int mode, int n_img, int H, int W, long M, int Nout, 
         const long pps = (patches + want - 1) / want;
         *splits = (int)((patches + pps - 1) / pps) * ksplit;       // number of partial slabs
         *rows_per_split = pps;
-        *ws_bytes = (long)(*splits) * Nout * taps * KP * 4;
+        *ws_bytes = (long)(*splits) * Nout * taps * KP * 4 + (long)(*splits) * Nout * 4;     // + the bias-gradient partial rows
         return HN_OK;
     }
     int bc, bn;
@@ -2086,23 +2136,33 @@ static int wgrad_plan_impl(int mode, int n_img, int H, int W, long M, int Nout, 
 
 static int conv_gemm_tn_impl(const void* x0, const void* x1, int mode, int n_img, int H, int W, int C0, int C1, int ld0, int ld1,
                              int up, long M, const void* dz, int ldz, int Nout, int KP, int taps, int phase_span, float* workspace, float* dw,
-                             hipStream_t st);
+                             float* dbias, hipStream_t st);
 extern "C" int hn_conv_gemm_tn(const void* x0, const void* x1, int mode, int n_img, int H, int W, int C0, int C1, int ld0, int ld1,
                                int up, long M, const void* dz, int ldz, int Nout, int KP, int taps, float* workspace, float* dw,
                                hipStream_t st) {
-    return conv_gemm_tn_impl(x0, x1, mode, n_img, H, W, C0, C1, ld0, ld1, up, M, dz, ldz, Nout, KP, taps, 0, workspace, dw, st);
+    return conv_gemm_tn_impl(x0, x1, mode, n_img, H, W, C0, C1, ld0, ld1, up, M, dz, ldz, Nout, KP, taps, 0, workspace, dw, nullptr, st);
+}
+/* hn_conv_gemm_tn of a 3x3 conv (modes 2 / 4, KP >= 32: the patch kernel) that also returns the conv's bias gradient dbias [Nout] = column
+ * sums of dz -- accumulated by one extra MFMA per k-step while the dz fragments are in registers, reduced by the launch that reduces the
+ * weight-gradient slabs: no column-statistics pass over dz, no extra reduce launches. */
+extern "C" int hn_conv_gemm_tn_bias(const void* x0, const void* x1, int mode, int n_img, int H, int W, int C0, int C1, int ld0, int ld1,
+                                    int up, long M, const void* dz, int ldz, int Nout, int KP, int taps, float* workspace, float* dw,
+                                    float* dbias, hipStream_t st) {
+    HN_CHECK_ARG(dbias);
+    return conv_gemm_tn_impl(x0, x1, mode, n_img, H, W, C0, C1, ld0, ld1, up, M, dz, ldz, Nout, KP, taps, 0, workspace, dw, dbias, st);
 }
 /* weight gradient of the phase-form conv (hn_conv3x3_phase mode 4): x0 = low-resolution input [N][H][W][C0], dz = space-to-depth output
  * gradient [N][H][W][Nout = 4*k] (hn_space_to_depth_bf16), dw = gradient of the EFFECTIVE weights fp32 [4*k][C0][3][3] (zeros at the
  * five taps a phase does not use).  workspace from hn_wgrad_plan_phase. */
 extern "C" int hn_conv_gemm_tn_phase(const void* x0, int n_img, int H, int W, int C0, int ld0, const void* dz, int ldz, int Nout, int KP,
-                                     int phase_span, float* workspace, float* dw, hipStream_t st) {
+                                     int phase_span, float* workspace, float* dw, float* dbias_eff, hipStream_t st) {
     HN_CHECK_ARG(phase_span >= 64 && phase_span % 64 == 0 && Nout == 4 * phase_span && KP >= 64);
-    return conv_gemm_tn_impl(x0, nullptr, 4, n_img, H, W, C0, 0, ld0, 0, 0, (long)n_img * H * W, dz, ldz, Nout, KP, 9, phase_span, workspace, dw, st);
+    return conv_gemm_tn_impl(x0, nullptr, 4, n_img, H, W, C0, 0, ld0, 0, 0, (long)n_img * H * W, dz, ldz, Nout, KP, 9, phase_span, workspace, dw,
+                             dbias_eff, st);
 }
 static int conv_gemm_tn_impl(const void* x0, const void* x1, int mode, int n_img, int H, int W, int C0, int C1, int ld0, int ld1,
                              int up, long M, const void* dz, int ldz, int Nout, int KP, int taps, int phase_span, float* workspace, float* dw,
-                             hipStream_t st) {
+                             float* dbias, hipStream_t st) {
     HN_CHECK_ARG(x0 && dz && workspace && dw && M > 0 && (KP & 31) == 0 && (ldz & 7) == 0 && ldz >= ((Nout + 7) & ~7));
     HN_CHECK_ARG((C0 & 7) == 0 && (C1 & 7) == 0 && (ld0 & 7) == 0 && ((mode >= 0 && mode <= 2) || ((mode == 4 || mode == 5) && up == 0 && C1 == 0)));
     HN_CHECK_ARG(mode != 5 || (KP == 64 && Nout == C0 && taps == 9));
@@ -2115,8 +2175,11 @@ static int conv_gemm_tn_impl(const void* x0, const void* x1, int mode, int n_img
     mode = p.x.mode;
     p.dz = (const bf16*)dz; p.ldz = ldz; p.Nout = Nout; p.KP = KP; p.taps = taps;
     p.part = workspace; p.rows_per_split = rps; p.phase_span = phase_span;
+    p.bias_part = nullptr;
     int bc, bn, rc;
+    if (dbias && (!use_patch_wgrad(mode, Nout, KP) || grouped)) return HN_ERR_UNSUPPORTED;
     if (use_patch_wgrad(mode, Nout, KP)) {
+        if (dbias) p.bias_part = workspace + (long)splits * Nout * taps * KP;
         static std::atomic<unsigned long long> optin{0};
         if (!lds_optin(optin, {(const void*)wgrad3x3_patch_kernel<128, 64>, (const void*)wgrad3x3_patch_kernel<64, 128>,
                                (const void*)wgrad3x3_patch_kernel<16, 64>, (const void*)wgrad3x3_patch_kernel<64, 64>,
@@ -2142,11 +2205,14 @@ static int conv_gemm_tn_impl(const void* x0, const void* x1, int mode, int n_img
         if (grouped)
             hipLaunchKernelGGL(gconv_diag_extract_kernel, dim3(cdiv(Nout * 72, 256)), dim3(256), 0, st, workspace, dw, splits, Nout);
         else if (taps == 9 && splits <= 64)
-            hipLaunchKernelGGL(wgrad_reduce9_kernel, dim3(cdiv(C0 + C1, 64), Nout), dim3(256), 0, st, workspace, dw, splits, Nout, C0 + C1, KP);
+            hipLaunchKernelGGL(wgrad_reduce9_kernel, dim3(cdiv(C0 + C1, 64), Nout), dim3(256), 0, st, workspace, dw, splits, Nout, C0 + C1, KP,
+                               p.bias_part, dbias);
         else if (splits <= 128 && cols >= 65536)
-            hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(cdiv(cols / 4, 256)), dim3(256), 0, st, workspace, dw, splits, Nout, C0 + C1, KP, taps);
+            hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(cdiv(cols / 4, 256)), dim3(256), 0, st, workspace, dw, splits, Nout, C0 + C1, KP, taps,
+                               p.bias_part, dbias);
         else
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(cols, 32)), dim3(512), 0, st, workspace, dw, splits, Nout, C0 + C1, KP, taps);
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(cols, 32)), dim3(512), 0, st, workspace, dw, splits, Nout, C0 + C1, KP, taps,
+                               p.bias_part, dbias);
         HN_LAUNCH_CHECK();
     }
     tn_tiles(Nout, KP, bc, bn);

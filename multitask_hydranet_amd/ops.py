@@ -325,8 +325,13 @@ def k_gemm_nt(x0, x1, mode, grid, wp, nout, kp, taps, bias=None, act=ACT_NONE, o
     return out, psum, psq
 
 
-def k_gemm_tn(x0, x1, mode, grid, dz, nout, kp, taps, cin, up=0, kh=1):
-    """weight gradient, returns fp32 [nout, cin, kh, kh]."""
+def wgrad_bias_ok(mode, kp):
+    """3x3 weight gradients that go through the patch kernel can return the conv's bias gradient (column sums of dz) from the same pass"""
+    return mode in (2, 4) and kp >= 32
+
+
+def k_gemm_tn(x0, x1, mode, grid, dz, nout, kp, taps, cin, up=0, kh=1, want_bias=False):
+    """weight gradient, returns fp32 [nout, cin, kh, kh] (want_bias: and the bias gradient [nout] out of the same launches)."""
     n, h, w = grid
     m = n * h * w
     dev = x0.device
@@ -337,6 +342,11 @@ def k_gemm_tn(x0, x1, mode, grid, dz, nout, kp, taps, cin, up=0, kh=1):
     c0 = x0.shape[3]
     c1 = x1.shape[3] if x1 is not None else 0
     ldz = dz.stride(2) if dz.dim() == 4 else dz.stride(0)
+    if want_bias:
+        db = torch.empty((nout,), device=dev, dtype=F32)
+        lib().call("hn_conv_gemm_tn_bias", ptr(x0), ptr(x1), mode, n, h, w, c0, c1, ld(x0), ld(x1) if x1 is not None else 0, up, m,
+                   ptr(dz), ldz, nout, kp, taps, ptr(ws), ptr(dw), ptr(db))
+        return dw, db
     lib().call("hn_conv_gemm_tn", ptr(x0), ptr(x1), mode, n, h, w, c0, c1, ld(x0), ld(x1) if x1 is not None else 0, up, m,
                ptr(dz), ldz, nout, kp, taps, ptr(ws), ptr(dw))
     return dw
@@ -1147,12 +1157,15 @@ class SegConv(torch.autograd.Function):
         else:
             dy = dense(dy)
             dz = k_eltwise(1, dy, y, act=ACT_ELU) if (ctx.act == ACT_ELU and not ctx.dy_is_dz) else dy
-        # bias gradient: per-channel sum of dz
-        ps, _, r = k_col_stats(dz)
-        dbias = k_rows_reduce(ps, 1, ps.shape[0], dz.shape[3]).view(-1)
-        if dbias.numel() != cout:
-            dbias = dbias[:cout] + 0.0                               # owning copy by a kernel (a clone would be a memcpy node in the graph)
-        dw = k_gemm_tn(x0, x1, 2, (n, h, w), dz, cout, kp32(cin), 9, cin, up=up, kh=3)
+        # bias gradient (per-channel sum of dz): out of the weight-gradient launches
+        if wgrad_bias_ok(2, kp32(cin)):
+            dw, dbias = k_gemm_tn(x0, x1, 2, (n, h, w), dz, cout, kp32(cin), 9, cin, up=up, kh=3, want_bias=True)
+        else:
+            ps, _, r = k_col_stats(dz)
+            dbias = k_rows_reduce(ps, 1, ps.shape[0], dz.shape[3]).view(-1)
+            if dbias.numel() != cout:
+                dbias = dbias[:cout] + 0.0                           # owning copy by a kernel (a clone would be a memcpy node in the graph)
+            dw = k_gemm_tn(x0, x1, 2, (n, h, w), dz, cout, kp32(cin), 9, cin, up=up, kh=3)
         # data gradient on the padded (H+2)x(W+2) grid, then fold the reflection / up-sampling / concat back
         dx0 = dx1 = None
         if not up and not ctx.has_x1 and dgrad_fold_ok(c0, h, w, n):
@@ -1699,9 +1712,12 @@ class SegOutUp(torch.autograd.Function):
             dz = d2 if dz is None else k_eltwise(0, dz, d2)
         if dz is None:
             return None, None, None, None, None
-        ps, _, _ = k_col_stats(dz)
-        db_eff = k_rows_reduce(ps, 1, ps.shape[0], ldz)
-        dw_eff = k_gemm_tn(x, None, 4, (n, h, w), dz, 4 * k, kp32(c), 9, c, kh=3)                       # [4k, c, 3, 3]
+        if wgrad_bias_ok(4, kp32(c)):
+            dw_eff, db_eff = k_gemm_tn(x, None, 4, (n, h, w), dz, 4 * k, kp32(c), 9, c, kh=3, want_bias=True)       # [4k, c, 3, 3], [4k]
+        else:
+            ps, _, _ = k_col_stats(dz)
+            db_eff = k_rows_reduce(ps, 1, ps.shape[0], ldz)
+            dw_eff = k_gemm_tn(x, None, 4, (n, h, w), dz, 4 * k, kp32(c), 9, c, kh=3)
         dw = torch.empty((k, c, 3, 3), device=dev, dtype=F32)
         dbias = torch.empty((k,), device=dev, dtype=F32)
         lib().call("hn_phase_fold", ptr(dw_eff), None, ptr(db_eff), ptr(dw), ptr(dbias), k, c, 0)
@@ -1782,23 +1798,17 @@ class SegConvUp(torch.autograd.Function):
         dev = x0.device
         dy = dense(dy)
         dz = dy if ctx.dy_is_dz else k_eltwise(1, dy, y, act=ACT_ELU)
-        # space-to-depth gradient: the operand of both low-resolution contractions; the bias gradient (channel sums of dz) comes out of
-        # the same pass as per-block partial rows
+        # space-to-depth gradient: the operand of both low-resolution contractions
         dzs = new_act(n, h, w, 4 * k, dev)
-        if 256 % (k // 2) == 0:
-            pb = lib().query("hn_space_to_depth_blocks", n, h, w, k)
-            ps = torch.empty((pb, k), device=dev, dtype=F32)
-            lib().call("hn_space_to_depth_bf16", ptr(dz), ld(dz), ptr(dzs), n, h, w, k, ptr(ps))
-        else:
-            ps, _, _ = k_col_stats(dz)
-            lib().call("hn_space_to_depth_bf16", ptr(dz), ld(dz), ptr(dzs), n, h, w, k, None)
-        dbias = k_rows_reduce(ps, 1, ps.shape[0], k).view(-1)
-        # effective-weight gradient (zeros at the taps a phase does not use), mapped back to the 3x3 weights by the phase matrix
+        lib().call("hn_space_to_depth_bf16", ptr(dz), ld(dz), ptr(dzs), n, h, w, k, None)
+        # effective-weight gradient (zeros at the taps a phase does not use), mapped back to the 3x3 weights by the phase matrix; the bias
+        # gradient (channel sums of dz, per phase) comes out of the same launches
         splits, rps, wsb = ctypes.c_int(), ctypes.c_long(), ctypes.c_long()
         lib().query("hn_wgrad_plan_phase", n, h, w, 4 * k, kp32(c0), k, ctypes.addressof(splits), ctypes.addressof(rps), ctypes.addressof(wsb))
         ws = torch.empty((wsb.value // 4,), device=dev, dtype=F32)
         dw_eff = torch.empty((4 * k, c0, 3, 3), device=dev, dtype=F32)
-        lib().call("hn_conv_gemm_tn_phase", ptr(x0), n, h, w, c0, ld(x0), ptr(dzs), ld(dzs), 4 * k, kp32(c0), k, ptr(ws), ptr(dw_eff))
+        db_eff = torch.empty((4 * k,), device=dev, dtype=F32)
+        lib().call("hn_conv_gemm_tn_phase", ptr(x0), n, h, w, c0, ld(x0), ptr(dzs), ld(dzs), 4 * k, kp32(c0), k, ptr(ws), ptr(dw_eff), ptr(db_eff))
         dx0 = dx1 = None
         if not ctx.dgrad_phase:
             # full-resolution data gradient for both operands at once (padded (2h+2) x (2w+2) grid), folded back per operand
@@ -1828,7 +1838,8 @@ class SegConvUp(torch.autograd.Function):
                 lib().call("hn_seg_fold", ptr(dvp1), ld(dvp1), 0, ptr(dx1), ld(dx1), None, 0, n, 2 * h, 2 * w, c1, 0)
         # effective-weight gradient mapped back to the 3x3 taps (the transpose of the phase map), joined with the skip operand's part
         dw = torch.empty((k, c0 + c1, 3, 3), device=dev, dtype=F32)
-        lib().call("hn_phase_fold", ptr(dw_eff), ptr(dw1), None, ptr(dw), None, k, c0, c1)
+        dbias = torch.empty((k,), device=dev, dtype=F32)
+        lib().call("hn_phase_fold", ptr(dw_eff), ptr(dw1), ptr(db_eff), ptr(dw), ptr(dbias), k, c0, c1)
         return dx0, dx1, dw, dbias, None, None
 
 
