@@ -219,9 +219,9 @@ int hn_conv3x3_out_argmax(const void* x0, int n_img, int H, int W, int C0, int l
 int hn_wgrad_plan_phase(int n_img, int H, int W, int Nout, int KP, int phase_span, int* splits, long* rows_per_split, long* ws_bytes);
 int hn_conv_gemm_tn_phase(const void* x0, int n_img, int H, int W, int C0, int ld0, const void* dz, int ldz, int Nout, int KP, int phase_span,
                           float* workspace, float* dw, float* dbias_eff, hipStream_t stream);
-/* hn_conv_gemm_tn of a 3x3 conv (modes 2 / 4 with KP >= 32: the patch kernel; otherwise HN_ERR_UNSUPPORTED) that also returns the conv's bias
- * gradient dbias [Nout] = column sums of dz (ConvBlock / Conv3x3 bias, head_seg/segmentation.py:40-58): one extra MFMA per k-step against an
- * all-ones operand while the dz fragments are in registers; the launch that reduces the weight-gradient slabs reduces the bias partials.
+/* hn_conv_gemm_tn (any mode but the grouped mode 5) that also returns the conv's bias gradient dbias [Nout] = column sums of dz (ConvBlock /
+ * Conv3x3 bias, head_seg/segmentation.py:40-58; head output convs): one extra MFMA per k-step against an all-ones operand while the dz
+ * fragments are in registers; the launch that reduces the weight-gradient slabs reduces the bias partials.
  * (dbias_eff of hn_conv_gemm_tn_phase: the same for the 4 k effective outputs, optional.) */
 int hn_conv_gemm_tn_bias(const void* x0, const void* x1, int mode, int n_img, int H, int W, int C0, int C1, int ld0, int ld1, int up, long M,
                          const void* dz, int ldz, int Nout, int KP, int taps, float* workspace, float* dw, float* dbias, hipStream_t stream);

@@ -1040,6 +1040,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {   // 
     for (int i = 0; i < TC; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // bias gradient (column sums of dZ): the (tap 0, first ci tile) workgroup's wn == 0 waves multiply their dZ fragments with ones
+    const bool do_bias = p.bias_part && bx == 0 && wn == 0;
+    f32x4 accb[TC];
+#pragma unroll
+    for (int i = 0; i < TC; ++i) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ones[k] = (bf16)1.0f;
 
     // per-piece pixel coordinates, advanced by 64 rows per stage without divisions
     int pn[XL], py[XL], px[XL];
@@ -1169,8 +1177,22 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {   // 
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                if (do_bias) {
+#pragma unroll
+                    for (int i = 0; i < TC; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], ones, accb[i], 0, 0, 0);
+                }
             }
         }
+    }
+    if (do_bias && (lane & 15) == 0) {
+        float* bp = p.bias_part + (long)bz * p.Nout;
+#pragma unroll
+        for (int i = 0; i < TC; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = c_blk + wc * WC + i * 16 + (lane >> 4) * 4 + r;
+                if (co < p.Nout) bp[co] = accb[i][r];
+            }
     }
     const int Ktot = p.taps * p.KP;
     float* part = p.part + (long)bz * p.Nout * Ktot;
@@ -2130,7 +2152,7 @@ static int wgrad_plan_impl(int mode, int n_img, int H, int W, long M, int Nout, 
     long rps = ((M + want - 1) / want + 63) / 64 * 64;
     *splits = (int)((M + rps - 1) / rps);
     *rows_per_split = rps;
-    *ws_bytes = (long)(*splits) * Nout * taps * KP * 4;
+    *ws_bytes = (long)(*splits) * Nout * taps * KP * 4 + (long)(*splits) * Nout * 4;         // + the bias-gradient partial rows
     return HN_OK;
 }
 
@@ -2142,9 +2164,9 @@ extern "C" int hn_conv_gemm_tn(const void* x0, const void* x1, int mode, int n_i
                                hipStream_t st) {
     return conv_gemm_tn_impl(x0, x1, mode, n_img, H, W, C0, C1, ld0, ld1, up, M, dz, ldz, Nout, KP, taps, 0, workspace, dw, nullptr, st);
 }
-/* hn_conv_gemm_tn of a 3x3 conv (modes 2 / 4, KP >= 32: the patch kernel) that also returns the conv's bias gradient dbias [Nout] = column
- * sums of dz -- accumulated by one extra MFMA per k-step while the dz fragments are in registers, reduced by the launch that reduces the
- * weight-gradient slabs: no column-statistics pass over dz, no extra reduce launches. */
+/* hn_conv_gemm_tn that also returns the conv's bias gradient dbias [Nout] = column sums of dz -- accumulated by one extra MFMA per k-step
+ * while the dz fragments are in registers, reduced by the launch that reduces the weight-gradient slabs: no column-statistics pass over
+ * dz, no extra reduce launches (not for the grouped mode 5). */
 extern "C" int hn_conv_gemm_tn_bias(const void* x0, const void* x1, int mode, int n_img, int H, int W, int C0, int C1, int ld0, int ld1,
                                     int up, long M, const void* dz, int ldz, int Nout, int KP, int taps, float* workspace, float* dw,
                                     float* dbias, hipStream_t st) {
@@ -2177,9 +2199,9 @@ static int conv_gemm_tn_impl(const void* x0, const void* x1, int mode, int n_img
     p.part = workspace; p.rows_per_split = rps; p.phase_span = phase_span;
     p.bias_part = nullptr;
     int bc, bn, rc;
-    if (dbias && (!use_patch_wgrad(mode, Nout, KP) || grouped)) return HN_ERR_UNSUPPORTED;
+    if (dbias && grouped) return HN_ERR_UNSUPPORTED;
+    if (dbias) p.bias_part = workspace + (long)splits * Nout * taps * KP;
     if (use_patch_wgrad(mode, Nout, KP)) {
-        if (dbias) p.bias_part = workspace + (long)splits * Nout * taps * KP;
         static std::atomic<unsigned long long> optin{0};
         if (!lds_optin(optin, {(const void*)wgrad3x3_patch_kernel<128, 64>, (const void*)wgrad3x3_patch_kernel<64, 128>,
                                (const void*)wgrad3x3_patch_kernel<16, 64>, (const void*)wgrad3x3_patch_kernel<64, 64>,
@@ -2226,9 +2248,11 @@ static int conv_gemm_tn_impl(const void* x0, const void* x1, int mode, int n_img
     if (rc != HN_OK) return rc;
     const long cols = (long)Nout * taps * KP;
     if (splits <= 128 && cols >= 65536)
-        hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(cdiv(cols / 4, 256)), dim3(256), 0, st, workspace, dw, splits, Nout, C0 + C1, KP, taps);
+        hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(cdiv(cols / 4, 256)), dim3(256), 0, st, workspace, dw, splits, Nout, C0 + C1, KP, taps,
+                           p.bias_part, dbias);
     else
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(cols, 32)), dim3(512), 0, st, workspace, dw, splits, Nout, C0 + C1, KP, taps);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(cols, 32)), dim3(512), 0, st, workspace, dw, splits, Nout, C0 + C1, KP, taps,
+                           p.bias_part, dbias);
     HN_LAUNCH_CHECK();
 }
 

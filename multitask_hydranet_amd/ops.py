@@ -326,8 +326,8 @@ def k_gemm_nt(x0, x1, mode, grid, wp, nout, kp, taps, bias=None, act=ACT_NONE, o
 
 
 def wgrad_bias_ok(mode, kp):
-    """3x3 weight gradients that go through the patch kernel can return the conv's bias gradient (column sums of dz) from the same pass"""
-    return mode in (2, 4) and kp >= 32
+    """weight-gradient launches that can return the conv's bias gradient (column sums of dz) from the same pass: all but the grouped mode"""
+    return mode != 5
 
 
 def k_gemm_tn(x0, x1, mode, grid, dz, nout, kp, taps, cin, up=0, kh=1, want_bias=False):
@@ -1237,9 +1237,9 @@ class HeadOut(torch.autograd.Function):
             base = off * ldc + ch_off
             lib().call("hn_head_grad", ptr(dout.view(-1)[base:]), ptr(yout.view(-1)[base:]) if yout is not None else None, h * w, img_stride,
                        ldc, cout, ptr(dz), ldz, m, 1 if act == ACT_SIGMOID else 0)
-            ps, _, _ = k_col_stats(dz)
-            dbias = acc(dbias, k_rows_reduce(ps, 1, ps.shape[0], ldz).view(-1)[:cout])
-            dpw = acc(dpw, k_gemm_tn(mid, None, 0, (n, h, w), dz, cout, kp32(cin), 1, cin))
+            dpw_l, db_l = k_gemm_tn(mid, None, 0, (n, h, w), dz, cout, kp32(cin), 1, cin, want_bias=True)
+            dbias = acc(dbias, db_l)
+            dpw = acc(dpw, dpw_l)
             dmid, _, _ = k_gemm_nt(dz, None, 0, (n, h, w), ctx.wt, cin, kp32(cout), 1, c0=ldz, c1=0)
             if has_dw:
                 df, dwl = k_dwconv_bwd(dmid, f, pack_dw_weight(dw_weight)[1])
@@ -1286,9 +1286,7 @@ class HeadOutCat(torch.autograd.Function):
             ldz = pad8(cout)
             dz = new_act(n, h, w, ldz, dev)
             lib().call("hn_head_grad", ptr(dout.view(-1)[off:]), None, h * w, h * w * ldc, ldc, cout, ptr(dz), ldz, n * h * w, 0)
-            ps, _, _ = k_col_stats(dz)
-            dbias = k_rows_reduce(ps, 1, ps.shape[0], ldz).view(-1)[:cout]
-            dwgt = k_gemm_tn(t, None, 0, (n, h, w), dz, cout, kp32(cin), 1, cin)
+            dwgt, dbias = k_gemm_tn(t, None, 0, (n, h, w), dz, cout, kp32(cin), 1, cin, want_bias=True)
             dt, _, _ = k_gemm_nt(dz, None, 0, (n, h, w), wt, cin, kp32(cout), 1, c0=ldz, c1=0)
             res.append((dwgt, dbias, dt))
         return res[0][0], res[0][1], res[1][0], res[1][1], res[0][2], res[1][2]
@@ -1644,9 +1642,7 @@ class HeadOutPacked(torch.autograd.Function):
             lib().call("hn_head_grad", ptr(dout.view(-1)[base:]), ptr(yout.view(-1)[base:]) if yout is not None else None, h * w, img_stride,
                        ldc, cout, ptr(v), ldz, n * h * w, 1 if act == ACT_SIGMOID else 0)
             off += h * w
-        ps, _, _ = k_col_stats(dz)
-        dbias = k_rows_reduce(ps, 1, ps.shape[0], ldz).view(-1)[:cout]
-        dpw = k_gemm_tn(mid, None, 0, (1, 1, total), dz, cout, kp32(cin), 1, cin)
+        dpw, dbias = k_gemm_tn(mid, None, 0, (1, 1, total), dz, cout, kp32(cin), 1, cin, want_bias=True)
         dmid, _, _ = k_gemm_nt(dz, None, 0, (1, 1, total), wt, cin, kp32(cout), 1, c0=ldz, c1=0)
         dx, ddw = k_dwconv_bwd(dmid, x, wf, geom)
         return ddw, dpw, dbias, None, None, None, dx
