@@ -219,6 +219,12 @@ int hn_conv3x3_out_argmax(const void* x0, int n_img, int H, int W, int C0, int l
 int hn_wgrad_plan_phase(int n_img, int H, int W, int Nout, int KP, int phase_span, int* splits, long* rows_per_split, long* ws_bytes);
 int hn_conv_gemm_tn_phase(const void* x0, int n_img, int H, int W, int C0, int ld0, const void* dz, int ldz, int Nout, int KP, int phase_span,
                           float* workspace, float* dw, float* dbias_eff, hipStream_t stream);
+/* hn_conv_gemm_tn without its slab reduce: job [8] (HOST array) receives {part, dw, splits, Nout, Cin, KP, taps, kind}; hn_wgrad_reduce_jobs
+ * reduces up to four such jobs (njobs x 8 longs, host) in ONE launch -- the weight gradients of an XBlock's conv_block_1 / 2 / 3 / shortcut
+ * (net/anynet.py:25-76) each had their own 5-7 us reduce launch.  dw is complete only after hn_wgrad_reduce_jobs. */
+int hn_conv_gemm_tn_deferred(const void* x0, const void* x1, int mode, int n_img, int H, int W, int C0, int C1, int ld0, int ld1, int up, long M,
+                             const void* dz, int ldz, int Nout, int KP, int taps, float* workspace, float* dw, long* job, hipStream_t stream);
+int hn_wgrad_reduce_jobs(const long* jobs, int njobs, hipStream_t stream);
 /* hn_conv_gemm_tn (any mode but the grouped mode 5) that also returns the conv's bias gradient dbias [Nout] = column sums of dz (ConvBlock /
  * Conv3x3 bias, head_seg/segmentation.py:40-58; head output convs): one extra MFMA per k-step against an all-ones operand while the dz
  * fragments are in registers; the launch that reduces the weight-gradient slabs reduces the bias partials.

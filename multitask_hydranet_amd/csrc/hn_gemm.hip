@@ -1427,12 +1427,10 @@ __global__ __launch_bounds__(512) void wgrad_reduce_kernel(const float* part, fl
 }
 
 // few splits, many columns (the wide deep layers): thread = 4 consecutive columns, float4 loads, splits walked serially
-__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* part, float* dw, int splits, int Nout, int Cin, int KP, int taps,
-                                                             const float* bias_part = nullptr, float* dbias = nullptr) {
-    reduce_bias_cols(bias_part, dbias, splits, Nout, blockIdx.x, 256);
+__device__ __forceinline__ void reduce4_body(const float* part, float* dw, int splits, int Nout, int Cin, int KP, int taps, long blk) {
     const long Ktot = (long)taps * KP;
     const long cols = (long)Nout * Ktot;
-    const long col = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    const long col = (blk * 256 + threadIdx.x) * 4;
     if (col >= cols) return;
     f32x4 s = *reinterpret_cast<const f32x4*>(part + col);
 #pragma unroll 8
@@ -1444,6 +1442,44 @@ __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* part, f
 #pragma unroll
     for (int j = 0; j < 4; ++j)
         if (ci + j < Cin) d[(long)j * taps] = s[j];
+}
+__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* part, float* dw, int splits, int Nout, int Cin, int KP, int taps,
+                                                             const float* bias_part = nullptr, float* dbias = nullptr) {
+    reduce_bias_cols(bias_part, dbias, splits, Nout, blockIdx.x, 256);
+    reduce4_body(part, dw, splits, Nout, Cin, KP, taps, blockIdx.x);
+}
+
+// many splits, few columns, 256 threads: 32 consecutive columns x 8 split lanes (four independent loads per lane and round)
+__device__ __forceinline__ void reduce_lanes_body(const float* part, float* dw, int splits, int Nout, int Cin, int KP, int taps, long blk,
+                                                  float (*red)[33]) {
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const long Ktot = (long)taps * KP;
+    const long cols = (long)Nout * Ktot;
+    const long col = blk * 32 + tx;
+    float s = 0.f;
+    if (col < cols) {
+        int k = ty;
+        float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (; k + 24 < splits; k += 32) {
+            s += part[(long)k * cols + col];
+            s1 += part[(long)(k + 8) * cols + col];
+            s2 += part[(long)(k + 16) * cols + col];
+            s3 += part[(long)(k + 24) * cols + col];
+        }
+        for (; k < splits; k += 8) s += part[(long)k * cols + col];
+        s = (s + s1) + (s2 + s3);
+    }
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && col < cols) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][tx];
+        const int co = (int)(col / Ktot);
+        const int r = (int)(col - (long)co * Ktot);
+        const int tap = r / KP, ci = r - tap * KP;
+        if (ci < Cin) dw[((long)co * Cin + ci) * taps + tap] = t;
+    }
 }
 
 // 3x3 weights: the partial slabs are [co][tap][KP] (ci contiguous), PyTorch wants [co][ci][3][3] (tap contiguous).  Writing that
@@ -1485,16 +1521,37 @@ __global__ __launch_bounds__(256) void wgrad_reduce9_kernel(const float* part, f
 }
 
 // grouped conv (group width 8) weight gradient from the block-diagonal slabs: dw[co][i][tap] = sum_split part[split][co][tap*64 + ((co&63)>>3)*8 + i]
-__global__ void gconv_diag_extract_kernel(const float* part, float* dw, int splits, int C) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= C * 72) return;
-    const int i = idx & 7, tap = (idx >> 3) % 9, co = idx / 72;       // i fastest: 8 consecutive floats of a slab row per 8 lanes
+__device__ __forceinline__ void diag_extract_body(const float* part, float* dw, int splits, int C, long blk) {
+    const long idx = blk * 256 + threadIdx.x;
+    if (idx >= (long)C * 72) return;
+    const int i = (int)(idx & 7), tap = (int)((idx >> 3) % 9), co = (int)(idx / 72);   // i fastest: 8 consecutive floats of a slab row per 8 lanes
     const long col = (long)co * 576 + tap * 64 + ((co & 63) >> 3) * 8 + i;
     const long slab = (long)C * 576;
     float s = 0.f;
 #pragma unroll 4
     for (int k = 0; k < splits; ++k) s += part[(long)k * slab + col];
     dw[((long)co * 8 + i) * 9 + tap] = s;
+}
+__global__ __launch_bounds__(256) void gconv_diag_extract_kernel(const float* part, float* dw, int splits, int C) {
+    diag_extract_body(part, dw, splits, C, blockIdx.x);
+}
+
+// The slab reduces of several weight gradients in ONE launch (an XBlock's conv_block_1 / 2 / 3 / shortcut gradients: each reduce is a
+// 5-7 us launch of mostly latency).  Jobs travel by value in the kernel arguments (no device table to fill inside a captured graph).
+//   kind 0: float4 columns (reduce4_body), 1: split lanes (reduce_lanes_body), 2: grouped-conv diagonal extract
+struct RJob { const float* part; float* dw; int splits, Nout, Cin, KP, taps, kind; long first_block; };
+struct RJobs { RJob j[4]; int n; };
+__global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const RJobs jobs) {
+    __shared__ float red[8][33];
+    int ji = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+        if (k < jobs.n && (long)blockIdx.x >= jobs.j[k].first_block) ji = k;
+    const RJob& jb = jobs.j[ji];
+    const long blk = (long)blockIdx.x - jb.first_block;
+    if (jb.kind == 0) reduce4_body(jb.part, jb.dw, jb.splits, jb.Nout, jb.Cin, jb.KP, jb.taps, blk);
+    else if (jb.kind == 1) reduce_lanes_body(jb.part, jb.dw, jb.splits, jb.Nout, jb.Cin, jb.KP, jb.taps, blk, red);
+    else diag_extract_body(jb.part, jb.dw, jb.splits, jb.Nout, blk);
 }
 // fp32 grouped weights [C][8][3][3] -> block-diagonal bf16 operands [C][9][64]: wk for the forward conv, wd for the stride-1 data
 // gradient (group-transposed, taps flipped)
@@ -2164,6 +2221,40 @@ extern "C" int hn_conv_gemm_tn(const void* x0, const void* x1, int mode, int n_i
                                hipStream_t st) {
     return conv_gemm_tn_impl(x0, x1, mode, n_img, H, W, C0, C1, ld0, ld1, up, M, dz, ldz, Nout, KP, taps, 0, workspace, dw, nullptr, st);
 }
+/* hn_conv_gemm_tn without its slab reduce: job [8] (host) receives {part, dw, splits, Nout, Cin, KP, taps, kind} for hn_wgrad_reduce_jobs,
+ * which reduces up to four such jobs in one launch (kind -1: the reduce was launched here after all -- the transposing 3x3 form). */
+static thread_local long* g_defer_job = nullptr;
+extern "C" int hn_conv_gemm_tn_deferred(const void* x0, const void* x1, int mode, int n_img, int H, int W, int C0, int C1, int ld0, int ld1,
+                                        int up, long M, const void* dz, int ldz, int Nout, int KP, int taps, float* workspace, float* dw,
+                                        long* job, hipStream_t st) {
+    HN_CHECK_ARG(job);
+    g_defer_job = job;
+    const int rc = conv_gemm_tn_impl(x0, x1, mode, n_img, H, W, C0, C1, ld0, ld1, up, M, dz, ldz, Nout, KP, taps, 0, workspace, dw, nullptr, st);
+    g_defer_job = nullptr;
+    return rc;
+}
+extern "C" int hn_wgrad_reduce_jobs(const long* jobs, int njobs, hipStream_t st) {
+    HN_CHECK_ARG(jobs && njobs >= 0 && njobs <= 4);
+    RJobs r;
+    r.n = 0;
+    long blocks = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const long* jb = jobs + 8 * i;
+        const int kind = (int)jb[7];
+        if (kind < 0) continue;
+        HN_CHECK_ARG(kind <= 2 && jb[0] && jb[1]);
+        RJob& d = r.j[r.n++];
+        d.part = reinterpret_cast<const float*>(jb[0]); d.dw = reinterpret_cast<float*>(jb[1]);
+        d.splits = (int)jb[2]; d.Nout = (int)jb[3]; d.Cin = (int)jb[4]; d.KP = (int)jb[5]; d.taps = (int)jb[6]; d.kind = kind;
+        d.first_block = blocks;
+        const long cols = (long)d.Nout * d.taps * d.KP;
+        blocks += kind == 0 ? cdiv(cols / 4, 256) : (kind == 1 ? cdiv(cols, 32) : cdiv((long)d.Nout * 72, 256));
+    }
+    if (r.n == 0) return HN_OK;
+    hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3((unsigned)blocks), dim3(256), 0, st, r);
+    HN_LAUNCH_CHECK();
+}
+
 /* hn_conv_gemm_tn that also returns the conv's bias gradient dbias [Nout] = column sums of dz -- accumulated by one extra MFMA per k-step
  * while the dz fragments are in registers, reduced by the launch that reduces the weight-gradient slabs: no column-statistics pass over
  * dz, no extra reduce launches (not for the grouped mode 5). */
@@ -2199,7 +2290,13 @@ static int conv_gemm_tn_impl(const void* x0, const void* x1, int mode, int n_img
     p.part = workspace; p.rows_per_split = rps; p.phase_span = phase_span;
     p.bias_part = nullptr;
     int bc, bn, rc;
-    if (dbias && grouped) return HN_ERR_UNSUPPORTED;
+    long* defer = g_defer_job;
+    g_defer_job = nullptr;
+    if (defer) {
+        defer[0] = (long)workspace; defer[1] = (long)dw; defer[2] = splits; defer[3] = Nout; defer[4] = C0 + C1; defer[5] = KP; defer[6] = taps;
+        defer[7] = -1;
+    }
+    if (dbias && (grouped || defer)) return HN_ERR_UNSUPPORTED;
     if (dbias) p.bias_part = workspace + (long)splits * Nout * taps * KP;
     if (use_patch_wgrad(mode, Nout, KP)) {
         static std::atomic<unsigned long long> optin{0};
@@ -2224,6 +2321,10 @@ static int conv_gemm_tn_impl(const void* x0, const void* x1, int mode, int n_img
         else hipLaunchKernelGGL((wgrad3x3_patch_kernel<16, 64>), grid, dim3(512), lds, st, p, (int)rps, patches);
         if (hipGetLastError() != hipSuccess) return HN_ERR_LAUNCH;
         const long cols = (long)Nout * taps * KP;
+        if (defer && (grouped || !(taps == 9 && splits <= 64))) {
+            defer[7] = grouped ? 2 : ((splits <= 128 && cols >= 65536) ? 0 : 1);
+            return HN_OK;
+        }
         if (grouped)
             hipLaunchKernelGGL(gconv_diag_extract_kernel, dim3(cdiv(Nout * 72, 256)), dim3(256), 0, st, workspace, dw, splits, Nout);
         else if (taps == 9 && splits <= 64)
@@ -2247,6 +2348,10 @@ static int conv_gemm_tn_impl(const void* x0, const void* x1, int mode, int n_img
 #undef TN_CASE
     if (rc != HN_OK) return rc;
     const long cols = (long)Nout * taps * KP;
+    if (defer) {
+        defer[7] = (splits <= 128 && cols >= 65536) ? 0 : 1;
+        return HN_OK;
+    }
     if (splits <= 128 && cols >= 65536)
         hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(cdiv(cols / 4, 256)), dim3(256), 0, st, workspace, dw, splits, Nout, C0 + C1, KP, taps,
                            p.bias_part, dbias);

@@ -330,8 +330,31 @@ def wgrad_bias_ok(mode, kp):
     return mode != 5
 
 
-def k_gemm_tn(x0, x1, mode, grid, dz, nout, kp, taps, cin, up=0, kh=1, want_bias=False):
-    """weight gradient, returns fp32 [nout, cin, kh, kh] (want_bias: and the bias gradient [nout] out of the same launches)."""
+class WgradBatch:
+    """collects the slab reduces of up to four weight gradients (k_gemm_tn(..., defer=batch)) and runs them in one launch (flush()); the
+    gradients are complete only after flush()"""
+
+    def __init__(self):
+        self.jobs = (ctypes.c_long * 32)()
+        self.n = 0
+        self.keep = []                  # workspaces stay alive until the reduce was enqueued
+
+    def slot(self, ws):
+        assert self.n < 4
+        self.keep.append(ws)
+        self.n += 1
+        return ctypes.addressof(self.jobs) + 64 * (self.n - 1)
+
+    def flush(self):
+        if self.n:
+            lib().call("hn_wgrad_reduce_jobs", ctypes.addressof(self.jobs), self.n)
+        self.n = 0
+        self.keep = []
+
+
+def k_gemm_tn(x0, x1, mode, grid, dz, nout, kp, taps, cin, up=0, kh=1, want_bias=False, defer=None):
+    """weight gradient, returns fp32 [nout, cin, kh, kh] (want_bias: and the bias gradient [nout] out of the same launches).
+    defer: a WgradBatch -- the slab reduce is left to its flush()."""
     n, h, w = grid
     m = n * h * w
     dev = x0.device
@@ -342,6 +365,11 @@ def k_gemm_tn(x0, x1, mode, grid, dz, nout, kp, taps, cin, up=0, kh=1, want_bias
     c0 = x0.shape[3]
     c1 = x1.shape[3] if x1 is not None else 0
     ldz = dz.stride(2) if dz.dim() == 4 else dz.stride(0)
+    if defer is not None:
+        assert not want_bias
+        lib().call("hn_conv_gemm_tn_deferred", ptr(x0), ptr(x1), mode, n, h, w, c0, c1, ld(x0), ld(x1) if x1 is not None else 0, up, m,
+                   ptr(dz), ldz, nout, kp, taps, ptr(ws), ptr(dw), defer.slot(ws))
+        return dw
     if want_bias:
         db = torch.empty((nout,), device=dev, dtype=F32)
         lib().call("hn_conv_gemm_tn_bias", ptr(x0), ptr(x1), mode, n, h, w, c0, c1, ld(x0), ld(x1) if x1 is not None else 0, up, m,
@@ -734,7 +762,8 @@ class XBlockFn(torch.autograd.Function):
         pdot = torch.empty(((m + rb - 1) // rb, c), device=dev, dtype=F32)
         lib().call("hn_se_bwd_reduce_fused", ptr(dbg), ld(dbg), ptr(z2), ld(z2), ptr(coef2), ptr(gate), hw, ptr(bg) if make_bg else None,
                    ld(bg), ptr(pdot), m, c, rb)
-        dw3 = k_gemm_tn(bg, None, 0, grid, dz3, c, kp32(c), 1, c)
+        batch = WgradBatch()                                  # the slab reduces of dw3 / dw2 / dw1 / dws: one launch at the end
+        dw3 = k_gemm_tn(bg, None, 0, grid, dz3, c, kp32(c), 1, c, defer=batch)
         dpre2 = torch.empty((n, c), device=dev, dtype=F32)
         dpool = torch.empty((n, c), device=dev, dtype=F32)
         dpre1 = torch.empty((n, cs), device=dev, dtype=F32)
@@ -746,7 +775,7 @@ class XBlockFn(torch.autograd.Function):
         dz2, dg2, db2, _ = bn_backward_fused(dbg, z2, None, coef2, ACT_RELU, m, gate=gate, dpool=dpool, hw=hw)
         if stride == 1:
             da, _, _ = k_gemm_nt(dz2, None, 5, grid, wd2, c, 64, 9)
-            dw2 = k_gemm_tn(a, None, 5, grid, dz2, c, 64, 9, 8, kh=3)
+            dw2 = k_gemm_tn(a, None, 5, grid, dz2, c, 64, 9, 8, kh=3, defer=batch)
         else:
             da = new_act(n, h, w, c, dev)
             lib().call("hn_gconv_dgrad_s2", ptr(dz2), ld(dz2), ptr(wd2), ptr(da), ld(da), n, h, w, c)
@@ -761,11 +790,12 @@ class XBlockFn(torch.autograd.Function):
             dzs, dgs, dbs, _ = bn_backward_fused(g, zs, None, coefs, ACT_NONE, m)
             addend, _, _ = k_gemm_nt(dzs, None, 0, grid, wts, cin, kp32(c), 1)           # shortcut data gradient on the output grid
             add_s2 = stride == 2
-            dws = k_gemm_tn(x, None, 0 if stride == 1 else 1, grid, dzs, c, kp32(cin), 1, cin)
+            dws = k_gemm_tn(x, None, 0 if stride == 1 else 1, grid, dzs, c, kp32(cin), 1, cin, defer=batch)
         dx = None
         if ctx.needs_input_grad[0]:
             dx, _, _ = k_gemm_nt(dz1, None, 0, (n, h, w), wt1, cin, kp32(c), 1, addend=addend, add_s2=add_s2)
-        dw1 = k_gemm_tn(x, None, 0, (n, h, w), dz1, c, kp32(cin), 1, cin)
+        dw1 = k_gemm_tn(x, None, 0, (n, h, w), dz1, c, kp32(cin), 1, cin, defer=batch)
+        batch.flush()
         return (dx, dw1, dg1, db1, None, None, dw2, dg2, db2, None, None, dsw1, dsb1, dsw2, dsb2, dw3, dg3, db3, None, None,
                 None, None, None, None, dws, dgs, dbs, None, None)
 

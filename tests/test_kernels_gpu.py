@@ -767,3 +767,26 @@ def test_dgrad_fold_direct_phase_form(K, n, h, w, k, c0):
     got = K.k_dgrad_fold(dzs, wt_eff, n, h, w, c0, K.kp32(4 * k), k, 1, yp)
     assert torch.equal(got[:, 2:h - 2, 2:w - 2], ref[:, 2:h - 2, 2:w - 2])
     close(got, ref, 1e-2, "folded phase dgrad")
+
+
+def test_wgrad_reduces_batched_in_one_launch(K):
+    """k_gemm_tn(..., defer=batch) + batch.flush(): the slab reduces of several weight gradients (1x1 with few / many splits, the grouped
+    3x3 block-diagonal form) in one launch give the gradients of the one-by-one launches"""
+    cases = [((16, 8, 16), 936, 936, 0), ((16, 64, 128), 56, 56, 0), ((16, 16, 32), 368, 368, 5), ((4, 32, 32), 152, 64, 0)]
+    batch = K.WgradBatch()
+    got, want = [], []
+    for (n, h, w), cin, cout, mode in cases:
+        x = nhwc(rnd(n, cin, h, w))
+        if mode == 5:
+            dz = nhwc(rnd(n, cin, h, w))
+            args = (x, None, 5, (n, h, w), dz, cin, 64, 9, 8)
+            kw = dict(kh=3)
+        else:
+            dz = nhwc(rnd(n, cout, h, w))
+            args = (x, None, 0, (n, h, w), dz, cout, K.kp32(cin), 1, cin)
+            kw = {}
+        want.append(K.k_gemm_tn(*args, **kw))
+        got.append(K.k_gemm_tn(*args, defer=batch, **kw))
+    batch.flush()
+    for g, r in zip(got, want):
+        close(g, r, 1e-5, "batched reduce")
