@@ -35,7 +35,7 @@ __device__ __forceinline__ bf16x8 zero8() {
 // activation codes shared by the C-ABI
 // tuning knobs for tools/ sweeps (hn_debug_knob; defaults = the shipped heuristics): 0 TN split target (workgroups), 1 TN minimum rows per
 // split, 2 fused-BatchNorm apply-pass target workgroups, 3 fused reduce-pass row-block divisor, 4 / 5 pixel thresholds of the 64x64 GEMM tile
-extern long g_hn_knob[8];
+extern long g_hn_knob[12];
 #define HN_ACT_NONE 0
 #define HN_ACT_RELU 1
 #define HN_ACT_SWISH 2
@@ -115,6 +115,16 @@ __device__ __forceinline__ void act_bwd_n(const float (&x)[N], float (&g)[N], in
 #pragma unroll
         for (int k = 0; k < N; ++k) { const float s = sigmoidf_(x[k]); g[k] *= s * (1.f - s); }
     }
+}
+
+// XCD-aware block order (8 XCDs, private L2s, workgroups dealt round-robin): hardware id -> logical id such that consecutive LOGICAL
+// ids run on one XCD.  Inside a launch, tiles that share an operand panel hit that XCD's L2; ACROSS launches it is a placement convention:
+// every kernel walks its tensor in row order with this mapping, so XCD k owns rows [k M / 8, (k + 1) M / 8) (images 2k, 2k+1 of a batch of
+// 16, at every pyramid level) in the producer and in the consumer, and what a launch wrote with plain stores is still in the L2 the next
+// launch reads it through (measured: +1 % on the whole step from the BatchNorm passes alone).  Bijective for any grid size.  Speed only.
+__device__ __forceinline__ int xcd_remap(int hw, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = hw & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (hw >> 3);
 }
 
 // sum over each row of 16 lanes (all 16 get the total): DPP row rotations are plain VALU ops, ~10x cheaper than ds_bpermute shuffles

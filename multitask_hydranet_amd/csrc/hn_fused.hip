@@ -15,6 +15,17 @@
 
 #define FCH 128
 
+// Logical (channel chunk, row block) of this workgroup: row-block-major logical order, contiguous per XCD like the GEMMs' xcd_remap -- XCD k
+// owns rows [k M / 8, (k + 1) M / 8) in the passes AND in the GEMMs that produce / consume them (the row-order placement convention of
+// hn_common.h; knob 8 = 0 turns it off for A/B runs: 701 -> 708 img/s from these passes alone).
+__device__ __forceinline__ void fused_block(int xcd, int& bx, int& by) {
+    if (!xcd) { bx = blockIdx.x; by = blockIdx.y; return; }
+    const int nwg = gridDim.x * gridDim.y, hw = blockIdx.y * gridDim.x + blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, x = hw & 7;
+    const int lid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (hw >> 3);
+    bx = lid % gridDim.x; by = lid / gridDim.x;
+}
+
 struct BnSrc {
     const float* psum; const float* psq;   // [P][C] partial sums / sums of squares
     int P;                                 // > 0: finalize from the partial rows; 0: read coef; < 0: eval mode (running statistics)
@@ -100,7 +111,7 @@ __device__ __forceinline__ void chunk_coefs(const BnSrc& b, int C, int c0, int n
 // per-channel sums over the workgroup's row lanes of up to two per-thread accumulators -> o1/o2[blockIdx.y][c] (fixed order)
 template <int NARR>
 __device__ __forceinline__ void chunk_row_reduce(float (&a1)[8], float (&a2)[8], bool active, int cln, int rln, int cl, int rl, int c0, int nch,
-                                                 int C, float* o1, float* o2, float* scratch /* [NARR][256*8] */, FusedLds& L) {
+                                                 int C, float* o1, float* o2, float* scratch /* [NARR][256*8] */, FusedLds& L, int by) {
     const int tid = threadIdx.x;
     if (active) {
 #pragma unroll
@@ -122,7 +133,7 @@ __device__ __forceinline__ void chunk_row_reduce(float (&a1)[8], float (&a2)[8],
     L.fr[0][j][c] = t1; L.fr[1][j][c] = t2;
     __syncthreads();
     if (tid < nch) {
-        const long o = (long)blockIdx.y * C + c0 + tid;
+        const long o = (long)by * C + c0 + tid;
         o1[o] = L.fr[0][0][tid] + L.fr[0][1][tid];
         if (NARR == 2) o2[o] = L.fr[1][0][tid] + L.fr[1][1][tid];
     }
@@ -139,22 +150,24 @@ struct FApply {
     bf16* out; int ldo;
     float* pool;                    // [gridDim.y][C] or null
     const float* gate; long HW;     // optional: out = bf16(act(bn(z))) * gate[row / HW][c]  (SE excite; RB divides HW)
-    long M; int C; long RB; int cw;
+    long M; int C; long RB; int cw; int xcd;
 };
 
 __global__ __launch_bounds__(256) void fused_apply_kernel(const FApply p) {
     __shared__ FusedLds L;
     __shared__ float scratch[2048];
-    const int c0 = blockIdx.x * p.cw;
+    int bx, by;
+    fused_block(p.xcd, bx, by);
+    const int c0 = bx * p.cw;
     const int nch = p.C - c0 < p.cw ? p.C - c0 : p.cw;
-    chunk_coefs(p.bn, p.C, c0, nch, blockIdx.y == 0, L);
+    chunk_coefs(p.bn, p.C, c0, nch, by == 0, L);
     const int cln = nch >> 3, rln = 256 / cln;
     const int tid = threadIdx.x, cl = tid % cln, rl = tid / cln;
     const bool active = rl < rln;
     float sc[8], sh[8], acc[8], dummy[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) { sc[k] = L.coef[0][cl * 8 + k]; sh[k] = L.coef[1][cl * 8 + k]; acc[k] = 0.f; dummy[k] = 0.f; }
-    const long m0 = (long)blockIdx.y * p.RB;
+    const long m0 = (long)by * p.RB;
     long m1 = m0 + p.RB;
     if (m1 > p.M) m1 = p.M;
     const int c = c0 + cl * 8;
@@ -200,7 +213,7 @@ __global__ __launch_bounds__(256) void fused_apply_kernel(const FApply p) {
             apply(vz0, vr0, m);
         }
     }
-    if (p.pool) chunk_row_reduce<1>(acc, dummy, active, cln, rln, cl, rl, c0, nch, p.C, p.pool, nullptr, scratch, L);
+    if (p.pool) chunk_row_reduce<1>(acc, dummy, active, cln, rln, cl, rl, c0, nch, p.C, p.pool, nullptr, scratch, L, by);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -219,14 +232,16 @@ struct FBwd {
     int P; double count;
     float* dgamma; float* dbeta; float* zvec;   // zvec (optional): C zeros (the gradient of a conv bias that feeds this BatchNorm)
     bf16* dz; int lddz; bf16* gout; int ldg;
-    long M; int C; long RB; int cw;
+    long M; int C; long RB; int cw; int xcd;
 };
 
 template <bool APPLY>
 __global__ __launch_bounds__(256) void fused_bwd_kernel(const FBwd p) {
     __shared__ FusedLds L;
     __shared__ float scratch[APPLY ? 1 : 4096];
-    const int c0 = blockIdx.x * p.cw;
+    int bx, by;
+    fused_block(p.xcd, bx, by);
+    const int c0 = bx * p.cw;
     const int nch = p.C - c0 < p.cw ? p.C - c0 : p.cw;
     const int tid = threadIdx.x;
     if (APPLY) {
@@ -235,7 +250,7 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(const FBwd p) {
             const double s1 = L.r1[0][tid], s2 = L.r2[0][tid];
             L.coef[4][tid] = (float)(s1 / p.count);
             L.coef[5][tid] = (float)(s2 / p.count);
-            if (blockIdx.y == 0) {
+            if (by == 0) {
                 p.dbeta[c0 + tid] = (float)s1; p.dgamma[c0 + tid] = (float)s2;
                 if (p.zvec) p.zvec[c0 + tid] = 0.f;
             }
@@ -251,7 +266,7 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(const FBwd p) {
     const bool active = rl < rln;
     const int c = c0 + cl * 8;
     float sc[8], sh[8], mu[8], rs[8], mg[8], mgx[8], gt[8], dp[8], s1[8], s2[8];
-    const long m0 = (long)blockIdx.y * p.RB;
+    const long m0 = (long)by * p.RB;
     long m1 = m0 + p.RB;
     if (m1 > p.M) m1 = p.M;
 #pragma unroll
@@ -317,19 +332,21 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(const FBwd p) {
             one(vd0, vz0, vy0, m);
         }
     }
-    if (!APPLY) chunk_row_reduce<2>(s1, s2, active, cln, rln, cl, rl, c0, nch, p.C, p.pg, p.pgx, scratch, L);
+    if (!APPLY) chunk_row_reduce<2>(s1, s2, active, cln, rln, cl, rl, c0, nch, p.C, p.pg, p.pgx, scratch, L, by);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // per-channel statistics of a bf16 tensor (producers without a statistics epilogue: stem, grouped / depthwise convs):
 // psum / psq [gridDim.y][C] of the stored (bf16) values
 // ---------------------------------------------------------------------------------------------------------------------------------
-struct FStats { const bf16* x; int ldx; float* psum; float* psq; long M; int C; long RB; int cw; };
+struct FStats { const bf16* x; int ldx; float* psum; float* psq; long M; int C; long RB; int cw; int xcd; };
 
 __global__ __launch_bounds__(256) void fused_stats_kernel(const FStats p) {
     __shared__ FusedLds L;
     __shared__ float scratch[4096];
-    const int c0 = blockIdx.x * p.cw;
+    int bx, by;
+    fused_block(p.xcd, bx, by);
+    const int c0 = bx * p.cw;
     const int nch = p.C - c0 < p.cw ? p.C - c0 : p.cw;
     const int cln = nch >> 3, rln = 256 / cln;
     const int tid = threadIdx.x, cl = tid % cln, rl = tid / cln;
@@ -338,7 +355,7 @@ __global__ __launch_bounds__(256) void fused_stats_kernel(const FStats p) {
     float s1[8], s2[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
-    const long m0 = (long)blockIdx.y * p.RB;
+    const long m0 = (long)by * p.RB;
     long m1 = m0 + p.RB;
     if (m1 > p.M) m1 = p.M;
     if (active) {
@@ -358,7 +375,7 @@ __global__ __launch_bounds__(256) void fused_stats_kernel(const FStats p) {
             for (int k = 0; k < 8; ++k) { const float f = bf2f(v[k]); s1[k] += f; s2[k] += f * f; }
         }
     }
-    chunk_row_reduce<2>(s1, s2, active, cln, rln, cl, rl, c0, nch, p.C, p.psum, p.psq, scratch, L);
+    chunk_row_reduce<2>(s1, s2, active, cln, rln, cl, rl, c0, nch, p.C, p.psum, p.psq, scratch, L, by);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -368,13 +385,15 @@ __global__ __launch_bounds__(256) void fused_stats_kernel(const FStats p) {
 // ---------------------------------------------------------------------------------------------------------------------------------
 struct FSeBwd {
     const bf16* dbg; int ldd; const bf16* z; int ldz; const float* coef; const float* gate; long HW;
-    bf16* bg; int ldb; float* pdot; long M; int C; long RB; int cw;
+    bf16* bg; int ldb; float* pdot; long M; int C; long RB; int cw; int xcd;
 };
 
 __global__ __launch_bounds__(256) void fused_se_bwd_kernel(const FSeBwd p) {
     __shared__ FusedLds L;
     __shared__ float scratch[2048];
-    const int c0 = blockIdx.x * p.cw;
+    int bx, by;
+    fused_block(p.xcd, bx, by);
+    const int c0 = bx * p.cw;
     const int nch = p.C - c0 < p.cw ? p.C - c0 : p.cw;
     const int tid = threadIdx.x;
     if (tid < nch) { L.coef[0][tid] = p.coef[c0 + tid]; L.coef[1][tid] = p.coef[p.C + c0 + tid]; }
@@ -383,7 +402,7 @@ __global__ __launch_bounds__(256) void fused_se_bwd_kernel(const FSeBwd p) {
     const int cl = tid % cln, rl = tid / cln;
     const bool active = rl < rln;
     const int c = c0 + cl * 8;
-    const long m0 = (long)blockIdx.y * p.RB;
+    const long m0 = (long)by * p.RB;
     long m1 = m0 + p.RB;
     if (m1 > p.M) m1 = p.M;
     float sc[8], sh[8], gt[8], acc[8], dummy[8];
@@ -415,7 +434,7 @@ __global__ __launch_bounds__(256) void fused_se_bwd_kernel(const FSeBwd p) {
         }
         if (m < m1) one(ld8(p.dbg + m * p.ldd + c), ld8(p.z + m * p.ldz + c), m);
     }
-    chunk_row_reduce<1>(acc, dummy, active, cln, rln, cl, rl, c0, nch, p.C, p.pdot, nullptr, scratch, L);
+    chunk_row_reduce<1>(acc, dummy, active, cln, rln, cl, rl, c0, nch, p.C, p.pdot, nullptr, scratch, L, by);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -468,7 +487,7 @@ extern "C" int hn_bn_apply_fused(const void* z, int ldz, long M, int C, const fl
     p.bn.psum = psum; p.bn.psq = psq; p.bn.P = P; p.bn.count = (double)count; p.bn.gamma = gamma; p.bn.beta = beta; p.bn.eps = eps;
     p.bn.momentum = momentum; p.bn.rm = rm; p.bn.rv = rv; p.bn.coef = coef;
     p.res = (const bf16*)res; p.ldr = ldr; p.act = act; p.out = (bf16*)out; p.ldo = ldo; p.pool = pool; p.M = M; p.C = C; p.RB = RB;
-    p.gate = gate; p.HW = HW; p.cw = chunk_width(C);
+    p.gate = gate; p.HW = HW; p.cw = chunk_width(C); p.xcd = (int)g_hn_knob[8];
     hipLaunchKernelGGL(fused_apply_kernel, fused_grid(M, C, RB), dim3(256), 0, st, p);
     HN_LAUNCH_CHECK();
 }
@@ -479,7 +498,7 @@ static int fill_bwd(FBwd& p, const void* dout, int ldd, const void* z, int ldz, 
     HN_CHECK_ARG((!y || (ldy & 7) == 0) && (!gate || (dpool && HW > 0 && HW % RB == 0)));
     p = FBwd{};
     p.dout = (const bf16*)dout; p.ldd = ldd; p.z = (const bf16*)z; p.ldz = ldz; p.y = (const bf16*)y; p.ldy = ldy; p.coef = coef; p.act = act;
-    p.gate = gate; p.dpool = dpool; p.HW = HW; p.pg = pg; p.pgx = pgx; p.M = M; p.C = C; p.RB = RB; p.cw = chunk_width(C);
+    p.gate = gate; p.dpool = dpool; p.HW = HW; p.pg = pg; p.pgx = pgx; p.M = M; p.C = C; p.RB = RB; p.cw = chunk_width(C); p.xcd = (int)g_hn_knob[8];
     return HN_OK;
 }
 
@@ -508,7 +527,7 @@ extern "C" int hn_bn_bwd_apply_fused(const void* dout, int ldd, const void* z, i
 
 extern "C" int hn_col_stats_fused(const void* x, int ldx, long M, int C, long RB, float* psum, float* psq, hipStream_t st) {
     HN_CHECK_ARG(x && psum && psq && M > 0 && C > 0 && (C & 7) == 0 && (ldx & 7) == 0 && RB > 0);
-    FStats p = {(const bf16*)x, ldx, psum, psq, M, C, RB, chunk_width(C)};
+    FStats p = {(const bf16*)x, ldx, psum, psq, M, C, RB, chunk_width(C), (int)g_hn_knob[8]};
     hipLaunchKernelGGL(fused_stats_kernel, fused_grid(M, C, RB), dim3(256), 0, st, p);
     HN_LAUNCH_CHECK();
 }
@@ -517,7 +536,7 @@ extern "C" int hn_se_bwd_reduce_fused(const void* dbg, int ldd, const void* z, i
                                       int ldb, float* pdot, long M, int C, long RB, hipStream_t st) {
     HN_CHECK_ARG(dbg && z && coef && gate && pdot && M > 0 && C > 0 && (C & 7) == 0 && (ldd & 7) == 0 && (ldz & 7) == 0);
     HN_CHECK_ARG(RB > 0 && HW > 0 && HW % RB == 0 && (!bg || (ldb & 7) == 0));
-    FSeBwd p = {(const bf16*)dbg, ldd, (const bf16*)z, ldz, coef, gate, HW, (bf16*)bg, ldb, pdot, M, C, RB, chunk_width(C)};
+    FSeBwd p = {(const bf16*)dbg, ldd, (const bf16*)z, ldz, coef, gate, HW, (bf16*)bg, ldb, pdot, M, C, RB, chunk_width(C), (int)g_hn_knob[8]};
     hipLaunchKernelGGL(fused_se_bwd_kernel, fused_grid(M, C, RB), dim3(256), 0, st, p);
     HN_LAUNCH_CHECK();
 }

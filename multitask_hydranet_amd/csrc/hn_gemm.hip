@@ -107,13 +107,6 @@ __device__ __forceinline__ long pixel_off(const XSrc& s, long m, int n, int oy, 
     return (((long)n * s.Hi + iy) * s.Wi + ix) * s.ld0;
 }
 
-// XCD-aware block order (8 XCDs, private L2s, workgroups dealt round-robin): hardware id -> logical id such that consecutive LOGICAL
-// ids run on one XCD, so tiles that share an operand panel hit that XCD's L2.  Bijective for any grid size.  Speed only.
-__device__ __forceinline__ int xcd_remap(int hw, int nwg) {
-    const int q = nwg >> 3, r = nwg & 7, x = hw & 7;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (hw >> 3);
-}
-
 __device__ __forceinline__ void glds16(const bf16* src, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
@@ -1888,8 +1881,8 @@ static int pick_bc(int Nout) {
 
 // Few pixel rows x wide cout (the deep backbone stages: 2048...8192 rows, 376/936 channels): 64x64 tiles give >= 2 workgroups per CU,
 // which overlap each other's load / wait / MFMA phases (a 64x128 tiling leaves one workgroup per CU waiting on its own loads).
-long g_hn_knob[8] = {1024, 256, 1024, 512, 8192, 32768, 0, 0};
-extern "C" int hn_debug_knob(int id, long value) { if (id < 0 || id >= 8) return HN_ERR_ARG; g_hn_knob[id] = value; return HN_OK; }
+long g_hn_knob[12] = {1024, 256, 1024, 512, 8192, 32768, 0, 0, 1, 0, 0, 0};
+extern "C" int hn_debug_knob(int id, long value) { if (id < 0 || id >= 12) return HN_ERR_ARG; g_hn_knob[id] = value; return HN_OK; }
 static bool small_tile(long M, int Nout) { return !g_nt_force_bc && Nout > 64 && (M <= g_hn_knob[4] || (M <= g_hn_knob[5] && Nout <= 128)); }
 
 // partial statistic rows of a mode-5 (grouped 3x3 on the direct kernel) launch: one per 16x16 output patch

@@ -29,6 +29,7 @@ struct ColRed {
 
 template <int MODE>
 __global__ __launch_bounds__(256) void colred_kernel(const ColRed p) {
+    const int bidx = xcd_remap(blockIdx.x, gridDim.x);     // row-order placement convention (hn_common.h)
     __shared__ float red[4][256 * 8];                 // [0..1]: the block's partial sums; all four: MODE 2 coefficient staging (C <= 2048)
     const int C8 = p.C >> 3;
     const int tid = threadIdx.x;
@@ -38,13 +39,13 @@ __global__ __launch_bounds__(256) void colred_kernel(const ColRed p) {
     float s1[8], s2[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
-    const long m0 = (long)blockIdx.x * p.R;
+    const long m0 = (long)bidx * p.R;
     long m1 = m0 + p.R;
     if (m1 > p.M) m1 = p.M;
     float sc[8], sh[8], mu[8], rs[8];
     if (MODE == 2) {                                  // stage the 4 x C coefficients through LDS once per block (red is free until the end)
         float* cf = &red[0][0];
-        const long cofs = p.sg.n > 1 ? (long)level_of_row(p.sg, (long)blockIdx.x * p.R) * p.coef_stride : 0;
+        const long cofs = p.sg.n > 1 ? (long)level_of_row(p.sg, (long)bidx * p.R) * p.coef_stride : 0;
         for (int i = tid; i < p.C; i += 256) {
             cf[i] = p.scale[cofs + i]; cf[p.C + i] = p.shift[cofs + i]; cf[2 * p.C + i] = p.mean[cofs + i]; cf[3 * p.C + i] = p.rstd[cofs + i];
         }
@@ -115,8 +116,8 @@ __global__ __launch_bounds__(256) void colred_kernel(const ColRed p) {
             t1 += red[0][(r * C8 + g8) * 8 + k];
             t2 += red[1][(r * C8 + g8) * 8 + k];
         }
-        p.o1[(long)blockIdx.x * p.C + c] = t1;
-        p.o2[(long)blockIdx.x * p.C + c] = t2;
+        p.o1[(long)bidx * p.C + c] = t1;
+        p.o2[(long)bidx * p.C + c] = t2;
     }
 }
 
@@ -250,6 +251,7 @@ struct BnAct {
 // coefficients for every 16 B of data dominated the small layers), each thread keeps its slice in registers while it walks rows
 // (256 / C8 rows per block pass), two rows in flight.
 __global__ __launch_bounds__(256) void bn_act_kernel(const BnAct p) {
+    const int bidx = xcd_remap(blockIdx.x, gridDim.x);     // row-order placement convention (hn_common.h)
     extern __shared__ float coefs[];                      // [4][C]: scale, shift, rscale, rshift
     for (int i = threadIdx.x; i < p.C; i += 256) {
         coefs[i] = p.scale ? p.scale[i] : 1.f;
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const BnAct p) {
         st8(p.out + m * p.ldo + c, o);
     };
     const long step = (long)gridDim.x * rpb;
-    long m = (long)blockIdx.x * rpb + rr;
+    long m = (long)bidx * rpb + rr;
     for (; m + step < p.M; m += 2 * step) {
         const long mb = m + step;
         const bf16x8 vz0 = ld8(p.z + m * p.ldz + c), vz1 = ld8(p.z + mb * p.ldz + c);
@@ -309,6 +311,7 @@ struct BnBwdApply {
 };
 // dz = scale * (g - mean(g) - xhat * mean(g*xhat)),  g = dout * act'(pre)   (optionally also emits g)
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApply p) {
+    const int bidx = xcd_remap(blockIdx.x, gridDim.x);     // row-order placement convention (hn_common.h)
     extern __shared__ float coefs[];                      // [6][C]: scale, shift, mean, rstd, mean(g), mean(g*xhat)
     for (int i = threadIdx.x; i < p.C; i += 256) {
         coefs[i] = p.scale[i]; coefs[p.C + i] = p.shift[i]; coefs[2 * p.C + i] = p.mean[i]; coefs[3 * p.C + i] = p.rstd[i];
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdApply p) {
         if (p.gout) st8(p.gout + m * p.ldg + c, og);
     };
     const long step = (long)gridDim.x * rpb;
-    long m = (long)blockIdx.x * rpb + rr;
+    long m = (long)bidx * rpb + rr;
     for (; m + step < p.M; m += 2 * step) {
         const long mb = m + step;
         const bf16x8 vd0 = ld8(p.dout + m * p.ldd + c), vd1 = ld8(p.dout + mb * p.ldd + c);
@@ -382,8 +385,9 @@ struct BnLevels {
 };
 template <bool BWD>
 __global__ __launch_bounds__(256) void bn_levels_kernel(const BnLevels p) {
+    const int bidx = xcd_remap(blockIdx.x, gridDim.x);     // row-order placement convention (hn_common.h)
     extern __shared__ float coefs[];                      // [4 or 6][C]
-    const long m0 = (long)blockIdx.x * p.RB;
+    const long m0 = (long)bidx * p.RB;
     const int lv = level_of_row(p.sg, m0);
     const float* cf = p.coef + (long)lv * 4 * p.C;
     for (int i = threadIdx.x; i < 4 * p.C; i += 256) coefs[i] = cf[i];
@@ -559,9 +563,10 @@ __global__ __launch_bounds__(256) void se_bwd_apply_kernel(const bf16* dout, int
 //   op 2: out = alpha * a      op 3: out = act(a)      op 4: out = a * act'(b) with b = PRE-activation
 struct Ew { const bf16* a; int lda; const bf16* b; int ldb; bf16* out; int ldo; long M; int C; int op; int act; float alpha; };
 __global__ __launch_bounds__(256) void ew_kernel(const Ew p) {
+    const int bidx = xcd_remap(blockIdx.x, gridDim.x);     // row-order placement convention (hn_common.h)
     const int C8 = p.C >> 3;
     const long total = p.M * C8;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    for (long idx = (long)bidx * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const long m = idx / C8;
         const int c = (int)(idx - m * C8) * 8;
         const bf16x8 va = ld8(p.a + m * p.lda + c);
@@ -595,9 +600,10 @@ __global__ __launch_bounds__(256) void ew_kernel(const Ew p) {
 
 // dx[n, 2y, 2x, :] += dxs[n, y, x, :]   (backward of a stride-2 1x1 conv's row gather)
 __global__ __launch_bounds__(256) void add_strided2_kernel(bf16* dx, int ldx, const bf16* dxs, int lds_, int N, int Ho, int Wo, int C) {
+    const int bidx = xcd_remap(blockIdx.x, gridDim.x);     // row-order placement convention (hn_common.h)
     const int C8 = C >> 3;
     const long total = (long)N * Ho * Wo * C8;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    for (long idx = (long)bidx * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const long ms = idx / C8;
         const int c = (int)(idx - ms * C8) * 8;
         const int ox = (int)(ms % Wo);

@@ -13,6 +13,7 @@
 // stem: x NCHW fp32 [N,3,H,W] -> z NHWC bf16 [N,H/2,W/2,32]; weights fp32 [32][3][3][3]
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* x, const float* w, bf16* z, bf16* patches, int N, int H, int W) {
+    const int bidx = xcd_remap(blockIdx.x, gridDim.x);     // row-order placement convention (hn_common.h)
     __shared__ float sw[27][32];
     for (int i = threadIdx.x; i < 27 * 32; i += 256) {
         const int co = i & 31, t = i >> 5;        // t = ci*9 + ky*3 + kx
@@ -21,7 +22,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* x, const flo
     __syncthreads();
     const int Ho = H >> 1, Wo = W >> 1;
     const long total = (long)N * Ho * Wo;
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long idx = (long)bidx * 256 + threadIdx.x;
     if (idx >= total) return;
     const int ox = (int)(idx % Wo);
     const long t1 = idx / Wo;
@@ -108,9 +109,10 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* x, const b
 template <int S>
 __global__ __launch_bounds__(256) void gconv_fwd_kernel(const bf16* in, int ldi, const bf16* wk, bf16* out, int ldo, int N, int Hi,
                                                         int Wi, int Ho, int Wo, int G) {
+    const int bidx = xcd_remap(blockIdx.x, gridDim.x);     // row-order placement convention (hn_common.h)
     const int strips = (Wo + 3) >> 2;
     const long total = (long)N * Ho * strips * G;
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long idx = (long)bidx * 256 + threadIdx.x;
     if (idx >= total) return;
     const int g = (int)(idx % G);
     long t = idx / G;
@@ -165,8 +167,9 @@ __global__ __launch_bounds__(256) void gconv_fwd_kernel(const bf16* in, int ldi,
 // per input pixel runs all nine tap bodies under lane masks in a mixed-parity wave: measured 157 us at stage 0 against a 22 us HBM floor).
 __global__ __launch_bounds__(256) void gconv_dgrad_s2_kernel(const bf16* dz, int ldz, const bf16* wd, bf16* dx, int ldx, int N, int Hi,
                                                              int Wi, int Ho, int Wo, int G) {
+    const int bidx = xcd_remap(blockIdx.x, gridDim.x);     // row-order placement convention (hn_common.h)
     const long total = (long)N * Ho * Wo * G;
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long idx = (long)bidx * 256 + threadIdx.x;
     if (idx >= total) return;
     const int g = (int)(idx % G);
     long t = idx / G;
@@ -219,8 +222,9 @@ __global__ __launch_bounds__(256) void gconv_dgrad_s2_kernel(const bf16* dz, int
 // wgrad partials: part[chunk][((g*8+o)*8 + i)*9 + tap] = sum over the chunk's output pixels of dz[pix][g*8+o] * x[pix(tap)][g*8+i]
 __global__ __launch_bounds__(256) void gconv_wgrad_kernel(const bf16* x, int ldx, const bf16* dz, int ldz, float* part, int N, int Hi,
                                                           int Wi, int Ho, int Wo, int G, int S, long ppc, long nchunks) {
+    const int bidx = xcd_remap(blockIdx.x, gridDim.x);     // row-order placement convention (hn_common.h)
     const int items = G * 9;
-    const long tid = (long)blockIdx.x * 256 + threadIdx.x;       // (chunk, item) flattened: neighbouring lanes = neighbouring groups
+    const long tid = (long)bidx * 256 + threadIdx.x;       // (chunk, item) flattened: neighbouring lanes = neighbouring groups
     const long chunk = tid / items;
     const int item = (int)(tid - chunk * items);
     if (chunk >= nchunks) return;
@@ -296,8 +300,9 @@ __global__ void gconv_pack_kernel(const float* w, bf16* wk, bf16* wd, int G, int
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const bf16* in, int ldi, const bf16* wk, bf16* out, int ldo, int N, int C,
                                                          const Levels L, int accumulate) {
+    const int bidx = xcd_remap(blockIdx.x, gridDim.x);     // row-order placement convention (hn_common.h)
     const int C8 = C >> 3;
-    long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    long idx = (long)bidx * 256 + threadIdx.x;
     if (idx >= L.work_off[L.n]) {
         // ragged level packing: every level is padded to a multiple of the row alignment; the work items behind the real ones ZERO those
         // alignment rows, so that downstream GEMMs see exact zeros there (their BatchNorm statistics are corrected analytically)
@@ -474,6 +479,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const bf16* dz, int ldz
     float* wl = red + 256 * 37;
     const int C4 = C >> 2;
     const int tid = threadIdx.x;
+    const long bidx = (long)blockIdx.x < blocks ? xcd_remap(blockIdx.x, (int)blocks) : blockIdx.x;    // row-order placement (hn_common.h)
     if ((long)blockIdx.x >= blocks) {
         const int C8 = C >> 3;
         long idx = ((long)blockIdx.x - blocks) * 256 + tid;
@@ -492,7 +498,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const bf16* dz, int ldz
     const int cg = tid % C4, lane = tid / C4;
     const bool active = lane < lanes;
     const long total = L.work_off[L.n];                               // strips
-    const long s0 = ((long)blockIdx.x * lanes + lane) * spl;
+    const long s0 = (bidx * lanes + lane) * spl;
     long s1 = s0 + spl;
     if (s1 > total) s1 = total;
     float acc[9][4];
@@ -591,7 +597,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const bf16* dz, int ldz
 #pragma unroll
         for (int k = 0; k < 4; ++k) red[tid * 37 + tq * 4 + k] = active ? acc[tq][k] : 0.f;
     __syncthreads();
-    float* dst = part + (long)blockIdx.x * C * 9;
+    float* dst = part + bidx * C * 9;
     for (int o = tid; o < C4 * 36; o += 256) {
         const int g = o / 36, v = o - g * 36;
         float sum = 0.f;
@@ -639,9 +645,10 @@ __device__ __forceinline__ void pool_window(const bf16* in, int ldi, long n, int
 
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const bf16* in, int ldi, bf16* out, int ldo, int N, int H, int W, int C,
                                                           int mode) {
+    const int bidx = xcd_remap(blockIdx.x, gridDim.x);     // row-order placement convention (hn_common.h)
     const int C8 = C >> 3, Ho = H >> 1, Wo = W >> 1;
     const long total = (long)N * Ho * Wo * C8;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    for (long idx = (long)bidx * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int cg = (int)(idx % C8);
         long t = idx / C8;
         const int ox = (int)(t % Wo);
@@ -661,11 +668,12 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const bf16* in, int ld
 // dx[n, iy, ix, c] = wscale * sum over windows whose (recomputed) arg-max is (iy, ix) of dout[window]
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const bf16* in, int ldi, const bf16* dout, int ldd, bf16* dx, int ldx,
                                                           const float* wscale, int N, int H, int W, int C, int mode) {
+    const int bidx = xcd_remap(blockIdx.x, gridDim.x);     // row-order placement convention (hn_common.h)
     const int C8 = C >> 3, Ho = H >> 1, Wo = W >> 1;
     const long total = (long)N * H * W * C8;
     const float ws = wscale ? *wscale : 1.0f;
     const int off = mode ? -1 : 0;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    for (long idx = (long)bidx * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int cg = (int)(idx % C8);
         long t = idx / C8;
         const int ix = (int)(t % W);
@@ -701,9 +709,10 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const bf16* in, int ld
 // per input pixel visits its <= 4 windows and reads only their arg bytes and gradients (the one-pass kernel above re-reads 9 inputs per
 // window per pixel: 40 loads per pixel instead of ~8)
 __global__ __launch_bounds__(256) void maxpool_arg_kernel(const bf16* in, int ldi, unsigned char* arg, int N, int H, int W, int C, int mode) {
+    const int bidx = xcd_remap(blockIdx.x, gridDim.x);     // row-order placement convention (hn_common.h)
     const int C8 = C >> 3, Ho = H >> 1, Wo = W >> 1;
     const long total = (long)N * Ho * Wo * C8;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    for (long idx = (long)bidx * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int cg = (int)(idx % C8);
         long t = idx / C8;
         const int ox = (int)(t % Wo);
@@ -721,11 +730,12 @@ __global__ __launch_bounds__(256) void maxpool_arg_kernel(const bf16* in, int ld
 }
 __global__ __launch_bounds__(256) void maxpool_bwd_arg_kernel(const unsigned char* arg, const bf16* dout, int ldd, bf16* dx, int ldx,
                                                               const float* wscale, int N, int H, int W, int C, int mode, int accumulate) {
+    const int bidx = xcd_remap(blockIdx.x, gridDim.x);     // row-order placement convention (hn_common.h)
     const int C8 = C >> 3, Ho = H >> 1, Wo = W >> 1;
     const long total = (long)N * H * W * C8;
     const float ws = wscale ? *wscale : 1.0f;
     const int off = mode ? -1 : 0;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    for (long idx = (long)bidx * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int cg = (int)(idx % C8);
         long t = idx / C8;
         const int ix = (int)(t % W);
@@ -764,9 +774,10 @@ __global__ __launch_bounds__(256) void maxpool_bwd_arg_kernel(const unsigned cha
 
 // nearest x2 up-sampling (forward) and its backward (2x2 sum, optional device-side scale)
 __global__ __launch_bounds__(256) void up2_fwd_kernel(const bf16* in, int ldi, bf16* out, int ldo, int N, int H, int W, int C) {
+    const int bidx = xcd_remap(blockIdx.x, gridDim.x);     // row-order placement convention (hn_common.h)
     const int C8 = C >> 3, Ho = 2 * H, Wo = 2 * W;
     const long total = (long)N * Ho * Wo * C8;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    for (long idx = (long)bidx * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int cg = (int)(idx % C8);
         long t = idx / C8;
         const int ox = (int)(t % Wo);
@@ -778,10 +789,11 @@ __global__ __launch_bounds__(256) void up2_fwd_kernel(const bf16* in, int ldi, b
 }
 __global__ __launch_bounds__(256) void sum2x2_kernel(const bf16* g, int ldg, bf16* out, int ldo, const float* wscale, int N, int H, int W,
                                                      int C, int accumulate) {   // H, W = LOW resolution
+    const int bidx = xcd_remap(blockIdx.x, gridDim.x);     // row-order placement convention (hn_common.h)
     const int C8 = C >> 3;
     const long total = (long)N * H * W * C8;
     const float ws = wscale ? *wscale : 1.0f;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    for (long idx = (long)bidx * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int cg = (int)(idx % C8);
         long t = idx / C8;
         const int x = (int)(t % W);
@@ -840,6 +852,7 @@ __device__ __forceinline__ void fuse_gather(const Fuse& p, int i, long n, int y,
     }
 }
 __global__ __launch_bounds__(256) void fuse_fwd_kernel(const Fuse p) {
+    const int bidx = xcd_remap(blockIdx.x, gridDim.x);     // row-order placement convention (hn_common.h)
     const int C8 = p.C >> 3;
     const long total = (long)p.N * p.H * p.W * C8;
     float wv[3];
@@ -849,12 +862,12 @@ __global__ __launch_bounds__(256) void fuse_fwd_kernel(const Fuse p) {
         for (int i = 0; i < 3; ++i) { wv[i] = i < p.nw ? fmaxf(p.praw[i], 0.f) : 0.f; sum += wv[i]; }
 #pragma unroll
         for (int i = 0; i < 3; ++i) wv[i] = wv[i] / (sum + p.eps);
-        if (blockIdx.x == 0 && threadIdx.x < 3) p.wn[threadIdx.x] = wv[threadIdx.x];
+        if (bidx == 0 && threadIdx.x < 3) p.wn[threadIdx.x] = wv[threadIdx.x];
     } else {
 #pragma unroll
         for (int i = 0; i < 3; ++i) wv[i] = p.w[i];
     }
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    for (long idx = (long)bidx * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int cg = (int)(idx % C8);
         long t = idx / C8;
         const int x = (int)(t % p.W);
@@ -923,11 +936,12 @@ struct FuseBwd {
     float* pw;
 };
 __global__ __launch_bounds__(256) void fuse_bwd_kernel(const FuseBwd q) {
+    const int bidx = xcd_remap(blockIdx.x, gridDim.x);     // row-order placement convention (hn_common.h)
     const Fuse& p = q.f;
     const int C8 = p.C >> 3;
     const long total = (long)p.N * p.H * p.W * C8;
     float dw[3] = {0.f, 0.f, 0.f};
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    for (long idx = (long)bidx * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int cg = (int)(idx % C8);
         long t = idx / C8;
         const int x = (int)(t % p.W);
@@ -981,7 +995,7 @@ __global__ __launch_bounds__(256) void fuse_bwd_kernel(const FuseBwd q) {
         if (lane == 0) red[wave][i] = s;
     }
     __syncthreads();
-    if (threadIdx.x < 3) q.pw[blockIdx.x * 3 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (threadIdx.x < 3) q.pw[bidx * 3 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -999,9 +1013,10 @@ __device__ __forceinline__ int refl_pre(int q, int L, int* pos, int clamp) {   /
 }
 __global__ __launch_bounds__(256) void seg_fold_kernel(const bf16* dvp, int ldv, int c0, bf16* out, int ldo, const bf16* yprev, int ldy,
                                                        int N, int H, int W, int C, int up, int clamp) {
+    const int bidx = xcd_remap(blockIdx.x, gridDim.x);     // row-order placement convention (hn_common.h)
     const int C8 = C >> 3, Ho = H >> up, Wo = W >> up;
     const long total = (long)N * Ho * Wo * C8;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    for (long idx = (long)bidx * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int cg = (int)(idx % C8);
         long t = idx / C8;
         const int x = (int)(t % Wo);
@@ -1075,13 +1090,14 @@ __global__ void space_to_depth_kernel(const float* dy, bf16* out, int ldo, int N
 // this is, for free (a separate column reduction re-read the 268 MB full-resolution dz of decoder.7).  Needs 256 % (4 * k/8) == 0: then a
 // thread keeps one channel group for the whole grid-stride loop.
 __global__ __launch_bounds__(256) void space_to_depth_bf16_kernel(const bf16* in, int ldi, bf16* out, int N, int h, int w, int k, float* psum) {
+    const int bidx = xcd_remap(blockIdx.x, gridDim.x);     // row-order placement convention (hn_common.h)
     __shared__ float red[256][9];
     const int k8 = k >> 3;
     const long total = (long)N * h * w * 4 * k8;
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    for (long idx = (long)bidx * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int c8 = (int)(idx % (4 * k8));
         long t = idx / (4 * k8);
         const int x = (int)(t % w);
@@ -1104,7 +1120,7 @@ __global__ __launch_bounds__(256) void space_to_depth_bf16_kernel(const bf16* in
             const int g = c >> 3, j = c & 7;
             float s = 0.f;
             for (int t = g; t < 256; t += k8) s += red[t][j];
-            psum[(long)blockIdx.x * k + c] = s;
+            psum[(long)bidx * k + c] = s;
         }
     }
 }
@@ -1115,8 +1131,9 @@ __global__ __launch_bounds__(256) void space_to_depth_bf16_kernel(const bf16* in
 // ---------------------------------------------------------------------------------------------------------
 __global__ void head_grad_kernel(const float* dy, const float* y, long rpi, long img_stride, int lds_, int Nout, bf16* dz, int ldz, long M,
                                  int sigmoid) {
+    const int bidx = xcd_remap(blockIdx.x, gridDim.x);     // row-order placement convention (hn_common.h)
     const long total = M * ldz;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    for (long idx = (long)bidx * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const long m = idx / ldz;
         const int c = (int)(idx - m * ldz);
         float v = 0.f;
@@ -1286,7 +1303,8 @@ extern "C" int hn_dwconv_wgrad_levels(const void* x, int ldx, const void* dz, in
 // one-pass backward of the depthwise conv (data gradient + weight-gradient partial rows): blocks / launch
 extern "C" long hn_dwconv_bwd_blocks(long strips, int C) {
     const int lanes = 256 / (C >> 2);
-    long spl = (strips + 767L * lanes) / (768L * lanes);          // ~768 blocks: three co-resident per CU, the lane reduction amortised
+    const long tb = g_hn_knob[7] > 0 ? g_hn_knob[7] : 768;        // ~768 blocks: three co-resident per CU, the lane reduction amortised (knob 7: sweeps)
+    long spl = (strips + (tb - 1) * lanes) / (tb * lanes);
     if (spl < 2) spl = 2;
     return (strips + spl * lanes - 1) / (spl * lanes);
 }
