@@ -647,7 +647,8 @@ __global__ void cast_f32_kernel(const bf16* src, int lds_, float* dst, int ldo, 
 template <bool FOLD>   // FOLD: `in` holds S >= 1 partial rows per image (register-heavy path); else one dense row
 __global__ __launch_bounds__(256) void se_fc_rows_kernel(const float* W, const float* bias, const float* in, float* out, int N, int O, int I,
                                                          int act, int S, float alpha, float* store) {
-    const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // image-major wave order with the row-order placement convention (hn_common.h): image n's waves run on the XCD that holds its rows
+    const long wid = (long)xcd_remap(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (wid >= (long)N * O) return;
     const int n = (int)(wid / O), o = (int)(wid - (long)n * O);
@@ -706,7 +707,9 @@ __global__ __launch_bounds__(16 * PARTS) void se_fc_cols_kernel(const float* W, 
                                                                 float* out, int N, int O, int I, int pre, int post, int S) {
     __shared__ float red[PARTS][17];
     const int ox = threadIdx.x & 15, part = threadIdx.x >> 4;         // 16 outputs x PARTS partitions of the contraction
-    const int o = blockIdx.x * 16 + ox, n = blockIdx.y;
+    const int lid = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);      // image-major, contiguous per XCD (hn_common.h)
+    const int bx = lid % gridDim.x, n = lid / gridDim.x;
+    const int o = bx * 16 + ox;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     const int i0 = (int)((long)I * part / PARTS), i1 = (int)((long)I * (part + 1) / PARTS);
     const float* inr = in + (long)n * (S > 0 ? S : 1) * I;
@@ -739,7 +742,7 @@ __global__ __launch_bounds__(16 * PARTS) void se_fc_cols_kernel(const float* W, 
                 if (ib + k < i1) {
                     const float g = auxr[ib + k];
                     v[k] *= g * (1.f - g);
-                    if (store && blockIdx.x == 0 && ox == 0) store[(long)n * I + ib + k] = v[k];
+                    if (store && bx == 0 && ox == 0) store[(long)n * I + ib + k] = v[k];
                 }
             }
         }
