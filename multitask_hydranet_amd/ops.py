@@ -754,16 +754,19 @@ class XBlockFn(torch.autograd.Function):
         # out = relu(bn3(z3) + shortcut): g = dout * [out > 0] is also the gradient of the shortcut branch
         dz3, dg3, db3, g = bn_backward_fused(dout, z3, out, coef3, ACT_RELU, m, want_g=True)
         dbg, _, _ = k_gemm_nt(dz3, None, 0, grid, wt3, c, kp32(c), 1)
+        batch = WgradBatch()                                  # the slab reduces of dw3 / dw2 / dw1 / dws: one launch at the end
+        make_bg = bg is None
+        if not make_bg:                                       # dz3's second reader right behind the first: still in the XCDs' L2s
+            dw3 = k_gemm_tn(bg, None, 0, grid, dz3, c, kp32(c), 1, c, defer=batch)
         # one pass over (dbg, z2): gate-gradient partials and the gated operand bg = relu(bn2(z2)) * gate of conv_block_3's wgrad
         rb = lib().query("hn_fused_row_block", m, c, hw, 0, 1)
-        make_bg = bg is None
         if make_bg:
             bg = new_act(n, ho, wo, c, dev)
         pdot = torch.empty(((m + rb - 1) // rb, c), device=dev, dtype=F32)
         lib().call("hn_se_bwd_reduce_fused", ptr(dbg), ld(dbg), ptr(z2), ld(z2), ptr(coef2), ptr(gate), hw, ptr(bg) if make_bg else None,
                    ld(bg), ptr(pdot), m, c, rb)
-        batch = WgradBatch()                                  # the slab reduces of dw3 / dw2 / dw1 / dws: one launch at the end
-        dw3 = k_gemm_tn(bg, None, 0, grid, dz3, c, kp32(c), 1, c, defer=batch)
+        if make_bg:
+            dw3 = k_gemm_tn(bg, None, 0, grid, dz3, c, kp32(c), 1, c, defer=batch)
         dpre2 = torch.empty((n, c), device=dev, dtype=F32)
         dpool = torch.empty((n, c), device=dev, dtype=F32)
         dpre1 = torch.empty((n, cs), device=dev, dtype=F32)
