@@ -508,7 +508,8 @@ def main():
         # optimizer step, reported separately (Adam as in model/train.py:147)
         ms_opt = None
         if not args.no_optimizer:
-            opt = torch.optim.Adam(net.parameters(), 1e-5, weight_decay=1e-8)
+            from multitask_hydranet_amd.optim import Adam       # torch.optim.Adam's rule, all tensors in one launch (HN_TORCH_ADAM=1: torch's)
+            opt = (torch.optim.Adam if os.environ.get("HN_TORCH_ADAM") else Adam)(net.parameters(), 1e-5, weight_decay=1e-8)
             for _ in range(2):
                 opt.step()
             torch.cuda.synchronize()

@@ -424,6 +424,13 @@ int hn_argmax_channels(const float* logits, int ldl, int C, long M, long* out, h
 int hn_weighted_sum(const void* const* xs, const float* w, const float* gw, const int* grp, int n, const float* gout, float* out, float* grads,
                     hipStream_t stream);
 
+/* Adam step of all parameters in one launch (torch.optim.Adam as model/train.py:147 constructs it: L2 weight decay on the gradient, bias
+ * correction, eps outside the square root; not amsgrad).  jobs (DEVICE) = n x 6 int64 {p, g, m, v (fp32 pointers), numel, first_block};
+ * a block = 256 threads x 4 consecutive elements of one tensor; block_job (DEVICE int32 [total_blocks]) = job index of every block;
+ * step = 1-based iteration count (bias corrections are computed on the host in double). */
+int hn_adam_step(const long* jobs, const int* block_job, long total_blocks, double lr, double beta1, double beta2, double eps,
+                 double weight_decay, long step, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

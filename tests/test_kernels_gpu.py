@@ -790,3 +790,34 @@ def test_wgrad_reduces_batched_in_one_launch(K):
     batch.flush()
     for g, r in zip(got, want):
         close(g, r, 1e-5, "batched reduce")
+
+
+@pytest.mark.parametrize("wd", [0.0, 1e-2])
+def test_hip_adam_tracks_torch_adam(K, wd):
+    """multitask_hydranet_amd.optim.Adam (one launch for all parameters) against torch.optim.Adam: same update rule and operation order;
+    odd sizes, a late-starting parameter (its own step count), a changing learning rate, interchangeable state_dict"""
+    from multitask_hydranet_amd.optim import Adam
+    torch.manual_seed(1)
+    shapes = [(936, 936, 1, 1), (7,), (3, 5), (1,), (64, 8, 3, 3), (1023,), (1025,)]
+    pa = [torch.nn.Parameter(torch.randn(s, device=dev())) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa = Adam(pa, 1e-2, weight_decay=wd)
+    ob = torch.optim.Adam(pb, 1e-2, weight_decay=wd)
+    for it in range(6):
+        for o in (oa, ob):
+            o.param_groups[0]["lr"] = 1e-2 / (1 + it)
+        for a, b in zip(pa, pb):
+            g = torch.randn_like(a) * (10.0 ** (it - 3))
+            a.grad = None if (it < 2 and a.numel() == 7) else g.clone()          # no gradient in the first iterations: its step starts later
+            b.grad = None if (it < 2 and b.numel() == 7) else g.clone()
+        oa.step()
+        ob.step()
+        for a, b in zip(pa, pb):
+            assert float((a - b).abs().max()) <= 2e-6 * max(float(b.abs().max()), 1e-3), (it, tuple(a.shape))
+    sa, sb = oa.state_dict()["state"], ob.state_dict()["state"]
+    for k in sb:
+        assert float(sa[k]["step"]) == float(sb[k]["step"])
+        close(sa[k]["exp_avg"], sb[k]["exp_avg"], 1e-5, "exp_avg")
+        close(sa[k]["exp_avg_sq"], sb[k]["exp_avg_sq"], 1e-5, "exp_avg_sq")
+    oc = torch.optim.Adam([torch.nn.Parameter(p.detach().clone()) for p in pa], 1e-2, weight_decay=wd)
+    oc.load_state_dict(oa.state_dict())                                           # interchangeable state
