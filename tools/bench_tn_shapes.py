@@ -19,8 +19,8 @@ def timeit(f, iters=20):
     for _ in range(5): g.replay()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / (5 * iters) * 1e3
-shapes = [(2048, 936, 936), (8192, 376, 376), (32768, 152, 152), (131072, 64, 64), (174592, 112, 112), (8192, 448, 448), (2048, 936, 232)]
-cfgs = [(0, 0, 0), (128, 128, 1), (128, 128, 2), (128, 128, 4), (64, 64, 1), (64, 64, 2), (64, 64, 4), (64, 64, 8), (64, 128, 2), (64, 128, 4), (128, 64, 2), (128, 64, 4)]
+shapes = [(2048, 936, 936), (8192, 376, 376), (8192, 368, 368), (32768, 152, 152), (2048, 936, 232), (2048, 368, 936)]
+cfgs = [(0, 0, 0), (64, 64, 3), (64, 64, 4), (64, 64, 6), (64, 64, 8), (64, 64, 12), (64, 64, 16), (64, 64, 32), (128, 64, 4), (128, 64, 8), (128, 64, 16), (64, 128, 8)]
 print("shape".ljust(24), " ".join(f"{a}x{b}/{c}".rjust(10) for a, b, c in cfgs))
 for (m, k, n) in shapes:
     x = torch.randn(1, 1, m, k, device=dev).bfloat16()
