@@ -1324,10 +1324,9 @@ extern "C" int hn_dwconv_bwd_levels(const void* dz, int ldz, const void* x, int 
     if (dx && !accumulate)
         for (int l = 0; l < L.n; ++l) pad_items += (L.row_off[l + 1] - L.row_off[l] - (long)N * L.H[l] * L.W[l]) * (C >> 3);
     const size_t lds = (256 * 37 + 9 * (size_t)C) * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute((const void*)dwconv_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((256 * 37 + 9 * 1024) * sizeof(float))) != hipSuccess) return HN_ERR_LAUNCH;
-        attr = true;
+    if (lds > 64 * 1024) {                                             // > 64 KiB of dynamic LDS: opt-in once per device (C > 727)
+        static std::atomic<unsigned long long> optin{0};
+        if (!lds_optin(optin, {(const void*)dwconv_bwd_kernel})) return HN_ERR_LAUNCH;
     }
     hipLaunchKernelGGL(dwconv_bwd_kernel, dim3((unsigned)(blocks + cdiv(pad_items, 256))), dim3(256), lds, st, (const bf16*)dz, ldz, (const bf16*)x,
                        ldx, (const bf16*)wf, (bf16*)dx, lddx, part, N, C, spl, blocks, L, accumulate);
