@@ -461,49 +461,69 @@ __global__ __launch_bounds__(256) void det_loss_fwd_kernel(const float* cls, con
 }
 
 // per image: cls = sum_cls / max(npos, 1), reg = sum_reg / max(4 npos, 1) (0 without positives); outputs = batch means; npos kept for bwd
-__global__ __launch_bounds__(64) void det_loss_finalize_kernel(const float* part, int blocks, int N, float* npos, float* out /* [2] */) {
-    __shared__ float acc[2];
-    if (threadIdx.x == 0) { acc[0] = 0.f; acc[1] = 0.f; }
-    __syncthreads();
-    for (int n = 0; n < N; ++n) {
+__global__ __launch_bounds__(1024) void det_loss_finalize_kernel(const float* part, int blocks, int N, float* npos, float* out /* [2] */) {
+    // one wave per image (16 images walked one after the other by a single wave took 30 us of dependent load rounds), images beyond 16
+    // in further passes; the batch means are summed in image order by one thread
+    __shared__ float pc[64], pr[64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float tc = 0.f, tr = 0.f;
+    for (int n0 = 0; n0 < N; n0 += 16) {
+        const int n = n0 + wave;
         float c = 0.f, r = 0.f, p = 0.f;
-        for (int b = threadIdx.x; b < blocks; b += 64) {
-            const float* q = part + ((long)n * blocks + b) * 3;
-            c += q[0]; r += q[1]; p += q[2];
-        }
+        if (n < N)
+            for (int b = lane; b < blocks; b += 64) {
+                const float* q = part + ((long)n * blocks + b) * 3;
+                c += q[0]; r += q[1]; p += q[2];
+            }
         c = wave_sum(c); r = wave_sum(r); p = wave_sum(p);
-        if (threadIdx.x == 0) {
+        __syncthreads();
+        if (lane == 0 && n < N) {
             npos[n] = p;
-            acc[0] += c / fmaxf(p, 1.f);
-            acc[1] += p > 0.f ? r / (4.f * p) : 0.f;
+            pc[wave] = c / fmaxf(p, 1.f);
+            pr[wave] = p > 0.f ? r / (4.f * p) : 0.f;
         }
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int k = 0; k < 16 && n0 + k < N; ++k) { tc += pc[k]; tr += pr[k]; }
     }
-    if (threadIdx.x == 0) { out[0] = acc[0] / N; out[1] = acc[1] / N; }
+    if (threadIdx.x == 0) { out[0] = tc / N; out[1] = tr / N; }
 }
 
 __global__ __launch_bounds__(256) void det_loss_bwd_kernel(const float* cls, const float* reg, const float* anchors, const float* ann, int N, int A,
                                                            int K, int Mx, const short* assign, const float* npos, const float* gout /* [2] */,
                                                            float* dcls, float* dreg) {
+    // the block's 256 x K probabilities / gradients are one contiguous run in memory: they move through LDS with coalesced 4-byte
+    // accesses (a thread walking its own K floats 36 bytes from its neighbour's wrote partial lines: 0.9 TB/s, 91 us per step)
+    extern __shared__ float tile[];                                    // [256][K]
     const int n = blockIdx.y;
-    const int a = blockIdx.x * 256 + threadIdx.x;
-    if (a >= A) return;
+    const int a0 = blockIdx.x * 256;
+    const int a = a0 + threadIdx.x;
+    const int nv = A - a0 < 256 ? A - a0 : 256;
+    const float* cblk = cls + ((long)n * A + a0) * K;
+    for (int i = threadIdx.x; i < nv * K; i += 256) tile[i] = cblk[i];
+    __syncthreads();
     const float p_n = npos[n];
     const float fc = gout[0] / (N * fmaxf(p_n, 1.f));
     const float fr = p_n > 0.f ? gout[1] / (N * 4.f * p_n) : 0.f;
-    const int as = assign[(long)n * A + a];
+    const int as = a < A ? assign[(long)n * A + a] : -2;
     const float* an = ann + (long)n * Mx * 5;
-    const float* c = cls + ((long)n * A + a) * K;
-    float* dc = dcls + ((long)n * A + a) * K;
-    const int cid = as >= 0 ? (int)an[as * 5 + 4] : -1;
-    for (int k = 0; k < K; ++k) {
-        float g = 0.f;
-        const float p = c[k];
-        if (as != -2 && p > 1e-4f && p < 1.f - 1e-4f) {                // the clamp has zero slope outside its range
-            if (k == cid) g = 0.25f * (2.f * (1.f - p) * __logf(p) - (1.f - p) * (1.f - p) / p);
-            else g = 0.75f * (-2.f * p * __logf(1.f - p) + p * p / (1.f - p));
+    if (a < A) {
+        float* c = tile + threadIdx.x * K;                             // (K odd or not: stride-K rows, each thread only touches its own)
+        const int cid = as >= 0 ? (int)an[as * 5 + 4] : -1;
+        for (int k = 0; k < K; ++k) {
+            float g = 0.f;
+            const float p = c[k];
+            if (as != -2 && p > 1e-4f && p < 1.f - 1e-4f) {            // the clamp has zero slope outside its range
+                if (k == cid) g = 0.25f * (2.f * (1.f - p) * __logf(p) - (1.f - p) * (1.f - p) / p);
+                else g = 0.75f * (-2.f * p * __logf(1.f - p) + p * p / (1.f - p));
+            }
+            c[k] = fc * g;
         }
-        dc[k] = fc * g;
     }
+    __syncthreads();
+    float* dblk = dcls + ((long)n * A + a0) * K;
+    for (int i = threadIdx.x; i < nv * K; i += 256) dblk[i] = tile[i];
+    if (a >= A) return;
     float* dr = dreg + ((long)n * A + a) * 4;
     if (as >= 0) {
         const float* anc = anchors + (long)a * 4;
@@ -658,14 +678,15 @@ extern "C" int hn_det_loss_fwd(const float* cls, const float* reg, const float* 
     HN_CHECK_ARG(cls && reg && anchors && ann && assign && part && npos && out && N > 0 && A > 0 && K > 0 && K <= HN_DET_MAXK && Mx > 0);
     const int blocks = hn_det_loss_blocks(A);
     hipLaunchKernelGGL(det_loss_fwd_kernel, dim3(blocks, N), dim3(256), 0, st, cls, reg, anchors, ann, A, K, Mx, (short*)assign, part);
-    hipLaunchKernelGGL(det_loss_finalize_kernel, dim3(1), dim3(64), 0, st, part, blocks, N, npos, out);
+    hipLaunchKernelGGL(det_loss_finalize_kernel, dim3(1), dim3(1024), 0, st, part, blocks, N, npos, out);
     HN_LAUNCH_CHECK();
 }
 
 extern "C" int hn_det_loss_bwd(const float* cls, const float* reg, const float* anchors, const float* ann, int N, int A, int K, int Mx,
                                const void* assign, const float* npos, const float* gout, float* dcls, float* dreg, hipStream_t st) {
     HN_CHECK_ARG(cls && reg && anchors && ann && assign && npos && gout && dcls && dreg && N > 0 && A > 0 && K > 0 && Mx > 0);
-    hipLaunchKernelGGL(det_loss_bwd_kernel, dim3(hn_det_loss_blocks(A), N), dim3(256), 0, st, cls, reg, anchors, ann, N, A, K, Mx,
+    HN_CHECK_ARG(K <= 48);                                             // 256 x K floats of LDS
+    hipLaunchKernelGGL(det_loss_bwd_kernel, dim3(hn_det_loss_blocks(A), N), dim3(256), 256 * (size_t)K * sizeof(float), st, cls, reg, anchors, ann, N, A, K, Mx,
                        (const short*)assign, npos, gout, dcls, dreg);
     HN_LAUNCH_CHECK();
 }
