@@ -500,6 +500,9 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
     loss_val = float(loss)
+    grad_norm = None
+    if os.environ.get("HN_BENCH_GRAD_NORM"):        # tests: the gradients after the (possibly in-graph) exchange of the last step
+        grad_norm = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in net.parameters() if p.grad is not None)))
     assert loss_val == loss_val and abs(loss_val) != float("inf"), "non-finite loss after the timed run"
 
     if rank == 0:
@@ -529,7 +532,7 @@ def main():
                        "resolution": "3x%dx%d" % (h, w), "parallelism": "dp%d" % world, "hipgraph": graph is not None,
                        "grad_allreduce": None if reducer is None else ("%s backend: " % backend) + reducer.describe(
                            after_replay=graph is not None and not in_graph_exchange)},
-            "ms_optimizer_step": round(ms_opt, 3) if ms_opt is not None else None, "loss": round(loss_val, 4),
+            "ms_optimizer_step": round(ms_opt, 3) if ms_opt is not None else None, "loss": round(loss_val, 4), **({"grad_norm": grad_norm} if grad_norm is not None else {}),
             "model_tflops": round(value * gflop_img / 1e3, 2),
             # SURVEY 8(d) segment-wise roofline of the whole step (seg decoder on MFMA, everything else on HBM): 0.177 ms/img at 512x1024
             "step_roofline": {"floor_ms_per_img": round(0.177 * scale, 4), "frac": round(value / world * 0.177e-3 * scale, 4)},

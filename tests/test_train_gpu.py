@@ -104,3 +104,33 @@ def test_trainer_captured_step_equals_eager(setup):
         assert torch.equal(p0[n], p1[n]), n
     for n in b0:
         assert torch.equal(b0[n], b1[n]), n
+
+
+def test_rccl_gradient_exchange_world1_in_graph():
+    """bench.py --ddp-world1: RCCL process group of one rank, bucketed ncclAvg all-reduce of the gradients captured INSIDE the hipGraph
+    on the reducer's side stream (the N > 1 code path, executed on one GPU).  The step must report the in-graph exchange and reproduce
+    the loss of the run without it (the average over one rank is the identity)."""
+    import json
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--no-optimizer", "--steps", "2", "--warmup", "1",
+            "--batch", "2", "--res", "256x512"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", HSA_ENABLE_IPC_MODE_LEGACY="0", HN_BENCH_GRAD_NORM="1")
+    outs = []
+    for extra in ([], ["--ddp-world1"], ["--ddp-world1", "--grad-payload", "bf16"]):
+        r = subprocess.run(base + extra, capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    plain, ddp, ddp16 = outs
+    assert plain["config"]["grad_allreduce"] is None
+    for o in (ddp, ddp16):
+        assert "captured inside the hipGraph" in o["config"]["grad_allreduce"], o["config"]["grad_allreduce"]
+        assert o["config"]["hipgraph"] is True
+        assert o["loss"] == plain["loss"]
+    # the exchanged gradients: fp32 payload = the plain run's gradients exactly, bf16 payload = to bf16 rounding
+    assert ddp["grad_norm"] == plain["grad_norm"], (ddp["grad_norm"], plain["grad_norm"])
+    assert abs(ddp16["grad_norm"] - plain["grad_norm"]) <= 5e-3 * plain["grad_norm"]
+    assert "bfloat16" in ddp16["config"]["grad_allreduce"]
