@@ -134,3 +134,26 @@ def test_rccl_gradient_exchange_world1_in_graph():
     assert ddp["grad_norm"] == plain["grad_norm"], (ddp["grad_norm"], plain["grad_norm"])
     assert abs(ddp16["grad_norm"] - plain["grad_norm"]) <= 5e-3 * plain["grad_norm"]
     assert "bfloat16" in ddp16["config"]["grad_allreduce"]
+
+
+def test_two_rank_control_flow_on_one_gpu():
+    """the N > 1 launch contract of bench.py (torch.distributed.run, one process per rank, barrier + max-over-ranks timing, rank 0 prints
+    the JSON line) with the two test hooks that make it runnable on a 1-GPU box: both ranks on cuda:0, gloo instead of RCCL (which refuses
+    two ranks on one device).  The gradient exchange then runs after each replay (only RCCL collectives are captured in the graph)."""
+    import json
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29561",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--no-cpu-baseline", "--no-optimizer", "--steps", "2", "--warmup", "1", "--batch", "2",
+           "--res", "256x512"]
+    env = dict(os.environ, HN_BENCH_ONE_DEVICE="1", HN_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1]
+    o = json.loads(line)
+    assert o["n_gpus"] == 2 and o["config"]["global_batch"] == 4 and o["config"]["parallelism"] == "dp2" and o["scaling"] == "weak"
+    assert "gloo" in o["config"]["grad_allreduce"]
+    assert o["value"] > 0 and o["loss"] == o["loss"]
