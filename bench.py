@@ -362,10 +362,15 @@ def main():
     skip = UNUSED_5STAGE if len(net.depths) == 5 else ()
 
     def make_reducer(**kw):
+        if os.environ.get("HN_BUCKET_MB"):                                   # tools/ sweeps of the exchange granularity
+            kw["bucket_bytes"] = int(float(os.environ["HN_BUCKET_MB"]) * (1 << 20))
         return GradReducer(list(net.named_parameters()), world_size=world, skip=skip, payload_dtype=payload,
                            force_collectives=args.ddp_world1, **kw)
     if exchange:
-        reducer = make_reducer()
+        # captured exchange: every bucket is a branch of the hipGraph, and a branch costs ~0.35 ms of step time on this runtime (world 1,
+        # same box: 7 buckets 620-640 img/s, 4: 655, 2: 671, 1: 693, no exchange: 712) -- two ~86 MB buckets keep the first half of the
+        # all-reduce under the backbone backward; eager hook mode keeps DDP's 25 MiB granularity
+        reducer = make_reducer(bucket_bytes=96 << 20) if use_graph and not args.exchange_after_replay else make_reducer()
 
     one = torch.ones((), device=dev)                # d loss / d loss, allocated once (loss.backward() alone fills a fresh one every step)
 

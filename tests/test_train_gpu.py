@@ -26,6 +26,13 @@ def setup():
     return z, cfgs, batch
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
 def test_trainer_steps_and_validation(setup):
     from multitask_hydranet_amd.train import HydraTrainer
     z, cfgs, batch = setup
@@ -118,12 +125,12 @@ def test_rccl_gradient_exchange_world1_in_graph():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     base = [sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--no-optimizer", "--steps", "2", "--warmup", "1",
             "--batch", "2", "--res", "256x512"]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", HSA_ENABLE_IPC_MODE_LEGACY="0", HN_BENCH_GRAD_NORM="1")
     outs = []
     for extra in ([], ["--ddp-world1"], ["--ddp-world1", "--grad-payload", "bf16"]):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0", HN_BENCH_GRAD_NORM="1")
         r = subprocess.run(base + extra, capture_output=True, text=True, env=env, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
-        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+        outs.append(json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1]))
     plain, ddp, ddp16 = outs
     assert plain["config"]["grad_allreduce"] is None
     for o in (ddp, ddp16):
@@ -146,7 +153,7 @@ def test_two_rank_control_flow_on_one_gpu():
     if not torch.cuda.is_available():
         pytest.skip("needs the MI355X")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29561",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(root, "bench.py"), "--gpus", "2", "--no-cpu-baseline", "--no-optimizer", "--steps", "2", "--warmup", "1", "--batch", "2",
            "--res", "256x512"]
     env = dict(os.environ, HN_BENCH_ONE_DEVICE="1", HN_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
