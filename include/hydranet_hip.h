@@ -431,6 +431,11 @@ int hn_weighted_sum(const void* const* xs, const float* w, const float* gw, cons
 int hn_adam_step(const long* jobs, const int* block_job, long total_blocks, double lr, double beta1, double beta2, double eps,
                  double weight_decay, long step, hipStream_t stream);
 
+/* Many contiguous tensors copied in one launch (the gather of a gradient bucket before its all-reduce, train.py:130-137's DDP buckets):
+ * jobs (DEVICE) = n x 4 int64 {src, dst, numel, first_block}, block = 256 threads x 4 elements, block_job (DEVICE int32) = job of every
+ * block; kind 0: fp32 -> fp32, 1: fp32 -> bf16 (reduced-precision payload), 2: bf16 -> fp32. */
+int hn_copy_many(const long* jobs, const int* block_job, long total_blocks, int kind, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

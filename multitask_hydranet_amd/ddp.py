@@ -110,17 +110,65 @@ class GradReducer:
                 self._launch(b)
         return hook
 
+    def _copy_many(self, b, key, dsts, srcs, kind):
+        """dsts[i] <- srcs[i] for all i in ONE launch on the device (hn_copy_many; the job table is cached while the pointers stay the same --
+        always, for the static tensors of a captured step); torch._foreach_copy_ elsewhere (CPU tensors of the gloo tests, mixed layouts)"""
+        ok = self.on_gpu and all(d.is_cuda and s.is_cuda and d.is_contiguous() and s.is_contiguous() and d.numel() == s.numel()
+                                 for d, s in zip(dsts, srcs))
+        if not ok:
+            torch._foreach_copy_(dsts, srcs)
+            return
+        sig = tuple((s.data_ptr(), d.data_ptr()) for d, s in zip(dsts, srcs))
+        nblk = sum((d.numel() + 1023) // 1024 for d in dsts)
+        plan = b.get(key)
+        if plan is None or plan["cap"][0] < len(dsts) or plan["cap"][1] < nblk:
+            if torch.cuda.is_current_stream_capturing():
+                torch._foreach_copy_(dsts, srcs)            # (pinned allocations are not allowed inside a capture: the eager warm-up makes them)
+                return
+            dev = dsts[0].device
+            plan = dict(cap=(len(dsts), nblk), sig=None,
+                        hrows=torch.empty((len(dsts), 4), dtype=torch.int64).pin_memory(), howner=torch.empty((nblk,), dtype=torch.int32).pin_memory(),
+                        drows=torch.empty((len(dsts), 4), dtype=torch.int64, device=dev), downer=torch.empty((nblk,), dtype=torch.int32, device=dev))
+            b[key] = plan
+        if plan["sig"] != sig:
+            rows, owner, blk = [], [], 0
+            for i, (d, s) in enumerate(zip(dsts, srcs)):
+                nb = (d.numel() + 1023) // 1024
+                rows.append([s.data_ptr(), d.data_ptr(), d.numel(), blk])
+                owner += [i] * nb
+                blk += nb
+            # the pinned host tables are filled by the host; the uploads are stream operations -- inside a capture (the graph-private
+            # gradient tensors are only known then) two small memcpy nodes that every replay repeats from the same pinned memory
+            if torch.cuda.is_current_stream_capturing():
+                plan["hrows"][:len(rows)] = torch.tensor(rows, dtype=torch.int64)
+                plan["howner"][:blk] = torch.tensor(owner, dtype=torch.int32)
+                plan["drows"].copy_(plan["hrows"], non_blocking=True)
+                plan["downer"].copy_(plan["howner"], non_blocking=True)
+            else:                                           # eager: blocking uploads (the pinned tables may still feed an earlier copy)
+                plan["drows"][:len(rows)].copy_(torch.tensor(rows, dtype=torch.int64))
+                plan["downer"][:blk].copy_(torch.tensor(owner, dtype=torch.int32))
+            plan["sig"], plan["blk"] = sig, blk
+        from ._lib import lib
+        lib().call("hn_copy_many", plan["drows"].data_ptr(), plan["downer"].data_ptr(), plan["blk"], kind)
+
     def _gather(self, b):
-        """bring the bucket's gradients into its flat payload buffer (multi-tensor copy; converts when the payload is bf16)"""
+        """bring the bucket's gradients into its flat payload buffer (one multi-tensor launch; converts when the payload is bf16)"""
         src = b["src"] if b["src"] is not None else [p.grad for _, p in b["params"]]
         need = [(v, s) for v, s in zip(b["views"], src) if s.data_ptr() != v.data_ptr()]
         if need:
-            torch._foreach_copy_([v for v, _ in need], [s for _, s in need])
+            dsts, srcs = [v for v, _ in need], [s for _, s in need]
+            same = all(d.dtype == s.dtype for d, s in need)
+            if same and dsts[0].dtype == torch.float32:
+                self._copy_many(b, "plan_gather", dsts, srcs, 0)
+            elif all(d.dtype == torch.bfloat16 and s.dtype == torch.float32 for d, s in need):
+                self._copy_many(b, "plan_gather", dsts, srcs, 1)
+            else:
+                torch._foreach_copy_(dsts, srcs)
 
     def _scatter(self, b):
         """after the exchange: .grad = averaged values (a view of the bucket, or of the fp32 landing buffer for a reduced payload)"""
         if b["land"] is not None:
-            torch._foreach_copy_(b["land"], b["views"])
+            self._copy_many(b, "plan_land", b["land"], b["views"], 2)
         dst = b["land"] if b["land"] is not None else b["views"]
         for (n, p), v in zip(b["params"], dst):
             p.grad = v
@@ -148,7 +196,7 @@ class GradReducer:
                 self._gather(b)
                 self._allreduce_mean(b["flat"])
                 if b["land"] is not None:
-                    torch._foreach_copy_(b["land"], b["views"])
+                    self._copy_many(b, "plan_land", b["land"], b["views"], 2)
                 done = torch.cuda.Event()
                 done.record(self.stream)
             b["event"] = done
@@ -180,7 +228,7 @@ class GradReducer:
                     if self.world > 1:
                         b["flat"].mul_(1.0 / self.world)
                     if b["land"] is not None:
-                        torch._foreach_copy_(b["land"], b["views"])
+                        self._copy_many(b, "plan_land", b["land"], b["views"], 2)
                     b["work"] = None
             b["pending"] = len(b["params"])
 
