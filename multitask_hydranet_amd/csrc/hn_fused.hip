@@ -450,12 +450,15 @@ static int chunk_count(int C) { const int cw = chunk_width(C); return (C + cw - 
 // Rows per row block (policy measured with tools/bench_fused.py on MI355X).
 //   kind 0 (apply passes, forward and backward): ~1000 workgroups over (chunks x row blocks), RB a power of two in [32, 1024]; larger when
 //           the prologue has many partial rows to reduce (P > 128);
-//   kind 1 (reduce passes: their row-block count is the P of the apply that follows): RB = max(128, M / 512).
+//   kind 1 (reduce passes: their row-block count is the P of the apply that follows): RB = clamp(M / 128, 32, 128), then max(.., M / 512).
 // With align (rows per image) RB divides align and is >= align / 8 (<= 8 SE partial rows per image).
 extern "C" long hn_fused_row_block(long M, int C, long align, int P, int kind) {
     long RB;
     if (kind == 1) {
-        RB = 128;
+        // 32 ... 128 rows for the few-row tensors of the deep stages (2048 rows: 64 blocks per chunk instead of 16 -- one load round per
+        // thread, still <= 128 partial rows for the apply prologue; 709 -> 714 img/s), 128 and up for the large ones
+        RB = 32;
+        while (RB < 128 && RB * 128 < M) RB <<= 1;
         while (RB * g_hn_knob[3] < M) RB <<= 1;
     } else {
         const long want = (M * chunk_count(C) + g_hn_knob[2] - 1) / g_hn_knob[2];
