@@ -2197,6 +2197,8 @@ static int wgrad_plan_impl(int mode, int n_img, int H, int W, long M, int Nout, 
     tn_tiles(Nout, KP, bc, bn);
     const long tiles = (long)cdiv(Nout, bc) * cdiv(KP, bn) * taps;
     long want = (g_hn_knob[0] + tiles - 1) / tiles;         // ~4 workgroups per CU in total
+    if (tiles <= 2) want = 512 / tiles;                     // one or two output tiles (the 112-channel convs of the neck / det towers): every split costs a
+                                                            // whole fp32 slab -- two workgroups per CU instead of four (+0.3 % on the step; 256 and 768 are worse)
     const long max_splits = (M + g_hn_knob[1] - 1) / g_hn_knob[1];   // at least 256 rows per split
     if (want > max_splits) want = max_splits;
     if (g_tn_force_splits) want = g_tn_force_splits;
