@@ -377,5 +377,5 @@ def test_eval_end_to_end_vs_unmirrored_fp32_oracle(big):
         assert v["l2_hip_vs_fp32"] <= EVAL_GAP_FACTOR * gap + EVAL_TOL_ABS, (k, v)
         assert v["l2_hip_vs_mirror"] <= EVAL_GAP_FACTOR_PAIR * gap + EVAL_TOL_ABS, (k, v)
     assert res["feat0"]["hip_vs_fp32"] <= EVAL_TOL_SHALLOW and res["feat1"]["hip_vs_fp32"] <= EVAL_TOL_SHALLOW
-    assert res["seg_mask_agreement"]["hip_vs_fp32"] >= res["seg_mask_agreement"]["mirror_vs_fp32"] - 0.03
+    assert res["seg_mask_agreement"]["hip_vs_fp32"] >= res["seg_mask_agreement"]["mirror_vs_fp32"] - 0.05     # (two chaotic realisations: 0.80 +- 0.02)
     assert torch.equal(dep[0], torch.argmax(out["seg"], 1))                   # the HIP arg-max is bit-exact on the HIP logits
