@@ -335,6 +335,9 @@ int hn_se_mlp_bwd(const float* dgate, const float* gate, const float* hid, const
                   float* dpre2, float* dpre1, float* dpool, float* dw1, float* db1, float* dw2, float* db2, int N, int C, int Cs,
                   hipStream_t stream);
 
+/* out += b0 [+ b1] [+ b2] (bf16 [M][C] tensors, fp32 sum, one rounding): the gradient sum of a multi-consumer map whose consumers return
+ * separate gradients (ops.Share.backward; net/bifpn.py outputs feed three heads) in one launch instead of one per extra consumer */
+int hn_add_n(void* out, int ldo, const void* b0, int ld0, const void* b1, int ld1, const void* b2, int ld2, long M, int C, hipStream_t stream);
 /* op 0: a+b, 1: a*act'(b = post-activation; ELU/ReLU), 2: alpha*a, 3: act(a), 4: a*act'(b = pre-activation) */
 int hn_eltwise(int op, const void* a, int lda, const void* b, int ldb, void* out, int ldo, long M, int C, int act, float alpha,
                hipStream_t stream);

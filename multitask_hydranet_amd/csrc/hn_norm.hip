@@ -1033,6 +1033,35 @@ extern "C" int hn_eltwise(int op, const void* a, int lda, const void* b, int ldb
     HN_LAUNCH_CHECK();
 }
 
+// out += b0 [+ b1] [+ b2] in one pass (fp32 sum, one bf16 rounding): the gradient of a tensor with several consumers that do not
+// accumulate in place themselves (ops.Share: the last BiFPN cell's maps feed the seg, det and lane heads) -- pairwise adds were one
+// launch and one rounding per extra consumer
+__global__ __launch_bounds__(256) void add_n_kernel(bf16* out, int ldo, const bf16* b0, int ld0, const bf16* b1, int ld1, const bf16* b2, int ld2,
+                                                    long M, int C) {
+    const int bidx = xcd_remap(blockIdx.x, gridDim.x);     // row-order placement convention (hn_common.h)
+    const int C8 = C >> 3;
+    const long total = M * C8;
+    for (long idx = (long)bidx * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long m = idx / C8;
+        const int c = (int)(idx - m * C8) * 8;
+        const bf16x8 vo = ld8(out + m * ldo + c), v0 = ld8(b0 + m * ld0 + c);
+        bf16x8 v1 = zero8(), v2 = zero8();
+        if (b1) v1 = ld8(b1 + m * ld1 + c);
+        if (b2) v2 = ld8(b2 + m * ld2 + c);
+        bf16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = f2bf(((bf2f(vo[k]) + bf2f(v0[k])) + bf2f(v1[k])) + bf2f(v2[k]));
+        st8(out + m * ldo + c, o);
+    }
+}
+extern "C" int hn_add_n(void* out, int ldo, const void* b0, int ld0, const void* b1, int ld1, const void* b2, int ld2, long M, int C,
+                        hipStream_t st) {
+    HN_CHECK_ARG(out && b0 && M > 0 && (C & 7) == 0 && ((ldo | ld0) & 7) == 0 && (!b1 || (ld1 & 7) == 0) && (!b2 || (b1 && (ld2 & 7) == 0)));
+    hipLaunchKernelGGL(add_n_kernel, dim3(ew_grid(M * (C >> 3))), dim3(256), 0, st, (bf16*)out, ldo, (const bf16*)b0, ld0, (const bf16*)b1, ld1,
+                       (const bf16*)b2, ld2, M, C);
+    HN_LAUNCH_CHECK();
+}
+
 extern "C" int hn_add_strided2(void* dx, int ldx, const void* dxs, int lds_, int N, int Ho, int Wo, int C, hipStream_t st) {
     HN_CHECK_ARG(dx && dxs && N > 0 && Ho > 0 && Wo > 0 && (C & 7) == 0 && ((ldx | lds_) & 7) == 0);
     hipLaunchKernelGGL(add_strided2_kernel, dim3(ew_grid((long)N * Ho * Wo * (C >> 3))), dim3(256), 0, st, (bf16*)dx, ldx,

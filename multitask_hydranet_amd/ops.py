@@ -1047,14 +1047,16 @@ class Share(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         buf, ctx.slot.buf = ctx.slot.buf, None
-        for g in grads:
-            if g is None:
-                continue
-            if buf is None:
-                buf = dense(g)
-            else:
-                g = dense(g)
-                k_eltwise(0, buf, g, out=buf)
+        gs = [dense(g) for g in grads if g is not None]
+        if buf is None and gs:
+            buf = gs.pop(0)
+            if gs and buf.data_ptr() in [g.data_ptr() for g in gs]:     # (never: every consumer returns its own tensor)
+                buf = buf.clone()
+        while gs:                                                   # up to three addends per launch, fp32 sum, one rounding
+            part, gs = gs[:3], gs[3:]
+            part += [None] * (3 - len(part))
+            lib().call("hn_add_n", ptr(buf), ld(buf), ptr(part[0]), ld(part[0]), ptr(part[1]), ld(part[1]) if part[1] is not None else 0,
+                       ptr(part[2]), ld(part[2]) if part[2] is not None else 0, rows(buf), buf.shape[3])
         return buf, None, None
 
 

@@ -220,9 +220,9 @@ def test_shared_gradient_slots(K, order):
     def run(shared):
         xk = nhwc(x).requires_grad_(True)
         if shared:
-            (x0, x1, x2, x3), slot = K.share(xk, 4)
+            (x0, x1, x2, x3, x4, x5), slot = K.share(xk, 6)
         else:
-            (x0, x1, x2, x3), slot = (xk,) * 4, None
+            (x0, x1, x2, x3, x4, x5), slot = (xk,) * 6, None
         pk = [p.clone().requires_grad_(True) for p in ps]
         nodes = [lambda: K.Fuse.apply(pk[0], 1, 1, 0, x0, nhwc(b_same), None, (slot, None, None)),
                  lambda: K.Fuse.apply(pk[1], 1, 1, 2, nhwc(a_hi), nhwc(b_hi), x1, (None, None, slot)),
@@ -230,8 +230,9 @@ def test_shared_gradient_slots(K, order):
         outs = [None] * 3
         for i in ([0, 1, 2] if order == 0 else [2, 0, 1]):      # backward visits the nodes in reverse creation order
             outs[i] = nodes[i]()
-        plain = x3 * 0.5                                        # a consumer without slot support: its gradient is added by Share.backward
-        loss = sum((o.float() * nhwc(u).float()).sum() for o, u in zip(outs, ups[:3])) + (plain.float() * nhwc(ups[3]).float()).sum()
+        # consumers without slot support: their gradients are added by Share.backward (hn_add_n: up to three per launch)
+        plain = x3 * 0.5, x4 * 0.25, x5 * -1.5
+        loss = sum((o.float() * nhwc(u).float()).sum() for o, u in zip(outs, ups[:3])) + sum((q.float() * nhwc(ups[3]).float()).sum() for q in plain)
         loss.backward()
         assert slot is None or slot.buf is None, "Share.backward hands the buffer over and resets the slot"
         return xk.grad.float(), [p.grad.clone() for p in pk]
