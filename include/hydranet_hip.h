@@ -225,6 +225,15 @@ int hn_conv_gemm_tn_phase(const void* x0, int n_img, int H, int W, int C0, int l
 int hn_conv_gemm_tn_deferred(const void* x0, const void* x1, int mode, int n_img, int H, int W, int C0, int C1, int ld0, int ld1, int up, long M,
                              const void* dz, int ldz, int Nout, int KP, int taps, float* workspace, float* dw, long* job, hipStream_t stream);
 int hn_wgrad_reduce_jobs(const long* jobs, int njobs, hipStream_t stream);
+/* Deferred, grouped 1x1 weight gradients: up to 32 independent dw_j [Nout][Cin] (fp32) = dz_j^T . x_j in ONE GEMM launch (+ one slab-reduce
+ * launch only when the jobs cannot fill the chip without a pixel split).  Replaces, for a whole backbone stage, the per-conv weight
+ * gradients autograd's convolution_backward produces one by one (reference: conv_block_1 / conv_block_3 / shortcut of every XBlock,
+ * net/anynet.py:29-33,52-60).  jobs: HOST table, 12 int64 per job {x0, dz, dw, mode, n_img, H, W, Cin, ld0, ldz, Nout, M}: x0 bf16 rows
+ * (row stride ld0), dz bf16 [M][ldz], dw fp32 [Nout][Cin] out; mode 0: x rows = dz rows; mode 1: x is the [n_img][2H][2W] input of a
+ * stride-2 1x1 conv with output grid [n_img][H][W] (M = n_img*H*W).  workspace: hn_wgrad_group_ws_bytes() bytes (-1: bad job table). */
+long hn_wgrad_group_ws_bytes(const long* jobs, int njobs);
+int hn_wgrad_group(const long* jobs, int njobs, float* workspace, hipStream_t stream);
+
 /* hn_conv_gemm_tn (any mode but the grouped mode 5) that also returns the conv's bias gradient dbias [Nout] = column sums of dz (ConvBlock /
  * Conv3x3 bias, head_seg/segmentation.py:40-58; head output convs): one extra MFMA per k-step against an all-ones operand while the dz
  * fragments are in registers; the launch that reduces the weight-gradient slabs reduces the bias partials.
@@ -362,6 +371,14 @@ int hn_seg_loss_bwd(const float* logits, int ldl, int C, const void* target, int
 int hn_seg_loss_bwd_s2d(const float* logits, int ldl, int C, const void* target, int target_is_float, const float* class_weights,
                         int ignore_index, int N, int H, int W, int use_topk, long k, const void* ws, const float* gout, void* dz, int ldz,
                         hipStream_t stream);
+/* Focal variant of the seg loss (CrossEntropyLoss.forward with use_focal, head_seg/segmentation_loss.py:31-46; cfgs/hydranet_joint_small_backbone.yml):
+ * p = softmax + 1e-8, t = one_hot + 1e-8, loss = mean over all N*HW pixels of sum_c t_c * (-alpha (1-p_c)^gamma log(p_c) w_c).  logits fp32
+ * [N*HW][ldl], target float32 / int64 class ids (no ignore_index on this path, as in the reference); ws: fp32 [hn_seg_loss_blocks(N, HW)]. */
+int hn_seg_loss_blocks(int N, long HW);
+int hn_seg_focal_fwd(const float* logits, int ldl, int C, const void* target, int target_is_float, const float* class_weights, float gamma,
+                     float alpha, int N, long HW, void* ws, float* out, hipStream_t stream);
+int hn_seg_focal_bwd(const float* logits, int ldl, int C, const void* target, int target_is_float, const float* class_weights, float gamma,
+                     float alpha, int N, long HW, const float* gout, float* dlogits, int ldd, hipStream_t stream);
 /* Detection loss (FocalLoss.forward, head_detect/detection_loss.py:132-267): cls fp32 [N][A][K] (post-sigmoid), reg [N][A][4], anchors
  * [A][4] (y1,x1,y2,x2), ann [N][Mx][5] (x1,y1,x2,y2,class; rows with class -1 are padding).  out[0] / out[1] = batch-mean classification /
  * regression loss.  assign: int16 [N][A]; part: fp32 [N][hn_det_loss_blocks(A)][3]; npos: fp32 [N] (all written by fwd, read by bwd). */
@@ -403,7 +420,7 @@ int hn_det_postprocess(const float* anchors, const float* regression, const floa
 
 /* Lane decode + lane NMS (LaneHeader.decode, head_lane/lanedetect.py:103-116 = softmax + LaneCodec.decode_lane, lane_codec.py:116-219 +
  * nms_with_pos, lane_codec_utils.py:487-543) for a batch: one workgroup per image.  predict_cls fp32 [N][hw][2] (logits), predict_loc fp32
- * [N][hw][2*ppl+2], hw = (W/stride)*(H/stride) <= 1024.  Outputs: X [N][hw][ppl] = x of anchor a at line position p (start[a] <= p < end[a]),
+ * [N][hw][2*ppl+2], hw = (W/stride)*(H/stride) <= 7168 (anchors are walked with a workgroup stride; 1152x1920 has 2160).  Outputs: X [N][hw][ppl] = x of anchor a at line position p (start[a] <= p < end[a]),
  * prob / start / end [N][hw] per anchor, order [N][hw] = candidates in descending-prob order (counts[n] of them), keep [N][hw] = 1 for the
  * candidates that survive. */
 int hn_lane_decode_nms(const float* predict_cls, const float* predict_loc, int N, int W, int H, int stride, int ppl, float exist_threshold,

@@ -995,6 +995,8 @@ struct GemmTN {
                       // non-zero effective weights on 4 of the 9 taps, the other five are skipped (their slab entries stay zero)
     float* bias_part; // patch wgrad only (optional): [slabs][Nout] per-slab column sums of dZ (= the conv's bias gradient), accumulated by
                       // one extra MFMA per k-step against an all-ones operand while the dZ fragments are in registers anyway
+    int out_ld;       // gemm_tn: 0 = partial slabs [split][Nout][taps*KP]; > 0 = ONE split writing the gradient itself, row stride out_ld
+    int cin_lim;      //          (= Cin of a 1x1 conv: dw[co][ci]), columns >= cin_lim (the K padding) are dropped
 };
 
 // LDS image of a pixel-major tile: rows of COLS bf16, UNPADDED (LDS-DMA writes lane-linear 1 KiB runs), 16-byte pieces XOR-swizzled so
@@ -1007,7 +1009,7 @@ __device__ __forceinline__ int tn_swz(int row, int piece) {
 }
 
 template <int BC, int BN, int WGC, int WGN>
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {   // <= 256 VGPRs: two workgroups per CU overlap issue / wait / MFMA
+__device__ __forceinline__ void gemm_tn_body(const GemmTN& p, const int lid) {   // lid: logical block id inside this GEMM (see below)
     constexpr int WC = BC / WGC, WN = BN / WGN, TC = WC / 16, TN = WN / 16;
     constexpr int ZPR = BC / 8, XPR = BN / 8;                     // 16-byte pieces per row
     constexpr int ZL = (64 * ZPR + 255) / 256, XL = (64 * XPR + 255) / 256;
@@ -1017,7 +1019,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {   // 
     const int wc = wave / WGN, wn = wave % WGN;
     const int ntile = (p.KP + BN - 1) / BN;
     // logical block id: (tap, ci tile) fastest, then cout tile, then pixel split -- the blocks of one split share dZ / X rows in one L2
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int gx = ntile * p.taps;
     const int bx = lid % gx, by = (lid / gx) % p.gy, bz = lid / (gx * p.gy);
     const int tap = bx / ntile;
@@ -1188,19 +1189,54 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {   // 
             }
     }
     const int Ktot = p.taps * p.KP;
+    const int row_ld = p.out_ld ? p.out_ld : Ktot, ci_lim = p.out_ld ? p.cin_lim : p.KP;
     float* part = p.part + (long)bz * p.Nout * Ktot;
 #pragma unroll
     for (int i = 0; i < TC; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int ci = ci_blk + wn * WN + j * 16 + (lane & 15);
-            if (ci >= p.KP) continue;
+            if (ci >= ci_lim) continue;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = c_blk + wc * WC + i * 16 + (lane >> 4) * 4 + r;
-                if (co < p.Nout) part[(long)co * Ktot + tap * p.KP + ci] = acc[i][j][r];
+                if (co < p.Nout) part[(long)co * row_ld + tap * p.KP + ci] = acc[i][j][r];
             }
         }
+}
+
+template <int BC, int BN, int WGC, int WGN>
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {   // <= 256 VGPRs: two workgroups per CU overlap issue / wait / MFMA
+    gemm_tn_body<BC, BN, WGC, WGN>(p, xcd_remap(blockIdx.x, gridDim.x));
+}
+
+// Several independent 1x1 weight gradients in ONE launch (hn_wgrad_group): the weight gradients of a whole backbone stage are not on the
+// backward pass's critical path, so they are deferred to the stage boundary and run together -- one launch that fills the chip (a
+// stage-4 gradient alone is 64 tiles of 128 x 128 over 2048 rows) instead of ~3 launches + 1 slab reduce per XBlock, mostly without a
+// pixel split (so without slabs and without a reduce pass: the tiles write the fp32 gradient itself).  Jobs travel by value in the
+// kernel arguments (nothing to upload inside a captured hipGraph).
+#define HN_TN_GROUP_MAX 32
+struct TNJob {
+    const bf16* x0; const bf16* dz; float* part;
+    long M, rows_per_split;
+    int mode, H, W, Hi, Wi, C0, ld0, ldz, Nout, KP, gy, first_block, out_ld;
+};
+struct TNJobs { TNJob j[HN_TN_GROUP_MAX]; int n; };
+
+template <int BC, int BN, int WGC, int WGN>
+__global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(const TNJobs jobs) {
+    // XCD-aware order over the WHOLE launch: consecutive logical ids (tiles of one job that share dZ / X rows) run on one XCD
+    const int glid = xcd_remap(blockIdx.x, gridDim.x);
+    int ji = 0;
+    for (int k = 1; k < jobs.n; ++k)
+        if (glid >= jobs.j[k].first_block) ji = k;
+    const TNJob& jb = jobs.j[ji];
+    GemmTN p;
+    p.x.x0 = jb.x0; p.x.x1 = nullptr; p.x.mode = jb.mode; p.x.H = jb.H; p.x.W = jb.W; p.x.Hi = jb.Hi; p.x.Wi = jb.Wi;
+    p.x.C0 = jb.C0; p.x.C1 = 0; p.x.ld0 = jb.ld0; p.x.ld1 = 0; p.x.up = 0; p.x.M = jb.M; p.x.clamp = 0; p.x.diag = 0;
+    p.dz = jb.dz; p.ldz = jb.ldz; p.Nout = jb.Nout; p.KP = jb.KP; p.taps = 1; p.part = jb.part; p.rows_per_split = jb.rows_per_split;
+    p.gy = jb.gy; p.phase_span = 0; p.bias_part = nullptr; p.out_ld = jb.out_ld; p.cin_lim = jb.C0;
+    gemm_tn_body<BC, BN, WGC, WGN>(p, glid - jb.first_block);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -2253,6 +2289,126 @@ extern "C" int hn_wgrad_reduce_jobs(const long* jobs, int njobs, hipStream_t st)
     HN_LAUNCH_CHECK();
 }
 
+// ---- deferred, grouped 1x1 weight gradients ------------------------------------------------------------------------------------------
+struct RJobsN { RJob j[HN_TN_GROUP_MAX]; int n; };
+__global__ __launch_bounds__(256) void wgrad_reduce_group_kernel(const RJobsN jobs) {
+    __shared__ float red[8][33];
+    int ji = 0;
+    for (int k = 1; k < jobs.n; ++k)
+        if ((long)blockIdx.x >= jobs.j[k].first_block) ji = k;
+    const RJob& jb = jobs.j[ji];
+    const long blk = (long)blockIdx.x - jb.first_block;
+    if (jb.kind == 0) reduce4_body(jb.part, jb.dw, jb.splits, jb.Nout, jb.Cin, jb.KP, jb.taps, blk);
+    else reduce_lanes_body(jb.part, jb.dw, jb.splits, jb.Nout, jb.Cin, jb.KP, jb.taps, blk, red);
+}
+
+#define HN_WG_FIELDS 12
+struct GroupPlan {
+    int bc, bn;
+    int splits[HN_TN_GROUP_MAX];
+    long rps[HN_TN_GROUP_MAX];
+    long ws_off[HN_TN_GROUP_MAX];      // float offset of the job's slabs in the workspace (splits > 1 only)
+    long ws_floats;
+};
+// jobs: host table, HN_WG_FIELDS int64 per job: {x0, dz, dw, mode (0 | 1), n_img, H, W, Cin, ld0, ldz, Nout, M}
+static int wgrad_group_plan(const long* jobs, int njobs, GroupPlan& g) {
+    HN_CHECK_ARG(jobs && njobs > 0 && njobs <= HN_TN_GROUP_MAX);
+    int max_nout = 0, max_kp = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const long* jb = jobs + HN_WG_FIELDS * i;
+        const int mode = (int)jb[3], cin = (int)jb[7], nout = (int)jb[10];
+        const long M = jb[11];
+        HN_CHECK_ARG(jb[0] && jb[1] && jb[2] && (mode == 0 || mode == 1) && cin > 0 && (cin & 7) == 0 && nout > 0 && M > 0 &&
+                     (jb[8] & 7) == 0 && (jb[9] & 7) == 0 && jb[9] >= ((nout + 7) & ~7));
+        HN_CHECK_ARG(mode == 0 || jb[4] * jb[5] * jb[6] == M);
+        if (nout > max_nout) max_nout = nout;
+        const int kp = (cin + 31) & ~31;
+        if (kp > max_kp) max_kp = kp;
+    }
+    // ONE tile shape per launch, picked for the largest job (the smaller ones of a stage -- its first block's narrower inputs -- pad)
+    tn_tiles(max_nout, max_kp, g.bc, g.bn);
+    long tiles = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const long* jb = jobs + HN_WG_FIELDS * i;
+        tiles += (long)cdiv(jb[10], g.bc) * cdiv(((int)jb[7] + 31) & ~31, g.bn);
+    }
+    // pixel splits only while the launch would not fill the chip (~4 workgroups per CU, as hn_wgrad_plan): every split costs an fp32 slab
+    long want = (g_hn_knob[0] + tiles - 1) / tiles;
+    g.ws_floats = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const long* jb = jobs + HN_WG_FIELDS * i;
+        const long M = jb[11];
+        long w = want;
+        const long max_splits = (M + g_hn_knob[1] - 1) / g_hn_knob[1];
+        if (w > max_splits) w = max_splits;
+        if (w < 1) w = 1;
+        const long rps = ((M + w - 1) / w + 63) / 64 * 64;
+        g.splits[i] = (int)((M + rps - 1) / rps);
+        g.rps[i] = rps;
+        g.ws_off[i] = g.ws_floats;
+        if (g.splits[i] > 1) g.ws_floats += (long)g.splits[i] * jb[10] * (((int)jb[7] + 31) & ~31);
+    }
+    return HN_OK;
+}
+extern "C" long hn_wgrad_group_ws_bytes(const long* jobs, int njobs) {
+    GroupPlan g;
+    if (wgrad_group_plan(jobs, njobs, g) != HN_OK) return -1;
+    return g.ws_floats * 4 + 64;
+}
+/* Up to 32 independent 1x1-conv weight gradients dw_j[Nout][Cin] (fp32) = dz_j^T [Nout x M] . x_j [M x Cin] in one GEMM launch (+ one slab
+ * reduce launch when the jobs are too few to fill the chip without a pixel split).  jobs: HOST table, 12 int64 per job (see above):
+ * mode 0: x rows = dz rows; mode 1: x is the [n_img][2H][2W] input of a stride-2 1x1 conv whose output grid is [n_img][H][W].
+ * workspace: hn_wgrad_group_ws_bytes(jobs, njobs) bytes.  Reference ops: the weight gradients of conv_block_1 / conv_block_3 / shortcut of
+ * the XBlocks of one backbone stage (net/anynet.py:29-33,52-60), which autograd produces one by one. */
+extern "C" int hn_wgrad_group(const long* jobs, int njobs, float* workspace, hipStream_t st) {
+    GroupPlan g;
+    const int rc0 = wgrad_group_plan(jobs, njobs, g);
+    if (rc0 != HN_OK) return rc0;
+    HN_CHECK_ARG(workspace || g.ws_floats == 0);
+    TNJobs t;
+    RJobsN r;
+    t.n = njobs;
+    r.n = 0;
+    long blocks = 0, rblocks = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const long* jb = jobs + HN_WG_FIELDS * i;
+        TNJob& d = t.j[i];
+        const int mode = (int)jb[3], H = (int)jb[5], W = (int)jb[6], cin = (int)jb[7], nout = (int)jb[10], kp = (cin + 31) & ~31;
+        d.x0 = reinterpret_cast<const bf16*>(jb[0]); d.dz = reinterpret_cast<const bf16*>(jb[1]);
+        d.M = jb[11]; d.rows_per_split = g.rps[i];
+        d.mode = mode; d.H = H; d.W = W; d.Hi = mode == 1 ? 2 * H : H; d.Wi = mode == 1 ? 2 * W : W;
+        d.C0 = cin; d.ld0 = (int)jb[8]; d.ldz = (int)jb[9]; d.Nout = nout; d.KP = kp;
+        d.gy = cdiv(nout, g.bc);
+        d.first_block = (int)blocks;
+        blocks += (long)cdiv(kp, g.bn) * d.gy * g.splits[i];
+        if (g.splits[i] == 1) {
+            d.part = reinterpret_cast<float*>(jb[2]); d.out_ld = cin;
+        } else {
+            d.part = workspace + g.ws_off[i]; d.out_ld = 0;
+            RJob& q = r.j[r.n++];
+            const long cols = (long)nout * kp;
+            q.part = d.part; q.dw = reinterpret_cast<float*>(jb[2]); q.splits = g.splits[i]; q.Nout = nout; q.Cin = cin; q.KP = kp; q.taps = 1;
+            q.kind = (g.splits[i] <= 128 && cols >= 65536) ? 0 : 1;
+            q.first_block = rblocks;
+            rblocks += q.kind == 0 ? cdiv(cols / 4, 256) : cdiv(cols, 32);
+        }
+    }
+    HN_CHECK_ARG(blocks > 0 && blocks < (1L << 31));
+    const size_t lds = (size_t)64 * (g.bc + g.bn) * 2 * 2;
+    int rc = HN_OK;
+#define TNG_CASE(BC_, BN_, A_, B_) if (g.bc == BC_ && g.bn == BN_) \
+        hipLaunchKernelGGL((gemm_tn_group_kernel<BC_, BN_, A_, B_>), dim3((unsigned)blocks), dim3(256), lds, st, t); else
+    TNG_CASE(128, 128, 2, 2) TNG_CASE(128, 64, 2, 2) TNG_CASE(128, 32, 4, 1)
+    TNG_CASE(64, 128, 2, 2) TNG_CASE(64, 64, 2, 2) TNG_CASE(64, 32, 4, 1)
+    TNG_CASE(32, 128, 1, 4) TNG_CASE(32, 64, 1, 4) TNG_CASE(32, 32, 2, 2)
+    TNG_CASE(16, 128, 1, 4) TNG_CASE(16, 64, 1, 4)
+    rc = HN_ERR_UNSUPPORTED;
+#undef TNG_CASE
+    if (rc != HN_OK) return rc;
+    if (r.n) hipLaunchKernelGGL(wgrad_reduce_group_kernel, dim3((unsigned)rblocks), dim3(256), 0, st, r);
+    HN_LAUNCH_CHECK();
+}
+
 /* hn_conv_gemm_tn that also returns the conv's bias gradient dbias [Nout] = column sums of dz -- accumulated by one extra MFMA per k-step
  * while the dz fragments are in registers, reduced by the launch that reduces the weight-gradient slabs: no column-statistics pass over
  * dz, no extra reduce launches (not for the grouped mode 5). */
@@ -2286,7 +2442,7 @@ static int conv_gemm_tn_impl(const void* x0, const void* x1, int mode, int n_img
     mode = p.x.mode;
     p.dz = (const bf16*)dz; p.ldz = ldz; p.Nout = Nout; p.KP = KP; p.taps = taps;
     p.part = workspace; p.rows_per_split = rps; p.phase_span = phase_span;
-    p.bias_part = nullptr;
+    p.bias_part = nullptr; p.out_ld = 0; p.cin_lim = 0;
     int bc, bn, rc;
     long* defer = g_defer_job;
     g_defer_job = nullptr;

@@ -662,6 +662,87 @@ extern "C" int hn_seg_loss_bwd_s2d(const float* logits, int ldl, int C, const vo
     HN_LAUNCH_CHECK();
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Focal variant of the seg loss (head_seg/segmentation_loss.py:31-46, `use_focal: True` of cfgs/hydranet_joint_small_backbone.yml):
+//   p = softmax(l) + 1e-8;  t = one_hot(y) + 1e-8;  loss_pix = sum_c t_c * (-alpha * (1 - p_c)^gamma * log(p_c) * w_c);  mean over all pixels
+// (every class contributes through the +1e-8 of the one-hot; no ignore_index on this path, as in the reference).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float focal_pow(float q, float gamma) { return gamma == 2.0f ? q * q : powf(q, gamma); }
+
+__global__ __launch_bounds__(256) void seg_focal_fwd_kernel(const float* logits, int ldl, int C, const void* target, int target_is_float,
+                                                            const float* cw, float gamma, float alpha, long M, float* psum) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long m = (long)blockIdx.x * 256 + threadIdx.x; m < M; m += (long)gridDim.x * 256) {
+        const int y = target_is_float ? (int)reinterpret_cast<const float*>(target)[m] : (int)reinterpret_cast<const long*>(target)[m];
+        const float* row = logits + m * ldl;
+        float mx = row[0];
+        for (int c = 1; c < C; ++c) mx = fmaxf(mx, row[c]);
+        float e[HN_SEG_MAXC], se = 0.f;
+        for (int c = 0; c < C; ++c) { e[c] = expf(row[c] - mx); se += e[c]; }
+        float l = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float p = e[c] / se + 1e-8f;
+            const float t = (c == y ? 1.0f : 0.0f) + 1e-8f;
+            l += t * (-alpha * focal_pow(1.0f - p, gamma) * logf(p) * cw[c]);
+        }
+        s += l;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) psum[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// dlogits_j = gout/M * s_j * (g_j - sum_c g_c s_c),  g_c = dloss/dp_c = t_c w_c alpha (gamma (1-p_c)^(gamma-1) log p_c - (1-p_c)^gamma / p_c)
+__global__ __launch_bounds__(256) void seg_focal_bwd_kernel(const float* logits, int ldl, int C, const void* target, int target_is_float,
+                                                            const float* cw, float gamma, float alpha, long M, const float* gout,
+                                                            float inv_denom, float* dlogits, int ldd) {
+    const float gs = gout[0] * inv_denom;
+    for (long m = (long)blockIdx.x * 256 + threadIdx.x; m < M; m += (long)gridDim.x * 256) {
+        const int y = target_is_float ? (int)reinterpret_cast<const float*>(target)[m] : (int)reinterpret_cast<const long*>(target)[m];
+        const float* row = logits + m * ldl;
+        float mx = row[0];
+        for (int c = 1; c < C; ++c) mx = fmaxf(mx, row[c]);
+        float sm[HN_SEG_MAXC], g[HN_SEG_MAXC], se = 0.f, dot = 0.f;
+        for (int c = 0; c < C; ++c) { sm[c] = expf(row[c] - mx); se += sm[c]; }
+        for (int c = 0; c < C; ++c) {
+            sm[c] /= se;
+            const float p = sm[c] + 1e-8f, q = 1.0f - p;
+            const float t = (c == y ? 1.0f : 0.0f) + 1e-8f;
+            const float qg1 = gamma == 2.0f ? q : powf(q, gamma - 1.0f);
+            g[c] = t * cw[c] * alpha * (gamma * qg1 * logf(p) - focal_pow(q, gamma) / p);
+            dot += g[c] * sm[c];
+        }
+        float* d = dlogits + m * ldd;
+        for (int c = 0; c < C; ++c) d[c] = gs * sm[c] * (g[c] - dot);
+    }
+}
+
+/* focal seg loss: logits fp32 [N*HW][ldl] (C classes), target float32 or int64 class ids [N*HW] (no ignore_index on this path, as in the
+ * reference), ws = fp32 [hn_seg_loss_blocks(N, HW)] partial sums, out[0] = mean over all N*HW pixels */
+extern "C" int hn_seg_focal_fwd(const float* logits, int ldl, int C, const void* target, int target_is_float, const float* cw, float gamma,
+                                float alpha, int N, long HW, void* ws, float* out, hipStream_t st) {
+    HN_CHECK_ARG(logits && target && cw && ws && out && C >= 1 && C <= HN_SEG_MAXC && N > 0 && HW > 0);
+    const long M = (long)N * HW;
+    const int blocks = hn_seg_loss_blocks(N, HW);
+    hipLaunchKernelGGL(seg_focal_fwd_kernel, dim3(blocks), dim3(256), 0, st, logits, ldl, C, target, target_is_float, cw, gamma, alpha, M,
+                       (float*)ws);
+    hipLaunchKernelGGL(seg_loss_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, blocks, (const SelState*)nullptr, N, 0, (double)M, out);
+    HN_LAUNCH_CHECK();
+}
+
+extern "C" int hn_seg_focal_bwd(const float* logits, int ldl, int C, const void* target, int target_is_float, const float* cw, float gamma,
+                                float alpha, int N, long HW, const float* gout, float* dlogits, int ldd, hipStream_t st) {
+    HN_CHECK_ARG(logits && target && cw && gout && dlogits && C >= 1 && C <= HN_SEG_MAXC && N > 0 && HW > 0);
+    const long M = (long)N * HW;
+    long blocks = (M + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(seg_focal_bwd_kernel, dim3(blocks), dim3(256), 0, st, logits, ldl, C, target, target_is_float, cw, gamma, alpha, M, gout,
+                       (float)(1.0 / (double)M), dlogits, ldd);
+    HN_LAUNCH_CHECK();
+}
+
 extern "C" int hn_argmax_channels(const float* logits, int ldl, int C, long M, long* out, hipStream_t st) {
     HN_CHECK_ARG(logits && out && C >= 1 && M > 0);
     long blocks = (M + 255) / 256;

@@ -204,7 +204,8 @@ extern "C" int hn_det_postprocess(const float* anchors, const float* regression,
 }
 
 // =====================================================================================================================================
-// 2. lane decode + lane NMS: one workgroup (1024 threads) per image, one thread per anchor
+// 2. lane decode + lane NMS: one workgroup (1024 threads) per image; the anchors (any count: 512x1024 has 512, the 1152x1920 deploy
+//    resolution 2160) are walked with a workgroup stride, their bookkeeping lives in dynamic LDS (21 bytes per anchor)
 // =====================================================================================================================================
 struct LaneGeo {
     int fw, fh, stride, ppl, W, H, L;
@@ -216,16 +217,21 @@ struct LaneGeo {
 __global__ __launch_bounds__(1024) void lane_decode_nms_kernel(const float* cls, const float* loc, LaneGeo g, float exist_thr, float nms_thr,
                                                                int use_mean, float* X, float* prob_out, int* start_out, int* end_out,
                                                                int* order_out, int* keep_out, int* counts) {
-    __shared__ float s_prob[1024];
-    __shared__ int s_valid[1024], s_order[1024], s_start[1024], s_end[1024];
-    __shared__ unsigned char s_sup[1024];
-    __shared__ int s_cnt;
-    const int n = blockIdx.x, a = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) char lane_smem[];
+    const int n = blockIdx.x, tid = threadIdx.x;
     const int hw = g.fw * g.fh;
+    float* s_prob = reinterpret_cast<float*>(lane_smem);
+    int* s_valid = reinterpret_cast<int*>(s_prob + hw);
+    int* s_order = s_valid + hw;
+    int* s_start = s_order + hw;
+    int* s_end = s_start + hw;
+    int* s_cntp = s_end + hw;                                       // (no static LDS beside the dynamic array: the opt-in above 64 KiB
+    unsigned char* s_sup = reinterpret_cast<unsigned char*>(s_cntp + 4);   //  asks for the whole 160 KiB as dynamic memory)
     float* Xn = X + (long)n * hw * g.ppl;
-    float prob = 0.f;
-    int start = 0, end = 0, valid = 0;
-    if (a < hw) {
+    if (tid == 0) *s_cntp = 0;
+    for (int a = tid; a < hw; a += 1024) {
+        float prob;
+        int start = 0, end = 0, valid = 0;
         const float l0 = cls[((long)n * hw + a) * 2], l1 = cls[((long)n * hw + a) * 2 + 1];
         const float mx = fmaxf(l0, l1);
         const float e0 = expf(l0 - mx), e1 = expf(l1 - mx);
@@ -254,60 +260,60 @@ __global__ __launch_bounds__(1024) void lane_decode_nms_kernel(const float* cls,
             }
             valid = (end - start) >= 2 ? 1 : 0;
         }
-    }
-    s_prob[a] = prob; s_valid[a] = valid; s_start[a] = start; s_end[a] = end;
-    if (a == 0) s_cnt = 0;
-    __syncthreads();
-    // stable descending-prob order of the valid anchors (Python's sorted() on Lane.__lt__ = prob > other.prob keeps raster order on ties)
-    if (valid) {
-        int rank = 0;
-        for (int b = 0; b < hw; ++b)
-            rank += (s_valid[b] && (s_prob[b] > prob || (s_prob[b] == prob && b < a))) ? 1 : 0;
-        s_order[rank] = a;
-        atomicAdd(&s_cnt, 1);
-    }
-    s_sup[a] = 0;
-    __syncthreads();
-    const int cnt = s_cnt;
-    // greedy suppression in that order: lane n_ (if still alive) suppresses every later lane t whose distance is <= thr
-    for (int k = 0; k < cnt; ++k) {
-        if (!s_sup[k]) {                                            // uniform: s_sup[k] was settled by earlier iterations
-            const int t = k + 1 + a;
-            if (t < cnt) {
-                const int la = s_order[k], lb = s_order[t];
-                const int lo = s_start[la] > s_start[lb] ? s_start[la] : s_start[lb];
-                const int hi = s_end[la] < s_end[lb] ? s_end[la] : s_end[lb];
-                if (!(hi <= lo || lo < 0 || hi < 1)) {
-                    const float* xa = Xn + (long)la * g.ppl;
-                    const float* xb = Xn + (long)lb * g.ppl;
-                    float dis = 0.f;
-                    for (int i = lo; i < hi; ++i) dis = __fadd_rn(dis, fabsf(__fsub_rn(xa[i], xb[i])));
-                    dis = __fdiv_rn(dis, (float)(hi - lo));
-                    if (!use_mean) {
-                        dis = fmaxf(dis, fabsf(__fsub_rn(xa[lo], xb[lo])));
-                        dis = fmaxf(dis, fabsf(__fsub_rn(xa[hi - 1], xb[hi - 1])));
-                    }
-                    if (dis <= nms_thr) s_sup[t] = 1;
-                }
-            }
-        }
-        __syncthreads();
-    }
-    if (a < hw) {
+        s_prob[a] = prob; s_valid[a] = valid; s_start[a] = start; s_end[a] = end;
+        s_sup[a] = 0;
         prob_out[(long)n * hw + a] = prob;
         start_out[(long)n * hw + a] = start;
         end_out[(long)n * hw + a] = end;
     }
-    if (a < cnt) {
+    __threadfence_block();                                          // this workgroup's X rows are read back below by other threads
+    __syncthreads();
+    // stable descending-prob order of the valid anchors (Python's sorted() on Lane.__lt__ = prob > other.prob keeps raster order on ties)
+    for (int a = tid; a < hw; a += 1024) {
+        if (!s_valid[a]) continue;
+        const float prob = s_prob[a];
+        int rank = 0;
+        for (int b = 0; b < hw; ++b)
+            rank += (s_valid[b] && (s_prob[b] > prob || (s_prob[b] == prob && b < a))) ? 1 : 0;
+        s_order[rank] = a;
+        atomicAdd(s_cntp, 1);
+    }
+    __syncthreads();
+    const int cnt = *s_cntp;
+    // greedy suppression in that order: candidate k (if still alive) suppresses every later candidate t whose distance is <= thr
+    for (int k = 0; k < cnt; ++k) {
+        if (!s_sup[k]) {                                            // uniform: s_sup[k] was settled by earlier iterations
+            const int la = s_order[k];
+            const float* xa = Xn + (long)la * g.ppl;
+            for (int t = k + 1 + tid; t < cnt; t += 1024) {
+                const int lb = s_order[t];
+                const int lo = s_start[la] > s_start[lb] ? s_start[la] : s_start[lb];
+                const int hi = s_end[la] < s_end[lb] ? s_end[la] : s_end[lb];
+                if (hi <= lo || lo < 0 || hi < 1) continue;
+                const float* xb = Xn + (long)lb * g.ppl;
+                float dis = 0.f;
+                for (int i = lo; i < hi; ++i) dis = __fadd_rn(dis, fabsf(__fsub_rn(xa[i], xb[i])));
+                dis = __fdiv_rn(dis, (float)(hi - lo));
+                if (!use_mean) {
+                    dis = fmaxf(dis, fabsf(__fsub_rn(xa[lo], xb[lo])));
+                    dis = fmaxf(dis, fabsf(__fsub_rn(xa[hi - 1], xb[hi - 1])));
+                }
+                if (dis <= nms_thr) s_sup[t] = 1;
+            }
+        }
+        __syncthreads();
+    }
+    for (int a = tid; a < cnt; a += 1024) {
         order_out[(long)n * hw + a] = s_order[a];
         keep_out[(long)n * hw + a] = s_sup[a] ? 0 : 1;
     }
-    if (a == 0) counts[n] = cnt;
+    if (tid == 0) counts[n] = cnt;
 }
 
-/* predict_cls fp32 [N][hw][2] (logits), predict_loc fp32 [N][hw][L = 2*ppl+2]; hw = (W/stride)*(H/stride) <= 1024, ppl <= 256.
- * Outputs: X [N][hw][ppl] = x coordinate of anchor a at position p (valid for start[a] <= p < end[a]), prob / start / end [N][hw] per anchor,
- * order [N][hw] = candidate anchors in descending-prob order (counts[n] entries), keep [N][hw] = 1 where the candidate survives the NMS. */
+/* predict_cls fp32 [N][hw][2] (logits), predict_loc fp32 [N][hw][L = 2*ppl+2]; hw = (W/stride)*(H/stride) <= 7168 (21 bytes of LDS per
+ * anchor).  Outputs: X [N][hw][ppl] = x coordinate of anchor a at position p (valid for start[a] <= p < end[a]), prob / start / end [N][hw]
+ * per anchor, order [N][hw] = candidate anchors in descending-prob order (counts[n] entries), keep [N][hw] = 1 where the candidate
+ * survives the NMS. */
 extern "C" int hn_lane_decode_nms(const float* predict_cls, const float* predict_loc, int N, int W, int H, int stride, int ppl,
                                   float exist_threshold, float nms_threshold, int use_mean, float margin, float* X, float* prob, int* start,
                                   int* end, int* order, int* keep, int* counts, hipStream_t st) {
@@ -317,8 +323,15 @@ extern "C" int hn_lane_decode_nms(const float* predict_cls, const float* predict
     g.interval = (float)((double)H / ppl);
     g.ppa = (double)ppl / g.fh;
     g.margin = margin;
-    HN_CHECK_ARG(g.fw * g.fh > 0 && g.fw * g.fh <= 1024);
-    hipLaunchKernelGGL(lane_decode_nms_kernel, dim3(N), dim3(1024), 0, st, predict_cls, predict_loc, g, exist_threshold, nms_threshold, use_mean,
+    const long hw = (long)g.fw * g.fh;
+    HN_CHECK_ARG(hw > 0);
+    if (hw > 7168) return HN_ERR_UNSUPPORTED;
+    const size_t lds = (size_t)hw * 21 + 32;
+    if (lds > 64 * 1024) {
+        static std::atomic<unsigned long long> optin{0};
+        if (!lds_optin(optin, {(const void*)lane_decode_nms_kernel})) return HN_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(lane_decode_nms_kernel, dim3(N), dim3(1024), lds, st, predict_cls, predict_loc, g, exist_threshold, nms_threshold, use_mean,
                        X, prob, start, end, order, keep, counts);
     HN_LAUNCH_CHECK();
 }

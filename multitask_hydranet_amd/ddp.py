@@ -76,9 +76,7 @@ class GradReducer:
                          _agree_on_avg(group, dev))
         self.captured = False
         self._hooks = []
-        for bi, b in enumerate(self.buckets):
-            for n, p in b["params"]:
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
+        self.arm()
 
     # ------------------------------------------------------------------------------------------------------------------------------
     def _close(self, plist):
@@ -97,7 +95,7 @@ class GradReducer:
             for _, p in plist:
                 land.append(lflat[off:off + p.numel()].view_as(p))
                 off += p.numel()
-        self.buckets.append(dict(params=plist, flat=flat, views=views, land=land, pending=len(plist), work=None, event=None, src=None))
+        self.buckets.append(dict(params=plist, flat=flat, views=views, land=land, pending=len(plist), work=None, event=None, src=None, keep=None))
 
     def _make_hook(self, bi):
         def hook(param):
@@ -188,6 +186,11 @@ class GradReducer:
         if capturing:
             b["src"] = [p.grad for _, p in b["params"]]        # graph-private tensors every replay rewrites
             self.captured = True
+        elif self.stream is not None:
+            # The gather below runs on the SIDE stream and reads the gradients autograd allocated on the main stream; _point() then rebinds
+            # .grad to the bucket views, which would drop the last reference to them while the gather may still be queued behind the previous
+            # bucket's all-reduce -- the caching allocator could hand their blocks to a later backward kernel.  Keep them until finish().
+            b["keep"] = [p.grad for _, p in b["params"]]
         if self.stream is not None:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
@@ -223,6 +226,7 @@ class GradReducer:
                 if b["event"] is not None:
                     torch.cuda.current_stream().wait_event(b["event"])
                     b["event"] = None
+                b["keep"] = None                                # the main stream is now ordered behind the gather: safe to recycle
                 if b["work"] is not None:
                     b["work"].wait()
                     if self.world > 1:
@@ -264,6 +268,16 @@ class GradReducer:
             if b["src"] is not None and self.active:
                 self._point(b)
 
+    def arm(self):
+        """(re-)register the autograd hooks (construction does; remove() + arm() parks a reducer while another parameter set trains: the
+        fine-tuning phases of HydraTrainer.set_phase)"""
+        if self._hooks:
+            return
+        for bi, b in enumerate(self.buckets):
+            b["pending"], b["work"], b["event"], b["keep"] = len(b["params"]), None, None, None
+            for n, p in b["params"]:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
+
     def remove(self):
         for h in self._hooks:
             h.remove()
@@ -287,3 +301,9 @@ def broadcast_state(module: torch.nn.Module, src: int = 0, group=None):
 
 UNUSED_5STAGE = ("neck.bifpn.0.p5_to_p6.0.conv.weight", "neck.bifpn.0.p5_to_p6.0.conv.bias", "neck.bifpn.0.p5_to_p6.1.weight",
                  "neck.bifpn.0.p5_to_p6.1.bias")
+
+
+def unused_parameters(net) -> tuple:
+    """names of the parameters a HydraNet never gives a gradient (excluded from the exchange on every rank alike): the first BiFPN cell's
+    p5_to_p6 reducer when the backbone has 5 stages (net/bifpn.py:162-165: the last stage IS P6); none in the 4-stage configurations"""
+    return UNUSED_5STAGE if len(net.depths) == 5 else ()

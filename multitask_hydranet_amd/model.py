@@ -20,7 +20,6 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import losses as L
 from . import ops as K
 from .ops import ACT_ELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SWISH
 
@@ -127,6 +126,7 @@ class HydraNet(nn.Module):
         self.deploy_postprocess = None      # (conf_thres, iou_thres): forward(x, "deploy") then appends the device-side detections
         self.pack_det_levels = True         # level-packed det towers when every level has a multiple of 128 rows
         self.levels_on_streams = False      # hipGraph branches cost more than they hide on gfx950 (55 vs 43 ms)
+        self.grad_scope = None              # "lane" | "det" | "seg": head-only fine-tuning phase (see _forward)
 
         spec = _Spec(self)
         self._declare_backbone(spec)
@@ -286,7 +286,15 @@ class HydraNet(nn.Module):
         module (train.py:437, keys "module.<name>") and strips the prefix when it loads them back (deparallel_model, train.py:96-109)."""
         if state_dict and all(k.startswith("module.") for k in state_dict):
             state_dict = type(state_dict)((k[len("module."):], v) for k, v in state_dict.items())
-        return super().load_state_dict(state_dict, strict=strict, assign=assign)
+        # new values: the BatchNorm-folded inference operands of prepare_inference() are stale.  In-place copies keep every parameter's
+        # storage, so the per-step pack plan (a device table of raw pointers, re-validated by forward()) stays; assign=True swaps storage.
+        self._folded = None
+        K.clear_pack_cache()
+        r = super().load_state_dict(state_dict, strict=strict, assign=assign)
+        if assign:
+            self._pack_plan = None
+            self._reindex()
+        return r
 
     # ------------------------------------------------------------------------------------------------------
     # inference with folded BatchNorm (BASELINE config 5)
@@ -295,7 +303,8 @@ class HydraNet(nn.Module):
         """Fold every eval-mode BatchNorm that directly follows a convolution into that convolution's packed bf16 weights and an fp32 bias
         (backbone conv_block_1/2/3 and shortcuts, BiFPN channel reducers and separable blocks, lane branches).  Call after .eval() and after
         loading weights; forward() in eval mode then runs conv + BN + activation (+ the XBlock identity branch) as one launch per conv.
-        .train() or any parameter change invalidates it (call again)."""
+        .train(), load_state_dict() and device / dtype moves drop the folded operands (call again); an in-place parameter update in eval
+        mode (an optimizer step without .train()) is detected through the parameters' version counters and raises in forward()."""
         assert not self.training, "prepare_inference() folds the RUNNING statistics: call .eval() first"
         P = self._idx
         folded = {}
@@ -325,7 +334,12 @@ class HydraNet(nn.Module):
             folded[conv] = K.fold_conv_bn(w, P.get(conv + ".bias"), P[bn + ".weight"], P[bn + ".bias"], P[bn + ".running_mean"],
                                           P[bn + ".running_var"], eps, kind)
         self._folded = folded
+        self._folded_versions = [(t, t._version) for n, t in P.items() if n.split(".")[-1] != "num_batches_tracked"]
         return self
+
+    def _check_folded(self):
+        if self._folded is not None and any(t._version != v for t, v in self._folded_versions):
+            raise RuntimeError("parameters or BatchNorm statistics changed after prepare_inference(): call prepare_inference() again")
 
     def train(self, mode: bool = True):
         if mode:
@@ -356,8 +370,8 @@ class HydraNet(nn.Module):
             kw.pop("slot", None)
         return K.conv_bn_act(x, P[conv + ".weight"], P.get(conv + ".bias"), self._bn(bn), training=self.training, **bnkw, **kw)
 
-    def _xblock(self, q, x, stride):
-        """XBlock.forward, net/anynet.py:65-76."""
+    def _xblock(self, q, x, stride, group=None):
+        """XBlock.forward, net/anynet.py:65-76.  group: the stage's ops.WgradGroup (1x1 weight gradients deferred to the stage boundary)"""
         P = self._idx
         has_se, has_sc = (q + "se.1.weight") in P, (q + "shortcut.0.weight") in P
         if self._folded is not None and not self.training:            # inference: 7 launches per block, nothing but GEMM epilogues
@@ -372,7 +386,8 @@ class HydraNet(nn.Module):
             sc = (P[q + "shortcut.0.weight"], *self._bn(q + "shortcut.1")[:4]) if has_sc else ()
             return K.XBlockFn.apply(x, P[q + "conv_block_1.0.weight"], *bn[0], P[q + "conv_block_2.0.weight"], *bn[1],
                                     P[q + "se.1.weight"], P[q + "se.1.bias"], P[q + "se.3.weight"], P[q + "se.3.bias"],
-                                    P[q + "conv_block_3.0.weight"], *bn[2], BN_STD["eps"], BN_STD["momentum"], self.training, stride, *sc)
+                                    P[q + "conv_block_3.0.weight"], *bn[2], BN_STD["eps"], BN_STD["momentum"], self.training, stride,
+                                    *(sc if sc else (None,) * 5), group)
         a = self._cba(x, q + "conv_block_1.0", q + "conv_block_1.1", BN_STD, act=ACT_RELU)
         b = self._cba(a, q + "conv_block_2.0", q + "conv_block_2.1", BN_STD, kind="g3x3", stride=stride, act=ACT_RELU)
         if (q + "se.1.weight") in P:
@@ -394,9 +409,20 @@ class HydraNet(nn.Module):
         x = x.contiguous().float()
         t = self._cba(x, p + "stem.conv", p + "stem.bn", BN_STD, kind="stem", act=ACT_RELU)
         feats = []
+        P = self._idx
         for k, d in enumerate(self.depths):
+            # The 1x1 weight gradients of the stage's XBlocks are deferred to the stage boundary and run as ONE grouped launch
+            # (ops.DeferredGrads / WgradGroup): the identity node sits on the tensor entering the stage, so its backward runs after the
+            # backward of every block of the stage.
+            group = None
+            names = [f"{p}stage_{k}.blocks.block_{i}.{c}.0.weight" for i in range(d) for c in ("conv_block_1", "conv_block_3", "shortcut")]
+            names = [nm for nm in names if nm in P]
+            if (K.DEFER_WGRAD and self.training and torch.is_grad_enabled() and t.requires_grad and t.is_cuda and (self.se_ratio is not None) and
+                    all(P[nm].requires_grad for nm in names)):
+                group = K.WgradGroup()
+                t = K.DeferredGrads.apply(t, group, *[P[nm] for nm in names])
             for i in range(d):
-                t = self._xblock(f"{p}stage_{k}.blocks.block_{i}.", t, self.backbone_stride if i == 0 else 1)
+                t = self._xblock(f"{p}stage_{k}.blocks.block_{i}.", t, self.backbone_stride if i == 0 else 1, group)
             last = k == len(self.depths) - 1
             al, slot = K.share(t, ext[k] + (0 if last else 1))
             feats.append((al[:ext[k]], slot))
@@ -630,6 +656,8 @@ class HydraNet(nn.Module):
     def forward(self, x, mode="train"):
         """HydraNet.forward, model/model.py:159-198."""
         K.clear_pack_cache()
+        if self._folded is not None and not self.training:
+            self._check_folded()
         params = {id(t) for t in self.parameters()}
         if self._pack_plan is not None and not self._pack_plan.valid():
             self._pack_plan = None                 # a parameter's storage was replaced: re-record the weights on this forward
@@ -646,15 +674,21 @@ class HydraNet(nn.Module):
                     self._pack_plan = K.PackPlan(log)
 
     def _forward(self, x, mode):
+        # grad_scope ("lane" | "det" | "seg", set by HydraTrainer.set_phase for the head-only phases of train.py:441-515): only that head's
+        # parameters are being optimised, so everything else runs forward only (no autograd graph: no saved activations, no backward
+        # launches); BatchNorm running statistics update as in any training-mode forward and every output is still produced.
+        scope = self.grad_scope if (self.training and torch.is_grad_enabled()) else None
+        off = lambda part: torch.no_grad() if (scope is not None and scope != part) else contextlib.nullcontext()
         neck_cnt = self.first_cell_counts()
         seg_skip = 1 if self.train_seg else 0          # the seg decoder's last skip operand is the stage-0 output
-        bb = self._backbone_shared(x, tuple(c + (seg_skip if k == 0 else 0) for k, c in enumerate(neck_cnt)))
-        feats = [(a[(seg_skip if k == 0 else 0):], s) for k, (a, s) in enumerate(bb)]      # what the neck sees
-        feat0_seg = bb[0][0][0] if seg_skip else None
         # consumers of every fused pyramid level among the heads: det towers (all five), seg decoder (P3..P5), lane fusion (P3..P6)
         users = [[h for h, on, lv in (("det", self.train_detect, range(5)), ("seg", self.train_seg, range(3)), ("lane", self.train_lane, range(4)))
                   if on and l in lv] for l in range(5)]
-        al = self._neck_shared(feats, tuple(max(len(u), 1) for u in users))
+        with off("shared"):
+            bb = self._backbone_shared(x, tuple(c + (seg_skip if k == 0 else 0) for k, c in enumerate(neck_cnt)))
+            feats = [(a[(seg_skip if k == 0 else 0):], s) for k, (a, s) in enumerate(bb)]      # what the neck sees
+            feat0_seg = bb[0][0][0] if seg_skip else None
+            al = self._neck_shared(feats, tuple(max(len(u), 1) for u in users))
         pick = lambda head: [al[l][users[l].index(head)] if head in users[l] else al[l][0] for l in range(5)]
         fused_det, fused_seg, fused_lane = pick("det"), pick("seg"), pick("lane")
         out = {}
@@ -669,15 +703,18 @@ class HydraNet(nn.Module):
             side.wait_stream(cur)
         with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
             if self.train_detect:
-                anchors, reg, cls = self._det(x, fused_det)
+                with off("det"):
+                    anchors, reg, cls = self._det(x, fused_det)
                 out["detection"] = {"anchors": anchors, "regression": reg, "classification": cls}
             if self.train_lane:
-                lane = self._lane(fused_lane)
+                with off("lane"):
+                    lane = self._lane(fused_lane)
                 out["lane"] = lane
                 lane_cls, lane_reg = lane["predict_cls"], lane["predict_loc"]
         seg_mask = None
         if self.train_seg:
-            seg = self._seg([feat0_seg, fused_seg[0], fused_seg[1], fused_seg[2]], want_mask=(mode == "deploy" and not torch.is_grad_enabled()))
+            with off("seg"):
+                seg = self._seg([feat0_seg, fused_seg[0], fused_seg[1], fused_seg[2]], want_mask=(mode == "deploy" and not torch.is_grad_enabled()))
             if seg.dtype == torch.int64:                   # deploy + no_grad: the output conv already took the arg-max
                 seg_mask, seg = seg, None
             out["seg"] = seg
@@ -700,19 +737,18 @@ class HydraNet(nn.Module):
         return dep
 
     def _seg_loss(self, logits, target):
-        """CrossEntropyLoss.forward (head_seg/segmentation_loss.py:27-65): HIP kernels for the weighted-CE / top-k path of the shipped
-        big cfgs; the focal variant of the small cfg is a handful of elementwise torch ops (not on the benchmarked path)."""
+        """CrossEntropyLoss.forward (head_seg/segmentation_loss.py:27-65) on HIP kernels: the weighted-CE / top-k path of the big cfgs
+        (hn_seg_loss_*) and the focal variant of the small cfg (hn_seg_focal_*).  No CPU fallback: raises off-device."""
         use_top_k, ratio, use_focal = self._seg_cfg
-        if use_focal:                                   # small-cfg variant (a few elementwise device ops on the HIP logits), not benchmarked
-            # the reference always hands gt_seg.long() to the loss (model.py:212); to_gpu delivers float32 class ids
-            return L.seg_loss(logits, target.long(), self._seg_class_weight, use_top_k, ratio, use_focal)
-        slot = None
         key = getattr(self, "_seg_grad_slot", None)
-        if key is not None:
-            self._seg_grad_slot = None                                # consumed (or dropped) by the first loss call after the forward
-            if key[1]() is logits:
-                slot = key[0]                                         # this forward's own "seg" output
-        return K.seg_loss_hip(logits, target, self._seg_class_weight, use_top_k, ratio, slot=slot)      # no CPU fallback: raises off-device
+        self._seg_grad_slot = None                                    # consumed (or dropped) by the first loss call after the forward
+        if use_focal:
+            # (the reference always hands gt_seg.long() to the loss, model.py:212; to_gpu delivers float32 class ids: both are accepted)
+            return K.seg_focal_loss_hip(logits, target, self._seg_class_weight)
+        slot = None
+        if key is not None and key[1]() is logits:
+            slot = key[0]                                             # this forward's own "seg" output
+        return K.seg_loss_hip(logits, target, self._seg_class_weight, use_top_k, ratio, slot=slot)
 
     def _guard(self, value, what, allow_zero=False):
         if self.check_finite and ((not allow_zero and value == 0) or not torch.isfinite(value)):

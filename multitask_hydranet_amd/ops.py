@@ -352,6 +352,63 @@ class WgradBatch:
         self.keep = []
 
 
+DEFER_WGRAD = os.environ.get("HN_DEFER_WGRAD", "1") != "0"   # 1x1 weight gradients of a backbone stage in one grouped launch at the stage boundary
+
+
+class WgradGroup:
+    """The 1x1-conv weight gradients of ONE backbone stage, deferred to the stage boundary (DeferredGrads.backward) and computed by one
+    grouped GEMM launch (hn_wgrad_group).  Weight gradients are not on the backward pass's critical path; launched one by one behind
+    every data gradient (3 GEMMs + a slab reduce per XBlock, each a 10-25 us launch that cannot fill the chip) they were 2.6 ms of the
+    22 ms step.  XBlockFn.backward only QUEUES (weight, x, dz) here and returns None for the weight; the queue keeps x / dz alive."""
+    MAX_JOBS = 32
+
+    def __init__(self):
+        self.weights = ()           # the parameters DeferredGrads hands gradients back for, in its argument order
+        self.jobs = []              # (weight, x0, dz, mode, (n, h, w), cin, nout)
+
+    def add(self, weight, x0, dz, mode, grid, cin, nout):
+        self.jobs.append((weight, x0, dz, mode, grid, cin, nout))
+
+    def flush(self):
+        """-> one fp32 gradient (or None) per entry of self.weights"""
+        jobs, self.jobs = self.jobs, []
+        out = {}
+        for c0 in range(0, len(jobs), self.MAX_JOBS):
+            chunk = jobs[c0:c0 + self.MAX_JOBS]
+            tab = (ctypes.c_long * (12 * len(chunk)))()
+            dws = []
+            for i, (wgt, x0, dz, mode, (n, h, w), cin, nout) in enumerate(chunk):
+                dw = torch.empty((nout, cin, 1, 1), device=dz.device, dtype=F32)
+                dws.append(dw)
+                ldz = dz.stride(2) if dz.dim() == 4 else dz.stride(0)
+                tab[12 * i:12 * i + 12] = [x0.data_ptr(), dz.data_ptr(), dw.data_ptr(), mode, n, h, w, cin, ld(x0), ldz, nout, n * h * w]
+            wsb = lib().query("hn_wgrad_group_ws_bytes", ctypes.addressof(tab), len(chunk))
+            if wsb < 0:
+                raise RuntimeError("hn_wgrad_group: bad job table")
+            ws = torch.empty((wsb // 4,), device=chunk[0][2].device, dtype=F32)
+            lib().call("hn_wgrad_group", ctypes.addressof(tab), len(chunk), ptr(ws))
+            for (wgt, *_), dw in zip(chunk, dws):
+                assert id(wgt) not in out, "one queued gradient per weight and backward pass"
+                out[id(wgt)] = dw
+        return [out.get(id(w)) for w in self.weights]
+
+
+class DeferredGrads(torch.autograd.Function):
+    """Identity on the tensor that ENTERS a backbone stage.  Its backward runs when the gradient leaves the stage -- after every XBlock
+    of the stage has run its backward and queued its 1x1 weight gradients in `group` -- launches them as one grouped GEMM and returns
+    them for `weights` (the same parameter tensors the XBlockFn nodes received; those nodes return None for them)."""
+
+    @staticmethod
+    def forward(ctx, x, group, *weights):
+        ctx.group = group
+        group.weights = weights
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g, None, *ctx.group.flush())
+
+
 def k_gemm_tn(x0, x1, mode, grid, dz, nout, kp, taps, cin, up=0, kh=1, want_bias=False, defer=None):
     """weight gradient, returns fp32 [nout, cin, kh, kh] (want_bias: and the bias gradient [nout] out of the same launches).
     defer: a WgradBatch -- the slab reduce is left to its flush()."""
@@ -693,7 +750,8 @@ class XBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, sw1, sb1, sw2, sb2, w3, g3, b3, rm3, rv3, eps, momentum, training,
-                stride=1, ws=None, gs=None, bs=None, rms=None, rvs=None):
+                stride=1, ws=None, gs=None, bs=None, rms=None, rvs=None, group=None):
+        """group (WgradGroup of the stage, or None): the 1x1 weight gradients are queued there instead of being launched here"""
         n, h, w, cin = x.shape
         c = w1.shape[0]
         ho, wo = h // stride, w // stride
@@ -735,6 +793,8 @@ class XBlockFn(torch.autograd.Function):
         out, coef3, _, _ = k_bn_apply_fused(z3, ps, pq, m, g3, b3, eps, momentum, rm3, rv3, ACT_RELU, res=res, training=training)
         ctx.training, ctx.stride = training, stride
         ctx.packs = (wt1, wd2, wt3, wts)
+        ctx.group = group
+        ctx.wrefs = (w1, w3, ws)                           # identities under which the stage's DeferredGrads node returns the gradients
         ctx.save_for_backward(x, z1, a, z2, z3, out, coef1, coef2, coef3, pooled, hid, gate, sw1, sw2, bg, zs, coefs)
         return out
 
@@ -754,10 +814,12 @@ class XBlockFn(torch.autograd.Function):
         # out = relu(bn3(z3) + shortcut): g = dout * [out > 0] is also the gradient of the shortcut branch
         dz3, dg3, db3, g = bn_backward_fused(dout, z3, out, coef3, ACT_RELU, m, want_g=True)
         dbg, _, _ = k_gemm_nt(dz3, None, 0, grid, wt3, c, kp32(c), 1)
+        group = ctx.group                                     # WgradGroup: the 1x1 weight gradients wait for the stage boundary
+        w1_, w3_, ws_ = ctx.wrefs
         batch = WgradBatch()                                  # the slab reduces of dw3 / dw2 / dw1 / dws: one launch at the end
         make_bg = bg is None
         if not make_bg:                                       # dz3's second reader right behind the first: still in the XCDs' L2s
-            dw3 = k_gemm_tn(bg, None, 0, grid, dz3, c, kp32(c), 1, c, defer=batch)
+            dw3 = group.add(w3_, bg, dz3, 0, grid, c, c) if group is not None else k_gemm_tn(bg, None, 0, grid, dz3, c, kp32(c), 1, c, defer=batch)
         # one pass over (dbg, z2): gate-gradient partials and the gated operand bg = relu(bn2(z2)) * gate of conv_block_3's wgrad
         rb = lib().query("hn_fused_row_block", m, c, hw, 0, 1)
         if make_bg:
@@ -766,7 +828,7 @@ class XBlockFn(torch.autograd.Function):
         lib().call("hn_se_bwd_reduce_fused", ptr(dbg), ld(dbg), ptr(z2), ld(z2), ptr(coef2), ptr(gate), hw, ptr(bg) if make_bg else None,
                    ld(bg), ptr(pdot), m, c, rb)
         if make_bg:
-            dw3 = k_gemm_tn(bg, None, 0, grid, dz3, c, kp32(c), 1, c, defer=batch)
+            dw3 = group.add(w3_, bg, dz3, 0, grid, c, c) if group is not None else k_gemm_tn(bg, None, 0, grid, dz3, c, kp32(c), 1, c, defer=batch)
         dpre2 = torch.empty((n, c), device=dev, dtype=F32)
         dpool = torch.empty((n, c), device=dev, dtype=F32)
         dpre1 = torch.empty((n, cs), device=dev, dtype=F32)
@@ -793,14 +855,20 @@ class XBlockFn(torch.autograd.Function):
             dzs, dgs, dbs, _ = bn_backward_fused(g, zs, None, coefs, ACT_NONE, m)
             addend, _, _ = k_gemm_nt(dzs, None, 0, grid, wts, cin, kp32(c), 1)           # shortcut data gradient on the output grid
             add_s2 = stride == 2
-            dws = k_gemm_tn(x, None, 0 if stride == 1 else 1, grid, dzs, c, kp32(cin), 1, cin, defer=batch)
+            if group is not None:
+                group.add(ws_, x, dzs, 0 if stride == 1 else 1, grid, cin, c)
+            else:
+                dws = k_gemm_tn(x, None, 0 if stride == 1 else 1, grid, dzs, c, kp32(cin), 1, cin, defer=batch)
         dx = None
         if ctx.needs_input_grad[0]:
             dx, _, _ = k_gemm_nt(dz1, None, 0, (n, h, w), wt1, cin, kp32(c), 1, addend=addend, add_s2=add_s2)
-        dw1 = k_gemm_tn(x, None, 0, (n, h, w), dz1, c, kp32(cin), 1, cin, defer=batch)
+        if group is not None:
+            dw1 = group.add(w1_, x, dz1, 0, (n, h, w), cin, c)
+        else:
+            dw1 = k_gemm_tn(x, None, 0, (n, h, w), dz1, c, kp32(cin), 1, cin, defer=batch)
         batch.flush()
         return (dx, dw1, dg1, db1, None, None, dw2, dg2, db2, None, None, dsw1, dsb1, dsw2, dsb2, dw3, dg3, db3, None, None,
-                None, None, None, None, dws, dgs, dbs, None, None)
+                None, None, None, None, dws, dgs, dbs, None, None, None)
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -1409,6 +1477,44 @@ def seg_loss_hip(seg_nchw, target, class_weights, use_top_k, top_k_ratio, ignore
     if not logits.is_contiguous():
         logits, slot = logits.contiguous(), None
     return SegLoss.apply(logits, target.contiguous(), class_weights, use_top_k, top_k_ratio, ignore_index, slot)
+
+
+class SegFocalLoss(torch.autograd.Function):
+    """focal variant of the seg loss (head_seg/segmentation_loss.py:31-46): logits fp32 NHWC [N, H, W, C] (dense rows), target [N, H, W]
+    int64 or float32 class ids; mean over all pixels"""
+
+    @staticmethod
+    def forward(ctx, logits, target, class_weights, gamma, alpha):
+        n, h, w, c = logits.shape
+        hw = h * w
+        dev = logits.device
+        tf = 1 if target.dtype == torch.float32 else 0
+        assert target.dtype in (torch.float32, torch.int64) and target.is_contiguous()
+        ws = torch.empty((lib().query("hn_seg_loss_blocks", n, hw),), device=dev, dtype=F32)
+        out = torch.empty((1,), device=dev, dtype=F32)
+        lib().call("hn_seg_focal_fwd", ptr(logits), logits.stride(2), c, ptr(target), tf, ptr(class_weights), float(gamma), float(alpha), n, hw,
+                   ptr(ws), ptr(out))
+        ctx.meta = (n, hw, c, tf, float(gamma), float(alpha))
+        ctx.save_for_backward(logits, target, class_weights)
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        logits, target, cw = ctx.saved_tensors
+        n, hw, c, tf, gamma, alpha = ctx.meta
+        g = gout.contiguous().to(F32).view(1)
+        dl = torch.empty_like(logits)
+        lib().call("hn_seg_focal_bwd", ptr(logits), logits.stride(2), c, ptr(target), tf, ptr(cw), gamma, alpha, n, hw, ptr(g), ptr(dl),
+                   dl.stride(2))
+        return dl, None, None, None, None
+
+
+def seg_focal_loss_hip(seg_nchw, target, class_weights, gamma=2.0, alpha=1.0):
+    """CrossEntropyLoss.forward with use_focal=True (gamma 2, alpha 1: the defaults model.py:119-124 leaves untouched)"""
+    logits = seg_nchw.permute(0, 2, 3, 1)
+    if not logits.is_contiguous():
+        logits = logits.contiguous()
+    return SegFocalLoss.apply(logits, target.contiguous(), class_weights, gamma, alpha)
 
 
 def argmax_channels(seg_nchw):

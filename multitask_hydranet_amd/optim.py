@@ -3,7 +3,7 @@
 The reference trains with `torch.optim.Adam(params, lr, weight_decay=wd)` (model/train.py:147).  On this model that is 693 parameter
 tensors: the foreach implementation issues ~10 multi-tensor launches and takes 3.9 ms per step on MI355X, 17 % on top of the 22.5 ms
 forward + loss + backward.  One pass over (p, g, m, v) moves 1.2 GB: ~0.35 ms.  Same update rule, same state layout (`step`, `exp_avg`,
-`exp_avg_sq` per parameter -- state_dicts are interchangeable with torch.optim.Adam), same operation order (so it tracks torch's result to
+`exp_avg_sq` per parameter -- state_dict() / load_state_dict() are interchangeable with torch.optim.Adam's), same operation order (so it tracks torch's result to
 the last bit or two of fp32); LR schedulers work on `param_groups[i]["lr"]` as usual.  fp32 CUDA parameters only; not amsgrad / maximize.
 """
 from __future__ import annotations
@@ -23,8 +23,26 @@ class Adam(torch.optim.Optimizer):
         self._plans = {}                # (group index, step value) -> (pointer signature, jobs, block_job, blocks)
         self._fast = {}                 # group index -> (gradient tensors of the last step, shared step scalar, plan)
 
+    def state_dict(self):
+        """torch.optim.Adam's layout.  Internally all parameters of a cohort share ONE host `step` scalar (one increment per step instead of
+        693); torch.optim.Adam bumps every parameter's `step` separately, so a shared tensor would advance by #params per step once loaded
+        there: the exported state gives every parameter its own copy."""
+        sd = super().state_dict()
+        sd["state"] = {k: ({**v, "step": v["step"].clone()} if isinstance(v.get("step"), torch.Tensor) else dict(v)) for k, v in sd["state"].items()}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        """the cached job tables hold raw exp_avg / exp_avg_sq pointers of the state they were built from: drop them with it"""
+        super().load_state_dict(state_dict)
+        self._plans.clear()
+        self._fast.clear()
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._plans, self._fast = {}, {}
+
     def _plan(self, key, ps):
-        sig = tuple((p.data_ptr(), p.grad.data_ptr()) for p in ps)
+        sig = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr()) for p in ps)
         pl = self._plans.get(key)
         if pl is not None and pl[0] == sig:
             return pl

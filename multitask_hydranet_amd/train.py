@@ -3,9 +3,11 @@
 Same roles and names as the reference's trainer for the part that touches the hot path: model construction (+ `module.`-prefixed
 checkpoint loading, train.py:96-126), the data-parallel wrap (train.py:130-137 -> multitask_hydranet_amd.ddp.GradReducer, one process per
 GPU over RCCL), Adam + per-iteration CosineAnnealingLR (train.py:147-150), `cal_total_loss` (train.py:192-203), `to_gpu` (train.py:228-239),
-`train_one_epoch` (train.py:241-269) and the segmentation part of `valid` (streaming mIoU on the device, train.py:402-407).  The dataset /
-augmentation pipeline (cv2 + imgaug), COCO json evaluation (pycocotools) and the lane F1 metric stay outside (out of
-scope); any iterable of batch dicts with the Collater contract (dataset/dataloader.py:557-633) drives the loop.
+`train_one_epoch` (train.py:241-269), `valid` (train.py:271-438: losses, streaming mIoU on the device, detection results in COCO json form
+from the device post-process, lane decode on the device) and `main`'s head-wise fine-tuning schedule (train.py:441-515: run_training /
+tuning_phase / HydraTrainer.set_phase).  The dataset / augmentation pipeline (cv2 + imgaug), COCOeval (pycocotools) and the lane F1 metric
+(cv2 rasterisation) stay outside (out of scope); any iterable of batch dicts with the Collater contract
+(dataset/dataloader.py:557-633) drives the loop.
 
 Launch for N GPUs of one node:  python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 your_script.py
 (the trainer reads RANK / LOCAL_RANK / WORLD_SIZE; world size 1 needs no launcher).
@@ -18,10 +20,46 @@ from typing import Dict, Iterable, Optional
 import torch
 import torch.distributed as dist
 
-from .ddp import UNUSED_5STAGE, GradReducer, broadcast_state
+from .ddp import GradReducer, broadcast_state, unused_parameters
 from .metrics import IntersectionOverUnion
 from .model import HydraNet
 from .optim import Adam
+
+
+PHASES = ("joint", "lane", "det", "seg")
+
+
+def tuning_phase(epoch: int, epoch_all: int, epoch_tuning: int, tuning_turn: int):
+    """main(), train.py:445-505: -> (turn, phase) of `epoch` under the head-wise fine-tuning schedule: every turn is `epoch_joint` joint
+    epochs followed by `epoch_tuning` epochs each of lane-only, det-only and seg-only optimisation."""
+    assert 3 * epoch_tuning * tuning_turn <= epoch_all
+    epoch_joint = int(epoch_all / tuning_turn) - epoch_tuning * 3
+    period = epoch_joint + epoch_tuning * 3
+    turn, e = int(epoch / period), epoch % period
+    if e < epoch_joint:
+        return turn, "joint"
+    if e < epoch_joint + epoch_tuning:
+        return turn, "lane"
+    if e < epoch_joint + 2 * epoch_tuning:
+        return turn, "det"
+    return turn, "seg"
+
+
+def run_training(trainer: "HydraTrainer", valid_every_epoch: bool = True, log=print):
+    """main(), train.py:441-515: the epoch loop with the fine-tuning schedule of cfgs["train"] (fine_tuning / epoch_tuning / tuning_turn)"""
+    t = trainer.cfgs["train"]
+    epoch_all = t["epoch"]
+    fine = t.get("fine_tuning", False)
+    for epoch in range(epoch_all):
+        if fine:
+            turn, phase = tuning_phase(epoch, epoch_all, t["epoch_tuning"], t["tuning_turn"])
+            log("======= TURN %i %s TRAINING =======" % (turn, phase.upper()))
+            trainer.set_phase(phase)
+        trainer.train_one_epoch(epoch)
+        if valid_every_epoch and trainer.validloader is not None:
+            log("=========================== VALIDATION %i ===========================" % epoch)
+            trainer.valid(epoch)
+    log("============== finish training ==============")
 
 
 class HydraTrainer:
@@ -53,9 +91,11 @@ class HydraTrainer:
         broadcast_state(self.hydranet)                               # what DDP does at construction (train.py:137)
         self.use_distribute = self.world > 1
         self.reducer = None
+        self.phase = "joint"
+        self._grad_payload = grad_payload
+        self._reducers = {}                                          # one bucket plan per fine-tuning phase (the set of live gradients differs)
         if self.use_distribute:
-            skip = UNUSED_5STAGE if len(self.hydranet.depths) == 5 else ()
-            self.reducer = GradReducer(list(self.hydranet.named_parameters()), world_size=self.world, skip=skip, payload_dtype=grad_payload)
+            self.reducer = self._reducers["joint"] = self._make_reducer("joint")
 
         self.lr, self.weight_decay, self.epoch = t["lr"], t["weight_decay"], t["epoch"]
         n_iter = iters_per_epoch if iters_per_epoch is not None else (len(trainloader) if hasattr(trainloader, "__len__") else 1)
@@ -76,6 +116,41 @@ class HydraTrainer:
             self.metric_evaluator_iou = IntersectionOverUnion(n_classes=len(s["class_list"]), device=self.device)
 
     # ------------------------------------------------------------------------------------------------------------------------------
+    def _phase_module(self, phase):
+        return {"joint": self.hydranet, "lane": self.hydranet.laneheader, "det": self.hydranet.detectheader, "seg": self.hydranet.segheader}[phase]
+
+    def _make_reducer(self, phase):
+        if phase == "joint":
+            named = list(self.hydranet.named_parameters())
+        else:
+            prefix = {"lane": "laneheader.", "det": "detectheader.", "seg": "segheader."}[phase]
+            named = [(n, p) for n, p in self.hydranet.named_parameters() if n.startswith(prefix)]
+        return GradReducer(named, world_size=self.world, skip=unused_parameters(self.hydranet), payload_dtype=self._grad_payload)
+
+    def set_phase(self, phase: str):
+        """One branch of main()'s schedule (train.py:462-505): the optimizer's first param group holds the parameters of the whole model
+        ("joint") or of ONE head; Adam's per-parameter state is kept across phases, exactly as swapping `param_groups[0]['params']` does.
+        In a head-only phase only that head's parameters can change, so the HIP path does not run the backward of the backbone, the neck
+        and the other two heads at all (HydraNet.grad_scope: those parts run forward under no_grad -- BatchNorm running statistics still
+        update, all six losses are still reported); the reference computes those gradients and throws them away."""
+        assert phase in PHASES
+        if self._phase_module(phase) is None:
+            raise ValueError("phase %r needs the %s head (cfgs['train'])" % (phase, phase))
+        self.optimizer.param_groups[0]["params"] = list(self._phase_module(phase).parameters())
+        if phase != self.phase:
+            self.hydranet.zero_grad(set_to_none=True)               # gradients of parameters leaving the group must not linger (or feed Adam later)
+            self._cap = None                                         # a captured step belongs to one phase
+            self._eager_iters = 0
+            if self.use_distribute:
+                self.reducer.remove()
+                if phase not in self._reducers:
+                    self._reducers[phase] = self._make_reducer(phase)
+                else:
+                    self._reducers[phase].arm()
+                self.reducer = self._reducers[phase]
+        self.phase = phase
+        self.hydranet.grad_scope = None if phase == "joint" else phase
+
     def cal_total_loss(self, loss_dict: Dict[str, torch.Tensor]):
         """train.py:192-203: the weighted sum of the task losses (same weights, same association order); on the device it is one launch
         (HydraNet.total_loss -> ops.WeightedLossSum)"""
@@ -164,19 +239,55 @@ class HydraTrainer:
               "  ".join("%s %.3f" % (k, float(v.detach())) for k, v in loss_dict.items()))
 
     @torch.no_grad()
-    def valid(self, epoch: int = 0):
-        """the segmentation part of train.py:271-438: deploy forward, streaming mIoU on the device (the detection COCO json and the lane F1
-        need pycocotools / cv2 and are out of scope); returns the per-class IoU tensor"""
-        self.hydranet.eval()
+    def valid(self, epoch: int = 0, eval_dir: Optional[str] = None, lane_coder=None, det_conf_thres: float = 0.3, det_iou_thres: float = 0.3):
+        """train.py:271-438 without the third-party evaluators: eval-mode forward + the six losses per batch, streaming mIoU on the device
+        (train.py:293-306), detection results through the device post-process in COCO-json form (train.py:308-364; written to
+        `eval_dir`/val_bbox_results.json like train.py:416-421 -- the file COCOeval reads), lane decode + NMS on the device and the
+        prediction json of LaneHeader.scale_to_org (train.py:366-395) when a `lane_coder` (LaneCodec) is given.  COCOeval / LaneMetric
+        themselves need pycocotools / cv2 (out of scope).  Returns the per-class IoU tensor; everything else is left in self.last_valid."""
+        from .coco_json import detections_to_coco, invert_affine, write_results
+        net = self.hydranet
+        net.eval()
         if self.train_seg:
             self.metric_evaluator_iou = IntersectionOverUnion(n_classes=self.metric_evaluator_iou.n_classes, device=self.device)
-        for batch_data in self.validloader:
+        detect_result, lane_result, losses = [], [], []
+        net_w, net_h = net.net_input_width, net.net_input_height
+        for iter_idx, batch_data in enumerate(self.validloader):
             batch_data = self.to_gpu(batch_data)
-            dep = self.hydranet(batch_data["image"], "deploy")
-            if self.train_seg:
-                self.metric_evaluator_iou.update(dep[0], batch_data["gt_seg"])
-        self.hydranet.train()
-        return self.metric_evaluator_iou.compute() if self.train_seg else None
+            inputs = batch_data["image"]
+            n = inputs.shape[0]
+            outputs = net(inputs)
+            have_gt = all(k in batch_data for k, on in (("gt_seg", self.train_seg), ("gt_det", self.train_detect), ("gt_cls", self.train_lane),
+                                                         ("gt_loc", self.train_lane)) if on)
+            if have_gt:
+                loss_dict = net.cal_loss(outputs, batch_data)
+                loss_dict["total_loss"] = self.cal_total_loss(loss_dict)
+                losses.append({k: float(v) for k, v in loss_dict.items()})
+                if self.rank == 0 and iter_idx % self.print_interval == 0:
+                    self.print_loss_info(loss_dict, epoch, iter_idx, mode="valid")
+            shapes = batch_data.get("src_image_shape") or [{"width": net_w, "height": net_h}] * n
+            if self.train_seg and "gt_seg" in batch_data:
+                from . import ops as K
+                self.metric_evaluator_iou.update(K.argmax_channels(outputs["seg"]), batch_data["gt_seg"])
+            if self.train_detect:
+                d = outputs["detection"]
+                preds = net.detectheader.decode(inputs, d["regression"], d["classification"], d["anchors"], conf_thres=det_conf_thres,
+                                                iou_thres=det_iou_thres)
+                metas = [[net_w, net_h, sh["width"], sh["height"], 0, 0] for sh in shapes]
+                preds = invert_affine(metas, preds)
+                detect_result += detections_to_coco(preds, iter_idx * self.cfgs["train"].get("batch_size_valid", n) + 1)
+            if self.train_lane and lane_coder is not None:
+                l = self.cfgs["lane"]
+                lanes = net.laneheader.decode_batch(outputs["lane"]["predict_cls"], outputs["lane"]["predict_loc"], lane_coder,
+                                                    l.get("conf_thres", 0.5), l.get("nms_thres", 100), False)
+                for ln, sh in zip(lanes, shapes):
+                    pj = net.laneheader.scale_to_org(ln, net_w, net_h, sh["width"], sh["height"])
+                    lane_result.append(dict(pr_result={**pj, **dict(Shape=sh)}))
+        net.train()
+        scores = self.metric_evaluator_iou.compute() if self.train_seg else None
+        path = write_results(detect_result, eval_dir) if (eval_dir and self.train_detect and self.rank == 0) else None
+        self.last_valid = dict(losses=losses, detect_result=detect_result, detect_json=path, lane_result=lane_result, iou=scores)
+        return scores
 
     def save(self, path: str):
         """checkpoint in the reference's format: a DDP-wrapped module's state_dict carries "module." prefixes (train.py:437)"""

@@ -49,11 +49,13 @@ def _np(t):
     return t.detach().cpu().numpy()
 
 
-def tiny_fixture():
+def tiny_fixture(cfg_name="hydranet_tiny.yml", out_name="tiny_hydranet.npz"):
+    """tiny 5-stage cfg (default) or the tiny 4-stage / focal cfg (hydranet_tiny4.yml: the family of the reference's
+    hydranet_joint_small_backbone.yml -- net/bifpn.py:158-160 p5_to_p6 path, segmentation_loss.py:31-46 focal loss)"""
     from model import HydraNet  # the reference
     from head_lane.lanedetect_loss import cal_loss_regress
 
-    cfgs = yaml.safe_load(open(os.path.join(ROOT, "cfgs", "hydranet_tiny.yml")))
+    cfgs = yaml.safe_load(open(os.path.join(ROOT, "cfgs", cfg_name)))
     h = w = 128
     n = 2
     torch.manual_seed(0)
@@ -137,8 +139,8 @@ def tiny_fixture():
         res[f"deploy/pp{i}/rois"] = np.asarray(o["rois"], dtype=np.float32)
         res[f"deploy/pp{i}/class_ids"] = np.asarray(o["class_ids"], dtype=np.int64)
         res[f"deploy/pp{i}/scores"] = np.asarray(o["scores"], dtype=np.float32)
-    np.savez_compressed(os.path.join(HERE, "tiny_hydranet.npz"), **res)
-    print("tiny fixture: %d arrays, losses:" % len(res), {k: float(v) for k, v in ld.items()}, "nograd", nograd)
+    np.savez_compressed(os.path.join(HERE, out_name), **res)
+    print("%s: %d arrays, losses:" % (out_name, len(res)), {k: float(v) for k, v in ld.items()}, "nograd", nograd)
 
 
 def loss_kats():
@@ -242,14 +244,16 @@ def _digest(t):
     return np.array([float(t.mean()), float(t.abs().max()), float(t.norm())], dtype=np.float64)
 
 
-def big_digest():
-    """Big cfg (the reference's own hydranet_joint_big_backbone.yml, repo-default 640x640), B=1: state_dict key/shape list and NUMERIC
+def big_digest(cond=False):
+    """cond: the same digests on the WELL-CONDITIONED state (tests/helpers.conditioned_state: residual-branch BatchNorm scale x0.1) ->
+    big_cond.npz: the state on which the HIP path is held to ABSOLUTE tolerances against fp32 at full size (tests/test_fullsize3_gpu.py).
+    Big cfg (the reference's own hydranet_joint_big_backbone.yml, repo-default 640x640), B=1: state_dict key/shape list and NUMERIC
     digests (mean, abs-max, L2) of every feature map / head output / loss / parameter gradient of a training-mode step and of the
     eval-mode forward.  The 171 MB of weights cannot be committed, so they come from a seeded recipe
     (tests/helpers.synthetic_state) that the CPU test re-runs to feed the oracle the same values."""
     from model import HydraNet
     from head_lane.lanedetect_loss import cal_loss_regress  # noqa: F401  (the default points_per_line=160 is live at H=640)
-    from tests.helpers import synthetic_state
+    from tests.helpers import conditioned_state, synthetic_state
     cfgs = yaml.safe_load(open(f"{REF}/cfgs/hydranet_joint_big_backbone.yml"))
     ours = yaml.safe_load(open(os.path.join(ROOT, "cfgs", "hydranet_big.yml")))
     for sec in ("backbone", "detection", "segment", "lane"):         # cfgs/hydranet_big.yml is the same model (paths blanked)
@@ -263,7 +267,7 @@ def big_digest():
     res = {"keys": np.array(keys), "shapes": np.array([",".join(map(str, s)) for s in shapes]),
            "n_params": np.array(sum(p.numel() for p in net.parameters())),
            "param_keys": np.array([k for k, _ in net.named_parameters()])}
-    sd = synthetic_state(keys, shapes, seed=11)
+    sd = (conditioned_state if cond else synthetic_state)(keys, shapes, seed=11)
     net.load_state_dict(sd)
     res["digest/state_sha256"] = np.array(hashlib.sha256(b"".join(np.ascontiguousarray(_np(sd[k])).tobytes() for k in keys)).hexdigest())
     batch = O.synthetic_batch(cfgs, 1, h, w, seed=1)
@@ -304,8 +308,8 @@ def big_digest():
     res["digest/eval/lane_cls"], res["digest/eval/lane_loc"] = _digest(dep[4]), _digest(dep[5])
     cnt = torch.bincount(dep[0].flatten(), minlength=5)
     res["digest/eval/seg_argmax_hist"] = _np(cnt).astype(np.int64)
-    np.savez_compressed(os.path.join(HERE, "big_keys.npz"), **res)
-    print("big cfg: %d state_dict entries, %d params; losses" % (len(keys), int(res["n_params"])),
+    np.savez_compressed(os.path.join(HERE, "big_cond.npz" if cond else "big_keys.npz"), **res)
+    print("big cfg%s: %d state_dict entries, %d params; losses" % (" (conditioned state)" if cond else "", len(keys), int(res["n_params"])),
           {k: float(v) for k, v in ld.items()}, "argmax hist", cnt.tolist())
 
 
@@ -394,15 +398,68 @@ def aux_fixture():
     print("aux fixture:", {k: v.shape for k, v in res.items()})
 
 
+def schedule_fixture():
+    """The head-wise fine-tuning schedule (train.py:441-515) by running the reference's own `main` -- extracted from its source with ast
+    and executed against a recording stand-in for HydraTrainer (train.py itself cannot be imported: dataset / cv2 / pycocotools) -- for a
+    few (epoch, epoch_tuning, tuning_turn) settings: which module's parameters() the optimizer's first param group holds in every epoch."""
+    import ast
+    import json
+    src = open(f"{REF}/train.py").read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "main"][0]
+    code = compile(ast.Module(body=[fn], type_ignores=[]), "reference_train_main", "exec")
+
+    class _Mod:
+        def __init__(self, tag):
+            self.tag = tag
+
+        def parameters(self):
+            return [self.tag]
+
+    class _Net(_Mod):
+        def __init__(self):
+            super().__init__("joint")
+            self.laneheader, self.detectheader, self.segheader = _Mod("lane"), _Mod("det"), _Mod("seg")
+
+    out = {}
+    for epoch_all, epoch_tuning, turns, fine in ((16, 1, 2, True), (30, 1, 1, True), (24, 2, 2, True), (12, 1, 4, True), (5, 1, 1, False)):
+        log = []
+
+        class _Trainer:
+            def __init__(self, cfgs, cfg_path):
+                self.use_distribute = False
+                self.hydranet = _Net()
+                self.optimizer = types.SimpleNamespace(param_groups=[{"params": ["initial"]}])
+
+            def train_one_epoch(self, epoch):
+                log.append(self.optimizer.param_groups[0]["params"][0])
+
+            def valid(self, epoch):
+                pass
+
+        cfg = {"train": {"epoch": epoch_all, "fine_tuning": fine, "epoch_tuning": epoch_tuning, "tuning_turn": turns}}
+        ns = {"yaml": types.SimpleNamespace(safe_load=lambda f: cfg), "open": lambda p: p, "HydraTrainer": _Trainer, "print": lambda *a, **k: None}
+        exec(code, ns)
+        ns["main"]("cfg")
+        out["%d,%d,%d,%d" % (epoch_all, epoch_tuning, turns, int(fine))] = log
+        print("schedule", epoch_all, epoch_tuning, turns, fine, log)
+    json.dump(out, open(os.path.join(HERE, "tuning_schedule.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
     _install_shims()
-    which = sys.argv[1:] or ["tiny", "kats", "big", "lane", "aux"]
+    which = sys.argv[1:] or ["tiny", "tiny4", "kats", "big", "bigcond", "lane", "aux", "schedule"]
     if "tiny" in which:
         tiny_fixture()
+    if "tiny4" in which:
+        tiny_fixture("hydranet_tiny4.yml", "tiny4_hydranet.npz")
+    if "schedule" in which:
+        schedule_fixture()
     if "kats" in which:
         loss_kats()
     if "big" in which:
         big_digest()
+    if "bigcond" in which:
+        big_digest(cond=True)
     if "lane" in which:
         lane_fixture()
     if "aux" in which:

@@ -69,3 +69,18 @@ def synthetic_state(keys, shapes, seed=11):
         else:                                                # BatchNorm gamma
             sd[k] = 0.5 + torch.rand(shp, generator=g)
     return sd
+
+
+RESIDUAL_GAMMA = 0.1
+
+
+def conditioned_state(keys, shapes, seed=11, residual_gamma=RESIDUAL_GAMMA):
+    """synthetic_state with the LAST BatchNorm of every XBlock (conv_block_3.1.weight, the scale of the residual branch) multiplied by
+    `residual_gamma`: the zero-init-residual practice of trained residual networks.  The random-weight synthetic_state amplifies any
+    perturbation ~1.5x per block (30 blocks: x200), which makes end-to-end bf16-vs-fp32 statements vacuous; on this
+    state the backbone is well conditioned and absolute tolerances can be stated (tests/test_fullsize3_gpu.py)."""
+    sd = synthetic_state(keys, shapes, seed)
+    for k in sd:
+        if k.endswith("conv_block_3.1.weight"):
+            sd[k] = sd[k] * residual_gamma
+    return sd

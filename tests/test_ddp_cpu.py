@@ -113,3 +113,61 @@ def test_reduce_now_tracks_static_graph_grads():
         for i, (a, b) in enumerate(zip(res[0][step], res[1][step])):
             expect = 0.5 * ((1 * (step + 1) + i) + (2 * (step + 1) + i))
             assert (a == b).all() and abs(float(a.reshape(-1)[0]) - expect) < 1e-6 and (a == a.reshape(-1)[0]).all()
+
+
+def _worker_real(rank, world, port, q):
+    """GradReducer over HydraNet's real 697-tensor parameter list (names / shapes recorded from the reference: tests/golden/big_keys.npz)"""
+    import hashlib
+    import numpy as np
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from multitask_hydranet_amd.ddp import GradReducer, UNUSED_5STAGE
+    from tests.helpers import load_npz
+    z = load_npz("big_keys.npz")
+    shapes = dict(zip(z["keys"].tolist(), z["shapes"].tolist()))
+    named = []
+    for i, k in enumerate(z["param_keys"].tolist()):
+        shp = tuple(int(v) for v in shapes[k].split(",")) if shapes[k] else ()
+        named.append((k, torch.nn.Parameter(torch.zeros(shp))))
+    red = GradReducer(list(named), skip=UNUSED_5STAGE)           # DDP's 25 MiB default
+    comp = [[n for n, _ in b["params"]] for b in red.buckets]
+    sizes = [int(b["flat"].numel()) for b in red.buckets]
+    # after-replay mode on the real composition: static gradients, one exchange
+    for j, (n, p) in enumerate(named):
+        if n not in UNUSED_5STAGE:
+            p.grad = torch.full_like(p, float(rank + 1) * (1 + (j % 7)))
+    red.remove()
+    red.bind_static_grads()
+    red.reduce_now()
+    ok = True
+    for j, (n, p) in enumerate(named):
+        if n in UNUSED_5STAGE:
+            ok &= p.grad is None
+        else:
+            ok &= bool((p.grad == 1.5 * (1 + (j % 7))).all())
+    digest = hashlib.sha256("|".join(",".join(c) for c in comp).encode()).hexdigest()
+    q.put((rank, dict(n_buckets=len(comp), sizes=sizes, digest=digest, first=comp[0][:3], last=comp[-1][-3:], ok=bool(ok),
+                      total=sum(len(c) for c in comp))))
+    dist.destroy_process_group()
+
+
+def test_real_parameter_list_buckets_identically_on_both_ranks():
+    """bucket composition / ordering for HydraNet's real parameter list (693 exchanged tensors of 697; 170.9 MB fp32 -> 7 buckets of
+    ~25 MiB in reverse execution order: lane head first, stem last) is identical on both ranks, the four never-used p5_to_p6 tensors are
+    excluded by name, and one exchange over that composition averages every gradient"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_real, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    a, b = res[0], res[1]
+    assert a["digest"] == b["digest"] and a["sizes"] == b["sizes"] and a["n_buckets"] == b["n_buckets"]
+    assert a["ok"] and b["ok"]
+    assert a["total"] == 693 and sum(a["sizes"]) == 42715747 - (376 * 112 + 112 + 112 + 112)
+    assert 6 <= a["n_buckets"] <= 8
+    assert a["first"][0].startswith("laneheader.") and a["last"][-1] == "backbone.net.stem.conv.weight"

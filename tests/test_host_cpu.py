@@ -58,13 +58,35 @@ def test_state_dict_contract_matches_reference(built):
     assert len(list(net.laneheader.parameters())) == 15 and len(list(net.segheader.parameters())) == 18
 
 
-def test_tiny_state_dict_loads_reference_checkpoint(built):
+@pytest.mark.parametrize("fixture,cfg", [("tiny_hydranet.npz", "hydranet_tiny.yml"), ("tiny4_hydranet.npz", "hydranet_tiny4.yml")])
+def test_tiny_state_dict_loads_reference_checkpoint(built, fixture, cfg):
+    """5-stage and 4-stage (small-backbone family) tiny cfgs: the reference's own state_dict loads strictly, key ORDER included"""
     from multitask_hydranet_amd import HydraNet
     from tests.helpers import tiny_state
-    z = load_npz("tiny_hydranet.npz")
-    net = HydraNet(load_cfg("hydranet_tiny.yml"))
-    missing, unexpected = net.load_state_dict(tiny_state(z), strict=True)
+    z = load_npz(fixture)
+    net = HydraNet(load_cfg(cfg))
+    ref = tiny_state(z)
+    missing, unexpected = net.load_state_dict(ref, strict=True)
     assert not missing and not unexpected
+    assert list(net.state_dict().keys()) == [k[3:] for k in z.files if k.startswith("sd/")]
+
+
+def test_small_cfg_is_the_references_four_stage_configuration(built):
+    """cfgs/hydranet_small.yml = model/cfgs/hydranet_joint_small_backbone.yml: RegNet derivation pinned by loss_kats.npz, 4 stages ->
+    p5_to_p6 is USED (no parameter excluded from the gradient exchange), focal seg loss"""
+    from multitask_hydranet_amd import HydraNet
+    from multitask_hydranet_amd.ddp import unused_parameters
+    z = load_npz("loss_kats.npz")
+    cfgs = load_cfg("hydranet_small.yml")
+    net = HydraNet(cfgs)
+    assert net.widths == z["regnet/hydranet_joint_small_backbone/widths"].tolist() == [24, 64, 152, 376]
+    assert net.depths == z["regnet/hydranet_joint_small_backbone/depths"].tolist() == [1, 1, 4, 10]
+    assert net.first_cell_counts() == [0, 1, 2, 3] and net._seg_cfg == (False, 0.3, True)
+    assert "neck.bifpn.0.p5_to_p6.0.conv.weight" in net.state_dict() and "neck.bifpn.0.p6_down_channel.0.conv.weight" not in net.state_dict()
+    assert unused_parameters(net) == ()
+    big = HydraNet(load_cfg("hydranet_big.yml"))
+    assert set(unused_parameters(big)) == {"neck.bifpn.0.p5_to_p6.0.conv.weight", "neck.bifpn.0.p5_to_p6.0.conv.bias",
+                                           "neck.bifpn.0.p5_to_p6.1.weight", "neck.bifpn.0.p5_to_p6.1.bias"}
 
 
 def test_anchor_table_matches_oracle(built):
@@ -76,7 +98,7 @@ def test_anchor_table_matches_oracle(built):
 
 
 def test_static_losses_equal_oracle_loops():
-    from multitask_hydranet_amd import losses as L
+    from tests import torch_losses as L
     z = load_npz("loss_kats.npz")
     t = lambda k: torch.from_numpy(z[k])
     for ann in (t("det/ann"), torch.ones(3, 16, 5)):
@@ -154,3 +176,53 @@ def test_dispatcher_ops_are_registered_with_schemas():
         assert out.shape == (2, 8, 8, 64) and coef.shape == (4, 64)
         m = ns.argmax_channels(torch.empty(2, 8, 8, 5, device="cuda"))
         assert m.shape == (2, 8, 8) and m.dtype == torch.int64
+
+
+def test_tuning_schedule_matches_reference_main():
+    """the head-wise fine-tuning schedule (train.py:441-515) against what the reference's own main() did, epoch by epoch
+    (tests/golden/tuning_schedule.json, recorded by make_golden.py::schedule_fixture from the reference source)"""
+    import json
+    import os
+    from multitask_hydranet_amd.train import tuning_phase
+    from tests.helpers import GOLD
+    ref = json.load(open(os.path.join(GOLD, "tuning_schedule.json")))
+    checked = 0
+    for key, phases in ref.items():
+        epoch_all, epoch_tuning, turns, fine = (int(v) for v in key.split(","))
+        if not fine:
+            assert set(phases) == {"initial"}                            # fine_tuning off: the param group is never touched
+            continue
+        period = len(phases) // turns
+        for e, ph in enumerate(phases):
+            turn, mine = tuning_phase(e, epoch_all, epoch_tuning, turns)
+            assert mine == ph and turn == e // period, (key, e, mine, ph)
+            checked += 1
+    assert checked > 60
+    with pytest.raises(AssertionError):
+        tuning_phase(0, 5, 1, 2)                                         # 3 * epoch_tuning * tuning_turn > epoch: the reference asserts too
+
+
+def test_coco_json_records(tmp_path):
+    """COCO-side bookkeeping of HydraTrainer.valid (train.py:308-364, 412-421; head_detect/detection.py:217-229; gen_val_json.py:29-117)"""
+    import json
+    from multitask_hydranet_amd.coco_json import coco_ground_truth, detections_to_coco, invert_affine, write_results
+    preds = [dict(rois=np.array([[64., 32., 128., 96.], [0., 0., 640., 640.]], np.float32), class_ids=np.array([7, 0]), scores=np.array([0.9, 0.31], np.float32)),
+             dict(rois=np.array(()), class_ids=np.array(()), scores=np.array(())),
+             dict(rois=np.array([[10., 20., 30., 50.]], np.float32), class_ids=np.array([2]), scores=np.array([0.5], np.float32))]
+    metas = [[640, 640, 1920, 1080, 0, 0]] * 3
+    preds = invert_affine(metas, preds)
+    np.testing.assert_allclose(preds[0]["rois"][0], [192., 54., 384., 162.])      # x / (640/1920), y / (640/1080)
+    rec = detections_to_coco(preds, first_image_id=9)
+    assert [r["image_id"] for r in rec] == [9, 9, 11] and [r["category_id"] for r in rec] == [8, 1, 3]
+    np.testing.assert_allclose(rec[0]["bbox"], [192., 54., 192., 108.])           # x, y, w, h
+    np.testing.assert_allclose(rec[2]["bbox"], [30., 33.75, 60., 50.625])
+    assert abs(rec[1]["score"] - 0.31) < 1e-6
+    path = write_results(rec, str(tmp_path))
+    assert json.load(open(path)) == rec and write_results([], str(tmp_path)) is None
+    gt = coco_ground_truth([dict(file_name="a.jpg", height=1080, width=1920, annos=["100,200,300,260,7\n", "5.5,6.5,9.5,9.9,0"]),
+                            dict(file_name="empty.jpg", height=1080, width=1920, annos=[]),
+                            dict(file_name="b.jpg", height=720, width=1280, annos=[(1, 2, 3, 4, 8)])])
+    assert [im["id"] for im in gt["images"]] == [1, 2] and [im["file_name"] for im in gt["images"]] == ["a.jpg", "b.jpg"]
+    assert [a["image_id"] for a in gt["annotations"]] == [1, 1, 2] and [a["id"] for a in gt["annotations"]] == [1, 2, 3]
+    assert gt["annotations"][0]["bbox"] == [100.0, 200.0, 200, 60] and gt["annotations"][0]["area"] == 12000
+    assert gt["annotations"][1]["bbox"] == [5.5, 6.5, 4, 3] and len(gt["categories"]) == 9 and gt["categories"][7]["name"] == "vehicle"

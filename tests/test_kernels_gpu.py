@@ -629,7 +629,7 @@ def test_det_loss_matches_reference_loop(K):
 def test_lane_losses_hip_vs_torch(K, case):
     """HIP lane losses (radix-select OHEM threshold, masked Huber) against the static-shape torch forms of losses.py (which
     tests/test_host_cpu.py pins to the oracle / reference KATs), values and gradients."""
-    from multitask_hydranet_amd import losses as L
+    from tests import torch_losses as L
     g = torch.Generator(device="cuda").manual_seed(3)
     n, hw, ppl = 4, 96, 20
     Lc = 2 * ppl + 2
@@ -793,6 +793,76 @@ def test_wgrad_reduces_batched_in_one_launch(K):
         close(g, r, 1e-5, "batched reduce")
 
 
+@pytest.mark.parametrize("stage", ["stage4", "stage2", "stage0", "many"])
+def test_grouped_deferred_wgrad(K, stage):
+    """ops.WgradGroup / hn_wgrad_group: the 1x1 weight gradients of a whole backbone stage in one grouped launch (pixel splits + one
+    grouped slab reduce only where the jobs cannot fill the chip) == the fp32 einsum on the bf16 operands (2e-3 of the gradient's max:
+    fp32 accumulation in another order) and == the one-by-one k_gemm_tn launches (1e-5).  Shapes: a stage-4-like group (no split, tiles
+    write the gradient itself), a stage-2-like group (splits + reduce; the first block's stride-2 shortcut reads x on the stride-2
+    sub-grid, mode 1), stage 0 (24 / 32 channels: K padding and ragged couts), and more jobs than one launch holds."""
+    if stage == "stage4":
+        jobs = [((4, 8, 16), 376, 936, 1), ((4, 16, 32), 376, 936, 0)] + [((4, 8, 16), 936, 936, 0)] * 5
+    elif stage == "stage2":
+        jobs = [((4, 32, 64), 64, 152, 1), ((4, 64, 128), 64, 152, 0)] + [((4, 32, 64), 152, 152, 0)] * 3
+    elif stage == "stage0":
+        jobs = [((2, 64, 128), 32, 24, 1), ((2, 128, 256), 32, 24, 0), ((2, 64, 128), 24, 24, 0)]
+    else:
+        jobs = [((2, 8, 16), 152, 152, 0)] * 37
+    group = K.WgradGroup()
+    ws, refs, ones = [], [], []
+    for i, ((n, h, w), cin, cout, mode) in enumerate(jobs):
+        hi, wi = (2 * h, 2 * w) if mode == 1 else (h, w)
+        x = nhwc(rnd(n, cin, hi, wi))
+        dz = nhwc(rnd(n, cout, h, w, scale=0.1))
+        wgt = torch.empty(cout, cin, 1, 1, device=dev())
+        ws.append(wgt)
+        group.add(wgt, x, dz, mode, (n, h, w), cin, cout)
+        xs = x[:, ::2, ::2] if mode == 1 else x
+        refs.append(torch.einsum("nhwo,nhwi->oi", dz.float(), xs.float()).reshape(cout, cin, 1, 1))
+        ones.append(K.k_gemm_tn(x, None, mode, (n, h, w), dz, cout, K.kp32(cin), 1, cin))
+    group.weights = tuple(ws)
+    got = group.flush()
+    assert len(got) == len(jobs) and not group.jobs
+    for g, r, o in zip(got, refs, ones):
+        assert g.shape == r.shape and g.dtype == torch.float32
+        close(g, r, 2e-3, "grouped wgrad vs einsum")
+        close(g, o, 1e-5, "grouped wgrad vs one-by-one")
+    # weights without a queued job get no gradient
+    group.weights = (ws[0], torch.empty(1))
+    assert group.flush() == [None, None]
+
+
+def test_backbone_stage_with_deferred_wgrad_equals_immediate(K):
+    """HydraNet._backbone_shared with ops.DEFER_WGRAD: a stage's 1x1 weight gradients come out of the DeferredGrads node at the stage
+    boundary.  Same forward (bit-identical outputs), every parameter gradient equal to the immediate path's to fp32 summation-order noise,
+    identical input gradient."""
+    from multitask_hydranet_amd import HydraNet
+    from tests.helpers import load_cfg
+    cfgs = load_cfg("hydranet_tiny.yml")
+    torch.manual_seed(3)
+    net = HydraNet(cfgs).cuda().train()
+    x = torch.randn(4, 3, 128, 256, device=dev())
+    res = []
+    for defer in (False, True):
+        K.DEFER_WGRAD = defer
+        try:
+            net.zero_grad(set_to_none=True)
+            sd = {k: v.clone() for k, v in net.state_dict().items()}
+            feats = net._backbone(x)
+            net._flush_nbt()
+            loss = sum((f.float() ** 2).mean() for f in feats)
+            loss.backward()
+            res.append(([f.detach().clone() for f in feats], {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}))
+            net.load_state_dict(sd)
+        finally:
+            K.DEFER_WGRAD = True
+    (f0, g0), (f1, g1) = res
+    assert all(torch.equal(a, b) for a, b in zip(f0, f1))
+    assert g0.keys() == g1.keys() and any(".conv_block_1.0.weight" in k for k in g0)
+    for k in g0:
+        close(g1[k], g0[k], 1e-5, k)
+
+
 @pytest.mark.parametrize("wd", [0.0, 1e-2])
 def test_hip_adam_tracks_torch_adam(K, wd):
     """multitask_hydranet_amd.optim.Adam (one launch for all parameters) against torch.optim.Adam: same update rule and operation order;
@@ -821,4 +891,29 @@ def test_hip_adam_tracks_torch_adam(K, wd):
         close(sa[k]["exp_avg"], sb[k]["exp_avg"], 1e-5, "exp_avg")
         close(sa[k]["exp_avg_sq"], sb[k]["exp_avg_sq"], 1e-5, "exp_avg_sq")
     oc = torch.optim.Adam([torch.nn.Parameter(p.detach().clone()) for p in pa], 1e-2, weight_decay=wd)
-    oc.load_state_dict(oa.state_dict())                                           # interchangeable state
+    import copy
+    # (deep copies: Optimizer.load_state_dict keeps tensors that already have the parameter's dtype / device, i.e. it would ALIAS the moment
+    # buffers of the optimizer the state came from, and stepping both would update them twice)
+    oc.load_state_dict(copy.deepcopy(oa.state_dict()))                            # interchangeable state
+    # ... also for STEPPING: torch's Adam bumps every parameter's `step` on its own (a shared tensor would advance by #params per step),
+    # and a load into the HIP optimizer after a step must not keep writing into the old moment buffers (cached job tables)
+    pc = oc.param_groups[0]["params"]
+    od = Adam([torch.nn.Parameter(p.detach().clone()) for p in pa], 1e-2, weight_decay=wd)
+    pd = od.param_groups[0]["params"]
+    for q in pd:
+        q.grad = torch.zeros_like(q)
+    od.step()                                                                     # builds the cached tables on a throw-away state
+    for q, a in zip(pd, pa):
+        q.data.copy_(a.detach())
+    od.load_state_dict(copy.deepcopy(ob.state_dict()))
+    for it in range(2):
+        for a, b, c, d in zip(pa, pb, pc, pd):
+            g = torch.randn_like(a)
+            a.grad, b.grad, c.grad, d.grad = g.clone(), g.clone(), g.clone(), g.clone()
+        for o in (oa, ob, oc, od):
+            o.step()
+        for a, b, c, d in zip(pa, pb, pc, pd):
+            tol = 2e-6 * max(float(b.abs().max()), 1e-3)
+            assert float((c - b).abs().max()) <= tol and float((d - b).abs().max()) <= tol and float((a - b).abs().max()) <= tol, (it, tuple(a.shape))
+    for k, v in oc.state_dict()["state"].items():
+        assert float(v["step"]) == float(ob.state_dict()["state"][k]["step"])

@@ -48,16 +48,23 @@ def from_dev(t):
     return t.detach().float().permute(0, 3, 1, 2).cpu()
 
 
-@pytest.fixture(scope="module")
-def env():
+# "tiny": 5 backbone stages, top-k CE (the family of the big cfgs); "tiny4": 4 stages -> the p5_to_p6 path of the first BiFPN cell
+# (net/bifpn.py:158-160) and the focal seg loss (segmentation_loss.py:31-46): the family of model/cfgs/hydranet_joint_small_backbone.yml
+VARIANTS = {"tiny": ("tiny_hydranet.npz", "hydranet_tiny.yml"), "tiny4": ("tiny4_hydranet.npz", "hydranet_tiny4.yml")}
+_variant = ["tiny"]
+
+
+@pytest.fixture(scope="module", params=["tiny", "tiny4"])
+def env(request):
     if not torch.cuda.is_available():
         pytest.skip("needs the MI355X")
     import __graft_entry__ as g
     g.build()
     from multitask_hydranet_amd import HydraNet
     from oracle import hydranet_oracle as O
-    z = load_npz("tiny_hydranet.npz")
-    cfgs = load_cfg("hydranet_tiny.yml")
+    _variant[0] = request.param
+    z = load_npz(VARIANTS[request.param][0])
+    cfgs = load_cfg(VARIANTS[request.param][1])
     sd = tiny_state(z)
     batch = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in/")}
     ppl = int(z["meta/lane_points_per_line"])
@@ -119,9 +126,12 @@ def check_params(net, oracle, prefix, report):
     bad = {}
     n = 0
     for name, p in net.named_parameters():
-        if not name.startswith(prefix) or name.startswith("neck.bifpn.0.p5_to_p6"):
+        if not name.startswith(prefix):
             continue
         ref = oracle["sd"][name].grad
+        if name.startswith("neck.bifpn.0.p5_to_p6") and ref is None:       # 5-stage cfgs: the last stage is P6, p5_to_p6 never runs
+            assert p.grad is None, name
+            continue
         assert p.grad is not None and ref is not None, name
         g = p.grad.float().cpu()
         n += 1
@@ -131,7 +141,11 @@ def check_params(net, oracle, prefix, report):
         cos = float(F.cosine_similarity(g.flatten(), ref.flatten(), dim=0)) if g.numel() > 1 else float(torch.sign(g * ref).item())
         e = serr(g, ref)
         report[name] = (cos, e)
-        if re.search(r"\.p\d_w\d$", name):
+        if g.numel() <= 4 and name.endswith(".bias"):
+            # a 2-class head bias: its gradient is the sum of 32 bf16-rounded per-pixel gradients of mixed sign (cancellation) on this
+            # 2-image fixture -- direction exact, magnitude to 1e-1
+            ok = cos >= SEG_GRAD_COS and e <= 1e-1
+        elif re.search(r"\.p\d_w\d$", name):
             # BiFPN fusion weights: d/dp_i = (dw_i - sum_j w_j dw_j) / (sum relu(p) + eps) is a difference of nearly equal sums, which
             # amplifies the bf16 noise of dw (itself checked at 3e-2 in test_kernels_gpu.py::test_bifpn_fuse) by the cancellation factor
             ok = cos >= 0.98 and e <= 0.5
@@ -170,7 +184,7 @@ def run_segment(net, fn, inputs, ref_out, ref_in_grads, ref_out_grads):
 
 def finish(name, res, bad, report):
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    json.dump({"io": res, "param_grads": report}, open(os.path.join(ROOT, "gpurun_out", f"segment_{name}.json"), "w"), indent=1)
+    json.dump({"io": res, "param_grads": report}, open(os.path.join(ROOT, "gpurun_out", f"segment_{_variant[0]}_{name}.json"), "w"), indent=1)
     print(name, res, "worst param grads:", sorted(report.items(), key=lambda kv: kv[1][0])[:3])
     for k, v in res.items():
         assert v <= (SEG_ACT_TOL if k.startswith("out") else SEG_GRAD_TOL), (name, k, v)
@@ -180,6 +194,8 @@ def finish(name, res, bad, report):
 @pytest.mark.parametrize("stage", [0, 1, 2, 3, 4])
 def test_segment_backbone_stage(env, stage):
     z, cfgs, net, batch, oracle, sd = env
+    if stage >= len(oracle["depths"]):
+        pytest.skip("4-stage cfg")
     p = "backbone.net."
 
     def fn(x):
@@ -277,12 +293,12 @@ def test_end_to_end_losses_features_and_statistics(env):
     rep["rel_l2_vs_reference_fp32"]["regression"] = l2err(out["detection"]["regression"], z["out/regression"])
     rep["rel_l2_vs_reference_fp32"]["classification"] = l2err(out["detection"]["classification"], z["out/classification"])
     rep["rel_l2_vs_reference_fp32"]["lane_loc"] = l2err(out["lane"]["predict_loc"], z["out/lane_loc"])
-    json.dump(rep, open(os.path.join(ROOT, "gpurun_out", "tiny_end_to_end.json"), "w"), indent=1)
+    json.dump(rep, open(os.path.join(ROOT, "gpurun_out", f"{_variant[0]}_end_to_end.json"), "w"), indent=1)
     print(rep)
     for k, (a, b) in rep["loss"].items():                      # lane losses sit behind the deepest (most chaotic) features
         assert abs(a - b) <= (1e-2 if k in ("total", "loss_seg", "loss_det_cls", "loss_det_reg") else 6e-2) * abs(b), (k, a, b)
-    for k in ("feat0", "feat1", "feat2"):
-        assert rep["max_norm_vs_reference_fp32"][k] <= 3e-2, (k, rep["max_norm_vs_reference_fp32"][k])
+    for k in ("feat0", "feat1", "feat2"):           # (feat2 of the tiny4 state sits behind its noisiest block: 4.3e-2 measured, 2.8e-2 in L2)
+        assert rep["max_norm_vs_reference_fp32"][k] <= (5e-2 if (k == "feat2" and _variant[0] == "tiny4") else 3e-2), (k, rep["max_norm_vs_reference_fp32"][k])
     assert rep["rel_l2_vs_reference_fp32"]["seg"] <= 5e-2
     # deep tensors of this 2-image, 128x128 fixture are normalised over as few as 2..8 samples: informational only (see module docstring)
     assert np.array_equal(out["detection"]["anchors"].cpu().numpy(), z["out/anchors"])
@@ -292,7 +308,7 @@ def test_end_to_end_losses_features_and_statistics(env):
         assert (p.grad is None) == (name in nograd), name
     cur = net.state_dict()
     for k in z.files:
-        if k.startswith("sd_after/") and not k[9:].startswith("neck.bifpn.0.p5_to_p6"):
+        if k.startswith("sd_after/") and not (k[9:].startswith("neck.bifpn.0.p5_to_p6") and nograd):
             name = k[9:]
             if name.endswith("num_batches_tracked"):
                 assert int(cur[name]) == int(z[k]), name
@@ -314,7 +330,7 @@ def test_deploy_mode_and_bit_exact_bookkeeping(env):
     e2e = dict(regression=serr(dep[2], z["deploy/regression"]), classification=serr(dep[3], z["deploy/classification"]),
                lane_cls=serr(dep[4], z["deploy/lane_cls"]),
                seg_mask_agreement=float((dep[0].cpu() == torch.from_numpy(z["deploy/seg_argmax"])).float().mean()))
-    json.dump(e2e, open(os.path.join(ROOT, "gpurun_out", "tiny_eval_end_to_end.json"), "w"), indent=1)
+    json.dump(e2e, open(os.path.join(ROOT, "gpurun_out", f"{_variant[0]}_eval_end_to_end.json"), "w"), indent=1)
     print("tiny eval end-to-end vs reference fp32:", e2e)
     assert e2e["regression"] <= 4e-2 and e2e["classification"] <= 4e-2 and e2e["lane_cls"] <= 4e-2 and e2e["seg_mask_agreement"] >= 0.97
     # argmax is bit-exact GIVEN identical logits (device argmax of the reference's logits == CPU argmax)
@@ -388,23 +404,27 @@ def test_det_towers_level_packed_equals_per_level(hh, ww, n):
 
 
 @pytest.mark.gpu
-def test_focal_seg_loss_takes_float_class_ids():
-    """small-backbone cfg variant (segment.use_focal): to_gpu delivers gt_seg as float32 class ids (train.py:228-239) and the reference
-    casts them with .long() (model.py:212); the drop-in must accept the same batch.  Value against the oracle's restatement."""
-    import copy
+@pytest.mark.parametrize("float_ids", [True, False])
+def test_focal_seg_loss_kernels(float_ids):
+    """small-backbone cfg variant (segment.use_focal, head_seg/segmentation_loss.py:31-46) on the HIP kernels (hn_seg_focal_fwd / _bwd):
+    to_gpu delivers gt_seg as float32 class ids (train.py:228-239) and the reference casts them with .long() (model.py:212); the drop-in
+    accepts both.  Value (1e-5) and logits gradient (1e-4 of its max) against the oracle's restatement in fp32."""
     from multitask_hydranet_amd import HydraNet
     from oracle import hydranet_oracle as O
-    cfgs = copy.deepcopy(load_cfg("hydranet_tiny.yml"))
-    cfgs["segment"]["use_focal"], cfgs["segment"]["use_top_k"] = True, False
+    cfgs = load_cfg("hydranet_tiny4.yml")
+    assert cfgs["segment"]["use_focal"] and not cfgs["segment"]["use_top_k"]
     torch.manual_seed(1)
     net = HydraNet(cfgs).cuda().train()
     g = torch.Generator(device="cuda").manual_seed(2)
-    logits = torch.randn(2, 5, 64, 64, device="cuda", generator=g, requires_grad=True)
-    gt = torch.randint(0, 5, (2, 64, 64), device="cuda", generator=g).float()
-    loss = net.loss_seg(logits, gt)
-    loss.backward()
-    ref = O.seg_loss(logits.detach().cpu(), gt.long().cpu(), cfgs["segment"]["class_weight"], False, cfgs["segment"]["top_k_ratio"], True)
-    assert abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref)) and logits.grad is not None
+    logits = (3 * torch.randn(2, 5, 64, 96, device="cuda", generator=g)).requires_grad_(True)
+    gt = torch.randint(0, 5, (2, 64, 96), device="cuda", generator=g)
+    loss = net.loss_seg(logits, gt.float() if float_ids else gt)
+    (loss * 3.0).backward()
+    lr = logits.detach().cpu().requires_grad_(True)
+    ref = O.seg_loss(lr, gt.cpu(), cfgs["segment"]["class_weight"], False, cfgs["segment"]["top_k_ratio"], True)
+    (ref * 3.0).backward()
+    assert abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref))
+    assert float((logits.grad.cpu() - lr.grad).abs().max()) <= 1e-4 * float(lr.grad.abs().max())
 
 
 @pytest.mark.gpu
@@ -413,6 +433,8 @@ def test_seg_loss_gradient_handover_is_bit_identical(env):
     operand form (hn_seg_loss_bwd_s2d through a GradSlot: no fp32 dlogits tensor, no space-to-depth pass).  Same roundings at the same
     places: every seg-decoder gradient must be bit-identical to the plain dlogits path; a second consumer of the logits is added on top."""
     z, cfgs, net, batch, oracle, sd = env
+    if cfgs["segment"]["use_focal"]:
+        pytest.skip("the hand-over exists for the weighted-CE / top-k loss of the big cfgs")
     net.load_state_dict(sd)
     net.train()
     x = batch["image"].to("cuda:0")
@@ -574,7 +596,7 @@ def test_inference_folded_batchnorm(env):
                        seg_mask_agreement=float((fold[0].cpu() == torch.from_numpy(z["deploy/seg_argmax"])).float().mean()),
                        vs_unfolded=dict(regression=serr(fold[2], plain[2]), classification=serr(fold[3], plain[3]), lane_cls=serr(fold[4], plain[4]),
                                         lane_loc=serr(fold[5], plain[5]), mask=float((fold[0] == plain[0]).float().mean())))
-            json.dump(e2e, open(os.path.join(ROOT, "gpurun_out", "tiny_infer_folded.json"), "w"), indent=1)
+            json.dump(e2e, open(os.path.join(ROOT, "gpurun_out", f"{_variant[0]}_infer_folded.json"), "w"), indent=1)
             print("folded inference vs reference fp32:", e2e)
             assert e2e["regression"] <= 4e-2 and e2e["classification"] <= 4e-2 and e2e["lane_cls"] <= 4e-2 and e2e["seg_mask_agreement"] >= 0.97
             assert all(v <= 4e-2 for k, v in e2e["vs_unfolded"].items() if k != "mask") and e2e["vs_unfolded"]["mask"] >= 0.97

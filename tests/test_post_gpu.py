@@ -131,11 +131,14 @@ def test_lane_decode_nms_vs_reference_codec(pkg, tag, case):
     assert len(d["Lines"]) == len(lanes)
 
 
-def test_lane_decode_nms_batch_vs_oracle(pkg):
-    """a random batch of 16 images at 512x1024 (most anchors firing: hundreds of candidates per image) against the oracle, one launch"""
+@pytest.mark.parametrize("n,w,h,thr", [(16, 1024, 512, 0.5), (2, 1920, 1152, 0.5), (1, 2560, 2048, 0.9)])
+def test_lane_decode_nms_batch_vs_oracle(pkg, n, w, h, thr):
+    """a random batch at 512x1024 (512 anchors, most of them firing: hundreds of candidates per image), at the BASELINE config-5 deploy
+    resolution 1152x1920 (2160 anchors: more than one per thread of the workgroup) and at 5120 anchors (> 64 KiB of LDS bookkeeping) against
+    the oracle, one launch each"""
     P, O = pkg
     from multitask_hydranet_amd import lane_codec as LC
-    n, w, h, stride, ppl = 16, 1024, 512, 32, 64
+    stride, ppl = 32, h // 8
     g = torch.Generator().manual_seed(77)
     hw = (w // stride) * (h // stride)
     cls = torch.randn(n, hw, 2, generator=g) * 2
@@ -144,9 +147,9 @@ def test_lane_decode_nms_batch_vs_oracle(pkg):
     loc[:, :, ppl + 1] = torch.rand(n, hw, generator=g) * ppl
     codec = LC.LaneCodec(w, h, stride, ppl)
     geo = O.LaneGeometry(w, h, stride, ppl)
-    res = LC.decode_batch(cls.cuda(), loc.cuda(), codec, 0.5, 30.0, False)
+    res = LC.decode_batch(cls.cuda(), loc.cuda(), codec, thr, 30.0, False)
     for i in range(n):
-        ref = O.lane_postprocess(geo, cls[i].numpy(), loc[i].numpy(), 0.5, 30.0, False)
+        ref = O.lane_postprocess(geo, cls[i].numpy(), loc[i].numpy(), thr, 30.0, False)
         _check_lanes(res[i], [l["prob"] for l in ref], [l["start_pos"] for l in ref], [l["end_pos"] for l in ref], [len(l["xs"]) for l in ref],
                      np.concatenate([l["xs"] for l in ref]) if ref else [], np.concatenate([l["ys"] for l in ref]) if ref else [])
         assert len(ref) > 3

@@ -164,3 +164,135 @@ def test_two_rank_control_flow_on_one_gpu():
     assert o["n_gpus"] == 2 and o["config"]["global_batch"] == 4 and o["config"]["parallelism"] == "dp2" and o["scaling"] == "weak"
     assert "gloo" in o["config"]["grad_allreduce"]
     assert o["value"] > 0 and o["loss"] == o["loss"]
+
+
+def test_fine_tuning_schedule_two_turns(setup):
+    """main()'s head-wise fine-tuning schedule (train.py:441-515) through run_training on the tiny cfg: epoch = 8, epoch_tuning = 1,
+    tuning_turn = 2 -> per turn joint, lane, det, seg.  After every epoch only the parameters of that phase's param group may have moved
+    (joint: the whole model); Adam's state survives the swaps; head-only phases run NO backward outside their head (no gradient appears on
+    any other parameter) while the BatchNorm running statistics of the shared trunk keep updating and all six losses are reported.
+    A head-only step moves its head's parameters exactly like a full-backward step does (same gradients for those parameters)."""
+    import copy
+    from multitask_hydranet_amd.train import HydraTrainer, run_training, tuning_phase
+    z, cfgs0, batch = setup
+    cfgs = copy.deepcopy(cfgs0)
+    cfgs["train"].update(dict(epoch=8, fine_tuning=True, epoch_tuning=1, tuning_turn=2, lr=1e-3))
+    loader = [dict(batch), dict(batch)]
+    tr = HydraTrainer(cfgs, trainloader=loader, validloader=None, iters_per_epoch=len(loader))
+    tr.hydranet.load_state_dict(tiny_state(z))
+    tr.hydranet.lane_points_per_line = int(z["meta/lane_points_per_line"])
+    net = tr.hydranet
+    prefix = {"lane": "laneheader.", "det": "detectheader.", "seg": "segheader."}
+    log = []
+    orig = tr.train_one_epoch
+
+    def spy(epoch):
+        before = {n: p.detach().clone() for n, p in net.named_parameters()}
+        stats = net.state_dict()["backbone.net.stem.bn.running_mean"].clone()
+        orig(epoch)
+        torch.cuda.synchronize()
+        moved = {n for n, p in net.named_parameters() if not torch.equal(p.detach(), before[n])}
+        turn, phase = tuning_phase(epoch, 8, 1, 2)
+        assert tr.phase == phase and net.grad_scope == (None if phase == "joint" else phase)
+        if phase == "joint":
+            assert len(moved) > 0.8 * len(before)
+        else:
+            assert moved and all(n.startswith(prefix[phase]) for n in moved), (phase, sorted(moved)[:5])
+            own = [n for n, _ in net.named_parameters() if n.startswith(prefix[phase])]
+            assert len(moved) >= 0.7 * len(own)
+            # no backward ran outside the head: nothing else holds a gradient
+            assert all(p.grad is None for n, p in net.named_parameters() if not n.startswith(prefix[phase])), phase
+        assert not torch.equal(net.state_dict()["backbone.net.stem.bn.running_mean"], stats)       # training-mode forward everywhere
+        log.append(phase)
+    tr.train_one_epoch = spy
+    run_training(tr, valid_every_epoch=False, log=lambda *a: None)
+    assert log == ["joint", "lane", "det", "seg"] * 2
+    st = tr.optimizer.state
+    lane_w = dict(net.named_parameters())["laneheader.conv_cls_conv.0.weight"]
+    stem_w = dict(net.named_parameters())["backbone.net.stem.conv.weight"]
+    assert int(st[lane_w]["step"]) == 2 * 2 * 2 and int(st[stem_w]["step"]) == 2 * 2       # (joint + lane) x 2 turns x 2 iterations / joint only
+    # a head-only step == the same step with the full backward, for the head's parameters (the reference's semantics)
+    res = []
+    for scoped in (True, False):
+        t2 = HydraTrainer(cfgs, trainloader=loader, validloader=None, iters_per_epoch=len(loader))
+        t2.hydranet.load_state_dict(tiny_state(z))
+        t2.hydranet.lane_points_per_line = int(z["meta/lane_points_per_line"])
+        t2.set_phase("det")
+        if not scoped:
+            t2.hydranet.grad_scope = None                    # the reference: full backward, optimizer only holds the head
+        ld = t2.train_step({k: v.clone() for k, v in batch.items()})
+        res.append(({k: float(v) for k, v in ld.items()},
+                    {n: p.detach().clone() for n, p in t2.hydranet.named_parameters() if n.startswith("detectheader.")}))
+    assert res[0][0] == res[1][0]                            # all six losses reported, identical
+    for n in res[0][1]:
+        assert torch.equal(res[0][1][n], res[1][1][n]), n
+
+
+def test_valid_writes_coco_results_and_lane_json(setup, tmp_path):
+    """HydraTrainer.valid (train.py:271-438) on the device: per-batch losses, streaming mIoU, detection records in COCO-json form out of
+    hn_det_postprocess (+ invert_affine to the source-image size), lane prediction json out of hn_lane_decode_nms"""
+    import json
+    from multitask_hydranet_amd.lane_codec import LaneCodec
+    from multitask_hydranet_amd.train import HydraTrainer
+    z, cfgs, batch = setup
+    vb = dict(batch)
+    vb["src_image_shape"] = [{"width": 1920, "height": 1080}] * batch["image"].shape[0]
+    tr = HydraTrainer(cfgs, trainloader=[dict(batch)], validloader=[vb, dict(vb)], iters_per_epoch=1)
+    tr.hydranet.load_state_dict(tiny_state(z))
+    tr.hydranet.lane_points_per_line = int(z["meta/lane_points_per_line"])
+    h, w = batch["image"].shape[2], batch["image"].shape[3]
+    coder = LaneCodec(w, h, cfgs["lane"]["anchor_stride"], h // cfgs["lane"]["interval"])
+    iou = tr.valid(0, eval_dir=str(tmp_path), lane_coder=coder, det_conf_thres=0.02)
+    lv = tr.last_valid
+    assert torch.isfinite(torch.as_tensor(iou)).all() and len(lv["losses"]) == 2 and set(lv["losses"][0]) >= {"loss_seg", "loss_det_cls", "total_loss"}
+    assert lv["losses"][0] == lv["losses"][1]                      # eval mode: the same batch twice gives the same losses
+    assert len(lv["lane_result"]) == 2 * batch["image"].shape[0] and "Lines" in lv["lane_result"][0]["pr_result"]
+    rec = lv["detect_result"]
+    assert rec and lv["detect_json"] and json.load(open(lv["detect_json"])) == rec
+    n = batch["image"].shape[0]
+    ids = {r["image_id"] for r in rec}
+    assert ids <= set(range(1, 2 * cfgs["train"]["batch_size_valid"] + 1)) and all(1 <= r["category_id"] <= 9 for r in rec)
+    # boxes are in SOURCE-image pixels (1920 x 1080) after invert_affine, x/y/w/h
+    assert max(r["bbox"][0] + r["bbox"][2] for r in rec) <= 1920 + 1e-3 and max(r["bbox"][1] + r["bbox"][3] for r in rec) <= 1080 + 1e-3
+    assert max(r["bbox"][0] + r["bbox"][2] for r in rec) > w
+
+
+def test_eager_hook_exchange_world1_keeps_first_step_gradients(setup):
+    """GradReducer in eager hook mode (the HydraTrainer multi-GPU path) at world size 1 with RCCL: the side-stream gather reads the gradients
+    autograd allocated on the main stream; they must stay alive until the join (stream lifetime).  Two small buckets, first
+    step and a second one: the exchanged gradients equal those of a run without the reducer, bit for bit (average over one rank)."""
+    import torch.distributed as dist
+    from multitask_hydranet_amd import HydraNet
+    from multitask_hydranet_amd.ddp import GradReducer, unused_parameters
+    z, cfgs, batch = setup
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    gb = {k: v.cuda() for k, v in batch.items()}
+    grads = []
+    for use in (False, True):
+        net = HydraNet(cfgs).cuda().train()
+        net.load_state_dict(tiny_state(z))
+        net.lane_points_per_line = int(z["meta/lane_points_per_line"])
+        red = GradReducer(list(net.named_parameters()), world_size=1, skip=unused_parameters(net), bucket_bytes=64 << 10,
+                          force_collectives=True) if use else None
+        if red is not None:
+            assert len(red.buckets) >= 4 and red.active
+        per_step = []
+        for step in range(2):
+            net.zero_grad(set_to_none=(red is None or step == 0))
+            # allocator pressure between backward and the join: recycled blocks would be overwritten here
+            out = net(gb["image"])
+            net.total_loss(net.cal_loss(out, gb)).backward()
+            junk = [torch.full((1 << 18,), 7.0, device="cuda") for _ in range(8)]
+            if red is not None:
+                red.finish()
+            torch.cuda.synchronize()
+            per_step.append({n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None})
+            del junk
+        grads.append(per_step)
+    for step in range(2):
+        assert grads[0][step].keys() == grads[1][step].keys()
+        for n in grads[0][step]:
+            assert torch.equal(grads[0][step][n], grads[1][step][n]), (step, n)

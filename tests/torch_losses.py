@@ -1,5 +1,5 @@
-"""Multitask loss of HydraNet.cal_loss (model/model.py:201-264) restated with static shapes and no host synchronisation, so a
-whole forward+loss+backward step can be captured in one hipGraph.  Values are identical to the reference's per-image Python loops
+"""TEST REFERENCE (not part of the product package): the multitask loss of HydraNet.cal_loss (model/model.py:201-264) as static-shape
+torch ops that run on any device -- the fp32 checker the GPU tests hold the HIP loss kernels against on the device.  Values are identical to the reference's per-image Python loops
 (head_detect/detection_loss.py:132-267, head_lane/lanedetect_loss.py:18-78, head_seg/segmentation_loss.py:27-65); only the control
 flow differs (masks instead of boolean compaction, a sort instead of a data-dependent top-k).
 """
