@@ -225,6 +225,15 @@ int hn_conv_gemm_tn_phase(const void* x0, int n_img, int H, int W, int C0, int l
 int hn_conv_gemm_tn_deferred(const void* x0, const void* x1, int mode, int n_img, int H, int W, int C0, int C1, int ld0, int ld1, int up, long M,
                              const void* dz, int ldz, int Nout, int KP, int taps, float* workspace, float* dw, long* job, hipStream_t stream);
 int hn_wgrad_reduce_jobs(const long* jobs, int njobs, hipStream_t stream);
+/* Deferred parameter-gradient tails in ONE launch (ops.GradQueue): up to 64 small reductions that finish parameter gradients off the
+ * backward pass's critical path.  jobs: HOST table, 8 int64 per job {kind, a, b, out, out2, n0, n1, n2}:
+ *   kind 0: out[c] = sum_r a[r][c], a fp32 [n0 rows][n1 cols] -- partial-row folds of depthwise / stride-2 grouped conv weight gradients
+ *           (reference ops: the weight gradient of net/common.py:85-95 depthwise convs, net/anynet.py:34-38 grouped convs);
+ *   kind 1: BiFPN fusion-weight Jacobian (net/bifpn.py:179-180): a = per-block sums [n0][3], b = raw parameter [n1 <= 3], out = gradient
+ *           [n1], n2 = float bits of eps;
+ *   kind 2: SE MLP outer product (net/anynet.py:43-47): out[i][j] = sum_n a[n][i] * b[n][j], out2[i] = sum_n a[n][i]; a [n2][n0], b [n2][n1]. */
+int hn_grad_tail(const long* jobs, int njobs, hipStream_t stream);
+
 /* Deferred, grouped 1x1 weight gradients: up to 32 independent dw_j [Nout][Cin] (fp32) = dz_j^T . x_j in ONE GEMM launch (+ one slab-reduce
  * launch only when the jobs cannot fill the chip without a pixel split).  Replaces, for a whole backbone stage, the per-conv weight
  * gradients autograd's convolution_backward produces one by one (reference: conv_block_1 / conv_block_3 / shortcut of every XBlock,

@@ -995,6 +995,7 @@ struct GemmTN {
                       // non-zero effective weights on 4 of the 9 taps, the other five are skipped (their slab entries stay zero)
     float* bias_part; // patch wgrad only (optional): [slabs][Nout] per-slab column sums of dZ (= the conv's bias gradient), accumulated by
                       // one extra MFMA per k-step against an all-ones operand while the dZ fragments are in registers anyway
+    int dbg;          // tools/ only (hn_debug_knob 9): 1 = skip the epilogue stores, 2 = skip the MFMAs, 4 = skip the loads
     int out_ld;       // gemm_tn: 0 = partial slabs [split][Nout][taps*KP]; > 0 = ONE split writing the gradient itself, row stride out_ld
     int cin_lim;      //          (= Cin of a 1x1 conv: dw[co][ci]), columns >= cin_lim (the K padding) are dropped
 };
@@ -1004,7 +1005,7 @@ struct GemmTN {
 //   physical piece = piece ^ ((((row & 7) / (16 / NP)) << 1) & (NP - 1)),  NP = COLS / 8 pieces per row.
 template <int COLS>
 __device__ __forceinline__ int tn_swz(int row, int piece) {
-    constexpr int NP = COLS / 8, RPL = 16 / NP;
+    constexpr int NP = COLS / 8, RPL = NP >= 16 ? 1 : 16 / NP;      // (rows of >= 256 B alias the same banks: one 32-byte shift per row)
     return piece ^ ((((row & 7) / RPL) << 1) & (NP - 1));
 }
 
@@ -1012,7 +1013,8 @@ template <int BC, int BN, int WGC, int WGN>
 __device__ __forceinline__ void gemm_tn_body(const GemmTN& p, const int lid) {   // lid: logical block id inside this GEMM (see below)
     constexpr int WC = BC / WGC, WN = BN / WGN, TC = WC / 16, TN = WN / 16;
     constexpr int ZPR = BC / 8, XPR = BN / 8;                     // 16-byte pieces per row
-    constexpr int ZL = (64 * ZPR + 255) / 256, XL = (64 * XPR + 255) / 256;
+    constexpr int NT = 64 * WGC * WGN;                             // 4 waves, or 8 for the largest tile
+    constexpr int ZL = (64 * ZPR + NT - 1) / NT, XL = (64 * XPR + NT - 1) / NT;
     constexpr int ZB = 64 * BC * 2, XB = 64 * BN * 2, STAGE = ZB + XB;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // two stages of [dZ tile | X tile]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1046,7 +1048,7 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTN& p, const int lid) {  
     // per-piece pixel coordinates, advanced by 64 rows per stage without divisions
     int pn[XL], py[XL], px[XL];
 #pragma unroll
-    for (int i = 0; i < XL; ++i) decomp_row(p.x, m_begin + (tid + 256 * i) / XPR, pn[i], py[i], px[i]);
+    for (int i = 0; i < XL; ++i) decomp_row(p.x, m_begin + (tid + NT * i) / XPR, pn[i], py[i], px[i]);
     const int adv_q = p.x.mode ? 64 / p.x.W : 0, adv_r = p.x.mode ? 64 % p.x.W : 0;
     const int Ctot = p.x.C0 + p.x.C1;
     // mode 2 (3x3 reflect + up + concat), this block's tap: source coordinates are separable, so they are tabulated once per block:
@@ -1057,13 +1059,13 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTN& p, const int lid) {  
     int* tx1 = ty1 + p.x.H;
     if (p.x.mode == 2) {
         const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
-        for (int i = tid; i < p.x.H; i += 256) {
+        for (int i = tid; i < p.x.H; i += NT) {
             int iy = i + ky - 1;
             iy = border_idx(iy, p.x.Hi, p.x.clamp);
             ty1[i] = iy;
             ty0[i] = iy >> p.x.up;
         }
-        for (int i = tid; i < p.x.W; i += 256) {
+        for (int i = tid; i < p.x.W; i += NT) {
             int ix = i + kx - 1;
             ix = border_idx(ix, p.x.Wi, p.x.clamp);
             tx1[i] = ix;
@@ -1082,7 +1084,7 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTN& p, const int lid) {  
     int zrow[ZL], xrow[XL];
 #pragma unroll
     for (int i = 0; i < ZL; ++i) {
-        const int e = tid + 256 * i;
+        const int e = tid + NT * i;
         const int row = e / ZPR, cp = tn_swz<BC>(row, e - row * ZPR);
         const int co = c_blk + cp * 8;
         zrow[i] = row;
@@ -1090,7 +1092,7 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTN& p, const int lid) {  
     }
 #pragma unroll
     for (int i = 0; i < XL; ++i) {
-        const int e = tid + 256 * i;
+        const int e = tid + NT * i;
         const int row = e / XPR, cp = tn_swz<BN>(row, e - row * XPR);
         const int c = ci_blk + cp * 8;
         xrow[i] = row;
@@ -1099,29 +1101,29 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTN& p, const int lid) {  
     for (int it = 0; it <= S; ++it) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's LDS-DMA of stage it-1 has landed ...
         __syncthreads();                                           // ... and so has everybody else's; buffer it&1 is free again
-        if (it < S) {
+        if (it < S && !(p.dbg & 4)) {
             char* sZ = smem + (it & 1) * STAGE;
             char* sX = sZ + ZB;
             const long m0 = m_begin + (long)it * 64;
 #pragma unroll
             for (int i = 0; i < ZL; ++i) {
-                if (256 * i + 64 * wave < 64 * ZPR) {              // wave-uniform: this 1 KiB run lies inside the tile
+                if (NT * i + 64 * wave < 64 * ZPR) {              // wave-uniform: this 1 KiB run lies inside the tile
                     // dZ rows are zero padded up to ldz (>= Nout rounded up to 8), so a piece that starts below Nout is readable
                     const bf16* src = (m0 + zrow[i] < m_end && zoff[i] >= 0) ? p.dz + zoff[i] : g_zero_piece;
-                    glds16(src, sZ + (256 * i + 64 * wave) * 16);
+                    glds16(src, sZ + (NT * i + 64 * wave) * 16);
                     zoff[i] += zoff[i] >= 0 ? 64L * p.ldz : 0;
                 }
             }
 #pragma unroll
             for (int i = 0; i < XL; ++i) {
-                if (256 * i + 64 * wave < 64 * XPR) {
+                if (NT * i + 64 * wave < 64 * XPR) {
                     if (p.x.mode == 0) {                           // plain rows: pointer walk
                         const bf16* src0 = (m0 + xrow[i] < m_end && xoff[i] >= 0) ? p.x.x0 + xoff[i] : g_zero_piece;
-                        glds16(src0, sX + (256 * i + 64 * wave) * 16);
+                        glds16(src0, sX + (NT * i + 64 * wave) * 16);
                         xoff[i] += xoff[i] >= 0 ? 64L * p.x.ld0 : 0;
                         continue;
                     }
-                    const int e = tid + 256 * i;
+                    const int e = tid + NT * i;
                     const int row = e / XPR, cp = tn_swz<BN>(row, e - row * XPR);
                     const long m = m0 + row;
                     const int c = ci_blk + cp * 8;
@@ -1135,7 +1137,7 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTN& p, const int lid) {  
                             if (off >= 0) src = p.x.x0 + c + off;
                         }
                     }
-                    glds16(src, sX + (256 * i + 64 * wave) * 16);
+                    glds16(src, sX + (NT * i + 64 * wave) * 16);
                     if (p.x.mode) {                                // advance this piece's pixel by 64 rows
                         px[i] += adv_r;
                         py[i] += adv_q;
@@ -1145,7 +1147,7 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTN& p, const int lid) {  
                 }
             }
         }
-        if (it > 0) {
+        if (it > 0 && !(p.dbg & 2)) {
             const char* sZ = smem + ((it - 1) & 1) * STAGE;
             const char* sX = sZ + ZB;
 #pragma unroll
@@ -1189,6 +1191,7 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTN& p, const int lid) {  
             }
     }
     const int Ktot = p.taps * p.KP;
+    if (p.dbg & 1) return;
     const int row_ld = p.out_ld ? p.out_ld : Ktot, ci_lim = p.out_ld ? p.cin_lim : p.KP;
     float* part = p.part + (long)bz * p.Nout * Ktot;
 #pragma unroll
@@ -1210,6 +1213,139 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {   // 
     gemm_tn_body<BC, BN, WGC, WGN>(p, xcd_remap(blockIdx.x, gridDim.x));
 }
 
+// The same contraction for the plain 1x1 cases (mode 0 rows / mode 1 stride-2 gather, one tap) with a ring of R LDS stages of BK pixel
+// rows and COUNTED vmcnt waits: stages it+1 .. it+R-2 stay in flight while stage it is multiplied.  The two-stage loop above exposes one
+// whole LDS-DMA round trip per 64-row step (measured on the grouped stage-4 launch: the loads alone take 186 us, the MFMAs alone 90 us,
+// together 304 us -- nothing overlaps once a workgroup's step is a 2-3 us round trip); the ring keeps R-1 round trips in flight.
+template <int BC, int BN, int WGC, int WGN, int BK, int R>
+__device__ __forceinline__ void gemm_tn_ring_body(const GemmTN& p, const int lid) {
+    constexpr int WC = BC / WGC, WN = BN / WGN, TC = WC / 16, TN = WN / 16;
+    constexpr int ZPR = BC / 8, XPR = BN / 8, NT = 64 * WGC * WGN;
+    static_assert((BK * ZPR) % NT == 0 && (BK * XPR) % NT == 0 && BK % 32 == 0 && R >= 2 && R <= 4, "every wave issues the same number of loads per stage");
+    constexpr int ZL = BK * ZPR / NT, XL = BK * XPR / NT, G = ZL + XL;
+    constexpr int ZB = BK * BC * 2, XB = BK * BN * 2, STAGE = ZB + XB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wc = wave / WGN, wn = wave % WGN;
+    const int ntile = (p.KP + BN - 1) / BN;
+    const int bx = lid % ntile, by = (lid / ntile) % p.gy, bz = lid / (ntile * p.gy);
+    const int ci_blk = bx * BN, c_blk = by * BC;
+    const long m_begin = (long)bz * p.rows_per_split;
+    long m_end = m_begin + p.rows_per_split;
+    if (m_end > p.x.M) m_end = p.x.M;
+    const int S = m_end > m_begin ? (int)((m_end - m_begin + BK - 1) / BK) : 0;
+
+    f32x4 acc[TC][TN];
+#pragma unroll
+    for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // per-piece source offsets, advanced by BK rows per stage
+    long zoff[ZL], xoff[XL];
+    int zrow[ZL], xrow[XL], pn[XL], py[XL], px[XL];
+#pragma unroll
+    for (int i = 0; i < ZL; ++i) {
+        const int e = tid + NT * i;
+        const int row = e / ZPR, cp = tn_swz<BC>(row, e - row * ZPR);
+        const int co = c_blk + cp * 8;
+        zrow[i] = row;
+        zoff[i] = co < p.Nout ? (m_begin + row) * (long)p.ldz + co : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+        const int e = tid + NT * i;
+        const int row = e / XPR, cp = tn_swz<BN>(row, e - row * XPR);
+        const int c = ci_blk + cp * 8;
+        xrow[i] = row;
+        xoff[i] = c < p.x.C0 ? (p.x.mode == 0 ? (m_begin + row) * (long)p.x.ld0 + c : (long)c) : -1;
+        decomp_row(p.x, m_begin + row, pn[i], py[i], px[i]);
+    }
+    const int adv_q = p.x.mode ? BK / p.x.W : 0, adv_r = p.x.mode ? BK % p.x.W : 0;
+    const int g = lane >> 4, t16 = lane & 15, q = t16 >> 2, pp = t16 & 3;
+    typedef __bf16 trv4 __attribute__((__vector_size__(4 * sizeof(__bf16))));
+    typedef __attribute__((address_space(3))) trv4* lds_b4;
+
+    for (int it = 0; it < S + R - 1; ++it) {
+        if (it >= R - 1) {
+            const int newer = (it < S ? it : S) - 1 - (it - (R - 1));     // stages issued after the one multiplied now
+            if (R >= 4 && newer >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * G) : "memory");
+            else if (R >= 3 && newer >= 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(G) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        if (it < S && !(p.dbg & 4)) {
+            char* sZ = smem + (it % R) * STAGE;
+            char* sX = sZ + ZB;
+            const long m0 = m_begin + (long)it * BK;
+#pragma unroll
+            for (int i = 0; i < ZL; ++i) {
+                const bf16* src = (m0 + zrow[i] < m_end && zoff[i] >= 0) ? p.dz + zoff[i] : g_zero_piece;
+                glds16(src, sZ + (NT * i + 64 * wave) * 16);
+                zoff[i] += zoff[i] >= 0 ? (long)BK * p.ldz : 0;
+            }
+#pragma unroll
+            for (int i = 0; i < XL; ++i) {
+                const bf16* src = g_zero_piece;
+                if (m0 + xrow[i] < m_end && xoff[i] >= 0) {
+                    if (p.x.mode == 0) src = p.x.x0 + xoff[i];
+                    else src = p.x.x0 + xoff[i] + (((long)pn[i] * p.x.Hi + 2 * py[i]) * p.x.Wi + 2 * px[i]) * p.x.ld0;
+                }
+                glds16(src, sX + (NT * i + 64 * wave) * 16);
+                if (p.x.mode == 0) xoff[i] += xoff[i] >= 0 ? (long)BK * p.x.ld0 : 0;
+                else {
+                    px[i] += adv_r;
+                    py[i] += adv_q;
+                    if (px[i] >= p.x.W) { px[i] -= p.x.W; ++py[i]; }
+                    while (py[i] >= p.x.H) { py[i] -= p.x.H; ++pn[i]; }
+                }
+            }
+        }
+        if (it >= R - 1 && !(p.dbg & 2)) {
+            const char* sZ = smem + ((it - (R - 1)) % R) * STAGE;
+            const char* sX = sZ + ZB;
+#pragma unroll
+            for (int ks = 0; ks < BK / 32; ++ks) {
+                bf16x8 a[TC], b[TN];
+                const int rlo = ks * 32 + g * 4 + q, rhi = rlo + 16;
+#pragma unroll
+                for (int i = 0; i < TC; ++i) {
+                    const int piece = (wc * WC + i * 16) / 8 + (pp >> 1);
+                    const trv4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(sZ + rlo * (BC * 2) + tn_swz<BC>(rlo, piece) * 16 + (pp & 1) * 8));
+                    const trv4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(sZ + rhi * (BC * 2) + tn_swz<BC>(rhi, piece) * 16 + (pp & 1) * 8));
+                    a[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int piece = (wn * WN + j * 16) / 8 + (pp >> 1);
+                    const trv4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(sX + rlo * (BN * 2) + tn_swz<BN>(rlo, piece) * 16 + (pp & 1) * 8));
+                    const trv4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(sX + rhi * (BN * 2) + tn_swz<BN>(rhi, piece) * 16 + (pp & 1) * 8));
+                    b[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+                for (int i = 0; i < TC; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+    if (p.dbg & 1) return;
+    const int row_ld = p.out_ld ? p.out_ld : p.KP, ci_lim = p.out_ld ? p.cin_lim : p.KP;
+    float* part = p.part + (long)bz * p.Nout * p.KP;
+#pragma unroll
+    for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int ci = ci_blk + wn * WN + j * 16 + (lane & 15);
+            if (ci >= ci_lim) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = c_blk + wc * WC + i * 16 + (lane >> 4) * 4 + r;
+                if (co < p.Nout) part[(long)co * row_ld + ci] = acc[i][j][r];
+            }
+        }
+}
+
 // Several independent 1x1 weight gradients in ONE launch (hn_wgrad_group): the weight gradients of a whole backbone stage are not on the
 // backward pass's critical path, so they are deferred to the stage boundary and run together -- one launch that fills the chip (a
 // stage-4 gradient alone is 64 tiles of 128 x 128 over 2048 rows) instead of ~3 launches + 1 slab reduce per XBlock, mostly without a
@@ -1219,24 +1355,42 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {   // 
 struct TNJob {
     const bf16* x0; const bf16* dz; float* part;
     long M, rows_per_split;
-    int mode, H, W, Hi, Wi, C0, ld0, ldz, Nout, KP, gy, first_block, out_ld;
-};
-struct TNJobs { TNJob j[HN_TN_GROUP_MAX]; int n; };
+    int mode, H, W, Hi, Wi, C0, ld0, ldz, Nout, KP, gy, out_ld;
+    int unit0, splits, tiles;      // placement: this job's units (one unit = one pixel split = `tiles` workgroups that share dZ / X rows)
+};                                 // are the global units [unit0, unit0 + splits)
+struct TNJobs { TNJob j[HN_TN_GROUP_MAX]; int n; int dbg; };
 
-template <int BC, int BN, int WGC, int WGN>
-__global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(const TNJobs jobs) {
-    // XCD-aware order over the WHOLE launch: consecutive logical ids (tiles of one job that share dZ / X rows) run on one XCD
-    const int glid = xcd_remap(blockIdx.x, gridDim.x);
-    int ji = 0;
-    for (int k = 1; k < jobs.n; ++k)
-        if (glid >= jobs.j[k].first_block) ji = k;
+// Placement of a grouped launch.  A 128 x 128 tile over 2048 rows reads 1 MB of operands for 67 MFLOP: the launch lives on L2 hits, i.e. on
+// the tiles that share operand rows running on ONE XCD at the same time (measured with consecutive logical ids spread by xcd_remap over
+// whole-launch ranges: 1.9 GB of L2 misses for 220 MB of operands, 378 us for the 104 GFLOP of stage 4).  So the unit of placement is
+// (job, pixel split) = the `tiles` workgroups that walk the same rows: unit u runs on XCD u % 8 (workgroups are dealt round-robin over the
+// XCDs: hardware block b is on XCD b % 8 and is that XCD's (b / 8)-th workgroup), units of one XCD follow each other, so its 64 resident
+// workgroups are whole units in lockstep and every operand slab is fetched into that L2 once.  Speed only: any placement is correct.
+template <int BC, int BN, int WGC, int WGN, int BK = 64, int R = 0>
+__global__ __launch_bounds__(64 * WGC * WGN, 2) void gemm_tn_group_kernel(const TNJobs jobs) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    int acc = 0, ji = -1, lid = 0;
+    for (int k = 0; k < jobs.n; ++k) {
+        const int u0 = jobs.j[k].unit0, S = jobs.j[k].splits, T = jobs.j[k].tiles;
+        const int first = u0 + ((xcd - u0) & 7);                    // first unit of this job on this XCD
+        const int cnt = first < u0 + S ? (u0 + S - 1 - first) / 8 + 1 : 0;
+        if (slot < acc + cnt * T) {
+            const int r = slot - acc;
+            lid = (first + 8 * (r / T) - u0) * T + r % T;            // split * tiles + tile: the body's (tile fastest, split slowest) order
+            ji = k;
+            break;
+        }
+        acc += cnt * T;
+    }
+    if (ji < 0) return;                                              // this XCD has fewer workgroups than the busiest one
     const TNJob& jb = jobs.j[ji];
     GemmTN p;
     p.x.x0 = jb.x0; p.x.x1 = nullptr; p.x.mode = jb.mode; p.x.H = jb.H; p.x.W = jb.W; p.x.Hi = jb.Hi; p.x.Wi = jb.Wi;
     p.x.C0 = jb.C0; p.x.C1 = 0; p.x.ld0 = jb.ld0; p.x.ld1 = 0; p.x.up = 0; p.x.M = jb.M; p.x.clamp = 0; p.x.diag = 0;
     p.dz = jb.dz; p.ldz = jb.ldz; p.Nout = jb.Nout; p.KP = jb.KP; p.taps = 1; p.part = jb.part; p.rows_per_split = jb.rows_per_split;
-    p.gy = jb.gy; p.phase_span = 0; p.bias_part = nullptr; p.out_ld = jb.out_ld; p.cin_lim = jb.C0;
-    gemm_tn_body<BC, BN, WGC, WGN>(p, glid - jb.first_block);
+    p.gy = jb.gy; p.phase_span = 0; p.bias_part = nullptr; p.out_ld = jb.out_ld; p.cin_lim = jb.C0; p.dbg = jobs.dbg;
+    if constexpr (R == 0) gemm_tn_body<BC, BN, WGC, WGN>(p, lid);
+    else gemm_tn_ring_body<BC, BN, WGC, WGN, BK, R>(p, lid);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -2327,6 +2481,13 @@ static int wgrad_group_plan(const long* jobs, int njobs, GroupPlan& g) {
     }
     // ONE tile shape per launch, picked for the largest job (the smaller ones of a stage -- its first block's narrower inputs -- pad)
     tn_tiles(max_nout, max_kp, g.bc, g.bn);
+    // Measured on the stage-4 group (29 jobs, 104 GFLOP, tools/bench_wgrad_group.py; hn_debug_knob(10, v) selects the variant): the shipped
+    // two-stage 128 x 128 tile 304 us = loads alone 186 us + MFMAs alone 90 us + 64-byte-segment stores 48 us, barely overlapped (1.9 GB
+    // through L2 -> LDS at ~40 GB/s per CU, 87 % L2 hits at best).  A 256 x 256 tile (8 waves, one workgroup per CU) halves the bytes but
+    // runs 332 us (two-stage) / 378 us (ring of 4 x 32 rows, counted vmcnt): its loads alone still take 194-218 us (one workgroup per CU
+    // pulls only 17-19 GB/s, L2 hit rate 56 %: each slab has 4 readers instead of 8).  Rings on the 128 tile: 392 (4 x 32 rows) / 501 us
+    // (3 x 64 rows, one workgroup per CU).  So: 128 x 128, two stages, two workgroups per CU.
+    if (max_nout >= 640 && max_kp >= 640 && (g_hn_knob[10] == 2 || g_hn_knob[10] == 3 || g_hn_knob[10] == 6)) { g.bc = 256; g.bn = 256; }
     long tiles = 0;
     for (int i = 0; i < njobs; ++i) {
         const long* jb = jobs + HN_WG_FIELDS * i;
@@ -2368,8 +2529,10 @@ extern "C" int hn_wgrad_group(const long* jobs, int njobs, float* workspace, hip
     TNJobs t;
     RJobsN r;
     t.n = njobs;
+    t.dbg = (int)g_hn_knob[9];
     r.n = 0;
-    long blocks = 0, rblocks = 0;
+    long rblocks = 0, per_xcd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int units = 0;
     for (int i = 0; i < njobs; ++i) {
         const long* jb = jobs + HN_WG_FIELDS * i;
         TNJob& d = t.j[i];
@@ -2379,8 +2542,9 @@ extern "C" int hn_wgrad_group(const long* jobs, int njobs, float* workspace, hip
         d.mode = mode; d.H = H; d.W = W; d.Hi = mode == 1 ? 2 * H : H; d.Wi = mode == 1 ? 2 * W : W;
         d.C0 = cin; d.ld0 = (int)jb[8]; d.ldz = (int)jb[9]; d.Nout = nout; d.KP = kp;
         d.gy = cdiv(nout, g.bc);
-        d.first_block = (int)blocks;
-        blocks += (long)cdiv(kp, g.bn) * d.gy * g.splits[i];
+        d.unit0 = units; d.splits = g.splits[i]; d.tiles = cdiv(kp, g.bn) * d.gy;
+        for (int s_ = 0; s_ < d.splits; ++s_) per_xcd[(units + s_) & 7] += d.tiles;
+        units += d.splits;
         if (g.splits[i] == 1) {
             d.part = reinterpret_cast<float*>(jb[2]); d.out_ld = cin;
         } else {
@@ -2393,17 +2557,35 @@ extern "C" int hn_wgrad_group(const long* jobs, int njobs, float* workspace, hip
             rblocks += q.kind == 0 ? cdiv(cols / 4, 256) : cdiv(cols, 32);
         }
     }
+    long blocks = 0;
+    for (int x = 0; x < 8; ++x) blocks = per_xcd[x] > blocks ? per_xcd[x] : blocks;
+    blocks *= 8;                                                     // every XCD gets as many workgroups as the busiest one (the rest exit)
     HN_CHECK_ARG(blocks > 0 && blocks < (1L << 31));
-    const size_t lds = (size_t)64 * (g.bc + g.bn) * 2 * 2;
     int rc = HN_OK;
+    const int variant = (int)g_hn_knob[10];           // tools/: 0 = shipped choice; 1 = two-stage 128 x 128; 2..5 = ring variants below
+    static std::atomic<unsigned long long> optin{0};
+    if (!lds_optin(optin, {(const void*)gemm_tn_group_kernel<256, 256, 2, 4, 32, 4>, (const void*)gemm_tn_group_kernel<256, 256, 2, 4, 32, 3>,
+                           (const void*)gemm_tn_group_kernel<256, 256, 2, 4>,
+                           (const void*)gemm_tn_group_kernel<128, 128, 2, 2, 64, 3>, (const void*)gemm_tn_group_kernel<128, 128, 2, 2, 32, 4>}))
+        return HN_ERR_LAUNCH;
+#define TNG_RING(BC_, BN_, A_, B_, BK_, R_) \
+        hipLaunchKernelGGL((gemm_tn_group_kernel<BC_, BN_, A_, B_, BK_, R_>), dim3((unsigned)blocks), dim3(64 * A_ * B_), \
+                           (size_t)BK_ * (BC_ + BN_) * 2 * R_, st, t)
+    const size_t lds = (size_t)64 * (g.bc + g.bn) * 2 * 2;
+    if (g.bc == 256 && g.bn == 256 && variant == 2) TNG_RING(256, 256, 2, 4, 32, 4);
+    else if (g.bc == 256 && g.bn == 256 && variant == 3) TNG_RING(256, 256, 2, 4, 32, 3);
+    else if (g.bc == 128 && g.bn == 128 && variant == 4) TNG_RING(128, 128, 2, 2, 64, 3);
+    else if (g.bc == 128 && g.bn == 128 && variant == 5) TNG_RING(128, 128, 2, 2, 32, 4);
+    else
 #define TNG_CASE(BC_, BN_, A_, B_) if (g.bc == BC_ && g.bn == BN_) \
-        hipLaunchKernelGGL((gemm_tn_group_kernel<BC_, BN_, A_, B_>), dim3((unsigned)blocks), dim3(256), lds, st, t); else
-    TNG_CASE(128, 128, 2, 2) TNG_CASE(128, 64, 2, 2) TNG_CASE(128, 32, 4, 1)
+        hipLaunchKernelGGL((gemm_tn_group_kernel<BC_, BN_, A_, B_>), dim3((unsigned)blocks), dim3(64 * A_ * B_), lds, st, t); else
+    TNG_CASE(256, 256, 2, 4) TNG_CASE(128, 128, 2, 2) TNG_CASE(128, 64, 2, 2) TNG_CASE(128, 32, 4, 1)
     TNG_CASE(64, 128, 2, 2) TNG_CASE(64, 64, 2, 2) TNG_CASE(64, 32, 4, 1)
     TNG_CASE(32, 128, 1, 4) TNG_CASE(32, 64, 1, 4) TNG_CASE(32, 32, 2, 2)
     TNG_CASE(16, 128, 1, 4) TNG_CASE(16, 64, 1, 4)
     rc = HN_ERR_UNSUPPORTED;
 #undef TNG_CASE
+#undef TNG_RING
     if (rc != HN_OK) return rc;
     if (r.n) hipLaunchKernelGGL(wgrad_reduce_group_kernel, dim3((unsigned)rblocks), dim3(256), 0, st, r);
     HN_LAUNCH_CHECK();
@@ -2442,7 +2624,7 @@ static int conv_gemm_tn_impl(const void* x0, const void* x1, int mode, int n_img
     mode = p.x.mode;
     p.dz = (const bf16*)dz; p.ldz = ldz; p.Nout = Nout; p.KP = KP; p.taps = taps;
     p.part = workspace; p.rows_per_split = rps; p.phase_span = phase_span;
-    p.bias_part = nullptr; p.out_ld = 0; p.cin_lim = 0;
+    p.bias_part = nullptr; p.out_ld = 0; p.cin_lim = 0; p.dbg = 0;
     int bc, bn, rc;
     long* defer = g_defer_job;
     g_defer_job = nullptr;

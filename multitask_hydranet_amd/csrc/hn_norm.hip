@@ -1120,16 +1120,148 @@ extern "C" int hn_se_mlp_bwd_parts(const float* dgate_part, int S, const float* 
 static int se_mlp_bwd_impl(const float* dgate, int S, const float* gate, const float* hid, const float* pooled, const float* w1, const float* w2,
                            float* dpre2, float* dpre1, float* dpool, float* dw1, float* db1, float* dw2, float* db2, int N, int C, int Cs,
                            hipStream_t st) {
-    HN_CHECK_ARG(dgate && gate && hid && pooled && w1 && w2 && dpre2 && dpre1 && dpool && dw1 && db1 && dw2 && db2 && N > 0 && C > 0 && Cs > 0);
+    HN_CHECK_ARG(dgate && gate && hid && pooled && w1 && w2 && dpre2 && dpre1 && dpool && N > 0 && C > 0 && Cs > 0);
+    HN_CHECK_ARG((dw1 && db1 && dw2 && db2) || (!dw1 && !db1 && !dw2 && !db2));       // all four, or none (the caller defers them: hn_grad_tail)
     // dpre1[n][j] = [hid > 0] * sum_c W2[c][j] * (dgate * g (1-g))[n][c]        (also stores dpre2)
     // (contraction over C: 64 partitions; over Cs = C/4 below: 16)
     hipLaunchKernelGGL(se_fc_cols_kernel<64>, dim3(cdiv(Cs, 16), N), dim3(1024), 0, st, w2, dgate, gate, dpre2, hid, dpre1, N, Cs, C, 1, 1, S);
     // dpool[n][c] = sum_j W1[j][c] * dpre1[n][j]
     hipLaunchKernelGGL(se_fc_cols_kernel<16>, dim3(cdiv(C, 16), N), dim3(256), 0, st, w1, (const float*)dpre1, (const float*)nullptr,
                        (float*)nullptr, (const float*)nullptr, dpool, N, C, Cs, 0, 0, 0);
+    if (!dw1) { HN_LAUNCH_CHECK(); }
     const int tc = cdiv(C, 16), ts = cdiv(Cs, 16);
     const SeOuter j0 = {dpre2, C, hid, Cs, dw2, db2, ts, tc * ts};
     const SeOuter j1 = {dpre1, Cs, pooled, C, dw1, db1, tc, tc * ts};
     hipLaunchKernelGGL(se_mlp_wgrad_kernel, dim3(cdiv(2L * tc * ts, 4)), dim3(256), 0, st, j0, j1, N);
+    HN_LAUNCH_CHECK();
+}
+
+
+// =====================================================================================================================================
+// Deferred parameter-gradient tails in ONE launch (hn_grad_tail).  The last step of many parameter gradients is a tiny reduction that is
+// not on the backward pass's critical path -- the partial-row fold of a depthwise / stride-2 grouped conv weight gradient, the weight
+// normalisation Jacobian of a BiFPN fusion node, the two outer products of an SE block's MLP -- and each one used to be its own ~5 us
+// launch (~120 of them per step).  They are queued (ops.GradQueue) and run together at a segment boundary; jobs travel by value.
+//   kind 0: out[c] = sum_r a[r][c]                      a: [n0 rows][n1 cols]
+//   kind 1: BiFPN fusion weights (fuse_dweights_kernel): a = pw [n0 blocks][3], b = raw parameter [n1], out = d(raw) [n1], f0 = eps
+//   kind 2: SE outer product (se_mlp_wgrad_kernel): out[i][j] = sum_n a[n][i] * b[n][j], out2[i] = sum_n a[n][i];  a: [n2][n0], b: [n2][n1]
+// =====================================================================================================================================
+#define HN_TAIL_MAX 64
+struct TailJob { const float* a; const float* b; float* out; float* out2; int kind, n0, n1, n2; float f0; int first_block; };
+struct TailJobs { TailJob j[HN_TAIL_MAX]; int n; };
+
+__global__ __launch_bounds__(256) void grad_tail_kernel(const TailJobs jobs) {
+    __shared__ float red[8][33];
+    int ji = 0;
+    for (int k = 1; k < jobs.n; ++k)
+        if ((int)blockIdx.x >= jobs.j[k].first_block) ji = k;
+    const TailJob& jb = jobs.j[ji];
+    const int blk = (int)blockIdx.x - jb.first_block;
+    if (jb.kind == 0) {                                              // 32 columns x 8 row lanes, four independent loads per lane and round
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+        const int c = blk * 32 + tx, R = jb.n0, C = jb.n1;
+        float s = 0.f;
+        if (c < C) {
+            const float* src = jb.a + c;
+            int r = ty;
+            float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            for (; r + 24 < R; r += 32) {
+                s += src[(long)r * C];
+                s1 += src[(long)(r + 8) * C];
+                s2 += src[(long)(r + 16) * C];
+                s3 += src[(long)(r + 24) * C];
+            }
+            for (; r < R; r += 8) s += src[(long)r * C];
+            s = (s + s1) + (s2 + s3);
+        }
+        red[ty][tx] = s;
+        __syncthreads();
+        if (ty == 0 && c < C) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += red[k][tx];
+            jb.out[c] = t;
+        }
+    } else if (jb.kind == 1) {
+        float a[3] = {0.f, 0.f, 0.f};
+        for (int b = threadIdx.x; b < jb.n0; b += 256)
+            for (int i = 0; i < 3; ++i) a[i] += jb.a[b * 3 + i];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (int i = 0; i < 3; ++i) {
+            const float t = wave_sum(a[i]);
+            if (lane == 0) red[wave][i] = t;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int nw = jb.n1;
+            const float eps = jb.f0;
+            float dw[3], r[3], sum = 0.f, dot = 0.f;
+            for (int i = 0; i < 3; ++i) {
+                dw[i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+                r[i] = i < nw ? fmaxf(jb.b[i], 0.f) : 0.f;
+                sum += r[i];
+            }
+            for (int i = 0; i < 3; ++i) dot += dw[i] * r[i] / (sum + eps);
+            for (int i = 0; i < nw; ++i) jb.out[i] = jb.b[i] > 0.f ? (dw[i] - dot) / (sum + eps) : 0.f;
+        }
+    } else {
+        const int PI = jb.n0, QJ = jb.n1, N = jb.n2;
+        const int tiles_j = (QJ + 15) >> 4, tiles = ((PI + 15) >> 4) * tiles_j;
+        const int lane = threadIdx.x & 63;
+        const int tile = blk * 4 + (threadIdx.x >> 6);
+        if (tile >= tiles) return;
+        const int ti = tile / tiles_j, tj = tile - ti * tiles_j;
+        const int r = lane & 15, kk = lane >> 4;
+        const int i = ti * 16 + r, j = tj * 16 + r;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        float colsum = 0.f;
+        for (int n0 = 0; n0 < N; n0 += 4) {
+            const int n = n0 + kk;
+            const float a = (n < N && i < PI) ? jb.a[(long)n * PI + i] : 0.f;
+            const float b = (n < N && j < QJ) ? jb.b[(long)n * QJ + j] : 0.f;
+            colsum += a;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int oi = ti * 16 + 4 * kk + q;
+            if (oi < PI && j < QJ) jb.out[(long)oi * QJ + j] = acc[q];
+        }
+        if (tj == 0) {
+            colsum += __shfl_xor(colsum, 16);
+            colsum += __shfl_xor(colsum, 32);
+            if (kk == 0 && i < PI) jb.out2[i] = colsum;
+        }
+    }
+}
+
+/* jobs: HOST table, 8 int64 per job {kind, a, b, out, out2, n0, n1, n2 | float bits of f0 (kind 1)}; njobs <= 64 */
+extern "C" int hn_grad_tail(const long* jobs, int njobs, hipStream_t st) {
+    HN_CHECK_ARG(jobs && njobs > 0 && njobs <= HN_TAIL_MAX);
+    TailJobs t;
+    t.n = njobs;
+    long blocks = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const long* jb = jobs + 8 * i;
+        TailJob& d = t.j[i];
+        d.kind = (int)jb[0];
+        d.a = reinterpret_cast<const float*>(jb[1]); d.b = reinterpret_cast<const float*>(jb[2]);
+        d.out = reinterpret_cast<float*>(jb[3]); d.out2 = reinterpret_cast<float*>(jb[4]);
+        d.n0 = (int)jb[5]; d.n1 = (int)jb[6]; d.n2 = 0; d.f0 = 0.f;
+        HN_CHECK_ARG(d.kind >= 0 && d.kind <= 2 && d.a && d.out && d.n0 > 0 && d.n1 > 0);
+        d.first_block = (int)blocks;
+        if (d.kind == 0) blocks += cdiv(d.n1, 32);
+        else if (d.kind == 1) {
+            HN_CHECK_ARG(d.b && d.n1 <= 3);
+            const unsigned bits = (unsigned)jb[7];
+            __builtin_memcpy(&d.f0, &bits, 4);
+            blocks += 1;
+        } else {
+            d.n2 = (int)jb[7];
+            HN_CHECK_ARG(d.b && d.out2 && d.n2 > 0);
+            blocks += cdiv((long)cdiv(d.n0, 16) * cdiv(d.n1, 16), 4);
+        }
+    }
+    hipLaunchKernelGGL(grad_tail_kernel, dim3((unsigned)blocks), dim3(256), 0, st, t);
     HN_LAUNCH_CHECK();
 }

@@ -402,7 +402,7 @@ class HydraNet(nn.Module):
         """AnyNetX.forward, net/anynet.py:136-145: x NCHW fp32 -> list of NHWC bf16 stage outputs."""
         return [a[0] for a, _ in self._backbone_shared(x, (1,) * len(self.depths))]
 
-    def _backbone_shared(self, x, ext):
+    def _backbone_shared(self, x, ext, tail=None):
         """-> per stage (aliases, slot): ext[k] aliases of the stage output for its consumers OUTSIDE the backbone (BiFPN input convs, the seg
         decoder's skip operand); the next stage takes one more alias.  Consumers that know the slot add their gradient in place (ops.share)."""
         p = "backbone.net."
@@ -415,7 +415,9 @@ class HydraNet(nn.Module):
             # (ops.DeferredGrads / WgradGroup): the identity node sits on the tensor entering the stage, so its backward runs after the
             # backward of every block of the stage.
             group = None
-            names = [f"{p}stage_{k}.blocks.block_{i}.{c}.0.weight" for i in range(d) for c in ("conv_block_1", "conv_block_3", "shortcut")]
+            names = [f"{p}stage_{k}.blocks.block_{i}.{c}" for i in range(d)
+                     for c in ("conv_block_1.0.weight", "conv_block_2.0.weight", "conv_block_3.0.weight", "shortcut.0.weight", "se.1.weight",
+                               "se.1.bias", "se.3.weight", "se.3.bias")]
             names = [nm for nm in names if nm in P]
             if (K.DEFER_WGRAD and self.training and torch.is_grad_enabled() and t.requires_grad and t.is_cuda and (self.se_ratio is not None) and
                     all(P[nm].requires_grad for nm in names)):
@@ -424,6 +426,11 @@ class HydraNet(nn.Module):
             for i in range(d):
                 t = self._xblock(f"{p}stage_{k}.blocks.block_{i}.", t, self.backbone_stride if i == 0 else 1, group)
             last = k == len(self.depths) - 1
+            if last and tail is not None and K.DEFER_WGRAD and self.training and torch.is_grad_enabled() and t.requires_grad and t.is_cuda:
+                # the neck's and the det / lane heads' deferred parameter gradients (ops.GradQueue) are flushed by this node: created after
+                # every backbone node and before every neck / head node, so in backward it runs after all of the latter
+                t = K.DeferredGrads.apply(t, tail[0], *tail[1])
+                tail[2] = True
             al, slot = K.share(t, ext[k] + (0 if last else 1))
             feats.append((al[:ext[k]], slot))
             if not last:
@@ -684,11 +691,16 @@ class HydraNet(nn.Module):
         # consumers of every fused pyramid level among the heads: det towers (all five), seg decoder (P3..P5), lane fusion (P3..P6)
         users = [[h for h, on, lv in (("det", self.train_detect, range(5)), ("seg", self.train_seg, range(3)), ("lane", self.train_lane, range(4)))
                   if on and l in lv] for l in range(5)]
+        tail = [K.GradQueue(), [t for n_, t in self.named_parameters() if n_.startswith(("neck.", "detectheader.", "laneheader."))], False]
         with off("shared"):
-            bb = self._backbone_shared(x, tuple(c + (seg_skip if k == 0 else 0) for k, c in enumerate(neck_cnt)))
+            bb = self._backbone_shared(x, tuple(c + (seg_skip if k == 0 else 0) for k, c in enumerate(neck_cnt)), tail)
             feats = [(a[(seg_skip if k == 0 else 0):], s) for k, (a, s) in enumerate(bb)]      # what the neck sees
             feat0_seg = bb[0][0][0] if seg_skip else None
-            al = self._neck_shared(feats, tuple(max(len(u), 1) for u in users))
+            K.set_queue(tail[0] if tail[2] else None)    # the neck's weight / fusion gradients wait for the flush node behind the backbone
+            try:
+                al = self._neck_shared(feats, tuple(max(len(u), 1) for u in users))
+            finally:
+                K.set_queue(None)
         pick = lambda head: [al[l][users[l].index(head)] if head in users[l] else al[l][0] for l in range(5)]
         fused_det, fused_seg, fused_lane = pick("det"), pick("seg"), pick("lane")
         out = {}
@@ -701,16 +713,20 @@ class HydraNet(nn.Module):
             cur = torch.cuda.current_stream()
             side = self._streams(x.device, 6)[5]
             side.wait_stream(cur)
-        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
-            if self.train_detect:
-                with off("det"):
-                    anchors, reg, cls = self._det(x, fused_det)
-                out["detection"] = {"anchors": anchors, "regression": reg, "classification": cls}
-            if self.train_lane:
-                with off("lane"):
-                    lane = self._lane(fused_lane)
-                out["lane"] = lane
-                lane_cls, lane_reg = lane["predict_cls"], lane["predict_loc"]
+        K.set_queue(tail[0] if (tail[2] and side is None) else None)
+        try:
+            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                if self.train_detect:
+                    with off("det"):
+                        anchors, reg, cls = self._det(x, fused_det)
+                    out["detection"] = {"anchors": anchors, "regression": reg, "classification": cls}
+                if self.train_lane:
+                    with off("lane"):
+                        lane = self._lane(fused_lane)
+                    out["lane"] = lane
+                    lane_cls, lane_reg = lane["predict_cls"], lane["predict_loc"]
+        finally:
+            K.set_queue(None)
         seg_mask = None
         if self.train_seg:
             with off("seg"):

@@ -355,26 +355,51 @@ class WgradBatch:
 DEFER_WGRAD = os.environ.get("HN_DEFER_WGRAD", "1") != "0"   # 1x1 weight gradients of a backbone stage in one grouped launch at the stage boundary
 
 
-class WgradGroup:
-    """The 1x1-conv weight gradients of ONE backbone stage, deferred to the stage boundary (DeferredGrads.backward) and computed by one
-    grouped GEMM launch (hn_wgrad_group).  Weight gradients are not on the backward pass's critical path; launched one by one behind
-    every data gradient (3 GEMMs + a slab reduce per XBlock, each a 10-25 us launch that cannot fill the chip) they were 2.6 ms of the
-    22 ms step.  XBlockFn.backward only QUEUES (weight, x, dz) here and returns None for the weight; the queue keeps x / dz alive."""
-    MAX_JOBS = 32
+class GradQueue:
+    """Parameter gradients that are NOT on the backward pass's critical path, deferred to a segment boundary (DeferredGrads.backward) and
+    finished by a handful of grouped launches instead of one or two small launches each:
+      * add_gemm: 1x1-conv weight gradients -> one grouped GEMM launch (hn_wgrad_group; + one slab reduce if pixel splits were needed);
+      * add_rows / add_fuse / add_se: partial-row folds of depthwise / stride-2 grouped conv weight gradients, BiFPN fusion-weight
+        Jacobians, SE MLP outer products -> one launch (hn_grad_tail).
+    Launched one by one behind every data gradient these were ~350 of the ~1600 launches of a step, each at or near the ~5 us floor of a
+    dependent launch.  The backward nodes only QUEUE (parameter, operands) here and return None for the parameter; the queue keeps the
+    operands alive; DeferredGrads hands the gradients to autograd under the same parameter objects."""
+    MAX_GEMM = 32
+    MAX_TAIL = 64
 
     def __init__(self):
         self.weights = ()           # the parameters DeferredGrads hands gradients back for, in its argument order
-        self.jobs = []              # (weight, x0, dz, mode, (n, h, w), cin, nout)
+        self.jobs = []              # 1x1 weight gradients: (weight, x0, dz, mode, (n, h, w), cin, nout)
+        self.tail = []              # (weights tuple, kind, a, b, n0, n1, n2, out shapes)
 
+    # -- queueing ------------------------------------------------------------------------------------------------------------------
     def add(self, weight, x0, dz, mode, grid, cin, nout):
         self.jobs.append((weight, x0, dz, mode, grid, cin, nout))
 
+    add_gemm = add
+
+    def add_rows(self, weight, part, rows, cols, shape):
+        """weight.grad (shape `shape`, rows * 0 + cols elements) = column sums of part [rows, cols]"""
+        self.tail.append(((weight,), 0, part, None, rows, cols, 0, (shape,)))
+
+    def add_fuse(self, praw, pw, blocks, eps):
+        self.tail.append(((praw,), 1, pw, praw, blocks, praw.numel(), ctypes.c_uint.from_buffer(ctypes.c_float(eps)).value, (tuple(praw.shape),)))
+
+    def add_outer(self, weight, bias, p, q):
+        """weight.grad [PI, QJ, 1, 1] = p^T q, bias.grad [PI] = column sums of p;  p fp32 [N, PI], q fp32 [N, QJ] (SE MLP)"""
+        self.tail.append(((weight, bias), 2, p, q, p.shape[1], q.shape[1], p.shape[0], (tuple(weight.shape), tuple(bias.shape))))
+
+    # -- flushing ------------------------------------------------------------------------------------------------------------------
     def flush(self):
         """-> one fp32 gradient (or None) per entry of self.weights"""
         jobs, self.jobs = self.jobs, []
+        tail, self.tail = self.tail, []
         out = {}
-        for c0 in range(0, len(jobs), self.MAX_JOBS):
-            chunk = jobs[c0:c0 + self.MAX_JOBS]
+
+        def put(wgt, g):
+            out[id(wgt)] = g if id(wgt) not in out else out[id(wgt)] + g      # (a weight applied several times: per-level det towers)
+        for c0 in range(0, len(jobs), self.MAX_GEMM):
+            chunk = jobs[c0:c0 + self.MAX_GEMM]
             tab = (ctypes.c_long * (12 * len(chunk)))()
             dws = []
             for i, (wgt, x0, dz, mode, (n, h, w), cin, nout) in enumerate(chunk):
@@ -388,9 +413,31 @@ class WgradGroup:
             ws = torch.empty((wsb // 4,), device=chunk[0][2].device, dtype=F32)
             lib().call("hn_wgrad_group", ctypes.addressof(tab), len(chunk), ptr(ws))
             for (wgt, *_), dw in zip(chunk, dws):
-                assert id(wgt) not in out, "one queued gradient per weight and backward pass"
-                out[id(wgt)] = dw
+                put(wgt, dw)
+        for c0 in range(0, len(tail), self.MAX_TAIL):
+            chunk = tail[c0:c0 + self.MAX_TAIL]
+            tab = (ctypes.c_long * (8 * len(chunk)))()
+            for i, (wts, kind, a, b, n0, n1, n2, shapes) in enumerate(chunk):
+                outs = [torch.empty(shp, device=a.device, dtype=F32) for shp in shapes]
+                tab[8 * i:8 * i + 8] = [kind, a.data_ptr(), b.data_ptr() if b is not None else 0, outs[0].data_ptr(),
+                                        outs[1].data_ptr() if len(outs) > 1 else 0, n0, n1, n2]
+                for wgt, g in zip(wts, outs):
+                    put(wgt, g)
+            lib().call("hn_grad_tail", ctypes.addressof(tab), len(chunk))
         return [out.get(id(w)) for w in self.weights]
+
+
+WgradGroup = GradQueue
+_CUR_QUEUE = None            # the GradQueue of the segment whose forward is being built (HydraNet sets it around neck + det / lane heads)
+
+
+def set_queue(q):
+    global _CUR_QUEUE
+    _CUR_QUEUE = q
+
+
+def cur_queue():
+    return _CUR_QUEUE if DEFER_WGRAD else None
 
 
 class DeferredGrads(torch.autograd.Function):
@@ -649,6 +696,8 @@ class ConvBnAct(torch.autograd.Function):
                 coef = k_bn_eval_coeff(gamma, beta, rm, rv, eps)
             out = k_bn_act(z, coef, act, res=res)
         ctx.kind, ctx.stride, ctx.act, ctx.count = kind, stride, act, count
+        ctx.queue = cur_queue() if (kind == "1x1" and training and weight.requires_grad) else None
+        ctx.wref = weight
         ctx.has_bias = conv_bias is not None
         ctx.has_res = res is not None
         ctx.training = training
@@ -718,7 +767,10 @@ class ConvBnAct(torch.autograd.Function):
                 else:
                     dx = zeros((n, hi, wi, cin), dev, BF16)
                     lib().call("hn_add_strided2", ptr(dx), ld(dx), ptr(dxs), ld(dxs), n, ho, wo, cin)
-            dw = k_gemm_tn(x, None, 0 if stride == 1 else 1, (n, ho, wo), dz, cout, kp32(cin), 1, cin)
+            if ctx.queue is not None:
+                dw = ctx.queue.add_gemm(ctx.wref, x, dz, 0 if stride == 1 else 1, (n, ho, wo), cin, cout)
+            else:
+                dw = k_gemm_tn(x, None, 0 if stride == 1 else 1, (n, ho, wo), dz, cout, kp32(cin), 1, cin)
         return dx, dw, dbias, dgamma, dbeta, None, None, None, dres, None, None, None, None, None, None, None
 
 
@@ -794,7 +846,7 @@ class XBlockFn(torch.autograd.Function):
         ctx.training, ctx.stride = training, stride
         ctx.packs = (wt1, wd2, wt3, wts)
         ctx.group = group
-        ctx.wrefs = (w1, w3, ws)                           # identities under which the stage's DeferredGrads node returns the gradients
+        ctx.wrefs = (w1, w3, ws, w2, sw1, sb1, sw2, sb2)   # identities under which the stage's DeferredGrads node returns the gradients
         ctx.save_for_backward(x, z1, a, z2, z3, out, coef1, coef2, coef3, pooled, hid, gate, sw1, sw2, bg, zs, coefs)
         return out
 
@@ -815,7 +867,7 @@ class XBlockFn(torch.autograd.Function):
         dz3, dg3, db3, g = bn_backward_fused(dout, z3, out, coef3, ACT_RELU, m, want_g=True)
         dbg, _, _ = k_gemm_nt(dz3, None, 0, grid, wt3, c, kp32(c), 1)
         group = ctx.group                                     # WgradGroup: the 1x1 weight gradients wait for the stage boundary
-        w1_, w3_, ws_ = ctx.wrefs
+        w1_, w3_, ws_, w2_, sw1_, sb1_, sw2_, sb2_ = ctx.wrefs
         batch = WgradBatch()                                  # the slab reduces of dw3 / dw2 / dw1 / dws: one launch at the end
         make_bg = bg is None
         if not make_bg:                                       # dz3's second reader right behind the first: still in the XCDs' L2s
@@ -832,8 +884,13 @@ class XBlockFn(torch.autograd.Function):
         dpre2 = torch.empty((n, c), device=dev, dtype=F32)
         dpool = torch.empty((n, c), device=dev, dtype=F32)
         dpre1 = torch.empty((n, cs), device=dev, dtype=F32)
-        dsw1, dsb1 = torch.empty_like(sw1), torch.empty((cs,), device=dev, dtype=F32)
-        dsw2, dsb2 = torch.empty_like(sw2), torch.empty((c,), device=dev, dtype=F32)
+        if group is not None:                                  # the two outer products wait for the stage boundary (hn_grad_tail)
+            dsw1 = dsb1 = dsw2 = dsb2 = None
+            group.add_outer(sw2_, sb2_, dpre2, hid)
+            group.add_outer(sw1_, sb1_, dpre1, pooled)
+        else:
+            dsw1, dsb1 = torch.empty_like(sw1), torch.empty((cs,), device=dev, dtype=F32)
+            dsw2, dsb2 = torch.empty_like(sw2), torch.empty((c,), device=dev, dtype=F32)
         lib().call("hn_se_mlp_bwd_parts", ptr(pdot), hw // rb, ptr(gate), ptr(hid), ptr(pooled), ptr(sw1), ptr(sw2), ptr(dpre2), ptr(dpre1),
                    ptr(dpool), ptr(dsw1), ptr(dsb1), ptr(dsw2), ptr(dsb2), n, c, cs)
         # BN2 backward with the SE data path folded in: g2 = (dbg * gate + dpool / HW) * [bn2(z2) > 0]
@@ -847,7 +904,10 @@ class XBlockFn(torch.autograd.Function):
             chunks = lib().query("hn_wgrad_chunks", m, (c // 8) * 9)
             part = torch.empty((chunks, c * 72), device=dev, dtype=F32)
             lib().call("hn_gconv_wgrad", ptr(a), ld(a), ptr(dz2), ld(dz2), ptr(part), n, h, w, c, stride)
-            dw2 = k_rows_reduce(part, 1, chunks, c * 72).view(c, 8, 3, 3)
+            if group is not None:
+                dw2 = group.add_rows(w2_, part, chunks, c * 72, (c, 8, 3, 3))
+            else:
+                dw2 = k_rows_reduce(part, 1, chunks, c * 72).view(c, 8, 3, 3)
         dz1, dg1, db1, _ = bn_backward_fused(da, z1, None, coef1, ACT_RELU, m_in)
         dws = dgs = dbs = None
         addend, add_s2 = g, False                               # identity block: + gradient of the identity branch
@@ -1011,9 +1071,10 @@ def k_dwconv_wgrad(x, dz):
     return k_rows_reduce(part, 1, chunks, c * 9).view(c, 1, 3, 3)
 
 
-def k_dwconv_bwd(dz, x, wf, geom=None, want_dx=True, into=None):
+def k_dwconv_bwd(dz, x, wf, geom=None, want_dx=True, into=None, queue=None, weight=None):
     """depthwise 3x3 backward in one launch (+ the partial-row reduce): (dx | None, dweight [C,1,3,3]).  geom: level-packed tensors;
-    into: an existing tensor dx is ADDED to (GradSlot accumulation)."""
+    into: an existing tensor dx is ADDED to (GradSlot accumulation); queue (GradQueue): the partial-row fold of the weight gradient is
+    queued for `weight` instead of launched (returns None for it)."""
     c = x.shape[3]
     if geom is None:
         n, h, w, _ = x.shape
@@ -1030,6 +1091,9 @@ def k_dwconv_bwd(dz, x, wf, geom=None, want_dx=True, into=None):
         dx = torch.empty_like(dz) if into is None else into
     lib().call("hn_dwconv_bwd_levels", ptr(dz), ld(dz), ptr(x), ld(x), ptr(wf), ptr(dx), ld(dx) if dx is not None else 0, ptr(part), n, c, nl,
                ctypes.addressof(H), ctypes.addressof(W), align, 0 if into is None else 1)
+    if queue is not None:
+        queue.add_rows(weight, part, blocks, c * 9, (c, 1, 3, 3))
+        return dx, None
     return dx, k_rows_reduce(part, 1, blocks, c * 9).view(c, 1, 3, 3)
 
 
@@ -1037,6 +1101,7 @@ class DwConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight):
         wk, wf = pack_dw_weight(weight)
+        ctx.queue, ctx.wref = (cur_queue() if weight.requires_grad else None), weight
         ctx.save_for_backward(x, wf)
         return k_dwconv(x, wk)
 
@@ -1044,7 +1109,7 @@ class DwConv(torch.autograd.Function):
     def backward(ctx, dout):
         x, wf = ctx.saved_tensors
         dout = dense(dout)
-        return k_dwconv_bwd(dout, x, wf, want_dx=ctx.needs_input_grad[0])
+        return k_dwconv_bwd(dout, x, wf, want_dx=ctx.needs_input_grad[0], queue=ctx.queue, weight=ctx.wref)
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -1154,6 +1219,7 @@ class Fuse(torch.autograd.Function):
                    ptr(out), ld(out), n, h, wd, ch)
         ctx.modes = modes
         ctx.slots = slots if slots is not None else (None, None, None)
+        ctx.queue, ctx.pref = (cur_queue() if praw.requires_grad else None), praw
         ctx.save_for_backward(praw, w, *[t for t in ins if t is not None])
         return out
 
@@ -1187,8 +1253,11 @@ class Fuse(torch.autograd.Function):
         pw = torch.empty((blocks, 3), device=dev, dtype=F32)
         lib().call("hn_fuse_bwd", ctypes.addressof(ap), ctypes.addressof(al), ctypes.addressof(am), ptr(w), ptr(dout), ld(dout), ptr(g), ld(g),
                    ctypes.addressof(dp_), ctypes.addressof(dl), ctypes.addressof(da), ptr(pw), n, h, wd, ch)
-        dpraw = torch.empty_like(praw)
-        lib().call("hn_fuse_dweights", ptr(pw), blocks, ptr(praw), praw.numel(), 1e-4, ptr(dpraw))
+        if ctx.queue is not None:
+            dpraw = ctx.queue.add_fuse(ctx.pref, pw, blocks, 1e-4)
+        else:
+            dpraw = torch.empty_like(praw)
+            lib().call("hn_fuse_dweights", ptr(pw), blocks, ptr(praw), praw.numel(), 1e-4, ptr(dpraw))
         for i, m in enumerate(modes):
             if m == 2:                                               # nearest x2 of a half-res input: 2x2 sum of g
                 lib().call("hn_sum2x2", ptr(g), ld(g), ptr(dst[i]), ld(dst[i]), ptr(w[i]), n, h // 2, wd // 2, ch, accum[i])
@@ -1691,6 +1760,7 @@ class TowerLayer(torch.autograd.Function):
         ctx.geom, ctx.act, ctx.training = geom, act, training
         ctx.has_bias = pw_b is not None
         ctx.packs = (wf, wt)
+        ctx.queue, ctx.wrefs = (cur_queue() if (training and dw_w.requires_grad and pw_w.requires_grad) else None), (dw_w, pw_w)
         ctx.save_for_backward(x, d, z, coef, pw_w)
         return out
 
@@ -1723,16 +1793,20 @@ class TowerLayer(torch.autograd.Function):
         lib().call("hn_bn_bwd_apply_levels", ptr(dout), ld(dout), ptr(z), ld(z), None, 0, ptr(coef), ptr(red), act, ptr(dz), ld(dz), cout, nl,
                    ctypes.addressof(R))
         dd, _, _ = k_gemm_nt(dz, None, 0, (1, 1, total), wt, c, kp32(cout), 1)
-        dpw = k_gemm_tn(d, None, 0, (1, 1, total), dz, cout, kp32(c), 1, c)
+        q_, (dw_ref, pw_ref) = ctx.queue, ctx.wrefs
+        if q_ is not None:
+            dpw = q_.add_gemm(pw_ref, d, dz, 0, (1, 1, total), c, cout)
+        else:
+            dpw = k_gemm_tn(d, None, 0, (1, 1, total), dz, cout, kp32(c), 1, c)
         dx = None
         if ctx.needs_input_grad[0] and ctx.slot is not None:
             sl = ctx.slot
             if sl.buf is None:
-                sl.buf, ddw = k_dwconv_bwd(dd, x, wf, geom)
+                sl.buf, ddw = k_dwconv_bwd(dd, x, wf, geom, queue=q_, weight=dw_ref)
             else:
-                _, ddw = k_dwconv_bwd(dd, x, wf, geom, into=sl.buf)
+                _, ddw = k_dwconv_bwd(dd, x, wf, geom, into=sl.buf, queue=q_, weight=dw_ref)
         else:
-            dx, ddw = k_dwconv_bwd(dd, x, wf, geom, want_dx=ctx.needs_input_grad[0])
+            dx, ddw = k_dwconv_bwd(dd, x, wf, geom, want_dx=ctx.needs_input_grad[0], queue=q_, weight=dw_ref)
         bn_grads = []
         for l in range(nl):
             bn_grads += [dgam[l], dbet[l], None, None]
@@ -1761,6 +1835,7 @@ class HeadOutPacked(torch.autograd.Function):
             off += h * w
         ctx.meta = (k, act, ldc, img_stride, geom)
         ctx.packs = (wf, wt)
+        ctx.queue, ctx.wref = (cur_queue() if dw_weight.requires_grad else None), dw_weight
         ctx.save_for_backward(pw_weight, out if act == ACT_SIGMOID else None, x, mid)
         return out
 
@@ -1785,7 +1860,7 @@ class HeadOutPacked(torch.autograd.Function):
             off += h * w
         dpw, dbias = k_gemm_tn(mid, None, 0, (1, 1, total), dz, cout, kp32(cin), 1, cin, want_bias=True)
         dmid, _, _ = k_gemm_nt(dz, None, 0, (1, 1, total), wt, cin, kp32(cout), 1, c0=ldz, c1=0)
-        dx, ddw = k_dwconv_bwd(dmid, x, wf, geom)
+        dx, ddw = k_dwconv_bwd(dmid, x, wf, geom, queue=ctx.queue, weight=ctx.wref)
         return ddw, dpw, dbias, None, None, None, dx
 
 

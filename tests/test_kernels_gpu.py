@@ -832,6 +832,74 @@ def test_grouped_deferred_wgrad(K, stage):
     assert group.flush() == [None, None]
 
 
+def test_grad_tail_jobs(K):
+    """hn_grad_tail through ops.GradQueue: partial-row folds (short and tall), BiFPN fusion-weight Jacobians (2 and 3 weights, one clamped
+    by the relu) and SE outer products, > 64 jobs (two launches), against torch in fp32"""
+    q = K.GradQueue()
+    ws, want = [], []
+    g = torch.Generator(device=dev()).manual_seed(5)
+    for rows, cols, shape in [(37, 1008, (112, 1, 3, 3)), (768, 1008, (112, 1, 3, 3)), (5, 64 * 72, (64, 8, 3, 3)), (2049, 72, (8, 1, 3, 3))] * 12:
+        part = torch.randn(rows, cols, device=dev(), generator=g)
+        w = torch.empty(shape, device=dev())
+        q.add_rows(w, part, rows, cols, shape)
+        ws.append(w)
+        want.append(part.double().sum(0).float().view(shape))
+    for nw, blocks in [(2, 1024), (3, 100), (3, 1)] * 6:
+        praw = torch.tensor([0.7, -0.2, 1.3][:nw], device=dev())
+        pw = torch.randn(blocks, 3, device=dev(), generator=g)
+        q.add_fuse(praw, pw, blocks, 1e-4)
+        ws.append(praw)
+        p64 = praw.double().clone().requires_grad_(True)
+        r = torch.relu(p64)
+        wn = r / (r.sum() + 1e-4)
+        (wn * pw.double().sum(0)[:nw]).sum().backward()
+        want.append(p64.grad.float())
+    for n, pi, qj in [(16, 234, 936), (16, 936, 234), (2, 6, 24)] * 3:
+        p_, q_ = torch.randn(n, pi, device=dev(), generator=g), torch.randn(n, qj, device=dev(), generator=g)
+        w, b = torch.empty(pi, qj, 1, 1, device=dev()), torch.empty(pi, device=dev())
+        q.add_outer(w, b, p_, q_)
+        ws += [w, b]
+        want += [(p_.double().t() @ q_.double()).float().view(pi, qj, 1, 1), p_.double().sum(0).float()]
+    assert len(q.tail) > K.GradQueue.MAX_TAIL
+    q.weights = tuple(ws)
+    got = q.flush()
+    assert not q.tail and len(got) == len(want)
+    for i, (a, b) in enumerate(zip(got, want)):
+        # fp32 accumulation of up to 2049 terms vs float64; the fusion Jacobian is a difference of nearly equal sums
+        close(a, b, 1e-3 if b.numel() <= 3 else 1e-4, "grad tail job %d %s" % (i, tuple(b.shape)))
+
+
+def test_full_model_with_deferred_gradients_equals_immediate(K):
+    """the whole tiny HydraNet step with ops.DEFER_WGRAD (stage-boundary and backbone-tail GradQueue flushes) vs every parameter gradient
+    launched where autograd asks for it: identical losses, all gradients equal to fp32 summation-order noise, same set of parameters"""
+    from multitask_hydranet_amd import HydraNet
+    from tests.helpers import load_cfg, load_npz, tiny_state
+    z = load_npz("tiny_hydranet.npz")
+    cfgs = load_cfg("hydranet_tiny.yml")
+    net = HydraNet(cfgs)
+    net.load_state_dict(tiny_state(z))
+    net = net.cuda().train()
+    net.lane_points_per_line = int(z["meta/lane_points_per_line"])
+    batch = {k[3:]: torch.from_numpy(z[k]).cuda() for k in z.files if k.startswith("in/")}
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    res = []
+    for defer in (False, True):
+        K.DEFER_WGRAD = defer
+        try:
+            net.load_state_dict(sd)
+            net.zero_grad(set_to_none=True)
+            out = net(batch["image"])
+            ld = net.cal_loss(out, batch)
+            net.total_loss(ld).backward()
+            res.append(({k: float(v) for k, v in ld.items()}, {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}))
+        finally:
+            K.DEFER_WGRAD = True
+    (l0, g0), (l1, g1) = res
+    assert l0 == l1 and g0.keys() == g1.keys() and len(g0) > 300
+    for k in g0:
+        close(g1[k], g0[k], 2e-5, k)
+
+
 def test_backbone_stage_with_deferred_wgrad_equals_immediate(K):
     """HydraNet._backbone_shared with ops.DEFER_WGRAD: a stage's 1x1 weight gradients come out of the DeferredGrads node at the stage
     boundary.  Same forward (bit-identical outputs), every parameter gradient equal to the immediate path's to fp32 summation-order noise,
