@@ -8,10 +8,19 @@ A "step" = one forward + multitask loss + backward over one synthetic batch that
 not part of the reference's fwd+bwd metric; its time is reported separately as ms_optimizer_step).  At N=1 the workload is
 BASELINE.json configs[2]: full HydraNet (big cfg), batch 16, 3x512x1024, bf16 compute.  For N>1 every rank runs the same per-GPU
 batch (weak scaling) and the gradients are averaged with the bucketed RCCL all-reduce of multitask_hydranet_amd.ddp.
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant launch (largest seg-decoder implicit-GEMM conv), timed live with HIP
-events; `cpu_baseline` is the fp32 oracle (a port, oracle/hydranet_oracle.py) timed on this box's host cores on a bounded sample.
+Rank 0 prints ONE JSON line:
+  * value / ms_per_step: the K timed steps bracketed by barrier + device sync on both sides (wall clock, max over ranks);
+    ms_per_step_median: median of the per-step HIP-event durations recorded on the launch stream inside the same timed loop;
+  * roofline: the dominant launch (largest seg-decoder conv), timed live with HIP events;
+  * segments: {backbone, neck, seg, det, lane, losses}: {ms, floor_ms, frac} -- each segment's forward + backward as its own captured
+    hipGraph (ablation: backbone, backbone + neck, forward-only, head-only backward phases), floors from accounting.segment_floors_ms;
+  * extra_configs (N=1 only): the other BASELINE configurations on the same device, ~0.5 s each: backbone-only N=8, the repo-default
+    640x640, inference 1152x1920 N=32, the gradient exchange at world size 1, the three head-only fine-tuning phases;
+  * cpu_baseline: the fp32 oracle (a port, oracle/hydranet_oracle.py) timed on this box's host cores on a bounded sample;
+  * env_overrides: every HN_* environment variable that was set (tools/ hooks change what runs; none of them skips work in the timed region).
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -27,6 +36,7 @@ import yaml  # noqa: E402
 PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 FWD_GFLOP_PER_IMG_512x1024 = 81.13   # BASELINE.md section 3 (conv MACs x 2); fwd+bwd = 3x
+METRIC = "images/sec (fwd+bwd) HydraNet @ default res, 1/2/4/8 MI355X; CPU-ref same run"
 
 
 def emit(res):
@@ -67,13 +77,16 @@ def synthetic_batch(cfgs, n, h, w, seed, device):
     return {k: v.to(device) for k, v in dict(image=image, gt_seg=gt_seg, gt_det=gt_det, gt_cls=gt_cls, gt_loc=gt_loc).items()}
 
 
+# ------------------------------------------------------------------------------------------------------------------------------------
+# dominant launch
+# ------------------------------------------------------------------------------------------------------------------------------------
 def dominant_launch_roofline(net, n, h, w, iters=100, graph_timing=False):
     """Time the largest seg-decoder launch with HIP events on the stream it is launched on (the launches of the timed region are replayed
     from one captured hipGraph, as they run inside the training step), and price it against the dense bf16 MFMA peak.
-    decoder.3 of the big cfg = Conv3x3(reflect-pad(cat[up2(x 256 ch), P3 112 ch])) -> 256 @ (h/8) x (w/8).  Since round 2 its up-sampled
-    operand runs in PHASE form on the low-resolution grid (hn_conv3x3_phase: 4 of 9 taps per output phase, the skip operand's partial sum
-    arrives as a pre-activation addend): that launch is timed here.  `achieved` prices the ALGORITHMIC flops of the convolution it
-    replaces (2*N*H*W*Cout*C0*9, SURVEY 8(d) conv-MAC figure); `executed_tflops` is what the MFMA pipe actually ran (16/36 of it)."""
+    decoder.3 of the big cfg = Conv3x3(reflect-pad(cat[up2(x 256 ch), P3 112 ch])) -> 256 @ (h/8) x (w/8).  Its up-sampled operand runs in
+    PHASE form on the low-resolution grid (hn_conv3x3_phase: 4 of 9 taps per output phase, the skip operand's partial sum arrives as a
+    pre-activation addend): that launch is timed here.  `achieved` prices the ALGORITHMIC flops of the convolution it replaces
+    (2*N*H*W*Cout*C0*9, SURVEY 8(d) conv-MAC figure); `executed_tflops` is what the MFMA pipe actually ran (16/36 of it)."""
     from multitask_hydranet_amd import ops as K
     from multitask_hydranet_amd._lib import lib
     P = net._idx
@@ -98,6 +111,7 @@ def dominant_launch_roofline(net, n, h, w, iters=100, graph_timing=False):
         flops = 2.0 * n * hh * ww * cout * c0 * 9
         executed = flops * 16.0 / 36.0
         alg_bytes = 2.0 * (n * (hh // 2) * (ww // 2) * c0 + 2 * n * hh * ww * cout + 4 * cout * c0 * 9)
+        form = "phase"
         kname = "conv3x3_direct_kernel<128,false,false> phase form: seg decoder.3 up-sampled operand (256 ch @ %dx%d -> 4 phases x 256 @ %dx%d, " \
                 "+ skip addend, ELU), N=%d, fwd" % (hh // 2, ww // 2, hh, ww, n)
     else:
@@ -105,6 +119,7 @@ def dominant_launch_roofline(net, n, h, w, iters=100, graph_timing=False):
         run = lambda: K.k_gemm_nt(x0, x1, 2, (n, hh, ww), wp, cout, K.kp32(cin), 9, bias=bias, act=K.ACT_ELU, out=out, up=1)
         flops = executed = 2.0 * n * hh * ww * cout * cin * 9
         alg_bytes = 2.0 * (n * (hh // 2) * (ww // 2) * c0 + n * hh * ww * c1 + n * hh * ww * cout + cout * cin * 9)
+        form = "full"
         kname = "conv3x3_direct_kernel<128,false,false> seg decoder.3 (reflect-pad 3x3 over cat[up2(x), skip], 368->256 @ %dx%d, N=%d) fwd" % (hh, ww, n)
     for _ in range(3):
         run()
@@ -138,22 +153,28 @@ def dominant_launch_roofline(net, n, h, w, iters=100, graph_timing=False):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     ach = flops / (ms * 1e-3) / 1e12
+    traffic, source = measured_traffic(n, h, w, form)
     return {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-            "traffic": measured_traffic(alg_bytes), "kernel": kname, "launch_ms": round(ms, 4), "flop_per_launch": flops,
+            "traffic": traffic, "traffic_source": source, "kernel": kname, "launch_ms": round(ms, 4), "flop_per_launch": flops,
             "executed_flop_per_launch": executed, "executed_tflops": round(executed / (ms * 1e-3) / 1e12, 2),
             "frac_executed": round(executed / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), "algorithmic_bytes_per_launch": alg_bytes}
 
 
-def measured_traffic(alg_bytes):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r02_dominant_pmc.json: FETCH_SIZE
-    doubled per the gfx950 correction + WRITE_SIZE, separate passes); None if the file is absent.  PMC counters cannot be read from
-    inside this process, so the figure is the one measured with `rocprofv3 --pmc` on `bench.py --dominant-only`."""
-    path = os.path.join(ROOT, "profiles", "r02_dominant_pmc.json")
-    try:
-        with open(path) as f:
-            return json.load(f)["hbm_bytes_per_launch"]
-    except Exception:       # noqa: BLE001
-        return None
+def measured_traffic(n, h, w, form):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 correction +
+    WRITE_SIZE, separate passes: PMC counters cannot be read from inside this process).  The figure belongs to ONE workload: it is only
+    emitted when batch, resolution and kernel form match what the profile recorded; otherwise null."""
+    for name in ("r03_dominant_pmc.json", "r02_dominant_pmc.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except Exception:       # noqa: BLE001
+            continue
+        rec = d.get("workload", {"batch": 16, "res": "512x1024", "form": "phase"})        # (r02 file: recorded before the field existed)
+        if rec.get("batch") == n and rec.get("res") == "%dx%d" % (h, w) and rec.get("form") == form:
+            return d["hbm_bytes_per_launch"], "profiles/" + name
+    return None, None
 
 
 def usable_cores():
@@ -180,7 +201,8 @@ def cpu_model():
 
 
 def cpu_baseline(cfgs, h, w, budget_s=20.0):
-    """fp32 CPU oracle (port of the reference path) on this box's host cores: N=1 fwd+loss+bwd, bounded sample."""
+    """fp32 CPU oracle (port of the reference path) on this box's host cores: N=1 fwd+loss+bwd, bounded sample (3 warm-up +
+    up to 10 timed iterations, median; the budget caps the timed ones)."""
     from oracle import hydranet_oracle as O
     import multitask_hydranet_amd as pkg
     cores = usable_cores()
@@ -200,62 +222,120 @@ def cpu_baseline(cfgs, h, w, budget_s=20.0):
         ld = O.hydranet_losses(cfgs, out, batch, lane_points_per_line=ppl)
         O.total_loss(cfgs, ld).backward()
     t0 = time.time()
-    step()                                                           # warm-up
+    nwarm = 0
+    while nwarm < 3 and (nwarm == 0 or time.time() - t0 < 0.3 * budget_s):
+        step()
+        nwarm += 1
     warm = time.time() - t0
     times = []
     while len(times) < 10 and (sum(times) + warm) < budget_s:
-        t0 = time.time()
+        t1 = time.time()
         step()
-        times.append(time.time() - t0)
+        times.append(time.time() - t1)
     if not times:
-        times = [warm]
+        times = [warm / nwarm]
     times.sort()
     med = times[len(times) // 2]
     # one-thread figure: ONE timed iteration after the warm multi-thread runs (a second would double the bounded sample)
     torch.set_num_threads(1)
-    t0 = time.time()
+    t1 = time.time()
     step()
-    one = time.time() - t0
+    one = time.time() - t1
     torch.set_num_threads(cores)
     return {"value": round(1.0 / med, 4), "unit": "images/sec", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
             "value_1thread": round(1.0 / one, 4),
-            "sample": "fp32 oracle, big cfg, N=1, 3x%dx%d, fwd+loss+bwd, 1 warm-up + %d timed iterations (median) on %d threads; "
-                      "1 iteration on 1 thread" % (h, w, len(times), cores)}
+            "sample": "fp32 oracle, big cfg, N=1, 3x%dx%d, fwd+loss+bwd, %d warm-up + %d timed iterations (median) on %d threads; "
+                      "1 iteration on 1 thread" % (h, w, nwarm, len(times), cores)}
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# timing helpers
+# ------------------------------------------------------------------------------------------------------------------------------------
+def capture(fn, eager_warmup=2):
+    """two eager runs on a side stream (allocator warm-up, lazy packs), then `fn` captured as one hipGraph -> (graph, fn's return value)"""
+    s_ = torch.cuda.Stream()
+    s_.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s_):
+        for _ in range(eager_warmup):
+            fn()
+    torch.cuda.current_stream().wait_stream(s_)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        out = fn()
+    return g, out
+
+
+def time_replays(step, steps, warmup, world=1):
+    """`warmup` untimed + EXACTLY `steps` timed calls of step(), bracketed by barrier + device synchronize on both sides (wall clock), with
+    one HIP event recorded on the launch stream before every call and after the last -> (seconds, [per-step ms from the events])"""
+    for _ in range(warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    for i in range(steps):
+        ev[i].record()
+        step()
+    ev[steps].record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    return dt, [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
+
+
+def median(v):
+    v = sorted(v)
+    return v[len(v) // 2] if v else None
+
+
+def build_net(cfg_path, h, w, dev):
+    from multitask_hydranet_amd import HydraNet
+    cfgs = yaml.safe_load(open(cfg_path))
+    cfgs["dataloader"]["network_input_height"], cfgs["dataloader"]["network_input_width"] = h, w
+    torch.manual_seed(0)
+    net = HydraNet(cfgs).to(dev).train()
+    net.check_finite = False                       # the reference's exit()-on-NaN guard is a host sync; checked once after the run instead
+    net.lane_points_per_line = h // cfgs["lane"]["interval"]     # the reference default (160) raises IndexError at H=512 (SURVEY 0 #3)
+    return net, cfgs
+
+
+def quick_graph_ms(fn, reps=10, warm=2):
+    """median per-replay milliseconds (HIP events) of `fn` captured as one hipGraph"""
+    g, _ = capture(fn)
+    _, per = time_replays(g.replay, reps, warm)
+    del g
+    return median(per)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# inference (BASELINE config 5)
+# ------------------------------------------------------------------------------------------------------------------------------------
+def infer_measure(net, batch_n, h, w, dev, steps, warmup, use_graph=True, world=1, seed=1):
+    net.eval()
+    net.prepare_inference()
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(batch_n, 3, h, w, generator=g).to(dev)
+    with torch.no_grad():
+        fn = lambda: net(x, "deploy")
+        if use_graph:
+            graph, out = capture(fn)
+            step = graph.replay
+        else:
+            graph, out = None, fn()
+            step = fn
+        dt, per = time_replays(step, steps, warmup, world)
+    assert bool(torch.isfinite(out[2]).all()) and out[0].dtype == torch.int64
+    return dt, per, graph is not None
 
 
 def infer_bench(args, net, cfgs, h, w, dev, rank, world):
     """BASELINE config 5: inference-only deploy forward (seg arg-max + detection / lane head outputs), batch per GPU, replicas only (no
     collective on the data path).  One captured hipGraph per step; BatchNorm folded into the packed weights (HydraNet.prepare_inference)."""
-    net.eval()
-    net.prepare_inference()
-    g = torch.Generator().manual_seed(1 + rank)
-    x = torch.randn(args.batch, 3, h, w, generator=g).to(dev)
-    with torch.no_grad():
-        s_ = torch.cuda.Stream()
-        s_.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s_):
-            for _ in range(2):
-                out = net(x, "deploy")
-        torch.cuda.current_stream().wait_stream(s_)
-        torch.cuda.synchronize()
-        graph = None
-        if not args.no_graph:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out = net(x, "deploy")
-        step = graph.replay if graph is not None else (lambda: net(x, "deploy"))
-        for _ in range(args.warmup):
-            step()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        dt = time.perf_counter() - t0
+    dt, per, graphed = infer_measure(net, args.batch, h, w, dev, args.steps, args.warmup, not args.no_graph, world, seed=1 + rank)
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -263,17 +343,17 @@ def infer_bench(args, net, cfgs, h, w, dev, rank, world):
     dt = float(tmax)
     if rank != 0:
         return
-    assert bool(torch.isfinite(out[2]).all()) and out[0].dtype == torch.int64
     value = args.batch * world * args.steps / dt
     scale = (h * w) / (512.0 * 1024.0)
     res = {"metric": "images/sec (inference fwd) HydraNet, deploy mode, BASELINE config 5", "value": round(value, 2), "unit": "images/sec",
-           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+           "ms_per_step_median": round(median(per), 3), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
            "config": {"workload": "full HydraNet eval-mode deploy forward (seg arg-max, det + lane head outputs), big cfg, BatchNorm folded",
                       "batch_per_gpu": args.batch, "global_batch": args.batch * world, "resolution": "3x%dx%d" % (h, w),
-                      "parallelism": "replicas x%d (no collective)" % world, "hipgraph": graph is not None,
+                      "parallelism": "replicas x%d (no collective)" % world, "hipgraph": graphed,
                       "padding": "1080-row frames are zero-padded (post-normalisation) by 36 rows top and bottom to 1152 = 9 x 128"},
-           "model_tflops": round(value * FWD_GFLOP_PER_IMG_512x1024 * scale / 1e3, 2)}
+           "model_tflops": round(value * FWD_GFLOP_PER_IMG_512x1024 * scale / 1e3, 2), "env_overrides": env_overrides()}
     try:
         res["roofline"] = dominant_launch_roofline(net, args.batch, h, w)
     except Exception as e:      # noqa: BLE001
@@ -281,6 +361,282 @@ def infer_bench(args, net, cfgs, h, w, dev, rank, world):
     emit(res)
 
 
+def env_overrides():
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith("HN_") or k == "HIPCC"}
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# the training step under measurement
+# ------------------------------------------------------------------------------------------------------------------------------------
+class TrainRun:
+    """one configuration of the fwd + loss + bwd step: builds the (optionally DDP-exchanging) captured step and times it"""
+
+    def __init__(self, net, cfgs, batch, dev, rank=0, world=1, backend="nccl", backbone_only=False, use_graph=True, exchange=False,
+                 force_world1=False, payload=torch.float32, exchange_after_replay=False):
+        self.net, self.cfgs, self.batch, self.dev = net, cfgs, batch, dev
+        self.rank, self.world, self.backend = rank, world, backend
+        self.backbone_only = backbone_only
+        self.graph = self.static_loss = self.reducer = None
+        self.in_graph_exchange = False
+        self.one = torch.ones((), device=dev)       # d loss / d loss, allocated once (loss.backward() alone fills a fresh one every step)
+        from multitask_hydranet_amd.ddp import GradReducer, unused_parameters
+        self._skip = unused_parameters(net)
+        self._GradReducer = GradReducer
+        self._payload, self._force = payload, force_world1
+        if exchange:
+            # captured exchange: every bucket is a branch of the hipGraph, and a branch costs ~0.35 ms of step time on this runtime (world 1,
+            # same box: 7 buckets 620-640 img/s, 4: 655, 2: 671, 1: 693, no exchange: 712) -- two ~86 MB buckets keep the first half of the
+            # all-reduce under the backbone backward; eager hook mode keeps DDP's 25 MiB granularity
+            self.reducer = self._make_reducer(bucket_bytes=96 << 20) if use_graph and not exchange_after_replay else self._make_reducer()
+        capture_failed = False
+        if use_graph:
+            try:
+                # (only RCCL collectives can be captured: the gloo test hook exchanges after the replay)
+                if self.reducer is not None and not exchange_after_replay and (backend == "nccl" or os.environ.get("HN_BENCH_TRY_CAPTURE") == "1"):
+                    try:
+                        self.graph, self.static_loss = self._capture(with_hooks=True)
+                        self.reducer.adopt_bucket_grads()
+                        self.reducer.remove()
+                        self.in_graph_exchange = self.reducer.captured
+                    except Exception as e:              # noqa: BLE001  (an RCCL build that cannot be captured)
+                        # a capture that failed half-way leaves PyTorch's graph bookkeeping unusable for a second capture in this process
+                        # ("Cannot register the state during capturing stage"): run eager launches with the overlapped hook exchange instead
+                        if rank == 0:
+                            print("capturing the all-reduce inside the hipGraph failed (%r): eager launches with the hook exchange instead" % (e,),
+                                  file=sys.stderr)
+                        try:
+                            torch.cuda.synchronize()
+                        except Exception:               # noqa: BLE001  (a capture that could not be ended keeps its stream in capture mode)
+                            pass
+                        self.graph = None
+                        capture_failed = True
+                        self.reducer.remove()
+                        self.reducer = self._make_reducer()
+                if self.graph is None and not capture_failed:
+                    if self.reducer is not None:
+                        self.reducer.remove()           # no hooks during this capture; gradients are exchanged right after each replay
+                    self.graph, self.static_loss = self._capture(with_hooks=False)
+                    if self.reducer is not None:
+                        # after a replay nothing is left to overlap with: ONE flat bucket = one gather + one all-reduce for all 693 gradients
+                        self.reducer = self._make_reducer(bucket_bytes=1 << 40)
+                        self.reducer.remove()
+                        self.reducer.bind_static_grads()    # every replay rewrites these tensors; reduce_now() gathers them into the bucket
+            except Exception as e:                      # noqa: BLE001
+                if rank == 0:
+                    import traceback
+                    traceback.print_exc()
+                    print("hipGraph capture failed, falling back to eager launches: %r" % (e,), file=sys.stderr)
+                self.graph = None
+                torch.cuda.synchronize()
+                if exchange:
+                    self.reducer = self._make_reducer()
+
+    def _make_reducer(self, **kw):
+        if os.environ.get("HN_BUCKET_MB"):                                   # tools/ sweeps of the exchange granularity
+            kw["bucket_bytes"] = int(float(os.environ["HN_BUCKET_MB"]) * (1 << 20))
+        return self._GradReducer(list(self.net.named_parameters()), world_size=self.world, skip=self._skip, payload_dtype=self._payload,
+                                 force_collectives=self._force, **kw)
+
+    def fwd_bwd(self):
+        net, batch = self.net, self.batch
+        if self.backbone_only:
+            feats = net._backbone(batch["image"])
+            loss = sum(f.float().mean() for f in feats)
+            loss.backward(self.one)
+            return loss
+        out = net(batch["image"])
+        ld = net.cal_loss(out, batch)
+        loss = net.total_loss(ld)
+        loss.backward(self.one)
+        return loss
+
+    def _capture(self, with_hooks):
+        """two eager warm-up steps on a side stream, then the capture.  with_hooks: the reducer's autograd hooks stay armed, so every
+        bucket's gather + all-reduce is captured on the reducer's side stream, forked from / joined to the capture stream by events."""
+        net, reducer = self.net, self.reducer
+        s_ = torch.cuda.Stream()
+        s_.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s_):
+            for _ in range(2):
+                net.zero_grad(set_to_none=True)
+                l0 = self.fwd_bwd()
+                if reducer is not None and with_hooks:
+                    reducer.finish()
+                if os.environ.get("HN_BENCH_DEBUG"):
+                    print("rank", self.rank, "eager loss", float(l0.detach()), file=sys.stderr, flush=True)
+        torch.cuda.current_stream().wait_stream(s_)
+        torch.cuda.synchronize()
+        net.zero_grad(set_to_none=True)
+        g = torch.cuda.CUDAGraph()
+        # thread-local capture mode: the RCCL watchdog thread's event queries (N > 1) must not invalidate the capture
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            sl = self.fwd_bwd()
+            if reducer is not None and with_hooks:
+                reducer.join_capture()
+        return g, sl
+
+    def step(self):
+        if self.graph is not None:
+            self.graph.replay()
+            if self.reducer is not None and not self.in_graph_exchange:
+                self.reducer.reduce_now()
+            return self.static_loss
+        self.net.zero_grad(set_to_none=False) if self.reducer is not None else self.net.zero_grad(set_to_none=True)
+        loss = self.fwd_bwd()
+        if self.reducer is not None:
+            self.reducer.finish()
+        return loss
+
+    def describe_exchange(self):
+        if self.reducer is None:
+            return None
+        return ("%s backend: " % self.backend) + self.reducer.describe(after_replay=self.graph is not None and not self.in_graph_exchange)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# per-segment table (ablation graphs) and the other BASELINE configurations
+# ------------------------------------------------------------------------------------------------------------------------------------
+def segment_table(net, cfgs, batch, n, h, w, full_ms):
+    """{backbone, neck, seg, det, lane, losses}: {ms, floor_ms, frac} for the step under measurement, plus `unattributed_ms`.  Timing events
+    cannot be recorded inside a captured hipGraph on ROCm, so every segment's forward + backward is measured as its OWN captured graph
+    (median of 10 replays, HIP events), by ablation on the same module and batch:
+      backbone        = fwd+bwd of the backbone alone (loss = sum of feature means)
+      neck            = fwd+bwd of backbone + BiFPN (loss = sum of fused-map means)  -  backbone
+      <head> forward  = that head alone on fixed fused maps, under no_grad
+      <head> backward = head-only fine-tuning step (grad_scope: whole forward + losses, backward through that head only)  -  forward-only step
+      losses          = the three losses + weighted total, forward + backward, on fixed head outputs
+    frac = floor_ms / ms with the floors of accounting.segment_floors_ms (seg on the MFMA peak, the rest on HBM bytes)."""
+    from multitask_hydranet_amd.accounting import segment_floors_ms
+    from multitask_hydranet_amd import ops as K
+    one = torch.ones((), device=batch["image"].device)
+    x = batch["image"]
+
+    def bb():
+        net.zero_grad(set_to_none=True)
+        feats = net._backbone(x)
+        net._flush_nbt()
+        sum(f.float().mean() for f in feats).backward(one)
+
+    def bbn():
+        net.zero_grad(set_to_none=True)
+        fused = net._neck(net._backbone(x))
+        net._flush_nbt()
+        sum(f.float().mean() for f in fused).backward(one)
+
+    def fwd_all():
+        with torch.no_grad():
+            out = net(x)
+            return net.total_loss(net.cal_loss(out, batch))
+
+    def scoped(head):
+        def f():
+            net.zero_grad(set_to_none=True)
+            net.grad_scope = head
+            try:
+                net.total_loss(net.cal_loss(net(x), batch)).backward(one)
+            finally:
+                net.grad_scope = None
+        return f
+    t = {"backbone": quick_graph_ms(bb), "bbn": quick_graph_ms(bbn), "fwd_all": quick_graph_ms(fwd_all)}
+    for head in ("seg", "det", "lane"):
+        t["scope_" + head] = quick_graph_ms(scoped(head))
+    with torch.no_grad():
+        feats = net._backbone(x)
+        fused = [f.detach() for f in net._neck(feats)]
+        feat0 = feats[0].detach()
+        out = net(x)
+    heads_fwd = {"seg": lambda: net._seg([feat0, fused[0], fused[1], fused[2]]), "det": lambda: net._det(x, fused), "lane": lambda: net._lane(fused)}
+    for head, fn in heads_fwd.items():
+        def f(fn=fn):
+            with torch.no_grad():
+                return fn()
+        t["fwd_" + head] = quick_graph_ms(f)
+    leaf = {"seg": out["seg"].detach().requires_grad_(True),
+            "detection": {"anchors": out["detection"]["anchors"], "regression": out["detection"]["regression"].detach().requires_grad_(True),
+                          "classification": out["detection"]["classification"].detach().requires_grad_(True)},
+            "lane": {k: v.detach().requires_grad_(True) for k, v in out["lane"].items()}}
+
+    def losses():
+        net.total_loss(net.cal_loss(leaf, batch)).backward(one)
+    t["losses"] = quick_graph_ms(losses)
+    net.zero_grad(set_to_none=True)
+    ms = {"backbone": t["backbone"], "neck": t["bbn"] - t["backbone"], "losses": t["losses"]}
+    for head in ("seg", "det", "lane"):
+        ms[head] = t["fwd_" + head] + (t["scope_" + head] - t["fwd_all"])
+    floors = segment_floors_ms(cfgs, h, w, n)
+    table = {k: {"ms": round(v, 3), "floor_ms": round(floors[k], 3), "frac": round(floors[k] / v, 4) if v > 0 else None} for k, v in ms.items()}
+    table["unattributed_ms"] = round(full_ms - sum(ms.values()), 3)
+    table["method"] = "per-segment captured hipGraphs (ablation), median of 10 replays; raw: " + json.dumps({k: round(v, 3) for k, v in t.items()})
+    return table
+
+
+def extra_configs(args, dev, headline_net, headline_cfgs):
+    """the other BASELINE.json configurations on this device, each a short driver-timed run (10 timed steps after 3 warm-up replays)"""
+    res = {}
+    K_STEPS, K_WARM = 10, 3
+
+    def rec(name, fn):
+        try:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res[name] = fn()
+            res[name]["wall_s"] = round(time.perf_counter() - t0, 2)
+        except Exception as e:       # noqa: BLE001
+            res[name] = {"error": repr(e)[:300]}
+        torch.cuda.empty_cache()
+
+    def train_cfg(batch_n, h, w, backbone_only=False, exchange=False, scope=None, net=None, cfgs=None, what=""):
+        own = net is None
+        if own:
+            net, cfgs = build_net(args.cfg, h, w, dev)
+        batch = synthetic_batch(cfgs, batch_n, h, w, seed=1, device=dev)
+        net.grad_scope = scope
+        try:
+            run = TrainRun(net, cfgs, batch, dev, backbone_only=backbone_only, exchange=exchange, force_world1=exchange)
+            dt, per = time_replays(run.step, K_STEPS, K_WARM)
+            loss = float(run.static_loss if run.graph is not None else run.step())
+        finally:
+            net.grad_scope = None
+            net.zero_grad(set_to_none=True)
+        assert loss == loss and abs(loss) != float("inf")
+        out = {"value": round(batch_n * K_STEPS / dt, 2), "unit": "images/sec", "ms_per_step": round(dt / K_STEPS * 1e3, 3),
+               "ms_per_step_median": round(median(per), 3), "steps": K_STEPS, "warmup": K_WARM, "batch": batch_n, "resolution": "3x%dx%d" % (h, w),
+               "hipgraph": run.graph is not None, "workload": what}
+        if exchange:
+            out["grad_allreduce"] = run.describe_exchange()
+        return out
+    rec("config2_backbone_only_n8", lambda: train_cfg(8, 512, 1024, backbone_only=True, net=headline_net, cfgs=headline_cfgs,
+                                                       what="BASELINE config 2: RegNetY backbone fwd+bwd, loss = sum of the five feature means"))
+    rec("repo_default_640x640_n16", lambda: train_cfg(16, 640, 640, what="full HydraNet fwd+loss+bwd at the reference's default 640x640"))
+    for head in ("lane", "det", "seg"):
+        rec("finetune_phase_%s_n16" % head, lambda head=head: train_cfg(
+            16, 512, 1024, scope=head, net=headline_net, cfgs=headline_cfgs,
+            what="head-only fine-tuning phase (train.py:441-515): whole forward + six losses, backward through the %s head only" % head))
+
+    def ddp1():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if not dist.is_initialized():
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        return train_cfg(16, 512, 1024, exchange=True, net=headline_net, cfgs=headline_cfgs,
+                         what="BASELINE config 4's exchange path at world size 1: RCCL ncclAvg all-reduce of the gradient buckets inside the step")
+    rec("config4_ddp_exchange_world1_n16", ddp1)
+
+    def infer():
+        net, cfgs = build_net(args.cfg, 1152, 1920, dev)
+        dt, per, graphed = infer_measure(net, 32, 1152, 1920, dev, K_STEPS, K_WARM)
+        return {"value": round(32 * K_STEPS / dt, 2), "unit": "images/sec", "ms_per_step": round(dt / K_STEPS * 1e3, 3),
+                "ms_per_step_median": round(median(per), 3), "steps": K_STEPS, "warmup": K_WARM, "batch": 32, "resolution": "3x1152x1920",
+                "hipgraph": graphed, "workload": "BASELINE config 5: eval-mode deploy forward, BatchNorm folded, 1080-row frames zero-padded to 1152"}
+    rec("config5_inference_1152x1920_n32", infer)
+    if dist.is_initialized() and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        with contextlib.suppress(Exception):
+            dist.destroy_process_group()
+    return res
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -291,6 +647,7 @@ def main():
     ap.add_argument("--cfg", default=os.path.join(ROOT, "cfgs", "hydranet_big.yml"))
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one captured hipGraph per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra_configs and segments measurements (profiling runs)")
     ap.add_argument("--no-optimizer", action="store_true", help="skip the separate Adam-step timing (profiling runs: keeps the optimizer's "
                     "state initialisation and multi-tensor kernels out of the kernel statistics)")
     ap.add_argument("--backbone-only", action="store_true", help="BASELINE config[1]: backbone fwd+bwd, loss = sum of feature means")
@@ -301,6 +658,7 @@ def main():
                     "at world size 1 -- exercises the N > 1 code path on a single GPU")
     ap.add_argument("--grad-payload", default="fp32", choices=("fp32", "bf16"), help="gradient all-reduce payload type")
     ap.add_argument("--exchange-after-replay", action="store_true", help="do not capture the all-reduce inside the hipGraph")
+    ap.add_argument("--phase", default=None, choices=("lane", "det", "seg"), help="head-only fine-tuning phase (train.py:441-515)")
     args = ap.parse_args()
     h, w = (int(v) for v in args.res.split("x"))
     rank = int(os.environ.get("RANK", "0"))
@@ -330,15 +688,9 @@ def main():
         ge.build()
     if world > 1:
         dist.barrier()
-    from multitask_hydranet_amd import HydraNet
-    from multitask_hydranet_amd.ddp import GradReducer, UNUSED_5STAGE, broadcast_state
+    from multitask_hydranet_amd.ddp import broadcast_state
 
-    cfgs = yaml.safe_load(open(args.cfg))
-    cfgs["dataloader"]["network_input_height"], cfgs["dataloader"]["network_input_width"] = h, w
-    torch.manual_seed(0)
-    net = HydraNet(cfgs).to(dev).train()
-    net.check_finite = False                       # the reference's exit()-on-NaN guard is a host sync; checked once after the run instead
-    net.lane_points_per_line = h // cfgs["lane"]["interval"]     # the reference default (160) raises IndexError at H=512
+    net, cfgs = build_net(args.cfg, h, w, dev)
     broadcast_state(net)
     if os.environ.get("HN_TN"):                      # tools/ sweeps: "bc,bn,splits" -> hn_debug_tn_config
         from multitask_hydranet_amd._lib import lib
@@ -356,159 +708,28 @@ def main():
     if args.infer:
         return infer_bench(args, net, cfgs, h, w, dev, rank, world)
     batch = synthetic_batch(cfgs, args.batch, h, w, seed=1 + rank, device=dev)
-    reducer = None
-    use_graph = not args.no_graph
+    net.grad_scope = args.phase
     payload = torch.bfloat16 if args.grad_payload == "bf16" else torch.float32
-    skip = UNUSED_5STAGE if len(net.depths) == 5 else ()
-
-    def make_reducer(**kw):
-        if os.environ.get("HN_BUCKET_MB"):                                   # tools/ sweeps of the exchange granularity
-            kw["bucket_bytes"] = int(float(os.environ["HN_BUCKET_MB"]) * (1 << 20))
-        return GradReducer(list(net.named_parameters()), world_size=world, skip=skip, payload_dtype=payload,
-                           force_collectives=args.ddp_world1, **kw)
-    if exchange:
-        # captured exchange: every bucket is a branch of the hipGraph, and a branch costs ~0.35 ms of step time on this runtime (world 1,
-        # same box: 7 buckets 620-640 img/s, 4: 655, 2: 671, 1: 693, no exchange: 712) -- two ~86 MB buckets keep the first half of the
-        # all-reduce under the backbone backward; eager hook mode keeps DDP's 25 MiB granularity
-        reducer = make_reducer(bucket_bytes=96 << 20) if use_graph and not args.exchange_after_replay else make_reducer()
-
-    one = torch.ones((), device=dev)                # d loss / d loss, allocated once (loss.backward() alone fills a fresh one every step)
-
-    def fwd_bwd():
-        if args.backbone_only:
-            feats = net._backbone(batch["image"])
-            loss = sum(f.float().mean() for f in feats)
-            loss.backward(one)
-            return loss
-        out = net(batch["image"])
-        ld = net.cal_loss(out, batch)
-        loss = net.total_loss(ld)
-        loss.backward(one)
-        return loss
-
-    graph = None
-    static_loss = None
-    in_graph_exchange = False
-    capture_failed = False
-
-    def capture(with_hooks):
-        """two eager warm-up steps on a side stream, then the capture.  with_hooks: the reducer's autograd hooks stay armed, so every
-        bucket's gather + all-reduce is captured on the reducer's side stream, forked from / joined to the capture stream by events."""
-        s_ = torch.cuda.Stream()
-        s_.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s_):
-            for _ in range(2):
-                net.zero_grad(set_to_none=True)
-                l0 = fwd_bwd()
-                if reducer is not None and with_hooks:
-                    reducer.finish()
-                if os.environ.get("HN_BENCH_DEBUG"):
-                    print("rank", rank, "eager loss", float(l0.detach()), file=sys.stderr, flush=True)
-        torch.cuda.current_stream().wait_stream(s_)
-        torch.cuda.synchronize()
-        net.zero_grad(set_to_none=True)
-        g = torch.cuda.CUDAGraph()
-        # thread-local capture mode: the RCCL watchdog thread's event queries (N > 1) must not invalidate the capture
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
-            sl = fwd_bwd()
-            if reducer is not None and with_hooks:
-                reducer.join_capture()
-        return g, sl
-
-    if use_graph:
-        try:
-            # (only RCCL collectives can be captured: the gloo test hook exchanges after the replay)
-            if reducer is not None and not args.exchange_after_replay and (backend == "nccl" or os.environ.get("HN_BENCH_TRY_CAPTURE") == "1"):
-                try:
-                    graph, static_loss = capture(with_hooks=True)
-                    reducer.adopt_bucket_grads()
-                    reducer.remove()
-                    in_graph_exchange = reducer.captured
-                except Exception as e:              # noqa: BLE001  (an RCCL build that cannot be captured)
-                    # a capture that failed half-way leaves PyTorch's graph bookkeeping unusable for a second capture in this process
-                    # ("Cannot register the state during capturing stage"): run eager launches with the overlapped hook exchange instead
-                    if rank == 0:
-                        print("capturing the all-reduce inside the hipGraph failed (%r): eager launches with the hook exchange instead" % (e,),
-                              file=sys.stderr)
-                    try:
-                        torch.cuda.synchronize()
-                    except Exception:               # noqa: BLE001  (a capture that could not be ended keeps its stream in capture mode)
-                        pass
-                    graph = None
-                    capture_failed = True
-                    reducer.remove()
-                    reducer = make_reducer()
-            if graph is None and not capture_failed:
-                if reducer is not None:
-                    reducer.remove()                # no hooks during this capture; gradients are exchanged right after each replay
-                graph, static_loss = capture(with_hooks=False)
-                if reducer is not None:
-                    # after a replay nothing is left to overlap with: ONE flat bucket = one gather + one all-reduce for all 693 gradients
-                    reducer = make_reducer(bucket_bytes=1 << 40)
-                    reducer.remove()
-                    reducer.bind_static_grads()     # every replay rewrites these tensors; reduce_now() gathers them into the bucket
-        except Exception as e:                      # noqa: BLE001
-            if rank == 0:
-                import traceback
-                traceback.print_exc()
-                print("hipGraph capture failed, falling back to eager launches: %r" % (e,), file=sys.stderr)
-            graph = None
-            torch.cuda.synchronize()
-            if exchange:
-                reducer = make_reducer()
+    run = TrainRun(net, cfgs, batch, dev, rank, world, backend, backbone_only=args.backbone_only, use_graph=not args.no_graph,
+                   exchange=exchange, force_world1=args.ddp_world1, payload=payload, exchange_after_replay=args.exchange_after_replay)
 
     def step():
-        if graph is not None:
-            graph.replay()
-            if reducer is not None and not in_graph_exchange and not os.environ.get("HN_BENCH_SKIP_REDUCE"):
-                reducer.reduce_now()
-            return static_loss
-        net.zero_grad(set_to_none=False) if reducer is not None else net.zero_grad(set_to_none=True)
-        loss = fwd_bwd()
-        if reducer is not None:
-            reducer.finish()
+        loss = run.step()
+        if os.environ.get("HN_BENCH_DEBUG"):
+            print("rank", rank, "loss", float(loss.detach()), file=sys.stderr, flush=True)
         return loss
-
-    for _ in range(args.warmup):
-        loss = step()
-        if os.environ.get("HN_BENCH_DEBUG"):
-            print("rank", rank, "warm-up loss", float(loss.detach()), file=sys.stderr, flush=True)
-    if world > 1:
-        dist.barrier()
-    if os.environ.get("HN_BENCH_NO_DEVSYNC"):
-        torch.cuda.current_stream().synchronize()
-    else:
-        torch.cuda.synchronize()
-    if os.environ.get("HN_BENCH_DEBUG") and graph is not None:
-        print("rank", rank, "before timed loop (no replay)", float(static_loss.detach()), file=sys.stderr, flush=True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-        if os.environ.get("HN_BENCH_DEBUG"):
-            lv = float(loss.detach())
-            print("rank", rank, "timed loss", lv, file=sys.stderr, flush=True)
-            if lv != lv:
-                bad = [k for k, v in net.state_dict().items() if v.is_floating_point() and not torch.isfinite(v).all()]
-                badb = [k for k, v in batch.items() if v.is_floating_point() and not torch.isfinite(v).all()]
-                print("rank", rank, "non-finite state:", bad[:6], len(bad), "batch:", badb, file=sys.stderr, flush=True)
-                with torch.no_grad():
-                    o2 = net(batch["image"])
-                    print("rank", rank, "eager forward after NaN: seg finite", bool(torch.isfinite(o2["seg"]).all()),
-                          "cls finite", bool(torch.isfinite(o2["detection"]["classification"]).all()), file=sys.stderr, flush=True)
-                break
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+    dt, per = time_replays(step, args.steps, args.warmup, world)
+    loss = run.static_loss if run.graph is not None else step()
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
-    loss_val = float(loss)
+    loss_val = float(loss.detach())
     grad_norm = None
     if os.environ.get("HN_BENCH_GRAD_NORM"):        # tests: the gradients after the (possibly in-graph) exchange of the last step
         grad_norm = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in net.parameters() if p.grad is not None)))
     assert loss_val == loss_val and abs(loss_val) != float("inf"), "non-finite loss after the timed run"
+    net.grad_scope = None
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
@@ -517,7 +738,8 @@ def main():
         ms_opt = None
         if not args.no_optimizer:
             from multitask_hydranet_amd.optim import Adam       # torch.optim.Adam's rule, all tensors in one launch (HN_TORCH_ADAM=1: torch's)
-            opt = (torch.optim.Adam if os.environ.get("HN_TORCH_ADAM") else Adam)(net.parameters(), 1e-5, weight_decay=1e-8)
+            opt = (torch.optim.Adam if os.environ.get("HN_TORCH_ADAM") else Adam)([p for p in net.parameters() if p.grad is not None], 1e-5,
+                                                                                  weight_decay=1e-8)
             for _ in range(2):
                 opt.step()
             torch.cuda.synchronize()
@@ -526,33 +748,44 @@ def main():
                 opt.step()
             torch.cuda.synchronize()
             ms_opt = (time.perf_counter() - t1) / 5 * 1e3
+            del opt
         scale = (h * w) / (512.0 * 1024.0)
         gflop_img = 3 * FWD_GFLOP_PER_IMG_512x1024 * scale * (12.02 / 81.13 if args.backbone_only else 1.0)
+        what = "RegNetY backbone only" if args.backbone_only else "full HydraNet (backbone + BiFPN + seg/det/lane heads + multitask loss)"
+        if args.phase:
+            what += ", head-only fine-tuning phase '%s' (backward through that head only)" % args.phase
         res = {
-            "metric": "images/sec (fwd+bwd) HydraNet @ default res, 1/2/4/8 MI355X; CPU-ref same run", "value": round(value, 2), "unit": "images/sec", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": ("RegNetY backbone only" if args.backbone_only else "full HydraNet (backbone + BiFPN + seg/det/lane heads + multitask loss)")
-                       + ", big cfg, fwd+loss+bwd", "batch_per_gpu": args.batch, "global_batch": args.batch * world,
-                       "resolution": "3x%dx%d" % (h, w), "parallelism": "dp%d" % world, "hipgraph": graph is not None,
-                       "grad_allreduce": None if reducer is None else ("%s backend: " % backend) + reducer.describe(
-                           after_replay=graph is not None and not in_graph_exchange)},
-            "ms_optimizer_step": round(ms_opt, 3) if ms_opt is not None else None, "loss": round(loss_val, 4), **({"grad_norm": grad_norm} if grad_norm is not None else {}),
+            "metric": METRIC, "value": round(value, 2), "unit": "images/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "ms_per_step_median": round(median(per), 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": what + ", big cfg, fwd+loss+bwd", "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                       "resolution": "3x%dx%d" % (h, w), "parallelism": "dp%d" % world, "hipgraph": run.graph is not None,
+                       "grad_allreduce": run.describe_exchange()},
+            "ms_optimizer_step": round(ms_opt, 3) if ms_opt is not None else None, "loss": round(loss_val, 4),
+            **({"grad_norm": grad_norm} if grad_norm is not None else {}),
             "model_tflops": round(value * gflop_img / 1e3, 2),
             # SURVEY 8(d) segment-wise roofline of the whole step (seg decoder on MFMA, everything else on HBM): 0.177 ms/img at 512x1024
             "step_roofline": {"floor_ms_per_img": round(0.177 * scale, 4), "frac": round(value / world * 0.177e-3 * scale, 4)},
+            "env_overrides": env_overrides(),
         }
         try:
             res["roofline"] = dominant_launch_roofline(net, args.batch, h, w)
         except Exception as e:      # noqa: BLE001
             res["roofline"] = {"error": repr(e)}
+        plain = world == 1 and not (args.backbone_only or args.phase or args.ddp_world1 or args.no_graph or args.no_extras)
+        if plain:
+            try:
+                res["segments"] = segment_table(net, cfgs, batch, args.batch, h, w, median(per))
+            except Exception as e:  # noqa: BLE001
+                res["segments"] = {"error": repr(e)[:300]}
+            res["extra_configs"] = extra_configs(args, dev, net, cfgs)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(yaml.safe_load(open(args.cfg)) | {"dataloader": cfgs["dataloader"]}, h, w)
             except Exception as e:  # noqa: BLE001
                 res["cpu_baseline"] = {"error": repr(e)}
         emit(res)
-    if exchange:
+    if exchange and dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -440,10 +440,30 @@ def cur_queue():
     return _CUR_QUEUE if DEFER_WGRAD else None
 
 
+SIDE_FLUSH = os.environ.get("HN_SIDE_FLUSH", "0") == "1"     # run the deferred-gradient flushes on a side HIP stream (a hipGraph branch)
+_SIDE = {}                                                   # device -> (stream, [tensors kept alive until the join], join-queued flag)
+
+
+def _side_state(dev):
+    st = _SIDE.get(dev)
+    if st is None:
+        st = _SIDE[dev] = [torch.cuda.Stream(device=dev), [], False]
+    return st
+
+
+def _side_join(dev):
+    """end of the backward pass (engine callback): the main stream waits for the side stream's flushes; the operands may be recycled"""
+    st = _SIDE[dev]
+    torch.cuda.current_stream(dev).wait_stream(st[0])
+    st[1].clear()
+    st[2] = False
+
+
 class DeferredGrads(torch.autograd.Function):
-    """Identity on the tensor that ENTERS a backbone stage.  Its backward runs when the gradient leaves the stage -- after every XBlock
-    of the stage has run its backward and queued its 1x1 weight gradients in `group` -- launches them as one grouped GEMM and returns
-    them for `weights` (the same parameter tensors the XBlockFn nodes received; those nodes return None for them)."""
+    """Identity on the tensor that ENTERS a segment (a backbone stage; the backbone's last output for the neck + heads).  Its backward runs
+    when the gradient leaves the segment -- after every node of the segment has run its backward and queued its deferred parameter
+    gradients in `group` (autograd runs ready nodes in reverse creation order) -- flushes the queue and returns the gradients for `weights`
+    (the same parameter tensors the segment's nodes received; those nodes return None for them)."""
 
     @staticmethod
     def forward(ctx, x, group, *weights):
@@ -453,6 +473,21 @@ class DeferredGrads(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if SIDE_FLUSH and g.is_cuda:
+            # Deferred gradients are off the critical path by construction: their launches go to a side stream (inside a captured step: a
+            # branch of the hipGraph) next to the latency-bound data-gradient chain, which leaves most of the chip idle; one join at the
+            # end of the backward pass.
+            dev = g.device
+            st = _side_state(dev)
+            cur = torch.cuda.current_stream(dev)
+            st[0].wait_stream(cur)
+            st[1].append((list(ctx.group.jobs), list(ctx.group.tail)))          # operands stay alive until the join
+            with torch.cuda.stream(st[0]):
+                grads = ctx.group.flush()
+            if not st[2]:
+                st[2] = True
+                torch.autograd.Variable._execution_engine.queue_callback(lambda: _side_join(dev))
+            return (g, None, *grads)
         return (g, None, *ctx.group.flush())
 
 

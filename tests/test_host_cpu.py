@@ -226,3 +226,20 @@ def test_coco_json_records(tmp_path):
     assert [a["image_id"] for a in gt["annotations"]] == [1, 1, 2] and [a["id"] for a in gt["annotations"]] == [1, 2, 3]
     assert gt["annotations"][0]["bbox"] == [100.0, 200.0, 200, 60] and gt["annotations"][0]["area"] == 12000
     assert gt["annotations"][1]["bbox"] == [5.5, 6.5, 4, 3] and len(gt["categories"]) == 9 and gt["categories"][7]["name"] == "vehicle"
+
+
+def test_conv_work_accounting_matches_survey_totals():
+    """multitask_hydranet_amd.accounting (the per-segment floors of bench.py's `segments` table) against the figures the survey measured with
+    forward hooks on the reference: MACs, conv input / output elements, per-segment FLOP split; and the resulting
+    segment-wise roofline floor (0.177 ms per image at 512x1024)"""
+    from multitask_hydranet_amd.accounting import conv_work, segment_floors_ms
+    cfgs = load_cfg("hydranet_big.yml")
+    for (h, w), (gflop, sx, sy, split) in {(512, 1024): (81.13, 128.33, 82.50, (12.02, 1.48, 64.85, 2.10, 0.68)),
+                                          (640, 640): (63.40, 100.38, 64.48, (9.39, 1.15, 50.67, 1.64, 0.54))}.items():
+        wk = conv_work(cfgs, h, w)
+        assert abs(2 * sum(v["macs"] for v in wk.values()) / 1e9 - gflop) < 0.006
+        assert abs(sum(v["x"] for v in wk.values()) / 1e6 - sx) < 0.1 and abs(sum(v["y"] for v in wk.values()) / 1e6 - sy) < 0.02
+        for k, g in zip(("backbone", "neck", "seg", "det", "lane"), split):
+            assert abs(2 * wk[k]["macs"] / 1e9 - g) < 0.006, k
+    fl = segment_floors_ms(cfgs, 512, 1024, 16)
+    assert abs(sum(fl.values()) / 16 - 0.177) < 0.004 and fl["seg"] > fl["backbone"] > fl["det"] > fl["neck"] > fl["lane"]
