@@ -712,7 +712,49 @@ __global__ __launch_bounds__(512, PIPE ? 2 : 4) void conv3x3_direct_kernel(const
             }
         }
     };
-    if (PIPE) {
+    if (BC == 64 && !PIPE && xs.diag) {
+        // Grouped conv (group width 8) as block-diagonal 64 x 64 tiles: of the 8 KB weight tile of a tap only the eight 8 x 8 diagonal
+        // blocks (1 KB) are non-zero.  All nine taps' blocks (9 KB: [tap][cout 64][8 ci]) are fetched ONCE next to the patch, and the A
+        // fragments are built from them by a lane select -- the tap loop has no barrier and no DMA wait.  The tile-streaming loop below
+        // exposed one weight-DMA round trip per tap: 9 x 2.2 us = 19.8 us per launch on the deep stages, for 1 us of MFMA work.
+        issue_x(0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (512 * i + 64 * wave < 9 * 64) {                         // wave-uniform
+                const int e = 512 * i + tid, tap = e >> 6, col = e & 63, co = c_blk + col;
+                const bf16* src = co < p.Nout ? p.w + co * Ktot + tap * 64 + (col >> 3) * 8 : g_zero_piece;
+                glds16(src, sWb + (512 * i + 64 * wave) * 16);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int kq = lane >> 4;
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+            const int dy = xs.mode == 2 ? ky : 2 - ky, dx = xs.mode == 2 ? kx : 2 - kx;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 a[TC], b[TP];
+                const int piece = ks * 4 + kq;
+#pragma unroll
+                for (int i = 0; i < TC; ++i) {
+                    const int col = i * 16 + (lane & 15);              // (BC == 64: one cout group of waves, wc == 0)
+                    const bf16x8 v = *reinterpret_cast<const bf16x8*>(sWb + (tap * 64 + col) * 16);
+                    a[i] = piece == (col >> 3) ? v : zero8();
+                }
+#pragma unroll
+                for (int j = 0; j < TP; ++j) {
+                    const int pidx = (wp * ROWS + j + dy) * 18 + (lane & 15) + dx;
+                    b[j] = *reinterpret_cast<const bf16x8*>(sXb + pidx * 128 + ((piece ^ (pidx & 7)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < TC; ++i)
+#pragma unroll
+                    for (int j = 0; j < TP; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    } else if (PIPE) {
         static_assert(!PIPE || BC >= 64, "the counted waits need every wave to issue the same number of weight loads");
         issue_x(0);
         issue_w(0);
