@@ -225,6 +225,12 @@ int hn_conv_gemm_tn_phase(const void* x0, int n_img, int H, int W, int C0, int l
 int hn_conv_gemm_tn_deferred(const void* x0, const void* x1, int mode, int n_img, int H, int W, int C0, int C1, int ld0, int ld1, int up, long M,
                              const void* dz, int ldz, int Nout, int KP, int taps, float* workspace, float* dw, long* job, hipStream_t stream);
 int hn_wgrad_reduce_jobs(const long* jobs, int njobs, hipStream_t stream);
+/* Deferred, grouped weight gradients of grouped 3x3 convs (group width 8, stride 1): up to 32 dw_j [C][8][3][3] (fp32) in one launch of the
+ * patch kernel + one extract launch -- the conv_block_2 weight gradients of the identity XBlocks of one backbone stage (net/anynet.py:34-38).
+ * jobs: HOST table, 9 int64 per job {x, dz, dw, n_img, H, W, C, ldx, ldz}; workspace: hn_gconv_wgrad_group_ws_bytes() bytes. */
+long hn_gconv_wgrad_group_ws_bytes(const long* jobs, int njobs);
+int hn_gconv_wgrad_group(const long* jobs, int njobs, float* workspace, hipStream_t stream);
+
 /* Deferred parameter-gradient tails in ONE launch (ops.GradQueue): up to 64 small reductions that finish parameter gradients off the
  * backward pass's critical path.  jobs: HOST table, 8 int64 per job {kind, a, b, out, out2, n0, n1, n2}:
  *   kind 0: out[c] = sum_r a[r][c], a fp32 [n0 rows][n1 cols] -- partial-row folds of depthwise / stride-2 grouped conv weight gradients

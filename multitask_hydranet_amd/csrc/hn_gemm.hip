@@ -1442,7 +1442,7 @@ __global__ __launch_bounds__(64 * WGC * WGN, 2) void gemm_tn_group_kernel(const 
 // 512 threads = 8 waves = (BC/64 cout groups) x (CI/16 ci groups); wave tile = 64 couts x 16 ci x 9 taps (144 accumulator VGPRs).
 // ---------------------------------------------------------------------------------------------------------
 template <int BC, int CI>
-__global__ __launch_bounds__(512) void wgrad3x3_patch_kernel(const GemmTN p, int patches_per_split, int n_patches) {
+__device__ __forceinline__ void wgrad3x3_patch_body(const GemmTN& p, const int patches_per_split, const int n_patches, const int lid) {
     constexpr int WCO = BC >= 64 ? 64 : BC, TC = WCO / 16;
     constexpr int WGC = BC / WCO, WGN = CI / 16, KSPLIT = 8 / (WGC * WGN);   // KSPLIT > 1: waves also split the patch's k-steps
     static_assert(WGC * WGN * KSPLIT == 8, "8 waves must tile BC x CI x k-split");
@@ -1456,7 +1456,6 @@ __global__ __launch_bounds__(512) void wgrad3x3_patch_kernel(const GemmTN p, int
     const int wn = wave % WGN, wc = (wave / WGN) % WGC, wk = wave / (WGN * WGC);
     const XSrc& xs = p.x;
     const int ntile = (p.KP + CI - 1) / CI;                            // (diag: KP == CI == 64 -> 1)
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int bx = lid % ntile, by = (lid / ntile) % p.gy, bz = lid / (ntile * p.gy);
     const int c_blk = by * BC;
     const int ci_blk = p.x.diag ? c_blk : bx * CI;                    // input-channel base of this block's X patch
@@ -1593,6 +1592,30 @@ __global__ __launch_bounds__(512) void wgrad3x3_patch_kernel(const GemmTN p, int
                     if (co < p.Nout) part[(long)co * Ktot + tap * p.KP + ci] = acc[i][tap][r];
                 }
     }
+}
+
+template <int BC, int CI>
+__global__ __launch_bounds__(512) void wgrad3x3_patch_kernel(const GemmTN p, int patches_per_split, int n_patches) {
+    wgrad3x3_patch_body<BC, CI>(p, patches_per_split, n_patches, xcd_remap(blockIdx.x, gridDim.x));
+}
+
+// The grouped 3x3 (group width 8) weight gradients of a whole backbone stage in one launch (hn_gconv_wgrad_group): per XBlock this
+// was a 15-28 us launch of 120-190 workgroups plus a slab reduce; deferred to the stage boundary (ops.GradQueue) the jobs fill the chip
+// together and need fewer patch splits (= fewer 2 MB fp32 slabs each).
+struct PJob { const bf16* x; const bf16* dz; float* part; int n_img, H, W, C, ldx, ldz, gy, pps, n_patches, first_block; };
+struct PJobs { PJob j[HN_TN_GROUP_MAX]; int n; };
+__global__ __launch_bounds__(512) void gconv_wgrad_group_kernel(const PJobs jobs) {
+    const int glid = xcd_remap(blockIdx.x, gridDim.x);
+    int ji = 0;
+    for (int k = 1; k < jobs.n; ++k)
+        if (glid >= jobs.j[k].first_block) ji = k;
+    const PJob& jb = jobs.j[ji];
+    GemmTN p;
+    p.x.x0 = jb.x; p.x.x1 = nullptr; p.x.mode = 2; p.x.H = jb.H; p.x.W = jb.W; p.x.Hi = jb.H; p.x.Wi = jb.W; p.x.C0 = jb.C; p.x.C1 = 0;
+    p.x.ld0 = jb.ldx; p.x.ld1 = 0; p.x.up = 0; p.x.M = (long)jb.n_img * jb.H * jb.W; p.x.clamp = 2; p.x.diag = 1;
+    p.dz = jb.dz; p.ldz = jb.ldz; p.Nout = jb.C; p.KP = 64; p.taps = 9; p.part = jb.part; p.rows_per_split = jb.pps; p.gy = jb.gy;
+    p.phase_span = 0; p.bias_part = nullptr; p.out_ld = 0; p.cin_lim = 0; p.dbg = 0;
+    wgrad3x3_patch_body<64, 64>(p, jb.pps, jb.n_patches, glid - jb.first_block);
 }
 
 // dbias[co] = sum over the slabs of bias_part[slab][co]: done by the first ceil(Nout / 64) workgroups of whichever reduce kernel follows
@@ -2495,7 +2518,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_group_kernel(const RJobsN jo
     const RJob& jb = jobs.j[ji];
     const long blk = (long)blockIdx.x - jb.first_block;
     if (jb.kind == 0) reduce4_body(jb.part, jb.dw, jb.splits, jb.Nout, jb.Cin, jb.KP, jb.taps, blk);
-    else reduce_lanes_body(jb.part, jb.dw, jb.splits, jb.Nout, jb.Cin, jb.KP, jb.taps, blk, red);
+    else if (jb.kind == 1) reduce_lanes_body(jb.part, jb.dw, jb.splits, jb.Nout, jb.Cin, jb.KP, jb.taps, blk, red);
+    else diag_extract_body(jb.part, jb.dw, jb.splits, jb.Nout, blk);
 }
 
 #define HN_WG_FIELDS 12
@@ -2630,6 +2654,70 @@ extern "C" int hn_wgrad_group(const long* jobs, int njobs, float* workspace, hip
 #undef TNG_RING
     if (rc != HN_OK) return rc;
     if (r.n) hipLaunchKernelGGL(wgrad_reduce_group_kernel, dim3((unsigned)rblocks), dim3(256), 0, st, r);
+    HN_LAUNCH_CHECK();
+}
+
+// jobs: host table, 9 int64 per job {x, dz, dw, n_img, H, W, C, ldx, ldz}: stride-1 grouped 3x3 conv (group width 8, zero "same" padding)
+static int gconv_group_plan(const long* jobs, int njobs, int* psplits, long* pps, long* ws_off, long* ws_floats) {
+    HN_CHECK_ARG(jobs && njobs > 0 && njobs <= HN_TN_GROUP_MAX);
+    long tiles = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const long* jb = jobs + 9 * i;
+        HN_CHECK_ARG(jb[0] && jb[1] && jb[2] && jb[3] > 0 && jb[4] > 0 && jb[5] > 0 && jb[6] >= 8 && (jb[6] & 7) == 0 && (jb[7] & 7) == 0 &&
+                     (jb[8] & 7) == 0 && jb[8] >= jb[6]);
+        tiles += cdiv(jb[6], 64);
+    }
+    long want = (384 + tiles - 1) / tiles;                  // ~1.5 workgroups per CU in total (78 KB of LDS each: two fit)
+    *ws_floats = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const long* jb = jobs + 9 * i;
+        const long patches = jb[3] * cdiv(jb[4], 8) * cdiv(jb[5], 16);
+        long w = want;
+        if (w > patches / 2) w = patches / 2;
+        if (w < 1) w = 1;
+        pps[i] = (patches + w - 1) / w;
+        psplits[i] = (int)((patches + pps[i] - 1) / pps[i]);
+        ws_off[i] = *ws_floats;
+        *ws_floats += (long)psplits[i] * 2 * jb[6] * 576;    // two k-split wave groups per workgroup: one block-diagonal slab each
+    }
+    return HN_OK;
+}
+extern "C" long hn_gconv_wgrad_group_ws_bytes(const long* jobs, int njobs) {
+    int ps[HN_TN_GROUP_MAX]; long pp[HN_TN_GROUP_MAX], off[HN_TN_GROUP_MAX], total;
+    if (gconv_group_plan(jobs, njobs, ps, pp, off, &total) != HN_OK) return -1;
+    return total * 4 + 64;
+}
+/* Up to 32 grouped-3x3-conv weight gradients dw_j [C][8][3][3] (fp32) in one patch-kernel launch + one extract launch; jobs: HOST table,
+ * 9 int64 per job {x, dz, dw, n_img, H, W, C, ldx, ldz} (x = the conv's bf16 input [n_img][H][W][C], dz = its output gradient, stride 1).
+ * Reference op: the weight gradient of XBlock.conv_block_2 (net/anynet.py:34-38) of every identity block of a stage. */
+extern "C" int hn_gconv_wgrad_group(const long* jobs, int njobs, float* workspace, hipStream_t st) {
+    int ps[HN_TN_GROUP_MAX]; long pp[HN_TN_GROUP_MAX], off[HN_TN_GROUP_MAX], total;
+    const int rc0 = gconv_group_plan(jobs, njobs, ps, pp, off, &total);
+    if (rc0 != HN_OK) return rc0;
+    HN_CHECK_ARG(workspace);
+    static std::atomic<unsigned long long> optin{0};
+    if (!lds_optin(optin, {(const void*)gconv_wgrad_group_kernel})) return HN_ERR_LAUNCH;
+    PJobs t;
+    RJobsN r;
+    t.n = r.n = njobs;
+    long blocks = 0, rblocks = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const long* jb = jobs + 9 * i;
+        PJob& d = t.j[i];
+        d.x = reinterpret_cast<const bf16*>(jb[0]); d.dz = reinterpret_cast<const bf16*>(jb[1]); d.part = workspace + off[i];
+        d.n_img = (int)jb[3]; d.H = (int)jb[4]; d.W = (int)jb[5]; d.C = (int)jb[6]; d.ldx = (int)jb[7]; d.ldz = (int)jb[8];
+        d.gy = cdiv(d.C, 64); d.pps = (int)pp[i]; d.n_patches = d.n_img * cdiv(d.H, 8) * cdiv(d.W, 16);
+        d.first_block = (int)blocks;
+        blocks += (long)d.gy * ps[i];
+        RJob& q = r.j[i];
+        q.part = d.part; q.dw = reinterpret_cast<float*>(jb[2]); q.splits = ps[i] * 2; q.Nout = d.C; q.Cin = 8; q.KP = 64; q.taps = 9; q.kind = 2;
+        q.first_block = rblocks;
+        rblocks += cdiv((long)d.C * 72, 256);
+    }
+    const size_t xb = (size_t)((180 * 8 + 511) / 512) * 512 * 16;
+    const size_t lds = 2 * ((size_t)((128 * 64 * 2 + 1023) / 1024 * 1024) + xb);
+    hipLaunchKernelGGL(gconv_wgrad_group_kernel, dim3((unsigned)blocks), dim3(512), lds, st, t);
+    hipLaunchKernelGGL(wgrad_reduce_group_kernel, dim3((unsigned)rblocks), dim3(256), 0, st, r);
     HN_LAUNCH_CHECK();
 }
 

@@ -370,6 +370,7 @@ class GradQueue:
     def __init__(self):
         self.weights = ()           # the parameters DeferredGrads hands gradients back for, in its argument order
         self.jobs = []              # 1x1 weight gradients: (weight, x0, dz, mode, (n, h, w), cin, nout)
+        self.gconv = []             # grouped 3x3 weight gradients: (weight, x, dz, (n, h, w), c)
         self.tail = []              # (weights tuple, kind, a, b, n0, n1, n2, out shapes)
 
     # -- queueing ------------------------------------------------------------------------------------------------------------------
@@ -377,6 +378,10 @@ class GradQueue:
         self.jobs.append((weight, x0, dz, mode, grid, cin, nout))
 
     add_gemm = add
+
+    def add_gconv(self, weight, x, dz, grid, c):
+        """weight.grad [c, 8, 3, 3] of a stride-1 grouped 3x3 conv (group width 8): input x, output gradient dz, both [n, h, w, c] bf16"""
+        self.gconv.append((weight, x, dz, grid, c))
 
     def add_rows(self, weight, part, rows, cols, shape):
         """weight.grad (shape `shape`, rows * 0 + cols elements) = column sums of part [rows, cols]"""
@@ -394,6 +399,7 @@ class GradQueue:
         """-> one fp32 gradient (or None) per entry of self.weights"""
         jobs, self.jobs = self.jobs, []
         tail, self.tail = self.tail, []
+        gconv, self.gconv = self.gconv, []
         out = {}
 
         def put(wgt, g):
@@ -412,6 +418,21 @@ class GradQueue:
                 raise RuntimeError("hn_wgrad_group: bad job table")
             ws = torch.empty((wsb // 4,), device=chunk[0][2].device, dtype=F32)
             lib().call("hn_wgrad_group", ctypes.addressof(tab), len(chunk), ptr(ws))
+            for (wgt, *_), dw in zip(chunk, dws):
+                put(wgt, dw)
+        for c0 in range(0, len(gconv), self.MAX_GEMM):
+            chunk = gconv[c0:c0 + self.MAX_GEMM]
+            tab = (ctypes.c_long * (9 * len(chunk)))()
+            dws = []
+            for i, (wgt, x, dz, (n, h, w), c) in enumerate(chunk):
+                dw = torch.empty((c, 8, 3, 3), device=dz.device, dtype=F32)
+                dws.append(dw)
+                tab[9 * i:9 * i + 9] = [x.data_ptr(), dz.data_ptr(), dw.data_ptr(), n, h, w, c, ld(x), ld(dz)]
+            wsb = lib().query("hn_gconv_wgrad_group_ws_bytes", ctypes.addressof(tab), len(chunk))
+            if wsb < 0:
+                raise RuntimeError("hn_gconv_wgrad_group: bad job table")
+            ws = torch.empty((wsb // 4,), device=chunk[0][2].device, dtype=F32)
+            lib().call("hn_gconv_wgrad_group", ctypes.addressof(tab), len(chunk), ptr(ws))
             for (wgt, *_), dw in zip(chunk, dws):
                 put(wgt, dw)
         for c0 in range(0, len(tail), self.MAX_TAIL):
@@ -932,7 +953,10 @@ class XBlockFn(torch.autograd.Function):
         dz2, dg2, db2, _ = bn_backward_fused(dbg, z2, None, coef2, ACT_RELU, m, gate=gate, dpool=dpool, hw=hw)
         if stride == 1:
             da, _, _ = k_gemm_nt(dz2, None, 5, grid, wd2, c, 64, 9)
-            dw2 = k_gemm_tn(a, None, 5, grid, dz2, c, 64, 9, 8, kh=3, defer=batch)
+            if group is not None:
+                dw2 = group.add_gconv(w2_, a, dz2, grid, c)
+            else:
+                dw2 = k_gemm_tn(a, None, 5, grid, dz2, c, 64, 9, 8, kh=3, defer=batch)
         else:
             da = new_act(n, h, w, c, dev)
             lib().call("hn_gconv_dgrad_s2", ptr(dz2), ld(dz2), ptr(wd2), ptr(da), ld(da), n, h, w, c)

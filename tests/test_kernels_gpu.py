@@ -832,6 +832,31 @@ def test_grouped_deferred_wgrad(K, stage):
     assert group.flush() == [None, None]
 
 
+def test_grouped_deferred_gconv_wgrad(K):
+    """ops.GradQueue.add_gconv / hn_gconv_wgrad_group: the grouped 3x3 (group width 8) weight gradients of several identity XBlocks in one
+    patch-kernel launch + one extract launch == the one-by-one launches (hn_conv_gemm_tn mode 5; 1e-5: same kernel body, other patch
+    splits) and == torch's grouped conv weight gradient on the bf16 operands (2e-3)"""
+    import torch.nn.functional as F
+    q = K.GradQueue()
+    ws, want, ones = [], [], []
+    for (n, h, w), c in [((16, 8, 16), 936), ((16, 8, 16), 936), ((4, 16, 32), 376), ((2, 32, 64), 152), ((2, 20, 24), 64)]:
+        x = nhwc(rnd(n, c, h, w))
+        dz = nhwc(rnd(n, c, h, w, scale=0.1))
+        wgt = torch.empty(c, 8, 3, 3, device=dev())
+        q.add_gconv(wgt, x, dz, (n, h, w), c)
+        ws.append(wgt)
+        ones.append(K.k_gemm_tn(x, None, 5, (n, h, w), dz, c, 64, 9, 8, kh=3))
+        xx = x.float().permute(0, 3, 1, 2).requires_grad_(False)
+        wz = torch.zeros(c, 8, 3, 3, device=dev(), requires_grad=True)
+        F.conv2d(xx, wz, None, 1, 1, 1, c // 8).backward(dz.float().permute(0, 3, 1, 2))
+        want.append(wz.grad)
+    q.weights = tuple(ws)
+    got = q.flush()
+    for g, o, r in zip(got, ones, want):
+        close(g, o, 1e-5, "grouped gconv wgrad vs one-by-one")
+        close(g, r, 2e-3, "grouped gconv wgrad vs torch")
+
+
 def test_grad_tail_jobs(K):
     """hn_grad_tail through ops.GradQueue: partial-row folds (short and tall), BiFPN fusion-weight Jacobians (2 and 3 weights, one clamped
     by the relu) and SE outer products, > 64 jobs (two launches), against torch in fp32"""

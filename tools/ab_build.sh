@@ -5,6 +5,6 @@
 R=$(cd "$(dirname "$0")/.." && pwd)
 case "$1" in
   save) cp $R/multitask_hydranet_amd/libhydranet_hip.so $R/multitask_hydranet_amd/libhydranet_hip_B.so ;;
-  run) for i in 1 2; do python $R/bench.py --no-cpu-baseline 2>&1 | tail -1 | cut -c80-175; HN_LIB_AB=$R/multitask_hydranet_amd/libhydranet_hip_B.so python $R/bench.py --no-cpu-baseline 2>&1 | tail -1 | cut -c80-175; done ;;
+  run) for i in 1 2; do python $R/bench.py --no-cpu-baseline --no-extras 2>&1 | tail -1 | cut -c80-175; HN_LIB_AB=$R/multitask_hydranet_amd/libhydranet_hip_B.so python $R/bench.py --no-cpu-baseline --no-extras 2>&1 | tail -1 | cut -c80-175; done ;;
   *) echo "usage: ab_build.sh save|run" ;;
 esac

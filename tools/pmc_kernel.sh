@@ -6,7 +6,7 @@ rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 cd $R
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/$c -- python3 bench.py --no-cpu-baseline --no-optimizer --no-graph --steps 2 --warmup 1 > $O/$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/$c -- python3 bench.py --no-cpu-baseline --no-optimizer --no-extras --no-graph --steps 2 --warmup 1 > $O/$c.log 2>&1
   f=$(find $O/$c -name "*counter_collection.csv" | head -1)
   python3 - "$f" $c "$1" <<'PY'
 import csv, sys, re, collections

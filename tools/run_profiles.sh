@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 cd $R
 python bench.py > $O/bench_default.log 2>&1
 tail -1 $O/bench_default.log > $O/bench_n1.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py --no-cpu-baseline --no-optimizer > $O/bench_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py --no-cpu-baseline --no-optimizer --no-extras > $O/bench_rocprof.log 2>&1
 f=$(find $O/kt -name "*kernel_stats.csv" | head -1); cp "$f" $O/kernel_stats.csv
 t=$(find $O/kt -name "*kernel_trace.csv" | head -1); head -1 "$t" > $O/dominant_dispatches.csv; grep "conv3x3_direct_kernel<128" "$t" | tail -600 >> $O/dominant_dispatches.csv
 rm -rf $O/kt

@@ -5,7 +5,7 @@ O=$R/gpurun_out/stats
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 cd $R
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py --no-cpu-baseline --no-optimizer --steps 8 --warmup 2 "$@" > $O/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py --no-cpu-baseline --no-optimizer --no-extras --steps 8 --warmup 2 "$@" > $O/bench.log 2>&1
 f=$(find $O/kt -name "*kernel_stats.csv" | head -1); cp "$f" $O/kernel_stats.csv
 rm -rf $O/kt
 python3 - <<'PY'

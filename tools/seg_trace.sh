@@ -6,7 +6,7 @@ rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 cd $R
 for v in 1 0; do
-  HN_SEG_PHASE_UP=$v rocprofv3 --kernel-trace --output-format csv -d $O/kt$v -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 > $O/bench$v.log 2>&1
+  HN_SEG_PHASE_UP=$v rocprofv3 --kernel-trace --output-format csv -d $O/kt$v -- python3 bench.py --no-cpu-baseline --no-extras --steps 3 --warmup 1 > $O/bench$v.log 2>&1
   f=$(find $O/kt$v -name "*kernel_trace.csv" | head -1)
   python3 - "$f" $v <<'PY'
 import csv, sys
