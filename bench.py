@@ -648,6 +648,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one captured hipGraph per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra_configs and segments measurements (profiling runs)")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the dominant-launch timing loop (counter passes: only the step's own launches)")
     ap.add_argument("--no-optimizer", action="store_true", help="skip the separate Adam-step timing (profiling runs: keeps the optimizer's "
                     "state initialisation and multi-tensor kernels out of the kernel statistics)")
     ap.add_argument("--backbone-only", action="store_true", help="BASELINE config[1]: backbone fwd+bwd, loss = sum of feature means")
@@ -768,10 +769,11 @@ def main():
             "step_roofline": {"floor_ms_per_img": round(0.177 * scale, 4), "frac": round(value / world * 0.177e-3 * scale, 4)},
             "env_overrides": env_overrides(),
         }
-        try:
-            res["roofline"] = dominant_launch_roofline(net, args.batch, h, w)
-        except Exception as e:      # noqa: BLE001
-            res["roofline"] = {"error": repr(e)}
+        if not args.no_roofline:
+            try:
+                res["roofline"] = dominant_launch_roofline(net, args.batch, h, w)
+            except Exception as e:      # noqa: BLE001
+                res["roofline"] = {"error": repr(e)}
         plain = world == 1 and not (args.backbone_only or args.phase or args.ddp_world1 or args.no_graph or args.no_extras)
         if plain:
             try:
