@@ -384,9 +384,8 @@ class TrainRun:
         self._GradReducer = GradReducer
         self._payload, self._force = payload, force_world1
         if exchange:
-            # captured exchange: every bucket is a branch of the hipGraph, and a branch costs ~0.35 ms of step time on this runtime (world 1,
-            # same box: 7 buckets 620-640 img/s, 4: 655, 2: 671, 1: 693, no exchange: 712) -- two ~86 MB buckets keep the first half of the
-            # all-reduce under the backbone backward; eager hook mode keeps DDP's 25 MiB granularity
+            # captured exchange: gather + all-reduce of every bucket in line on the capture stream (ddp.py); two ~86 MB buckets: few, large
+            # collectives for the point-to-point xGMI links; eager hook mode keeps DDP's 25 MiB granularity
             self.reducer = self._make_reducer(bucket_bytes=96 << 20) if use_graph and not exchange_after_replay else self._make_reducer()
         capture_failed = False
         if use_graph:
@@ -451,8 +450,8 @@ class TrainRun:
         return loss
 
     def _capture(self, with_hooks):
-        """two eager warm-up steps on a side stream, then the capture.  with_hooks: the reducer's autograd hooks stay armed, so every
-        bucket's gather + all-reduce is captured on the reducer's side stream, forked from / joined to the capture stream by events."""
+        """two eager warm-up steps on a side stream, then the capture on the same stream.  with_hooks: the reducer's autograd hooks stay
+        armed, so every bucket's gather + all-reduce is captured where its last gradient appears."""
         net, reducer = self.net, self.reducer
         s_ = torch.cuda.Stream()
         s_.wait_stream(torch.cuda.current_stream())
@@ -469,7 +468,11 @@ class TrainRun:
         net.zero_grad(set_to_none=True)
         g = torch.cuda.CUDAGraph()
         # thread-local capture mode: the RCCL watchdog thread's event queries (N > 1) must not invalidate the capture
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        # The capture runs on the warm-up's stream: the reducer's hooks keep the AccumulateGrad nodes of the warm-up steps alive, and autograd
+        # runs such a node (and its post-accumulate hook, i.e. the bucket's gather + all-reduce) on the stream it was created on.  On
+        # another stream the exchange would be a fork/join of the graph, and a hipGraph with any fork replays every node slower
+        # (tools/graph_branch_probe.py; the training step: +1.0 ms for two 4-element kernels launched from the hooks).
+        with torch.cuda.graph(g, stream=s_, capture_error_mode="thread_local"):
             sl = self.fwd_bwd()
             if reducer is not None and with_hooks:
                 reducer.join_capture()

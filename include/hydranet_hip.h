@@ -86,6 +86,18 @@ int hn_conv_gemm_nt_ex(const void* x0, const void* x1, int mode, int n_img, int 
                        const void* w, int Nout, int KP, int taps, const float* bias, int act, void* out, int out_f32, int ldc, long rpi,
                        long img_stride, float* psum, float* psq, const float* xscale, const float* xshift, const float* xgate, long xhw,
                        int xact, const void* addend, int ld_add, int add_mode, hipStream_t stream);
+/* hn_conv_gemm_nt_ex (no operand transform) whose statistics rows carry a backward reduction over (output, ez) instead of the output's
+ * BatchNorm statistics, so that the reduce pass that would follow the launch is not needed (net/anynet.py:50-78 XBlock backward):
+ *   emode 1: psum[tile][c] = sum_rows q * bf16(relu(ecoef[0][c] * ez + ecoef[1][c]))   the SE gate-gradient partials of dbg = dz3 W3
+ *            (what hn_se_bwd_reduce_fused computes; psq may be NULL);
+ *   emode 2: g = q * [ecoef[0][c] * ez + ecoef[1][c] > 0];  psum = sum g,  psq = sum g * (ez - ecoef[2][c]) * ecoef[3][c]
+ *            (the partial sums of hn_bn_bwd_reduce_fused with ReLU; modes 0/1: one row per pixel tile, hn_nt_stat_rows; mode 5: one row
+ *            per 16x16 patch, hn_direct_stat_rows), consumed by hn_bn_bwd_apply_fused.
+ * q = the bf16-rounded output; ez = bf16 [M][ld_ez] on the output's pixel rows; ecoef = fp32 [4][Nout]; bf16 output, no activation. */
+int hn_conv_gemm_nt_stat(const void* x0, const void* x1, int mode, int n_img, int H, int W, int C0, int C1, int ld0, int ld1, int up, long M,
+                         const void* w, int Nout, int KP, int taps, const float* bias, int act, void* out, int out_f32, int ldc, long rpi,
+                         long img_stride, float* psum, float* psq, const void* addend, int ld_add, int add_mode, int emode, const void* ez,
+                         int ld_ez, const float* ecoef, hipStream_t stream);
 /* tuning hook for tools/: force the cout tile (16/32/64/128) and LDS ring depth (2..4) of later hn_conv_gemm_nt launches; 0 = automatic */
 int hn_debug_nt_config(int bc, int r);
 /* tools/ A/B hook: 1 = software-pipelined direct 3x3 kernel (one workgroup per CU, weight ring of 3 + 2 patch buffers), 0 (default, faster

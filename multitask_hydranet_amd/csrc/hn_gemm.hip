@@ -150,7 +150,46 @@ struct GemmNT {
     int fold;
     bf16* ring;
     const bf16* fold_y; int ld_fy;
+    // Statistics epilogue operand (psum / psq rows): what is summed per channel over the tile's pixels, q = the bf16-rounded output
+    //   emode 0: s1 = sum q, s2 = sum q^2                                                  (BatchNorm forward statistics)
+    //   emode 1: s1 = sum q * bf16(relu(sc z + sh))                                        (SE gate-gradient partials of the XBlock's
+    //            dbg = dz3 W3 GEMM: the pass hn_se_bwd_reduce_fused made over (dbg, z2); psq is not written)
+    //   emode 2: g = q [sc z + sh > 0]; s1 = sum g, s2 = sum g (z - mu) rs               (BatchNorm-backward partial sums of a data-gradient
+    //            producer: the reduce pass of hn_bn_bwd_fused over (da, z1))
+    // ez: the forward pre-BatchNorm tensor at the output's rows / channels (row stride ld_ez); ecoef: [4][Nout] = sc, sh, mu, rs
+    int emode; const bf16* ez; int ld_ez; const float* ecoef;
 };
+
+// one pixel x 4 consecutive channels of the statistics epilogue (GemmNT::emode); cf = (sc, sh, mu, rs) of the 4 channels
+struct StatCoef { f32x4 sc, sh, mu, rs; };
+__device__ __forceinline__ StatCoef stat_coef(const float* ecoef, int Nout, int emode, int co0, bool ev) {
+    StatCoef c;
+    c.sc = c.sh = c.mu = c.rs = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (ev) {
+        c.sc = *reinterpret_cast<const f32x4*>(ecoef + co0);
+        c.sh = *reinterpret_cast<const f32x4*>(ecoef + Nout + co0);
+        if (emode == 2) {
+            c.mu = *reinterpret_cast<const f32x4*>(ecoef + 2 * Nout + co0);
+            c.rs = *reinterpret_cast<const f32x4*>(ecoef + 3 * Nout + co0);
+        }
+    }
+    return c;
+}
+// (branch-free: the three forms differ by selects, the accumulators stay in registers)
+__device__ __forceinline__ void stat_terms4(int emode, const f32x4 q, const f32x4 z, const StatCoef& cf, float& a0, float& a1, float& a2, float& a3,
+                                            float& b0, float& b1, float& b2, float& b3) {
+    float t1[4], t2[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float pre = cf.sc[r] * z[r] + cf.sh[r];
+        const float b = bfround(pre > 0.f ? pre : 0.f);
+        const float g = pre > 0.f ? q[r] : 0.f;
+        t1[r] = emode == 0 ? q[r] : (emode == 1 ? q[r] * b : g);
+        t2[r] = emode == 0 ? q[r] * q[r] : g * (z[r] - cf.mu[r]) * cf.rs[r];
+    }
+    a0 += t1[0]; a1 += t1[1]; a2 += t1[2]; a3 += t1[3];
+    b0 += t2[0]; b1 += t2[1]; b2 += t2[2]; b3 += t2[3];
+}
 
 // KG = 2: 512 threads = two independent 4-wave groups that walk alternate K stages (their own LDS stages, common barriers) and meet in LDS
 // before the epilogue: half the barrier-separated K steps per workgroup for the small-M GEMMs of the deep stages, whose 15-step K loop is
@@ -448,16 +487,24 @@ __global__ __launch_bounds__(256 * KG) void gemm_nt_kernel(const GemmNT p) {
         for (int i = 0; i < TC; ++i) {
             const int co0 = c_blk + wc * WC + i * 16 + (lane >> 4) * 4;
             float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+            const bool ev = p.emode && co0 + 3 < p.Nout;
+            const StatCoef cf = stat_coef(p.ecoef, p.Nout, p.emode, co0, ev);
 #pragma unroll
             for (int j = 0; j < TP; ++j) {
-                const bool pv = p_blk + wp * WP + j * 16 + (lane & 15) < p.x.M;
+                const long pix = p_blk + wp * WP + j * 16 + (lane & 15);
+                const bool pv = pix < p.x.M;
+                f32x4 q, z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float q = OUT_F32 ? vv[(i * TP + j) * 4 + r] : bfround(vv[(i * TP + j) * 4 + r]);
-                    q = pv ? q : 0.f;
-                    s1[r] += q;
-                    s2[r] += q * q;
+                    q[r] = OUT_F32 ? vv[(i * TP + j) * 4 + r] : bfround(vv[(i * TP + j) * 4 + r]);
+                    q[r] = pv ? q[r] : 0.f;
                 }
+                if (ev && pv) {
+                    const bf16x4 zv = *reinterpret_cast<const bf16x4*>(p.ez + pix * p.ld_ez + co0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) z[r] = bf2f(zv[r]);
+                }
+                stat_terms4(p.emode, q, z, cf, s1[0], s1[1], s1[2], s1[3], s2[0], s2[1], s2[2], s2[3]);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -476,7 +523,7 @@ __global__ __launch_bounds__(256 * KG) void gemm_nt_kernel(const GemmNT p) {
 #pragma unroll
             for (int k = 0; k < WGP; ++k) { t1 += red[(k * BC + tid) * 2]; t2 += red[(k * BC + tid) * 2 + 1]; }
             p.psum[(long)p_tile * p.Nout + c_blk + tid] = t1;
-            p.psq[(long)p_tile * p.Nout + c_blk + tid] = t2;
+            if (p.psq) p.psq[(long)p_tile * p.Nout + c_blk + tid] = t2;
         }
         __syncthreads();                                              // before the staged epilogue reuses the same LDS
     }
@@ -801,25 +848,37 @@ __global__ __launch_bounds__(512, PIPE ? 2 : 4) void conv3x3_direct_kernel(const
 
     // optional BatchNorm partial statistics of the bf16-rounded outputs: one row per workgroup (patch), psum/psq [gridDim.x / ncy][Nout];
     // wave sums by DPP row rotations, the WGP pixel-row groups are folded through LDS (the operand buffers are free now)
-    if (p.psum) {
+    // (only the grouped convs -- block-diagonal 64-cout tiles -- are launched with statistics rows)
+    if (BC == 64 && p.psum) {
         __syncthreads();
         float* red = reinterpret_cast<float*>(smem);                  // [WGP][BC][2]
         const int oxs = ox0 + (lane & 15);
 #pragma unroll
         for (int i = 0; i < TC; ++i) {
             const int cl = wc * WCO + i * 16 + (lane >> 4) * 4;
+            const int co0 = c_blk + cl;
             float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+            f32x4 bsr;
+            const bool ev = p.emode && co0 + 3 < p.Nout;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bsr[r] = (p.bias && co0 + r < p.Nout) ? p.bias[co0 + r] : 0.f;
+            const StatCoef cf = stat_coef(p.ecoef, p.Nout, p.emode, co0, ev);
 #pragma unroll
             for (int j = 0; j < TP; ++j) {
-                const bool pv = (oy0 + wp * ROWS + j) < xs.H && oxs < xs.W;
+                const int oy = oy0 + wp * ROWS + j;
+                const bool pv = oy < xs.H && oxs < xs.W;
+                f32x4 q, z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float bsr = (p.bias && c_blk + cl + r < p.Nout) ? p.bias[c_blk + cl + r] : 0.f;
-                    float q = OUT_F32 ? acc[i][j][r] + bsr : bfround(acc[i][j][r] + bsr);
-                    q = pv ? q : 0.f;
-                    s1[r] += q;
-                    s2[r] += q * q;
+                    q[r] = OUT_F32 ? acc[i][j][r] + bsr[r] : bfround(acc[i][j][r] + bsr[r]);
+                    q[r] = pv ? q[r] : 0.f;
                 }
+                if (ev && pv) {
+                    const bf16x4 zv = *reinterpret_cast<const bf16x4*>(p.ez + ((long)(n * xs.H + oy) * xs.W + oxs) * p.ld_ez + co0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) z[r] = bf2f(zv[r]);
+                }
+                stat_terms4(p.emode, q, z, cf, s1[0], s1[1], s1[2], s1[3], s2[0], s2[1], s2[2], s2[3]);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) { s1[r] = row16_sum(s1[r]); s2[r] = row16_sum(s2[r]); }
@@ -835,7 +894,7 @@ __global__ __launch_bounds__(512, PIPE ? 2 : 4) void conv3x3_direct_kernel(const
             for (int k = 0; k < WGP; ++k) { t1 += red[(k * BC + tid) * 2]; t2 += red[(k * BC + tid) * 2 + 1]; }
             const long prow = lid / ncy;
             p.psum[prow * p.Nout + c_blk + tid] = t1;
-            p.psq[prow * p.Nout + c_blk + tid] = t2;
+            if (p.psq) p.psq[prow * p.Nout + c_blk + tid] = t2;
         }
     }
 
@@ -2150,6 +2209,8 @@ extern "C" int hn_nt_stat_rows(long M, int Nout) {               // one partial 
     return small_tile(M, Nout) ? cdiv(M, 64) : cdiv(M, 128);
 }
 
+struct NextStat { int mode; const bf16* z; int ldz; const float* coef; };
+static thread_local NextStat g_next_stat = {0, nullptr, 0, nullptr};   // set by hn_conv_gemm_nt_stat for the launch it makes
 struct NextFold { bf16* ring; const bf16* y; int ldy; };
 static thread_local NextFold g_next_fold = {nullptr, nullptr, 0};   // set by hn_conv3x3_dgrad_fold for the launch it makes
 static thread_local long* g_next_amax = nullptr;    // set by hn_conv3x3_out_argmax for the launch it makes (same thread, same call)
@@ -2173,6 +2234,23 @@ extern "C" int hn_conv_gemm_nt_ex(const void* x0, const void* x1, int mode, int 
                                   int add_mode, hipStream_t st) {
     return conv_gemm_nt_impl(x0, x1, mode, n_img, H, W, C0, C1, ld0, ld1, up, M, w, Nout, KP, taps, bias, act, out, out_f32, ldc, rpi,
                              img_stride, psum, psq, xscale, xshift, xgate, xhw, xact, addend, ld_add, add_mode, 0, 0, st);
+}
+
+/* hn_conv_gemm_nt_ex with a statistics-epilogue operand (GemmNT::emode): the partial rows psum / psq carry, instead of the BatchNorm
+ * forward statistics of the output, emode 1: the SE gate-gradient partials sum q * relu(bn(ez)) (psq may be null), or emode 2: the
+ * BatchNorm-backward partial sums (sum g, sum g * xhat) with g = q * [bn(ez) > 0] -- the reduce pass over (output, ez) that would
+ * otherwise follow the launch.  ez: bf16 [M][ld_ez] on the output's pixel rows, ecoef = [4][Nout] (scale, shift, mean, rstd). */
+extern "C" int hn_conv_gemm_nt_stat(const void* x0, const void* x1, int mode, int n_img, int H, int W, int C0, int C1, int ld0, int ld1,
+                                    int up, long M, const void* w, int Nout, int KP, int taps, const float* bias, int act, void* out,
+                                    int out_f32, int ldc, long rpi, long img_stride, float* psum, float* psq, const void* addend, int ld_add,
+                                    int add_mode, int emode, const void* ez, int ld_ez, const float* ecoef, hipStream_t st) {
+    HN_CHECK_ARG((emode == 1 || emode == 2) && psum && (psq || emode == 1) && ez && ecoef && (Nout & 7) == 0 && (ld_ez & 3) == 0 && !out_f32 &&
+                 act == HN_ACT_NONE && (mode <= 1 || mode == 5) && (reinterpret_cast<uintptr_t>(ez) & 7) == 0);
+    g_next_stat = {emode, (const bf16*)ez, ld_ez, ecoef};
+    const int rc = conv_gemm_nt_impl(x0, x1, mode, n_img, H, W, C0, C1, ld0, ld1, up, M, w, Nout, KP, taps, bias, act, out, out_f32, ldc, rpi,
+                                     img_stride, psum, psq, nullptr, nullptr, nullptr, 0, 0, addend, ld_add, add_mode, 0, 0, st);
+    g_next_stat = {0, nullptr, 0, nullptr};
+    return rc;
 }
 
 /* Phase form of Conv3x3(ReflectionPad2d(1)(nearest_up2(x0))) on the low-resolution grid (head_seg/segmentation.py:92-104 decoder blocks
@@ -2242,6 +2320,7 @@ static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img
     p.phase_mode = phase_mode; p.phase_span = phase_span;
     p.amax = g_next_amax;
     g_next_amax = nullptr;
+    p.emode = g_next_stat.mode; p.ez = g_next_stat.z; p.ld_ez = g_next_stat.ldz; p.ecoef = g_next_stat.coef;
     p.fold = g_next_fold.ring ? 1 : 0; p.ring = g_next_fold.ring; p.fold_y = g_next_fold.y; p.ld_fy = g_next_fold.ldy;
     if (img_stride < 0) {                                            // mode 4: -img_stride = channels per depth-to-space output pixel
         HN_CHECK_ARG(p.x.clamp == 1 && (out_f32 || phase_mode == 1) && rpi == 0 && !psum && Nout == 4 * (int)(-img_stride));

@@ -10,16 +10,26 @@ Replaces the reference's single-rank torch DistributedDataParallel(find_unused_p
     broadcast at construction.
 Three ways to run a step:
   1. eager: hooks fire during loss.backward(); finish() joins.                              (overlapped, one launch per kernel)
-  2. captured: the SAME hooks fire while the step is being captured into a hipGraph (torch.cuda.graph); each completed bucket forks the
-     side stream off the capture stream with an event, the bucket's gather + all-reduce are captured there, join_capture() joins the side
-     stream back before the capture ends.  A replay then runs backward and the bucket all-reduces CONCURRENTLY, in reverse execution
-     order -- the overlap of mode 1 without per-step host work.  adopt_bucket_grads() then points .grad at the averaged buckets.
+  2. captured: the SAME hooks fire while the step is being captured into a hipGraph (torch.cuda.graph).  By default each completed
+     bucket's gather + all-reduce are captured IN LINE on the capture stream (a synchronous torch.distributed collective is enqueued on
+     the current stream), so the graph stays one linear chain: on this runtime a hipGraph with ANY fork/join replays every node ~1.3 us
+     slower (tools/graph_branch_probe.py: 1200 dependent tiny kernels 1.9 ms linear, 3.4 ms with one fork; the training step: +1.1 ms =
+     5 %), more than the exposed all-reduce time it would hide.  The capture must run on the stream the warm-up steps ran on
+     (torch.cuda.graph(g, stream=warmup_stream)): the hooks keep the warm-up's AccumulateGrad nodes alive and autograd runs them -- and
+     therefore the exchange -- on the stream they were created on; on another stream the exchange becomes a fork of the graph anyway
+     (measured: two 4-element kernels launched from the hooks on the wrong stream cost 0.85 ms per step).  World size 1, big cfg, batch
+     16: 20.70 ms without the exchange, 21.01 ms with it (+1.5 %: RCCL's one-rank pre-multiplied-sum kernel over the 171 MB payload,
+     0.25 ms, and a 15 us gather of the 15 % of the elements that the backward kernels do not write into the buckets themselves).
+     graph_overlap=True (HN_DDP_GRAPH_OVERLAP=1) keeps the forked form: each completed bucket forks the side stream off the capture
+     stream with an event, join_capture() joins it back, a replay runs backward and the all-reduces concurrently.
+     adopt_bucket_grads() then points .grad at the averaged buckets.
   3. reduce_now(): non-overlapped exchange after a replay of a graph that holds no collectives (fallback if RCCL capture is unavailable).
 xGMI note: 8 MI355X are fully meshed with point-to-point links, so a ring all-reduce is per-link bound; a few large buckets keep every
 link busy while the backbone's backward (the longest part) is still running.
 """
 from __future__ import annotations
 
+import os
 from typing import Iterable, List, Optional, Sequence
 
 import torch
@@ -45,9 +55,13 @@ def _agree_on_avg(group, device) -> bool:
 class GradReducer:
     def __init__(self, named_params: Sequence, world_size: Optional[int] = None, bucket_bytes: int = 25 << 20,
                  skip: Iterable[str] = (), group=None, use_side_stream: Optional[bool] = None, payload_dtype: torch.dtype = torch.float32,
-                 force_collectives: bool = False):
+                 force_collectives: bool = False, graph_overlap: Optional[bool] = None):
         """force_collectives: issue the collectives even at world size 1 (exercises RCCL init, ncclAvg and the side-stream / capture path on
-        a single GPU)."""
+        a single GPU).  graph_overlap: inside a hipGraph capture, fork the exchange onto the side stream (True) or keep it in line on the
+        capture stream (False, default: a linear graph replays faster than a forked one by more than the overlap hides)."""
+        if graph_overlap is None:
+            graph_overlap = os.environ.get("HN_DDP_GRAPH_OVERLAP", "0") == "1"
+        self.graph_overlap = bool(graph_overlap)
         self.group = group
         self.world = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.active = self.world > 1 or (force_collectives and dist.is_initialized())
@@ -75,6 +89,7 @@ class GradReducer:
         self._avg = bool(self.active and self.on_gpu and dist.is_initialized() and dist.get_backend(group) == "nccl" and
                          _agree_on_avg(group, dev))
         self.captured = False
+        self._pending_uploads = []              # gather tables filled during a capture, uploaded by adopt_bucket_grads()
         self._hooks = []
         self.arm()
 
@@ -95,7 +110,12 @@ class GradReducer:
             for _, p in plist:
                 land.append(lflat[off:off + p.numel()].view_as(p))
                 off += p.numel()
-        self.buckets.append(dict(params=plist, flat=flat, views=views, land=land, pending=len(plist), work=None, event=None, src=None, keep=None))
+        offs, off = [], 0
+        for _, p in plist:
+            offs.append(off)
+            off += p.numel()
+        self.buckets.append(dict(params=plist, flat=flat, views=views, land=land, pending=len(plist), work=None, event=None, src=None, keep=None,
+                                 offs=offs))
 
     def _make_hook(self, bi):
         def hook(param):
@@ -135,13 +155,13 @@ class GradReducer:
                 rows.append([s.data_ptr(), d.data_ptr(), d.numel(), blk])
                 owner += [i] * nb
                 blk += nb
-            # the pinned host tables are filled by the host; the uploads are stream operations -- inside a capture (the graph-private
-            # gradient tensors are only known then) two small memcpy nodes that every replay repeats from the same pinned memory
+            # Inside a capture (the graph-private gradient tensors are only known then) the table is filled on the host and uploaded ONCE, after
+            # the capture and before the first replay (adopt_bucket_grads): the captured gather only reads the device table.  (Uploads as
+            # memcpy nodes of the graph cost ~45 us each per replay: the copy engine's hand-offs stall the otherwise linear kernel chain.)
             if torch.cuda.is_current_stream_capturing():
                 plan["hrows"][:len(rows)] = torch.tensor(rows, dtype=torch.int64)
                 plan["howner"][:blk] = torch.tensor(owner, dtype=torch.int32)
-                plan["drows"].copy_(plan["hrows"], non_blocking=True)
-                plan["downer"].copy_(plan["howner"], non_blocking=True)
+                self._pending_uploads.append(plan)
             else:                                           # eager: blocking uploads (the pinned tables may still feed an earlier copy)
                 plan["drows"][:len(rows)].copy_(torch.tensor(rows, dtype=torch.int64))
                 plan["downer"][:blk].copy_(torch.tensor(owner, dtype=torch.int32))
@@ -153,6 +173,7 @@ class GradReducer:
         """bring the bucket's gradients into its flat payload buffer (one multi-tensor launch; converts when the payload is bf16)"""
         src = b["src"] if b["src"] is not None else [p.grad for _, p in b["params"]]
         need = [(v, s) for v, s in zip(b["views"], src) if s.data_ptr() != v.data_ptr()]
+        b["direct_elems"] = b["flat"].numel() - sum(v.numel() for v, _ in need)     # produced in place by the HIP backward (ops.grad_out)
         if need:
             dsts, srcs = [v for v, _ in need], [s for _, s in need]
             same = all(d.dtype == s.dtype for d, s in need)
@@ -191,7 +212,16 @@ class GradReducer:
             # .grad to the bucket views, which would drop the last reference to them while the gather may still be queued behind the previous
             # bucket's all-reduce -- the caching allocator could hand their blocks to a later backward kernel.  Keep them until finish().
             b["keep"] = [p.grad for _, p in b["params"]]
-        if self.stream is not None:
+        if capturing and not self.graph_overlap:
+            # in line on the capture stream: gather, all-reduce (a synchronous collective runs on the current stream), landing copy
+            skip = os.environ.get("HN_DDP_DEBUG_SKIP", "")       # tools-only ablation of the captured exchange (never set in a real run)
+            if "gather" not in skip:
+                self._gather(b)
+            if "allreduce" not in skip:
+                self._allreduce_mean(b["flat"])
+            if b["land"] is not None:
+                self._copy_many(b, "plan_land", b["land"], b["views"], 2)
+        elif self.stream is not None:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self.stream.wait_event(ev)                          # fork: the side stream joins the capture through this dependency
@@ -242,7 +272,12 @@ class GradReducer:
         self.finish()
 
     def adopt_bucket_grads(self):
-        """after the capture: .grad of every exchanged parameter = the averaged values a replay leaves in the buckets"""
+        """after the capture and BEFORE the first replay: uploads the gather tables the capture filled, and points .grad of every exchanged
+        parameter at the averaged values a replay leaves in the buckets"""
+        for plan in self._pending_uploads:
+            plan["drows"].copy_(plan["hrows"])
+            plan["downer"].copy_(plan["howner"])
+        self._pending_uploads = []
         for b in self.buckets:
             if b["src"] is not None:
                 self._point(b)
@@ -275,20 +310,35 @@ class GradReducer:
             return
         for bi, b in enumerate(self.buckets):
             b["pending"], b["work"], b["event"], b["keep"] = len(b["params"]), None, None, None
-            for n, p in b["params"]:
+            for (n, p), off in zip(b["params"], b["offs"]):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
+                if self.active and self.payload_dtype == torch.float32:
+                    # the HIP backward writes this parameter's gradient straight into its bucket slot where it can (ops.grad_out):
+                    # the gather before the all-reduce then only moves what autograd produced elsewhere
+                    p._hn_grad_slot = (b["flat"], off)
 
     def remove(self):
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        for b in self.buckets:
+            for n, p in b["params"]:
+                if hasattr(p, "_hn_grad_slot"):
+                    del p._hn_grad_slot
+
+    def direct_fraction(self) -> float:
+        """share of the payload elements that the last step's backward wrote straight into the buckets (no gather copy)"""
+        tot = sum(b["flat"].numel() for b in self.buckets)
+        return sum(b.get("direct_elems", 0) for b in self.buckets) / max(tot, 1)
 
     def describe(self, after_replay: bool = False) -> str:
-        how = "captured inside the hipGraph on a side stream, overlapped with backward" if self.captured else \
+        how = ("captured inside the hipGraph on a side stream, overlapped with backward" if self.graph_overlap else
+               "captured in line inside the hipGraph (linear graph: no fork/join)") if self.captured else \
               ("after each hipGraph replay (reduce_now, not overlapped)" if after_replay else
                ("on a side stream from autograd hooks, overlapped with backward" if self.stream is not None else "after backward"))
-        return "%d buckets (%s payload, %s) %s" % (len(self.buckets), str(self.payload_dtype).replace("torch.", ""),
-                                                    "ncclAvg" if self._avg else "sum + scale", how)
+        return "%d buckets (%s payload, %s, %.0f%% of the elements written in place by the backward kernels) %s" % (
+            len(self.buckets), str(self.payload_dtype).replace("torch.", ""), "ncclAvg" if self._avg else "sum + scale",
+            100.0 * self.direct_fraction(), how)
 
 
 def broadcast_state(module: torch.nn.Module, src: int = 0, group=None):

@@ -295,8 +295,10 @@ def pack_dw_weight(w: torch.Tensor):
 # raw kernel wrappers (no autograd)
 # --------------------------------------------------------------------------------------------------------------
 def k_gemm_nt(x0, x1, mode, grid, wp, nout, kp, taps, bias=None, act=ACT_NONE, out=None, out_f32=False, up=0, stats=False,
-              c0=None, c1=None, rpi=0, img_stride=0, ldc=None, xform=None, addend=None, add_pre=False, add_s2=False):
+              c0=None, c1=None, rpi=0, img_stride=0, ldc=None, xform=None, addend=None, add_pre=False, add_s2=False, estat=None):
     """grid = (N, H, W) of the OUTPUT pixel grid.  Returns (out, psum, psq).
+    estat = (emode, ez, ecoef): the statistics rows carry the SE gate-gradient partials (emode 1; psq is None) or the BatchNorm-backward
+    partial sums (emode 2) of (output, ez) instead of the output's BatchNorm statistics (hn_conv_gemm_nt_stat).
     xform = (scale, shift, gate | None, rows_per_image, act): operand transform of hn_conv_gemm_nt_ex; addend: bf16 tensor added in the
     epilogue (same rows / channels as the output; add_s2: the addend lives on the stride-2 sub-grid and is added at even (y, x))."""
     n, h, w = grid
@@ -309,11 +311,17 @@ def k_gemm_nt(x0, x1, mode, grid, wp, nout, kp, taps, bias=None, act=ACT_NONE, o
     if ldc is None:
         ldc = out.stride(2) if out.dim() == 4 else nout
     psum = psq = None
-    if stats:
+    if stats or estat is not None:
         pr = lib().query("hn_direct_stat_rows", n, h, w) if mode == 5 else lib().query("hn_nt_stat_rows", m, nout)
         psum = torch.empty((pr, nout), device=dev, dtype=F32)
-        psq = torch.empty((pr, nout), device=dev, dtype=F32)
-    if xform is None and addend is None:
+        psq = torch.empty((pr, nout), device=dev, dtype=F32) if (estat is None or estat[0] != 1) else None
+    if estat is not None:
+        assert xform is None and not add_pre
+        emode, ez, ecoef = estat
+        lib().call("hn_conv_gemm_nt_stat", ptr(x0), ptr(x1), mode, n, h, w, c0, c1, ld(x0), ld(x1) if x1 is not None else 0, up, m,
+                   ptr(wp), nout, kp, taps, ptr(bias), act, ptr(out), 0, ldc, rpi, img_stride, ptr(psum), ptr(psq), ptr(addend),
+                   ld(addend) if addend is not None else 0, 1 if add_s2 else 0, emode, ptr(ez), ld(ez), ptr(ecoef))
+    elif xform is None and addend is None:
         lib().call("hn_conv_gemm_nt", ptr(x0), ptr(x1), mode, n, h, w, c0, c1, ld(x0), ld(x1) if x1 is not None else 0, up, m,
                    ptr(wp), nout, kp, taps, ptr(bias), act, ptr(out), 1 if out_f32 else 0, ldc, rpi, img_stride, ptr(psum), ptr(psq))
     else:
@@ -401,6 +409,7 @@ class GradQueue:
         tail, self.tail = self.tail, []
         gconv, self.gconv = self.gconv, []
         out = {}
+        taken = set()               # parameters whose gradient went straight into their data-parallel bucket slot (grad_out)
 
         def put(wgt, g):
             out[id(wgt)] = g if id(wgt) not in out else out[id(wgt)] + g      # (a weight applied several times: per-level det towers)
@@ -409,7 +418,7 @@ class GradQueue:
             tab = (ctypes.c_long * (12 * len(chunk)))()
             dws = []
             for i, (wgt, x0, dz, mode, (n, h, w), cin, nout) in enumerate(chunk):
-                dw = torch.empty((nout, cin, 1, 1), device=dz.device, dtype=F32)
+                dw = grad_out(wgt, (nout, cin, 1, 1), dz.device, taken)
                 dws.append(dw)
                 ldz = dz.stride(2) if dz.dim() == 4 else dz.stride(0)
                 tab[12 * i:12 * i + 12] = [x0.data_ptr(), dz.data_ptr(), dw.data_ptr(), mode, n, h, w, cin, ld(x0), ldz, nout, n * h * w]
@@ -425,7 +434,7 @@ class GradQueue:
             tab = (ctypes.c_long * (9 * len(chunk)))()
             dws = []
             for i, (wgt, x, dz, (n, h, w), c) in enumerate(chunk):
-                dw = torch.empty((c, 8, 3, 3), device=dz.device, dtype=F32)
+                dw = grad_out(wgt, (c, 8, 3, 3), dz.device, taken)
                 dws.append(dw)
                 tab[9 * i:9 * i + 9] = [x.data_ptr(), dz.data_ptr(), dw.data_ptr(), n, h, w, c, ld(x), ld(dz)]
             wsb = lib().query("hn_gconv_wgrad_group_ws_bytes", ctypes.addressof(tab), len(chunk))
@@ -439,13 +448,30 @@ class GradQueue:
             chunk = tail[c0:c0 + self.MAX_TAIL]
             tab = (ctypes.c_long * (8 * len(chunk)))()
             for i, (wts, kind, a, b, n0, n1, n2, shapes) in enumerate(chunk):
-                outs = [torch.empty(shp, device=a.device, dtype=F32) for shp in shapes]
+                outs = [grad_out(wgt, shp, a.device, taken) for wgt, shp in zip(wts, shapes)]
                 tab[8 * i:8 * i + 8] = [kind, a.data_ptr(), b.data_ptr() if b is not None else 0, outs[0].data_ptr(),
                                         outs[1].data_ptr() if len(outs) > 1 else 0, n0, n1, n2]
                 for wgt, g in zip(wts, outs):
                     put(wgt, g)
             lib().call("hn_grad_tail", ctypes.addressof(tab), len(chunk))
         return [out.get(id(w)) for w in self.weights]
+
+
+def grad_out(wgt, shape, dev, taken):
+    """fp32 output tensor for a parameter's gradient.  When a data-parallel reducer registered the parameter's slot in its flat fp32 bucket
+    (ddp.GradReducer.arm: wgt._hn_grad_slot = (flat, offset)) and this is the parameter's first gradient of the step, a FRESH view of that
+    slot: autograd's AccumulateGrad adopts the tensor as .grad, so the bucket already holds the gradient when the exchange starts and the
+    gather copy skips it.  A new tensor otherwise."""
+    slot = getattr(wgt, "_hn_grad_slot", None)
+    if slot is not None and wgt.grad is None and id(wgt) not in taken:
+        flat, off = slot
+        n = 1
+        for d in shape:
+            n *= d
+        if flat.device == dev and flat.dtype == F32:
+            taken.add(id(wgt))
+            return flat[off:off + n].view(shape)
+    return torch.empty(shape, device=dev, dtype=F32)
 
 
 WgradGroup = GradQueue
@@ -649,18 +675,23 @@ def k_bn_apply_fused(z, psum, psq, count, gamma, beta, eps, momentum, rm, rv, ac
     return out, coef, pool, rb
 
 
-def bn_backward_fused(dout, z, y, coef, act, count, want_g=False, gate=None, dpool=None, hw=0, zero_c=None):
+def bn_backward_fused(dout, z, y, coef, act, count, want_g=False, gate=None, dpool=None, hw=0, zero_c=None, parts=None):
     """BatchNorm(+activation) backward in two launches (reduce, apply with the finalize in its prologue): (dz, dgamma, dbeta, g|None).
-    The two passes use their own row blocks: the reduce pass's block count is the number of partial rows the apply prologue folds."""
+    The two passes use their own row blocks: the reduce pass's block count is the number of partial rows the apply prologue folds.
+    parts = (pg, pgx): the partial sums already exist (the producer of dout made them in its epilogue, k_gemm_nt(estat=(2, ...))): one launch."""
     n, h, w, c = z.shape
     m = rows(z)
     dev = z.device
-    rb_r = lib().query("hn_fused_row_block", m, c, hw, 0, 1)
-    pr = (m + rb_r - 1) // rb_r
-    pg = torch.empty((pr, c), device=dev, dtype=F32)
-    pgx = torch.empty((pr, c), device=dev, dtype=F32)
-    lib().call("hn_bn_bwd_reduce_fused", ptr(dout), ld(dout), ptr(z), ld(z), ptr(y), ld(y) if y is not None else 0, ptr(coef), act,
-               ptr(gate), ptr(dpool), hw, m, c, rb_r, ptr(pg), ptr(pgx))
+    if parts is not None:
+        pg, pgx = parts
+        pr = pg.shape[0]
+    else:
+        rb_r = lib().query("hn_fused_row_block", m, c, hw, 0, 1)
+        pr = (m + rb_r - 1) // rb_r
+        pg = torch.empty((pr, c), device=dev, dtype=F32)
+        pgx = torch.empty((pr, c), device=dev, dtype=F32)
+        lib().call("hn_bn_bwd_reduce_fused", ptr(dout), ld(dout), ptr(z), ld(z), ptr(y), ld(y) if y is not None else 0, ptr(coef), act,
+                   ptr(gate), ptr(dpool), hw, m, c, rb_r, ptr(pg), ptr(pgx))
     if pr > MAX_PROLOGUE_ROWS:
         pg, pgx = fold_rows(pg, pgx, limit=MAX_PROLOGUE_ROWS)
         pr = pg.shape[0]
@@ -847,6 +878,7 @@ def conv_bn_act(x, weight, conv_bias, bn, res=None, kind="1x1", stride=1, act=AC
 # dgrad epilogue).  The unfused composition of ConvBnAct / SEGate nodes is ~16 + ~27 launches per block.
 # --------------------------------------------------------------------------------------------------------------
 FUSED_XBLOCK = os.environ.get("HN_FUSED_XBLOCK", "1") != "0"
+EPILOGUE_STATS = os.environ.get("HN_EPILOGUE_STATS", "1") != "0"   # backward reduce passes folded into their producers' epilogues
 XBLOCK_XF_GEMM = os.environ.get("HN_XBLOCK_XF", "0") == "1"
 
 
@@ -921,20 +953,26 @@ class XBlockFn(torch.autograd.Function):
         grid = (n, ho, wo)
         # out = relu(bn3(z3) + shortcut): g = dout * [out > 0] is also the gradient of the shortcut branch
         dz3, dg3, db3, g = bn_backward_fused(dout, z3, out, coef3, ACT_RELU, m, want_g=True)
-        dbg, _, _ = k_gemm_nt(dz3, None, 0, grid, wt3, c, kp32(c), 1)
+        make_bg = bg is None
+        # SE gate-gradient partials sum_rows dbg * relu(bn2(z2)) from the GEMM's own epilogue (one partial row per pixel tile) where a
+        # tile lies inside one image and an image has few tiles (the deep stages); otherwise by a pass over (dbg, z2) below
+        bp = m // lib().query("hn_nt_stat_rows", m, c)
+        ep_dot = EPILOGUE_STATS and not make_bg and hw % bp == 0 and hw // bp <= 16
+        dbg, pdot, _ = k_gemm_nt(dz3, None, 0, grid, wt3, c, kp32(c), 1, estat=(1, z2, coef2) if ep_dot else None)
         group = ctx.group                                     # WgradGroup: the 1x1 weight gradients wait for the stage boundary
         w1_, w3_, ws_, w2_, sw1_, sb1_, sw2_, sb2_ = ctx.wrefs
         batch = WgradBatch()                                  # the slab reduces of dw3 / dw2 / dw1 / dws: one launch at the end
-        make_bg = bg is None
         if not make_bg:                                       # dz3's second reader right behind the first: still in the XCDs' L2s
             dw3 = group.add(w3_, bg, dz3, 0, grid, c, c) if group is not None else k_gemm_tn(bg, None, 0, grid, dz3, c, kp32(c), 1, c, defer=batch)
         # one pass over (dbg, z2): gate-gradient partials and the gated operand bg = relu(bn2(z2)) * gate of conv_block_3's wgrad
-        rb = lib().query("hn_fused_row_block", m, c, hw, 0, 1)
-        if make_bg:
-            bg = new_act(n, ho, wo, c, dev)
-        pdot = torch.empty(((m + rb - 1) // rb, c), device=dev, dtype=F32)
-        lib().call("hn_se_bwd_reduce_fused", ptr(dbg), ld(dbg), ptr(z2), ld(z2), ptr(coef2), ptr(gate), hw, ptr(bg) if make_bg else None,
-                   ld(bg), ptr(pdot), m, c, rb)
+        rb = bp
+        if not ep_dot:
+            rb = lib().query("hn_fused_row_block", m, c, hw, 0, 1)
+            if make_bg:
+                bg = new_act(n, ho, wo, c, dev)
+            pdot = torch.empty(((m + rb - 1) // rb, c), device=dev, dtype=F32)
+            lib().call("hn_se_bwd_reduce_fused", ptr(dbg), ld(dbg), ptr(z2), ld(z2), ptr(coef2), ptr(gate), hw, ptr(bg) if make_bg else None,
+                       ld(bg), ptr(pdot), m, c, rb)
         if make_bg:
             dw3 = group.add(w3_, bg, dz3, 0, grid, c, c) if group is not None else k_gemm_tn(bg, None, 0, grid, dz3, c, kp32(c), 1, c, defer=batch)
         dpre2 = torch.empty((n, c), device=dev, dtype=F32)
@@ -951,8 +989,14 @@ class XBlockFn(torch.autograd.Function):
                    ptr(dpool), ptr(dsw1), ptr(dsb1), ptr(dsw2), ptr(dsb2), n, c, cs)
         # BN2 backward with the SE data path folded in: g2 = (dbg * gate + dpool / HW) * [bn2(z2) > 0]
         dz2, dg2, db2, _ = bn_backward_fused(dbg, z2, None, coef2, ACT_RELU, m, gate=gate, dpool=dpool, hw=hw)
+        parts1 = None
         if stride == 1:
-            da, _, _ = k_gemm_nt(dz2, None, 5, grid, wd2, c, 64, 9)
+            # BatchNorm-1 backward partial sums (sum g, sum g * xhat over (da, z1)) from the data-gradient conv's epilogue: one row per
+            # 16 x 16 patch, folded by the apply pass's prologue
+            ep_bn = EPILOGUE_STATS and lib().query("hn_direct_stat_rows", n, ho, wo) <= MAX_PROLOGUE_ROWS
+            da, pg1, pgx1 = k_gemm_nt(dz2, None, 5, grid, wd2, c, 64, 9, estat=(2, z1, coef1) if ep_bn else None)
+            if ep_bn:
+                parts1 = (pg1, pgx1)
             if group is not None:
                 dw2 = group.add_gconv(w2_, a, dz2, grid, c)
             else:
@@ -967,7 +1011,7 @@ class XBlockFn(torch.autograd.Function):
                 dw2 = group.add_rows(w2_, part, chunks, c * 72, (c, 8, 3, 3))
             else:
                 dw2 = k_rows_reduce(part, 1, chunks, c * 72).view(c, 8, 3, 3)
-        dz1, dg1, db1, _ = bn_backward_fused(da, z1, None, coef1, ACT_RELU, m_in)
+        dz1, dg1, db1, _ = bn_backward_fused(da, z1, None, coef1, ACT_RELU, m_in, parts=parts1)
         dws = dgs = dbs = None
         addend, add_s2 = g, False                               # identity block: + gradient of the identity branch
         if zs is not None:

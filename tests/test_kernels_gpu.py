@@ -956,6 +956,85 @@ def test_backbone_stage_with_deferred_wgrad_equals_immediate(K):
         close(g1[k], g0[k], 1e-5, k)
 
 
+@pytest.mark.parametrize("n,h,w,c,mode", [(16, 8, 16, 936, 1), (4, 16, 32, 376, 1), (2, 32, 64, 152, 1), (2, 32, 64, 152, 2), (1, 64, 128, 64, 1),
+                                          (16, 8, 16, 936, 5), (4, 16, 32, 376, 5), (3, 20, 24, 64, 5), (2, 33, 47, 152, 5)])
+def test_backward_reductions_in_producer_epilogues(K, n, h, w, c, mode):
+    """hn_conv_gemm_nt_stat: the statistics rows of a data-gradient producer carry the reduce pass that used to follow it.
+    emode 1 (1x1 GEMM dbg = dz3 W3): sum over the rows of q * bf16(relu(sc z + sh)) == hn_se_bwd_reduce_fused's partials;
+    emode 2 (1x1 GEMM, or mode 5 = grouped 3x3 data gradient on the direct kernel): (sum g, sum g * xhat), g = q * [sc z + sh > 0]
+    == hn_bn_bwd_reduce_fused.  Checked against fp64 sums over the kernel's own bf16 output (1e-5 of the column's absolute sum) and the
+    output must be bit-identical to the launch without the epilogue operand."""
+    torch.manual_seed(n * 1000 + c)
+    m = n * h * w
+    z = nhwc(rnd(n, c, h, w))
+    coef = torch.stack([torch.rand(c, device=dev()) + 0.5, torch.randn(c, device=dev()) * 0.3, torch.randn(c, device=dev()) * 0.2,
+                        torch.rand(c, device=dev()) + 0.5]).contiguous()
+    dz = nhwc(rnd(n, c, h, w, scale=0.1))
+    if mode == 5:
+        wgt = rnd(c, 8, 3, 3, scale=0.2)
+        _, wd = K.pack_gconv_diag(wgt)
+        args = (dz, None, 5, (n, h, w), wd, c, 64, 9)
+        emode = 2
+    else:
+        wgt = rnd(c, c, 1, 1, scale=0.05)
+        _, wt = K.pack_conv_weight(wgt)
+        args = (dz, None, 0, (n, h, w), wt, c, K.kp32(c), 1)
+        emode = mode
+    plain, _, _ = K.k_gemm_nt(*args)
+    out, ps, pq = K.k_gemm_nt(*args, estat=(emode, z, coef))
+    assert torch.equal(out, plain)
+    q = out.double().view(m, c)
+    # the kernel's fp32 fused multiply-add decides the mask (one rounding)
+    pre32 = (coef[0].double() * z.double().view(m, c) + coef[1].double()).float()
+    if emode == 1:
+        b = torch.relu(pre32).bfloat16().double()
+        want1 = (q * b).sum(0)
+        scale1 = (q * b).abs().sum(0)
+        assert pq is None
+        close_cols = [(ps.double().sum(0), want1, scale1)]
+    else:
+        g = torch.where(pre32 > 0, q, torch.zeros_like(q))
+        xh = ((z.float().view(m, c) - coef[2]) * coef[3]).double()
+        close_cols = [(ps.double().sum(0), g.sum(0), g.abs().sum(0)), (pq.double().sum(0), (g * xh).sum(0), (g * xh).abs().sum(0))]
+    for got, want, scale in close_cols:
+        assert float(((got - want).abs() / (scale + 1e-6)).max()) < 1e-5
+    # rows: one per pixel tile (tiles never straddle the launch's rows), so per-image sums can be taken from whole rows when hw % tile == 0
+    if mode != 5 and (h * w) % (m // ps.shape[0]) == 0:
+        per_img = ps.double().view(n, -1, c).sum(1)
+        want_img = ((q * b) if emode == 1 else g).view(n, h * w, c).sum(1)
+        assert float(((per_img - want_img).abs() / (want_img.abs() + 1e-3)).max()) < 1e-3
+
+
+def test_backbone_with_epilogue_reductions_equals_reduce_passes(K):
+    """the XBlock backward with ops.EPILOGUE_STATS (SE gate-gradient partials and BatchNorm-1 backward sums from the producers' epilogues)
+    vs the separate reduce passes: same forward, gradients equal up to the bf16 roundings a 1e-7 change of a channel mean can flip"""
+    from multitask_hydranet_amd import HydraNet
+    from tests.helpers import load_cfg
+    cfgs = load_cfg("hydranet_tiny.yml")
+    torch.manual_seed(5)
+    net = HydraNet(cfgs).cuda().train()
+    x = torch.randn(4, 3, 128, 256, device=dev())
+    res = []
+    for ep in (False, True):
+        K.EPILOGUE_STATS = ep
+        try:
+            net.zero_grad(set_to_none=True)
+            sd = {k: v.clone() for k, v in net.state_dict().items()}
+            feats = net._backbone(x)
+            net._flush_nbt()
+            loss = sum((f.float() ** 2).mean() for f in feats)
+            loss.backward()
+            res.append(([f.detach().clone() for f in feats], {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}))
+            net.load_state_dict(sd)
+        finally:
+            K.EPILOGUE_STATS = True
+    (f0, g0), (f1, g1) = res
+    assert all(torch.equal(a, b) for a, b in zip(f0, f1))
+    assert g0.keys() == g1.keys()
+    for k in g0:
+        close(g1[k], g0[k], 5e-3, k)
+
+
 @pytest.mark.parametrize("wd", [0.0, 1e-2])
 def test_hip_adam_tracks_torch_adam(K, wd):
     """multitask_hydranet_amd.optim.Adam (one launch for all parameters) against torch.optim.Adam: same update rule and operation order;

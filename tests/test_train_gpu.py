@@ -134,9 +134,13 @@ def test_rccl_gradient_exchange_world1_in_graph():
     plain, ddp, ddp16 = outs
     assert plain["config"]["grad_allreduce"] is None
     for o in (ddp, ddp16):
-        assert "captured inside the hipGraph" in o["config"]["grad_allreduce"], o["config"]["grad_allreduce"]
+        assert "inside the hipGraph" in o["config"]["grad_allreduce"], o["config"]["grad_allreduce"]
         assert o["config"]["hipgraph"] is True
         assert o["loss"] == plain["loss"]
+    # fp32 payload: the deferred weight gradients are written into the buckets by the backward kernels themselves (ops.grad_out), the
+    # gather only moves the rest (85 % in place at the bench's 512 x 1024; at this size the deep stages' XBlocks take the unfused path)
+    import re
+    assert int(re.search(r"(\d+)% of the elements written in place", ddp["config"]["grad_allreduce"]).group(1)) >= 5
     # the exchanged gradients: fp32 payload = the plain run's gradients exactly, bf16 payload = to bf16 rounding
     assert ddp["grad_norm"] == plain["grad_norm"], (ddp["grad_norm"], plain["grad_norm"])
     assert abs(ddp16["grad_norm"] - plain["grad_norm"]) <= 5e-3 * plain["grad_norm"]
@@ -288,6 +292,9 @@ def test_eager_hook_exchange_world1_keeps_first_step_gradients(setup):
             junk = [torch.full((1 << 18,), 7.0, device="cuda") for _ in range(8)]
             if red is not None:
                 red.finish()
+                # step 0 (.grad was None): the deferred HIP weight gradients were written straight into the bucket slots (ops.grad_out);
+                # step 1: autograd accumulates into the bucket views of step 0
+                assert red.direct_fraction() > 0.0, (step, red.direct_fraction())
             torch.cuda.synchronize()
             per_step.append({n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None})
             del junk
