@@ -863,6 +863,99 @@ __global__ __launch_bounds__(1024) void lane_cls_fwd_kernel(const float* logits,
         aux[0] = thr; aux[1] = posn; aux[2] = npos; aux[3] = nneg;
     }
 }
+// The same selection with every row held in registers (M <= 1024 * RPT): the seven passes of the kernel above each made a global-memory
+// round trip over the rows with one workgroup (58 us for 32 768 rows); here the rows are read once, the radix passes run on registers.
+template <int RPT>
+__global__ __launch_bounds__(1024) void lane_cls_fwd_reg_kernel(const float* logits, const float* target, long M, float neg_ratio, float alpha,
+                                                                float* lsm, unsigned char* pmask, float* out, float* aux) {
+    __shared__ unsigned int hist[256];
+    __shared__ float red[16];
+    __shared__ unsigned int s_prefix, s_k;
+    const int tid = threadIdx.x;
+    float bg[RPT], fg[RPT];
+    unsigned int pos = 0, valid = 0;                                  // bit j: row tid + 1024 j is a positive / exists
+    float npos = 0.f, nneg = 0.f;
+#pragma unroll
+    for (int j0 = 0; j0 < RPT; j0 += 8) {                              // eight rows' loads in flight at a time
+        float2 zz[8], tt[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const long i = tid + 1024L * (j0 + jj);
+            zz[jj] = make_float2(0.f, 0.f); tt[jj] = make_float2(0.f, 0.f);
+            if (i < M) {
+                zz[jj] = *reinterpret_cast<const float2*>(logits + 2 * i);
+                tt[jj] = *reinterpret_cast<const float2*>(target + 2 * i);
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int j = j0 + jj;
+            const long i = tid + 1024L * j;
+            const float z0 = zz[jj].x, z1 = zz[jj].y;
+            const float mx = fmaxf(z0, z1);
+            const float lse = mx + logf(expf(z0 - mx) + expf(z1 - mx));
+            bg[j] = z0 - lse;
+            fg[j] = z1 - lse;
+            if (i < M) {
+                const bool p = tt[jj].y > 0.f;
+                valid |= 1u << j;
+                pos |= p ? (1u << j) : 0u;
+                *reinterpret_cast<float2*>(lsm + 2 * i) = make_float2(bg[j], fg[j]);
+                pmask[i] = p ? 1 : 0;
+                npos += p ? 1.f : 0.f;
+                nneg += p ? 0.f : 1.f;
+            }
+        }
+    }
+    npos = block_sum_1024(npos, red);
+    nneg = block_sum_1024(nneg, red);
+    const float posn = fmaxf(npos, 1.f);
+    long kk = (long)fmaxf(fminf(npos * neg_ratio, nneg), 1.f);
+    float thr = __builtin_inff();
+    const unsigned int negs = valid & ~pos;
+    if (nneg >= 1.f) {
+        unsigned int prefix = 0, k = (unsigned int)kk;
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
+            const unsigned int himask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+#pragma unroll
+            for (int j = 0; j < RPT; ++j) {
+                if (!((negs >> j) & 1u)) continue;
+                const unsigned int key = f2ord(bg[j]);
+                if ((key & himask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                unsigned int acc = 0, b = 0;
+                for (; b < 256; ++b) {
+                    if (acc + hist[b] >= k) break;
+                    acc += hist[b];
+                }
+                s_prefix = prefix | (b << shift);
+                s_k = k - acc;
+            }
+            __syncthreads();
+            prefix = s_prefix;
+            k = s_k;
+        }
+        thr = ord2f(prefix);
+    }
+    float sp = 0.f, sn = 0.f;
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+        if ((pos >> j) & 1u) sp += fg[j];
+        else if (((negs >> j) & 1u) && bg[j] <= thr) sn += bg[j];
+    }
+    sp = block_sum_1024(sp, red);
+    sn = block_sum_1024(sn, red);
+    if (tid == 0) {
+        out[0] = -alpha * sp / posn;
+        out[1] = -alpha * sn / posn;
+        aux[0] = thr; aux[1] = posn; aux[2] = npos; aux[3] = nneg;
+    }
+}
 // dlogits = gpos * d(pos)/dz + gneg * d(neg)/dz
 __global__ void lane_cls_bwd_kernel(const float* lsm, const unsigned char* pmask, const float* aux, const float* gpos, const float* gneg,
                                     float alpha, long M, float* dlogits) {
@@ -939,7 +1032,13 @@ __global__ void lane_loc_bwd_kernel(const float* pred, const float* tgt, const u
 extern "C" int hn_lane_cls_loss_fwd(const float* logits, const float* target, long M, float neg_ratio, float alpha, float* lsm,
                                     void* pmask, float* out, float* aux, hipStream_t st) {
     HN_CHECK_ARG(logits && target && lsm && pmask && out && aux && M > 0 && M <= (1L << 22));
-    hipLaunchKernelGGL(lane_cls_fwd_kernel, dim3(1), dim3(1024), 0, st, logits, target, M, neg_ratio, alpha, lsm, (unsigned char*)pmask, out, aux);
+    const bool al8 = ((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(target) | reinterpret_cast<uintptr_t>(lsm)) & 7) == 0;
+    if (al8 && M <= 1024L * 8)
+        hipLaunchKernelGGL(lane_cls_fwd_reg_kernel<8>, dim3(1), dim3(1024), 0, st, logits, target, M, neg_ratio, alpha, lsm, (unsigned char*)pmask, out, aux);
+    else if (al8 && M <= 1024L * 32)
+        hipLaunchKernelGGL(lane_cls_fwd_reg_kernel<32>, dim3(1), dim3(1024), 0, st, logits, target, M, neg_ratio, alpha, lsm, (unsigned char*)pmask, out, aux);
+    else
+        hipLaunchKernelGGL(lane_cls_fwd_kernel, dim3(1), dim3(1024), 0, st, logits, target, M, neg_ratio, alpha, lsm, (unsigned char*)pmask, out, aux);
     HN_LAUNCH_CHECK();
 }
 extern "C" int hn_lane_cls_loss_bwd(const float* lsm, const void* pmask, const float* aux, const float* gpos, const float* gneg, float alpha,

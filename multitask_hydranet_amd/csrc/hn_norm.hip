@@ -1151,35 +1151,38 @@ struct TailJob { const float* a; const float* b; float* out; float* out2; int ki
 struct TailJobs { TailJob j[HN_TAIL_MAX]; int n; };
 
 __global__ __launch_bounds__(256) void grad_tail_kernel(const TailJobs jobs) {
-    __shared__ float red[8][33];
+    __shared__ float red[8][33];                                      // (kind 0 uses it flat: 256 floats)
     int ji = 0;
     for (int k = 1; k < jobs.n; ++k)
         if ((int)blockIdx.x >= jobs.j[k].first_block) ji = k;
     const TailJob& jb = jobs.j[ji];
     const int blk = (int)blockIdx.x - jb.first_block;
-    if (jb.kind == 0) {                                              // 32 columns x 8 row lanes, four independent loads per lane and round
-        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-        const int c = blk * 32 + tx, R = jb.n0, C = jb.n1;
+    if (jb.kind == 0) {                                              // cw columns x (256 / cw) row lanes, four independent loads per lane and round
+        // (cw = jb.n2 = 32 ... 4: tall folds -- the stride-2 grouped conv / stem partial rows, up to 4096 of them -- get more row lanes;
+        // with 32 columns x 8 lanes a 4096-row fold was 128 dependent load rounds, 65 us for 27 MB)
+        const int cw = jb.n2, nl = 256 / cw;
+        const int tx = threadIdx.x % cw, ty = threadIdx.x / cw;
+        const int c = blk * cw + tx, R = jb.n0, C = jb.n1;
+        float* redf = &red[0][0];
         float s = 0.f;
         if (c < C) {
             const float* src = jb.a + c;
             int r = ty;
             float s1 = 0.f, s2 = 0.f, s3 = 0.f;
-            for (; r + 24 < R; r += 32) {
+            for (; r + 3 * nl < R; r += 4 * nl) {
                 s += src[(long)r * C];
-                s1 += src[(long)(r + 8) * C];
-                s2 += src[(long)(r + 16) * C];
-                s3 += src[(long)(r + 24) * C];
+                s1 += src[(long)(r + nl) * C];
+                s2 += src[(long)(r + 2 * nl) * C];
+                s3 += src[(long)(r + 3 * nl) * C];
             }
-            for (; r < R; r += 8) s += src[(long)r * C];
+            for (; r < R; r += nl) s += src[(long)r * C];
             s = (s + s1) + (s2 + s3);
         }
-        red[ty][tx] = s;
+        redf[ty * cw + tx] = s;
         __syncthreads();
         if (ty == 0 && c < C) {
             float t = 0.f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) t += red[k][tx];
+            for (int k = 0; k < nl; ++k) t += redf[k * cw + tx];
             jb.out[c] = t;
         }
     } else if (jb.kind == 1) {
@@ -1250,7 +1253,12 @@ extern "C" int hn_grad_tail(const long* jobs, int njobs, hipStream_t st) {
         d.n0 = (int)jb[5]; d.n1 = (int)jb[6]; d.n2 = 0; d.f0 = 0.f;
         HN_CHECK_ARG(d.kind >= 0 && d.kind <= 2 && d.a && d.out && d.n0 > 0 && d.n1 > 0);
         d.first_block = (int)blocks;
-        if (d.kind == 0) blocks += cdiv(d.n1, 32);
+        if (d.kind == 0) {
+            int cw = 32;                                             // fewer columns per block = more row lanes for tall folds
+            while (cw > 4 && d.n0 > 16 * (256 / cw)) cw >>= 1;
+            d.n2 = cw;
+            blocks += cdiv(d.n1, cw);
+        }
         else if (d.kind == 1) {
             HN_CHECK_ARG(d.b && d.n1 <= 3);
             const unsigned bits = (unsigned)jb[7];
