@@ -106,20 +106,34 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* x, const b
 //   out[n, oy, ox, g*8 + o] = sum_{tap, i} in[n, oy*s + ky - 1, ox*s + kx - 1, g*8 + i] * wk[tap][i][g][o]
 // One thread = one group x a strip of 4 output pixels along x.
 // ---------------------------------------------------------------------------------------------------------
-template <int S>
-__global__ __launch_bounds__(256) void gconv_fwd_kernel(const bf16* in, int ldi, const bf16* wk, bf16* out, int ldo, int N, int Hi,
+// LDSW: the packed weights (G x 1152 B) are copied to LDS first and read from there: every thread reads 72 16-byte weight pieces against
+// 36 pixel pieces, and through the vector-memory path (64 B/clk per CU) those re-reads, not HBM, set the time; LDS serves them at 256 B/clk
+// (stage 0, 16 x 256 x 512 x 24: 71 -> 40 us cold).
+__device__ __forceinline__ const bf16* stage_gconv_weights(const bf16* wk, int G, bool ldsw) {
+    extern __shared__ __attribute__((aligned(16))) char gconv_smem[];
+    if (!ldsw) return wk;
+    const int pieces = 72 * G;                                 // 16-byte pieces
+    for (int i = threadIdx.x; i < pieces; i += 256) *reinterpret_cast<bf16x8*>(gconv_smem + i * 16) = ld8(wk + (long)i * 8);
+    __syncthreads();
+    return reinterpret_cast<const bf16*>(gconv_smem);
+}
+template <int S, bool LDSW = false>
+__global__ __launch_bounds__(256) void gconv_fwd_kernel(const bf16* in, int ldi, const bf16* wk_g, bf16* out, int ldo, int N, int Hi,
                                                         int Wi, int Ho, int Wo, int G) {
+    const bf16* wk = stage_gconv_weights(wk_g, G, LDSW);
     const int bidx = xcd_remap(blockIdx.x, gridDim.x);     // row-order placement convention (hn_common.h)
     const int strips = (Wo + 3) >> 2;
     const long total = (long)N * Ho * strips * G;
     const long idx = (long)bidx * 256 + threadIdx.x;
     if (idx >= total) return;
-    const int g = (int)(idx % G);
-    long t = idx / G;
-    const int sx = (int)(t % strips);
-    t /= strips;
-    const int oy = (int)(t % Ho);
-    const long n = t / Ho;
+    // (32-bit decomposition: the host checks total < 2^32)
+    const unsigned ui = (unsigned)idx;
+    const int g = (int)(ui % (unsigned)G);
+    unsigned t = ui / (unsigned)G;
+    const int sx = (int)(t % (unsigned)strips);
+    t /= (unsigned)strips;
+    const int oy = (int)(t % (unsigned)Ho);
+    const long n = t / (unsigned)Ho;
     const int ox0 = sx * 4;
     float acc[4][8];
 #pragma unroll
@@ -165,18 +179,21 @@ __global__ __launch_bounds__(256) void gconv_fwd_kernel(const bf16* in, int ldi,
 // Thread = one 2x2 quad of input pixels (2yh+py, 2xh+px) x one group: the four parity classes use 1 + 2 + 2 + 4 of the nine taps and all of
 // them read the same four dz pixels (yh..yh+1, xh..xh+1), so the quad costs exactly the nine tap products with no divergence (a thread
 // per input pixel runs all nine tap bodies under lane masks in a mixed-parity wave: measured 157 us at stage 0 against a 22 us HBM floor).
-__global__ __launch_bounds__(256) void gconv_dgrad_s2_kernel(const bf16* dz, int ldz, const bf16* wd, bf16* dx, int ldx, int N, int Hi,
+template <bool LDSW>
+__global__ __launch_bounds__(256) void gconv_dgrad_s2_kernel(const bf16* dz, int ldz, const bf16* wd_g, bf16* dx, int ldx, int N, int Hi,
                                                              int Wi, int Ho, int Wo, int G) {
+    const bf16* wd = stage_gconv_weights(wd_g, G, LDSW);
     const int bidx = xcd_remap(blockIdx.x, gridDim.x);     // row-order placement convention (hn_common.h)
     const long total = (long)N * Ho * Wo * G;
     const long idx = (long)bidx * 256 + threadIdx.x;
     if (idx >= total) return;
-    const int g = (int)(idx % G);
-    long t = idx / G;
-    const int xh = (int)(t % Wo);
-    t /= Wo;
-    const int yh = (int)(t % Ho);
-    const long n = t / Ho;
+    const unsigned ui = (unsigned)idx;                       // (the host checks total < 2^32)
+    const int g = (int)(ui % (unsigned)G);
+    unsigned t = ui / (unsigned)G;
+    const int xh = (int)(t % (unsigned)Wo);
+    t /= (unsigned)Wo;
+    const int yh = (int)(t % (unsigned)Ho);
+    const long n = t / (unsigned)Ho;
     bf16x8 zv[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -276,6 +293,88 @@ __global__ __launch_bounds__(256) void gconv_wgrad_kernel(const bf16* x, int ldx
     for (int o = 0; o < 8; ++o)
 #pragma unroll
         for (int i = 0; i < 8; ++i) dst[((long)(g * 8 + o) * 8 + i) * 9 + tap] = acc[o][i];
+}
+
+
+// The same partial sums with SUB = 8 sub-chunks per pixel chunk folded inside the workgroup: workgroup = (chunk, block of 32 items) x 8
+// sub-chunks, so the launch has 8x the threads for the same number of partial rows (the thread count above is tied to chunks x items, and
+// the partial rows [chunks][C * 72] are what the fold pass pays for: stage 0 ran as 432 workgroups, 1.7 per CU, 16 dependent load rounds
+// each).  The eight sub-chunk sums are added in fixed order through LDS: deterministic.
+__global__ __launch_bounds__(256) void gconv_wgrad_sub_kernel(const bf16* x, int ldx, const bf16* dz, int ldz, float* part, int N, int Hi,
+                                                              int Wi, int Ho, int Wo, int G, int S, long ppc, long nchunks) {
+    __shared__ float red[256][9];
+    const int bidx = xcd_remap(blockIdx.x, gridDim.x);
+    const int items = G * 9, iblocks = (items + 31) >> 5;
+    const long chunk = bidx / iblocks;
+    const int ib = bidx - (int)(chunk * iblocks);
+    const int il = threadIdx.x & 31, sub = threadIdx.x >> 5;
+    const int item = ib * 32 + il;
+    const bool live = item < items;
+    const int g = live ? item % G : 0, tap = live ? item / G : 0;
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const long total = (long)N * Ho * Wo;
+    const long c0 = chunk * ppc;
+    long c1 = c0 + ppc;
+    if (c1 > total) c1 = total;
+    const long q = (ppc + 7) >> 3;
+    const long p0 = c0 + sub * q;
+    long p1 = p0 + q;
+    if (p1 > c1) p1 = c1;
+    float acc[8][8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[o][i] = 0.f;
+    if (live && p0 < p1) {
+        // pixel coordinates by one 32-bit decomposition + increments (the 64-bit divisions of the kernel above cost more than the FMAs)
+        unsigned ox = (unsigned)p0 % (unsigned)Wo, t1 = (unsigned)p0 / (unsigned)Wo;
+        unsigned oy = t1 % (unsigned)Ho, n = t1 / (unsigned)Ho;
+        for (long pb = p0; pb < p1; pb += 4) {
+            bf16x8 zv[4], xv[4];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long pix = pb + u;
+                const int iy = (int)oy * S + ky - 1, ix = (int)ox * S + kx - 1;
+                ok[u] = pix < p1 && iy >= 0 && iy < Hi && ix >= 0 && ix < Wi;
+                if (ok[u]) {
+                    zv[u] = ld8(dz + pix * ldz + g * 8);
+                    xv[u] = ld8(x + (((long)n * Hi + iy) * (long)Wi + ix) * ldx + g * 8);
+                }
+                if (++ox == (unsigned)Wo) { ox = 0; if (++oy == (unsigned)Ho) { oy = 0; ++n; } }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (!ok[u]) continue;
+                float xf[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) xf[i] = bf2f(xv[u][i]);
+#pragma unroll
+                for (int o = 0; o < 8; ++o) {
+                    const float zf = bf2f(zv[u][o]);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[o][i] = fmaf(zf, xf[i], acc[o][i]);
+                }
+            }
+        }
+    }
+    float* dst = part + chunk * G * 576;
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) red[threadIdx.x][i] = acc[o][i];
+        __syncthreads();
+        if (sub == 0 && live) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float t = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) t += red[k * 32 + il][i];
+                dst[((long)(g * 8 + o) * 8 + i) * 9 + tap] = t;
+            }
+        }
+    }
 }
 
 // pack fp32 grouped weights [C][8][3][3] into wk[tap][i][G][o] (forward) and wd[tap'][o][G][i]:
@@ -1191,9 +1290,13 @@ extern "C" int hn_gconv_fwd(const void* in, int ldi, const void* wk, void* out, 
     HN_CHECK_ARG(in && wk && out && (C & 7) == 0 && ((ldi | ldo) & 7) == 0 && (stride == 1 || stride == 2));
     const int G = C >> 3, Ho = stride == 1 ? Hi : Hi >> 1, Wo = stride == 1 ? Wi : Wi >> 1;
     const long total = (long)N * Ho * ((Wo + 3) >> 2) * G;
+    HN_CHECK_ARG(total < (1L << 32));
     if (stride == 1)
         hipLaunchKernelGGL(gconv_fwd_kernel<1>, dim3(cdiv(total, 256)), dim3(256), 0, st, (const bf16*)in, ldi, (const bf16*)wk, (bf16*)out,
                            ldo, N, Hi, Wi, Ho, Wo, G);
+    else if (G * 1152 <= 24 * 1024)
+        hipLaunchKernelGGL((gconv_fwd_kernel<2, true>), dim3(cdiv(total, 256)), dim3(256), (size_t)G * 1152, st, (const bf16*)in, ldi,
+                           (const bf16*)wk, (bf16*)out, ldo, N, Hi, Wi, Ho, Wo, G);
     else
         hipLaunchKernelGGL(gconv_fwd_kernel<2>, dim3(cdiv(total, 256)), dim3(256), 0, st, (const bf16*)in, ldi, (const bf16*)wk, (bf16*)out,
                            ldo, N, Hi, Wi, Ho, Wo, G);
@@ -1204,8 +1307,13 @@ extern "C" int hn_gconv_dgrad_s2(const void* dz, int ldz, const void* wd, void* 
     const int G = C >> 3;
     HN_CHECK_ARG(!(Hi & 1) && !(Wi & 1));
     const long total = (long)N * (Hi >> 1) * (Wi >> 1) * G;       // one thread per 2x2 input quad and group
-    hipLaunchKernelGGL(gconv_dgrad_s2_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, (const bf16*)dz, ldz, (const bf16*)wd, (bf16*)dx, ldx,
-                       N, Hi, Wi, Hi >> 1, Wi >> 1, G);
+    HN_CHECK_ARG(total < (1L << 32));
+    if (G * 1152 <= 24 * 1024)
+        hipLaunchKernelGGL(gconv_dgrad_s2_kernel<true>, dim3(cdiv(total, 256)), dim3(256), (size_t)G * 1152, st, (const bf16*)dz, ldz,
+                           (const bf16*)wd, (bf16*)dx, ldx, N, Hi, Wi, Hi >> 1, Wi >> 1, G);
+    else
+        hipLaunchKernelGGL(gconv_dgrad_s2_kernel<false>, dim3(cdiv(total, 256)), dim3(256), 0, st, (const bf16*)dz, ldz, (const bf16*)wd,
+                           (bf16*)dx, ldx, N, Hi, Wi, Hi >> 1, Wi >> 1, G);
     HN_LAUNCH_CHECK();
 }
 extern "C" long hn_wgrad_chunks(long pixels, long items) {          // pixel chunks so that chunks*items ~ 256k threads
@@ -1224,8 +1332,12 @@ extern "C" int hn_gconv_wgrad(const void* x, int ldx, const void* dz, int ldz, f
     const long pixels = (long)N * Ho * Wo;
     const long chunks = hn_wgrad_chunks(pixels, G * 9);
     const long ppc = (pixels + chunks - 1) / chunks;
-    hipLaunchKernelGGL(gconv_wgrad_kernel, dim3(cdiv(chunks * G * 9, 256)), dim3(256), 0, st, (const bf16*)x, ldx, (const bf16*)dz, ldz, part,
-                       N, Hi, Wi, Ho, Wo, G, stride, ppc, chunks);
+    if (ppc >= 32 && pixels < (1L << 32))
+        hipLaunchKernelGGL(gconv_wgrad_sub_kernel, dim3((unsigned)(chunks * cdiv(G * 9, 32))), dim3(256), 0, st, (const bf16*)x, ldx,
+                           (const bf16*)dz, ldz, part, N, Hi, Wi, Ho, Wo, G, stride, ppc, chunks);
+    else
+        hipLaunchKernelGGL(gconv_wgrad_kernel, dim3(cdiv(chunks * G * 9, 256)), dim3(256), 0, st, (const bf16*)x, ldx, (const bf16*)dz, ldz,
+                           part, N, Hi, Wi, Ho, Wo, G, stride, ppc, chunks);
     HN_LAUNCH_CHECK();
 }
 
