@@ -361,6 +361,16 @@ def infer_bench(args, net, cfgs, h, w, dev, rank, world):
     emit(res)
 
 
+_CAPTURE_STREAM = None
+
+
+def capture_stream():
+    global _CAPTURE_STREAM
+    if _CAPTURE_STREAM is None:
+        _CAPTURE_STREAM = torch.cuda.Stream()
+    return _CAPTURE_STREAM
+
+
 def env_overrides():
     return {k: v for k, v in sorted(os.environ.items()) if k.startswith("HN_") or k == "HIPCC"}
 
@@ -453,7 +463,9 @@ class TrainRun:
         """two eager warm-up steps on a side stream, then the capture on the same stream.  with_hooks: the reducer's autograd hooks stay
         armed, so every bucket's gather + all-reduce is captured where its last gradient appears."""
         net, reducer = self.net, self.reducer
-        s_ = torch.cuda.Stream()
+        s_ = capture_stream()                   # one stream for every warm-up and capture of this process
+        if reducer is not None:
+            reducer.set_capture_stream(s_)
         s_.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s_):
             for _ in range(2):
@@ -476,7 +488,7 @@ class TrainRun:
             sl = self.fwd_bwd()
             if reducer is not None and with_hooks:
                 reducer.join_capture()
-        return g, sl
+        return g, sl.detach()                   # (the value lives in graph memory; its autograd graph would pin AccumulateGrad nodes)
 
     def step(self):
         if self.graph is not None:

@@ -2367,8 +2367,11 @@ static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img
         }
     }
     if (small_tile(M, Nout)) {
-        // 1x1 convs of the deep stages: two K groups per workgroup when the K loop is long enough to split (knob 6 = 0 turns it off)
-        if (mode <= 1 && taps == 1 && KP >= 256 && g_hn_knob[6] == 0 && !g_nt_force_r) return launch_nt_r<64, 64, 2, 2, 2, 2>(p, out_f32, st);
+        // 1x1 convs of the deep stages: two K groups per workgroup when the K loop is long enough to split
+        // (K >= 512 only: at stage 3 -- K = 376, 8192 rows -- the 768 two-group workgroups of 64 KB LDS do not fit the chip's 512 slots in
+        // one round, the 256-thread form's 768 do: 775 -> 781 img/s; knob 6 = 1 turns the form off, > 1 sets the threshold)
+        if (mode <= 1 && taps == 1 && KP >= (g_hn_knob[6] > 1 ? g_hn_knob[6] : 512) && g_hn_knob[6] != 1 && !g_nt_force_r)
+            return launch_nt_r<64, 64, 2, 2, 2, 2>(p, out_f32, st);
         return launch_nt<64, 64, 2, 2, 4>(p, out_f32, st);
     }
     switch (pick_bc(Nout)) {

@@ -29,6 +29,7 @@ link busy while the backbone's backward (the longest part) is still running.
 """
 from __future__ import annotations
 
+import contextlib
 import os
 from typing import Iterable, List, Optional, Sequence
 
@@ -89,6 +90,7 @@ class GradReducer:
         self._avg = bool(self.active and self.on_gpu and dist.is_initialized() and dist.get_backend(group) == "nccl" and
                          _agree_on_avg(group, dev))
         self.captured = False
+        self.capture_stream = None              # set_capture_stream(): where the in-line captured exchange is enqueued
         self._pending_uploads = []              # gather tables filled during a capture, uploaded by adopt_bucket_grads()
         self._hooks = []
         self.arm()
@@ -213,14 +215,19 @@ class GradReducer:
             # bucket's all-reduce -- the caching allocator could hand their blocks to a later backward kernel.  Keep them until finish().
             b["keep"] = [p.grad for _, p in b["params"]]
         if capturing and not self.graph_overlap:
-            # in line on the capture stream: gather, all-reduce (a synchronous collective runs on the current stream), landing copy
+            # in line on the capture stream: gather, all-reduce (a synchronous collective runs on the current stream), landing copy.
+            # The hook runs on the stream its AccumulateGrad node was created on; when that is not the capture stream (nodes kept alive
+            # from earlier steps on another stream) the exchange is enqueued on the capture stream explicitly -- the gradients were
+            # produced there, so no extra dependency is needed -- instead of becoming a fork of the graph.
             skip = os.environ.get("HN_DDP_DEBUG_SKIP", "")       # tools-only ablation of the captured exchange (never set in a real run)
-            if "gather" not in skip:
-                self._gather(b)
-            if "allreduce" not in skip:
-                self._allreduce_mean(b["flat"])
-            if b["land"] is not None:
-                self._copy_many(b, "plan_land", b["land"], b["views"], 2)
+            cs = self.capture_stream
+            with (torch.cuda.stream(cs) if cs is not None and cs != torch.cuda.current_stream() else contextlib.nullcontext()):
+                if "gather" not in skip:
+                    self._gather(b)
+                if "allreduce" not in skip:
+                    self._allreduce_mean(b["flat"])
+                if b["land"] is not None:
+                    self._copy_many(b, "plan_land", b["land"], b["views"], 2)
         elif self.stream is not None:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
@@ -265,6 +272,10 @@ class GradReducer:
                         self._copy_many(b, "plan_land", b["land"], b["views"], 2)
                     b["work"] = None
             b["pending"] = len(b["params"])
+
+    def set_capture_stream(self, stream):
+        """the stream a following torch.cuda.graph(...) capture runs on: the in-line exchange of a captured step is enqueued there"""
+        self.capture_stream = stream
 
     def join_capture(self):
         """inside torch.cuda.graph(...), after loss.backward(): join the side stream back into the capture stream (every bucket's all-reduce
