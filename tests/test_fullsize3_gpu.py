@@ -35,7 +35,8 @@ pytestmark = pytest.mark.gpu
 # (measured, gpurun_out/fullsize3_*.json: backbone features 0.8 / 1.3 / 0.9 / 1.8 / 2.6e-2 max-norm -- SURVEY 8(c)'s 2e-2 for stages 0-3;
 #  fused maps 6-11e-2, seg / regression 1.0e-1, lane 7-8e-2, classification 3.4e-2 in L2 (its max-norm is set by single sigmoid outputs);
 #  losses <= 1.5e-2; the oracle's own bf16-mirror run differs from its fp32 run by the same amounts)
-TOL_MAX = dict(feat0=2e-2, feat1=2e-2, feat2=2e-2, feat3=3e-2, feat4=4e-2, fused=1.4e-1, seg=1.3e-1, regression=1.3e-1, lane_cls=1.1e-1,
+# (feat4's max-norm is set by single elements: 2.1 ... 4.4e-2 across GEMM accumulation-order variants at an unchanged L2 of 2.1-2.2e-2)
+TOL_MAX = dict(feat0=2e-2, feat1=2e-2, feat2=2e-2, feat3=3e-2, feat4=6e-2, fused=1.4e-1, seg=1.3e-1, regression=1.3e-1, lane_cls=1.1e-1,
                lane_loc=1.1e-1)
 TOL_L2 = dict(feat0=1e-2, feat1=1.5e-2, feat2=2e-2, feat3=2.5e-2, feat4=3.5e-2, fused=1e-1, seg=1e-1, regression=1e-1, classification=5e-2,
               lane_cls=1e-1, lane_loc=1e-1)
