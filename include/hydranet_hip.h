@@ -125,7 +125,10 @@ long hn_stem_wgrad_blocks(int N, int H, int W);
 int hn_stem_wgrad(const float* x, const void* dz, float* part, int N, int H, int W, hipStream_t stream);
 
 /* Grouped 3x3 conv, group width 8, pad 1, stride 1|2 (XBlock conv_block_2, net/anynet.py:34-35).
- * hn_gconv_pack: fp32 [C][8][3][3] -> wk[tap][i][G][o] and wd (o/i swapped; flip=1 also flips the taps for stride-1 dgrad). */
+ * hn_gconv_pack: fp32 [C][8][3][3] -> wk[tap][i][G][o] and wd (o/i swapped; flip=1 also flips the taps for stride-1 dgrad).
+ * The stride-2 kernels contract with packed bf16 dot products and want the CONTRACTION index contiguous: hn_gconv_fwd(stride 2) takes the
+ * pack whose last index is the input channel = `wd` of hn_gconv_pack(flip = 0); hn_gconv_dgrad_s2 takes the pack whose last index is the
+ * output channel = `wk`.  (stride 1, the VALU form: hn_gconv_fwd takes `wk`, its data gradient = hn_gconv_fwd on dz with `wd` of flip = 1.) */
 int hn_gconv_pack(const float* w, void* wk, void* wd, int C, int flip, hipStream_t stream);
 int hn_gconv_fwd(const void* in, int ldi, const void* wk, void* out, int ldo, int N, int Hi, int Wi, int C, int stride, hipStream_t stream);
 int hn_gconv_dgrad_s2(const void* dz, int ldz, const void* wd, void* dx, int ldx, int N, int Hi, int Wi, int C, hipStream_t stream);

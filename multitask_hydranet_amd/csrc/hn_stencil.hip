@@ -174,8 +174,76 @@ __global__ __launch_bounds__(256) void gconv_fwd_kernel(const bf16* in, int ldi,
     }
 }
 
-// stride-2 dgrad: dx[n, iy, ix, g*8+i] = sum_{ky,kx,o : (iy+1-ky, ix+1-kx) even} dz[n, (iy+1-ky)/2, (ix+1-kx)/2, g*8+o] * wd[tap][o][g][i]
-// where wd is the forward weight packed with the o/i roles swapped (tap NOT flipped).
+
+// Packed-bf16 dot products for the stride-2 grouped convs (v_dot2c_f32_bf16: d += a.lo * b.lo + a.hi * b.hi, fp32 accumulate).  With the
+// contraction index contiguous in BOTH operands (8 input channels of a pixel piece / of a weight piece) a 3x3 tap of one group is 8 outputs
+// x 4 instructions instead of 64 FMAs + 72 bf16 -> f32 conversions: the kernels above were VALU-bound, not bandwidth-bound.
+__device__ __forceinline__ float dot2c_bf16(unsigned a, unsigned b, float c) {
+    asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(c) : "v"(a), "v"(b));
+    return c;
+}
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float dot8_bf16(const u32x4 a, const u32x4 b, float c) {
+    c = dot2c_bf16(a[0], b[0], c);
+    c = dot2c_bf16(a[1], b[1], c);
+    c = dot2c_bf16(a[2], b[2], c);
+    return dot2c_bf16(a[3], b[3], c);
+}
+// forward, stride 2: wo = weights packed [tap][o][G][i] (i contiguous: the `wd` array of hn_gconv_pack(flip = 0)).  Same thread mapping as
+// gconv_fwd_kernel (one group x a strip of 4 output pixels).
+template <bool LDSW>
+__global__ __launch_bounds__(256) void gconv_fwd_s2_kernel(const bf16* in, int ldi, const bf16* wo_g, bf16* out, int ldo, int N, int Hi,
+                                                           int Wi, int Ho, int Wo, int G) {
+    const bf16* wo = stage_gconv_weights(wo_g, G, LDSW);
+    const int bidx = xcd_remap(blockIdx.x, gridDim.x);
+    const int strips = (Wo + 3) >> 2;
+    const long total = (long)N * Ho * strips * G;
+    const long idx = (long)bidx * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const unsigned ui = (unsigned)idx;
+    const int g = (int)(ui % (unsigned)G);
+    unsigned t = ui / (unsigned)G;
+    const int sx = (int)(t % (unsigned)strips);
+    t /= (unsigned)strips;
+    const int oy = (int)(t % (unsigned)Ho);
+    const long n = t / (unsigned)Ho;
+    const int ox0 = sx * 4;
+    float acc[4][8];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int o = 0; o < 8; ++o) acc[p][o] = 0.f;
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int iy = oy * 2 + ky - 1;
+        if (iy < 0 || iy >= Hi) continue;
+        u32x4 xv[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int ix = (ox0 + p) * 2 + kx - 1;
+            xv[p] = (ix >= 0 && ix < Wi) ? *reinterpret_cast<const u32x4*>(in + ((n * Hi + iy) * (long)Wi + ix) * ldi + g * 8) : (u32x4){0u, 0u, 0u, 0u};
+        }
+        u32x4 wv[8];                                          // all eight weight pieces requested before the first dot (one round trip)
+#pragma unroll
+        for (int o = 0; o < 8; ++o) wv[o] = *reinterpret_cast<const u32x4*>(wo + (((long)tap * 8 + o) * G + g) * 8);
+#pragma unroll
+        for (int o = 0; o < 8; ++o)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) acc[p][o] = dot8_bf16(xv[p], wv[o], acc[p][o]);
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        if (ox0 + p >= Wo) break;
+        bf16x8 v;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) v[o] = f2bf(acc[p][o]);
+        st8(out + ((n * Ho + oy) * (long)Wo + ox0 + p) * ldo + g * 8, v);
+    }
+}
+
+// stride-2 dgrad: dx[n, iy, ix, g*8+i] = sum_{ky,kx,o : (iy+1-ky, ix+1-kx) even} dz[n, (iy+1-ky)/2, (ix+1-kx)/2, g*8+o] * w[o][i][tap]
+// with the weights packed [tap][i][G][o] (o, the contraction index, contiguous; tap NOT flipped) = hn_gconv_pack's `wk` array.
 // Thread = one 2x2 quad of input pixels (2yh+py, 2xh+px) x one group: the four parity classes use 1 + 2 + 2 + 4 of the nine taps and all of
 // them read the same four dz pixels (yh..yh+1, xh..xh+1), so the quad costs exactly the nine tap products with no divergence (a thread
 // per input pixel runs all nine tap bodies under lane masks in a mixed-parity wave: measured 157 us at stage 0 against a 22 us HBM floor).
@@ -194,13 +262,13 @@ __global__ __launch_bounds__(256) void gconv_dgrad_s2_kernel(const bf16* dz, int
     t /= (unsigned)Wo;
     const int yh = (int)(t % (unsigned)Ho);
     const long n = t / (unsigned)Ho;
-    bf16x8 zv[2][2];
+    u32x4 zv[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const bool ok = yh + a < Ho && xh + c < Wo;
-            zv[a][c] = ok ? ld8(dz + ((n * Ho + yh + a) * (long)Wo + xh + c) * ldz + g * 8) : zero8();
+            zv[a][c] = ok ? *reinterpret_cast<const u32x4*>(dz + ((n * Ho + yh + a) * (long)Wo + xh + c) * ldz + g * 8) : (u32x4){0u, 0u, 0u, 0u};
         }
     float acc[2][2][8];
 #pragma unroll
@@ -216,13 +284,12 @@ __global__ __launch_bounds__(256) void gconv_dgrad_s2_kernel(const bf16* dz, int
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
             const int px = kx == 1 ? 0 : 1, c = kx == 0 ? 1 : 0;
+            // wd here = weights packed [tap][i][G][o] (o contiguous: the `wk` array of hn_gconv_pack): one packed dot over the 8 couts
+            u32x4 wv[8];
 #pragma unroll
-            for (int o = 0; o < 8; ++o) {
-                const bf16x8 wv = ld8(wd + (((long)(ky * 3 + kx) * 8 + o) * G + g) * 8);
-                const float zf = bf2f(zv[a][c][o]);
+            for (int i = 0; i < 8; ++i) wv[i] = *reinterpret_cast<const u32x4*>(wd + (((long)(ky * 3 + kx) * 8 + i) * G + g) * 8);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) acc[py][px][i] = fmaf(zf, bf2f(wv[i]), acc[py][px][i]);
-            }
+            for (int i = 0; i < 8; ++i) acc[py][px][i] = dot8_bf16(zv[a][c], wv[i], acc[py][px][i]);
         }
     }
 #pragma unroll
@@ -1295,11 +1362,11 @@ extern "C" int hn_gconv_fwd(const void* in, int ldi, const void* wk, void* out, 
         hipLaunchKernelGGL(gconv_fwd_kernel<1>, dim3(cdiv(total, 256)), dim3(256), 0, st, (const bf16*)in, ldi, (const bf16*)wk, (bf16*)out,
                            ldo, N, Hi, Wi, Ho, Wo, G);
     else if (G * 1152 <= 24 * 1024)
-        hipLaunchKernelGGL((gconv_fwd_kernel<2, true>), dim3(cdiv(total, 256)), dim3(256), (size_t)G * 1152, st, (const bf16*)in, ldi,
+        hipLaunchKernelGGL(gconv_fwd_s2_kernel<true>, dim3(cdiv(total, 256)), dim3(256), (size_t)G * 1152, st, (const bf16*)in, ldi,
                            (const bf16*)wk, (bf16*)out, ldo, N, Hi, Wi, Ho, Wo, G);
     else
-        hipLaunchKernelGGL(gconv_fwd_kernel<2>, dim3(cdiv(total, 256)), dim3(256), 0, st, (const bf16*)in, ldi, (const bf16*)wk, (bf16*)out,
-                           ldo, N, Hi, Wi, Ho, Wo, G);
+        hipLaunchKernelGGL(gconv_fwd_s2_kernel<false>, dim3(cdiv(total, 256)), dim3(256), 0, st, (const bf16*)in, ldi, (const bf16*)wk,
+                           (bf16*)out, ldo, N, Hi, Wi, Ho, Wo, G);
     HN_LAUNCH_CHECK();
 }
 extern "C" int hn_gconv_dgrad_s2(const void* dz, int ldz, const void* wd, void* dx, int ldx, int N, int Hi, int Wi, int C, hipStream_t st) {

@@ -757,7 +757,8 @@ class ConvBnAct(torch.autograd.Function):
             else:
                 packs = pack_gconv_weight(weight, 1 if stride == 1 else 0)
                 z = new_act(n, ho, wo, c, dev)
-                lib().call("hn_gconv_fwd", ptr(x), ld(x), ptr(packs[0]), ptr(z), ld(z), n, hi, wi, c, stride)
+                # (stride 2 contracts with packed bf16 dots over the input channels: the pack with i contiguous = packs[1], hydranet_hip.h)
+                lib().call("hn_gconv_fwd", ptr(x), ld(x), ptr(packs[0] if stride == 1 else packs[1]), ptr(z), ld(z), n, hi, wi, c, stride)
             psum = psq = None
         else:
             n, hi, wi, cin = x.shape
@@ -829,7 +830,7 @@ class ConvBnAct(torch.autograd.Function):
                     if stride == 1:
                         lib().call("hn_gconv_fwd", ptr(dz), ld(dz), ptr(wd), ptr(dx), ld(dx), n, hi, wi, c, 1)
                     else:
-                        lib().call("hn_gconv_dgrad_s2", ptr(dz), ld(dz), ptr(wd), ptr(dx), ld(dx), n, hi, wi, c)
+                        lib().call("hn_gconv_dgrad_s2", ptr(dz), ld(dz), ptr(wk), ptr(dx), ld(dx), n, hi, wi, c)
             if mfma:
                 dw = k_gemm_tn(x, None, 5, (n, ho, wo), dz, c, 64, 9, 8, kh=3)
             else:
@@ -906,7 +907,9 @@ class XBlockFn(torch.autograd.Function):
             wk2, wd2 = pack_gconv_diag(w2)
             z2, ps, pq = k_gemm_nt(a, None, 5, grid, wk2, c, 64, 9, stats=training)
         else:
-            wk2, wd2 = pack_gconv_weight(w2, 0)
+            # stride 2: packed-bf16-dot kernels, contraction index contiguous (hydranet_hip.h): the forward takes the (o, i)-swapped pack,
+            # the data gradient the plain one
+            wd2, wk2 = pack_gconv_weight(w2, 0)
             z2 = new_act(n, ho, wo, c, dev)
             lib().call("hn_gconv_fwd", ptr(a), ld(a), ptr(wk2), ptr(z2), ld(z2), n, h, w, c, stride)
             ps, pq = k_col_stats_fused(z2) if training else (None, None)

@@ -39,8 +39,8 @@ for n, hi, wi, c in SHAPES:
     chunks = lib().query("hn_wgrad_chunks", n * ho * wo, (c // 8) * 9)
     part = torch.empty(chunks, c * 72, device=dev)
     p = K.ptr
-    t_f = timeit(lambda: lib().call("hn_gconv_fwd", p(x), c, p(wk), p(z), c, n, hi, wi, c, 2))
-    t_d = timeit(lambda: lib().call("hn_gconv_dgrad_s2", p(dz), c, p(wd), p(dx), c, n, hi, wi, c))
+    t_f = timeit(lambda: lib().call("hn_gconv_fwd", p(x), c, p(wd), p(z), c, n, hi, wi, c, 2))
+    t_d = timeit(lambda: lib().call("hn_gconv_dgrad_s2", p(dz), c, p(wk), p(dx), c, n, hi, wi, c))
     t_w = timeit(lambda: lib().call("hn_gconv_wgrad", p(x), c, p(dz), c, p(part), n, hi, wi, c, 2))
     bx, bz = x.numel() * 2 / 1e6, dz.numel() * 2 / 1e6
     print(f"C={c:4d} {hi}x{wi}: fwd {t_f:7.1f} us ({(bx + bz) / t_f:6.2f} TB/s)  dgrad {t_d:7.1f} us ({(bx + bz) / t_d:6.2f})  "
