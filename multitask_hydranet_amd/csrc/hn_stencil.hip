@@ -397,31 +397,36 @@ __global__ __launch_bounds__(256) void gconv_wgrad_sub_kernel(const bf16* x, int
         unsigned ox = (unsigned)p0 % (unsigned)Wo, t1 = (unsigned)p0 / (unsigned)Wo;
         unsigned oy = t1 % (unsigned)Ho, n = t1 / (unsigned)Ho;
         for (long pb = p0; pb < p1; pb += 4) {
-            bf16x8 zv[4], xv[4];
-            bool ok[4];
+            u32x4 zv[4], xv[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const long pix = pb + u;
                 const int iy = (int)oy * S + ky - 1, ix = (int)ox * S + kx - 1;
-                ok[u] = pix < p1 && iy >= 0 && iy < Hi && ix >= 0 && ix < Wi;
-                if (ok[u]) {
-                    zv[u] = ld8(dz + pix * ldz + g * 8);
-                    xv[u] = ld8(x + (((long)n * Hi + iy) * (long)Wi + ix) * ldx + g * 8);
+                const bool ok = pix < p1 && iy >= 0 && iy < Hi && ix >= 0 && ix < Wi;
+                zv[u] = (u32x4){0u, 0u, 0u, 0u};
+                xv[u] = (u32x4){0u, 0u, 0u, 0u};
+                if (ok) {
+                    zv[u] = *reinterpret_cast<const u32x4*>(dz + pix * ldz + g * 8);
+                    xv[u] = *reinterpret_cast<const u32x4*>(x + (((long)n * Hi + iy) * (long)Wi + ix) * ldx + g * 8);
                 }
                 if (++ox == (unsigned)Wo) { ox = 0; if (++oy == (unsigned)Ho) { oy = 0; ++n; } }
             }
+            // two pixels per packed dot: (dz[p][o], dz[p+1][o]) . (x[p][i], x[p+1][i]); the pairs are built with byte permutes
+            // (16 per pixel pair) and feed 64 v_dot2c_f32_bf16 -- instead of 128 FMAs + 32 conversions (a missing pixel is a zero vector)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (!ok[u]) continue;
-                float xf[8];
+            for (int u = 0; u < 4; u += 2) {
+                unsigned zp[8], xp[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) xf[i] = bf2f(xv[u][i]);
-#pragma unroll
-                for (int o = 0; o < 8; ++o) {
-                    const float zf = bf2f(zv[u][o]);
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) acc[o][i] = fmaf(zf, xf[i], acc[o][i]);
+                for (int k = 0; k < 4; ++k) {
+                    zp[2 * k] = __builtin_amdgcn_perm(zv[u + 1][k], zv[u][k], 0x05040100u);
+                    zp[2 * k + 1] = __builtin_amdgcn_perm(zv[u + 1][k], zv[u][k], 0x07060302u);
+                    xp[2 * k] = __builtin_amdgcn_perm(xv[u + 1][k], xv[u][k], 0x05040100u);
+                    xp[2 * k + 1] = __builtin_amdgcn_perm(xv[u + 1][k], xv[u][k], 0x07060302u);
                 }
+#pragma unroll
+                for (int o = 0; o < 8; ++o)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[o][i] = dot2c_bf16(zp[o], xp[i], acc[o][i]);
             }
         }
     }
