@@ -665,7 +665,7 @@ __global__ __launch_bounds__(512, PIPE ? 2 : 4) void conv3x3_direct_kernel(const
     };
     const int xc0 = xs.diag ? c_blk : 0;                              // first input channel of chunk 0
 
-    // patch pieces owned by this thread: e = tid + 512 i -> patch pixel e>>3, PHYSICAL piece e&7 (logical = physical ^ (pixel&7)).
+    // patch pieces owned by this thread: e = tid + 512 i -> patch pixel e>>3, PHYSICAL piece e&7 (logical = physical ^ (patch column & 7)).
     // One register per piece: the source pixel as (gy << 16 | gx) in full-resolution coordinates (-1: outside / zero); the row index in
     // either operand and the channel sub-offset are recomputed when the load is issued (this kernel sits at the 128-VGPR limit of two
     // co-resident workgroups: three registers per piece cost 12 spilled VGPRs = 52 B/lane of scratch traffic).
@@ -709,6 +709,10 @@ __global__ __launch_bounds__(512, PIPE ? 2 : 4) void conv3x3_direct_kernel(const
         const int dy = xs.mode == 2 ? ky : 2 - ky, dx = xs.mode == 2 ? kx : 2 - kx;
         const char* sW = sWb + (st % WBUFS) * WBYTES;
         const char* sX = sXb + (XBUFS == 2 ? (chunk & 1) : 0) * XBYTES;
+        // The 16-byte pieces of a patch pixel are XOR-swizzled by its patch COLUMN (not its pixel index): a wave's 16 lanes read 16
+        // consecutive columns of one row, so the reads stay bank-conflict free, and the rows of a wave tile (j) and of a tap (dy) differ
+        // by constant byte offsets -- one LDS address per (tap column, K half) instead of one per read (was 3.8 VALU instructions per MFMA).
+        const int pxk = ((lane & 15) + dx) & 7;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 a[TC], b[TP];
@@ -718,7 +722,7 @@ __global__ __launch_bounds__(512, PIPE ? 2 : 4) void conv3x3_direct_kernel(const
 #pragma unroll
             for (int j = 0; j < TP; ++j) {
                 const int pidx = (wp * ROWS + j + dy) * 18 + (lane & 15) + dx;
-                b[j] = *reinterpret_cast<const bf16x8*>(sX + pidx * 128 + ((piece ^ (pidx & 7)) << 4));
+                b[j] = *reinterpret_cast<const bf16x8*>(sX + pidx * 128 + ((piece ^ pxk) << 4));
             }
 #pragma unroll
             for (int i = 0; i < TC; ++i)
@@ -746,7 +750,8 @@ __global__ __launch_bounds__(512, PIPE ? 2 : 4) void conv3x3_direct_kernel(const
         for (int i = 0; i < XL; ++i) {
             if (PIPE || 512 * i + 64 * wave < PPIX * 8) {              // PIPE: every wave issues all XL rounds (padded buffer)
                 const int e = tid + 512 * i;
-                const int c = xc0 + k0 + ((((e & 7) ^ ((e >> 3) & 7))) << 3);
+                const int ppx = (e >> 3) % 18;                         // patch column of this piece's pixel: the swizzle key
+                const int c = xc0 + k0 + ((((e & 7) ^ (ppx & 7))) << 3);
                 const bf16* src = g_zero_piece;
                 int pk = spack[i];
                 asm volatile("" : "+v"(pk));                          // keep the 64-bit row pointers out of loop-invariant registers
@@ -779,6 +784,7 @@ __global__ __launch_bounds__(512, PIPE ? 2 : 4) void conv3x3_direct_kernel(const
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
             const int dy = xs.mode == 2 ? ky : 2 - ky, dx = xs.mode == 2 ? kx : 2 - kx;
+            const int pxk = ((lane & 15) + dx) & 7;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 bf16x8 a[TC], b[TP];
@@ -792,7 +798,7 @@ __global__ __launch_bounds__(512, PIPE ? 2 : 4) void conv3x3_direct_kernel(const
 #pragma unroll
                 for (int j = 0; j < TP; ++j) {
                     const int pidx = (wp * ROWS + j + dy) * 18 + (lane & 15) + dx;
-                    b[j] = *reinterpret_cast<const bf16x8*>(sXb + pidx * 128 + ((piece ^ (pidx & 7)) << 4));
+                    b[j] = *reinterpret_cast<const bf16x8*>(sXb + pidx * 128 + ((piece ^ pxk) << 4));
                 }
 #pragma unroll
                 for (int i = 0; i < TC; ++i)
