@@ -36,7 +36,8 @@ __device__ __forceinline__ bf16x8 zero8() {
 // tuning knobs for tools/ sweeps (hn_debug_knob; defaults = the shipped heuristics): 0 TN split target (workgroups), 1 TN minimum rows per
 // split, 2 fused-BatchNorm apply-pass target workgroups, 3 fused reduce-pass row-block divisor, 4 / 5 pixel thresholds of the 64x64 GEMM tile,
 // 6 = 1: no two-K-group GEMM variant (> 1: its K threshold, default 512), 7 depthwise-backward block target, 8 = 0: fused passes without the
-// XCD row-order placement, 9 grouped-TN debug bits (skip stores / MFMAs / loads), 10 grouped-TN tile variant; 11 spare
+// XCD row-order placement, 9 grouped-TN debug bits (skip stores / MFMAs / loads), 10 grouped-TN tile variant, 11 = 1: direct 3x3 kernel walks
+// the patches of one cout tile first (measured: no gain)
 extern long g_hn_knob[12];
 #define HN_ACT_NONE 0
 #define HN_ACT_RELU 1

@@ -158,6 +158,7 @@ struct GemmNT {
     //            producer: the reduce pass of hn_bn_bwd_fused over (da, z1))
     // ez: the forward pre-BatchNorm tensor at the output's rows / channels (row stride ld_ez); ecoef: [4][Nout] = sc, sh, mu, rs
     int emode; const bf16* ez; int ld_ez; const float* ecoef;
+    int tile_major;                   // direct kernel: block id order (see there)
 };
 
 // one pixel x 4 consecutive channels of the statistics epilogue (GemmNT::emode); cf = (sc, sh, mu, rs) of the 4 channels
@@ -645,8 +646,13 @@ __global__ __launch_bounds__(512, PIPE ? 2 : 4) void conv3x3_direct_kernel(const
     const int ncy = (p.Nout + BC - 1) / BC;
     const int tx_n = (xs.W + 15) >> 4, ty_n = (xs.H + 15) >> 4;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
-    const int c_tile = lid % ncy;
-    int t = lid / ncy;
+    // block id -> (cout tile, patch).  p.tile_major = 0: the cout tiles of a patch are neighbours (an XCD works on a contiguous range of
+    // patches with ALL cout tiles: the patch is read once into its L2, the whole weight tensor must stay there); 1: a cout tile's patches
+    // are neighbours (an XCD works on few cout tiles -- their weights stay L2-hot for the per-tap tile streams -- and reads every patch)
+    const int npatch = gridDim.x / ncy;
+    const int c_tile = p.tile_major ? lid / npatch : lid % ncy;
+    int t = p.tile_major ? lid % npatch : lid / ncy;
+    const int patch_id = t;
     const int tx = t % tx_n;
     t /= tx_n;
     const int ty = t % ty_n;
@@ -898,7 +904,7 @@ __global__ __launch_bounds__(512, PIPE ? 2 : 4) void conv3x3_direct_kernel(const
             float t1 = 0.f, t2 = 0.f;
 #pragma unroll
             for (int k = 0; k < WGP; ++k) { t1 += red[(k * BC + tid) * 2]; t2 += red[(k * BC + tid) * 2 + 1]; }
-            const long prow = lid / ncy;
+            const long prow = patch_id;
             p.psum[prow * p.Nout + c_blk + tid] = t1;
             if (p.psq) p.psq[prow * p.Nout + c_blk + tid] = t2;
         }
@@ -2327,6 +2333,7 @@ static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img
     p.amax = g_next_amax;
     g_next_amax = nullptr;
     p.emode = g_next_stat.mode; p.ez = g_next_stat.z; p.ld_ez = g_next_stat.ldz; p.ecoef = g_next_stat.coef;
+    p.tile_major = (int)g_hn_knob[11];
     p.fold = g_next_fold.ring ? 1 : 0; p.ring = g_next_fold.ring; p.fold_y = g_next_fold.y; p.ld_fy = g_next_fold.ldy;
     if (img_stride < 0) {                                            // mode 4: -img_stride = channels per depth-to-space output pixel
         HN_CHECK_ARG(p.x.clamp == 1 && (out_f32 || phase_mode == 1) && rpi == 0 && !psum && Nout == 4 * (int)(-img_stride));
