@@ -797,11 +797,34 @@ __device__ __forceinline__ float block_sum_1024(float v, float* red) {  // red: 
     for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
     return t;
 }
+// k-th element's bin of a 256-bin LDS histogram, found by all threads together: thread b < 256 takes bin b, an inclusive prefix sum runs
+// inside each of the four waves (shuffles) and across them (LDS), and the one thread whose bin satisfies excl < k <= incl publishes
+// (bin, k - excl).  (One thread walking the 256 bins was ~10 us per radix pass: 256 dependent LDS reads.)  All 1024 threads call it.
+__device__ __forceinline__ void hist_select_256(const unsigned int* hist, unsigned int k, unsigned int* wsum /* [4] LDS */, unsigned int* out_bin,
+                                                unsigned int* out_k) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned int v = tid < 256 ? hist[tid] : 0u, incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned int t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    if (tid < 256 && lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    if (tid < 256) {
+        unsigned int base = 0;
+        for (int w2 = 0; w2 < wave; ++w2) base += wsum[w2];
+        incl += base;
+        const unsigned int excl = incl - v;
+        if (excl < k && k <= incl) { *out_bin = (unsigned int)tid; *out_k = k - excl; }
+    }
+    __syncthreads();
+}
 __global__ __launch_bounds__(1024) void lane_cls_fwd_kernel(const float* logits, const float* target, long M, float neg_ratio, float alpha,
                                                             float* lsm, unsigned char* pmask, float* out, float* aux) {
     __shared__ unsigned int hist[256];
     __shared__ float red[16];
-    __shared__ unsigned int s_prefix, s_k;
+    __shared__ unsigned int s_bin, s_k, s_wsum[4];
     const int tid = threadIdx.x;
     float npos = 0.f, nneg = 0.f;
     for (long i = tid; i < M; i += 1024) {
@@ -834,17 +857,8 @@ __global__ __launch_bounds__(1024) void lane_cls_fwd_kernel(const float* logits,
                 if ((key & himask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1u);
             }
             __syncthreads();
-            if (tid == 0) {
-                unsigned int acc = 0, b = 0;
-                for (; b < 256; ++b) {
-                    if (acc + hist[b] >= k) break;
-                    acc += hist[b];
-                }
-                s_prefix = prefix | (b << shift);
-                s_k = k - acc;
-            }
-            __syncthreads();
-            prefix = s_prefix;
+            hist_select_256(hist, k, s_wsum, &s_bin, &s_k);
+            prefix |= s_bin << shift;
             k = s_k;
         }
         thr = ord2f(prefix);
@@ -870,7 +884,7 @@ __global__ __launch_bounds__(1024) void lane_cls_fwd_reg_kernel(const float* log
                                                                 float* lsm, unsigned char* pmask, float* out, float* aux) {
     __shared__ unsigned int hist[256];
     __shared__ float red[16];
-    __shared__ unsigned int s_prefix, s_k;
+    __shared__ unsigned int s_bin, s_k, s_wsum[4];
     const int tid = threadIdx.x;
     float bg[RPT], fg[RPT];
     unsigned int pos = 0, valid = 0;                                  // bit j: row tid + 1024 j is a positive / exists
@@ -927,17 +941,8 @@ __global__ __launch_bounds__(1024) void lane_cls_fwd_reg_kernel(const float* log
                 if ((key & himask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1u);
             }
             __syncthreads();
-            if (tid == 0) {
-                unsigned int acc = 0, b = 0;
-                for (; b < 256; ++b) {
-                    if (acc + hist[b] >= k) break;
-                    acc += hist[b];
-                }
-                s_prefix = prefix | (b << shift);
-                s_k = k - acc;
-            }
-            __syncthreads();
-            prefix = s_prefix;
+            hist_select_256(hist, k, s_wsum, &s_bin, &s_k);
+            prefix |= s_bin << shift;
             k = s_k;
         }
         thr = ord2f(prefix);

@@ -12,6 +12,9 @@
 // ---------------------------------------------------------------------------------------------------------
 // stem: x NCHW fp32 [N,3,H,W] -> z NHWC bf16 [N,H/2,W/2,32]; weights fp32 [32][3][3][3]
 // ---------------------------------------------------------------------------------------------------------
+// One thread = TWO neighbouring output pixels (2p, 2p + 1) of a row: every weight read from LDS (a broadcast ds_read, 216 of them per
+// thread against 864 FMAs) feeds two FMAs, and the two 3 x 3 stride-2 windows share one of their six input columns.  With one pixel per
+// thread the kernel was bound by those LDS reads (186 us for 352 MB; 2 M pixels x 216 wave-wide reads).
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* x, const float* w, bf16* z, bf16* patches, int N, int H, int W) {
     const int bidx = xcd_remap(blockIdx.x, gridDim.x);     // row-order placement convention (hn_common.h)
     __shared__ float sw[27][32];
@@ -20,50 +23,78 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* x, const flo
         sw[t][co] = w[co * 27 + t];
     }
     __syncthreads();
-    const int Ho = H >> 1, Wo = W >> 1;
-    const long total = (long)N * Ho * Wo;
+    const int Ho = H >> 1, Wo = W >> 1, Wp = (Wo + 1) >> 1;
+    const long total = (long)N * Ho * Wp;
     const long idx = (long)bidx * 256 + threadIdx.x;
     if (idx >= total) return;
-    const int ox = (int)(idx % Wo);
-    const long t1 = idx / Wo;
+    const int ox = (int)(idx % Wp) * 2;
+    const long t1 = idx / Wp;
     const int oy = (int)(t1 % Ho);
     const long n = t1 / Ho;
-    float acc[32];
+    const bool two = ox + 1 < Wo;
+    float acc[2][32];
 #pragma unroll
-    for (int c = 0; c < 32; ++c) acc[c] = 0.f;
-    // im2col row (27 taps + 5 zeros) kept in bf16 for the MFMA wgrad: staged in LDS (2-byte writes are cheap there) and written out as
-    // four 16-byte stores per pixel instead of 27 two-byte global stores
-    __shared__ __attribute__((aligned(16))) bf16 sp[256][40];
-    bf16* prow = patches ? sp[threadIdx.x] : nullptr;
-#pragma unroll 1
-    for (int t = 0; t < 9; ++t) {                  // t = ci*3 + ky ; kept rolled so the 864 weights are not hoisted
-        const int ci = t / 3, ky = t - ci * 3;
+    for (int c = 0; c < 32; ++c) { acc[0][c] = 0.f; acc[1][c] = 0.f; }
+    // im2col rows (27 taps + 5 zeros) kept in bf16 for the MFMA wgrad: staged in LDS (2-byte writes are cheap there) and written out as
+    // 16-byte stores instead of 27 two-byte global stores per pixel
+    // (rows of 36 bf16 = 18 dwords per thread, pixel-major planes: the 2-byte LDS writes of a wave fall on 16 distinct banks -- a
+    // 40-element row put them on 4, i.e. 16-way conflicts on each of the 54 writes: that, not HBM, was most of the kernel's time)
+    __shared__ __attribute__((aligned(16))) bf16 sp[2][256][36];
+    bf16* prow = patches ? sp[0][threadIdx.x] : nullptr;
+    constexpr int PH = 256 * 36;                   // elements between the two pixels' rows of a thread
+    auto load_row = [&](int t, float* v) {         // input columns 2 ox - 1 ... 2 ox + 3 of row (ci, ky) = (t / 3, t % 3)
+        const int ci = t / 3, ky = t - ci * 3;     // (unconditional loads from clamped coordinates + selects measured slower: 179 vs 156 us)
         const int iy = 2 * oy + ky - 1;
 #pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int ix = 2 * ox + k - 1;
+            v[k] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[((n * 3 + ci) * H + iy) * (long)W + ix] : 0.f;
+        }
+    };
+    float vn[5];
+    load_row(0, vn);
+#pragma unroll 1
+    for (int t = 0; t < 9; ++t) {                  // t = ci*3 + ky ; kept rolled so the 864 weights are not hoisted
+        float v[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) v[k] = vn[k];
+        if (t + 1 < 9) load_row(t + 1, vn);        // the next row's loads fly under this row's 192 FMAs (the rolled loop exposed ~2 us per row)
+#pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-            const int ix = 2 * ox + kx - 1;
-            float v = 0.f;
-            if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[((n * 3 + ci) * H + iy) * (long)W + ix];
-            if (prow) prow[t * 3 + kx] = f2bf(v);
+            if (prow) { prow[t * 3 + kx] = f2bf(v[kx]); prow[PH + t * 3 + kx] = f2bf(v[kx + 2]); }
             const float* wr = sw[t * 3 + kx];
 #pragma unroll
-            for (int c = 0; c < 32; ++c) acc[c] = fmaf(v, wr[c], acc[c]);
+            for (int c = 0; c < 32; ++c) {
+                const float wc = wr[c];
+                acc[0][c] = fmaf(v[kx], wc, acc[0][c]);
+                acc[1][c] = fmaf(v[kx + 2], wc, acc[1][c]);
+            }
         }
     }
-    if (prow) {
+    const long pix = (n * Ho + oy) * (long)Wo + ox;
 #pragma unroll
-        for (int t = 27; t < 32; ++t) prow[t] = f2bf(0.f);
-        bf16* pg = patches + idx * 32;
+    for (int h = 0; h < 2; ++h) {
+        if (h == 1 && !two) break;
+        if (prow) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) st8(pg + q * 8, ld8(prow + q * 8));     // own row: no barrier needed
-    }
-    bf16* o = z + idx * 32;
+            for (int t = 27; t < 32; ++t) prow[h * PH + t] = f2bf(0.f);
+            bf16* pg = patches + (pix + h) * 32;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        bf16x8 v;
+            for (int q = 0; q < 4; ++q) {                                          // own rows: no barrier needed; 8-byte aligned LDS rows
+                const bf16x4 lo = *reinterpret_cast<const bf16x4*>(prow + h * PH + q * 8);
+                const bf16x4 hi = *reinterpret_cast<const bf16x4*>(prow + h * PH + q * 8 + 4);
+                bf16x8 v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                st8(pg + q * 8, v8);
+            }
+        }
+        bf16* o = z + (pix + h) * 32;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = f2bf(acc[q * 8 + k]);
-        st8(o + q * 8, v);
+        for (int q = 0; q < 4; ++q) {
+            bf16x8 v8;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v8[k] = f2bf(acc[h][q * 8 + k]);
+            st8(o + q * 8, v8);
+        }
     }
 }
 
@@ -1329,7 +1360,7 @@ static inline int ew_grid(long items) {
 
 extern "C" int hn_stem_fwd(const float* x, const float* w, void* z, void* patches, int N, int H, int W, hipStream_t st) {
     HN_CHECK_ARG(x && w && z && N > 0 && H > 1 && W > 1 && !(H & 1) && !(W & 1));
-    const long total = (long)N * (H >> 1) * (W >> 1);
+    const long total = (long)N * (H >> 1) * (((W >> 1) + 1) >> 1);          // one thread per pair of output pixels
     hipLaunchKernelGGL(stem_fwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, x, w, (bf16*)z, (bf16*)patches, N, H, W);
     HN_LAUNCH_CHECK();
 }
