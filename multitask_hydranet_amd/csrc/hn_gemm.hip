@@ -159,6 +159,7 @@ struct GemmNT {
     // ez: the forward pre-BatchNorm tensor at the output's rows / channels (row stride ld_ez); ecoef: [4][Nout] = sc, sh, mu, rs
     int emode; const bf16* ez; int ld_ez; const float* ecoef;
     int tile_major;                   // direct kernel: block id order (see there)
+    int wpre;                         // direct kernel: all weight tiles of the (single) chunk preloaded, one LDS slot per tap step
 };
 
 // one pixel x 4 consecutive channels of the statistics epilogue (GemmNT::emode); cf = (sc, sh, mu, rs) of the 4 channels
@@ -709,11 +710,13 @@ __global__ __launch_bounds__(512, PIPE ? 2 : 4) void conv3x3_direct_kernel(const
 
     // stage st = chunk * 9 + tap.  Iteration `it` issues the DMA of stage `it` (+ the X patch of its chunk when tap == 0) and multiplies
     // stage `it - 1`.
+    // weight-tile slots: two (three: PIPE) recycled ones, or -- p.wpre, single-chunk convs whose S tiles all fit -- one slot per tap step
+    const int wslots = p.wpre ? 16 : WBUFS;
     auto compute = [&](int st) {
         const int chunk = st / NT, tap = tap_of(chunk, st - chunk * NT);
         const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
         const int dy = xs.mode == 2 ? ky : 2 - ky, dx = xs.mode == 2 ? kx : 2 - kx;
-        const char* sW = sWb + (st % WBUFS) * WBYTES;
+        const char* sW = sWb + (st % wslots) * WBYTES;
         const char* sX = sXb + (XBUFS == 2 ? (chunk & 1) : 0) * XBYTES;
         // The 16-byte pieces of a patch pixel are XOR-swizzled by its patch COLUMN (not its pixel index): a wave's 16 lanes read 16
         // consecutive columns of one row, so the reads stay bank-conflict free, and the rows of a wave tile (j) and of a tap (dy) differ
@@ -740,7 +743,7 @@ __global__ __launch_bounds__(512, PIPE ? 2 : 4) void conv3x3_direct_kernel(const
     auto issue_w = [&](int st) {
         const int chunk = st / NT, tap = tap_of(chunk, st - chunk * NT);
         const int k0 = chunk * 64;
-        char* sW = sWb + (st % WBUFS) * WBYTES;
+        char* sW = sWb + (st % wslots) * WBYTES;
 #pragma unroll
         for (int i = 0; i < WL; ++i) {
             if (wave * 8 + 64 * i < BC) {                              // wave-uniform (all waves for BC >= 64)
@@ -770,7 +773,16 @@ __global__ __launch_bounds__(512, PIPE ? 2 : 4) void conv3x3_direct_kernel(const
             }
         }
     };
-    if (BC == 64 && !PIPE && xs.diag) {
+    if (!PIPE && p.wpre) {
+        // Single 64-channel chunk and few tap steps (the phase-form output convs: 4 steps): the patch and ALL weight tiles are requested
+        // together and the tap loop runs without barriers or DMA waits -- such a workgroup lived for ~14 us of which the four
+        // barrier-separated weight-tile round trips were a third.
+        issue_x(0);
+        for (int st = 0; st < S; ++st) issue_w(st);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int st = 0; st < S; ++st) compute(st);
+    } else if (BC == 64 && !PIPE && xs.diag) {
         // Grouped conv (group width 8) as block-diagonal 64 x 64 tiles: of the 8 KB weight tile of a tap only the eight 8 x 8 diagonal
         // blocks (1 KB) are non-zero.  All nine taps' blocks (9 KB: [tap][cout 64][8 ci]) are fetched ONCE next to the patch, and the A
         // fragments are built from them by a lane select -- the tap loop has no barrier and no DMA wait.  The tile-streaming loop below
@@ -2333,7 +2345,8 @@ static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img
     p.amax = g_next_amax;
     g_next_amax = nullptr;
     p.emode = g_next_stat.mode; p.ez = g_next_stat.z; p.ld_ez = g_next_stat.ldz; p.ecoef = g_next_stat.coef;
-    p.tile_major = (int)g_hn_knob[11];
+    p.tile_major = g_hn_knob[11] == 1 ? 1 : 0;
+    p.wpre = 0;
     p.fold = g_next_fold.ring ? 1 : 0; p.ring = g_next_fold.ring; p.fold_y = g_next_fold.y; p.ld_fy = g_next_fold.ldy;
     if (img_stride < 0) {                                            // mode 4: -img_stride = channels per depth-to-space output pixel
         HN_CHECK_ARG(p.x.clamp == 1 && (out_f32 || phase_mode == 1) && rpi == 0 && !psum && Nout == 4 * (int)(-img_stride));
@@ -2346,8 +2359,11 @@ static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img
         dim3 grid((unsigned)(cdiv(Nout, bc) * cdiv(W, 16) * cdiv(H, 16) * n_img));
         // software-pipelined variant (one workgroup per CU, 3 weight tiles + 2 patch buffers): the bf16 launches with >= 64 couts per tile
         const bool pipe = g_direct_pipe && bc >= 64 && !out_f32;
+        // preloaded form: one chunk, all its tap tiles (<= 16) in at most 32 KB next to the patch (two or three workgroups per CU as before)
+        const int nsteps = phase_mode ? 4 : 9;
+        p.wpre = (!pipe && !p.x.diag && KP <= 64 && (size_t)nsteps * bc * 128 <= 32768 && g_hn_knob[11] != 2) ? 1 : 0;
         const size_t lds = pipe ? (size_t)2 * (((18 * 18 * 8 + 511) / 512) * 512 * 16) + 3 * (size_t)bc * 128
-                                : (size_t)((18 * 18 * 128 + 1023) / 1024 * 1024) + 2 * (size_t)bc * 128;
+                                : (size_t)((18 * 18 * 128 + 1023) / 1024 * 1024) + (p.wpre ? nsteps : 2) * (size_t)bc * 128;
         // > 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel (done on the first, un-captured call)
         static std::atomic<unsigned long long> optin{0};
         if (!lds_optin(optin, {(const void*)conv3x3_direct_kernel<16, true, false>, (const void*)conv3x3_direct_kernel<16, false, false>,
