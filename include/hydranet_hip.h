@@ -185,6 +185,9 @@ int hn_fuse_fwd_raw(const void* const* in, const int* ld, const int* mode, const
 /* `accumulate` / acc[i] = 1 in hn_fuse_bwd, hn_sum2x2 and hn_maxpool_bwd2: the destination already holds the gradient another consumer of
  * the same tensor wrote (a BiFPN map feeds 2-3 nodes, net/bifpn.py:186-231) and this consumer's contribution is added in place (fp32 add,
  * one bf16 rounding) -- the autograd engine's separate gradient-accumulation kernels disappear (ops.Share / ops.GradSlot). */
+/* hn_fuse_bwd, din[i]: destination of input i's gradient for mode 1 (same grid) AND mode 2 inputs (nearest x2 of a half-resolution map:
+ * din[i] is [N][H/2][W/2][.], the kernel walks the output in 2x2 quads and writes w_i * the quad sum itself; NULL: the caller runs
+ * hn_sum2x2 over g); mode 3 (max-pooled) inputs: NULL, routed by hn_maxpool_bwd2. */
 int hn_fuse_bwd_blocks(int N, int H, int W, int C);
 int hn_fuse_bwd(const void* const* in, const int* ld, const int* mode, const float* w, const void* dout, int ldd, void* g, int ldg,
                 void* const* din, const int* ldin, const int* acc, float* pw, int N, int H, int W, int C, hipStream_t stream);

@@ -1137,19 +1137,32 @@ struct FuseBwd {
     int acc[3];                     // 1: din[i] += (the tensor already holds the gradient of another consumer)
     float* pw;
 };
+// Inputs of mode 2 (nearest x2 of a half-resolution map) that come with a destination (din[i] at the LOW resolution): the kernel walks
+// the output in 2 x 2 quads and writes w_i * (sum of the quad's g) itself -- the separate hn_sum2x2 pass over g (one launch per top-down
+// fusion node, 12 per step) is not needed; the sum is taken over the bf16-rounded g, as that pass did.
 __global__ __launch_bounds__(256) void fuse_bwd_kernel(const FuseBwd q) {
     const int bidx = xcd_remap(blockIdx.x, gridDim.x);     // row-order placement convention (hn_common.h)
     const Fuse& p = q.f;
     const int C8 = p.C >> 3;
-    const long total = (long)p.N * p.H * p.W * C8;
+    int up_i = -1;                                         // the (at most one) up-sampled input whose gradient is folded here
+#pragma unroll
+    for (int i = 0; i < 3; ++i) if (p.mode[i] == 2 && q.din[i]) up_i = i;
+    const bool quads = up_i >= 0;
+    const int Wq = quads ? p.W >> 1 : p.W, Hq = quads ? p.H >> 1 : p.H;
+    const long total = (long)p.N * Hq * Wq * C8;
     float dw[3] = {0.f, 0.f, 0.f};
     for (long idx = (long)bidx * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int cg = (int)(idx % C8);
         long t = idx / C8;
-        const int x = (int)(t % p.W);
-        t /= p.W;
-        const int y = (int)(t % p.H);
-        const long n = t / p.H;
+        const int xq = (int)(t % Wq);
+        t /= Wq;
+        const int yq = (int)(t % Hq);
+        const long n = t / Hq;
+        float qsum[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) qsum[k] = 0.f;
+        for (int sub = 0; sub < (quads ? 4 : 1); ++sub) {
+        const int x = quads ? 2 * xq + (sub & 1) : xq, y = quads ? 2 * yq + (sub >> 1) : yq;
         float v[3][8], pre[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) pre[k] = 0.f;
@@ -1166,7 +1179,7 @@ __global__ __launch_bounds__(256) void fuse_bwd_kernel(const FuseBwd q) {
         float gg[8];
         bf16x8 go;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { gg[k] = bf2f(d[k]) * act_bwd(pre[k], HN_ACT_SWISH); go[k] = f2bf(gg[k]); }
+        for (int k = 0; k < 8; ++k) { gg[k] = bf2f(d[k]) * act_bwd(pre[k], HN_ACT_SWISH); go[k] = f2bf(gg[k]); qsum[k] += bf2f(go[k]); }
         st8(q.g + orow * q.ldg + cg * 8, go);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -1187,6 +1200,21 @@ __global__ __launch_bounds__(256) void fuse_bwd_kernel(const FuseBwd q) {
                 }
                 st8(dst, o);
             }
+        }
+        }
+        if (quads) {                                       // = sum2x2_kernel on this quad
+            const float ws = p.w[up_i];
+            bf16* dst = q.din[up_i] + ((n * Hq + yq) * (long)Wq + xq) * q.ldin[up_i] + cg * 8;
+            bf16x8 o;
+            if (q.acc[up_i]) {
+                const bf16x8 prev = ld8(dst);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o[k] = f2bf(fmaf(qsum[k], ws, bf2f(prev[k])));
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o[k] = f2bf(qsum[k] * ws);
+            }
+            st8(dst, o);
         }
     }
     __shared__ float red[4][3];

@@ -1307,6 +1307,12 @@ def share(x, n):
     return Share.apply(x, slot, n), slot
 
 
+# HN_FUSE_SUM2X2=1: the 2x2 gradient sums of up-sampled fusion inputs inside hn_fuse_bwd (quad walk) instead of 12 hn_sum2x2 launches per
+# step.  Measured SLOWER (780.9 vs 783.9 img/s, same box): a thread then walks four pixels in sequence, and these launches are bound by
+# their dependent-load chains, not by their count -- off.
+FUSE_SUM2X2 = os.environ.get("HN_FUSE_SUM2X2", "0") == "1"
+
+
 class Fuse(torch.autograd.Function):
     """out = swish(w0*T0(a) + w1*T1(b) [+ w2*T2(c)]), w = relu(p)/(sum relu(p) + 1e-4) from the raw fusion parameter p (2 or 3 values).
     slots (optional): one GradSlot | None per input -- the gradient of a slotted input is accumulated into slot.buf (see Share)."""
@@ -1352,8 +1358,11 @@ class Fuse(torch.autograd.Function):
                 if s is not None:
                     s.buf = dst[i]
         ap, al, am = _fuse_args(ins, modes)
-        dp_ = (ctypes.c_void_p * 3)(*[ptr(dst[i]) if modes[i] == 1 else None for i in range(3)])
-        dl = (ctypes.c_int * 3)(*[ld(dst[i]) if modes[i] == 1 else 0 for i in range(3)])
+        # mode 1 (same grid) and mode 2 (nearest x2 of a half-resolution map: the kernel sums its 2x2 quads itself) gradients come out of
+        # the fusion kernel; mode 3 (max-pooled input) is routed by the max-pool backward below
+        inside = (1, 2) if FUSE_SUM2X2 else (1,)
+        dp_ = (ctypes.c_void_p * 3)(*[ptr(dst[i]) if modes[i] in inside else None for i in range(3)])
+        dl = (ctypes.c_int * 3)(*[ld(dst[i]) if modes[i] in inside else 0 for i in range(3)])
         da = (ctypes.c_int * 3)(*accum)
         blocks = lib().query("hn_fuse_bwd_blocks", n, h, wd, ch)
         pw = torch.empty((blocks, 3), device=dev, dtype=F32)
@@ -1365,9 +1374,9 @@ class Fuse(torch.autograd.Function):
             dpraw = torch.empty_like(praw)
             lib().call("hn_fuse_dweights", ptr(pw), blocks, ptr(praw), praw.numel(), 1e-4, ptr(dpraw))
         for i, m in enumerate(modes):
-            if m == 2:                                               # nearest x2 of a half-res input: 2x2 sum of g
+            if m == 2 and not FUSE_SUM2X2:                         # nearest x2 of a half-res input: 2x2 sum of g
                 lib().call("hn_sum2x2", ptr(g), ld(g), ptr(dst[i]), ld(dst[i]), ptr(w[i]), n, h // 2, wd // 2, ch, accum[i])
-            elif m == 3:                                             # zero-pad-same max pool of a double-res input
+            elif m == 3:                                           # zero-pad-same max pool of a double-res input
                 k_maxpool_bwd(ins[i], g, 0, wscale=w[i], into=dst[i], accumulate=bool(accum[i]))
         dins = [None if (slots[i] is not None or not modes[i]) else dst[i] for i in range(3)]
         return dpraw, None, None, None, dins[0], dins[1], dins[2], None
