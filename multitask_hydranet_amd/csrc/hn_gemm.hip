@@ -2222,7 +2222,9 @@ static int pick_bc(int Nout) {
 // 112-channel convs of the neck / det towers (64 < cout <= 128, a two-stage K loop) take the 64x64 tile up to 256 K rows (the training
 // step's 131 072 / 174 592-row maps): three or four small workgroups per CU hide each other's short load -> MFMA -> store chains better
 // than two 128x128 ones (712 -> 715 img/s); at the 1.1-1.5 M rows of the 32 x 1152 x 1920 inference maps the large tile wins (1053 vs 1045).
-long g_hn_knob[12] = {1024, 256, 1024, 512, 8192, 262144, 0, 0, 1, 0, 0, 0};
+// (knob 0, the TN split target: 1024 -> 2048 workgroups measured +0.75 % on the step -- 785 -> 791 img/s, tools/knob_sweep.sh: the
+// L2 -> LDS bound weight-gradient GEMMs want two full rounds of short K loops rather than one round of long ones)
+long g_hn_knob[12] = {2048, 256, 1024, 512, 8192, 262144, 0, 0, 1, 0, 0, 0};
 extern "C" int hn_debug_knob(int id, long value) { if (id < 0 || id >= 12) return HN_ERR_ARG; g_hn_knob[id] = value; return HN_OK; }
 static bool small_tile(long M, int Nout) { return !g_nt_force_bc && Nout > 64 && (M <= g_hn_knob[4] || (M <= g_hn_knob[5] && Nout <= 128)); }
 
