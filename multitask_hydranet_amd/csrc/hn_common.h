@@ -37,8 +37,8 @@ __device__ __forceinline__ bf16x8 zero8() {
 // split, 2 fused-BatchNorm apply-pass target workgroups, 3 fused reduce-pass row-block divisor, 4 / 5 pixel thresholds of the 64x64 GEMM tile,
 // 6 = 1: no two-K-group GEMM variant (> 1: its K threshold, default 512), 7 depthwise-backward block target, 8 = 0: fused passes without the
 // XCD row-order placement, 9 grouped-TN debug bits (skip stores / MFMAs / loads), 10 grouped-TN tile variant, 11 = 1: direct 3x3 kernel walks
-// the patches of one cout tile first (measured: no gain)
-extern long g_hn_knob[12];
+// the patches of one cout tile first (measured: no gain), 12 / 13 workgroup targets of the 3x3 patch weight-gradient / grouped-conv group plans
+extern long g_hn_knob[16];
 #define HN_ACT_NONE 0
 #define HN_ACT_RELU 1
 #define HN_ACT_SWISH 2

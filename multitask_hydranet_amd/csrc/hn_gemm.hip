@@ -2224,8 +2224,8 @@ static int pick_bc(int Nout) {
 // than two 128x128 ones (712 -> 715 img/s); at the 1.1-1.5 M rows of the 32 x 1152 x 1920 inference maps the large tile wins (1053 vs 1045).
 // (knob 0, the TN split target: 1024 -> 2048 workgroups measured +0.75 % on the step -- 785 -> 791 img/s, tools/knob_sweep.sh: the
 // L2 -> LDS bound weight-gradient GEMMs want two full rounds of short K loops rather than one round of long ones)
-long g_hn_knob[12] = {2048, 256, 1024, 512, 8192, 262144, 0, 0, 1, 0, 0, 0};
-extern "C" int hn_debug_knob(int id, long value) { if (id < 0 || id >= 12) return HN_ERR_ARG; g_hn_knob[id] = value; return HN_OK; }
+long g_hn_knob[16] = {2048, 256, 1024, 512, 8192, 262144, 0, 0, 1, 0, 0, 0, 256, 384, 0, 0};
+extern "C" int hn_debug_knob(int id, long value) { if (id < 0 || id >= 16) return HN_ERR_ARG; g_hn_knob[id] = value; return HN_OK; }
 static bool small_tile(long M, int Nout) { return !g_nt_force_bc && Nout > 64 && (M <= g_hn_knob[4] || (M <= g_hn_knob[5] && Nout <= 128)); }
 
 // partial statistic rows of a mode-5 (grouped 3x3 on the direct kernel) launch: one per 16x16 output patch
@@ -2551,7 +2551,7 @@ static int wgrad_plan_impl(int mode, int n_img, int H, int W, long M, int Nout, 
         if (phase_span && phase_span < bc) { bc = 64; ci = 64; ksplit = 2; }      // a cout tile must lie inside one phase
         const long tiles = (long)cdiv(Nout, bc) * cdiv(KP, ci);
         const long patches = (long)n_img * cdiv(H, 8) * cdiv(W, 16);
-        long want = (256 + tiles - 1) / tiles;          // one workgroup per CU in total: every split costs a full fp32 slab of dW (write + reduce)
+        long want = (g_hn_knob[12] + tiles - 1) / tiles;          // (knob 12 = 256) one workgroup per CU in total: every split costs a full fp32 slab of dW (write + reduce)
         // ... unless the slab is small: then two workgroups per CU (where their LDS fits) hide each other's DMA waits
         if (bc <= 64 && 2 * want * ksplit * (long)Nout * taps * KP * 4 <= (64L << 20)) want *= 2;
         if (want > patches / 2) want = patches / 2;
@@ -2780,7 +2780,7 @@ static int gconv_group_plan(const long* jobs, int njobs, int* psplits, long* pps
                      (jb[8] & 7) == 0 && jb[8] >= jb[6]);
         tiles += cdiv(jb[6], 64);
     }
-    long want = (384 + tiles - 1) / tiles;                  // ~1.5 workgroups per CU in total (78 KB of LDS each: two fit)
+    long want = (g_hn_knob[13] + tiles - 1) / tiles;                  // (knob 13 = 384) ~1.5 workgroups per CU in total (78 KB of LDS each: two fit)
     *ws_floats = 0;
     for (int i = 0; i < njobs; ++i) {
         const long* jb = jobs + 9 * i;

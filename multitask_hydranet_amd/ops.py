@@ -633,7 +633,7 @@ def k_eltwise(op, a, b=None, act=ACT_NONE, alpha=1.0, out=None):
 
 
 FUSED_BN = os.environ.get("HN_FUSED_BN", "1") != "0"   # BatchNorm finalize in the prologue of the consuming elementwise kernel (hn_fused.hip); False: round-1 kernels
-MAX_PROLOGUE_ROWS = 128    # partial rows a consumer prologue reduces itself (+1.5 us at 128 rows); more are folded to 32 rows first (one
+MAX_PROLOGUE_ROWS = int(os.environ.get("HN_MAX_PROLOGUE_ROWS", "128"))    # partial rows a consumer prologue reduces itself (+1.5 us at 128 rows); more are folded to 32 rows first (one
                            # ~5 us launch, only for the large early-stage tensors whose passes take 15-40 us anyway)
 
 
