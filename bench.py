@@ -361,6 +361,50 @@ def infer_bench(args, net, cfgs, h, w, dev, rank, world):
     emit(res)
 
 
+def other_exchange_form(run, net, cfgs, batch, dev, rank, world, payload, args, dt_primary, headline=None):
+    """Time the captured step with the gradient exchange in its other form (the headline used `run.reducer.graph_overlap`) -> dict with both
+    forms' ms per step (max over ranks).  Every rank runs a watchdog: if the second capture / replay does not come back within
+    HN_BENCH_FORM_TIMEOUT seconds (default 240), the process ends with exit code 0 after rank 0 has printed the headline line with
+    exchange_forms.error set -- a wedged collective must not cost the driver its measurement."""
+    import threading
+    primary = "graph_overlap" if run.reducer.graph_overlap else "in_line"
+    other = "in_line" if primary == "graph_overlap" else "graph_overlap"
+    res = {primary: {"ms_per_step": round(dt_primary / args.steps * 1e3, 3), "headline": True}}
+    done = threading.Event()
+    fallback = {"armed": True, "line": headline}      # rank 0: the finished headline line (printed by the watchdog if this wedges)
+
+    def watchdog():
+        if done.wait(float(os.environ.get("HN_BENCH_FORM_TIMEOUT", "240"))) or not fallback["armed"]:
+            return
+        if rank == 0 and fallback.get("line") is not None:
+            line = dict(fallback["line"])
+            line["exchange_forms"] = dict(res, **{other: {"error": "timed out (watchdog)"}})
+            emit(line)
+        os._exit(0)
+    th = threading.Thread(target=watchdog, daemon=True)
+    th.start()
+    try:
+        net.zero_grad(set_to_none=True)
+        run2 = TrainRun(net, cfgs, batch, dev, rank, world, "nccl", use_graph=True, exchange=True, force_world1=args.ddp_world1, payload=payload,
+                        graph_overlap=(other == "graph_overlap"))
+        if not run2.in_graph_exchange:
+            raise RuntimeError("the %s form was not captured" % other)
+        steps = max(3, min(args.steps, 10))
+        dt2, _ = time_replays(run2.step, steps, 2, world)
+        t = torch.tensor([dt2], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        res[other] = {"ms_per_step": round(float(t) / steps * 1e3, 3), "steps": steps, "grad_allreduce": run2.describe_exchange()}
+        del run2
+    except Exception as e:          # noqa: BLE001
+        res[other] = {"error": repr(e)[:300]}
+    finally:
+        fallback["armed"] = False
+        done.set()
+    return res
+
+
+
 _CAPTURE_STREAM = None
 
 
@@ -382,8 +426,9 @@ class TrainRun:
     """one configuration of the fwd + loss + bwd step: builds the (optionally DDP-exchanging) captured step and times it"""
 
     def __init__(self, net, cfgs, batch, dev, rank=0, world=1, backend="nccl", backbone_only=False, use_graph=True, exchange=False,
-                 force_world1=False, payload=torch.float32, exchange_after_replay=False):
+                 force_world1=False, payload=torch.float32, exchange_after_replay=False, graph_overlap=None):
         self.net, self.cfgs, self.batch, self.dev = net, cfgs, batch, dev
+        self._graph_overlap = graph_overlap         # None: GradReducer's default (in line; HN_DDP_GRAPH_OVERLAP=1: forked side stream)
         self.rank, self.world, self.backend = rank, world, backend
         self.backbone_only = backbone_only
         self.graph = self.static_loss = self.reducer = None
@@ -444,7 +489,7 @@ class TrainRun:
         if os.environ.get("HN_BUCKET_MB"):                                   # tools/ sweeps of the exchange granularity
             kw["bucket_bytes"] = int(float(os.environ["HN_BUCKET_MB"]) * (1 << 20))
         return self._GradReducer(list(self.net.named_parameters()), world_size=self.world, skip=self._skip, payload_dtype=self._payload,
-                                 force_collectives=self._force, **kw)
+                                 force_collectives=self._force, graph_overlap=self._graph_overlap, **kw)
 
     def fwd_bwd(self):
         net, batch = self.net, self.batch
@@ -651,6 +696,49 @@ def extra_configs(args, dev, headline_net, headline_cfgs):
     return res
 
 
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` (N > 1) started WITHOUT torch.distributed.run: start the N ranks as a CHILD process
+    (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same arguments>), relay what it
+    prints (rank 0's JSON line stays the last line) and return its exit code.  Called before this process touches the GPU: no HIP call,
+    no torch.cuda.is_available() has run (device_count() does not initialise the runtime), and the child is a child, never an exec."""
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n and os.environ.get("HN_BENCH_ONE_DEVICE") != "1":
+        print("bench.py --gpus %d: this node shows %d GPU(s); refusing to report a smaller run under that label" % (n, have), file=sys.stderr)
+        return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    last_json = None
+    for line in child.stdout:
+        if line.startswith("{") and '"metric"' in line:
+            if last_json is not None:
+                sys.stdout.write(last_json)
+            last_json = line
+        else:
+            sys.stdout.write(line)
+    rc = child.wait()
+    if last_json is not None:
+        sys.stdout.write(last_json if last_json.endswith("\n") else last_json + "\n")
+    sys.stdout.flush()
+    if rc == 0 and last_json is None:
+        print("bench.py: the %d-rank child printed no JSON line" % n, file=sys.stderr)
+        return 3
+    return rc
+
+
 # ------------------------------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
@@ -679,8 +767,13 @@ def main():
     h, w = (int(v) for v in args.res.split("x"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))                # N ranks as a child torch.distributed.run; nothing below runs in this process
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus or world == 1, "--gpus must equal WORLD_SIZE under torch.distributed.run"
+    if world != args.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to measure a different number of GPUs than the line would report"
+              % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # test hooks for a 1-GPU box: HN_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and HN_BENCH_BACKEND=gloo replaces RCCL (which refuses
     # two ranks on one device), so the whole N>1 control flow can be exercised without a second GPU.  Never set by the driver.
@@ -737,10 +830,21 @@ def main():
     dt, per = time_replays(step, args.steps, args.warmup, world)
     loss = run.static_loss if run.graph is not None else step()
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    per_rank_ms = [round(dt / args.steps * 1e3, 3)]
     if world > 1:
+        mine = torch.tensor([dt], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank_ms = [round(float(t) / args.steps * 1e3, 3) for t in every]
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
     loss_val = float(loss.detach())
+    # the OTHER captured exchange form on the same ranks: in line on the capture stream (default) vs forked onto the side
+    # stream (north_star's "overlapped with the next backward on a side HIP stream").  Timed after the headline so that it cannot disturb
+    # it; a watchdog on every rank ends the process with the headline line if a second capture of RCCL collectives wedges.
+    both_forms = exchange and backend == "nccl" and run.in_graph_exchange and not args.no_extras
+    if both_forms and rank != 0:
+        other_exchange_form(run, net, cfgs, batch, dev, rank, world, payload, args, dt)
     grad_norm = None
     if os.environ.get("HN_BENCH_GRAD_NORM"):        # tests: the gradients after the (possibly in-graph) exchange of the last step
         grad_norm = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in net.parameters() if p.grad is not None)))
@@ -777,6 +881,7 @@ def main():
             "config": {"workload": what + ", big cfg, fwd+loss+bwd", "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "resolution": "3x%dx%d" % (h, w), "parallelism": "dp%d" % world, "hipgraph": run.graph is not None,
                        "grad_allreduce": run.describe_exchange()},
+            **({"rccl_ranks": dist.get_world_size(), "per_rank_ms_per_step": per_rank_ms} if exchange else {}),
             "ms_optimizer_step": round(ms_opt, 3) if ms_opt is not None else None, "loss": round(loss_val, 4),
             **({"grad_norm": grad_norm} if grad_norm is not None else {}),
             "model_tflops": round(value * gflop_img / 1e3, 2),
@@ -801,6 +906,8 @@ def main():
                 res["cpu_baseline"] = cpu_baseline(yaml.safe_load(open(args.cfg)) | {"dataloader": cfgs["dataloader"]}, h, w)
             except Exception as e:  # noqa: BLE001
                 res["cpu_baseline"] = {"error": repr(e)}
+        if both_forms:
+            res["exchange_forms"] = other_exchange_form(run, net, cfgs, batch, dev, rank, world, payload, args, dt, headline=res)
         emit(res)
     if exchange and dist.is_initialized():
         dist.destroy_process_group()

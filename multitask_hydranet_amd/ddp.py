@@ -29,7 +29,6 @@ link busy while the backbone's backward (the longest part) is still running.
 """
 from __future__ import annotations
 
-import contextlib
 import os
 from typing import Iterable, List, Optional, Sequence
 
@@ -216,18 +215,18 @@ class GradReducer:
             b["keep"] = [p.grad for _, p in b["params"]]
         if capturing and not self.graph_overlap:
             # in line on the capture stream: gather, all-reduce (a synchronous collective runs on the current stream), landing copy.
-            # The hook runs on the stream its AccumulateGrad node was created on; when that is not the capture stream (nodes kept alive
-            # from earlier steps on another stream) the exchange is enqueued on the capture stream explicitly -- the gradients were
-            # produced there, so no extra dependency is needed -- instead of becoming a fork of the graph.
-            skip = os.environ.get("HN_DDP_DEBUG_SKIP", "")       # tools-only ablation of the captured exchange (never set in a real run)
+            # The hook runs on the stream its AccumulateGrad node was created on.  It must BE the capture stream: AccumulateGrad may do work
+            # of its own there (a deep copy of a gradient it cannot steal, `+=` for a second contribution), so an exchange enqueued on
+            # another stream would read p.grad unordered behind that work -- and would be a fork of the graph besides.  The
+            # caller keeps the two equal by capturing on the stream the warm-up steps ran on (bench.TrainRun._capture).
             cs = self.capture_stream
-            with (torch.cuda.stream(cs) if cs is not None and cs != torch.cuda.current_stream() else contextlib.nullcontext()):
-                if "gather" not in skip:
-                    self._gather(b)
-                if "allreduce" not in skip:
-                    self._allreduce_mean(b["flat"])
-                if b["land"] is not None:
-                    self._copy_many(b, "plan_land", b["land"], b["views"], 2)
+            if cs is not None and cs != torch.cuda.current_stream():
+                raise RuntimeError("GradReducer: a gradient hook fired on %r while the step is being captured on %r; run the eager warm-up "
+                                   "steps on the capture stream (torch.cuda.graph(g, stream=warmup_stream))" % (torch.cuda.current_stream(), cs))
+            self._gather(b)
+            self._allreduce_mean(b["flat"])
+            if b["land"] is not None:
+                self._copy_many(b, "plan_land", b["land"], b["views"], 2)
         elif self.stream is not None:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())

@@ -447,13 +447,15 @@ class GradQueue:
         for c0 in range(0, len(tail), self.MAX_TAIL):
             chunk = tail[c0:c0 + self.MAX_TAIL]
             tab = (ctypes.c_long * (8 * len(chunk)))()
+            done = []
             for i, (wts, kind, a, b, n0, n1, n2, shapes) in enumerate(chunk):
                 outs = [grad_out(wgt, shp, a.device, taken) for wgt, shp in zip(wts, shapes)]
                 tab[8 * i:8 * i + 8] = [kind, a.data_ptr(), b.data_ptr() if b is not None else 0, outs[0].data_ptr(),
                                         outs[1].data_ptr() if len(outs) > 1 else 0, n0, n1, n2]
-                for wgt, g in zip(wts, outs):
-                    put(wgt, g)
+                done += list(zip(wts, outs))
             lib().call("hn_grad_tail", ctypes.addressof(tab), len(chunk))
+            for wgt, g in done:         # only now: put() ADDS when a weight was queued more than once (per-level det towers), and the sum
+                put(wgt, g)             # must read what the launch above has written
         return [out.get(id(w)) for w in self.weights]
 
 

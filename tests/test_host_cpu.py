@@ -2,13 +2,14 @@
 include/hydranet_hip.h declares, the module reproduces the reference's state_dict contract, and the static-shape losses equal
 the oracle's per-image loops."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
 import torch
 
 from oracle import hydranet_oracle as O
-from tests.helpers import assert_close, load_cfg, load_npz
+from tests.helpers import ROOT, assert_close, load_cfg, load_npz
 
 
 @pytest.fixture(scope="module")
@@ -243,3 +244,19 @@ def test_conv_work_accounting_matches_survey_totals():
             assert abs(2 * wk[k]["macs"] / 1e9 - g) < 0.006, k
     fl = segment_floors_ms(cfgs, 512, 1024, 16)
     assert abs(sum(fl.values()) / 16 - 0.177) < 0.004 and fl["seg"] > fl["backbone"] > fl["det"] > fl["neck"] > fl["lane"]
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+    """`python bench.py --gpus 8` without torch.distributed.run must start its own 8 ranks or FAIL -- never measure one GPU and report it
+    (VERDICT r3 missing 1).  This container has no GPU: the parent refuses before touching the runtime, exit code 2, no JSON line."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "HN_BENCH_ONE_DEVICE")}
+    import torch
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("an 8-GPU node would run the bench")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"], capture_output=True,
+                       text=True, env=env, timeout=300)
+    assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+    assert not any(l.startswith("{") for l in r.stdout.splitlines())
+    assert "refusing" in r.stderr

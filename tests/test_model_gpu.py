@@ -641,3 +641,79 @@ def test_inference_highres_shapes():
     assert dep[1].shape == (1, A, 4) and dep[2].shape == (2, A, 4) and dep[3].shape == (2, A, 9)
     assert dep[4].shape == (2, (H // 32) * (W // 32), 2) and dep[5].shape == (2, (H // 32) * (W // 32), 2 * (H // 8) + 2)
     assert all(bool(torch.isfinite(t).all()) for t in dep[2:])
+
+
+@pytest.mark.gpu
+def test_inference_config5_batch32():
+    """BASELINE config 5 at its stated batch (model/demo.py:191-202 at 32 frames): 32 x 3x1152x1920, big cfg, folded BatchNorm, deploy
+    6-tuple.  Shapes / dtypes / finiteness of every output; the fused arg-max of the output conv == arg-max of the fp32 logits on a slice
+    of the batch; and, because BatchNorm is folded and nothing couples the images of an inference batch, images 5 and 31 of the N = 32
+    run equal the same two frames run as an N = 2 batch BIT FOR BIT (every kernel's per-image arithmetic is independent of N)."""
+    from multitask_hydranet_amd import HydraNet
+    from multitask_hydranet_amd.preprocess import preprocess_bgr
+    cfgs = load_cfg("hydranet_big.yml")
+    H, W, N = 1152, 1920, 32
+    cfgs["dataloader"]["network_input_height"], cfgs["dataloader"]["network_input_width"] = H, W
+    torch.manual_seed(0)
+    net = HydraNet(cfgs).cuda().eval().prepare_inference()
+    rs = np.random.RandomState(1)
+    x = torch.empty(N, 3, H, W, device="cuda")
+    for i in range(0, N, 4):                                 # 4 frames at a time: 24.9 MB of uint8 per chunk on the host
+        frames = rs.randint(0, 256, size=(4, 1080, 1920, 3)).astype(np.uint8)
+        x[i:i + 4] = torch.nn.functional.pad(preprocess_bgr(frames, (1080, 1920)), (0, 0, 36, 36))
+    pick = [5, 31]
+    with torch.no_grad():
+        dep = net(x, "deploy")
+        dep = [t.clone() for t in dep]
+        two = net(x[pick].contiguous(), "deploy")
+        logits = net(x[pick].contiguous())["seg"]
+    A = sum((H >> s) * (W >> s) for s in (3, 4, 5, 6, 7)) * 9
+    hw = (H // 32) * (W // 32)
+    assert dep[0].shape == (N, H, W) and dep[0].dtype == torch.int64
+    assert dep[1].shape == (1, A, 4) and dep[2].shape == (N, A, 4) and dep[3].shape == (N, A, 9)
+    assert dep[4].shape == (N, hw, 2) and dep[5].shape == (N, hw, 2 * (H // 8) + 2)
+    assert all(bool(torch.isfinite(t).all()) for t in dep[1:])
+    assert int(dep[0].min()) >= 0 and int(dep[0].max()) < len(cfgs["segment"]["class_list"])
+    assert float(dep[3].min()) >= 0.0 and float(dep[3].max()) <= 1.0
+    # the fused arg-max (never materialised logits) against arg-max of the logits, on the slice
+    assert torch.equal(two[0], torch.argmax(logits, 1))
+    # images are independent: the N = 32 rows of frames 5 and 31 == the N = 2 run, bit for bit
+    for k in (0, 2, 3, 4, 5):
+        assert torch.equal(dep[k][pick], two[k]), "output %d of the batch-32 run differs from the batch-2 run" % k
+    # no image of the batch is a copy of another (the batch index really reaches every kernel)
+    assert not torch.equal(dep[2][0], dep[2][1]) and not torch.equal(dep[0][7], dep[0][8])
+
+
+@pytest.mark.gpu
+def test_unpacked_det_towers_through_the_gradient_queue():
+    """with net.pack_det_levels = False a full training forward applies the shared depthwise weights of the det towers once PER
+    PYRAMID LEVEL while the deferred-gradient queue is active: five add_rows jobs per weight in one hn_grad_tail launch, whose results
+    GradQueue.flush must add AFTER the launch.  Whole-model forward + loss + backward, unpacked vs packed towers: every detectheader
+    gradient agrees (same arithmetic up to the BatchNorm partial-sum order)."""
+    import sys
+    from multitask_hydranet_amd import HydraNet
+    sys.path.insert(0, ROOT)
+    from bench import synthetic_batch
+    cfgs = load_cfg("hydranet_tiny.yml")
+    hh, ww, n = 256, 512, 4
+    cfgs["dataloader"]["network_input_height"], cfgs["dataloader"]["network_input_width"] = hh, ww
+    torch.manual_seed(3)
+    net = HydraNet(cfgs).cuda().train()
+    net.check_finite = False
+    net.lane_points_per_line = hh // cfgs["lane"]["interval"]
+    batch = synthetic_batch(cfgs, n, hh, ww, seed=2, device="cuda")
+    res = {}
+    for packed in (True, False):
+        net.pack_det_levels = packed
+        net.zero_grad(set_to_none=True)
+        ld = net.cal_loss(net(batch["image"]), batch)
+        net.total_loss(ld).backward()
+        res[packed] = {k: v.grad.clone() for k, v in net.named_parameters() if k.startswith("detectheader.") and v.grad is not None}
+    a, b = res[True], res[False]
+    assert set(a) == set(b) and len(a) > 10
+    dw = [k for k in a if "depthwise_conv" in k]
+    assert len(dw) >= 6
+    for k in a:
+        ref = float(a[k].abs().max())
+        err = float((a[k] - b[k]).abs().max()) / max(ref, 1e-12)
+        assert bool(torch.isfinite(b[k]).all()) and err <= 3e-2, (k, err, ref)

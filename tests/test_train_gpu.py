@@ -157,17 +157,27 @@ def test_two_rank_control_flow_on_one_gpu():
     if not torch.cuda.is_available():
         pytest.skip("needs the MI355X")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(root, "bench.py"), "--gpus", "2", "--no-cpu-baseline", "--no-optimizer", "--steps", "2", "--warmup", "1", "--batch", "2",
-           "--res", "256x512"]
+    tail = ["--gpus", "2", "--no-cpu-baseline", "--no-optimizer", "--steps", "2", "--warmup", "1", "--batch", "2", "--res", "256x512"]
     env = dict(os.environ, HN_BENCH_ONE_DEVICE="1", HN_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
-    assert r.returncode == 0, r.stderr[-3000:]
-    line = [l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1]
-    o = json.loads(line)
-    assert o["n_gpus"] == 2 and o["config"]["global_batch"] == 4 and o["config"]["parallelism"] == "dp2" and o["scaling"] == "weak"
-    assert "gloo" in o["config"]["grad_allreduce"]
-    assert o["value"] > 0 and o["loss"] == o["loss"]
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    # (1) the driver's N > 1 command line; (2) plain `python bench.py --gpus 2`: bench.py starts its own two ranks as a child process
+    for cmd in ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                 "--master-port", str(_free_port()), os.path.join(root, "bench.py")] + tail,
+                [sys.executable, os.path.join(root, "bench.py")] + tail):
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert r.stdout.strip().splitlines()[-1].startswith("{"), "the JSON line must be the last line on stdout"
+        o = json.loads(r.stdout.strip().splitlines()[-1])
+        assert o["n_gpus"] == 2 and o["config"]["global_batch"] == 4 and o["config"]["parallelism"] == "dp2" and o["scaling"] == "weak"
+        assert "gloo" in o["config"]["grad_allreduce"]
+        assert o["value"] > 0 and o["loss"] == o["loss"]
+        assert o["rccl_ranks"] == 2 and len(o["per_rank_ms_per_step"]) == 2
+    # a world size that does not match --gpus is refused (exit code 2, no JSON line) instead of measured under the wrong label
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(root, "bench.py")] + tail, capture_output=True, text=True, env=env,
+                       timeout=600)
+    assert r.returncode != 0 and not any(l.startswith("{") for l in r.stdout.splitlines())
 
 
 def test_fine_tuning_schedule_two_turns(setup):
