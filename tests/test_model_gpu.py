@@ -647,8 +647,12 @@ def test_inference_highres_shapes():
 def test_inference_config5_batch32():
     """BASELINE config 5 at its stated batch (model/demo.py:191-202 at 32 frames): 32 x 3x1152x1920, big cfg, folded BatchNorm, deploy
     6-tuple.  Shapes / dtypes / finiteness of every output; the fused arg-max of the output conv == arg-max of the fp32 logits on a slice
-    of the batch; and, because BatchNorm is folded and nothing couples the images of an inference batch, images 5 and 31 of the N = 32
-    run equal the same two frames run as an N = 2 batch BIT FOR BIT (every kernel's per-image arithmetic is independent of N)."""
+    of the batch.  BatchNorm is folded and nothing couples the images of an inference batch:
+      * the SAME frame at positions 5 and 31 of the batch gives the same outputs BIT FOR BIT (every kernel's per-image arithmetic is
+        independent of the image's position and of its neighbours);
+      * frames 5 and 9 run as an N = 2 batch agree with their rows of the N = 32 run to bf16 rounding -- not bit for bit: the 1x1 GEMMs
+        pick their tile (and with it the split of the contraction into two K groups) by the row count M = N H W, so the fp32 summation
+        order of a pixel depends on N (relative L2 <= 1e-2 on every float output, seg mask agreement >= 0.995)."""
     from multitask_hydranet_amd import HydraNet
     from multitask_hydranet_amd.preprocess import preprocess_bgr
     cfgs = load_cfg("hydranet_big.yml")
@@ -661,7 +665,8 @@ def test_inference_config5_batch32():
     for i in range(0, N, 4):                                 # 4 frames at a time: 24.9 MB of uint8 per chunk on the host
         frames = rs.randint(0, 256, size=(4, 1080, 1920, 3)).astype(np.uint8)
         x[i:i + 4] = torch.nn.functional.pad(preprocess_bgr(frames, (1080, 1920)), (0, 0, 36, 36))
-    pick = [5, 31]
+    x[31] = x[5]
+    pick = [5, 9]
     with torch.no_grad():
         dep = net(x, "deploy")
         dep = [t.clone() for t in dep]
@@ -677,11 +682,16 @@ def test_inference_config5_batch32():
     assert float(dep[3].min()) >= 0.0 and float(dep[3].max()) <= 1.0
     # the fused arg-max (never materialised logits) against arg-max of the logits, on the slice
     assert torch.equal(two[0], torch.argmax(logits, 1))
-    # images are independent: the N = 32 rows of frames 5 and 31 == the N = 2 run, bit for bit
+    # the same frame at two positions of the batch: bit for bit
     for k in (0, 2, 3, 4, 5):
-        assert torch.equal(dep[k][pick], two[k]), "output %d of the batch-32 run differs from the batch-2 run" % k
-    # no image of the batch is a copy of another (the batch index really reaches every kernel)
-    assert not torch.equal(dep[2][0], dep[2][1]) and not torch.equal(dep[0][7], dep[0][8])
+        assert torch.equal(dep[k][31], dep[k][5]), "output %d differs between two copies of one frame inside the batch" % k
+    # no other image of the batch is a copy (the batch index really reaches every kernel)
+    assert not torch.equal(dep[2][0], dep[2][1]) and not torch.equal(dep[0][7], dep[0][8]) and not torch.equal(dep[2][5], dep[2][9])
+    # N = 32 rows against the N = 2 run
+    agree = float((dep[0][pick] == two[0]).float().mean())
+    assert agree >= 0.995, agree
+    for k in (2, 3, 4, 5):
+        assert l2err(dep[k][pick], two[k]) <= 1e-2, (k, l2err(dep[k][pick], two[k]))
 
 
 @pytest.mark.gpu
