@@ -809,6 +809,9 @@ def main():
         for kv in os.environ["HN_KNOBS"].split(","):
             k, v = kv.split("=")
             lib().query("hn_debug_knob", int(k), int(v))
+    if os.environ.get("HN_DIRECT_PIPE"):             # tools/ A/B: 0 = two-buffer tap loop of the direct 3x3 conv, 1 = 32-channel ring form
+        from multitask_hydranet_amd._lib import lib
+        lib().query("hn_debug_direct_pipe", int(os.environ["HN_DIRECT_PIPE"]))
     if os.environ.get("HN_HEADS_SIDE") == "1":       # experiment hook: det + lane heads on a side stream (a hipGraph branch) next to the seg decoder
         net.heads_on_side_stream = True
     if args.dominant_only:

@@ -16,7 +16,10 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 HEADER = os.path.join(_ROOT, "include", "hydranet_hip.h")
 CSRC = os.path.join(_PKG, "csrc")
-SO_PATH = os.path.join(_PKG, "libhydranet_hip.so")
+# HN_TUNING=1 (tools/ only): a second build with -DHN_TUNING -- the kernels' ablation bits, in-kernel stamps and the never-shipped template
+# instantiations behind hn_debug_knob / hn_debug_* -- as libhydranet_hip_tuning.so.  The product library is built without any of it.
+TUNING = os.environ.get("HN_TUNING") == "1"
+SO_PATH = os.path.join(_PKG, "libhydranet_hip_tuning.so" if TUNING else "libhydranet_hip.so")
 SOURCES = ["hn_gemm.hip", "hn_norm.hip", "hn_fused.hip", "hn_stencil.hip", "hn_loss.hip", "hn_post.hip"]
 
 _ERR = {1: "bad argument", 2: "kernel launch failure", 3: "unsupported shape"}
@@ -62,9 +65,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     objs = []
     procs = []
     for s in srcs:
-        o = os.path.join(CSRC, os.path.basename(s).replace(".hip", ".o"))
+        o = os.path.join(CSRC, os.path.basename(s).replace(".hip", ".tuning.o" if TUNING else ".o"))
         objs.append(o)
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-c", s, "-o", o]
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17"] + (["-DHN_TUNING"] if TUNING else []) + ["-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -11,6 +11,14 @@
 #include "hn_common.h"
 #include <climits>
 
+// Ablation bits / stamps of the tools/ scripts (hn_debug_knob 9 / 14 / 15): compiled into the kernels only with -DHN_TUNING
+// (HN_TUNING=1 builds libhydranet_hip_tuning.so: multitask_hydranet_amd/_lib.py); the shipped library's kernels carry none of it.
+#ifdef HN_TUNING
+#define HN_DBG(p) ((p).dbg)
+#else
+#define HN_DBG(p) 0
+#endif
+
 struct XSrc {
     const bf16* x0;
     const bf16* x1;
@@ -113,6 +121,10 @@ __device__ __forceinline__ void glds16(const bf16* src, char* lds_wave_base) {
 }
 
 __device__ __forceinline__ int swz(int row, int piece) { return row * 128 + ((piece ^ (row & 7)) << 4); }
+// 64-byte LDS rows (32 bf16) read by ds_read_b128 with lane & 15 = 16 consecutive rows (offset 0..2) and lane >> 4 = the 16-byte piece:
+// physical piece = piece ^ pswz32(row).  The four lane groups of a ds_read_b128 ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...) then touch
+// 16 distinct 16-byte bank slots each (checked exhaustively for row offsets 0..2: tools/lds_swizzle_check.py).
+__device__ __forceinline__ int pswz32(int row) { return (row >> 1) & 2; }
 
 struct GemmNT {
     XSrc x;
@@ -160,6 +172,9 @@ struct GemmNT {
     int emode; const bf16* ez; int ld_ez; const float* ecoef;
     int tile_major;                   // direct kernel: block id order (see there)
     int wpre;                         // direct kernel: all weight tiles of the (single) chunk preloaded, one LDS slot per tap step
+    unsigned long long* dbg_buf;      // tools/ only: stamp buffer (hn_debug_knob 15)
+    int dbg;                          // tools/ only (hn_debug_knob 14; HN_TUNING builds): direct kernel ablation bits: 1 = no epilogue, 2 = no MFMAs,
+                                      // 4 = no operand DMA after the first tile, 8 = no LDS fragment reads
 };
 
 // one pixel x 4 consecutive channels of the statistics epilogue (GemmNT::emode); cf = (sc, sh, mu, rs) of the 4 channels
@@ -629,15 +644,17 @@ __global__ __launch_bounds__(256 * KG) void gemm_nt_kernel(const GemmNT p) {
 //   current chunk's taps) and a ring of three weight tiles with counted s_waitcnt vmcnt (the tile of tap step i+2 is issued before the
 //   MFMAs of step i, so two tile loads are always in flight); up to 256 VGPRs (no scratch spills).
 template <int BC, bool OUT_F32, bool PIPE>
-__global__ __launch_bounds__(512, PIPE ? 2 : 4) void conv3x3_direct_kernel(const GemmNT p) {
-    constexpr int XBUFS = PIPE ? 2 : 1, WBUFS = PIPE ? 3 : 2;
+__global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) {
+    constexpr int KC = PIPE ? 32 : 64;                                // channels per K chunk
+    constexpr int NPP = KC / 8, PB = KC * 2;                          // 16-byte pieces / bytes per pixel (or weight) row of a chunk in LDS
+    constexpr int XBUFS = PIPE ? 2 : 1, WBUFS = PIPE ? 4 : 2;
     constexpr int WCO = BC >= 64 ? 64 : BC;                           // couts per wave
     constexpr int WGC = BC / WCO, WGP = 8 / WGC, ROWS = 16 / WGP;     // rows of the patch per wave
     constexpr int TC = WCO / 16, TP = ROWS;
-    // X buffer padded to whole 1 KiB DMA runs (PIPE: to whole 512-thread rounds, so that every wave issues the same number of loads and
-    // the counted waits hold for all of them)
-    constexpr int PPIX = 18 * 18, XL = (PPIX * 8 + 511) / 512, WL = (BC * 8 + 511) / 512;
-    constexpr int XBYTES = PIPE ? XL * 512 * 16 : (PPIX * 128 + 1023) / 1024 * 1024, WBYTES = BC * 128;
+    // X buffer padded to whole 1 KiB DMA runs (PIPE: X and W buffers padded to whole 512-thread rounds, so that every wave issues the
+    // same number of loads and the counted waits hold for all of them)
+    constexpr int PPIX = 18 * 18, XL = (PPIX * NPP + 511) / 512, WL = (BC * NPP + 511) / 512;
+    constexpr int XBYTES = PIPE ? XL * 512 * 16 : (PPIX * 128 + 1023) / 1024 * 1024, WBYTES = PIPE ? WL * 512 * 16 : BC * 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];       // X patch x2 | W tile x2
     char* sXb = smem;
     char* sWb = smem + XBUFS * XBYTES;
@@ -647,6 +664,13 @@ __global__ __launch_bounds__(512, PIPE ? 2 : 4) void conv3x3_direct_kernel(const
     const int ncy = (p.Nout + BC - 1) / BC;
     const int tx_n = (xs.W + 15) >> 4, ty_n = (xs.H + 15) >> 4;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    // tools/ only (knob 14 bit 16 + knob 15 = buffer): s_memtime stamps of every 64th workgroup's wave 0: [0] start, [1] loop entry,
+    // [2 + it] after the barrier of iteration it, then loop end and kernel end
+    unsigned long long* stampb = (HN_DBG(p) & 16) && (blockIdx.x & 63) == 0 && tid == 0
+                                     ? reinterpret_cast<unsigned long long*>(p.dbg_buf) + (blockIdx.x >> 6) * 128 : nullptr;
+    int stampi = 0;
+    auto stamp = [&]() { if (stampb && stampi < 128) stampb[stampi++] = __builtin_amdgcn_s_memtime(); };
+    stamp();
     // block id -> (cout tile, patch).  p.tile_major = 0: the cout tiles of a patch are neighbours (an XCD works on a contiguous range of
     // patches with ALL cout tiles: the patch is read once into its L2, the whole weight tensor must stay there); 1: a cout tile's patches
     // are neighbours (an XCD works on few cout tiles -- their weights stay L2-hot for the per-tap tile streams -- and reads every patch)
@@ -662,44 +686,59 @@ __global__ __launch_bounds__(512, PIPE ? 2 : 4) void conv3x3_direct_kernel(const
     const int org = xs.mode == 2 ? -1 : -2;                           // patch origin relative to the output tile
     const int Ctot = xs.C0 + xs.C1;
     const int NT = p.phase_mode ? 4 : 9;                              // taps visited per 64-channel chunk
-    const int nchunk = xs.diag ? 1 : (p.KP + 63) >> 6, S = nchunk * NT;
+    const int nchunk = xs.diag ? 1 : (p.KP + KC - 1) / KC, S = nchunk * NT;
     const int Ktot = 9 * p.KP;
     const int tile_phase = p.phase_mode == 1 ? c_blk / p.phase_span : 0;
-    auto tap_of = [&](int chunk, int ti) {
-        if (!p.phase_mode) return ti;
-        const int ph = p.phase_mode == 1 ? tile_phase : (chunk * 64) / p.phase_span;
-        return ((ph >> 1) + (ti >> 1)) * 3 + (ph & 1) + (ti & 1);
+    // Loop bookkeeping without integer divisions: a cursor (chunk, tap index, phase) advanced by compare-and-wrap.  (Stamps of the round-3
+    // loop -- tools/stamp_seg.py -- showed ~2500 cycles per tap step with the DMA, the LDS reads and the MFMAs all ablated: st / NT,
+    // st % wslots, (chunk * 64) / phase_span and the per-read swizzle arithmetic, replicated in 16 waves per CU, cost more VALU issue
+    // time than the step's 1024 MFMA cycles.)
+    const int cpp = p.phase_mode == 2 ? p.phase_span / KC : 0;        // chunks per phase (data gradient: the K chunk's phase)
+    struct Cur { int chunk, ti, ph, cnt; };
+    auto cur0 = [&]() { Cur c; c.chunk = 0; c.ti = 0; c.ph = tile_phase; c.cnt = 0; return c; };
+    auto adv = [&](Cur& c) {
+        if (++c.ti == NT) {
+            c.ti = 0;
+            ++c.chunk;
+            if (p.phase_mode == 2 && ++c.cnt == cpp) { c.cnt = 0; ++c.ph; }
+        }
     };
+    auto tap_at = [&](const Cur& c) { return p.phase_mode ? ((c.ph >> 1) + (c.ti >> 1)) * 3 + (c.ph & 1) + (c.ti & 1) : c.ti; };
     const int xc0 = xs.diag ? c_blk : 0;                              // first input channel of chunk 0
 
     // patch pieces owned by this thread: e = tid + 512 i -> patch pixel e>>3, PHYSICAL piece e&7 (logical = physical ^ (patch column & 7)).
     // One register per piece: the source pixel as (gy << 16 | gx) in full-resolution coordinates (-1: outside / zero); the row index in
     // either operand and the channel sub-offset are recomputed when the load is issued (this kernel sits at the 128-VGPR limit of two
     // co-resident workgroups: three registers per piece cost 12 spilled VGPRs = 52 B/lane of scratch traffic).
+    // (bits 13-15: the LOGICAL 16-byte piece of the chunk this thread's physical LDS piece holds -- the swizzle resolved once; gx < 8192)
     int spack[XL];
 #pragma unroll
     for (int i = 0; i < XL; ++i) {
-        const int pp = (tid + 512 * i) >> 3;
+        const int e = tid + 512 * i;
+        const int pp = e / NPP;
         spack[i] = -1;
         if (pp < PPIX) {
             const int py = pp / 18, px = pp - py * 18;
+            const int sub = PIPE ? ((e & 3) ^ pswz32(px)) : ((e & 7) ^ (px & 7));
             int gy = oy0 + org + py, gx = ox0 + org + px;
             if (xs.mode == 2) {
                 gy = border_idx(gy, xs.Hi, xs.clamp);
                 gx = border_idx(gx, xs.Wi, xs.clamp);
-                if (gy >= 0 && gx >= 0) spack[i] = (gy << 16) | gx;   // (negative only for pixels that feed no in-image output)
+                if (gy >= 0 && gx >= 0) spack[i] = (gy << 16) | (sub << 13) | gx;   // (negative only for pixels that feed no in-image output)
             } else if (gy >= 0 && gy < xs.Hi && gx >= 0 && gx < xs.Wi) {
-                spack[i] = (gy << 16) | gx;
+                spack[i] = (gy << 16) | (sub << 13) | gx;
             }
         }
     }
-    // weight pieces: row = (tid>>3) + 64 i, physical piece tid&7
-    const int wsub = (((tid & 7) ^ ((tid >> 3) & 7)) << 3);
+    // weight pieces: row = (tid>>3) + 64 i, physical piece tid&7 (32-channel chunks: row = (tid>>2) + 128 i, physical piece tid&3; the
+    // swizzle of 64-byte rows is pswz32 below)
+    const int wsub = PIPE ? (((tid & 3) ^ pswz32(tid >> 2)) << 3) : (((tid & 7) ^ ((tid >> 3) & 7)) << 3);
     int wrow[WL];                                                      // element offset of the thread's weight row (32-bit: Nout * 9 * KP < 2^31)
 #pragma unroll
     for (int i = 0; i < WL; ++i) {
-        const int co = c_blk + (tid >> 3) + 64 * i;
-        wrow[i] = ((tid >> 3) + 64 * i < BC && co < p.Nout) ? co * Ktot + wsub : -1;
+        const int r = tid / NPP + (512 / NPP) * i;                    // (512 / NPP is a multiple of 8: the row's swizzle key is that of tid)
+        const int co = c_blk + r;
+        wrow[i] = (r < BC && co < p.Nout) ? co * Ktot + wsub : -1;
     }
 
     f32x4 acc[TC][TP];
@@ -708,30 +747,39 @@ __global__ __launch_bounds__(512, PIPE ? 2 : 4) void conv3x3_direct_kernel(const
 #pragma unroll
         for (int j = 0; j < TP; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // stage st = chunk * 9 + tap.  Iteration `it` issues the DMA of stage `it` (+ the X patch of its chunk when tap == 0) and multiplies
-    // stage `it - 1`.
-    // weight-tile slots: two (three: PIPE) recycled ones, or -- p.wpre, single-chunk convs whose S tiles all fit -- one slot per tap step
-    const int wslots = p.wpre ? 16 : WBUFS;
-    auto compute = [&](int st) {
-        const int chunk = st / NT, tap = tap_of(chunk, st - chunk * NT);
+    // per-lane LDS read offsets, hoisted out of the tap loop: A rows i * 16 + (lane & 15) of the weight tile, B patch columns
+    // (lane & 15) + dx for the three tap columns; the second K half of a 128-byte row is the first one's address ^ 64
+    const int aofs = PIPE ? (wc * WCO + (lane & 15)) * PB + (((lane >> 4) ^ pswz32(lane & 15)) << 4) : swz(wc * WCO + (lane & 15), lane >> 4);
+    int bofs[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int pc = (lane & 15) + d;
+        bofs[d] = (wp * ROWS * 18 + pc) * PB + (PIPE ? (((lane >> 4) ^ pswz32(pc)) << 4) : (((lane >> 4) ^ (pc & 7)) << 4));
+    }
+
+    // stage = (chunk, tap).  Iteration `it` issues the DMA of stage `it` (+ the X patch of its chunk when tap == 0) and multiplies
+    // stage `it - 1`.  Weight-tile slots: two (four: PIPE) recycled ones, or -- p.wpre, single-chunk convs whose S tiles all fit -- one
+    // slot per tap step
+    auto compute = [&](const Cur& c, int slot) {
+        const int tap = tap_at(c);
         const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
         const int dy = xs.mode == 2 ? ky : 2 - ky, dx = xs.mode == 2 ? kx : 2 - kx;
-        const char* sW = sWb + (st % wslots) * WBYTES;
-        const char* sX = sXb + (XBUFS == 2 ? (chunk & 1) : 0) * XBYTES;
-        // The 16-byte pieces of a patch pixel are XOR-swizzled by its patch COLUMN (not its pixel index): a wave's 16 lanes read 16
-        // consecutive columns of one row, so the reads stay bank-conflict free, and the rows of a wave tile (j) and of a tap (dy) differ
-        // by constant byte offsets -- one LDS address per (tap column, K half) instead of one per read (was 3.8 VALU instructions per MFMA).
-        const int pxk = ((lane & 15) + dx) & 7;
+        // (integer offsets into the LDS arrays, never pointer <-> integer casts: those make the reads flat_load instead of ds_read.
+        // The second K half of a 128-byte row = the first one's offset ^ 64, and adding multiples of 128 commutes with that.)
+        const int wo = slot * WBYTES + aofs;
+        const int xo = (XBUFS == 2 ? (c.chunk & 1) : 0) * XBYTES + dy * (18 * PB) + (dx == 0 ? bofs[0] : (dx == 1 ? bofs[1] : bofs[2]));
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < KC / 32; ++ks) {
             bf16x8 a[TC], b[TP];
-            const int piece = ks * 4 + (lane >> 4);
+            const int wk = ks ? (wo ^ 64) : wo, xk = ks ? (xo ^ 64) : xo;
 #pragma unroll
-            for (int i = 0; i < TC; ++i) a[i] = *reinterpret_cast<const bf16x8*>(sW + swz(wc * WCO + i * 16 + (lane & 15), piece));
+            for (int i = 0; i < TC; ++i) a[i] = (HN_DBG(p) & 8) ? zero8() : *reinterpret_cast<const bf16x8*>(sWb + wk + i * 16 * PB);
 #pragma unroll
-            for (int j = 0; j < TP; ++j) {
-                const int pidx = (wp * ROWS + j + dy) * 18 + (lane & 15) + dx;
-                b[j] = *reinterpret_cast<const bf16x8*>(sX + pidx * 128 + ((piece ^ pxk) << 4));
+            for (int j = 0; j < TP; ++j) b[j] = (HN_DBG(p) & 8) ? zero8() : *reinterpret_cast<const bf16x8*>(sXb + xk + j * 18 * PB);
+            if (HN_DBG(p) & 2) {
+#pragma unroll
+                for (int i = 0; i < (TC < TP ? TC : TP); ++i) asm volatile("" :: "v"(a[i]), "v"(b[i]));
+                continue;
             }
 #pragma unroll
             for (int i = 0; i < TC; ++i)
@@ -740,32 +788,32 @@ __global__ __launch_bounds__(512, PIPE ? 2 : 4) void conv3x3_direct_kernel(const
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     };
-    auto issue_w = [&](int st) {
-        const int chunk = st / NT, tap = tap_of(chunk, st - chunk * NT);
-        const int k0 = chunk * 64;
-        char* sW = sWb + (st % wslots) * WBYTES;
+    auto issue_w = [&](const Cur& c, int slot, int seq) {
+        if ((HN_DBG(p) & 4) && seq >= WBUFS) return;
+        const int k0 = c.chunk * KC;
+        const int koff = tap_at(c) * p.KP + k0;                        // (uniform)
+        char* sW = sWb + slot * WBYTES;
 #pragma unroll
         for (int i = 0; i < WL; ++i) {
-            if (wave * 8 + 64 * i < BC) {                              // wave-uniform (all waves for BC >= 64)
-                const bf16* src = (wrow[i] >= 0 && k0 + wsub < p.KP) ? p.w + wrow[i] + tap * p.KP + k0 : g_zero_piece;
-                glds16(src, sW + (wave * 8 + 64 * i) * 128);
+            if (PIPE || wave * 8 + 64 * i < BC) {                      // wave-uniform (PIPE: every wave issues every round, padded tile)
+                const bf16* src = (wrow[i] >= 0 && k0 + wsub < p.KP) ? p.w + wrow[i] + koff : g_zero_piece;
+                glds16(src, sW + (512 * i + 64 * wave) * 16);
             }
         }
     };
     auto issue_x = [&](int chunk) {
-        const int k0 = chunk * 64;
+        if ((HN_DBG(p) & 4) && chunk >= XBUFS) return;
+        const int k0 = chunk * KC;
         char* sX = sXb + (XBUFS == 2 ? (chunk & 1) : 0) * XBYTES;
 #pragma unroll
         for (int i = 0; i < XL; ++i) {
             if (PIPE || 512 * i + 64 * wave < PPIX * 8) {              // PIPE: every wave issues all XL rounds (padded buffer)
-                const int e = tid + 512 * i;
-                const int ppx = (e >> 3) % 18;                         // patch column of this piece's pixel: the swizzle key
-                const int c = xc0 + k0 + ((((e & 7) ^ (ppx & 7))) << 3);
                 const bf16* src = g_zero_piece;
                 int pk = spack[i];
                 asm volatile("" : "+v"(pk));                          // keep the 64-bit row pointers out of loop-invariant registers
+                const int c = xc0 + k0 + (((pk >> 13) & 7) << 3);
                 if (c < Ctot && pk >= 0) {
-                    const int gy = pk >> 16, gx = pk & 0xffff;
+                    const int gy = pk >> 16, gx = pk & 0x1fff;
                     if (c < xs.C0) src = xs.x0 + c + (long)((n * (xs.Hi >> xs.up) + (gy >> xs.up)) * (xs.Wi >> xs.up) + (gx >> xs.up)) * xs.ld0;
                     else src = xs.x1 + (c - xs.C0) + (long)((n * xs.Hi + gy) * xs.Wi + gx) * xs.ld1;
                 }
@@ -773,15 +821,18 @@ __global__ __launch_bounds__(512, PIPE ? 2 : 4) void conv3x3_direct_kernel(const
             }
         }
     };
+    stamp();
     if (!PIPE && p.wpre) {
         // Single 64-channel chunk and few tap steps (the phase-form output convs: 4 steps): the patch and ALL weight tiles are requested
         // together and the tap loop runs without barriers or DMA waits -- such a workgroup lived for ~14 us of which the four
         // barrier-separated weight-tile round trips were a third.
         issue_x(0);
-        for (int st = 0; st < S; ++st) issue_w(st);
+        Cur ci = cur0();
+        for (int st = 0; st < S; ++st) { issue_w(ci, st, 0); adv(ci); }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        for (int st = 0; st < S; ++st) compute(st);
+        Cur cc = cur0();
+        for (int st = 0; st < S; ++st) { compute(cc, st); adv(cc); }
     } else if (BC == 64 && !PIPE && xs.diag) {
         // Grouped conv (group width 8) as block-diagonal 64 x 64 tiles: of the 8 KB weight tile of a tap only the eight 8 x 8 diagonal
         // blocks (1 KB) are non-zero.  All nine taps' blocks (9 KB: [tap][cout 64][8 ci]) are fetched ONCE next to the patch, and the A
@@ -826,50 +877,66 @@ __global__ __launch_bounds__(512, PIPE ? 2 : 4) void conv3x3_direct_kernel(const
             }
         }
     } else if (PIPE) {
-        static_assert(!PIPE || BC >= 64, "the counted waits need every wave to issue the same number of weight loads");
+        // 32-channel chunks: two patch buffers + a ring of four 8 KB weight tiles = 80 KB: still two workgroups per CU, and now with the
+        // loads of the next three tap steps (and of the next chunk's patch) in flight under COUNTED waits -- the two-buffer loop below
+        // waits for a DMA round trip (vmcnt(0)) at every tap step and for the patch at every chunk boundary.
+        //   iteration i: everything up to W(i) has landed (in-order completion: the loads issued after W(i) may stay in flight);
+        //   barrier: every wave is done with step i - 1, so ring slot (i - 1) % R and (at a chunk's first step) the other patch buffer
+        //   are free; issue X(chunk + 1) / W(i + R - 1); multiply step i.
+        constexpr int R = WBUFS;
         issue_x(0);
-        issue_w(0);
-        if (S > 1) issue_w(1);
-        bool x_prev = false;                                           // did the previous iteration issue a patch (before its weight tile)?
+        Cur ci = cur0(), cc = cur0();
+        int si = 0;                                                    // ring slot of the next weight tile to issue (= its step % R)
+        for (int s0 = 0; s0 < R - 1 && s0 < S; ++s0) { issue_w(ci, si, s0); adv(ci); si = si + 1 == R ? 0 : si + 1; }
+        unsigned xhist = 0;                                            // bit k: iteration i - 1 - k issued a patch
+        int sc = 0;                                                    // ring slot of step i
         for (int i = 0; i < S; ++i) {
-            // everything up to and including the weight tile of step i has landed; what the previous iteration issued may stay in flight
-            const bool w_next = i + 1 < S;
-            if (w_next && x_prev) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(WL + XL) : "memory");
-            else if (w_next) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(WL) : "memory");
-            else if (x_prev) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(XL) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            const int chunk = i / NT, ti = i - chunk * NT;
-            x_prev = ti == 0 && chunk + 1 < nchunk;
-            if (x_prev) issue_x(chunk + 1);                            // its buffer was last read by the previous chunk's last tap
-            if (i + 2 < S) issue_w(i + 2);                             // its ring slot was last read by step i - 1
-            compute(i);
-        }
-    } else
-    for (int it = 0; it <= S; ++it) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        // single patch buffer: at a chunk boundary the last tap of the old chunk is multiplied BEFORE the new patch may overwrite it
-        const bool boundary = XBUFS == 1 && it > 0 && it < S && (it % NT) == 0;
-        if (boundary) {
-            compute(it - 1);
-            __syncthreads();
-        }
-        if (it < S) {
-            const int chunk = it / NT, ti = it - chunk * NT, tap = tap_of(chunk, ti);
-            const int k0 = chunk * 64;
-            char* sW = sWb + (it & 1) * WBYTES;
-#pragma unroll
-            for (int i = 0; i < WL; ++i) {
-                if (wave * 8 + 64 * i < BC) {                          // wave-uniform
-                    const bf16* src = (wrow[i] >= 0 && k0 + wsub < p.KP) ? p.w + wrow[i] + tap * p.KP + k0 : g_zero_piece;
-                    glds16(src, sW + (wave * 8 + 64 * i) * 128);
-                }
+            const int nw = min(R - 2, S - 1 - i);                      // weight tiles issued after W(i)
+            const int nx = __builtin_popcount(xhist & ((1u << (R - 2)) - 1u));   // patches issued after W(i) (iterations i-R+2 .. i-1)
+            switch (nw * WL + nx * XL) {
+                case 0: asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); break;
+                case WL: asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(WL) : "memory"); break;
+                case 2 * WL: asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * WL) : "memory"); break;
+                case XL: asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(XL) : "memory"); break;
+                case WL + XL: asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(WL + XL) : "memory"); break;
+                case 2 * WL + XL: asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * WL + XL) : "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); break;
             }
-            if (ti == 0) issue_x(chunk);
+            stamp();
+            const bool xi = cc.ti == 0 && cc.chunk + 1 < nchunk;
+            if (xi) issue_x(cc.chunk + 1);                             // its buffer was last read by the previous chunk's last tap
+            if (i + R - 1 < S) { issue_w(ci, si, i + R - 1); adv(ci); si = si + 1 == R ? 0 : si + 1; }   // slot last read by step i - 1
+            xhist = (xhist << 1) | (xi ? 1u : 0u);
+            compute(cc, sc);
+            adv(cc);
+            sc = sc + 1 == R ? 0 : sc + 1;
         }
-        if (it > 0 && !boundary) compute(it - 1);
+    } else {
+        Cur ci = cur0(), cc = cur0();
+        for (int it = 0; it <= S; ++it) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            stamp();
+            // single patch buffer: at a chunk boundary the last tap of the old chunk is multiplied BEFORE the new patch may overwrite it
+            const bool boundary = XBUFS == 1 && it > 0 && it < S && ci.ti == 0;
+            if (boundary) {
+                compute(cc, (it - 1) & 1);
+                adv(cc);
+                __syncthreads();
+            }
+            if (it < S) {
+                issue_w(ci, it & 1, it);
+                if (ci.ti == 0) issue_x(ci.chunk);
+                adv(ci);
+            }
+            if (it > 0 && !boundary) {
+                compute(cc, (it - 1) & 1);
+                adv(cc);
+            }
+        }
     }
 
+    stamp();
     // optional BatchNorm partial statistics of the bf16-rounded outputs: one row per workgroup (patch), psum/psq [gridDim.x / ncy][Nout];
     // wave sums by DPP row rotations, the WGP pixel-row groups are folded through LDS (the operand buffers are free now)
     // (only the grouped convs -- block-diagonal 64-cout tiles -- are launched with statistics rows)
@@ -922,6 +989,15 @@ __global__ __launch_bounds__(512, PIPE ? 2 : 4) void conv3x3_direct_kernel(const
         }
     }
 
+    if (HN_DBG(p) & 1) {                                                   // ablation: one store keeps the accumulators alive
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < TC; ++i)
+#pragma unroll
+            for (int j = 0; j < TP; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (t == 12345.678f) reinterpret_cast<float*>(p.out)[0] = t;
+        return;
+    }
     // epilogue: bias, activation (one uniform branch per 4 values, in place on the accumulators: no second copy of the wave tile in
     // registers), store 4 consecutive couts per lane
     const int ox = ox0 + (lane & 15);
@@ -937,12 +1013,94 @@ __global__ __launch_bounds__(512, PIPE ? 2 : 4) void conv3x3_direct_kernel(const
                            ((32 * p.d2s) & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0;
     char* stage = smem;
     if (stage_d2s || stage_f32) __syncthreads();                      // every wave is done with the operand buffers
+    // phase form with a pre-activation addend (the skip operand's partial result): all TC x TP loads of a lane are requested up front.
+    // Issued one by one inside the loop below each was a dependent round trip: the stamps show 26 000 cycles for this epilogue, a
+    // quarter of the workgroup's lifetime, against 16 x 3 400 cycles for all of its tap steps (tools/stamp_seg.py).
+    const bool pre_add = !OUT_F32 && p.d2s && p.addend;
+    bf16x4 addq[3][TP];                                               // ring: cout sub-tiles i (in use), i + 1 and i + 2 (in flight)
+    auto load_add = [&](int i, bf16x4 (&dst)[TP]) {
+        const int co0 = c_blk + wc * WCO + i * 16 + (lane >> 4) * 4;
+        const int ph = co0 / p.d2s, oc = co0 - ph * p.d2s;
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            const int oy = oy0 + wp * ROWS + j;
+            const long opix = ((long)(n * 2 * xs.H + 2 * oy + (ph >> 1)) * (2 * xs.W) + 2 * ox + (ph & 1));
+            dst[j] = (oy < xs.H && ox < xs.W && co0 < p.Nout) ? *reinterpret_cast<const bf16x4*>(p.addend + opix * p.ld_add + oc)
+                                                              : (bf16x4){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+        }
+    };
+    if (pre_add) {                                                     // three of the TC = 4 rounds in flight from the start: the
+        load_add(0, addq[0]);                                          // addend comes from HBM (2-3 us under load), one round trip is
+        if (TC > 1) load_add(1, addq[1]);                              // exposed instead of four
+        if (TC > 2) load_add(2, addq[2]);
+    }
+    if constexpr (BC >= 64 && !OUT_F32) {
+        // (the host entry point only launches these instantiations when the staged form applies: stage_d2s is true)
+        // Compact form of the staged bf16 epilogue (every seg-decoder launch with >= 64 couts per tile): bias and addend are added in
+        // place on the accumulators, the activation is ONE uniform branch around all 16 * TC * TP / 4 values, then the tile is rounded
+        // and staged.  The generic epilogue below re-decides activation and store form inside each of its TC x TP unrolled bodies: 10 000
+        // instructions (80 KB: more than the instruction cache two CUs share), and the stamps showed 17 000 cycles for an epilogue
+        // without a single global load (tools/stamp_seg.py) -- instruction fetch, not arithmetic.
+#pragma unroll
+        for (int i = 0; i < TC; ++i) {
+            const int co0 = c_blk + wc * WCO + i * 16 + (lane >> 4) * 4;
+            f32x4 bs;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bs[r] = (p.bias && co0 + r < p.Nout) ? p.bias[co0 + r] : 0.f;
+#pragma unroll
+            for (int j = 0; j < TP; ++j) acc[i][j] += bs;
+            if (pre_add) {
+#pragma unroll
+                for (int j = 0; j < TP; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] += bf2f(addq[i % 3][j][r]);
+                if (i + 3 < TC) load_add(i + 3, addq[i % 3]);
+            }
+        }
+        if (p.act == HN_ACT_ELU) {
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int j = 0; j < TP; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const float x = acc[i][j][r]; acc[i][j][r] = x > 0.f ? x : (__expf(x) - 1.0f); }
+        } else if (p.act != HN_ACT_NONE) {
+            const int act = p.act;
+#pragma unroll 1
+            for (int k = 0; k < 4; ++k) {                              // (rare: any other activation, small code)
+#pragma unroll
+                for (int i = 0; i < TC; ++i)
+#pragma unroll
+                    for (int j = 0; j < TP; ++j) {
+                        float x = acc[i][j][0];                        // rotate the lane's 4 values through element 0: no dynamic index
+                        x = act_fwd(x, act);
+                        acc[i][j] = (f32x4){acc[i][j][1], acc[i][j][2], acc[i][j][3], x};
+                    }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TC; ++i) {
+            const int cl = wc * WCO + i * 16 + (lane >> 4) * 4;
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                const int pl = (wp * ROWS + j) * 16 + (lane & 15);
+                const bf16x4 tv = {f2bf(acc[i][j][0]), f2bf(acc[i][j][1]), f2bf(acc[i][j][2]), f2bf(acc[i][j][3])};
+                *reinterpret_cast<bf16x4*>(stage + pl * (BC * 2) + ((((cl >> 3) ^ pl) & (BC / 8 - 1)) << 4) + (cl & 7) * 2) = tv;
+            }
+        }
+    } else
 #pragma unroll
     for (int i = 0; i < TC; ++i) {
         const int co0 = c_blk + wc * WCO + i * 16 + (lane >> 4) * 4;
         float bsv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) bsv[r] = (p.bias && co0 + r < p.Nout) ? p.bias[co0 + r] : 0.f;
+        bf16x4 addv[TP];
+        if (pre_add) {
+#pragma unroll
+            for (int j = 0; j < TP; ++j) addv[j] = addq[i % 3][j];
+            if (i + 3 < TC) load_add(i + 3, addq[i % 3]);
+        }
 #pragma unroll
         for (int j = 0; j < TP; ++j) {
             const int oy = oy0 + wp * ROWS + j;
@@ -958,11 +1116,10 @@ __global__ __launch_bounds__(512, PIPE ? 2 : 4) void conv3x3_direct_kernel(const
                     const int ph = co0 / p.d2s, oc = co0 - ph * p.d2s;
                     const long opix = ((long)(n * 2 * xs.H + 2 * oy + (ph >> 1)) * (2 * xs.W) + 2 * ox + (ph & 1));
                     if (p.addend) {
-                        // (plain load: the four cout sub-tiles of a lane touch the same 128-byte lines one after the other -- a
+                        // (plain loads: the four cout sub-tiles of a lane touch the same 128-byte lines one after the other -- a
                         // non-temporal load re-fetched them from memory every time: 2x FETCH_SIZE, 128 -> 178 us)
-                        const bf16x4 a = *reinterpret_cast<const bf16x4*>(p.addend + opix * p.ld_add + oc);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += bf2f(a[r]);
+                        for (int r = 0; r < 4; ++r) v[r] += bf2f(addv[j][r]);
                     }
                     act_fwd_n(v, p.act);
                     bf16x4 tv = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
@@ -1046,6 +1203,7 @@ __global__ __launch_bounds__(512, PIPE ? 2 : 4) void conv3x3_direct_kernel(const
             }
         }
     }
+    stamp();
     if (stage_d2s) {
         __syncthreads();
         constexpr int NPC = BC / 8;                                   // 16-byte pieces per output pixel
@@ -1103,6 +1261,8 @@ __global__ __launch_bounds__(512, PIPE ? 2 : 4) void conv3x3_direct_kernel(const
                 *reinterpret_cast<bf16x8*>(outp + opix * p.ldc + oc0 + pc * 8) = v;
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp();
     }
 }
 
@@ -1226,7 +1386,7 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTN& p, const int lid) {  
     for (int it = 0; it <= S; ++it) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's LDS-DMA of stage it-1 has landed ...
         __syncthreads();                                           // ... and so has everybody else's; buffer it&1 is free again
-        if (it < S && !(p.dbg & 4)) {
+        if (it < S && !(HN_DBG(p) & 4)) {
             char* sZ = smem + (it & 1) * STAGE;
             char* sX = sZ + ZB;
             const long m0 = m_begin + (long)it * 64;
@@ -1272,7 +1432,7 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTN& p, const int lid) {  
                 }
             }
         }
-        if (it > 0 && !(p.dbg & 2)) {
+        if (it > 0 && !(HN_DBG(p) & 2)) {
             const char* sZ = smem + ((it - 1) & 1) * STAGE;
             const char* sX = sZ + ZB;
 #pragma unroll
@@ -1316,7 +1476,7 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTN& p, const int lid) {  
             }
     }
     const int Ktot = p.taps * p.KP;
-    if (p.dbg & 1) return;
+    if (HN_DBG(p) & 1) return;
     const int row_ld = p.out_ld ? p.out_ld : Ktot, ci_lim = p.out_ld ? p.cin_lim : p.KP;
     float* part = p.part + (long)bz * p.Nout * Ktot;
 #pragma unroll
@@ -1398,7 +1558,7 @@ __device__ __forceinline__ void gemm_tn_ring_body(const GemmTN& p, const int lid
             else if (R >= 3 && newer >= 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(G) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         }
-        if (it < S && !(p.dbg & 4)) {
+        if (it < S && !(HN_DBG(p) & 4)) {
             char* sZ = smem + (it % R) * STAGE;
             char* sX = sZ + ZB;
             const long m0 = m_begin + (long)it * BK;
@@ -1425,7 +1585,7 @@ __device__ __forceinline__ void gemm_tn_ring_body(const GemmTN& p, const int lid
                 }
             }
         }
-        if (it >= R - 1 && !(p.dbg & 2)) {
+        if (it >= R - 1 && !(HN_DBG(p) & 2)) {
             const char* sZ = smem + ((it - (R - 1)) % R) * STAGE;
             const char* sX = sZ + ZB;
 #pragma unroll
@@ -1454,7 +1614,7 @@ __device__ __forceinline__ void gemm_tn_ring_body(const GemmTN& p, const int lid
             }
         }
     }
-    if (p.dbg & 1) return;
+    if (HN_DBG(p) & 1) return;
     const int row_ld = p.out_ld ? p.out_ld : p.KP, ci_lim = p.out_ld ? p.cin_lim : p.KP;
     float* part = p.part + (long)bz * p.Nout * p.KP;
 #pragma unroll
@@ -2349,6 +2509,8 @@ static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img
     p.emode = g_next_stat.mode; p.ez = g_next_stat.z; p.ld_ez = g_next_stat.ldz; p.ecoef = g_next_stat.coef;
     p.tile_major = g_hn_knob[11] == 1 ? 1 : 0;
     p.wpre = 0;
+    p.dbg = (int)g_hn_knob[14];
+    p.dbg_buf = reinterpret_cast<unsigned long long*>(g_hn_knob[15]);
     p.fold = g_next_fold.ring ? 1 : 0; p.ring = g_next_fold.ring; p.fold_y = g_next_fold.y; p.ld_fy = g_next_fold.ldy;
     if (img_stride < 0) {                                            // mode 4: -img_stride = channels per depth-to-space output pixel
         HN_CHECK_ARG(p.x.clamp == 1 && (out_f32 || phase_mode == 1) && rpi == 0 && !psum && Nout == 4 * (int)(-img_stride));
@@ -2356,15 +2518,21 @@ static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img
         p.img_stride = 0;
     }
     if (mode >= 2 && (!psum || p.x.diag) && !rpi) {      // statistics epilogue: grouped convs only (one partial row per 16x16 patch)
+        HN_CHECK_ARG(p.x.Wi < 8192 && p.x.Hi < 32768);  // packed patch coordinates of the direct kernel
         int bc = p.x.diag ? 64 : (Nout <= 16 ? 16 : (Nout <= 32 ? 32 : (Nout <= 64 ? 64 : 128)));
         if (phase_mode == 1 && phase_span < bc) bc = 64;            // a cout tile must lie inside one phase
+        // bf16 tiles of >= 64 couts leave through the LDS-staged epilogue only (whole 16-byte pieces of aligned rows)
+        const bool staged_ok = (ldc & 7) == 0 && (Nout & 7) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
+                               (!p.d2s || ((p.d2s & 7) == 0 && Nout % bc == 0));
+        if (bc >= 64 && !out_f32 && !staged_ok) return HN_ERR_UNSUPPORTED;
         dim3 grid((unsigned)(cdiv(Nout, bc) * cdiv(W, 16) * cdiv(H, 16) * n_img));
-        // software-pipelined variant (one workgroup per CU, 3 weight tiles + 2 patch buffers): the bf16 launches with >= 64 couts per tile
-        const bool pipe = g_direct_pipe && bc >= 64 && !out_f32;
         // preloaded form: one chunk, all its tap tiles (<= 16) in at most 32 KB next to the patch (two or three workgroups per CU as before)
         const int nsteps = phase_mode ? 4 : 9;
-        p.wpre = (!pipe && !p.x.diag && KP <= 64 && (size_t)nsteps * bc * 128 <= 32768 && g_hn_knob[11] != 2) ? 1 : 0;
-        const size_t lds = pipe ? (size_t)2 * (((18 * 18 * 8 + 511) / 512) * 512 * 16) + 3 * (size_t)bc * 128
+        p.wpre = (!p.x.diag && KP <= 64 && (size_t)nsteps * bc * 128 <= 32768 && g_hn_knob[11] != 2) ? 1 : 0;
+        // software-pipelined variant (32-channel chunks, two patch buffers + ring of four weight tiles, counted waits; still two workgroups
+        // per CU): the multi-chunk bf16 launches with >= 64 couts per tile
+        const bool pipe = g_direct_pipe && bc >= 64 && !out_f32 && !p.x.diag && !p.wpre && KP > 64;
+        const size_t lds = pipe ? (size_t)2 * (((18 * 18 * 4 + 511) / 512) * 512 * 16) + 4 * (size_t)(512 * 16)
                                 : (size_t)((18 * 18 * 128 + 1023) / 1024 * 1024) + (p.wpre ? nsteps : 2) * (size_t)bc * 128;
         // > 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel (done on the first, un-captured call)
         static std::atomic<unsigned long long> optin{0};
@@ -2482,7 +2650,7 @@ extern "C" int hn_conv3x3_dgrad_fold(const void* dz, int ldz, int Cz, int n_img,
                                      int clamp, void* out, int ldo, const void* yprev, int ldy, void* ring, hipStream_t st) {
     HN_CHECK_ARG(dz && wt && out && ring && n_img > 0 && (ldo & 7) == 0 && (!yprev || (ldy & 7) == 0) && (clamp == 0 || clamp == 1));
     HN_CHECK_ARG(phase_k == 0 || (Cz == 4 * phase_k && phase_k % 64 == 0));
-    if ((Nout & 7) || Nout <= 32 || H < 4 || W < 4 || g_direct_pipe || (reinterpret_cast<uintptr_t>(out) & 15)) return HN_ERR_UNSUPPORTED;
+    if ((Nout & 7) || Nout <= 32 || H < 4 || W < 4 || (reinterpret_cast<uintptr_t>(out) & 15)) return HN_ERR_UNSUPPORTED;
     g_next_fold = {(bf16*)ring, (const bf16*)yprev, ldy};
     const int rc = conv_gemm_nt_impl(dz, nullptr, 3, n_img, H + 2, W + 2, Cz, 0, ldz, 0, 0, (long)n_img * (H + 2) * (W + 2), wt, Nout, KP, 9,
                                      nullptr, HN_ACT_NONE, out, 0, ldo, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, 0,

@@ -50,4 +50,4 @@ for name, c0, c1, k, h, w, up in LAYERS:
             line += f" | phase fwd x1 {t1:.0f} + x0 {t2:.0f} ({flops/(t1+t2)/1e6:.0f} TF alg) dgrad-x0 {t3:.0f}"
         line += " ||"
     print(line, flush=True)
-lib().query("hn_debug_direct_pipe", 1)
+lib().query("hn_debug_direct_pipe", 0)

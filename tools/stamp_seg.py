@@ -1,0 +1,43 @@
+"""s_memtime stamps of the dominant seg-decoder launch (decoder.3 phase form): per-iteration cycle counts of every 64th workgroup's wave 0."""
+import sys, os, torch
+os.environ["HN_TUNING"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as g
+g.build()
+from multitask_hydranet_amd import ops as K
+from multitask_hydranet_amd._lib import lib
+
+dev = torch.device("cuda:0")
+N, c0, k, h, w = 16, 256, 256, 32, 64
+x0 = torch.randn(N, h, w, c0, device=dev).to(torch.bfloat16)
+wt = torch.randn(k, c0, 3, 3, device=dev) * 0.02
+bias = torch.zeros(4 * k, device=dev)
+T = K._phase_matrix(dev)
+w_eff = (wt.reshape(k * c0, 9) @ T.t()).view(k, c0, 2, 2, 3, 3).permute(2, 3, 0, 1, 4, 5).reshape(4 * k, c0, 3, 3).contiguous()
+wpe, wte = K.pack_conv_weight(w_eff)
+out = torch.empty(N, 2 * h, 2 * w, k, device=dev, dtype=torch.bfloat16)
+z1 = torch.randn(N, 2 * h, 2 * w, k, device=dev).to(torch.bfloat16)
+ADD = os.environ.get("NO_ADDEND") != "1"
+run = lambda: lib().call("hn_conv3x3_phase", x0.data_ptr(), 4, N, h, w, c0, c0, wpe.data_ptr(), 4 * k, K.kp32(c0), bias.data_ptr(), 3,
+                         out.data_ptr(), k, k, z1.data_ptr() if ADD else None, k)
+buf = torch.zeros(64 * 128, device=dev, dtype=torch.int64)
+for pipe in (0,):
+    lib().query("hn_debug_direct_pipe", pipe)
+    for _ in range(20):
+        run()
+    torch.cuda.synchronize()
+    for dbg in (16,):
+        buf.zero_()
+        lib().query("hn_debug_knob", 15, buf.data_ptr())
+        lib().query("hn_debug_knob", 14, dbg)
+        run()
+        torch.cuda.synchronize()
+        lib().query("hn_debug_knob", 14, 0)
+        b = buf.view(64, 128).cpu()
+        print(f"--- pipe{pipe} dbg {dbg} (cycles at 100 MHz s_memtime? -> deltas)")
+        t0 = int(b[:16, 0][b[:16, 0] > 0].min())
+        for blk in (0, 3, 8, 15):
+            row = [int(v) for v in b[blk] if int(v) > 0]
+            d = [row[i + 1] - row[i] for i in range(len(row) - 1)]
+            print(f"blk {blk * 64}: start+{row[0] - t0} total {row[-1] - row[0]} | prologue {d[0]} | iters {d[1:-2]} | tail {d[-2:]}")
+lib().query("hn_debug_direct_pipe", 0)
