@@ -1684,7 +1684,11 @@ __global__ __launch_bounds__(64 * WGC * WGN, 2) void gemm_tn_group_kernel(const 
 // only shifts which patch pixels the transposed reads pick up), so the bytes per FLOP drop ~5x against the row-gather wgrad above.
 // 512 threads = 8 waves = (BC/64 cout groups) x (CI/16 ci groups); wave tile = 64 couts x 16 ci x 9 taps (144 accumulator VGPRs).
 // ---------------------------------------------------------------------------------------------------------
-template <int BC, int CI>
+// PH = 1: phase-form conv (GemmTN::phase_span): the cout tile's phase (py, px) only has the taps ky in {py, py+1}, kx in {px, px+1} --
+// four accumulators per cout sub-tile instead of nine, and no per-tap branch: with the tap loop fully unrolled and branch-free the
+// compiler requests the B fragments of every tap ahead of the MFMAs (the masked nine-tap loop exposed one LDS round trip per tap:
+// decoder.3's weight gradient ran 8 700 cycles per patch against 2 048 cycles of MFMA work, 24 % MFMA busy in profiles/r03).
+template <int BC, int CI, int PH>
 __device__ __forceinline__ void wgrad3x3_patch_body(const GemmTN& p, const int patches_per_split, const int n_patches, const int lid) {
     constexpr int WCO = BC >= 64 ? 64 : BC, TC = WCO / 16;
     constexpr int WGC = BC / WCO, WGN = CI / 16, KSPLIT = 8 / (WGC * WGN);   // KSPLIT > 1: waves also split the patch's k-steps
@@ -1710,11 +1714,13 @@ __device__ __forceinline__ void wgrad3x3_patch_body(const GemmTN& p, const int p
     const int S = pe > pb ? pe - pb : 0;
     const int Ctot = xs.C0 + xs.C1;
 
-    f32x4 acc[TC][9];
+    constexpr int NTAP = PH ? 4 : 9;
+    const int ph_ = PH ? c_blk / p.phase_span : 0, ph_y = ph_ >> 1, ph_x = ph_ & 1;
+    f32x4 acc[TC][NTAP];
 #pragma unroll
     for (int i = 0; i < TC; ++i)
 #pragma unroll
-        for (int t = 0; t < 9; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NTAP; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // bias gradient: the first input-channel tile's wn == 0 waves also multiply their dZ fragments with ones (every output column of
     // that MFMA is the fragment's pixel sum)
     const bool do_bias = p.bias_part && bx == 0 && wn == 0;
@@ -1724,14 +1730,6 @@ __device__ __forceinline__ void wgrad3x3_patch_body(const GemmTN& p, const int p
     bf16x8 ones;
 #pragma unroll
     for (int k = 0; k < 8; ++k) ones[k] = (bf16)1.0f;
-    unsigned tapmask = 0x1ffu;
-    if (p.phase_span) {
-        const int ph = c_blk / p.phase_span, py = ph >> 1, px = ph & 1;
-        tapmask = 0;
-        for (int a = 0; a < 2; ++a)
-            for (int b = 0; b < 2; ++b) tapmask |= 1u << ((py + a) * 3 + px + b);
-    }
-
     const int g = lane >> 4, t16 = lane & 15, q = t16 >> 2, pp = t16 & 3;
     typedef __bf16 trv4 __attribute__((__vector_size__(4 * sizeof(__bf16))));
     typedef __attribute__((address_space(3))) trv4* lds_b4;
@@ -1797,17 +1795,19 @@ __device__ __forceinline__ void wgrad3x3_patch_body(const GemmTN& p, const int p
                     for (int i = 0; i < TC; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], ones, accb[i], 0, 0, 0);
                 }
                 const int bpiece = (wn * 16) / 8 + (pp >> 1);
+                bf16x8 b[NTAP];
 #pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    if (!((tapmask >> tap) & 1u)) continue;            // workgroup-uniform
-                    const int ky = tap / 3, kx = tap - 3 * ky;
+                for (int t = 0; t < NTAP; ++t) {
+                    const int ky = PH ? ph_y + (t >> 1) : t / 3, kx = PH ? ph_x + (t & 1) : t - 3 * (t / 3);
                     const int plo = (2 * ks + ky) * 18 + kx + g * 4 + q, phi = plo + 18;
                     const trv4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(sX + plo * XROW + tn_swz<CI>(plo, bpiece) * 16 + (pp & 1) * 8));
                     const trv4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(sX + phi * XROW + tn_swz<CI>(phi, bpiece) * 16 + (pp & 1) * 8));
-                    const bf16x8 b = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-                    for (int i = 0; i < TC; ++i) acc[i][tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b, acc[i][tap], 0, 0, 0);
+                    b[t] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
+#pragma unroll
+                for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+                    for (int i = 0; i < TC; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[t], acc[i][t], 0, 0, 0);
             }
         }
     }
@@ -1828,18 +1828,33 @@ __device__ __forceinline__ void wgrad3x3_patch_body(const GemmTN& p, const int p
 #pragma unroll
         for (int i = 0; i < TC; ++i)
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap)
+            for (int t = 0; t < NTAP; ++t) {
+                const int tap = PH ? (ph_y + (t >> 1)) * 3 + ph_x + (t & 1) : t;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int co = c_blk + wc * WCO + i * 16 + (lane >> 4) * 4 + r;
-                    if (co < p.Nout) part[(long)co * Ktot + tap * p.KP + ci] = acc[i][tap][r];
+                    if (co < p.Nout) part[(long)co * Ktot + tap * p.KP + ci] = acc[i][t][r];
                 }
+            }
+        if (PH) {                                                      // the five taps outside the phase: zeros in the slab (the reduce sums all nine)
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap - 3 * ky;
+                if ((unsigned)(ky - ph_y) < 2u && (unsigned)(kx - ph_x) < 2u) continue;   // workgroup-uniform
+#pragma unroll
+                for (int i = 0; i < TC; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int co = c_blk + wc * WCO + i * 16 + (lane >> 4) * 4 + r;
+                        if (co < p.Nout) part[(long)co * Ktot + tap * p.KP + ci] = 0.f;
+                    }
+            }
+        }
     }
 }
 
-template <int BC, int CI>
+template <int BC, int CI, int PH = 0>
 __global__ __launch_bounds__(512) void wgrad3x3_patch_kernel(const GemmTN p, int patches_per_split, int n_patches) {
-    wgrad3x3_patch_body<BC, CI>(p, patches_per_split, n_patches, xcd_remap(blockIdx.x, gridDim.x));
+    wgrad3x3_patch_body<BC, CI, PH>(p, patches_per_split, n_patches, xcd_remap(blockIdx.x, gridDim.x));
 }
 
 // The grouped 3x3 (group width 8) weight gradients of a whole backbone stage in one launch (hn_gconv_wgrad_group): per XBlock this
@@ -1858,7 +1873,7 @@ __global__ __launch_bounds__(512) void gconv_wgrad_group_kernel(const PJobs jobs
     p.x.ld0 = jb.ldx; p.x.ld1 = 0; p.x.up = 0; p.x.M = (long)jb.n_img * jb.H * jb.W; p.x.clamp = 2; p.x.diag = 1;
     p.dz = jb.dz; p.ldz = jb.ldz; p.Nout = jb.C; p.KP = 64; p.taps = 9; p.part = jb.part; p.rows_per_split = jb.pps; p.gy = jb.gy;
     p.phase_span = 0; p.bias_part = nullptr; p.out_ld = 0; p.cin_lim = 0; p.dbg = 0;
-    wgrad3x3_patch_body<64, 64>(p, jb.pps, jb.n_patches, glid - jb.first_block);
+    wgrad3x3_patch_body<64, 64, 0>(p, jb.pps, jb.n_patches, glid - jb.first_block);
 }
 
 // dbias[co] = sum over the slabs of bias_part[slab][co]: done by the first ceil(Nout / 64) workgroups of whichever reduce kernel follows
@@ -3047,9 +3062,10 @@ static int conv_gemm_tn_impl(const void* x0, const void* x1, int mode, int n_img
     if (dbias) p.bias_part = workspace + (long)splits * Nout * taps * KP;
     if (use_patch_wgrad(mode, Nout, KP)) {
         static std::atomic<unsigned long long> optin{0};
-        if (!lds_optin(optin, {(const void*)wgrad3x3_patch_kernel<128, 64>, (const void*)wgrad3x3_patch_kernel<64, 128>,
-                               (const void*)wgrad3x3_patch_kernel<16, 64>, (const void*)wgrad3x3_patch_kernel<64, 64>,
-                               (const void*)wgrad3x3_patch_kernel<32, 64>, (const void*)wgrad3x3_patch_kernel<128, 32>}))
+        if (!lds_optin(optin, {(const void*)wgrad3x3_patch_kernel<128, 64>, (const void*)wgrad3x3_patch_kernel<16, 64>,
+                               (const void*)wgrad3x3_patch_kernel<64, 64>, (const void*)wgrad3x3_patch_kernel<32, 64>,
+                               (const void*)wgrad3x3_patch_kernel<128, 32>, (const void*)wgrad3x3_patch_kernel<128, 64, 1>,
+                               (const void*)wgrad3x3_patch_kernel<64, 64, 1>, (const void*)wgrad3x3_patch_kernel<128, 32, 1>}))
             return HN_ERR_LAUNCH;
         int pbc, pci, ksplit;
         patch_tiles(Nout, KP, pbc, pci, ksplit);
@@ -3061,6 +3077,9 @@ static int conv_gemm_tn_impl(const void* x0, const void* x1, int mode, int n_img
         const size_t xb = (size_t)((180 * (pci / 8) + 511) / 512) * 512 * 16;
         const size_t lds = 2 * ((size_t)((128 * pbc * 2 + 1023) / 1024 * 1024) + xb);
         if (grouped) hipLaunchKernelGGL((wgrad3x3_patch_kernel<64, 64>), grid, dim3(512), lds, st, p, (int)rps, patches);
+        else if (phase_span && pbc == 128 && pci == 32) hipLaunchKernelGGL((wgrad3x3_patch_kernel<128, 32, 1>), grid, dim3(512), lds, st, p, (int)rps, patches);
+        else if (phase_span && pbc == 128) hipLaunchKernelGGL((wgrad3x3_patch_kernel<128, 64, 1>), grid, dim3(512), lds, st, p, (int)rps, patches);
+        else if (phase_span) hipLaunchKernelGGL((wgrad3x3_patch_kernel<64, 64, 1>), grid, dim3(512), lds, st, p, (int)rps, patches);   // (phase_span >= 64)
         else if (pbc == 128 && pci == 32) hipLaunchKernelGGL((wgrad3x3_patch_kernel<128, 32>), grid, dim3(512), lds, st, p, (int)rps, patches);
         else if (pbc == 128) hipLaunchKernelGGL((wgrad3x3_patch_kernel<128, 64>), grid, dim3(512), lds, st, p, (int)rps, patches);
         else if (pbc == 64) hipLaunchKernelGGL((wgrad3x3_patch_kernel<64, 64>), grid, dim3(512), lds, st, p, (int)rps, patches);
