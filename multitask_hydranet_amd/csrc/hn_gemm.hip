@@ -669,7 +669,13 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
     unsigned long long* stampb = (HN_DBG(p) & 16) && (blockIdx.x & 63) == 0 && tid == 0
                                      ? reinterpret_cast<unsigned long long*>(p.dbg_buf) + (blockIdx.x >> 6) * 128 : nullptr;
     int stampi = 0;
-    auto stamp = [&]() { if (stampb && stampi < 128) stampb[stampi++] = __builtin_amdgcn_s_memtime(); };
+    auto stamp = [&]() {
+#ifdef HN_TUNING
+        __builtin_amdgcn_sched_barrier(0);
+        if (stampb && stampi < 128) stampb[stampi++] = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+    };
     stamp();
     // block id -> (cout tile, patch).  p.tile_major = 0: the cout tiles of a patch are neighbours (an XCD works on a contiguous range of
     // patches with ALL cout tiles: the patch is read once into its L2, the whole weight tensor must stay there); 1: a cout tile's patches

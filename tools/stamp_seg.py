@@ -39,5 +39,5 @@ for pipe in (0,):
         for blk in (0, 3, 8, 15):
             row = [int(v) for v in b[blk] if int(v) > 0]
             d = [row[i + 1] - row[i] for i in range(len(row) - 1)]
-            print(f"blk {blk * 64}: start+{row[0] - t0} total {row[-1] - row[0]} | prologue {d[0]} | iters {d[1:-2]} | tail {d[-2:]}")
+            print(f"blk {blk * 64}: start+{row[0] - t0} total {row[-1] - row[0]} | prologue {d[0]} | iters {d[1:-5]} | tail {d[-5:]}")
 lib().query("hn_debug_direct_pipe", 0)
