@@ -464,6 +464,13 @@ int hn_lane_decode_nms(const float* predict_cls, const float* predict_loc, int N
  * INTER_LINEAR fixed-point form for 8-bit images) -> RGB -> (v/255 - mean)/std -> fp32 [N][3][Hd][Wd]. */
 int hn_preprocess_bgr(const void* src, int N, int Hs, int Ws, float* dst, int Hd, int Wd, hipStream_t stream);
 
+/* Segmentation overlay = SegmentHeader.decode (head_seg/segmentation.py:107-125; deploy/src/model/hydranet_model.cpp:758) after the
+ * arg-max: mask int64 [N][H][W] -> colour LUT uint8 [ncls][3] (ids without a colour stay black) -> cv2.resize to the frame size (the
+ * reference passes cv2.INTER_NEAREST in the `dst` position, so the resize is the default 8-bit INTER_LINEAR) -> cv2.addWeighted(frame,
+ * 0.8, colours, 0.5, 0) with float32 arithmetic, round-half-even, saturation.  frames / out: uint8 [N][Ho][Wo][3]. */
+int hn_seg_overlay(const long* mask, int N, int H, int W, const void* lut, int ncls, const void* frames, void* out, int Ho, int Wo,
+                   hipStream_t stream);
+
 /* Streaming confusion counts for the segmentation mIoU (head_seg/seg_metrics.py:12-47): conf uint64 [(C+1)*(C+1)] += counts of
  * (pred, target) pairs, both clamped to C (the ignore bucket).  pred int64 [M]; target int64 or float32 [M]. */
 int hn_seg_confusion(const long* pred, const void* target, int target_is_float, long M, int C, void* conf, hipStream_t stream);

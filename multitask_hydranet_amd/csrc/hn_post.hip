@@ -430,3 +430,66 @@ extern "C" int hn_seg_confusion(const long* pred, const void* target, int target
                        M, C, (unsigned long long*)conf);
     HN_LAUNCH_CHECK();
 }
+
+// =====================================================================================================================================
+// 5. segmentation overlay (SegmentHeader.decode, head_seg/segmentation.py:107-125; C++ twin deploy/src/model/hydranet_model.cpp:758):
+//    class ids -> colour LUT -> 8-bit bilinear resize to the frame size -> saturating blend 0.8 * frame + 0.5 * colours.
+//    The reference calls cv2.resize(vis_seg, org_size, cv2.INTER_NEAREST): the third POSITIONAL parameter of cv2.resize is `dst`, so the
+//    flag never reaches `interpolation` and the resize runs with the default INTER_LINEAR -- restated here in cv2's fixed-point form
+//    (lin_coef above, as in the pre-processing kernel).  cv2.addWeighted on 8-bit images: float32 arithmetic, round half to even,
+//    saturate.  cv2 is absent from this image: parity of both steps is UNPINNED (checked against the oracle's restatement only).
+//    One thread per output pixel; the colour image at network resolution is never materialised (the four neighbours' colours are looked
+//    up from their class ids).
+// =====================================================================================================================================
+__global__ __launch_bounds__(256) void seg_overlay_kernel(const long* mask, int H, int W, const unsigned char* lut, int ncls,
+                                                          const unsigned char* frames, unsigned char* out, int Ho, int Wo, int N) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)N * Ho * Wo;
+    if (idx >= total) return;
+    const int x = (int)(idx % Wo);
+    const long t = idx / Wo;
+    const int y = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    const long* m = mask + (long)n * H * W;
+    auto colour = [&](int yy, int xx, int c) -> int {
+        const long k = m[(long)yy * W + xx];
+        return (k >= 0 && k < ncls) ? (int)lut[k * 3 + c] : 0;
+    };
+    int v[3];
+    if (H == Ho && W == Wo) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = colour(y, x, c);
+    } else {
+        int sx, sy;
+        short ax0, ax1, by0, by1;
+        lin_coef(x, (double)W / Wo, W, sx, ax0, ax1);
+        lin_coef(y, (double)H / Ho, H, sy, by0, by1);
+        const int sx1 = sx + 1 < W ? sx + 1 : W - 1, sy1 = sy + 1 < H ? sy + 1 : H - 1;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int h0 = colour(sy, sx, c) * ax0 + colour(sy, sx1, c) * ax1;
+            const int h1 = colour(sy1, sx, c) * ax0 + colour(sy1, sx1, c) * ax1;
+            int r = (((by0 * (h0 >> 4)) >> 16) + ((by1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            v[c] = r < 0 ? 0 : (r > 255 ? 255 : r);
+        }
+    }
+    const unsigned char* f = frames + idx * 3;
+    unsigned char* o = out + idx * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float s = __fadd_rn(__fmul_rn((float)f[c], 0.8f), __fmul_rn((float)v[c], 0.5f));
+        int r = __float2int_rn(s);                                              // cvRound: round half to even
+        o[c] = (unsigned char)(r < 0 ? 0 : (r > 255 ? 255 : r));
+    }
+}
+
+/* mask: int64 class ids [N][H][W] (arg-max of the seg logits); lut: uint8 [ncls][3] colours in the frame's channel order (ids without an
+ * entry, and ids outside [0, ncls), stay black as in the reference's zero-initialised vis_seg); frames / out: uint8 [N][Ho][Wo][3]. */
+extern "C" int hn_seg_overlay(const long* mask, int N, int H, int W, const void* lut, int ncls, const void* frames, void* out, int Ho, int Wo,
+                              hipStream_t st) {
+    HN_CHECK_ARG(mask && lut && frames && out && N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && ncls > 0);
+    const long total = (long)N * Ho * Wo;
+    hipLaunchKernelGGL(seg_overlay_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, mask, H, W, (const unsigned char*)lut, ncls,
+                       (const unsigned char*)frames, (unsigned char*)out, Ho, Wo, N);
+    HN_LAUNCH_CHECK();
+}

@@ -258,7 +258,8 @@ class HydraNet(nn.Module):
         object.__setattr__(self.neck, "_fwd", lambda feats: flushed(tuple(K_to_nchw(t) for t in me()._neck([K_to_nhwc(t) for t in feats]))))
         if self.train_seg:
             object.__setattr__(self.segheader, "_fwd", lambda feats: me()._seg([K_to_nhwc(t) for t in feats]))
-            self.segheader.decode = _unavailable("segheader.decode (cv2 visualisation)")
+            from .visual import seg_decode             # SegmentHeader.decode (head_seg/segmentation.py:107-125) on the device
+            self.segheader.decode = seg_decode
         if self.train_detect:
             object.__setattr__(self.detectheader, "_fwd", lambda x, fused: flushed(me()._det(x, [K_to_nhwc(t) for t in fused])))
             self.detectheader.decode = _det_decode
