@@ -48,6 +48,7 @@ TOL_GRAD_NORM = 7e-1                # ... and the worst (the 6..16-wide SE squee
 GRAD_COS = 0.88                     # cosine of individual gradients vs fp32 (measured: heads 0.996-1.0, neck 0.98, backbone 0.91-0.95)
 TOL_FUSION = 0.6                    # the 24 BiFPN fusion-weight gradients: | ||g_hip|| - ||g_fp32|| | / max_j ||g_fp32_j|| (see _is_fusion_weight)
 MASK_AGREEMENT = 0.95               # fraction of pixels whose arg-max class equals the fp32 oracle's
+MIRROR_FACTOR, MIRROR_FLOOR = 1.25, 5e-3   # HIP-vs-fp32 relative L2 <= 1.25 x (oracle bf16-mirror vs fp32) + 5e-3, per tensor, same state and batch
 # digests vs the reference (norms only): |L2_hip - L2_ref| / L2_ref
 TOL_DIGEST = dict(feat=2e-2, fused=4e-2, head=4e-2)
 
@@ -197,6 +198,14 @@ def test_conditioned_state_elementwise_vs_fp32_oracle_512x1024(training):
         for k, v in osd.items():
             if v.is_floating_point() and "running" not in k:
                 v.requires_grad_(True)
+    # The bf16 noise floor, measured in the same run instead of asserted in prose: the oracle -- PyTorch's own kernels --
+    # in bf16-MIRROR mode (rounding wherever the HIP path stores bf16) on the same state and batch, and the same with the BiFPN cells kept
+    # in fp32 (what fp32 storage of the 24 fusion nodes + fused maps would buy).  Forward only (running statistics restored afterwards).
+    def mirror_run(fp32_parts):
+        msd = {k: v.clone() for k, v in sd.items()}
+        with torch.no_grad(), O.bf16_mirror(fp32_parts):
+            return O.hydranet_forward(msd, cfgs, batch["image"], training=training, want_features=True)
+    mir, mir_neck32 = mirror_run(()), mirror_run(("neck",))
     with (torch.enable_grad() if training else torch.no_grad()):
         ref = O.hydranet_forward(osd, cfgs, batch["image"], training=training, want_features=True)          # UNMIRRORED fp32
         feats = net._backbone(batch["image"])
@@ -239,7 +248,18 @@ def test_conditioned_state_elementwise_vs_fp32_oracle_512x1024(training):
     l2 = lambda a, b: float((a.detach().float() - b.detach().float()).norm() / b.detach().float().norm().clamp(min=1e-20))
     res["tensors"] = {k: dict(max=rel(tm[k], tr[k]), l2=l2(tm[k], tr[k])) for k in tr}
     res["seg_mask_agreement"] = float((torch.argmax(out["seg"], 1) == torch.argmax(ref["seg"], 1)).float().mean())
+    tmir, tn32 = tensors(mir), tensors(mir_neck32)
+    res["mirror_vs_fp32"] = {k: dict(max=rel(tmir[k], tr[k]), l2=l2(tmir[k], tr[k])) for k in tr}
+    res["mirror_fp32_neck_vs_fp32"] = {k: dict(max=rel(tn32[k], tr[k]), l2=l2(tn32[k], tr[k])) for k in tr}
+    res["mirror_seg_mask_agreement"] = float((torch.argmax(mir["seg"], 1) == torch.argmax(ref["seg"], 1)).float().mean())
+    res["mirror_fp32_neck_seg_mask_agreement"] = float((torch.argmax(mir_neck32["seg"], 1) == torch.argmax(ref["seg"], 1)).float().mean())
+    res["hip_over_mirror_l2"] = {k: res["tensors"][k]["l2"] / max(res["mirror_vs_fp32"][k]["l2"], 1e-12) for k in tr}
     dump("elementwise_%s" % ("train" if training else "eval"), res)
+    # the HIP path is no further from fp32 than PyTorch's own bf16-storage realisation of the same network: 1.25 x + a 5e-3 floor
+    # (relative L2; the max-norm ratio of two chaotic bf16 realisations scatters and is only recorded)
+    for k in tr:
+        assert res["tensors"][k]["l2"] <= MIRROR_FACTOR * res["mirror_vs_fp32"][k]["l2"] + MIRROR_FLOOR, (k, res["tensors"][k], res["mirror_vs_fp32"][k])
+    assert res["seg_mask_agreement"] >= res["mirror_seg_mask_agreement"] - 1.5e-2, (res["seg_mask_agreement"], res["mirror_seg_mask_agreement"])
     for k, v in res["tensors"].items():
         g = _group(k)
         if g in TOL_MAX:
