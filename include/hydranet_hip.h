@@ -98,16 +98,6 @@ int hn_conv_gemm_nt_stat(const void* x0, const void* x1, int mode, int n_img, in
                          const void* w, int Nout, int KP, int taps, const float* bias, int act, void* out, int out_f32, int ldc, long rpi,
                          long img_stride, float* psum, float* psq, const void* addend, int ld_add, int add_mode, int emode, const void* ez,
                          int ld_ez, const float* ecoef, hipStream_t stream);
-/* tuning hook for tools/: force the cout tile (16/32/64/128) and LDS ring depth (2..4) of later hn_conv_gemm_nt launches; 0 = automatic */
-int hn_debug_nt_config(int bc, int r);
-/* tools/ A/B hook: 1 = software-pipelined direct 3x3 kernel (one workgroup per CU, weight ring of 3 + 2 patch buffers), 0 (default, faster
- * on every measured shape) = the two-workgroups-per-CU double-buffer form */
-int hn_debug_direct_pipe(int on);
-int hn_debug_tn_config(int bc, int bn, int splits);
-/* tools/ sweep hook: heuristic constants (0 TN split target, 1 TN minimum rows per split, 2 / 3 fused-BatchNorm row-block targets, 4 / 5 pixel
- * thresholds of the 64x64 GEMM tile); the defaults are the shipped heuristics */
-int hn_debug_knob(int id, long value);
-
 /* wgrad: dw[Cout][Cin][taps] (PyTorch layout, fp32) = sum_pixel dz[pixel][cout] * X(pixel, tap)[c]; X modes 0..2 as above.
  * dz rows must be zero padded up to ldz >= Nout rounded up to 8.  workspace: fp32, size from hn_wgrad_plan.
  * Replaces aten::convolution_backward's weight gradient. */

@@ -38,9 +38,14 @@ def _ctype(decl: str):
     return {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double}[base]
 
 
+TUNING_HEADER = os.path.join(_ROOT, "include", "hydranet_hip_tuning.h")
+
+
 def parse_header(path: str = HEADER) -> Dict[str, Tuple[object, List[object], bool]]:
-    """name -> (restype, argtypes, takes_stream)."""
+    """name -> (restype, argtypes, takes_stream).  The tuning build also binds include/hydranet_hip_tuning.h (hn_debug_*)."""
     txt = open(path).read()
+    if TUNING and path == HEADER:
+        txt += open(TUNING_HEADER).read()
     txt = re.sub(r"/\*.*?\*/", " ", txt, flags=re.S)
     out = {}
     for m in re.finditer(r"\b(int|long)\s+(hn_\w+)\s*\((.*?)\)\s*;", txt, flags=re.S):
@@ -116,6 +121,9 @@ class _Lib:
 
     def query(self, name, *args):
         """Invoke a host-side planning helper that returns a value (no stream, no status)."""
+        if name not in self._fn and name.startswith("hn_debug_"):
+            raise HipKernelError(f"{name} exists only in the tuning build of the library: set HN_TUNING=1 before importing the package "
+                                 "(tools/ only; the product library has no tuning hooks)")
         return self._fn[name][0](*args)
 
 

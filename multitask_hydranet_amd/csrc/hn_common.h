@@ -38,7 +38,11 @@ __device__ __forceinline__ bf16x8 zero8() {
 // 6 = 1: no two-K-group GEMM variant (> 1: its K threshold, default 512), 7 depthwise-backward block target, 8 = 0: fused passes without the
 // XCD row-order placement, 9 grouped-TN debug bits (skip stores / MFMAs / loads), 10 grouped-TN tile variant, 11 = 1: direct 3x3 kernel walks
 // the patches of one cout tile first (measured: no gain), 12 / 13 workgroup targets of the 3x3 patch weight-gradient / grouped-conv group plans
+#ifdef HN_TUNING
 extern long g_hn_knob[16];
+#else
+extern const long g_hn_knob[16];      // product build: the shipped heuristics as constants, no setter (the library has no mutable state)
+#endif
 #define HN_ACT_NONE 0
 #define HN_ACT_RELU 1
 #define HN_ACT_SWISH 2

@@ -2353,10 +2353,14 @@ static int launch_nt_r(const GemmNT& p, int out_f32, hipStream_t st) {
 // direct 3x3 kernel: software-pipelined variant on/off (tools/ A/B hook).  Default OFF: measured on MI355X (tools/bench_seg.py) the
 // one-workgroup-per-CU ring-of-3 pipeline is 10-60 % SLOWER than two co-resident double-buffer workgroups on every seg-decoder shape
 // (decoder.3 forward 306 vs 231 us): the second resident workgroup hides more latency than the deeper prefetch does.
+#ifdef HN_TUNING
 static int g_direct_pipe = 0;
 extern "C" int hn_debug_direct_pipe(int on) { g_direct_pipe = on; return 0; }
+#endif
 
-// operand-transform variant (bf16 output, double buffer)
+// operand-transform variant (bf16 output, double buffer): measured slower than LDS-DMA + one extra BatchNorm pass, never launched by the
+// product path (ops.XBLOCK_XF_GEMM is a tools/ experiment): compiled with -DHN_TUNING only
+#ifdef HN_TUNING
 template <int BC, int BP, int WGC, int WGP>
 static int launch_nt_xf(const GemmNT& p, hipStream_t st) {
     dim3 grid(cdiv(p.x.M, BP) * cdiv(p.Nout, BC));
@@ -2366,10 +2370,15 @@ static int launch_nt_xf(const GemmNT& p, hipStream_t st) {
     hipLaunchKernelGGL((gemm_nt_kernel<BC, BP, WGC, WGP, false, 2, true>), grid, dim3(256), lds, st, p);
     HN_LAUNCH_CHECK();
 }
+#endif
 
-// Tuning hook (tools/ only): force the cout tile and/or ring depth of the next hn_conv_gemm_nt launches; 0 = automatic.
+// Tuning hook (tools/ only, -DHN_TUNING): force the cout tile and/or ring depth of the next hn_conv_gemm_nt launches; 0 = automatic.
+#ifdef HN_TUNING
 static int g_nt_force_bc = 0, g_nt_force_r = 0;
 extern "C" int hn_debug_nt_config(int bc, int r) { g_nt_force_bc = bc; g_nt_force_r = r; return 0; }
+#else
+static constexpr int g_nt_force_bc = 0, g_nt_force_r = 0;
+#endif
 
 // Ring depth: R = 2 (double buffer) in production; R = 3/4 stay instantiated behind the tuning hook.
 template <int BC, int BP, int WGC, int WGP, int RDEEP>
@@ -2378,11 +2387,14 @@ static int launch_nt(const GemmNT& p, int out_f32, hipStream_t st) {
     const int stages = (p.taps * (p.KP >> 5) + 1) >> 1;
     int r = 2;     // measured: the deeper rings never beat the double buffer (their LDS footprint costs the second resident workgroup)
     (void)blocks; (void)stages;
+#ifdef HN_TUNING
     if (g_nt_force_r && BC >= 32) r = g_nt_force_r;
     if (BC >= 32) {
         if (r == 3) return launch_nt_r<BC, BP, WGC, WGP, (BC >= 32 ? 3 : 2)>(p, out_f32, st);
         if (r == 4) return launch_nt_r<BC, BP, WGC, WGP, (BC >= 32 ? 4 : 2)>(p, out_f32, st);
     }
+#endif
+    (void)r;
     return launch_nt_r<BC, BP, WGC, WGP, 2>(p, out_f32, st);
 }
 
@@ -2405,8 +2417,12 @@ static int pick_bc(int Nout) {
 // than two 128x128 ones (712 -> 715 img/s); at the 1.1-1.5 M rows of the 32 x 1152 x 1920 inference maps the large tile wins (1053 vs 1045).
 // (knob 0, the TN split target: 1024 -> 2048 workgroups measured +0.75 % on the step -- 785 -> 791 img/s, tools/knob_sweep.sh: the
 // L2 -> LDS bound weight-gradient GEMMs want two full rounds of short K loops rather than one round of long ones)
+#ifdef HN_TUNING
 long g_hn_knob[16] = {2048, 256, 1024, 512, 8192, 262144, 0, 0, 1, 0, 0, 0, 256, 384, 0, 0};
 extern "C" int hn_debug_knob(int id, long value) { if (id < 0 || id >= 16) return HN_ERR_ARG; g_hn_knob[id] = value; return HN_OK; }
+#else
+extern const long g_hn_knob[16] = {2048, 256, 1024, 512, 8192, 262144, 0, 0, 1, 0, 0, 0, 256, 384, 0, 0};   // the shipped heuristics: constants
+#endif
 static bool small_tile(long M, int Nout) { return !g_nt_force_bc && Nout > 64 && (M <= g_hn_knob[4] || (M <= g_hn_knob[5] && Nout <= 128)); }
 
 // partial statistic rows of a mode-5 (grouped 3x3 on the direct kernel) launch: one per 16x16 output patch
@@ -2531,7 +2547,7 @@ static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img
     p.tile_major = g_hn_knob[11] == 1 ? 1 : 0;
     p.wpre = 0;
     p.dbg = (int)g_hn_knob[14];
-    p.dbg_buf = reinterpret_cast<unsigned long long*>(g_hn_knob[15]);
+    p.dbg_buf = reinterpret_cast<unsigned long long*>(g_hn_knob[15]);          // (read by the kernels with -DHN_TUNING only)
     p.fold = g_next_fold.ring ? 1 : 0; p.ring = g_next_fold.ring; p.fold_y = g_next_fold.y; p.ld_fy = g_next_fold.ldy;
     if (img_stride < 0) {                                            // mode 4: -img_stride = channels per depth-to-space output pixel
         HN_CHECK_ARG(p.x.clamp == 1 && (out_f32 || phase_mode == 1) && rpi == 0 && !psum && Nout == 4 * (int)(-img_stride));
@@ -2552,7 +2568,11 @@ static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img
         p.wpre = (!p.x.diag && KP <= 64 && (size_t)nsteps * bc * 128 <= 32768 && g_hn_knob[11] != 2) ? 1 : 0;
         // software-pipelined variant (32-channel chunks, two patch buffers + ring of four weight tiles, counted waits; still two workgroups
         // per CU): the multi-chunk bf16 launches with >= 64 couts per tile
+#ifdef HN_TUNING
         const bool pipe = g_direct_pipe && bc >= 64 && !out_f32 && !p.x.diag && !p.wpre && KP > 64;
+#else
+        constexpr bool pipe = false;                                // (measured slower on every seg-decoder shape: tools/bench_seg.py)
+#endif
         const size_t lds = pipe ? (size_t)2 * (((18 * 18 * 4 + 511) / 512) * 512 * 16) + 4 * (size_t)(512 * 16)
                                 : (size_t)((18 * 18 * 128 + 1023) / 1024 * 1024) + (p.wpre ? nsteps : 2) * (size_t)bc * 128;
         // > 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel (done on the first, un-captured call)
@@ -2560,14 +2580,18 @@ static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img
         if (!lds_optin(optin, {(const void*)conv3x3_direct_kernel<16, true, false>, (const void*)conv3x3_direct_kernel<16, false, false>,
                                (const void*)conv3x3_direct_kernel<32, true, false>, (const void*)conv3x3_direct_kernel<32, false, false>,
                                (const void*)conv3x3_direct_kernel<64, true, false>, (const void*)conv3x3_direct_kernel<64, false, false>,
-                               (const void*)conv3x3_direct_kernel<128, true, false>, (const void*)conv3x3_direct_kernel<128, false, false>,
-                               (const void*)conv3x3_direct_kernel<64, false, true>, (const void*)conv3x3_direct_kernel<128, false, true>}))
+                               (const void*)conv3x3_direct_kernel<128, true, false>, (const void*)conv3x3_direct_kernel<128, false, false>}))
             return HN_ERR_LAUNCH;
+#ifdef HN_TUNING
+        static std::atomic<unsigned long long> optin_pipe{0};
         if (pipe) {
+            if (!lds_optin(optin_pipe, {(const void*)conv3x3_direct_kernel<64, false, true>, (const void*)conv3x3_direct_kernel<128, false, true>}))
+                return HN_ERR_LAUNCH;
             if (bc == 64) hipLaunchKernelGGL((conv3x3_direct_kernel<64, false, true>), grid, dim3(512), lds, st, p);
             else hipLaunchKernelGGL((conv3x3_direct_kernel<128, false, true>), grid, dim3(512), lds, st, p);
             HN_LAUNCH_CHECK();
         }
+#endif
 #define DIRECT_CASE(BC_) \
         if (bc == BC_) { \
             if (out_f32) hipLaunchKernelGGL((conv3x3_direct_kernel<BC_, true, false>), grid, dim3(512), lds, st, p); \
@@ -2578,6 +2602,7 @@ static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img
         HN_LAUNCH_CHECK();
     }
     if (xscale) {
+#ifdef HN_TUNING
         if (small_tile(M, Nout)) return launch_nt_xf<64, 64, 2, 2>(p, st);
         switch (pick_bc(Nout)) {
             case 16: return launch_nt_xf<16, 128, 1, 4>(p, st);
@@ -2585,6 +2610,9 @@ static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img
             case 64: return launch_nt_xf<64, 128, 2, 2>(p, st);
             default: return launch_nt_xf<128, 128, 2, 2>(p, st);
         }
+#else
+        return HN_ERR_UNSUPPORTED;                                   // operand-transform loader: tuning builds only (see launch_nt_xf)
+#endif
     }
     if (small_tile(M, Nout)) {
         // 1x1 convs of the deep stages: two K groups per workgroup when the K loop is long enough to split
@@ -2695,8 +2723,12 @@ static int launch_tn(const GemmTN& p, int splits, hipStream_t st) {
 }
 
 // Tuning hook (tools/ only): force the wgrad tile and split count of later hn_conv_gemm_tn launches; 0 = automatic.
+#ifdef HN_TUNING
 static int g_tn_force_bc = 0, g_tn_force_bn = 0, g_tn_force_splits = 0;
 extern "C" int hn_debug_tn_config(int bc, int bn, int splits) { g_tn_force_bc = bc; g_tn_force_bn = bn; g_tn_force_splits = splits; return 0; }
+#else
+static constexpr int g_tn_force_bc = 0, g_tn_force_bn = 0, g_tn_force_splits = 0;
+#endif
 
 static void tn_tiles(int Nout, int KP, int& bc, int& bn) {
     if (g_tn_force_bc && g_tn_force_bn) { bc = g_tn_force_bc; bn = g_tn_force_bn; return; }
@@ -2931,6 +2963,12 @@ extern "C" int hn_wgrad_group(const long* jobs, int njobs, float* workspace, hip
     HN_CHECK_ARG(blocks > 0 && blocks < (1L << 31));
     int rc = HN_OK;
     const int variant = (int)g_hn_knob[10];           // tools/: 0 = shipped choice; 1 = two-stage 128 x 128; 2..5 = ring variants below
+    (void)variant;
+    const size_t lds = (size_t)64 * (g.bc + g.bn) * 2 * 2;
+#define TNG_CASE(BC_, BN_, A_, B_) if (g.bc == BC_ && g.bn == BN_) \
+        hipLaunchKernelGGL((gemm_tn_group_kernel<BC_, BN_, A_, B_>), dim3((unsigned)blocks), dim3(64 * A_ * B_), lds, st, t); else
+#ifdef HN_TUNING
+    // ring / 256 x 256 variants (knob 10): all measured slower than the two-stage 128 x 128 tile with two workgroups per CU
     static std::atomic<unsigned long long> optin{0};
     if (!lds_optin(optin, {(const void*)gemm_tn_group_kernel<256, 256, 2, 4, 32, 4>, (const void*)gemm_tn_group_kernel<256, 256, 2, 4, 32, 3>,
                            (const void*)gemm_tn_group_kernel<256, 256, 2, 4>,
@@ -2939,21 +2977,20 @@ extern "C" int hn_wgrad_group(const long* jobs, int njobs, float* workspace, hip
 #define TNG_RING(BC_, BN_, A_, B_, BK_, R_) \
         hipLaunchKernelGGL((gemm_tn_group_kernel<BC_, BN_, A_, B_, BK_, R_>), dim3((unsigned)blocks), dim3(64 * A_ * B_), \
                            (size_t)BK_ * (BC_ + BN_) * 2 * R_, st, t)
-    const size_t lds = (size_t)64 * (g.bc + g.bn) * 2 * 2;
     if (g.bc == 256 && g.bn == 256 && variant == 2) TNG_RING(256, 256, 2, 4, 32, 4);
     else if (g.bc == 256 && g.bn == 256 && variant == 3) TNG_RING(256, 256, 2, 4, 32, 3);
     else if (g.bc == 128 && g.bn == 128 && variant == 4) TNG_RING(128, 128, 2, 2, 64, 3);
     else if (g.bc == 128 && g.bn == 128 && variant == 5) TNG_RING(128, 128, 2, 2, 32, 4);
     else
-#define TNG_CASE(BC_, BN_, A_, B_) if (g.bc == BC_ && g.bn == BN_) \
-        hipLaunchKernelGGL((gemm_tn_group_kernel<BC_, BN_, A_, B_>), dim3((unsigned)blocks), dim3(64 * A_ * B_), lds, st, t); else
-    TNG_CASE(256, 256, 2, 4) TNG_CASE(128, 128, 2, 2) TNG_CASE(128, 64, 2, 2) TNG_CASE(128, 32, 4, 1)
+    TNG_CASE(256, 256, 2, 4)
+#undef TNG_RING
+#endif
+    TNG_CASE(128, 128, 2, 2) TNG_CASE(128, 64, 2, 2) TNG_CASE(128, 32, 4, 1)
     TNG_CASE(64, 128, 2, 2) TNG_CASE(64, 64, 2, 2) TNG_CASE(64, 32, 4, 1)
     TNG_CASE(32, 128, 1, 4) TNG_CASE(32, 64, 1, 4) TNG_CASE(32, 32, 2, 2)
     TNG_CASE(16, 128, 1, 4) TNG_CASE(16, 64, 1, 4)
     rc = HN_ERR_UNSUPPORTED;
 #undef TNG_CASE
-#undef TNG_RING
     if (rc != HN_OK) return rc;
     if (r.n) hipLaunchKernelGGL(wgrad_reduce_group_kernel, dim3((unsigned)rblocks), dim3(256), 0, st, r);
     HN_LAUNCH_CHECK();

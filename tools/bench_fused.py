@@ -1,4 +1,5 @@
 """micro-benchmark of the fused BatchNorm passes / XF GEMM at the backbone's stage shapes (N = 16, 512x1024), timed as hipGraph replays"""
+import os as _os; _os.environ.setdefault("HN_TUNING", "1")   # hn_debug_* hooks: tuning build of the library
 import sys, os, ctypes, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g

@@ -1,5 +1,6 @@
 """1x1-conv GEMM launches (NT forward/dgrad form and TN wgrad form) at the shapes the network uses; optional forced tile / ring depth.
 usage: python tools/bench_nt_shapes.py [bc r]"""
+import os as _os; _os.environ.setdefault("HN_TUNING", "1")   # hn_debug_* hooks: tuning build of the library
 import sys, torch
 sys.path.insert(0, '.')
 from multitask_hydranet_amd import ops as K

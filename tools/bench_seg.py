@@ -1,4 +1,5 @@
 """micro-benchmark of the seg-decoder convs (N = 16, 512x1024): direct 3x3 kernel double-buffer vs software-pipelined, full-res vs phase form"""
+import os as _os; _os.environ.setdefault("HN_TUNING", "1")   # hn_debug_* hooks: tuning build of the library
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g

@@ -1,4 +1,5 @@
 """1x1 weight-gradient launches (gemm_tn + wgrad_reduce) at the shapes of the small layers; sweep tile / split count."""
+import os as _os; _os.environ.setdefault("HN_TUNING", "1")   # hn_debug_* hooks: tuning build of the library
 import sys, torch
 sys.path.insert(0, '.')
 from multitask_hydranet_amd import ops as K

@@ -1,5 +1,6 @@
 """micro-benchmark of the grouped deferred weight-gradient launch (hn_wgrad_group) on a backbone-stage-like job list; HN_DBG = bits of
 hn_debug_knob(9): 1 skip stores, 2 skip MFMAs, 4 skip loads"""
+import os as _os; _os.environ.setdefault("HN_TUNING", "1")   # hn_debug_* hooks: tuning build of the library
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g
