@@ -2098,7 +2098,7 @@ class SegConvUp(torch.autograd.Function):
         # low-resolution grid cannot fill the chip (decoder.1: 18x34 cells -> 384 workgroups); the weight gradient is always in phase form.
         fwd_phase = (c1 == 0 or c1 >= 32) if SEG_FWD_PHASE is None else SEG_FWD_PHASE
         tiles = n * ((h + 2 + 15) // 16) * ((w + 2 + 15) // 16) * ((c0 + 127) // 128)
-        ctx.dgrad_phase = (tiles >= 448) if SEG_DGRAD_PHASE is None else SEG_DGRAD_PHASE
+        ctx.dgrad_phase = (tiles >= SEG_DGRAD_PHASE_MIN_TILES) if SEG_DGRAD_PHASE is None else SEG_DGRAD_PHASE
         wp_eff, wt_eff, b_eff = pack_phase_weight(weight, c0, bias, want_wt=ctx.dgrad_phase)
         if c1 and (fwd_phase or ctx.dgrad_phase):
             wp1, wt1 = pack_conv_weight_slice(weight, c0, c1)
@@ -2173,6 +2173,7 @@ class SegConvUp(torch.autograd.Function):
 
 
 SEG_PHASE_UP = os.environ.get("HN_SEG_PHASE_UP", "1") != "0"
+SEG_DGRAD_PHASE_MIN_TILES = int(os.environ.get("HN_SEG_DGRAD_PHASE_MIN_TILES", "448"))
 SEG_FWD_PHASE = None        # None: per-layer heuristic; True / False force the forward form (tests)
 SEG_DGRAD_PHASE = None      # the same for the data gradient w.r.t. the up-sampled operand
 

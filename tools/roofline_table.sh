@@ -3,7 +3,7 @@
 # captured hipGraph, HBM traffic (FETCH_SIZE x2 + WRITE_SIZE per MI355X_MICROARCH.md), GB/s, fraction of 8 TB/s, MFMA busy share.
 #   pass 1: rocprofv3 --kernel-trace --stats        on the captured step (timing; no counters)
 #   pass 2-4: rocprofv3 --pmc <one group> --kernel-trace on eager launches of the same step (counters; separate passes, no other tracing)
-# -> gpurun_out/roofline/{kernel_stats.csv, pmc_*.csv, roofline_table.md}; tools/copy_profiles.sh copies them to profiles/r03_*
+# -> gpurun_out/roofline/{kernel_stats.csv, pmc_*.csv, roofline_table.md}; tools/copy_profiles.sh copies them to profiles/${ROUND}_*
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/roofline
 rm -rf $O; mkdir -p $O

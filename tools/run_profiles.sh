@@ -1,8 +1,9 @@
 #!/bin/bash
 # Round-end measurement on the GPU box: default bench line, rocprofv3 kernel stats of the captured step, the priced dominant launch's
 # dispatch rows, PMC passes (HBM traffic + MFMA counters) on the dominant launch, the counter-backed roofline table of the whole step.
-# -> gpurun_out/prof/*; tools/copy_profiles.sh copies the summaries to profiles/r03_*
+# -> gpurun_out/prof/*; tools/copy_profiles.sh copies the summaries to profiles/${ROUND}_*
 R=${GRAFT_REPO_ROOT:-/root/repo}
+ROUND=${ROUND:-r04}
 O=$R/gpurun_out/prof
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
@@ -59,8 +60,8 @@ try:
 except Exception as e:
     print("pmc summary failed:", repr(e))
 PY
-# the default bench line LAST, so that its roofline.traffic is this round's counter result (bench.py reads profiles/r03_dominant_pmc.json)
-[ -s $O/dominant_pmc.json ] && cp $O/dominant_pmc.json $R/profiles/r03_dominant_pmc.json
+# the default bench line LAST, so that its roofline.traffic is this round's counter result (bench.py reads the newest profiles/rNN_dominant_pmc.json)
+[ -s $O/dominant_pmc.json ] && cp $O/dominant_pmc.json $R/profiles/${ROUND}_dominant_pmc.json
 python bench.py > $O/bench_default.log 2>&1
 tail -1 $O/bench_default.log > $O/bench_n1.json
 bash tools/roofline_table.sh > $O/roofline_table.log 2>&1
