@@ -461,6 +461,16 @@ int hn_preprocess_bgr(const void* src, int N, int Hs, int Ws, float* dst, int Hd
 int hn_seg_overlay(const long* mask, int N, int H, int W, const void* lut, int ncls, const void* frames, void* out, int Ho, int Wo,
                    hipStream_t stream);
 
+/* Lane F1 (head_lane/lane_metric.py:166-266, used by train.py:188,397,433): the bitwise IoU of lanes drawn as thick polylines.
+ * hn_lane_raster paints every segment (p_i, p_{i+1}) of every lane's spline-interpolated polyline with width lane_width into the lane's
+ * uint8 mask (cv2.line restated as "pixel centre within lane_width / 2 of the segment": parity with OpenCV's fill rules unpinned);
+ * hn_lane_iou counts |mask_g & mask_p| and |mask| for ground-truth lanes g < G and predictions p < P (G, P <= 32) with integer atomics.
+ * pts int32 [npts][2]; seg_lane / seg_first int32 [nseg]; masks uint8 [lanes][H][W] zeroed by the caller; inter uint64 [G][P] and area
+ * uint64 [G + P] zeroed by the caller. */
+int hn_lane_raster(const int* pts, const int* seg_lane, const int* seg_first, int nseg, int lane_width, int H, int W, void* masks,
+                   hipStream_t stream);
+int hn_lane_iou(const void* masks, int G, int P, long HW, void* inter, void* area, hipStream_t stream);
+
 /* Streaming confusion counts for the segmentation mIoU (head_seg/seg_metrics.py:12-47): conf uint64 [(C+1)*(C+1)] += counts of
  * (pred, target) pairs, both clamped to C (the ignore bucket).  pred int64 [M]; target int64 or float32 [M]. */
 int hn_seg_confusion(const long* pred, const void* target, int target_is_float, long M, int C, void* conf, hipStream_t stream);

@@ -1023,7 +1023,8 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
     // Issued one by one inside the loop below each was a dependent round trip: the stamps show 26 000 cycles for this epilogue, a
     // quarter of the workgroup's lifetime, against 16 x 3 400 cycles for all of its tap steps (tools/stamp_seg.py).
     const bool pre_add = !OUT_F32 && p.d2s && p.addend;
-    bf16x4 addq[3][TP];                                               // ring: cout sub-tiles i (in use), i + 1 and i + 2 (in flight)
+    constexpr int AQ = 2;                                             // ring: cout sub-tile i (in use) and i + 1 (in flight); a third slot
+    bf16x4 addq[AQ][TP];                                              // spilled 13 VGPRs = +24 MB of scratch traffic per launch
     auto load_add = [&](int i, bf16x4 (&dst)[TP]) {
         const int co0 = c_blk + wc * WCO + i * 16 + (lane >> 4) * 4;
         const int ph = co0 / p.d2s, oc = co0 - ph * p.d2s;
@@ -1035,20 +1036,22 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
                                                               : (bf16x4){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
         }
     };
-    if (pre_add) {                                                     // three of the TC = 4 rounds in flight from the start: the
-        load_add(0, addq[0]);                                          // addend comes from HBM (2-3 us under load), one round trip is
-        if (TC > 1) load_add(1, addq[1]);                              // exposed instead of four
-        if (TC > 2) load_add(2, addq[2]);
+    if (pre_add) {                                                     // AQ of the TC = 4 rounds in flight from the start (the addend
+#pragma unroll
+        for (int q = 0; q < AQ && q < TC; ++q) load_add(q, addq[q]);   // comes from HBM: 2-3 us under load)
     }
     if constexpr (BC >= 64 && !OUT_F32) {
         // (the host entry point only launches these instantiations when the staged form applies: stage_d2s is true)
-        // Compact form of the staged bf16 epilogue (every seg-decoder launch with >= 64 couts per tile): bias and addend are added in
-        // place on the accumulators, the activation is ONE uniform branch around all 16 * TC * TP / 4 values, then the tile is rounded
+        // Compact form of the staged bf16 epilogue (every seg-decoder launch with >= 64 couts per tile): per cout sub-tile, bias and addend
+        // are added in place on the accumulators, the activation is one uniform branch around its 16 values, then the sub-tile is rounded
         // and staged.  The generic epilogue below re-decides activation and store form inside each of its TC x TP unrolled bodies: 10 000
         // instructions (80 KB: more than the instruction cache two CUs share), and the stamps showed 17 000 cycles for an epilogue
         // without a single global load (tools/stamp_seg.py) -- instruction fetch, not arithmetic.
+        const int act = p.act;
 #pragma unroll
         for (int i = 0; i < TC; ++i) {
+            // one cout sub-tile at a time, start to finish: its 16 accumulator registers are dead once it is staged (all 64 values
+            // through bias / addend, then all through the activation, then all staged kept everything live at once: 13 spilled VGPRs)
             const int co0 = c_blk + wc * WCO + i * 16 + (lane >> 4) * 4;
             f32x4 bs;
 #pragma unroll
@@ -1059,33 +1062,24 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
 #pragma unroll
                 for (int j = 0; j < TP; ++j)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[i][j][r] += bf2f(addq[i % 3][j][r]);
-                if (i + 3 < TC) load_add(i + 3, addq[i % 3]);
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] += bf2f(addq[i % AQ][j][r]);
+                if (i + AQ < TC) load_add(i + AQ, addq[i % AQ]);
             }
-        }
-        if (p.act == HN_ACT_ELU) {
-#pragma unroll
-            for (int i = 0; i < TC; ++i)
+            if (act == HN_ACT_ELU) {
 #pragma unroll
                 for (int j = 0; j < TP; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { const float x = acc[i][j][r]; acc[i][j][r] = x > 0.f ? x : (__expf(x) - 1.0f); }
-        } else if (p.act != HN_ACT_NONE) {
-            const int act = p.act;
+            } else if (act != HN_ACT_NONE) {
 #pragma unroll 1
-            for (int k = 0; k < 4; ++k) {                              // (rare: any other activation, small code)
-#pragma unroll
-                for (int i = 0; i < TC; ++i)
+                for (int k = 0; k < 4; ++k) {                          // (rare: any other activation; the lane's 4 values rotate through element 0)
 #pragma unroll
                     for (int j = 0; j < TP; ++j) {
-                        float x = acc[i][j][0];                        // rotate the lane's 4 values through element 0: no dynamic index
-                        x = act_fwd(x, act);
+                        const float x = act_fwd(acc[i][j][0], act);
                         acc[i][j] = (f32x4){acc[i][j][1], acc[i][j][2], acc[i][j][3], x};
                     }
+                }
             }
-        }
-#pragma unroll
-        for (int i = 0; i < TC; ++i) {
             const int cl = wc * WCO + i * 16 + (lane >> 4) * 4;
 #pragma unroll
             for (int j = 0; j < TP; ++j) {
@@ -1094,6 +1088,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
                 *reinterpret_cast<bf16x4*>(stage + pl * (BC * 2) + ((((cl >> 3) ^ pl) & (BC / 8 - 1)) << 4) + (cl & 7) * 2) = tv;
             }
         }
+        stamp();
     } else
 #pragma unroll
     for (int i = 0; i < TC; ++i) {
@@ -1104,8 +1099,8 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
         bf16x4 addv[TP];
         if (pre_add) {
 #pragma unroll
-            for (int j = 0; j < TP; ++j) addv[j] = addq[i % 3][j];
-            if (i + 3 < TC) load_add(i + 3, addq[i % 3]);
+            for (int j = 0; j < TP; ++j) addv[j] = addq[i % AQ][j];
+            if (i + AQ < TC) load_add(i + AQ, addq[i % AQ]);
         }
 #pragma unroll
         for (int j = 0; j < TP; ++j) {

@@ -493,3 +493,87 @@ extern "C" int hn_seg_overlay(const long* mask, int N, int H, int W, const void*
                        (const unsigned char*)frames, (unsigned char*)out, Ho, Wo, N);
     HN_LAUNCH_CHECK();
 }
+
+// =====================================================================================================================================
+// 6. lane F1 (head_lane/lane_metric.py:166-266): bitwise IoU of two lanes drawn as thick polylines.  The reference rasterises with
+//    cv2.line(img, p_i, p_{i+1}, 255, lane_width) -- OpenCV's ThickLine: the quadrilateral of half-width lane_width / 2 around the segment
+//    plus filled circles of radius round(lane_width / 2) at both end points = the pixels within lane_width / 2 of the segment.  cv2 is
+//    absent: restated as that distance test on pixel centres (parity with OpenCV's polygon / circle fill at the boundary pixels: UNPINNED).
+//    One workgroup per polyline segment paints its bounding box into the lane's uint8 mask; a second kernel counts |A|, |B|, |A & B| for
+//    every (ground truth, prediction) pair with integer atomics (exact, order independent).
+// =====================================================================================================================================
+__global__ __launch_bounds__(256) void lane_raster_kernel(const int* pts, const int* seg_lane, const int* seg_first, int nseg, int width2,
+                                                          int H, int W, unsigned char* masks) {
+    const int s = blockIdx.x;
+    if (s >= nseg) return;
+    const int lane = seg_lane[s], i = seg_first[s];
+    const int x0 = pts[2 * i], y0 = pts[2 * i + 1], x1 = pts[2 * i + 2], y1 = pts[2 * i + 3];
+    const int r = (width2 + 3) / 4 + 1;                                  // width2 = 2 * lane_width: radius lane_width / 2, rounded up, + 1
+    const int bx0 = max(min(x0, x1) - r, 0), bx1 = min(max(x0, x1) + r, W - 1);
+    const int by0 = max(min(y0, y1) - r, 0), by1 = min(max(y0, y1) + r, H - 1);
+    if (bx1 < bx0 || by1 < by0) return;
+    const int bw = bx1 - bx0 + 1, n = bw * (by1 - by0 + 1);
+    const long dx = x1 - x0, dy = y1 - y0, len2 = dx * dx + dy * dy;
+    unsigned char* m = masks + (long)lane * H * W;
+    for (int k = threadIdx.x; k < n; k += 256) {
+        const int x = bx0 + k % bw, y = by0 + k / bw;
+        const long px = x - x0, py = y - y0;
+        // squared distance from (x, y) to the segment, scaled by len2 (integers: exact).  t = clamp(dot / len2, 0, 1)
+        long num;                                                       // distance^2 * len2  (or distance^2 when len2 == 0)
+        long den;
+        const long dot = px * dx + py * dy;
+        if (len2 == 0 || dot <= 0) { num = px * px + py * py; den = 1; }
+        else if (dot >= len2) { const long qx = x - x1, qy = y - y1; num = qx * qx + qy * qy; den = 1; }
+        else { const long cr = px * dy - py * dx; num = cr * cr; den = len2; }
+        // inside: distance <= lane_width / 2  <=>  4 * distance^2 <= lane_width^2  (width2 = 2 * lane_width -> (width2 / 2)^2)
+        if (16 * num <= (long)width2 * width2 * den) m[(long)y * W + x] = 255;
+    }
+}
+
+__global__ __launch_bounds__(256) void lane_iou_kernel(const unsigned char* masks, int G, int P, long HW, unsigned long long* inter,
+                                                       unsigned long long* area) {
+    extern __shared__ unsigned int cnt[];                                // [G * P + G + P]
+    const int nc = G * P + G + P;
+    for (int i = threadIdx.x; i < nc; i += 256) cnt[i] = 0;
+    __syncthreads();
+    for (long px = (long)blockIdx.x * 256 + threadIdx.x; px < HW; px += (long)gridDim.x * 256) {
+        unsigned int gbits = 0, pbits = 0;                               // (G, P <= 32)
+        for (int g = 0; g < G; ++g) gbits |= (masks[(long)g * HW + px] ? 1u : 0u) << g;
+        for (int p = 0; p < P; ++p) pbits |= (masks[(long)(G + p) * HW + px] ? 1u : 0u) << p;
+        if (!(gbits | pbits)) continue;
+        for (int g = 0; g < G; ++g)
+            if ((gbits >> g) & 1u) {
+                atomicAdd(&cnt[G * P + g], 1u);
+                for (int p = 0; p < P; ++p)
+                    if ((pbits >> p) & 1u) atomicAdd(&cnt[g * P + p], 1u);
+            }
+        for (int p = 0; p < P; ++p)
+            if ((pbits >> p) & 1u) atomicAdd(&cnt[G * P + G + p], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nc; i += 256)
+        if (cnt[i]) atomicAdd(i < G * P ? inter + i : area + (i - G * P), (unsigned long long)cnt[i]);
+}
+
+/* pts: int32 [npts][2] = the (x, y) pixel coordinates of every lane's interpolated polyline, lanes back to back (already truncated with
+ * int() as lane_metric.py:198-203 does); seg_lane / seg_first: int32 [nseg] = the lane index and the index of the first point of every
+ * segment; masks: uint8 [n_lanes][H][W], ZEROED by the caller.  lane_width = the reference's `lane_width` (30). */
+extern "C" int hn_lane_raster(const int* pts, const int* seg_lane, const int* seg_first, int nseg, int lane_width, int H, int W, void* masks,
+                              hipStream_t st) {
+    HN_CHECK_ARG(pts && seg_lane && seg_first && masks && nseg >= 0 && lane_width > 0 && H > 0 && W > 0);
+    if (nseg == 0) return HN_OK;
+    hipLaunchKernelGGL(lane_raster_kernel, dim3((unsigned)nseg), dim3(256), 0, st, pts, seg_lane, seg_first, nseg, 2 * lane_width, H, W,
+                       (unsigned char*)masks);
+    HN_LAUNCH_CHECK();
+}
+
+/* masks: uint8 [G + P][HW] (ground-truth lanes first); inter: uint64 [G][P], area: uint64 [G + P], both ZEROED by the caller: pixel counts of
+ * mask_g & mask_p and of every mask.  IoU(g, p) = inter / (area_g + area_p - inter) (lane_metric.py:204-209).  G, P <= 32. */
+extern "C" int hn_lane_iou(const void* masks, int G, int P, long HW, void* inter, void* area, hipStream_t st) {
+    HN_CHECK_ARG(masks && inter && area && G > 0 && P > 0 && G <= 32 && P <= 32 && HW > 0);
+    long blocks = (HW + 256 * 8 - 1) / (256 * 8);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(lane_iou_kernel, dim3((unsigned)blocks), dim3(256), (size_t)(G * P + G + P) * 4, st, (const unsigned char*)masks, G, P, HW,
+                       (unsigned long long*)inter, (unsigned long long*)area);
+    HN_LAUNCH_CHECK();
+}

@@ -5,8 +5,9 @@ checkpoint loading, train.py:96-126), the data-parallel wrap (train.py:130-137 -
 GPU over RCCL), Adam + per-iteration CosineAnnealingLR (train.py:147-150), `cal_total_loss` (train.py:192-203), `to_gpu` (train.py:228-239),
 `train_one_epoch` (train.py:241-269), `valid` (train.py:271-438: losses, streaming mIoU on the device, detection results in COCO json form
 from the device post-process, lane decode on the device) and `main`'s head-wise fine-tuning schedule (train.py:441-515: run_training /
-tuning_phase / HydraTrainer.set_phase).  The dataset / augmentation pipeline (cv2 + imgaug), COCOeval (pycocotools) and the lane F1 metric
-(cv2 rasterisation) stay outside (out of scope); any iterable of batch dicts with the Collater contract
+tuning_phase / HydraTrainer.set_phase), the lane F1 metric of train.py:188,397,433 (lane_metric.LaneMetric: rasterisation + IoU counts on the
+device).  The dataset / augmentation pipeline (cv2 + imgaug) and COCOeval (pycocotools) stay outside (out of scope); any
+iterable of batch dicts with the Collater contract
 (dataset/dataloader.py:557-633) drives the loop.
 
 Launch for N GPUs of one node:  python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 your_script.py
@@ -243,9 +244,14 @@ class HydraTrainer:
         """train.py:271-438 without the third-party evaluators: eval-mode forward + the six losses per batch, streaming mIoU on the device
         (train.py:293-306), detection results through the device post-process in COCO-json form (train.py:308-364; written to
         `eval_dir`/val_bbox_results.json like train.py:416-421 -- the file COCOeval reads), lane decode + NMS on the device and the
-        prediction json of LaneHeader.scale_to_org (train.py:366-395) when a `lane_coder` (LaneCodec) is given.  COCOeval / LaneMetric
-        themselves need pycocotools / cv2 (out of scope).  Returns the per-class IoU tensor; everything else is left in self.last_valid."""
+        prediction json of LaneHeader.scale_to_org (train.py:366-395) when a `lane_coder` (LaneCodec) is given, and -- when the batches carry
+        the ground-truth lanes of train.py:393 as `gt_lane_json` (one {"Lines": [...], "Labels": [...]} dict per image) -- the lane F1 of
+        train.py:188,397,433 (LaneMetric, f1_measure, IoU 0.5, width 30, score threshold 0.5).  COCOeval needs pycocotools (out of scope).
+        Returns the per-class IoU tensor; everything else is left in self.last_valid."""
         from .coco_json import detections_to_coco, invert_affine, write_results
+        from .lane_metric import LaneMetric
+        lane_metric = LaneMetric(method="f1_measure", iou_thresh=0.5, lane_width=30, thresh_list=[0.5])           # train.py:188
+        lane_pairs = []
         net = self.hydranet
         net.eval()
         if self.train_seg:
@@ -280,13 +286,23 @@ class HydraTrainer:
                 l = self.cfgs["lane"]
                 lanes = net.laneheader.decode_batch(outputs["lane"]["predict_cls"], outputs["lane"]["predict_loc"], lane_coder,
                                                     l.get("conf_thres", 0.5), l.get("nms_thres", 100), False)
-                for ln, sh in zip(lanes, shapes):
+                gts = batch_data.get("gt_lane_json")
+                for i, (ln, sh) in enumerate(zip(lanes, shapes)):
                     pj = net.laneheader.scale_to_org(ln, net_w, net_h, sh["width"], sh["height"])
                     lane_result.append(dict(pr_result={**pj, **dict(Shape=sh)}))
+                    if gts is not None:
+                        lane_pairs.append(dict(pr_result=lane_result[-1]["pr_result"], gt_result={**gts[i], **dict(Shape=sh)}))
         net.train()
         scores = self.metric_evaluator_iou.compute() if self.train_seg else None
         path = write_results(detect_result, eval_dir) if (eval_dir and self.train_detect and self.rank == 0) else None
-        self.last_valid = dict(losses=losses, detect_result=detect_result, detect_json=path, lane_result=lane_result, iou=scores)
+        lane_f1 = None
+        if lane_pairs:
+            lane_metric(output=lane_pairs)                                                                         # train.py:397
+            lane_f1 = lane_metric.summary()                                                                        # train.py:433
+            if self.rank == 0:
+                print("=========================== metric lane %i ===========================" % epoch)
+                print(lane_f1)
+        self.last_valid = dict(losses=losses, detect_result=detect_result, detect_json=path, lane_result=lane_result, iou=scores, lane_f1=lane_f1)
         return scores
 
     def save(self, path: str):

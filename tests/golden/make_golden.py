@@ -11,6 +11,7 @@ gradients.  Run:  python tests/golden/make_golden.py
 """
 import functools
 import hashlib
+import json
 import os
 import sys
 import tempfile
@@ -36,7 +37,11 @@ def _install_shims():
     open(os.path.join(d, "torchvision", "ops", "__init__.py"), "w").write("")
     open(os.path.join(d, "torchvision", "ops", "boxes.py"), "w").write(
         "import sys\nsys.path.insert(0, %r)\nfrom oracle.hydranet_oracle import nms_greedy as nms, batched_nms\n" % ROOT)
-    open(os.path.join(d, "cv2.py"), "w").write("INTER_NEAREST = 0\n")
+    # cv2 stand-in: the constant model.py reads, and -- for head_lane/lane_metric.py -- line / bitwise_or (cv2.line = the oracle's restated
+    # thick-line rasteriser: parity with OpenCV itself stays unpinned, everything around it is the reference's own code)
+    open(os.path.join(d, "cv2.py"), "w").write(
+        "INTER_NEAREST = 0\nimport sys\nsys.path.insert(0, %r)\nfrom oracle.hydranet_oracle import cv2_line as line\n"
+        "def bitwise_or(a, b):\n    return a | b\n" % ROOT)
     open(os.path.join(d, "webcolors.py"), "w").write(
         "class _C:\n    red = green = blue = 0\n\ndef name_to_rgb(name):\n    return _C()\n")
     sys.path.insert(0, d)
@@ -445,9 +450,56 @@ def schedule_fixture():
     json.dump(out, open(os.path.join(HERE, "tuning_schedule.json"), "w"), indent=1)
 
 
+def lane_metric_fixture():
+    """(f4) lane F1 through the reference's own head_lane/lane_metric.py (spline_interp, calc_iou, evaluate_core, LaneMetric) on synthetic
+    ground-truth / prediction sets; cv2.line is the stand-in above.  -> lane_metric.json"""
+    from head_lane import lane_metric as LM
+    rs = np.random.RandomState(31)
+    H, W = 360, 640
+
+    def lane(x0, slope, curve, n, y0=350.0, dy=-40.0, jitter=0.0):
+        return [{"x": float(x0 + slope * i + curve * i * i + jitter * rs.randn()), "y": float(y0 + dy * i)} for i in range(n)]
+    splines = [lane(100, 10, 0.3, 8), lane(300, -5, 0.0, 2), lane(500, 2, -1.0, 3), lane(50, 30, 0.5, 9, jitter=2.0)]
+    out = {"H": H, "W": W, "splines": []}
+    for ln in splines:
+        ip = LM.spline_interp(lane=ln, step_t=1)
+        out["splines"].append({"lane": ln, "x": [float(p["x"]) for p in ip], "y": [float(p["y"]) for p in ip]})
+    images = []
+    for k in range(4):
+        gts = [lane(80 + 150 * j + 10 * k, 6 - 3 * j, 0.2 * (j - 1), 8) for j in range(3 + (k % 2))]
+        prs = []
+        for j, g in enumerate(gts):
+            if (j + k) % 4 == 3:
+                continue                                           # a missed lane
+            off = (2.0, 7.0, 25.0, 4.0)[(j + k) % 4]               # IoU well above / above / far below the 0.5 threshold
+            prs.append({"score": float(0.3 + 0.2 * ((j + 2 * k) % 4)), "points": [{"x": p["x"] + off, "y": p["y"]} for p in g]})
+        if k == 2:
+            prs.append({"score": 0.9, "points": lane(600, -20, 0.0, 6)})     # a false positive
+        shape = {"width": W, "height": H}
+        images.append(dict(pr_result={"Lines": prs, "Shape": shape}, gt_result={"Lines": gts, "Labels": [1] * len(gts), "Shape": shape}))
+    out["images"] = images
+    res = {}
+    for lw in (30, 10):
+        for thr in (0.5, 0.3):
+            m = LM.LaneMetric(method="f1_measure", iou_thresh=0.5, lane_width=lw, thresh_list=[thr])
+            [h.reset() for h in m.metric_handlers]
+            m(output=images)
+            h = m.metric_handlers[0]
+            res["%d,%g" % (lw, thr)] = {"records": h.result_record, "summary": h.summary(), "f1": m.summary()}
+            print("lane metric", lw, thr, h.summary())
+    out["results"] = res
+    # one IoU matrix in full (lane width 30, all predictions of image 0)
+    g0 = images[0]["gt_result"]["Lines"]
+    p0 = [l["points"] for l in images[0]["pr_result"]["Lines"]]
+    out["iou_image0"] = [[float(LM.calc_iou(g, p, dict(eval_height=H, eval_width=W, lane_width=30))) for p in p0] for g in g0]
+    json.dump(out, open(os.path.join(HERE, "lane_metric.json"), "w"))
+
+
 if __name__ == "__main__":
     _install_shims()
-    which = sys.argv[1:] or ["tiny", "tiny4", "kats", "big", "bigcond", "lane", "aux", "schedule"]
+    which = sys.argv[1:] or ["tiny", "tiny4", "kats", "big", "bigcond", "lane", "aux", "schedule", "lanemetric"]
+    if "lanemetric" in which:
+        lane_metric_fixture()
     if "tiny" in which:
         tiny_fixture()
     if "tiny4" in which:

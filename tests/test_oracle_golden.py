@@ -301,3 +301,29 @@ def test_preprocess_and_iou_vs_reference():
         b = O.seg_stat_scores(tgt.clamp_max(4), tgt, nc)
         sc = O.seg_iou_scores(*(x + y for x, y in zip(a, b)), **kw)
         np.testing.assert_allclose(sc.numpy(), z[f"iou/{name}/scores"], rtol=1e-6)
+
+
+def test_lane_metric_vs_reference_recording():
+    """(f4) lane F1: the oracle's restatement of head_lane/lane_metric.py (spline_interp / calc_params, calc_iou, evaluate_core) against the
+    recording made by the reference's own functions (tests/golden/lane_metric.json; cv2.line = the same restated rasteriser on both sides)."""
+    import json
+    import os
+    z = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "lane_metric.json")))
+    for s in z["splines"]:
+        ip = O.lane_spline_interp(s["lane"], 1)
+        assert len(ip) == len(s["x"])
+        np.testing.assert_allclose([p["x"] for p in ip], s["x"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose([p["y"] for p in ip], s["y"], rtol=0, atol=1e-9)
+    H, W = z["H"], z["W"]
+    g0 = z["images"][0]["gt_result"]["Lines"]
+    p0 = [l["points"] for l in z["images"][0]["pr_result"]["Lines"]]
+    iou = [[O.lane_iou(g, p, H, W, 30) for p in p0] for g in g0]
+    np.testing.assert_allclose(iou, z["iou_image0"], rtol=0, atol=1e-12)
+    for key, rec in z["results"].items():
+        lw, thr = key.split(",")
+        recs = []
+        for im in z["images"]:
+            gts = [l for l in im["gt_result"]["Lines"] if len(l) > 0]
+            prs = [l["points"] for l in im["pr_result"]["Lines"] if l["score"] > float(thr)]
+            recs.append(O.lane_evaluate(gts, prs, H, W, 0.5, int(lw)))
+        assert recs == rec["records"], key

@@ -312,3 +312,41 @@ def test_demo_loop_end_to_end(pkg):
                                 out["detection"]["classification"].float().cpu(), demo.det_conf, demo.det_iou)
         _check_det(det, ref_det)
     assert "NotImplemented" not in repr(demo.net.segheader.decode)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# (f4) lane F1 (head_lane/lane_metric.py)
+# ------------------------------------------------------------------------------------------------------------------------------------
+def test_lane_metric_device_vs_reference_recording(pkg):
+    """LaneMetric on the device (hn_lane_raster + hn_lane_iou) against the recording made by the reference's own lane_metric.py
+    (tests/golden/lane_metric.json): spline samples, the full IoU matrix of one image, per-image (gt, pr, hit) counts and the F1 summary for
+    two lane widths x two score thresholds -- identical (integer pixel counts on both sides; cv2.line itself is restated on both: unpinned)."""
+    import json
+    import os
+    P, O = pkg
+    from multitask_hydranet_amd import lane_metric as LM
+    z = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "lane_metric.json")))
+    for s in z["splines"]:
+        ip = LM.spline_interp(lane=s["lane"], step_t=1)
+        np.testing.assert_allclose([p["x"] for p in ip], s["x"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose([p["y"] for p in ip], s["y"], rtol=0, atol=1e-9)
+    H, W = z["H"], z["W"]
+    g0 = z["images"][0]["gt_result"]["Lines"]
+    p0 = [l["points"] for l in z["images"][0]["pr_result"]["Lines"]]
+    np.testing.assert_allclose(LM.iou_matrix(g0, p0, H, W, 30), np.array(z["iou_image0"]), rtol=0, atol=1e-12)
+    for key, rec in z["results"].items():
+        lw, thr = key.split(",")
+        m = LM.LaneMetric(method="f1_measure", iou_thresh=0.5, lane_width=int(lw), thresh_list=[float(thr)])
+        m.reset()
+        m(output=z["images"])
+        h = m.metric_handlers[0]
+        assert h.result_record == rec["records"], key
+        assert h.summary() == rec["summary"] and m.summary() == rec["f1"], key
+    # full-size frame, many lanes: device counts == the oracle's numpy rasteriser
+    rs = np.random.RandomState(2)
+    gts = [[{"x": float(200 + 300 * j + 15 * i + 0.8 * i * i * (j - 2)), "y": float(1070 - 90 * i)} for i in range(11)] for j in range(5)]
+    prs = [[{"x": p["x"] + float(rs.randint(-20, 20)), "y": p["y"]} for p in g] for g in gts[:4]] + [[{"x": 50.0, "y": 1000.0}, {"x": 1900.0, "y": 300.0}]]
+    got = LM.iou_matrix(gts, prs, 1080, 1920, 30)
+    ref = np.array([[O.lane_iou(g, p, 1080, 1920, 30) for p in prs] for g in gts])
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12)
+    assert got.max() > 0.5 and got.min() == 0.0
