@@ -155,7 +155,7 @@ class LaneMetric:
             raise NotImplementedError("method should be one of ['f1_measure', 'precision', 'recall']")
         self.method = method
         self.eval_params = dict(iou_thresh=iou_thresh, lane_width=lane_width)
-        self.metric_handlers = [LaneMetricCore(**self.eval_params, prob_thresh=t) for t in thresh_list] if thresh_list is not None \\
+        self.metric_handlers = [LaneMetricCore(**self.eval_params, prob_thresh=t) for t in thresh_list] if thresh_list is not None \
             else [LaneMetricCore(**self.eval_params, prob_thresh=None)]
 
     def __call__(self, output, *args, **kwargs):
