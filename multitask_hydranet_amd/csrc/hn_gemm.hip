@@ -837,6 +837,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
         for (int st = 0; st < S; ++st) { issue_w(ci, st, 0); adv(ci); }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        stamp();
         Cur cc = cur0();
         for (int st = 0; st < S; ++st) { compute(cc, st); adv(cc); }
     } else if (BC == 64 && !PIPE && xs.diag) {

@@ -9,6 +9,8 @@ from multitask_hydranet_amd._lib import lib
 
 dev = torch.device("cuda:0")
 N, c0, k, h, w = 16, 256, 256, 32, 64
+if os.environ.get("LAYER") == "d7":            # decoder.7: 64 -> 64 over the up-sampled 128 x 256 map, no skip operand (single chunk: wpre path)
+    c0, k, h, w = 64, 64, 128, 256
 x0 = torch.randn(N, h, w, c0, device=dev).to(torch.bfloat16)
 wt = torch.randn(k, c0, 3, 3, device=dev) * 0.02
 bias = torch.zeros(4 * k, device=dev)
@@ -17,10 +19,10 @@ w_eff = (wt.reshape(k * c0, 9) @ T.t()).view(k, c0, 2, 2, 3, 3).permute(2, 3, 0,
 wpe, wte = K.pack_conv_weight(w_eff)
 out = torch.empty(N, 2 * h, 2 * w, k, device=dev, dtype=torch.bfloat16)
 z1 = torch.randn(N, 2 * h, 2 * w, k, device=dev).to(torch.bfloat16)
-ADD = os.environ.get("NO_ADDEND") != "1"
+ADD = os.environ.get("NO_ADDEND") != "1" and os.environ.get("LAYER") != "d7"
 run = lambda: lib().call("hn_conv3x3_phase", x0.data_ptr(), 4, N, h, w, c0, c0, wpe.data_ptr(), 4 * k, K.kp32(c0), bias.data_ptr(), 3,
                          out.data_ptr(), k, k, z1.data_ptr() if ADD else None, k)
-buf = torch.zeros(64 * 128, device=dev, dtype=torch.int64)
+buf = torch.zeros(256 * 128, device=dev, dtype=torch.int64)
 for pipe in (0,):
     lib().query("hn_debug_direct_pipe", pipe)
     for _ in range(20):
@@ -33,10 +35,10 @@ for pipe in (0,):
         run()
         torch.cuda.synchronize()
         lib().query("hn_debug_knob", 14, 0)
-        b = buf.view(64, 128).cpu()
+        b = buf.view(256, 128).cpu()
         print(f"--- pipe{pipe} dbg {dbg} (cycles at 100 MHz s_memtime? -> deltas)")
         t0 = int(b[:16, 0][b[:16, 0] > 0].min())
-        for blk in (0, 3, 8, 15):
+        for blk in (0, 3, 8, 15, 40, 100):
             row = [int(v) for v in b[blk] if int(v) > 0]
             d = [row[i + 1] - row[i] for i in range(len(row) - 1)]
             print(f"blk {blk * 64}: start+{row[0] - t0} total {row[-1] - row[0]} | prologue {d[0]} | iters {d[1:-5]} | tail {d[-5:]}")
