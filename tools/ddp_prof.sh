@@ -1,5 +1,7 @@
+#!/bin/bash
+set -eu
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out/ddpprof
 export MASTER_ADDR=127.0.0.1 MASTER_PORT=29577
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/ddpprof/a -o ddp -- python3 $R/bench.py --ddp-world1 --no-extras --no-roofline --no-cpu-baseline --steps 10 --warmup 2 > $R/gpurun_out/ddpprof/ddp.log 2>&1
