@@ -1385,6 +1385,16 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTN& p, const int lid) {  
         xrow[i] = row;
         xoff[i] = (p.x.mode == 0 && c < Ctot) ? (m_begin + row) * (long)p.x.ld0 + c : -1;
     }
+    // per-lane LDS offsets of the transposed fragment reads (stage 0, k rows 0..15 of the 32-row half; +16 rows / +32 rows are constants:
+    // the swizzle key row & 7 does not change with them)
+    int zofs[TC], xofs[TN];
+    {
+        const int r0_ = g * 4 + q;
+#pragma unroll
+        for (int i = 0; i < TC; ++i) zofs[i] = r0_ * (BC * 2) + tn_swz<BC>(r0_, (wc * WC + i * 16) / 8 + (pp >> 1)) * 16 + (pp & 1) * 8;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) xofs[j] = r0_ * (BN * 2) + tn_swz<BN>(r0_, (wn * WN + j * 16) / 8 + (pp >> 1)) * 16 + (pp & 1) * 8;
+    }
     for (int it = 0; it <= S; ++it) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's LDS-DMA of stage it-1 has landed ...
         __syncthreads();                                           // ... and so has everybody else's; buffer it&1 is free again
@@ -1435,24 +1445,25 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTN& p, const int lid) {  
             }
         }
         if (it > 0 && !(HN_DBG(p) & 2)) {
-            const char* sZ = smem + ((it - 1) & 1) * STAGE;
-            const char* sX = sZ + ZB;
+            // (all LDS read offsets are loop invariants hoisted above: the per-read swizzle arithmetic -- 32 transposed reads per step at ~8
+            // VALU each against 32 MFMAs -- was a third of this kernel's time: the loop skeleton alone, loads / MFMAs / stores ablated, took
+            // 115 of the stage-4 group's 370 us, tools/bench_wgrad_group.py)
+            const int sbase = ((it - 1) & 1) * STAGE;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 bf16x8 a[TC], b[TN];
-                const int rlo = ks * 32 + g * 4 + q, rhi = rlo + 16;
 #pragma unroll
                 for (int i = 0; i < TC; ++i) {
-                    const int piece = (wc * WC + i * 16) / 8 + (pp >> 1);
-                    const trv4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(sZ + rlo * (BC * 2) + tn_swz<BC>(rlo, piece) * 16 + (pp & 1) * 8));
-                    const trv4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(sZ + rhi * (BC * 2) + tn_swz<BC>(rhi, piece) * 16 + (pp & 1) * 8));
+                    const char* pa = smem + sbase + zofs[i] + ks * 32 * (BC * 2);
+                    const trv4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(pa));
+                    const trv4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(pa + 16 * (BC * 2)));
                     a[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    const int piece = (wn * WN + j * 16) / 8 + (pp >> 1);
-                    const trv4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(sX + rlo * (BN * 2) + tn_swz<BN>(rlo, piece) * 16 + (pp & 1) * 8));
-                    const trv4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(sX + rhi * (BN * 2) + tn_swz<BN>(rhi, piece) * 16 + (pp & 1) * 8));
+                    const char* pb = smem + sbase + ZB + xofs[j] + ks * 32 * (BN * 2);
+                    const trv4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(pb));
+                    const trv4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(pb + 16 * (BN * 2)));
                     b[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
 #pragma unroll
@@ -1633,6 +1644,162 @@ __device__ __forceinline__ void gemm_tn_ring_body(const GemmTN& p, const int lid
         }
 }
 
+// The same contraction with the operand stages prefetched into REGISTERS (T14: issue early, write late): stage it + RS is requested with
+// global_load_dwordx4 while stage it is multiplied; the loaded registers are written to the two LDS buffers one step before their turn.
+// Why: this kernel is bound by bytes in flight.  Two workgroups per CU x one 32 KB LDS-DMA stage = 64 KB per CU against a 2.5 us
+// (Infinity-cache / HBM) round trip = 26 GB/s per CU (stage-4 group: loads 154 of the launch's 287 us, tools/trace_wgrad_group.sh); LDS
+// cannot hold a deeper ring at two workgroups per CU, but the register file can: a 256-thread workgroup at two per CU may use 256 VGPRs per
+// lane and the tile needs 64 accumulators -- RS = 2 stages are 64 more registers and triple the bytes in flight.  Plain rows (mode 0) and the
+// stride-2 gather (mode 1), one tap: the grouped 1x1 weight gradients.
+template <int BC, int BN, int WGC, int WGN, int RS>
+__device__ __forceinline__ void gemm_tn_regs_body(const GemmTN& p, const int lid) {
+    constexpr int WC = BC / WGC, WN = BN / WGN, TC = WC / 16, TN = WN / 16;
+    constexpr int ZPR = BC / 8, XPR = BN / 8, NT = 64 * WGC * WGN;
+    static_assert((64 * ZPR) % NT == 0 && (64 * XPR) % NT == 0 && RS == 2, "whole 16-byte pieces per thread and stage; two register stages");
+    constexpr int ZL = 64 * ZPR / NT, XL = 64 * XPR / NT;
+    constexpr int ZB = 64 * BC * 2, XB = 64 * BN * 2, STAGE = ZB + XB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wc = wave / WGN, wn = wave % WGN;
+    const int ntile = (p.KP + BN - 1) / BN;
+    const int bx = lid % ntile, by = (lid / ntile) % p.gy, bz = lid / (ntile * p.gy);
+    const int ci_blk = bx * BN, c_blk = by * BC;
+    const long m_begin = (long)bz * p.rows_per_split;
+    long m_end = m_begin + p.rows_per_split;
+    if (m_end > p.x.M) m_end = p.x.M;
+    const int S = m_end > m_begin ? (int)((m_end - m_begin + 63) >> 6) : 0;
+
+    f32x4 acc[TC][TN];
+#pragma unroll
+    for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // per-piece source offsets, advanced by 64 rows per stage; LDS image as in gemm_tn_body (lane-linear 16-byte pieces, source-side swizzle)
+    long zoff[ZL], xoff[XL];
+    int zrow[ZL], xrow[XL], pn[XL], py[XL], px[XL];
+#pragma unroll
+    for (int i = 0; i < ZL; ++i) {
+        const int e = tid + NT * i;
+        const int row = e / ZPR, cp = tn_swz<BC>(row, e - row * ZPR);
+        const int co = c_blk + cp * 8;
+        zrow[i] = row;
+        zoff[i] = co < p.Nout ? (m_begin + row) * (long)p.ldz + co : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+        const int e = tid + NT * i;
+        const int row = e / XPR, cp = tn_swz<BN>(row, e - row * XPR);
+        const int c = ci_blk + cp * 8;
+        xrow[i] = row;
+        xoff[i] = c < p.x.C0 ? (p.x.mode == 0 ? (m_begin + row) * (long)p.x.ld0 + c : (long)c) : -1;
+        decomp_row(p.x, m_begin + row, pn[i], py[i], px[i]);
+    }
+    const int adv_q = p.x.mode ? 64 / p.x.W : 0, adv_r = p.x.mode ? 64 % p.x.W : 0;
+    const int g = lane >> 4, t16 = lane & 15, q = t16 >> 2, pp = t16 & 3;
+    typedef __bf16 trv4 __attribute__((__vector_size__(4 * sizeof(__bf16))));
+    typedef __attribute__((address_space(3))) trv4* lds_b4;
+    int zofs[TC], xofs[TN];
+    {
+        const int r0_ = g * 4 + q;
+#pragma unroll
+        for (int i = 0; i < TC; ++i) zofs[i] = r0_ * (BC * 2) + tn_swz<BC>(r0_, (wc * WC + i * 16) / 8 + (pp >> 1)) * 16 + (pp & 1) * 8;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) xofs[j] = r0_ * (BN * 2) + tn_swz<BN>(r0_, (wn * WN + j * 16) / 8 + (pp >> 1)) * 16 + (pp & 1) * 8;
+    }
+
+    bf16x8 rz[RS][ZL], rx[RS][XL];
+    auto fetch = [&](int st, bf16x8 (&dz_)[ZL], bf16x8 (&dx_)[XL]) {         // stage st -> registers (zeros past the split / the tensor)
+        const long m0 = m_begin + (long)st * 64;
+        const bool live = st < S && !(HN_DBG(p) & 4);
+#pragma unroll
+        for (int i = 0; i < ZL; ++i) {
+            dz_[i] = (live && m0 + zrow[i] < m_end && zoff[i] >= 0) ? ld8(p.dz + zoff[i]) : zero8();
+            zoff[i] += zoff[i] >= 0 ? 64L * p.ldz : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < XL; ++i) {
+            const bf16* src = nullptr;
+            if (live && m0 + xrow[i] < m_end && xoff[i] >= 0)
+                src = p.x.mode == 0 ? p.x.x0 + xoff[i] : p.x.x0 + xoff[i] + (((long)pn[i] * p.x.Hi + 2 * py[i]) * p.x.Wi + 2 * px[i]) * p.x.ld0;
+            dx_[i] = src ? ld8(src) : zero8();
+            if (p.x.mode == 0) xoff[i] += xoff[i] >= 0 ? 64L * p.x.ld0 : 0;
+            else {
+                px[i] += adv_r;
+                py[i] += adv_q;
+                if (px[i] >= p.x.W) { px[i] -= p.x.W; ++py[i]; }
+                while (py[i] >= p.x.H) { py[i] -= p.x.H; ++pn[i]; }
+            }
+        }
+    };
+    auto stash = [&](int buf, const bf16x8 (&dz_)[ZL], const bf16x8 (&dx_)[XL]) {     // registers -> LDS buffer (the DMA path's lane-linear image)
+        char* sZ = smem + buf * STAGE;
+        char* sX = sZ + ZB;
+#pragma unroll
+        for (int i = 0; i < ZL; ++i) *reinterpret_cast<bf16x8*>(sZ + (NT * i + tid) * 16) = dz_[i];
+#pragma unroll
+        for (int i = 0; i < XL; ++i) *reinterpret_cast<bf16x8*>(sX + (NT * i + tid) * 16) = dx_[i];
+    };
+    auto multiply = [&](int buf) {
+        if (HN_DBG(p) & 2) return;
+        const int sbase = buf * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[TC], b[TN];
+#pragma unroll
+            for (int i = 0; i < TC; ++i) {
+                const char* pa = smem + sbase + zofs[i] + ks * 32 * (BC * 2);
+                const trv4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(pa));
+                const trv4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(pa + 16 * (BC * 2)));
+                a[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const char* pb = smem + sbase + ZB + xofs[j] + ks * 32 * (BN * 2);
+                const trv4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(pb));
+                const trv4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4)(pb + 16 * (BN * 2)));
+                b[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    // step it: the registers of slot it & 1 hold stage it (requested two steps ago) -> LDS buffer it & 1 (last read by step it - 2, which
+    // every wave finished before the barrier of step it - 1); request stage it + 2 into the same registers; barrier; multiply stage it.
+    fetch(0, rz[0], rx[0]);
+    fetch(1, rz[1], rx[1]);
+    for (int it = 0; it < S; it += 2) {
+        stash(0, rz[0], rx[0]);
+        fetch(it + 2, rz[0], rx[0]);
+        __syncthreads();
+        multiply(0);
+        if (it + 1 < S) {                                              // (workgroup-uniform)
+            stash(1, rz[1], rx[1]);
+            fetch(it + 3, rz[1], rx[1]);
+            __syncthreads();
+            multiply(1);
+        }
+    }
+    if (HN_DBG(p) & 1) return;
+    const int row_ld = p.out_ld ? p.out_ld : p.KP, ci_lim = p.out_ld ? p.cin_lim : p.KP;
+    float* part = p.part + (long)bz * p.Nout * p.KP;
+#pragma unroll
+    for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int ci = ci_blk + wn * WN + j * 16 + (lane & 15);
+            if (ci >= ci_lim) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = c_blk + wc * WC + i * 16 + (lane >> 4) * 4 + r;
+                if (co < p.Nout) part[(long)co * row_ld + ci] = acc[i][j][r];
+            }
+        }
+}
+
 // Several independent 1x1 weight gradients in ONE launch (hn_wgrad_group): the weight gradients of a whole backbone stage are not on the
 // backward pass's critical path, so they are deferred to the stage boundary and run together -- one launch that fills the chip (a
 // stage-4 gradient alone is 64 tiles of 128 x 128 over 2048 rows) instead of ~3 launches + 1 slab reduce per XBlock, mostly without a
@@ -1677,6 +1844,7 @@ __global__ __launch_bounds__(64 * WGC * WGN, 2) void gemm_tn_group_kernel(const 
     p.dz = jb.dz; p.ldz = jb.ldz; p.Nout = jb.Nout; p.KP = jb.KP; p.taps = 1; p.part = jb.part; p.rows_per_split = jb.rows_per_split;
     p.gy = jb.gy; p.phase_span = 0; p.bias_part = nullptr; p.out_ld = jb.out_ld; p.cin_lim = jb.C0; p.dbg = jobs.dbg;
     if constexpr (R == 0) gemm_tn_body<BC, BN, WGC, WGN>(p, lid);
+    else if constexpr (R < 0) gemm_tn_regs_body<BC, BN, WGC, WGN, -R>(p, lid);
     else gemm_tn_ring_body<BC, BN, WGC, WGN, BK, R>(p, lid);
 }
 
@@ -2981,6 +3149,10 @@ extern "C" int hn_wgrad_group(const long* jobs, int njobs, float* workspace, hip
     TNG_CASE(256, 256, 2, 4)
 #undef TNG_RING
 #endif
+    // 128 x 128: operand stages prefetched into registers, two ahead (gemm_tn_regs_body); knob 10 = 1 (tuning build): the LDS-DMA double buffer
+    if (g.bc == 128 && g.bn == 128 && variant != 1)
+        hipLaunchKernelGGL((gemm_tn_group_kernel<128, 128, 2, 2, 64, -2>), dim3((unsigned)blocks), dim3(256), lds, st, t);
+    else
     TNG_CASE(128, 128, 2, 2) TNG_CASE(128, 64, 2, 2) TNG_CASE(128, 32, 4, 1)
     TNG_CASE(64, 128, 2, 2) TNG_CASE(64, 64, 2, 2) TNG_CASE(64, 32, 4, 1)
     TNG_CASE(32, 128, 1, 4) TNG_CASE(32, 64, 1, 4) TNG_CASE(32, 32, 2, 2)

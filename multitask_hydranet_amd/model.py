@@ -273,6 +273,9 @@ class HydraNet(nn.Module):
 
     def _reindex(self):
         self._idx = {k: v for k, v in itertools.chain(self.named_parameters(), self.named_buffers()) if not k.startswith("_")}
+        # the parameters whose deferred gradients the flush node behind the backbone hands back (neck + det / lane heads): built once per
+        # (re)index, not on every forward (~700 named_parameters() walks per step on the eager path)
+        self._tail_params = [t for n_, t in self.named_parameters() if n_.startswith(("neck.", "detectheader.", "laneheader."))]
 
     def _apply(self, fn, recurse=True):
         r = super()._apply(fn, recurse)
@@ -692,7 +695,7 @@ class HydraNet(nn.Module):
         # consumers of every fused pyramid level among the heads: det towers (all five), seg decoder (P3..P5), lane fusion (P3..P6)
         users = [[h for h, on, lv in (("det", self.train_detect, range(5)), ("seg", self.train_seg, range(3)), ("lane", self.train_lane, range(4)))
                   if on and l in lv] for l in range(5)]
-        tail = [K.GradQueue(), [t for n_, t in self.named_parameters() if n_.startswith(("neck.", "detectheader.", "laneheader."))], False]
+        tail = [K.GradQueue(), self._tail_params, False]
         with off("shared"):
             bb = self._backbone_shared(x, tuple(c + (seg_skip if k == 0 else 0) for k, c in enumerate(neck_cnt)), tail)
             feats = [(a[(seg_skip if k == 0 else 0):], s) for k, (a, s) in enumerate(bb)]      # what the neck sees

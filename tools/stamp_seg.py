@@ -22,6 +22,12 @@ z1 = torch.randn(N, 2 * h, 2 * w, k, device=dev).to(torch.bfloat16)
 ADD = os.environ.get("NO_ADDEND") != "1" and os.environ.get("LAYER") != "d7"
 run = lambda: lib().call("hn_conv3x3_phase", x0.data_ptr(), 4, N, h, w, c0, c0, wpe.data_ptr(), 4 * k, K.kp32(c0), bias.data_ptr(), 3,
                          out.data_ptr(), k, k, z1.data_ptr() if ADD else None, k)
+if os.environ.get("LAYER") in ("g3", "g4"):       # grouped 3x3 conv (group width 8) of a stage-3 / stage-4 XBlock, forward with BatchNorm statistics
+    c, hh, ww = (376, 16, 32) if os.environ["LAYER"] == "g3" else (936, 8, 16)
+    xa = torch.randn(N, hh, ww, c, device=dev).to(torch.bfloat16)
+    wg = torch.randn(c, 8, 3, 3, device=dev) * 0.1
+    wk2, wd2 = K.pack_gconv_diag(wg)
+    run = lambda: K.k_gemm_nt(xa, None, 5, (N, hh, ww), wk2, c, 64, 9, stats=True)
 buf = torch.zeros(256 * 128, device=dev, dtype=torch.int64)
 for pipe in (0,):
     lib().query("hn_debug_direct_pipe", pipe)
@@ -38,8 +44,10 @@ for pipe in (0,):
         b = buf.view(256, 128).cpu()
         print(f"--- pipe{pipe} dbg {dbg} (cycles at 100 MHz s_memtime? -> deltas)")
         t0 = int(b[:16, 0][b[:16, 0] > 0].min())
-        for blk in (0, 3, 8, 15, 40, 100):
+        for blk in (0, 1, 2, 3, 8, 15, 40, 100):
             row = [int(v) for v in b[blk] if int(v) > 0]
+            if len(row) < 3:
+                continue
             d = [row[i + 1] - row[i] for i in range(len(row) - 1)]
             print(f"blk {blk * 64}: start+{row[0] - t0} total {row[-1] - row[0]} | prologue {d[0]} | iters {d[1:-5]} | tail {d[-5:]}")
 lib().query("hn_debug_direct_pipe", 0)
