@@ -364,7 +364,7 @@ def infer_bench(args, net, cfgs, h, w, dev, rank, world):
 def other_exchange_form(run, net, cfgs, batch, dev, rank, world, payload, args, dt_primary, headline=None):
     """Time the captured step with the gradient exchange in its other form (the headline used `run.reducer.graph_overlap`) -> dict with both
     forms' ms per step (max over ranks).  Every rank runs a watchdog: if the second capture / replay does not come back within
-    HN_BENCH_FORM_TIMEOUT seconds (default 240), the process ends with exit code 0 after rank 0 has printed the headline line with
+    HN_BENCH_FORM_TIMEOUT seconds (default 120), the process ends with exit code 0 after rank 0 has printed the headline line with
     exchange_forms.error set -- a wedged collective must not cost the driver its measurement."""
     import threading
     primary = "graph_overlap" if run.reducer.graph_overlap else "in_line"
@@ -374,7 +374,7 @@ def other_exchange_form(run, net, cfgs, batch, dev, rank, world, payload, args, 
     fallback = {"armed": True, "line": headline}      # rank 0: the finished headline line (printed by the watchdog if this wedges)
 
     def watchdog():
-        if done.wait(float(os.environ.get("HN_BENCH_FORM_TIMEOUT", "240"))) or not fallback["armed"]:
+        if done.wait(float(os.environ.get("HN_BENCH_FORM_TIMEOUT", "120"))) or not fallback["armed"]:
             return
         if rank == 0 and fallback.get("line") is not None:
             line = dict(fallback["line"])

@@ -3058,7 +3058,9 @@ static int wgrad_group_plan(const long* jobs, int njobs, GroupPlan& g) {
         tiles += (long)cdiv(jb[10], g.bc) * cdiv(((int)jb[7] + 31) & ~31, g.bn);
     }
     // pixel splits only while the launch would not fill the chip (~4 workgroups per CU, as hn_wgrad_plan): every split costs an fp32 slab
-    long want = (g_hn_knob[0] + tiles - 1) / tiles;
+    // (no split at all once the tiles alone come within a quarter of the target: the stage-4 group has 1 856 tiles; splitting it in two
+    // bought a second half-empty round but cost 203 MB of slabs and a 78 us reduce launch)
+    long want = 4 * tiles >= 3 * g_hn_knob[0] ? 1 : (g_hn_knob[0] + tiles - 1) / tiles;
     g.ws_floats = 0;
     for (int i = 0; i < njobs; ++i) {
         const long* jb = jobs + HN_WG_FIELDS * i;
