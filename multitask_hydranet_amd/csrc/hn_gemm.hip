@@ -2271,7 +2271,7 @@ __global__ void pack_w_kernel(const float* w, bf16* wp, bf16* wt, int Cout, int 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Phase-form effective weights of a 3x3 conv over a nearest-x2 up-sampled map (ops.py SegConvUp / SegOutUp): on the low-resolution grid the
+// Phase-form effective weights of a 3x3 conv over a nearest-x2 up-sampled map (ops/seg.py SegConvUp / SegOutUp): on the low-resolution grid the
 // conv has 4*Cout outputs, one Cout-vector per output phase (py,px):
 //   W_eff[(py*2+px)*Cout + o][c][dy][dx] = sum over the taps (ky,kx) whose up-sampled source falls on low-res offset (dy,dx)
 //   phase 0: k=0 -> d=0, k=1,2 -> d=1;   phase 1: k=0,1 -> d=1, k=2 -> d=2      (per axis; d = offset + 1)
