@@ -2725,7 +2725,10 @@ static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img
         // bf16 tiles of >= 64 couts leave through the LDS-staged epilogue only (whole 16-byte pieces of aligned rows)
         const bool staged_ok = (ldc & 7) == 0 && (Nout & 7) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
                                (!p.d2s || ((p.d2s & 7) == 0 && Nout % bc == 0));
-        if (bc >= 64 && !out_f32 && !staged_ok) return HN_ERR_UNSUPPORTED;
+        if (bc >= 64 && !out_f32 && !staged_ok) {       // (odd channel counts / unaligned slices: the 32-cout tile keeps the generic epilogue)
+            if (p.x.diag) return HN_ERR_UNSUPPORTED;
+            bc = 32;
+        }
         dim3 grid((unsigned)(cdiv(Nout, bc) * cdiv(W, 16) * cdiv(H, 16) * n_img));
         // preloaded form: one chunk, all its tap tiles (<= 16) in at most 32 KB next to the patch (two or three workgroups per CU as before)
         const int nsteps = phase_mode ? 4 : 9;

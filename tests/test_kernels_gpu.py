@@ -1089,3 +1089,17 @@ def test_hip_adam_tracks_torch_adam(K, wd):
             assert float((c - b).abs().max()) <= tol and float((d - b).abs().max()) <= tol and float((a - b).abs().max()) <= tol, (it, tuple(a.shape))
     for k, v in oc.state_dict()["state"].items():
         assert float(v["step"]) == float(ob.state_dict()["state"][k]["step"])
+
+
+def test_direct_conv_unstageable_output_takes_the_32_cout_tile(K):
+    """a bf16 output whose rows cannot leave through the LDS-staged epilogue (cout not a multiple of 8, or a channel-slice view that is
+    not 16-byte aligned) must not reach the >= 64-cout instantiations (compact staged epilogue only): the host picks the 32-cout tile,
+    whose generic epilogue stores 4 couts per lane directly.  Forward of Conv3x3(reflect_pad(x)) + bias + ELU, cout = 100."""
+    n, c0, cout, h, w = 2, 64, 100, 12, 20
+    x0 = rnd(n, c0, h, w)
+    wt = rnd(cout, c0, 3, 3, scale=(9 * c0) ** -0.5)
+    bs = rnd(cout, scale=0.1)
+    wp, _ = K.pack_conv_weight(wt)
+    out, _, _ = K.k_gemm_nt(nhwc(x0), None, 2, (n, h, w), wp, cout, K.kp32(c0), 9, bias=bs, act=3)
+    y = F.elu(F.conv2d(F.pad(x0.bfloat16().float(), [1, 1, 1, 1], mode="reflect"), wt.bfloat16().float(), bs))
+    close(nchw(out), y, ACT_TOL, "out")
