@@ -305,6 +305,11 @@ def test_se_gate(K):
     (112, 0, 512, 0, 3, False, 1, 6, 10),
     (128, 24, 128, 1, 3, False, 1, 12, 8),
     (64, 0, 5, 1, 0, True, 2, 8, 12),
+    # many-workgroup launches (hundreds of patches x several cout tiles, more than one round of workgroups per CU): forward with
+    # up-sampling + concat and a K that is not a multiple of 64, ragged patches, data gradient on the padded grid
+    (128, 24, 512, 1, 3, False, 8, 50, 100),
+    # ... and the folding data-gradient epilogue (interior + ring) at the size where ops.seg switches it on (>= 2^24 elements)
+    (256, 0, 256, 0, 3, False, 8, 64, 128),
 ])
 def test_seg_conv(K, c0, c1, cout, up, act, f32, n, h, w):
     """h, w = OUTPUT resolution; x0 lives at (h>>up, w>>up)."""
@@ -339,6 +344,7 @@ def test_seg_conv(K, c0, c1, cout, up, act, f32, n, h, w):
     (128, 24, 128, 1, 24, 16),       # decoder.5: skip operand joins as a pre-activation addend
     (256, 112, 256, 1, 16, 32),      # decoder.3 (the dominant launch): 128-cout tiles, four K chunks per phase in the data gradient
     (64, 16, 64, 3, 10, 6),          # ragged tiles (output 10x6 low-res cells)
+    (256, 112, 256, 8, 48, 96),      # decoder.3 at a many-workgroup size (phase forward with addend, skip conv, phase data gradient)
 ])
 @pytest.mark.parametrize("fwd_phase,dgrad_phase", [(True, True), (False, True), (True, False), (None, None)])
 def test_seg_conv_up_phase_form(K, c0, c1, cout, n, h, w, fwd_phase, dgrad_phase):
