@@ -711,6 +711,9 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
     };
     auto tap_at = [&](const Cur& c) { return p.phase_mode ? ((c.ph >> 1) + (c.ti >> 1)) * 3 + (c.ph & 1) + (c.ti & 1) : c.ti; };
     const int xc0 = xs.diag ? c_blk : 0;                              // first input channel of chunk 0
+    // the tile's bias values wait in LDS behind the operand buffers (the epilogue's per-sub-tile global loads were a dependent round trip each)
+    float* sbias = reinterpret_cast<float*>(smem + XBUFS * XBYTES + (!PIPE && p.wpre ? S : WBUFS) * WBYTES);
+    if (tid < BC) sbias[tid] = (p.bias && c_blk + tid < p.Nout) ? p.bias[c_blk + tid] : 0.f;
 
     // patch pieces owned by this thread: e = tid + 512 i -> patch pixel e>>3, PHYSICAL piece e&7 (logical = physical ^ (patch column & 7)).
     // One register per piece: the source pixel as (gy << 16 | gx) in full-resolution coordinates (-1: outside / zero); the row index in
@@ -827,6 +830,25 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
             }
         }
     };
+    // phase form with a pre-activation addend (the skip operand's partial result): all TC x TP loads of a lane are requested up front.
+    // Issued one by one inside the loop below each was a dependent round trip: the stamps show 26 000 cycles for this epilogue, a
+    // quarter of the workgroup's lifetime, against 16 x 3 400 cycles for all of its tap steps (tools/stamp_seg.py).
+    const int ox = ox0 + (lane & 15);
+    const bool pre_add = !OUT_F32 && p.d2s && p.addend;
+    constexpr int AQ = 2;                                             // ring: cout sub-tile i (in use) and i + 1 (in flight); a third slot
+    bf16x4 addq[AQ][TP];                                              // spilled 13 VGPRs = +24 MB of scratch traffic per launch
+    auto load_add = [&](int i, bf16x4 (&dst)[TP]) {
+        const int co0 = c_blk + wc * WCO + i * 16 + (lane >> 4) * 4;
+        const int ph = co0 / p.d2s, oc = co0 - ph * p.d2s;
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            const int oy = oy0 + wp * ROWS + j;
+            const long opix = ((long)(n * 2 * xs.H + 2 * oy + (ph >> 1)) * (2 * xs.W) + 2 * ox + (ph & 1));
+            dst[j] = (oy < xs.H && ox < xs.W && co0 < p.Nout) ? *reinterpret_cast<const bf16x4*>(p.addend + opix * p.ld_add + oc)
+                                                              : (bf16x4){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+        }
+    };
+    bool add_issued = false;
     stamp();
     if (!PIPE && p.wpre) {
         // Single 64-channel chunk and few tap steps (the phase-form output convs: 4 steps): the patch and ALL weight tiles are requested
@@ -920,27 +942,37 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
         }
     } else {
         Cur ci = cur0(), cc = cur0();
-        for (int it = 0; it <= S; ++it) {
+        for (int it = 0; it < S; ++it) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             stamp();
             // single patch buffer: at a chunk boundary the last tap of the old chunk is multiplied BEFORE the new patch may overwrite it
-            const bool boundary = XBUFS == 1 && it > 0 && it < S && ci.ti == 0;
+            const bool boundary = XBUFS == 1 && it > 0 && ci.ti == 0;
             if (boundary) {
                 compute(cc, (it - 1) & 1);
                 adv(cc);
                 __syncthreads();
             }
-            if (it < S) {
-                issue_w(ci, it & 1, it);
-                if (ci.ti == 0) issue_x(ci.chunk);
-                adv(ci);
-            }
+            issue_w(ci, it & 1, it);
+            if (ci.ti == 0) issue_x(ci.chunk);
+            adv(ci);
             if (it > 0 && !boundary) {
                 compute(cc, (it - 1) & 1);
                 adv(cc);
             }
         }
+        // last tap step, peeled: the loaders' registers (patch / weight row offsets) are dead here, which makes room for the addend of the
+        // first cout sub-tile -- requested now (HBM: 2-3 us under load), it flies under this step's MFMAs instead of heading the epilogue;
+        // the second one follows behind the MFMAs (both at once: 4 spilled VGPRs at BC = 128)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        stamp();
+        if (pre_add) {
+            load_add(0, addq[0]);
+            add_issued = true;
+        }
+        compute(cc, (S - 1) & 1);
+        if (pre_add && TC > 1) load_add(1, addq[1]);
     }
 
     stamp();
@@ -1007,7 +1039,6 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
     }
     // epilogue: bias, activation (one uniform branch per 4 values, in place on the accumulators: no second copy of the wave tile in
     // registers), store 4 consecutive couts per lane
-    const int ox = ox0 + (lane & 15);
     // phase form, bf16: the depth-to-space scatter writes 8 bytes per lane 1 KiB apart; partial-line writes make L2 fetch every output
     // line before merging (measured: FETCH_SIZE +124 MB, WRITE_SIZE +28 MB on a 67 MB output).  The finished bf16 tile is staged in LDS
     // ([256 px][BC], 16-byte pieces XOR-swizzled by the pixel) and leaves as whole BC*2-byte runs per output pixel.
@@ -1020,26 +1051,9 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
                            ((32 * p.d2s) & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0;
     char* stage = smem;
     if (stage_d2s || stage_f32) __syncthreads();                      // every wave is done with the operand buffers
-    // phase form with a pre-activation addend (the skip operand's partial result): all TC x TP loads of a lane are requested up front.
-    // Issued one by one inside the loop below each was a dependent round trip: the stamps show 26 000 cycles for this epilogue, a
-    // quarter of the workgroup's lifetime, against 16 x 3 400 cycles for all of its tap steps (tools/stamp_seg.py).
-    const bool pre_add = !OUT_F32 && p.d2s && p.addend;
-    constexpr int AQ = 2;                                             // ring: cout sub-tile i (in use) and i + 1 (in flight); a third slot
-    bf16x4 addq[AQ][TP];                                              // spilled 13 VGPRs = +24 MB of scratch traffic per launch
-    auto load_add = [&](int i, bf16x4 (&dst)[TP]) {
-        const int co0 = c_blk + wc * WCO + i * 16 + (lane >> 4) * 4;
-        const int ph = co0 / p.d2s, oc = co0 - ph * p.d2s;
+    if (pre_add && !add_issued) {                                      // (loop forms without the early request)
 #pragma unroll
-        for (int j = 0; j < TP; ++j) {
-            const int oy = oy0 + wp * ROWS + j;
-            const long opix = ((long)(n * 2 * xs.H + 2 * oy + (ph >> 1)) * (2 * xs.W) + 2 * ox + (ph & 1));
-            dst[j] = (oy < xs.H && ox < xs.W && co0 < p.Nout) ? *reinterpret_cast<const bf16x4*>(p.addend + opix * p.ld_add + oc)
-                                                              : (bf16x4){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
-        }
-    };
-    if (pre_add) {                                                     // AQ of the TC = 4 rounds in flight from the start (the addend
-#pragma unroll
-        for (int q = 0; q < AQ && q < TC; ++q) load_add(q, addq[q]);   // comes from HBM: 2-3 us under load)
+        for (int q = 0; q < AQ && q < TC; ++q) load_add(q, addq[q]);
     }
     if constexpr (BC >= 64 && !OUT_F32) {
         // (the host entry point only launches these instantiations when the staged form applies: stage_d2s is true)
@@ -1053,10 +1067,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
         for (int i = 0; i < TC; ++i) {
             // one cout sub-tile at a time, start to finish: its 16 accumulator registers are dead once it is staged (all 64 values
             // through bias / addend, then all through the activation, then all staged kept everything live at once: 13 spilled VGPRs)
-            const int co0 = c_blk + wc * WCO + i * 16 + (lane >> 4) * 4;
-            f32x4 bs;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bs[r] = (p.bias && co0 + r < p.Nout) ? p.bias[co0 + r] : 0.f;
+            const f32x4 bs = *reinterpret_cast<const f32x4*>(sbias + wc * WCO + i * 16 + (lane >> 4) * 4);
 #pragma unroll
             for (int j = 0; j < TP; ++j) acc[i][j] += bs;
             if (pre_add) {
@@ -2742,6 +2753,7 @@ static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img
 #endif
         const size_t lds = pipe ? (size_t)2 * (((18 * 18 * 4 + 511) / 512) * 512 * 16) + 4 * (size_t)(512 * 16)
                                 : (size_t)((18 * 18 * 128 + 1023) / 1024 * 1024) + (p.wpre ? nsteps : 2) * (size_t)bc * 128;
+        const size_t lds_bias = (size_t)bc * 4;                     // the tile's bias values behind the operand buffers
         // > 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel (done on the first, un-captured call)
         static std::atomic<unsigned long long> optin{0};
         if (!lds_optin(optin, {(const void*)conv3x3_direct_kernel<16, true, false>, (const void*)conv3x3_direct_kernel<16, false, false>,
@@ -2754,15 +2766,15 @@ static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img
         if (pipe) {
             if (!lds_optin(optin_pipe, {(const void*)conv3x3_direct_kernel<64, false, true>, (const void*)conv3x3_direct_kernel<128, false, true>}))
                 return HN_ERR_LAUNCH;
-            if (bc == 64) hipLaunchKernelGGL((conv3x3_direct_kernel<64, false, true>), grid, dim3(512), lds, st, p);
-            else hipLaunchKernelGGL((conv3x3_direct_kernel<128, false, true>), grid, dim3(512), lds, st, p);
+            if (bc == 64) hipLaunchKernelGGL((conv3x3_direct_kernel<64, false, true>), grid, dim3(512), lds + lds_bias, st, p);
+            else hipLaunchKernelGGL((conv3x3_direct_kernel<128, false, true>), grid, dim3(512), lds + lds_bias, st, p);
             HN_LAUNCH_CHECK();
         }
 #endif
 #define DIRECT_CASE(BC_) \
         if (bc == BC_) { \
-            if (out_f32) hipLaunchKernelGGL((conv3x3_direct_kernel<BC_, true, false>), grid, dim3(512), lds, st, p); \
-            else hipLaunchKernelGGL((conv3x3_direct_kernel<BC_, false, false>), grid, dim3(512), lds, st, p); \
+            if (out_f32) hipLaunchKernelGGL((conv3x3_direct_kernel<BC_, true, false>), grid, dim3(512), lds + lds_bias, st, p); \
+            else hipLaunchKernelGGL((conv3x3_direct_kernel<BC_, false, false>), grid, dim3(512), lds + lds_bias, st, p); \
         }
         DIRECT_CASE(16) DIRECT_CASE(32) DIRECT_CASE(64) DIRECT_CASE(128)
 #undef DIRECT_CASE
