@@ -666,13 +666,18 @@ class HydraNet(nn.Module):
     # ------------------------------------------------------------------------------------------------------
     def forward(self, x, mode="train"):
         """HydraNet.forward, model/model.py:159-198."""
-        K.clear_pack_cache()
         if self._folded is not None and not self.training:
             self._check_folded()
         params = {id(t) for t in self.parameters()}
         if self._pack_plan is not None and not self._pack_plan.valid():
             self._pack_plan = None                 # a parameter's storage was replaced: re-record the weights on this forward
-        if self._pack_plan is not None and x.is_cuda:
+        # eval mode with unchanged parameters (serving): the packed operands of the last forward are still right -- no pack launches
+        reuse = not self.training and self._pack_plan is not None and x.is_cuda and self._pack_plan.fresh()
+        if not reuse:
+            K.clear_pack_cache()
+        if reuse:
+            pass
+        elif self._pack_plan is not None and x.is_cuda:
             self._pack_plan.run()                  # every dense conv weight -> bf16 operands, one launch
         elif x.is_cuda:
             K.start_pack_log()                     # first forward on this device: record which weights get packed

@@ -188,6 +188,7 @@ class PackPlan:
         self.small_table, self.small_owner = mk(small_rows, torch.int64), mk(small_owner, torch.int32)
         self.n_dense = len(dense_rows)
         self.device = dev
+        self._ran = None                                   # parameter versions at the last run()
         self.ptrs = [(w.data_ptr(), meta.data_ptr() if isinstance(meta, torch.Tensor) else 0) for _, w, meta in entries]
 
     @property
@@ -201,7 +202,17 @@ class PackPlan:
         return all(w.data_ptr() == p_[0] and w.device == self.device and (not isinstance(meta, torch.Tensor) or meta.data_ptr() == p_[1])
                    for (_, w, meta), p_ in zip(self.entries, self.ptrs))
 
+    def _versions(self):
+        return [(w._version, meta._version if isinstance(meta, torch.Tensor) else 0) for _, w, meta in self.entries]
+
+    def fresh(self):
+        """the packed buffers still hold what run() made of the CURRENT parameter values (no in-place update since) and the pack cache still
+        points at them: an eval-mode forward may skip run() (serving: the weights are constants; inside a captured deploy forward the two
+        pack launches then are not part of the graph at all)"""
+        return self._ran == self._versions() and all(_PACK_CACHE.get((key, id(w)), (None,))[0] is w for key, w, _ in self.entries)
+
     def run(self):
+        self._ran = self._versions()
         if self.dense_table is not None:
             lib().call("hn_pack_weights_batched", ptr(self.dense_table), self.n_dense, self.dense_blocks, ptr(self.dense_owner))
         if self.small_table is not None:

@@ -319,6 +319,10 @@ def test_end_to_end_losses_features_and_statistics(env):
 def test_deploy_mode_and_bit_exact_bookkeeping(env):
     z, cfgs, net, batch, oracle, sd = env
     from multitask_hydranet_amd.postprocess import postprocess
+    # (the reference recorded its deploy outputs AFTER one training step: eval mode saw the post-step state, "sd_after/")
+    state = dict(sd)
+    state.update({k[9:]: torch.from_numpy(z[k].copy()) for k in z.files if k.startswith("sd_after/")})
+    net.load_state_dict(state)
     net.eval()
     with torch.no_grad():
         dep = net(batch["image"].to("cuda:0"), "deploy")
@@ -617,6 +621,47 @@ def test_inference_folded_batchnorm(env):
     finally:
         net.train()
     assert net._folded is None
+
+
+@pytest.mark.gpu
+def test_eval_forward_reuses_packed_operands_until_a_parameter_changes(env):
+    """Serving: in eval mode with unchanged parameters the packed bf16 operands (PackPlan) and the det towers' eval-mode BatchNorm
+    coefficients of the previous forward are reused -- no pack / coefficient launches -- and an in-place update of a weight or of a running
+    statistic is picked up by the next forward (version counters)."""
+    z, cfgs, net, batch, oracle, sd = env
+    net.load_state_dict(sd)
+    x = batch["image"].to("cuda:0")
+    net.eval()
+    try:
+        with torch.no_grad():
+            net(x)
+            ref = net(x)                                           # the plan exists now and has run
+            plan = net._pack_plan
+            assert plan is not None and plan.fresh()
+            runs = []
+            orig = plan.run
+            plan.run = lambda: (runs.append(1), orig())[1]
+            again = net(x)
+            assert not runs, "an eval forward with unchanged parameters must not re-pack"
+            assert torch.equal(again["seg"], ref["seg"])
+            for k in ("classification", "regression"):
+                assert torch.equal(again["detection"][k], ref["detection"][k]), k
+            names = list(net._idx)
+            wname = [n for n in names if n.startswith("segheader.") and n.endswith(".weight")][-1]
+            net._idx[wname].mul_(1.5)
+            assert not plan.fresh()
+            changed = net(x)
+            assert runs == [1] and not torch.equal(changed["seg"], ref["seg"])
+            assert torch.equal(changed["detection"]["classification"], ref["detection"]["classification"])
+            rname = [n for n in names if n.startswith("detectheader.") and n.endswith(".running_mean")]
+            if rname:
+                net._idx[rname[0]].add_(0.25)
+                moved = net(x)
+                assert (not torch.equal(moved["detection"]["classification"], ref["detection"]["classification"]) or
+                        not torch.equal(moved["detection"]["regression"], ref["detection"]["regression"]))
+    finally:
+        net.train()
+        net.load_state_dict(sd)
 
 
 @pytest.mark.gpu
