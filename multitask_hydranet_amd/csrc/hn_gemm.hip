@@ -499,7 +499,10 @@ __global__ __launch_bounds__(256 * KG) void gemm_nt_kernel(const GemmNT p) {
     }
     if (want_stats) {
         if (!staged) __syncthreads();                                 // the operand ring is free: [WGP][BC][2] floats of it hold the wave sums
-        float* red = reinterpret_cast<float*>(smem);
+        // (BEHIND the staged output tile: the wave sums and the tile are written in one phase and read after ONE common barrier --
+        // the statistics used to cost two barriers of their own, +2.2 us on the 11 us stage-4 GEMM)
+        static_assert(BP * BC * 2 + WGP * BC * 8 <= R * KG * STAGE, "staged tile + wave sums fit the operand ring");
+        float* red = reinterpret_cast<float*>(smem + BP * BC * 2);
 #pragma unroll
         for (int i = 0; i < TC; ++i) {
             const int co0 = c_blk + wc * WC + i * 16 + (lane >> 4) * 4;
@@ -534,15 +537,6 @@ __global__ __launch_bounds__(256 * KG) void gemm_nt_kernel(const GemmNT p) {
                 for (int r = 0; r < 4; ++r) { red[(wp * BC + cl + r) * 2] = s1[r]; red[(wp * BC + cl + r) * 2 + 1] = s2[r]; }
             }
         }
-        __syncthreads();
-        if (tid < BC && c_blk + tid < p.Nout) {                       // one partial row per pixel tile: the WGP wave sums in fixed order
-            float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-            for (int k = 0; k < WGP; ++k) { t1 += red[(k * BC + tid) * 2]; t2 += red[(k * BC + tid) * 2 + 1]; }
-            p.psum[(long)p_tile * p.Nout + c_blk + tid] = t1;
-            if (p.psq) p.psq[(long)p_tile * p.Nout + c_blk + tid] = t2;
-        }
-        __syncthreads();                                              // before the staged epilogue reuses the same LDS
     }
     act_fwd_n(vv, p.act);
     if (staged) {
@@ -592,8 +586,16 @@ __global__ __launch_bounds__(256 * KG) void gemm_nt_kernel(const GemmNT p) {
             }
         }
     }
+    if (staged || want_stats) __syncthreads();
+    if (want_stats && tid < BC && c_blk + tid < p.Nout) {             // one partial row per pixel tile: the WGP wave sums in fixed order
+        const float* red = reinterpret_cast<const float*>(smem + BP * BC * 2);
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < WGP; ++k) { t1 += red[(k * BC + tid) * 2]; t2 += red[(k * BC + tid) * 2 + 1]; }
+        p.psum[(long)p_tile * p.Nout + c_blk + tid] = t1;
+        if (p.psq) p.psq[(long)p_tile * p.Nout + c_blk + tid] = t2;
+    }
     if (staged) {
-        __syncthreads();
         bf16* outp = reinterpret_cast<bf16*>(p.out);
 #pragma unroll 2
         for (int idx = tid; idx < BP * NPC; idx += 256) {
