@@ -211,9 +211,13 @@ __device__ __forceinline__ void stat_terms4(int emode, const f32x4 q, const f32x
 // KG = 2: 512 threads = two independent 4-wave groups that walk alternate K stages (their own LDS stages, common barriers) and meet in LDS
 // before the epilogue: half the barrier-separated K steps per workgroup for the small-M GEMMs of the deep stages, whose 15-step K loop is
 // pure latency (one or two workgroups per CU).
-template <int BC, int BP, int WGC, int WGP, bool OUT_F32, int R, bool XF = false, int KG = 1>
+// PLAIN: plain pixel rows of ONE tensor, one tap (x.mode 0: every 1x1 conv and its data gradient) -- no coordinate tables, no tap
+// bookkeeping, per-row source offsets computed once: the generic form carries ~1 000 instructions of prologue and a branchy loop body for
+// the 3x3 / stride-2 / concat modes that these launches (the latency-bound majority of the step's GEMMs) never use.
+template <int BC, int BP, int WGC, int WGP, bool OUT_F32, int R, bool XF = false, int KG = 1, bool PLAIN = false>
 __global__ __launch_bounds__(256 * KG) void gemm_nt_kernel(const GemmNT p) {
     static_assert(!XF || R == 2, "the register-staged operand transform is written for the double buffer");
+    static_assert(!PLAIN || !XF, "the plain-rows form has no operand transform");
     static_assert(KG == 1 || (!XF && R == 2), "the K-group form is written for the plain double buffer");
     constexpr int WC = BC / WGC, WP = BP / WGP, TC = WC / 16, TP = WP / 16;
     constexpr int XR = BP / 32, WR = (BC + 31) / 32;
@@ -234,7 +238,10 @@ __global__ __launch_bounds__(256 * KG) void gemm_nt_kernel(const GemmNT p) {
 
     int xn[XR], xy[XR], xx[XR];
 #pragma unroll
-    for (int i = 0; i < XR; ++i) decomp_row(p.x, p_blk + r0 + 32 * i, xn[i], xy[i], xx[i]);
+    for (int i = 0; i < XR; ++i) {
+        if constexpr (PLAIN) { xn[i] = 0; xy[i] = 0; xx[i] = 0; }
+        else decomp_row(p.x, p_blk + r0 + 32 * i, xn[i], xy[i], xx[i]);
+    }
 
     // 3x3 modes: the source coordinates of a tap are separable in (oy, ky) and (ox, kx), so they are tabulated once per block in LDS:
     //   ty0[ky][oy], tx0[kx][ox] in x0's grid (reflected, >> up for mode 2; -1 = outside for mode 3); ty1/tx1 in x1's full-res grid
@@ -242,7 +249,7 @@ __global__ __launch_bounds__(256 * KG) void gemm_nt_kernel(const GemmNT p) {
     int* tx0 = ty0 + 3 * p.x.H;
     int* ty1 = tx0 + 3 * p.x.W;
     int* tx1 = ty1 + 3 * p.x.H;
-    if (p.x.mode >= 2) {
+    if (!PLAIN && p.x.mode >= 2) {
         for (int i = tid; i < 3 * p.x.H; i += 256) {
             const int k = i / p.x.H, o = i - k * p.x.H;
             if (p.x.mode == 2) {
@@ -271,9 +278,15 @@ __global__ __launch_bounds__(256 * KG) void gemm_nt_kernel(const GemmNT p) {
     }
     const int hh0 = p.x.mode == 2 ? p.x.Hi >> p.x.up : p.x.Hi, ww0 = p.x.mode == 2 ? p.x.Wi >> p.x.up : p.x.Wi;
 
-    int tap = (2 * kg + half) / kc, cidx = (2 * kg + half) - tap * kc;   // chunk q = 2*stage + half -> (tap, cidx); group kg owns stages it*KG + kg
-    const int Ctot = p.x.C0 + p.x.C1;
+    int tap = PLAIN ? 0 : (2 * kg + half) / kc, cidx = (2 * kg + half) - tap * kc;   // chunk q = 2*stage + half -> (tap, cidx); group kg owns stages it*KG + kg
+    const int Ctot = PLAIN ? p.x.C0 : p.x.C0 + p.x.C1;
     int pix0[XR], pix1[XR];                        // per-row source PIXEL index for the current tap (-1 = zeros); pixels fit int32
+    long xoff[XR];                                 // PLAIN: element offset of the row in x0 (-1 = zeros)
+#pragma unroll
+    for (int i = 0; i < XR; ++i) {
+        const long m = p_blk + r0 + 32 * i;
+        xoff[i] = m < p.x.M ? m * p.x.ld0 : -1;
+    }
     auto retap = [&]() {
         const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
 #pragma unroll
@@ -293,7 +306,7 @@ __global__ __launch_bounds__(256 * KG) void gemm_nt_kernel(const GemmNT p) {
             pix1[i] = a1;
         }
     };
-    if (tap < p.taps) retap();
+    if (!PLAIN && tap < p.taps) retap();
     else {
 #pragma unroll
         for (int i = 0; i < XR; ++i) { pix0[i] = -1; pix1[i] = -1; }
@@ -363,6 +376,12 @@ __global__ __launch_bounds__(256 * KG) void gemm_nt_kernel(const GemmNT p) {
                     const bf16* src = xval[i] ? xbase + (long)pix * ldx : g_zero_piece;
                     xraw[i] = ld8(src);
                 }
+            } else if constexpr (PLAIN) {
+#pragma unroll
+                for (int i = 0; i < XR; ++i) {
+                    const bf16* src = (cv && xoff[i] >= 0) ? p.x.x0 + xoff[i] + c : g_zero_piece;
+                    glds16(src, sX + (wave * 8 + 32 * i) * 128);
+                }
             } else {
 #pragma unroll
             for (int i = 0; i < XR; ++i) {
@@ -378,7 +397,9 @@ __global__ __launch_bounds__(256 * KG) void gemm_nt_kernel(const GemmNT p) {
                     glds16(src, sW + (wave * 8 + 32 * i) * 128);
                 }
             }
-            if (qv) {
+            if constexpr (PLAIN) {
+                cidx += 2 * KG;                                        // (one tap: cidx is the chunk index q itself, q < Q ends the loads)
+            } else if (qv) {
                 cidx += 2 * KG;
                 if (cidx >= kc) {
                     while (cidx >= kc) { cidx -= kc; ++tap; }
@@ -2522,6 +2543,14 @@ static int launch_nt_r(const GemmNT& p, int out_f32, hipStream_t st) {
                                (const void*)gemm_nt_kernel<BC, BP, WGC, WGP, false, R, false, KG>}))
             return HN_ERR_LAUNCH;
     }
+#ifndef HN_NO_PLAIN
+    if constexpr (R == 2 && BC == 64 && BP == 64) {                   // plain pixel rows, one tap, bf16 out: the lean instantiation
+        if (p.x.mode == 0 && p.taps == 1 && p.x.C1 == 0 && !out_f32) {
+            hipLaunchKernelGGL((gemm_nt_kernel<BC, BP, WGC, WGP, false, R, false, KG, true>), grid, dim3(256 * KG), lds, st, p);
+            HN_LAUNCH_CHECK();
+        }
+    }
+#endif
     if (out_f32) hipLaunchKernelGGL((gemm_nt_kernel<BC, BP, WGC, WGP, true, R, false, KG>), grid, dim3(256 * KG), lds, st, p);
     else hipLaunchKernelGGL((gemm_nt_kernel<BC, BP, WGC, WGP, false, R, false, KG>), grid, dim3(256 * KG), lds, st, p);
     HN_LAUNCH_CHECK();
