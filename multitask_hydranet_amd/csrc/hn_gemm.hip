@@ -2540,13 +2540,16 @@ static int launch_nt_r(const GemmNT& p, int out_f32, hipStream_t st) {
     if (lds > 64 * 1024) {
         static std::atomic<unsigned long long> optin{0};             // one per instantiation, one bit per device
         if (!lds_optin(optin, {(const void*)gemm_nt_kernel<BC, BP, WGC, WGP, true, R, false, KG>,
-                               (const void*)gemm_nt_kernel<BC, BP, WGC, WGP, false, R, false, KG>}))
+                               (const void*)gemm_nt_kernel<BC, BP, WGC, WGP, false, R, false, KG>,
+                               (const void*)gemm_nt_kernel<BC, BP, WGC, WGP, true, R, false, KG, (R == 2)>,
+                               (const void*)gemm_nt_kernel<BC, BP, WGC, WGP, false, R, false, KG, (R == 2)>}))
             return HN_ERR_LAUNCH;
     }
 #ifndef HN_NO_PLAIN
-    if constexpr (R == 2 && BC == 64 && BP == 64) {                   // plain pixel rows, one tap, bf16 out: the lean instantiation
-        if (p.x.mode == 0 && p.taps == 1 && p.x.C1 == 0 && !out_f32) {
-            hipLaunchKernelGGL((gemm_nt_kernel<BC, BP, WGC, WGP, false, R, false, KG, true>), grid, dim3(256 * KG), lds, st, p);
+    if constexpr (R == 2) {                                           // plain pixel rows, one tap: the lean instantiation
+        if (p.x.mode == 0 && p.taps == 1 && p.x.C1 == 0) {
+            if (out_f32) hipLaunchKernelGGL((gemm_nt_kernel<BC, BP, WGC, WGP, true, R, false, KG, true>), grid, dim3(256 * KG), lds, st, p);
+            else hipLaunchKernelGGL((gemm_nt_kernel<BC, BP, WGC, WGP, false, R, false, KG, true>), grid, dim3(256 * KG), lds, st, p);
             HN_LAUNCH_CHECK();
         }
     }
