@@ -528,7 +528,20 @@ __global__ __launch_bounds__(256 * KG) void gemm_nt_kernel(const GemmNT p) {
         for (int i = 0; i < TC; ++i) {
             const int co0 = c_blk + wc * WC + i * 16 + (lane >> 4) * 4;
             float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-            const bool ev = p.emode && co0 + 3 < p.Nout;
+            if (p.emode == 0) {                                       // BatchNorm forward statistics: sums and sums of squares, nothing to load
+#pragma unroll
+                for (int j = 0; j < TP; ++j) {
+                    const bool pv = p_blk + wp * WP + j * 16 + (lane & 15) < p.x.M;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float q = OUT_F32 ? vv[(i * TP + j) * 4 + r] : bfround(vv[(i * TP + j) * 4 + r]);
+                        q = pv ? q : 0.f;
+                        s1[r] += q;
+                        s2[r] += q * q;
+                    }
+                }
+            } else {
+            const bool ev = co0 + 3 < p.Nout;
             const StatCoef cf = stat_coef(p.ecoef, p.Nout, p.emode, co0, ev);
 #pragma unroll
             for (int j = 0; j < TP; ++j) {
@@ -546,6 +559,7 @@ __global__ __launch_bounds__(256 * KG) void gemm_nt_kernel(const GemmNT p) {
                     for (int r = 0; r < 4; ++r) z[r] = bf2f(zv[r]);
                 }
                 stat_terms4(p.emode, q, z, cf, s1[0], s1[1], s1[2], s1[3], s2[0], s2[1], s2[2], s2[3]);
+            }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
