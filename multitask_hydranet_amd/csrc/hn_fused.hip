@@ -235,7 +235,9 @@ struct FBwd {
     long M; int C; long RB; int cw; int xcd;
 };
 
-template <bool APPLY>
+// VAR: 0 = plain (g = dout * act'), 1 = masked by the saved block output y, 2 = SE (gate / dpool): one instantiation per form -- the
+// all-in-one kernel held every form's operands in registers (142 VGPRs: three workgroups per CU)
+template <bool APPLY, int VAR>
 __global__ __launch_bounds__(256) void fused_bwd_kernel(const FBwd p) {
     __shared__ FusedLds L;
     __shared__ float scratch[APPLY ? 1 : 4096];
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(const FBwd p) {
         mg[k] = APPLY ? L.coef[4][cl * 8 + k] : 0.f; mgx[k] = APPLY ? L.coef[5][cl * 8 + k] : 0.f;
         s1[k] = 0.f; s2[k] = 0.f; gt[k] = 1.f; dp[k] = 0.f;
     }
-    if (p.gate && active) {
+    if (VAR == 2 && active) {
         const long n = m0 / p.HW;
         const float inv = 1.0f / (float)p.HW;
 #pragma unroll
@@ -285,11 +287,11 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(const FBwd p) {
         float z[8], g[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) { z[k] = bf2f(vz[k]); g[k] = bf2f(vd[k]); }
-        if (p.gate) {
+        if (VAR == 2) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) g[k] = bfround(g[k] * gt[k] + dp[k]);       // db, rounded where the unfused path stored it
         }
-        if (p.y) {
+        if (VAR == 1) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) g[k] = bf2f(vy[k]) > 0.f ? g[k] : 0.f;
         } else {
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(const FBwd p) {
             const bf16x8 vd0 = ld8(p.dout + m * p.ldd + c), vd1 = ld8(p.dout + mb * p.ldd + c);
             const bf16x8 vz0 = ld8(p.z + m * p.ldz + c), vz1 = ld8(p.z + mb * p.ldz + c);
             bf16x8 vy0 = vz0, vy1 = vz1;
-            if (p.y) { vy0 = ld8(p.y + m * p.ldy + c); vy1 = ld8(p.y + mb * p.ldy + c); }
+            if (VAR == 1) { vy0 = ld8(p.y + m * p.ldy + c); vy1 = ld8(p.y + mb * p.ldy + c); }
             one(vd0, vz0, vy0, m);
             one(vd1, vz1, vy1, mb);
         }
@@ -328,7 +330,7 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(const FBwd p) {
             const bf16x8 vd0 = ld8(p.dout + m * p.ldd + c);
             const bf16x8 vz0 = ld8(p.z + m * p.ldz + c);
             bf16x8 vy0 = vz0;
-            if (p.y) vy0 = ld8(p.y + m * p.ldy + c);
+            if (VAR == 1) vy0 = ld8(p.y + m * p.ldy + c);
             one(vd0, vz0, vy0, m);
         }
     }
@@ -511,7 +513,9 @@ extern "C" int hn_bn_bwd_reduce_fused(const void* dout, int ldd, const void* z, 
     FBwd p;
     const int rc = fill_bwd(p, dout, ldd, z, ldz, y, ldy, coef, act, gate, dpool, HW, pg, pgx, M, C, RB);
     if (rc) return rc;
-    hipLaunchKernelGGL(fused_bwd_kernel<false>, fused_grid(M, C, RB), dim3(256), 0, st, p);
+    if (gate) hipLaunchKernelGGL((fused_bwd_kernel<false, 2>), fused_grid(M, C, RB), dim3(256), 0, st, p);
+    else if (y) hipLaunchKernelGGL((fused_bwd_kernel<false, 1>), fused_grid(M, C, RB), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((fused_bwd_kernel<false, 0>), fused_grid(M, C, RB), dim3(256), 0, st, p);
     HN_LAUNCH_CHECK();
 }
 
@@ -524,7 +528,9 @@ extern "C" int hn_bn_bwd_apply_fused(const void* dout, int ldd, const void* z, i
     if (rc) return rc;
     HN_CHECK_ARG(P > 0 && count > 0 && dgamma && dbeta && dz && (lddz & 7) == 0 && (!gout || (ldg & 7) == 0));
     p.P = P; p.count = (double)count; p.dgamma = dgamma; p.dbeta = dbeta; p.zvec = zero_c; p.dz = (bf16*)dz; p.lddz = lddz; p.gout = (bf16*)gout; p.ldg = ldg;
-    hipLaunchKernelGGL(fused_bwd_kernel<true>, fused_grid(M, C, RB), dim3(256), 0, st, p);
+    if (gate) hipLaunchKernelGGL((fused_bwd_kernel<true, 2>), fused_grid(M, C, RB), dim3(256), 0, st, p);
+    else if (y) hipLaunchKernelGGL((fused_bwd_kernel<true, 1>), fused_grid(M, C, RB), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((fused_bwd_kernel<true, 0>), fused_grid(M, C, RB), dim3(256), 0, st, p);
     HN_LAUNCH_CHECK();
 }
 
