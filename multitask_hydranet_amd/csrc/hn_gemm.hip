@@ -806,7 +806,11 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
     // stage = (chunk, tap).  Iteration `it` issues the DMA of stage `it` (+ the X patch of its chunk when tap == 0) and multiplies
     // stage `it - 1`.  Weight-tile slots: two (four: PIPE) recycled ones, or -- p.wpre, single-chunk convs whose S tiles all fit -- one
     // slot per tap step
+    // a wave whose output rows all lie below the image (ragged bottom patches: the 8-row maps of stage 4, the (H + 2)-row padded grids of
+    // the data gradients) multiplies nothing: it still loads and meets every barrier, but leaves the MFMA pipe to the live waves
+    const bool rows_live = oy0 + wp * ROWS < xs.H;
     auto compute = [&](const Cur& c, int slot) {
+        if (!rows_live) return;
         const int tap = tap_at(c);
         const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
         const int dy = xs.mode == 2 ? ky : 2 - ky, dx = xs.mode == 2 ? kx : 2 - kx;
@@ -916,7 +920,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int kq = lane >> 4;
-        for (int tap = 0; tap < 9; ++tap) {
+        for (int tap = 0; tap < (rows_live ? 9 : 0); ++tap) {
             const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
             const int dy = xs.mode == 2 ? ky : 2 - ky, dx = xs.mode == 2 ? kx : 2 - kx;
             const int pxk = ((lane & 15) + dx) & 7;
