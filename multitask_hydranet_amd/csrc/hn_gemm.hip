@@ -1029,30 +1029,44 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
             const int cl = wc * WCO + i * 16 + (lane >> 4) * 4;
             const int co0 = c_blk + cl;
             float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-            f32x4 bsr;
-            const bool ev = p.emode && co0 + 3 < p.Nout;
+            if (rows_live) {                                          // (a row group below the image contributes zeros: no arithmetic)
+                const f32x4 bsr = *reinterpret_cast<const f32x4*>(sbias + cl);
+                if (p.emode == 0) {                                   // BatchNorm forward statistics: sums and sums of squares, nothing to load
 #pragma unroll
-            for (int r = 0; r < 4; ++r) bsr[r] = (p.bias && co0 + r < p.Nout) ? p.bias[co0 + r] : 0.f;
-            const StatCoef cf = stat_coef(p.ecoef, p.Nout, p.emode, co0, ev);
+                    for (int j = 0; j < TP; ++j) {
+                        const bool pv = oy0 + wp * ROWS + j < xs.H && oxs < xs.W;
 #pragma unroll
-            for (int j = 0; j < TP; ++j) {
-                const int oy = oy0 + wp * ROWS + j;
-                const bool pv = oy < xs.H && oxs < xs.W;
-                f32x4 q, z = {0.f, 0.f, 0.f, 0.f};
+                        for (int r = 0; r < 4; ++r) {
+                            float q = OUT_F32 ? acc[i][j][r] + bsr[r] : bfround(acc[i][j][r] + bsr[r]);
+                            q = pv ? q : 0.f;
+                            s1[r] += q;
+                            s2[r] += q * q;
+                        }
+                    }
+                } else {
+                    const bool ev = co0 + 3 < p.Nout;
+                    const StatCoef cf = stat_coef(p.ecoef, p.Nout, p.emode, co0, ev);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    q[r] = OUT_F32 ? acc[i][j][r] + bsr[r] : bfround(acc[i][j][r] + bsr[r]);
-                    q[r] = pv ? q[r] : 0.f;
+                    for (int j = 0; j < TP; ++j) {
+                        const int oy = oy0 + wp * ROWS + j;
+                        const bool pv = oy < xs.H && oxs < xs.W;
+                        f32x4 q, z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            q[r] = OUT_F32 ? acc[i][j][r] + bsr[r] : bfround(acc[i][j][r] + bsr[r]);
+                            q[r] = pv ? q[r] : 0.f;
+                        }
+                        if (ev && pv) {
+                            const bf16x4 zv = *reinterpret_cast<const bf16x4*>(p.ez + ((long)(n * xs.H + oy) * xs.W + oxs) * p.ld_ez + co0);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) z[r] = bf2f(zv[r]);
+                        }
+                        stat_terms4(p.emode, q, z, cf, s1[0], s1[1], s1[2], s1[3], s2[0], s2[1], s2[2], s2[3]);
+                    }
                 }
-                if (ev && pv) {
-                    const bf16x4 zv = *reinterpret_cast<const bf16x4*>(p.ez + ((long)(n * xs.H + oy) * xs.W + oxs) * p.ld_ez + co0);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) z[r] = bf2f(zv[r]);
-                }
-                stat_terms4(p.emode, q, z, cf, s1[0], s1[1], s1[2], s1[3], s2[0], s2[1], s2[2], s2[3]);
+                for (int r = 0; r < 4; ++r) { s1[r] = row16_sum(s1[r]); s2[r] = row16_sum(s2[r]); }
             }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { s1[r] = row16_sum(s1[r]); s2[r] = row16_sum(s2[r]); }
             if ((lane & 15) == 0) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { red[(wp * BC + cl + r) * 2] = s1[r]; red[(wp * BC + cl + r) * 2 + 1] = s2[r]; }
@@ -1105,7 +1119,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
         // without a single global load (tools/stamp_seg.py) -- instruction fetch, not arithmetic.
         const int act = p.act;
 #pragma unroll
-        for (int i = 0; i < TC; ++i) {
+        for (int i = 0; i < (rows_live ? TC : 0); ++i) {              // (a row group below the image stages nothing: the write-out masks its pixels)
             // one cout sub-tile at a time, start to finish: its 16 accumulator registers are dead once it is staged (all 64 values
             // through bias / addend, then all through the activation, then all staged kept everything live at once: 13 spilled VGPRs)
             const f32x4 bs = *reinterpret_cast<const f32x4*>(sbias + wc * WCO + i * 16 + (lane >> 4) * 4);
