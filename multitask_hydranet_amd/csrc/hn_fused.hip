@@ -298,7 +298,12 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(const FBwd p) {
             float pre[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) pre[k] = sc[k] * z[k] + sh[k];
-            act_bwd_n(pre, g, p.act);
+            if constexpr (VAR == 2) {                                  // (the SE form is ReLU only: checked by the launchers)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) g[k] = pre[k] > 0.f ? g[k] : 0.f;
+            } else {
+                act_bwd_n(pre, g, p.act);
+            }
         }
         if (!APPLY) {
 #pragma unroll
@@ -500,7 +505,7 @@ extern "C" int hn_bn_apply_fused(const void* z, int ldz, long M, int C, const fl
 static int fill_bwd(FBwd& p, const void* dout, int ldd, const void* z, int ldz, const void* y, int ldy, const float* coef, int act,
                     const float* gate, const float* dpool, long HW, float* pg, float* pgx, long M, int C, long RB) {
     HN_CHECK_ARG(dout && z && coef && pg && pgx && M > 0 && C > 0 && (C & 7) == 0 && (ldd & 7) == 0 && (ldz & 7) == 0 && RB > 0);
-    HN_CHECK_ARG((!y || (ldy & 7) == 0) && (!gate || (dpool && HW > 0 && HW % RB == 0)));
+    HN_CHECK_ARG((!y || (ldy & 7) == 0) && (!gate || (dpool && HW > 0 && HW % RB == 0 && act == HN_ACT_RELU && !y)));
     p = FBwd{};
     p.dout = (const bf16*)dout; p.ldd = ldd; p.z = (const bf16*)z; p.ldz = ldz; p.y = (const bf16*)y; p.ldy = ldy; p.coef = coef; p.act = act;
     p.gate = gate; p.dpool = dpool; p.HW = HW; p.pg = pg; p.pgx = pgx; p.M = M; p.C = C; p.RB = RB; p.cw = chunk_width(C); p.xcd = (int)g_hn_knob[8];
