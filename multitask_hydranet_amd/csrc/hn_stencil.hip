@@ -1648,7 +1648,7 @@ extern "C" int hn_fuse_fwd_raw(const void* const* in, const int* ld, const int* 
 }
 extern "C" int hn_fuse_bwd_blocks(int N, int H, int W, int C) {
     long b = ((long)N * H * W * (C >> 3) + 255) / 256;
-    if (b > 1024) b = 1024;
+    if (b > 768) b = 768;                  // three workgroups per CU are resident (141 VGPRs): one round, no quarter-full second one
     return (int)(b < 1 ? 1 : b);
 }
 // pw: fp32 [hn_fuse_bwd_blocks][3]; reduce with hn_rows_reduce(pw, dw, 1, blocks, 3, 1)
