@@ -757,6 +757,21 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
     // either operand and the channel sub-offset are recomputed when the load is issued (this kernel sits at the 128-VGPR limit of two
     // co-resident workgroups: three registers per piece cost 12 spilled VGPRs = 52 B/lane of scratch traffic).
     // (bits 13-15: the LOGICAL 16-byte piece of the chunk this thread's physical LDS piece holds -- the swizzle resolved once; gx < 8192)
+    // (the 18 source rows and 18 source columns of the patch are resolved ONCE, by 36 threads, into an LDS table: done per piece, the
+    // reflect / clamp / zero border arithmetic was ~150 of the prologue's ~380 VALU instructions, each costing 16 cycles of workgroup
+    // lifetime with four waves per SIMD starting at the same time)
+    // [0..17]: source row of patch row py (-1: none), [18..35]: columns; behind the operand buffers and the bias values (dynamic LDS: a
+    // static array on top of the 160 KB dynamic opt-in is refused by the runtime)
+    int* patch_src = reinterpret_cast<int*>(sbias + BC);
+    if (tid < 36) {
+        const bool isy = tid < 18;
+        const int k = isy ? tid : tid - 18, L = isy ? xs.Hi : xs.Wi;
+        int g = (isy ? oy0 : ox0) + org + k;
+        if (xs.mode == 2) g = border_idx(g, L, xs.clamp);             // (negative only for pixels that feed no in-image output)
+        else g = (g >= 0 && g < L) ? g : -1;
+        patch_src[tid] = g;
+    }
+    __syncthreads();
     int spack[XL];
 #pragma unroll
     for (int i = 0; i < XL; ++i) {
@@ -766,14 +781,8 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
         if (pp < PPIX) {
             const int py = pp / 18, px = pp - py * 18;
             const int sub = PIPE ? ((e & 3) ^ pswz32(px)) : ((e & 7) ^ (px & 7));
-            int gy = oy0 + org + py, gx = ox0 + org + px;
-            if (xs.mode == 2) {
-                gy = border_idx(gy, xs.Hi, xs.clamp);
-                gx = border_idx(gx, xs.Wi, xs.clamp);
-                if (gy >= 0 && gx >= 0) spack[i] = (gy << 16) | (sub << 13) | gx;   // (negative only for pixels that feed no in-image output)
-            } else if (gy >= 0 && gy < xs.Hi && gx >= 0 && gx < xs.Wi) {
-                spack[i] = (gy << 16) | (sub << 13) | gx;
-            }
+            const int gy = patch_src[py], gx = patch_src[18 + px];
+            if ((gy | gx) >= 0) spack[i] = (gy << 16) | (sub << 13) | gx;
         }
     }
     // weight pieces: row = (tid>>3) + 64 i, physical piece tid&7 (32-channel chunks: row = (tid>>2) + 128 i, physical piece tid&3; the
@@ -2819,7 +2828,7 @@ static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img
 #endif
         const size_t lds = pipe ? (size_t)2 * (((18 * 18 * 4 + 511) / 512) * 512 * 16) + 4 * (size_t)(512 * 16)
                                 : (size_t)((18 * 18 * 128 + 1023) / 1024 * 1024) + (p.wpre ? nsteps : 2) * (size_t)bc * 128;
-        const size_t lds_bias = (size_t)bc * 4;                     // the tile's bias values behind the operand buffers
+        const size_t lds_bias = (size_t)bc * 4 + 36 * 4;            // the tile's bias values + the patch source table behind the operand buffers
         // > 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel (done on the first, un-captured call)
         static std::atomic<unsigned long long> optin{0};
         if (!lds_optin(optin, {(const void*)conv3x3_direct_kernel<16, true, false>, (const void*)conv3x3_direct_kernel<16, false, false>,
