@@ -757,6 +757,18 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
     // either operand and the channel sub-offset are recomputed when the load is issued (this kernel sits at the 128-VGPR limit of two
     // co-resident workgroups: three registers per piece cost 12 spilled VGPRs = 52 B/lane of scratch traffic).
     // (bits 13-15: the LOGICAL 16-byte piece of the chunk this thread's physical LDS piece holds -- the swizzle resolved once; gx < 8192)
+    if (BC == 64 && !PIPE && xs.diag) {
+        // grouped conv: the 9 KB of diagonal weight blocks do not depend on anything computed below -- requested first, their latency runs
+        // under the prologue's index arithmetic
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (512 * i + 64 * wave < 9 * 64) {                         // wave-uniform
+                const int e = 512 * i + tid, tap = e >> 6, col = e & 63, co = c_blk + col;
+                const bf16* src = co < p.Nout ? p.w + co * (9 * p.KP) + tap * 64 + (col >> 3) * 8 : g_zero_piece;
+                glds16(src, smem + XBUFS * XBYTES + (512 * i + 64 * wave) * 16);
+            }
+        }
+    }
     // (the 18 source rows and 18 source columns of the patch are resolved ONCE, by 36 threads, into an LDS table: done per piece, the
     // reflect / clamp / zero border arithmetic was ~150 of the prologue's ~380 VALU instructions, each costing 16 cycles of workgroup
     // lifetime with four waves per SIMD starting at the same time)
@@ -917,15 +929,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
         // blocks (1 KB) are non-zero.  All nine taps' blocks (9 KB: [tap][cout 64][8 ci]) are fetched ONCE next to the patch, and the A
         // fragments are built from them by a lane select -- the tap loop has no barrier and no DMA wait.  The tile-streaming loop below
         // exposed one weight-DMA round trip per tap: 9 x 2.2 us = 19.8 us per launch on the deep stages, for 1 us of MFMA work.
-        issue_x(0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (512 * i + 64 * wave < 9 * 64) {                         // wave-uniform
-                const int e = 512 * i + tid, tap = e >> 6, col = e & 63, co = c_blk + col;
-                const bf16* src = co < p.Nout ? p.w + co * Ktot + tap * 64 + (col >> 3) * 8 : g_zero_piece;
-                glds16(src, sWb + (512 * i + 64 * wave) * 16);
-            }
-        }
+        issue_x(0);                                                    // (the nine taps' diagonal blocks were requested at kernel start)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int kq = lane >> 4;
