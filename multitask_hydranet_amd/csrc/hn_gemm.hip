@@ -1730,7 +1730,11 @@ __device__ __forceinline__ void gemm_tn_ring_body(const GemmTN& p, const int lid
 // cannot hold a deeper ring at two workgroups per CU, but the register file can: a 256-thread workgroup at two per CU may use 256 VGPRs per
 // lane and the tile needs 64 accumulators -- RS = 2 stages are 64 more registers and triple the bytes in flight.  Plain rows (mode 0) and the
 // stride-2 gather (mode 1), one tap: the grouped 1x1 weight gradients.
-template <int BC, int BN, int WGC, int WGN, int RS>
+// PLAIN (x.mode 0, the stride-1 1x1 convs: most jobs): branch-free fetch -- every lane loads (the zero piece where its row or channel is
+// out of range), no stride-2 coordinate bookkeeping.  The generic fetch wraps each of its 8 loads in exec-mask branches and carries the
+// gather's (n, y, x) walk with a run-time loop: ~400 instructions per 64-row stage against 32 MFMAs per wave -- the stage-4 group ran
+// 182 of its 288 us with loads AND MFMAs ablated (tools/bench_wgrad_group.py, HN_DBG=6).
+template <int BC, int BN, int WGC, int WGN, int RS, bool PLAIN = false>
 __device__ __forceinline__ void gemm_tn_regs_body(const GemmTN& p, const int lid) {
     constexpr int WC = BC / WGC, WN = BN / WGN, TC = WC / 16, TN = WN / 16;
     constexpr int ZPR = BC / 8, XPR = BN / 8, NT = 64 * WGC * WGN;
@@ -1771,10 +1775,11 @@ __device__ __forceinline__ void gemm_tn_regs_body(const GemmTN& p, const int lid
         const int row = e / XPR, cp = tn_swz<BN>(row, e - row * XPR);
         const int c = ci_blk + cp * 8;
         xrow[i] = row;
-        xoff[i] = c < p.x.C0 ? (p.x.mode == 0 ? (m_begin + row) * (long)p.x.ld0 + c : (long)c) : -1;
-        decomp_row(p.x, m_begin + row, pn[i], py[i], px[i]);
+        xoff[i] = c < p.x.C0 ? ((PLAIN || p.x.mode == 0) ? (m_begin + row) * (long)p.x.ld0 + c : (long)c) : -1;
+        if constexpr (PLAIN) { pn[i] = 0; py[i] = 0; px[i] = 0; }
+        else decomp_row(p.x, m_begin + row, pn[i], py[i], px[i]);
     }
-    const int adv_q = p.x.mode ? 64 / p.x.W : 0, adv_r = p.x.mode ? 64 % p.x.W : 0;
+    const int adv_q = (!PLAIN && p.x.mode) ? 64 / p.x.W : 0, adv_r = (!PLAIN && p.x.mode) ? 64 % p.x.W : 0;
     const int g = lane >> 4, t16 = lane & 15, q = t16 >> 2, pp = t16 & 3;
     typedef __bf16 trv4 __attribute__((__vector_size__(4 * sizeof(__bf16))));
     typedef __attribute__((address_space(3))) trv4* lds_b4;
@@ -1791,6 +1796,21 @@ __device__ __forceinline__ void gemm_tn_regs_body(const GemmTN& p, const int lid
     auto fetch = [&](int st, bf16x8 (&dz_)[ZL], bf16x8 (&dx_)[XL]) {         // stage st -> registers (zeros past the split / the tensor)
         const long m0 = m_begin + (long)st * 64;
         const bool live = st < S && !(HN_DBG(p) & 4);
+        if constexpr (PLAIN) {
+#pragma unroll
+            for (int i = 0; i < ZL; ++i) {
+                const bf16* src = (live && m0 + zrow[i] < m_end && zoff[i] >= 0) ? p.dz + zoff[i] : g_zero_piece;
+                dz_[i] = ld8(src);
+                zoff[i] += zoff[i] >= 0 ? 64L * p.ldz : 0;
+            }
+#pragma unroll
+            for (int i = 0; i < XL; ++i) {
+                const bf16* src = (live && m0 + xrow[i] < m_end && xoff[i] >= 0) ? p.x.x0 + xoff[i] : g_zero_piece;
+                dx_[i] = ld8(src);
+                xoff[i] += xoff[i] >= 0 ? 64L * p.x.ld0 : 0;
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < ZL; ++i) {
             dz_[i] = (live && m0 + zrow[i] < m_end && zoff[i] >= 0) ? ld8(p.dz + zoff[i]) : zero8();
@@ -1923,7 +1943,10 @@ __global__ __launch_bounds__(64 * WGC * WGN, 2) void gemm_tn_group_kernel(const 
     p.dz = jb.dz; p.ldz = jb.ldz; p.Nout = jb.Nout; p.KP = jb.KP; p.taps = 1; p.part = jb.part; p.rows_per_split = jb.rows_per_split;
     p.gy = jb.gy; p.phase_span = 0; p.bias_part = nullptr; p.out_ld = jb.out_ld; p.cin_lim = jb.C0; p.dbg = jobs.dbg;
     if constexpr (R == 0) gemm_tn_body<BC, BN, WGC, WGN>(p, lid);
-    else if constexpr (R < 0) gemm_tn_regs_body<BC, BN, WGC, WGN, -R>(p, lid);
+    else if constexpr (R < 0) {
+        if (jb.mode == 0) gemm_tn_regs_body<BC, BN, WGC, WGN, -R, true>(p, lid);
+        else gemm_tn_regs_body<BC, BN, WGC, WGN, -R, false>(p, lid);
+    }
     else gemm_tn_ring_body<BC, BN, WGC, WGN, BK, R>(p, lid);
 }
 
