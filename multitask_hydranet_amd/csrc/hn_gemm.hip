@@ -1950,6 +1950,25 @@ __global__ __launch_bounds__(64 * WGC * WGN, 2) void gemm_tn_group_kernel(const 
     else gemm_tn_ring_body<BC, BN, WGC, WGN, BK, R>(p, lid);
 }
 
+// 56-entry table of a patch's source rows / columns (wgrad3x3_patch_body): r0[10] | c0[18] in x0's grid (up-sampling applied), r1[10] | c1[18]
+// in x1's full-resolution grid; -1 = no source (pixels that feed no in-image output)
+__device__ __forceinline__ void fill_patch_table(int* tab, int tid, const XSrc& xs, int n, int pty, int ptx) {
+    if (tid < 56) {
+        const bool op1 = tid >= 28;
+        const int k = op1 ? tid - 28 : tid;
+        const bool isy = k < 10;
+        const int j = isy ? k : k - 10;
+        int g = (isy ? pty * 8 : ptx * 16) - 1 + j;
+        g = border_idx(g, isy ? xs.Hi : xs.Wi, xs.clamp);
+        int v = -1;
+        if (g >= 0) {
+            if (!op1) v = isy ? (n * (xs.Hi >> xs.up) + (g >> xs.up)) * (xs.Wi >> xs.up) : (g >> xs.up);
+            else v = isy ? (n * xs.Hi + g) * xs.Wi : g;
+        }
+        tab[tid] = v;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // 3x3 weight gradient with patch reuse: one workgroup owns dW[BC couts][9 taps][CI ci] and walks 8x16-pixel output patches.  Per
 // patch the dZ tile [128 px][BC] and the 10x18 input patch [180 px][CI] are DMA'd into LDS once and serve all nine taps (the tap
@@ -2006,16 +2025,36 @@ __device__ __forceinline__ void wgrad3x3_patch_body(const GemmTN& p, const int p
     typedef __bf16 trv4 __attribute__((__vector_size__(4 * sizeof(__bf16))));
     typedef __attribute__((address_space(3))) trv4* lds_b4;
 
+    // Patch cursor (advanced by compare-and-wrap) and, per patch, a 56-entry LDS table of its source rows / columns in both operands
+    // (reflect / clamp / up-sampling resolved once by 56 threads, one patch ahead): done per piece and patch, the coordinate divisions and
+    // border arithmetic were ~400 instructions per patch and wave against 64-144 MFMAs -- the loader, not the MFMA pipe, set the pace.
+    int* tab = reinterpret_cast<int*>(smem + 2 * STAGE);              // [2][56]: r0[10] | c0[18] | r1[10] | c1[18]
+    int cptx, cpty, cn;
+    {
+        int t = pb;
+        cptx = t % tx_n;
+        t /= tx_n;
+        cpty = t % ty_n;
+        cn = t / ty_n;
+    }
+    // per-piece constants of the X patch loader: patch pixel (py, px) and channel of each of the thread's pieces
+    int xpy[XL], xpx[XL], xc[XL];
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+        const int e = tid + 512 * i;
+        const int px_ = e / XNP;
+        const int c = ci_blk + tn_swz<CI>(px_, e - px_ * XNP) * 8;
+        xpy[i] = px_ / 18;
+        xpx[i] = px_ - xpy[i] * 18;
+        xc[i] = (px_ < XPIX && c < Ctot) ? c : -1;
+    }
+    if (S > 0) fill_patch_table(tab, tid, xs, cn, cpty, cptx);
     for (int it = 0; it <= S; ++it) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (it < S) {
-            int t = pb + it;
-            const int ptx = t % tx_n;
-            t /= tx_n;
-            const int pty = t % ty_n;
-            const int n = t / ty_n;
-            const int oy0 = pty * 8, ox0 = ptx * 16;
+            const int n = cn;
+            const int oy0 = cpty * 8, ox0 = cptx * 16;
             char* sZ = smem + (it & 1) * STAGE;
             char* sX = sZ + ZB;
 #pragma unroll
@@ -2029,23 +2068,28 @@ __device__ __forceinline__ void wgrad3x3_patch_body(const GemmTN& p, const int p
                     glds16(src, sZ + (512 * i + 64 * wave) * 16);
                 }
             }
+            const int* tb = tab + (it & 1) * 56;
 #pragma unroll
             for (int i = 0; i < XL; ++i) {
-                const int e = tid + 512 * i;
-                const int px_ = e / XNP;
-                const int c = ci_blk + tn_swz<CI>(px_, e - px_ * XNP) * 8;
                 const bf16* src = g_zero_piece;
-                if (px_ < XPIX && c < Ctot) {
-                    const int py = px_ / 18, pxx = px_ - py * 18;
-                    int gy = oy0 - 1 + py, gx = ox0 - 1 + pxx;
-                    gy = border_idx(gy, xs.Hi, xs.clamp);
-                    gx = border_idx(gx, xs.Wi, xs.clamp);
-                    if (gy >= 0 && gx >= 0) {
-                        if (c < xs.C0) src = xs.x0 + c + (long)((n * (xs.Hi >> xs.up) + (gy >> xs.up)) * (xs.Wi >> xs.up) + (gx >> xs.up)) * xs.ld0;
-                        else src = xs.x1 + (c - xs.C0) + (long)((n * xs.Hi + gy) * xs.Wi + gx) * xs.ld1;
+                const int c = xc[i];
+                if (c >= 0) {
+                    int r = tb[xpy[i]], cc = tb[10 + xpx[i]];
+                    const bf16* base = xs.x0 + c;
+                    long ldx = xs.ld0;
+                    if (xs.C1 > 0 && c >= xs.C0) {                     // the full-resolution (skip) operand of a concat conv
+                        r = tb[28 + xpy[i]];
+                        cc = tb[38 + xpx[i]];
+                        base = xs.x1 + (c - xs.C0);
+                        ldx = xs.ld1;
                     }
+                    if ((r | cc) >= 0) src = base + (long)(r + cc) * ldx;
                 }
                 glds16(src, sX + (512 * i + 64 * wave) * 16);
+            }
+            if (it + 1 < S) {                                          // next patch: cursor, then its table (read after the next barrier)
+                if (++cptx == tx_n) { cptx = 0; if (++cpty == ty_n) { cpty = 0; ++cn; } }
+                fill_patch_table(tab + ((it + 1) & 1) * 56, tid, xs, cn, cpty, cptx);
             }
         }
         if (it > 0) {
@@ -3341,7 +3385,7 @@ extern "C" int hn_gconv_wgrad_group(const long* jobs, int njobs, float* workspac
         rblocks += cdiv((long)d.C * 72, 256);
     }
     const size_t xb = (size_t)((180 * 8 + 511) / 512) * 512 * 16;
-    const size_t lds = 2 * ((size_t)((128 * 64 * 2 + 1023) / 1024 * 1024) + xb);
+    const size_t lds = 2 * ((size_t)((128 * 64 * 2 + 1023) / 1024 * 1024) + xb) + 2 * 56 * sizeof(int);    // + the two patch source tables
     hipLaunchKernelGGL(gconv_wgrad_group_kernel, dim3((unsigned)blocks), dim3(512), lds, st, t);
     hipLaunchKernelGGL(wgrad_reduce_group_kernel, dim3((unsigned)rblocks), dim3(256), 0, st, r);
     HN_LAUNCH_CHECK();
@@ -3405,7 +3449,7 @@ static int conv_gemm_tn_impl(const void* x0, const void* x1, int mode, int n_img
         const int patches = n_img * cdiv(H, 8) * cdiv(W, 16);
         dim3 grid((unsigned)(cdiv(KP, pci) * p.gy * (splits / ksplit)));
         const size_t xb = (size_t)((180 * (pci / 8) + 511) / 512) * 512 * 16;
-        const size_t lds = 2 * ((size_t)((128 * pbc * 2 + 1023) / 1024 * 1024) + xb);
+        const size_t lds = 2 * ((size_t)((128 * pbc * 2 + 1023) / 1024 * 1024) + xb) + 2 * 56 * sizeof(int);   // + the two patch source tables
         if (grouped) hipLaunchKernelGGL((wgrad3x3_patch_kernel<64, 64>), grid, dim3(512), lds, st, p, (int)rps, patches);
         else if (phase_span && pbc == 128 && pci == 32) hipLaunchKernelGGL((wgrad3x3_patch_kernel<128, 32, 1>), grid, dim3(512), lds, st, p, (int)rps, patches);
         else if (phase_span && pbc == 128) hipLaunchKernelGGL((wgrad3x3_patch_kernel<128, 64, 1>), grid, dim3(512), lds, st, p, (int)rps, patches);
