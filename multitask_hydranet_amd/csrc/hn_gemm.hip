@@ -784,6 +784,9 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
         patch_src[tid] = g;
     }
     __syncthreads();
+    // one operand only (no concat: every phase-form conv and data gradient) and < 2^28 source pixels: the piece holds its source PIXEL index
+    // ((pixel << 3) | logical piece), the per-chunk address is one multiply-add instead of the two-operand coordinate arithmetic
+    const bool single = xs.C1 == 0 && (long)p.x.M < (1L << 27);
     int spack[XL];
 #pragma unroll
     for (int i = 0; i < XL; ++i) {
@@ -794,7 +797,9 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
             const int py = pp / 18, px = pp - py * 18;
             const int sub = PIPE ? ((e & 3) ^ pswz32(px)) : ((e & 7) ^ (px & 7));
             const int gy = patch_src[py], gx = patch_src[18 + px];
-            if ((gy | gx) >= 0) spack[i] = (gy << 16) | (sub << 13) | gx;
+            if ((gy | gx) >= 0)
+                spack[i] = single ? ((((n * (xs.Hi >> xs.up) + (gy >> xs.up)) * (xs.Wi >> xs.up) + (gx >> xs.up)) << 3) | sub)
+                                  : ((gy << 16) | (sub << 13) | gx);
         }
     }
     // weight pieces: row = (tid>>3) + 64 i, physical piece tid&7 (32-channel chunks: row = (tid>>2) + 128 i, physical piece tid&3; the
@@ -882,11 +887,16 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
                 const bf16* src = g_zero_piece;
                 int pk = spack[i];
                 asm volatile("" : "+v"(pk));                          // keep the 64-bit row pointers out of loop-invariant registers
-                const int c = xc0 + k0 + (((pk >> 13) & 7) << 3);
-                if (c < Ctot && pk >= 0) {
-                    const int gy = pk >> 16, gx = pk & 0x1fff;
-                    if (c < xs.C0) src = xs.x0 + c + (long)((n * (xs.Hi >> xs.up) + (gy >> xs.up)) * (xs.Wi >> xs.up) + (gx >> xs.up)) * xs.ld0;
-                    else src = xs.x1 + (c - xs.C0) + (long)((n * xs.Hi + gy) * xs.Wi + gx) * xs.ld1;
+                if (single) {
+                    const int c = xc0 + k0 + ((pk & 7) << 3);
+                    if (c < Ctot && pk >= 0) src = xs.x0 + c + (long)(pk >> 3) * xs.ld0;
+                } else {
+                    const int c = xc0 + k0 + (((pk >> 13) & 7) << 3);
+                    if (c < Ctot && pk >= 0) {
+                        const int gy = pk >> 16, gx = pk & 0x1fff;
+                        if (c < xs.C0) src = xs.x0 + c + (long)((n * (xs.Hi >> xs.up) + (gy >> xs.up)) * (xs.Wi >> xs.up) + (gx >> xs.up)) * xs.ld0;
+                        else src = xs.x1 + (c - xs.C0) + (long)((n * xs.Hi + gy) * xs.Wi + gx) * xs.ld1;
+                    }
                 }
                 glds16(src, sX + (512 * i + 64 * wave) * 16);
             }
