@@ -181,6 +181,14 @@ int hn_fuse_fwd_raw(const void* const* in, const int* ld, const int* mode, const
 int hn_fuse_bwd_blocks(int N, int H, int W, int C);
 int hn_fuse_bwd(const void* const* in, const int* ld, const int* mode, const float* w, const void* dout, int ldd, void* g, int ldg,
                 void* const* din, const int* ldin, const int* acc, float* pw, int N, int H, int W, int C, hipStream_t stream);
+/* hn_fuse_bwd that also writes the arg-max bytes of the pooling windows of every mode-3 input i with arg_out[i] != NULL ([N][H][W][C] uint8:
+ * the kernel recomputes those windows anyway), and the second pass of hn_maxpool_bwd2 on its own, fed with such bytes (H, W = the pool's
+ * INPUT resolution): one launch per pooled fusion input in the backward pass instead of two (net/bifpn.py:206-231) */
+int hn_fuse_bwd_arg(const void* const* in, const int* ld, const int* mode, const float* w, const void* dout, int ldd, void* g, int ldg,
+                    void* const* din, const int* ldin, const int* acc, float* pw, void* const* arg_out, int N, int H, int W, int C,
+                    hipStream_t stream);
+int hn_maxpool_bwd_from_arg(const void* arg, const void* dout, int ldd, void* dx, int ldx, const float* wscale, int N, int H, int W, int C,
+                            int mode, int accumulate, hipStream_t stream);
 
 /* Data gradient of a 3x3 conv over a reflection-padded (clamp = 0: ConvBlock / Conv3x3, head_seg/segmentation.py:40-58) or, in phase form,
  * replicate-padded (clamp = 1) input, written straight to the unpadded gradient: dx [N][H][W][Nout] (row stride ldo) = fold(full

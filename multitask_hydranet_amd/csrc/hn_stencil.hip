@@ -1136,7 +1136,8 @@ struct FuseBwd {
     bf16* din[3]; int ldin[3];      // only for mode 1 inputs (else null)
     int acc[3];                     // 1: din[i] += (the tensor already holds the gradient of another consumer)
     float* pw;
-};
+    unsigned char* arg[3];          // mode 3 inputs (optional): the arg-max byte of every pooling window / channel, the layout of maxpool_arg_kernel --
+};                                  // the kernel recomputes the windows anyway; hn_maxpool_bwd_from_arg then needs no arg pass of its own
 // Inputs of mode 2 (nearest x2 of a half-resolution map) that come with a destination (din[i] at the LOW resolution): the kernel walks
 // the output in 2 x 2 quads and writes w_i * (sum of the quad's g) itself -- the separate hn_sum2x2 pass over g (one launch per top-down
 // fusion node, 12 per step) is not needed; the sum is taken over the bf16-rounded g, as that pass did.
@@ -1169,7 +1170,16 @@ __global__ __launch_bounds__(256) void fuse_bwd_kernel(const FuseBwd q) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             if (!p.mode[i]) continue;
-            fuse_gather(p, i, n, y, x, cg * 8, v[i]);
+            if (p.mode[i] == 3 && q.arg[i]) {
+                int a[8];
+                pool_window(p.in[i], p.ld[i], n, 2 * p.H, 2 * p.W, y, x, cg * 8, 0, v[i], a);
+                unsigned long long packed = 0ull;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) packed |= (unsigned long long)(a[k] & 0xff) << (8 * k);
+                *reinterpret_cast<unsigned long long*>(q.arg[i] + ((n * p.H + y) * (long)p.W + x) * p.C + cg * 8) = packed;
+            } else {
+                fuse_gather(p, i, n, y, x, cg * 8, v[i]);
+            }
             const float wi = p.w[i];
 #pragma unroll
             for (int k = 0; k < 8; ++k) pre[k] = fmaf(wi, v[i][k], pre[k]);
@@ -1599,6 +1609,14 @@ extern "C" int hn_maxpool_bwd2(const void* in, int ldi, const void* dout, int ld
                        (const bf16*)dout, ldd, (bf16*)dx, ldx, wscale, N, H, W, C, mode, accumulate);
     HN_LAUNCH_CHECK();
 }
+/* second pass of hn_maxpool_bwd2 alone: the arg-max bytes come from elsewhere (hn_fuse_bwd_arg); H, W = the INPUT resolution of the pool */
+extern "C" int hn_maxpool_bwd_from_arg(const void* arg, const void* dout, int ldd, void* dx, int ldx, const float* wscale, int N, int H, int W,
+                                       int C, int mode, int accumulate, hipStream_t st) {
+    HN_CHECK_ARG(arg && dout && dx && (C & 7) == 0 && ((ldd | ldx) & 7) == 0 && !(H & 1) && !(W & 1));
+    hipLaunchKernelGGL(maxpool_bwd_arg_kernel, dim3(ew_grid((long)N * H * W * (C >> 3))), dim3(256), 0, st, (const unsigned char*)arg,
+                       (const bf16*)dout, ldd, (bf16*)dx, ldx, wscale, N, H, W, C, mode, accumulate);
+    HN_LAUNCH_CHECK();
+}
 extern "C" int hn_up2_fwd(const void* in, int ldi, void* out, int ldo, int N, int H, int W, int C, hipStream_t st) {
     HN_CHECK_ARG(in && out && (C & 7) == 0 && ((ldi | ldo) & 7) == 0);
     hipLaunchKernelGGL(up2_fwd_kernel, dim3(ew_grid((long)N * 4 * H * W * (C >> 3))), dim3(256), 0, st, (const bf16*)in, ldi, (bf16*)out, ldo,
@@ -1660,7 +1678,24 @@ extern "C" int hn_fuse_bwd(const void* const* in, const int* ld, const int* mode
     const int rc = fill_fuse(q.f, in, ld, mode, w, nullptr, 8, N, H, W, C);
     if (rc) return rc;
     q.dout = (const bf16*)dout; q.ldd = ldd; q.g = (bf16*)g; q.ldg = ldg; q.pw = pw;
-    for (int i = 0; i < 3; ++i) { q.din[i] = (bf16*)din[i]; q.ldin[i] = ldin[i]; q.acc[i] = acc ? acc[i] : 0; }
+    for (int i = 0; i < 3; ++i) { q.din[i] = (bf16*)din[i]; q.ldin[i] = ldin[i]; q.acc[i] = acc ? acc[i] : 0; q.arg[i] = nullptr; }
+    hipLaunchKernelGGL(fuse_bwd_kernel, dim3(hn_fuse_bwd_blocks(N, H, W, C)), dim3(256), 0, st, q);
+    HN_LAUNCH_CHECK();
+}
+/* hn_fuse_bwd that also writes, for every mode-3 (max-pooled) input i with arg_out[i] != NULL, the arg-max bytes of its pooling windows
+ * ([N][H][W][C] uint8, the layout hn_maxpool_bwd_from_arg reads) */
+extern "C" int hn_fuse_bwd_arg(const void* const* in, const int* ld, const int* mode, const float* w, const void* dout, int ldd, void* g,
+                               int ldg, void* const* din, const int* ldin, const int* acc, float* pw, void* const* arg_out, int N, int H,
+                               int W, int C, hipStream_t st) {
+    FuseBwd q;
+    HN_CHECK_ARG(dout && g && pw && din && ldin && arg_out && ((ldd | ldg) & 7) == 0);
+    const int rc = fill_fuse(q.f, in, ld, mode, w, nullptr, 8, N, H, W, C);
+    if (rc) return rc;
+    q.dout = (const bf16*)dout; q.ldd = ldd; q.g = (bf16*)g; q.ldg = ldg; q.pw = pw;
+    for (int i = 0; i < 3; ++i) {
+        q.din[i] = (bf16*)din[i]; q.ldin[i] = ldin[i]; q.acc[i] = acc ? acc[i] : 0;
+        q.arg[i] = mode[i] == 3 ? (unsigned char*)arg_out[i] : nullptr;
+    }
     hipLaunchKernelGGL(fuse_bwd_kernel, dim3(hn_fuse_bwd_blocks(N, H, W, C)), dim3(256), 0, st, q);
     HN_LAUNCH_CHECK();
 }

@@ -166,6 +166,7 @@ def share(x, n):
 # step.  Measured SLOWER (780.9 vs 783.9 img/s, same box): a thread then walks four pixels in sequence, and these launches are bound by
 # their dependent-load chains, not by their count -- off.
 FUSE_SUM2X2 = os.environ.get("HN_FUSE_SUM2X2", "0") == "1"
+FUSE_ARG = os.environ.get("HN_FUSE_ARG", "1") != "0"      # the fusion backward kernel leaves the pooling arg-max bytes behind (0: hn_maxpool_bwd2's own pass)
 
 
 class Fuse(torch.autograd.Function):
@@ -221,8 +222,12 @@ class Fuse(torch.autograd.Function):
         da = (ctypes.c_int * 3)(*accum)
         blocks = lib().query("hn_fuse_bwd_blocks", n, h, wd, ch)
         pw = torch.empty((blocks, 3), device=dev, dtype=F32)
-        lib().call("hn_fuse_bwd", ctypes.addressof(ap), ctypes.addressof(al), ctypes.addressof(am), ptr(w), ptr(dout), ld(dout), ptr(g), ld(g),
-                   ctypes.addressof(dp_), ctypes.addressof(dl), ctypes.addressof(da), ptr(pw), n, h, wd, ch)
+        # the fusion kernel recomputes the pooling windows of a max-pooled input anyway: it leaves their arg-max bytes behind, and the
+        # max-pool backward below is its scatter pass alone (hn_maxpool_bwd2's own arg pass was one more ~7 us launch per pooled input)
+        args = [torch.empty((n * h * wd * ch,), device=dev, dtype=torch.uint8) if (m == 3 and FUSE_ARG) else None for m in modes]
+        aa = (ctypes.c_void_p * 3)(*[ptr(t) for t in args])
+        lib().call("hn_fuse_bwd_arg", ctypes.addressof(ap), ctypes.addressof(al), ctypes.addressof(am), ptr(w), ptr(dout), ld(dout), ptr(g),
+                   ld(g), ctypes.addressof(dp_), ctypes.addressof(dl), ctypes.addressof(da), ptr(pw), ctypes.addressof(aa), n, h, wd, ch)
         if ctx.queue is not None:
             dpraw = ctx.queue.add_fuse(ctx.pref, pw, blocks, 1e-4)
         else:
@@ -231,8 +236,11 @@ class Fuse(torch.autograd.Function):
         for i, m in enumerate(modes):
             if m == 2 and not FUSE_SUM2X2:                         # nearest x2 of a half-res input: 2x2 sum of g
                 lib().call("hn_sum2x2", ptr(g), ld(g), ptr(dst[i]), ld(dst[i]), ptr(w[i]), n, h // 2, wd // 2, ch, accum[i])
-            elif m == 3:                                           # zero-pad-same max pool of a double-res input
+            elif m == 3 and not FUSE_ARG:
                 k_maxpool_bwd(ins[i], g, 0, wscale=w[i], into=dst[i], accumulate=bool(accum[i]))
+            elif m == 3:                                           # zero-pad-same max pool of a double-res input
+                lib().call("hn_maxpool_bwd_from_arg", ptr(args[i]), ptr(g), ld(g), ptr(dst[i]), ld(dst[i]), ptr(w[i]), n, 2 * h, 2 * wd, ch, 0,
+                           accum[i])
         dins = [None if (slots[i] is not None or not modes[i]) else dst[i] for i in range(3)]
         return dpraw, None, None, None, dins[0], dins[1], dins[2], None
 
