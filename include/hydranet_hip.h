@@ -73,6 +73,14 @@ int hn_conv_gemm_nt(const void* x0, const void* x1, int mode, int n_img, int H, 
 int hn_nt_stat_rows(long M, int Nout);
 /* mode 5 with psum/psq: one partial row per 16x16 output patch */
 int hn_direct_stat_rows(int n_img, int H, int W);
+/* Plain-rows 1x1 GEMM (hn_conv_gemm_nt mode 0, one tap, bf16 out) with ONE PACKED WEIGHT MATRIX PER IMAGE: rows [n * rows_per_image,
+ * (n + 1) * rows_per_image) of x0 use w + n * w_img_stride ([Nout][KP] bf16 each; rows_per_image % 128 == 0).  addend (optional): added
+ * BEFORE the activation.  hn_scale_weight_gate makes such operands: out[n][co][k] = bf16(wp[co][k] * gate[n][k]).  Inference: an XBlock's
+ * conv_block_3 with the SE gate folded into its weights per image (net/anynet.py:68-75) instead of a b * gate pass over the activation. */
+int hn_conv_gemm_nt_imgw(const void* x0, int ld0, long M, int C0, const void* w, long w_img_stride, long rows_per_image, int Nout, int KP,
+                         const float* bias, int act, void* out, int ldc, const void* addend, int ld_add, hipStream_t stream);
+int hn_scale_weight_gate(const void* wp, const float* gate, void* out, int N, int Cout, int C, int KP, hipStream_t stream);
+
 /* hn_conv_gemm_nt with (a) an operand transform for modes 0/1 (bf16 output): the pixel operand is act(xscale[c]*x + xshift[c]) rounded to
  * bf16 and optionally multiplied by xgate[row / xhw][c] -- BatchNorm apply (+ReLU, + SE gate) of the producer folded into this conv's
  * operand path (net/anynet.py:67-70: conv_block_3 consumes SE(relu(bn2(conv_block_2)))), nothing materialised; and (b) an addend for the

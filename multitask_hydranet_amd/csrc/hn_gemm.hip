@@ -155,6 +155,10 @@ struct GemmNT {
                                       // maximum wins) instead of the logits (deploy forward: model/model.py:197 only needs the mask)
     int add_pre;                      // 1: the addend goes in BEFORE the activation: out = act(acc + bias + addend) (inference: folded
                                       // BatchNorm + identity branch + ReLU of an XBlock in conv_block_3's epilogue)
+    // 1x1 GEMMs, one weight matrix PER IMAGE (w_rpi > 0): rows [n * w_rpi, (n + 1) * w_rpi) use w + n * w_img_stride.  Inference: the SE
+    // gate g[n][ci] of an XBlock folded into conv_block_3's weights (W_n = W diag(g_n), hn_scale_weight_gate) instead of a pass over the
+    // activation; a pixel tile must lie inside one image (w_rpi % 128 == 0)
+    long w_img_stride; unsigned w_rpi;
     // Direct 3x3 kernel, mode 3 (data gradient on the padded (H+2) x (W+2) grid), staged bf16 epilogue: fold = 1 writes the INTERIOR of
     // the padded grid straight to the unpadded gradient out [N][H][W] (row stride ldc), multiplied by ELU'(fold_y) when the producer's
     // ELU output is given, and the one-pixel RING to ring [N][2 (W+2) + 2 H][Nout] (top row, bottom row, left column, right column);
@@ -311,6 +315,7 @@ __global__ __launch_bounds__(256 * KG) void gemm_nt_kernel(const GemmNT p) {
 #pragma unroll
         for (int i = 0; i < XR; ++i) { pix0[i] = -1; pix1[i] = -1; }
     }
+    const bf16* wimg = p.w + (p.w_rpi ? (long)((unsigned)p_blk / p.w_rpi) * p.w_img_stride : 0);    // (per-image weights: GemmNT::w_rpi)
     long wo[WR];                                   // weight row offset + this thread's in-chunk offset (-1 = zero row)
 #pragma unroll
     for (int i = 0; i < WR; ++i) {
@@ -393,7 +398,7 @@ __global__ __launch_bounds__(256 * KG) void gemm_nt_kernel(const GemmNT p) {
 #pragma unroll
             for (int i = 0; i < WR; ++i) {
                 if (wave * 8 + 32 * i < BC) {                          // wave-uniform (always true for BC >= 32)
-                    const bf16* src = (qv && wo[i] >= 0) ? p.w + wo[i] + q * 32 : g_zero_piece;
+                    const bf16* src = (qv && wo[i] >= 0) ? wimg + wo[i] + q * 32 : g_zero_piece;
                     glds16(src, sW + (wave * 8 + 32 * i) * 128);
                 }
             }
@@ -2768,6 +2773,8 @@ static thread_local NextStat g_next_stat = {0, nullptr, 0, nullptr};   // set by
 struct NextFold { bf16* ring; const bf16* y; int ldy; };
 static thread_local NextFold g_next_fold = {nullptr, nullptr, 0};   // set by hn_conv3x3_dgrad_fold for the launch it makes
 static thread_local long* g_next_amax = nullptr;    // set by hn_conv3x3_out_argmax for the launch it makes (same thread, same call)
+struct NextImgW { long stride; long rpi; };
+static thread_local NextImgW g_next_imgw = {0, 0};  // set by hn_conv_gemm_nt_imgw for the launch it makes
 static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img, int H, int W, int C0, int C1, int ld0, int ld1,
                              int up, long M, const void* w, int Nout, int KP, int taps, const float* bias, int act, void* out,
                              int out_f32, int ldc, long rpi, long img_stride, float* psum, float* psq, const float* xscale,
@@ -2779,6 +2786,45 @@ extern "C" int hn_conv_gemm_nt(const void* x0, const void* x1, int mode, int n_i
                                int out_f32, int ldc, long rpi, long img_stride, float* psum, float* psq, hipStream_t st) {
     return conv_gemm_nt_impl(x0, x1, mode, n_img, H, W, C0, C1, ld0, ld1, up, M, w, Nout, KP, taps, bias, act, out, out_f32, ldc, rpi,
                              img_stride, psum, psq, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, 0, 0, 0, st);
+}
+
+/* hn_conv_gemm_nt for plain rows (mode 0, one tap) with ONE PACKED WEIGHT MATRIX PER IMAGE: rows [n * rows_per_image, (n + 1) *
+ * rows_per_image) of x0 use w + n * w_img_stride ([Nout][KP] bf16 each).  rows_per_image % 128 == 0.  addend (optional, row stride
+ * ld_add): added BEFORE the activation (the identity branch of an XBlock).  Inference: conv_block_3 with the SE gate folded into its
+ * weights per image (hn_scale_weight_gate) -- net/anynet.py:68-75 without the b * gate pass over the activation. */
+extern "C" int hn_conv_gemm_nt_imgw(const void* x0, int ld0, long M, int C0, const void* w, long w_img_stride, long rows_per_image, int Nout,
+                                    int KP, const float* bias, int act, void* out, int ldc, const void* addend, int ld_add, hipStream_t st) {
+    HN_CHECK_ARG(rows_per_image > 0 && rows_per_image % 128 == 0 && M % rows_per_image == 0 && w_img_stride >= (long)Nout * KP);
+    g_next_imgw = {w_img_stride, rows_per_image};
+    const int rc = conv_gemm_nt_impl(x0, nullptr, 0, 1, 1, (int)(M < (1L << 30) ? M : 1), C0, 0, ld0, 0, 0, M, w, Nout, KP, 1, bias, act, out, 0, ldc, 0, 0,
+                                     nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, addend, addend ? -ld_add : 0, 0, 0, 0, st);
+    g_next_imgw = {0, 0};
+    return rc;
+}
+
+// out[n][co][k] = bf16(wp[co][k] * gate[n][k]) (k < C; the K padding stays zero): the per-image operands of hn_conv_gemm_nt_imgw
+__global__ __launch_bounds__(256) void scale_weight_gate_kernel(const bf16* wp, const float* gate, bf16* out, int N, int Cout, int C, int KP) {
+    const unsigned k8n = (unsigned)KP >> 3;
+    const unsigned total = (unsigned)N * (unsigned)Cout * k8n;
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        const unsigned t = idx / k8n, k8 = idx - t * k8n;
+        const unsigned n = t / (unsigned)Cout, co = t - n * (unsigned)Cout;
+        const bf16x8 v = ld8(wp + (long)co * KP + k8 * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = (int)k8 * 8 + j;
+            o[j] = f2bf(k < C ? bf2f(v[j]) * gate[(long)n * C + k] : 0.f);
+        }
+        st8(out + ((long)n * Cout + co) * KP + k8 * 8, o);
+    }
+}
+extern "C" int hn_scale_weight_gate(const void* wp, const float* gate, void* out, int N, int Cout, int C, int KP, hipStream_t st) {
+    HN_CHECK_ARG(wp && gate && out && N > 0 && Cout > 0 && C > 0 && C <= KP && (KP & 31) == 0 && (long)N * Cout * (KP >> 3) < (1L << 31));
+    long b = ((long)N * Cout * (KP >> 3) + 255) / 256;
+    if (b > 4096) b = 4096;
+    hipLaunchKernelGGL(scale_weight_gate_kernel, dim3((unsigned)b), dim3(256), 0, st, (const bf16*)wp, gate, (bf16*)out, N, Cout, C, KP);
+    HN_LAUNCH_CHECK();
 }
 
 extern "C" int hn_conv_gemm_nt_ex(const void* x0, const void* x1, int mode, int n_img, int H, int W, int C0, int C1, int ld0, int ld1,
@@ -2874,6 +2920,9 @@ static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img
     p.phase_mode = phase_mode; p.phase_span = phase_span;
     p.amax = g_next_amax;
     g_next_amax = nullptr;
+    p.w_img_stride = g_next_imgw.stride; p.w_rpi = (unsigned)g_next_imgw.rpi;
+    g_next_imgw = {0, 0};
+    HN_CHECK_ARG(p.w_rpi == 0 || (mode == 0 && taps == 1 && !xscale && p.w_rpi % 128 == 0 && M < (1L << 32)));
     p.emode = g_next_stat.mode; p.ez = g_next_stat.z; p.ld_ez = g_next_stat.ldz; p.ecoef = g_next_stat.coef;
     p.tile_major = g_hn_knob[11] == 1 ? 1 : 0;
     p.wpre = 0;

@@ -369,7 +369,7 @@ class HydraNet(nn.Module):
         f = self._folded.get(conv) if (self._folded is not None and not self.training) else None
         if f is not None and x.dim() == 4 and x.dtype == torch.bfloat16:
             return K.conv_infer(x, f[0], f[1], P[conv + ".weight"].shape[0], kw.get("kind", "1x1"), kw.get("stride", 1), kw.get("act", ACT_NONE),
-                                kw.get("res"))
+                                kw.get("res"), kw.get("gate"))
         if not x.requires_grad:
             kw.pop("slot", None)
         return K.conv_bn_act(x, P[conv + ".weight"], P.get(conv + ".bias"), self._bn(bn), training=self.training, **bnkw, **kw)
@@ -381,10 +381,9 @@ class HydraNet(nn.Module):
         if self._folded is not None and not self.training:            # inference: 7 launches per block, nothing but GEMM epilogues
             a = self._cba(x, q + "conv_block_1.0", q + "conv_block_1.1", BN_STD, act=ACT_RELU)
             b = self._cba(a, q + "conv_block_2.0", q + "conv_block_2.1", BN_STD, kind="g3x3", stride=stride, act=ACT_RELU)
-            if has_se:
-                b = K.se_gate_infer(b, P[q + "se.1.weight"], P[q + "se.1.bias"], P[q + "se.3.weight"], P[q + "se.3.bias"])
+            gate = K.se_gate_infer(b, P[q + "se.1.weight"], P[q + "se.1.bias"], P[q + "se.3.weight"], P[q + "se.3.bias"], apply=False) if has_se else None
             s = self._cba(x, q + "shortcut.0", q + "shortcut.1", BN_STD, stride=stride, act=ACT_NONE) if has_sc else x
-            return self._cba(b, q + "conv_block_3.0", q + "conv_block_3.1", BN_STD, res=s, act=ACT_RELU)
+            return self._cba(b, q + "conv_block_3.0", q + "conv_block_3.1", BN_STD, res=s, act=ACT_RELU, gate=gate)
         if K.xblock_fusable(x, P[q + "conv_block_1.0.weight"], stride, has_se, has_sc):     # one autograd node, 9 + 21 launches
             bn = [self._bn(q + f"conv_block_{i}.1")[:4] for i in (1, 2, 3)]
             sc = (P[q + "shortcut.0.weight"], *self._bn(q + "shortcut.1")[:4]) if has_sc else ()

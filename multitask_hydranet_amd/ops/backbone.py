@@ -345,10 +345,26 @@ def fold_conv_bn(w, conv_bias, gamma, beta, rm, rv, eps, kind):
         return wp, shift.contiguous()
 
 
-def conv_infer(x, packed, bias, cout, kind, stride, act, res=None):
-    """act(conv(x) + bias [+ res]) with folded-BatchNorm operands: one launch"""
+INFER_GATE_IN_WEIGHTS = os.environ.get("HN_INFER_GATE_IN_WEIGHTS", "1") != "0"
+
+
+def conv_infer(x, packed, bias, cout, kind, stride, act, res=None, gate=None):
+    """act(conv(x [* gate]) + bias [+ res]) with folded-BatchNorm operands: one launch.  gate [N, Cin] fp32 (the SE excitation of an XBlock,
+    x = the un-gated activation): folded into the 1x1 weights per image (W_n = W diag(gate_n): one small launch over N x Cout x Cin weights
+    instead of a read + write pass over the activation) where a pixel tile lies inside one image; else applied to x first."""
     n, hi, wi, cin = x.shape
     ho, wo = (hi, wi) if stride == 1 else (hi // 2, wi // 2)
+    if gate is not None:
+        hw = hi * wi
+        if INFER_GATE_IN_WEIGHTS and kind == "1x1" and stride == 1 and hw % 128 == 0:
+            kp = kp32(cin)
+            wn = torch.empty((n, cout, kp), device=x.device, dtype=BF16)
+            lib().call("hn_scale_weight_gate", ptr(packed), ptr(gate), ptr(wn), n, cout, cin, kp)
+            out = new_act(n, ho, wo, cout, x.device)
+            lib().call("hn_conv_gemm_nt_imgw", ptr(x), ld(x), n * hw, cin, ptr(wn), cout * kp, hw, cout, kp, ptr(bias), act, ptr(out), ld(out),
+                       ptr(res), ld(res) if res is not None else 0)
+            return out
+        x = apply_gate_rows(x, gate)
     if kind == "g3x3":
         assert stride == 1 and res is None
         out, _, _ = k_gemm_nt(x, None, 5, (n, ho, wo), packed, cout, 64, 9, bias=bias, act=act)
@@ -358,8 +374,9 @@ def conv_infer(x, packed, bias, cout, kind, stride, act, res=None):
     return out
 
 
-def se_gate_infer(b, w1, b1, w2, b2):
-    """SE squeeze / excite for the inference path: per-image channel sums (one pass), the MLP fed by the partial rows, then b * gate"""
+def se_gate_infer(b, w1, b1, w2, b2, apply=True):
+    """SE squeeze / excite for the inference path: per-image channel sums (one pass), the MLP fed by the partial rows, then b * gate
+    (apply = False: the gate [N, C] itself, for conv_infer(gate=...))"""
     n, h, w, c = b.shape
     hw, m = h * w, n * h * w
     cs = w1.shape[0]
@@ -375,7 +392,14 @@ def se_gate_infer(b, w1, b1, w2, b2):
     hid = torch.empty((n, cs), device=dev, dtype=F32)
     gate = torch.empty((n, c), device=dev, dtype=F32)
     lib().call("hn_se_mlp_fwd_parts", ptr(ps), hw // rb, 1.0 / hw, ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(pooled), ptr(hid), ptr(gate), n, c, cs)
-    out = new_act(n, h, w, c, dev)
+    return gate if not apply else apply_gate_rows(b, gate)
+
+
+def apply_gate_rows(b, gate):
+    """b * gate[n][c] (one pass over the activation)"""
+    n, h, w, c = b.shape
+    hw, m = h * w, n * h * w
+    out = new_act(n, h, w, c, b.device)
     rb2 = lib().query("hn_fused_row_block", m, c, hw, 0, 0)
     lib().call("hn_bn_apply_fused", ptr(b), ld(b), m, c, None, None, 0, m, None, None, 0.0, 0.0, None, None, None, None, 0, ACT_NONE, ptr(out),
                ld(out), None, ptr(gate), hw, rb2)
