@@ -80,6 +80,12 @@ int hn_direct_stat_rows(int n_img, int H, int W);
 int hn_conv_gemm_nt_imgw(const void* x0, int ld0, long M, int C0, const void* w, long w_img_stride, long rows_per_image, int Nout, int KP,
                          const float* bias, int act, void* out, int ldc, const void* addend, int ld_add, hipStream_t stream);
 int hn_scale_weight_gate(const void* wp, const float* gate, void* out, int N, int Cout, int C, int KP, hipStream_t stream);
+/* The same plain-rows GEMM on LEVEL-PACKED rows with the per-level eval-mode BatchNorm + activation of the det towers in the epilogue
+ * (head_detect/detection.py:60-75): out = act(coef[l][0][c] * (x W^T + bias) + coef[l][1][c]), l = the level of the row; rows [nlev] =
+ * rows of every level (multiples of 128: hn_bn_act_levels' argument), coef [nlev][4][Nout].  Inference: one launch per tower layer's
+ * pointwise conv + BatchNorm + Swish instead of two. */
+int hn_conv_gemm_nt_lvl(const void* x0, int ld0, long M, int C0, const void* w, int Nout, int KP, const float* bias, int act, void* out,
+                        int ldc, const float* coef, int nlev, const long* rows, hipStream_t stream);
 
 /* hn_conv_gemm_nt with (a) an operand transform for modes 0/1 (bf16 output): the pixel operand is act(xscale[c]*x + xshift[c]) rounded to
  * bf16 and optionally multiplied by xgate[row / xhw][c] -- BatchNorm apply (+ReLU, + SE gate) of the producer folded into this conv's

@@ -159,6 +159,10 @@ struct GemmNT {
     // gate g[n][ci] of an XBlock folded into conv_block_3's weights (W_n = W diag(g_n), hn_scale_weight_gate) instead of a pass over the
     // activation; a pixel tile must lie inside one image (w_rpi % 128 == 0)
     long w_img_stride; unsigned w_rpi;
+    // level-packed rows (det towers), inference: per-LEVEL eval-mode BatchNorm of the output in the epilogue, out = act(lcoef[l][0][c] *
+    // (acc + bias) + lcoef[l][1][c]) with l = the level of the pixel tile (levels start on 128-row boundaries: tile-uniform);
+    // lcoef [ln][4][Nout] (scale, shift, -, -), lrow = cumulative rows per level
+    const float* lcoef; int ln; long lrow[HN_MAX_LEVELS + 1];
     // Direct 3x3 kernel, mode 3 (data gradient on the padded (H+2) x (W+2) grid), staged bf16 epilogue: fold = 1 writes the INTERIOR of
     // the padded grid straight to the unpadded gradient out [N][H][W] (row stride ldc), multiplied by ELU'(fold_y) when the producer's
     // ELU output is given, and the one-pixel RING to ring [N][2 (W+2) + 2 H][Nout] (top row, bottom row, left column, right column);
@@ -503,6 +507,21 @@ __global__ __launch_bounds__(256 * KG) void gemm_nt_kernel(const GemmNT p) {
         for (int j = 0; j < TP; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) vv[(i * TP + j) * 4 + r] = acc[i][j][r] + bsv[r];
+    }
+    if (p.lcoef) {                                                    // per-level BatchNorm (running statistics) of the tile's level
+        int lv = 0;
+        while (lv + 1 < p.ln && p_blk >= p.lrow[lv + 1]) ++lv;
+        const float* cf = p.lcoef + (long)lv * 4 * p.Nout;
+#pragma unroll
+        for (int i = 0; i < TC; ++i) {
+            const int co0 = c_blk + wc * WC + i * 16 + (lane >> 4) * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sc = co0 + r < p.Nout ? cf[co0 + r] : 0.f, sh = co0 + r < p.Nout ? cf[p.Nout + co0 + r] : 0.f;
+#pragma unroll
+                for (int j = 0; j < TP; ++j) vv[(i * TP + j) * 4 + r] = vv[(i * TP + j) * 4 + r] * sc + sh;
+            }
+        }
     }
     if (p.addend && p.add_pre) {
 #pragma unroll
@@ -2775,6 +2794,8 @@ static thread_local NextFold g_next_fold = {nullptr, nullptr, 0};   // set by hn
 static thread_local long* g_next_amax = nullptr;    // set by hn_conv3x3_out_argmax for the launch it makes (same thread, same call)
 struct NextImgW { long stride; long rpi; };
 static thread_local NextImgW g_next_imgw = {0, 0};  // set by hn_conv_gemm_nt_imgw for the launch it makes
+struct NextLvl { const float* coef; int n; long row[HN_MAX_LEVELS + 1]; };
+static thread_local NextLvl g_next_lvl = {nullptr, 0, {0}};   // set by hn_conv_gemm_nt_lvl for the launch it makes
 static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img, int H, int W, int C0, int C1, int ld0, int ld1,
                              int up, long M, const void* w, int Nout, int KP, int taps, const float* bias, int act, void* out,
                              int out_f32, int ldc, long rpi, long img_stride, float* psum, float* psq, const float* xscale,
@@ -2799,6 +2820,25 @@ extern "C" int hn_conv_gemm_nt_imgw(const void* x0, int ld0, long M, int C0, con
     const int rc = conv_gemm_nt_impl(x0, nullptr, 0, 1, 1, (int)(M < (1L << 30) ? M : 1), C0, 0, ld0, 0, 0, M, w, Nout, KP, 1, bias, act, out, 0, ldc, 0, 0,
                                      nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, addend, addend ? -ld_add : 0, 0, 0, 0, st);
     g_next_imgw = {0, 0};
+    return rc;
+}
+
+/* hn_conv_gemm_nt for level-packed plain rows (mode 0, one tap) with the per-level eval-mode BatchNorm + activation of the det towers
+ * (head_detect/detection.py:60-75) in the epilogue: out = act(coef[l][0][c] * (x W^T + bias) + coef[l][1][c]), l = level of the row.  rows
+ * [nlev]: rows of every level in the packed tensor (multiples of 128, as hn_bn_act_levels takes them); coef [nlev][4][Nout]. */
+extern "C" int hn_conv_gemm_nt_lvl(const void* x0, int ld0, long M, int C0, const void* w, int Nout, int KP, const float* bias, int act,
+                                   void* out, int ldc, const float* coef, int nlev, const long* rows, hipStream_t st) {
+    HN_CHECK_ARG(coef && rows && nlev >= 1 && nlev <= HN_MAX_LEVELS);
+    NextLvl nl = {coef, nlev, {0}};
+    for (int l = 0; l < nlev; ++l) {
+        HN_CHECK_ARG(rows[l] > 0 && rows[l] % 128 == 0);
+        nl.row[l + 1] = nl.row[l] + rows[l];
+    }
+    HN_CHECK_ARG(nl.row[nlev] == M);
+    g_next_lvl = nl;
+    const int rc = conv_gemm_nt_impl(x0, nullptr, 0, 1, 1, (int)(M < (1L << 30) ? M : 1), C0, 0, ld0, 0, 0, M, w, Nout, KP, 1, bias, act, out, 0, ldc, 0, 0,
+                                     nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, 0, 0, 0, st);
+    g_next_lvl.coef = nullptr;
     return rc;
 }
 
@@ -2922,6 +2962,10 @@ static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img
     g_next_amax = nullptr;
     p.w_img_stride = g_next_imgw.stride; p.w_rpi = (unsigned)g_next_imgw.rpi;
     g_next_imgw = {0, 0};
+    p.lcoef = g_next_lvl.coef; p.ln = g_next_lvl.n;
+    for (int l = 0; l <= HN_MAX_LEVELS; ++l) p.lrow[l] = g_next_lvl.row[l];
+    g_next_lvl.coef = nullptr;
+    HN_CHECK_ARG(!p.lcoef || (mode == 0 && taps == 1 && !psum && !xscale));
     HN_CHECK_ARG(p.w_rpi == 0 || (mode == 0 && taps == 1 && !xscale && p.w_rpi % 128 == 0 && M < (1L << 32)));
     p.emode = g_next_stat.mode; p.ez = g_next_stat.z; p.ld_ez = g_next_stat.ldz; p.ecoef = g_next_stat.coef;
     p.tile_major = g_hn_knob[11] == 1 ? 1 : 0;

@@ -228,6 +228,7 @@ class PackLevels(torch.autograd.Function):
         return tuple(level_views(dense(g), ctx.geom))
 
 
+TOWER_BN_IN_GEMM = os.environ.get("HN_TOWER_BN_IN_GEMM", "1") != "0"
 _EVAL_COEF = {}             # id(gamma of level 0) -> (the 4 * nl BatchNorm tensors, their versions, eps, coef [nl, 4, cout])
 
 
@@ -258,10 +259,17 @@ class TowerLayer(torch.autograd.Function):
         wk, wf = pack_dw_weight(dw_w)
         d = k_dwconv_levels(x, wk, geom)
         wp, wt = pack_conv_weight(pw_w)
-        z, psum, psq = k_gemm_nt(d, None, 0, (1, 1, total), wp, cout, kp32(c), 1, bias=pw_b, stats=training)
         gam, bet = [bn[4 * l] for l in range(nl)], [bn[4 * l + 1] for l in range(nl)]
         rms, rvs = [bn[4 * l + 2] for l in range(nl)], [bn[4 * l + 3] for l in range(nl)]
         coef = torch.empty((nl, 4, cout), device=dev, dtype=F32)
+        if not training and not torch.is_grad_enabled() and TOWER_BN_IN_GEMM:
+            # inference: the per-level BatchNorm (running statistics) + activation ride in the pointwise conv's epilogue -- one launch
+            coef = _eval_coef_levels(gam, bet, rms, rvs, eps, cout, coef)
+            out = torch.empty((1, 1, total, cout), device=dev, dtype=BF16)
+            lib().call("hn_conv_gemm_nt_lvl", ptr(d), ld(d), total, c, ptr(wp), cout, kp32(c), ptr(pw_b), act, ptr(out), ld(out), ptr(coef), nl,
+                       ctypes.addressof(R))
+            return out
+        z, psum, psq = k_gemm_nt(d, None, 0, (1, 1, total), wp, cout, kp32(c), 1, bias=pw_b, stats=training)
         if training:
             div = total // psum.shape[0]
             ga, ba, rma, rva = _ptr_array(gam), _ptr_array(bet), _ptr_array(rms), _ptr_array(rvs)    # keep the host arrays alive
