@@ -1109,3 +1109,60 @@ def test_direct_conv_unstageable_output_takes_the_32_cout_tile(K):
     out, _, _ = K.k_gemm_nt(nhwc(x0), None, 2, (n, h, w), wp, cout, K.kp32(c0), 9, bias=bs, act=3)
     y = F.elu(F.conv2d(F.pad(x0.bfloat16().float(), [1, 1, 1, 1], mode="reflect"), wt.bfloat16().float(), bs))
     close(nchw(out), y, ACT_TOL, "out")
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout", [(3, 16, 24, 64, 64), (2, 8, 16, 152, 376)])
+def test_conv1x1_with_gate_folded_into_per_image_weights(K, n, h, w, cin, cout):
+    """inference form of an XBlock's conv_block_3 (net/anynet.py:68-76): relu(W (b * gate_n) + bias + identity) with the SE gate folded into
+    the packed weights per image (hn_scale_weight_gate + hn_conv_gemm_nt_imgw; h * w is a multiple of 128) == the gated activation through
+    the shared weights (the switch off), and both == the fp32 composition."""
+    b = rnd(n, cin, h, w)
+    res = rnd(n, cout, h, w)
+    wt = rnd(cout, cin, 1, 1, scale=cin ** -0.5)
+    bias = rnd(cout, scale=0.1)
+    gate = torch.rand(n, cin, device=b.device)
+    wp, _ = K.pack_conv_weight(wt)
+    outs = {}
+    for on in (True, False):
+        K.INFER_GATE_IN_WEIGHTS = on
+        try:
+            outs[on] = K.conv_infer(nhwc(b), wp, bias, cout, "1x1", 1, 1, res=nhwc(res), gate=gate)
+        finally:
+            K.INFER_GATE_IN_WEIGHTS = True
+    ref = F.relu(F.conv2d(b.bfloat16().float() * gate.view(n, cin, 1, 1), wt.bfloat16().float(), bias) + res.bfloat16().float())
+    close(nchw(outs[True]), ref, ACT_TOL, "gate in weights")
+    close(nchw(outs[False]), ref, ACT_TOL, "gate on the activation")
+
+
+def test_tower_pointwise_conv_with_level_batchnorm_epilogue(K):
+    """hn_conv_gemm_nt_lvl: level-packed rows, out = swish(scale_l * (x W^T + bias) + shift_l) with the level's eval-mode BatchNorm rows
+    (head_detect/detection.py:60-75) == the GEMM followed by hn_bn_act_levels, and == the fp32 composition per level."""
+    import ctypes
+    n, c, cout = 2, 64, 64
+    hs, ws = (16, 8, 4), (24, 12, 6)
+    geom = (n, hs, ws)
+    nl, H, W, R, CNT = K._geom_arrays(geom)
+    total = sum(R)
+    x = torch.zeros(1, 1, total, c, device="cuda", dtype=torch.bfloat16)
+    feats = [rnd(n, h, w, c) for h, w in zip(hs, ws)]
+    off = 0
+    for f, r in zip(feats, R):
+        x[0, 0, off:off + f.numel() // c] = f.reshape(-1, c).to(torch.bfloat16)
+        off += r
+    wt = rnd(cout, c, 1, 1, scale=c ** -0.5)
+    bias = rnd(cout, scale=0.1)
+    coef = torch.zeros(nl, 4, cout, device="cuda")
+    coef[:, 0] = torch.rand(nl, cout, device="cuda") + 0.5
+    coef[:, 1] = torch.randn(nl, cout, device="cuda") * 0.2
+    wp, _ = K.pack_conv_weight(wt)
+    out = torch.empty(1, 1, total, cout, device="cuda", dtype=torch.bfloat16)
+    K.lib().call("hn_conv_gemm_nt_lvl", x.data_ptr(), c, total, c, wp.data_ptr(), cout, K.kp32(c), bias.data_ptr(), 2, out.data_ptr(), cout,
+                 coef.data_ptr(), nl, ctypes.addressof(R))
+    off = 0
+    for l, (f, r) in enumerate(zip(feats, R)):
+        m = f.numel() // c
+        z = f.reshape(-1, c).bfloat16().float() @ wt.view(cout, c).bfloat16().float().t() + bias
+        y = z * coef[l, 0] + coef[l, 1]
+        y = y * torch.sigmoid(y)
+        close(out[0, 0, off:off + m].float(), y, ACT_TOL, f"level {l}")
+        off += r
