@@ -522,6 +522,12 @@ class TrainRun:
                     print("rank", self.rank, "eager loss", float(l0.detach()), file=sys.stderr, flush=True)
         torch.cuda.current_stream().wait_stream(s_)
         torch.cuda.synchronize()
+        if reducer is not None and with_hooks:
+            # The warm-up's collectives are complete, but the RCCL watchdog thread reaps their work objects on its own ~100 ms cadence: give
+            # it a few rounds before the capture starts.  A work object it polls while the stream its end event was recorded on is being
+            # captured makes hipEventQuery fail inside the watchdog, which aborts the process (the likely cause of one abort in ~40 runs of
+            # tests/test_train_gpu.py::test_rccl_gradient_exchange_world1_in_graph: the trace ended in WorkNCCL::isCompleted of the watchdog).
+            time.sleep(0.5)
         net.zero_grad(set_to_none=True)
         g = torch.cuda.CUDAGraph()
         # thread-local capture mode: the RCCL watchdog thread's event queries (N > 1) must not invalidate the capture
