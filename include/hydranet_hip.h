@@ -112,6 +112,14 @@ int hn_conv_gemm_nt_stat(const void* x0, const void* x1, int mode, int n_img, in
                          const void* w, int Nout, int KP, int taps, const float* bias, int act, void* out, int out_f32, int ldc, long rpi,
                          long img_stride, float* psum, float* psq, const void* addend, int ld_add, int add_mode, int emode, const void* ez,
                          int ld_ez, const float* ecoef, hipStream_t stream);
+/* Data-gradient GEMM of an identity XBlock's conv_block_1 (dx = dz1 W1 + g, the addend joining after the rounding), whose statistics rows
+ * are the reduce pass of the PREVIOUS block's masked BatchNorm-3 backward over the dx it produces: psum / psq [ceil(M / 64)][Nout] =
+ * sum g', sum g' (ez - mean) rstd with g' = dx [ey > 0] (ez = that block's conv_block_3 output, ey = its output, ecoef fp32 [4][Nout] its
+ * BatchNorm-3 coefficients).  Consumed by hn_bn_bwd_apply_fused.  Only where hn_nt_stat_rows(M, Nout) == ceil(M / 64) (the 64 x 64 tiling);
+ * HN_ERR_ARG otherwise.  Replaces the first pass of aten::native_batch_norm_backward of net/anynet.py:65-76's last BatchNorm. */
+int hn_conv_gemm_nt_stat3(const void* x0, int ld0, long M, int C0, const void* w, int Nout, int KP, void* out, int ldc, float* psum, float* psq,
+                          const void* addend, int ld_add, const void* ez, int ld_ez, const void* ey, int ld_ey, const float* ecoef,
+                          hipStream_t stream);
 /* wgrad: dw[Cout][Cin][taps] (PyTorch layout, fp32) = sum_pixel dz[pixel][cout] * X(pixel, tap)[c]; X modes 0..2 as above.
  * dz rows must be zero padded up to ldz >= Nout rounded up to 8.  workspace: fp32, size from hn_wgrad_plan.
  * Replaces aten::convolution_backward's weight gradient. */

@@ -178,6 +178,11 @@ struct GemmNT {
     //            producer: the reduce pass of hn_bn_bwd_fused over (da, z1))
     // ez: the forward pre-BatchNorm tensor at the output's rows / channels (row stride ld_ez); ecoef: [4][Nout] = sc, sh, mu, rs
     int emode; const bf16* ez; int ld_ez; const float* ecoef;
+    //   emode 3 (1x1 GEMMs, staged bf16 output with a post-activation addend): g = out [ey > 0] with out = the FINAL stored value
+    //            (accumulator + addend, rounded); s1 = sum g, s2 = sum g (z - mu) rs: the reduce pass of the masked BatchNorm backward of the
+    //            PREVIOUS XBlock (hn_bn_bwd_fused over (dout, z3, y)) out of the epilogue of the launch that produces that dout = this
+    //            block's data gradient dz1 W1 + g; computed in the write-out phase, where the addend joins
+    const bf16* ey; int ld_ey;
     int tile_major;                   // direct kernel: block id order (see there)
     int wpre;                         // direct kernel: all weight tiles of the (single) chunk preloaded, one LDS slot per tap step
     unsigned long long* dbg_buf;      // tools/ only: stamp buffer (hn_debug_knob 15)
@@ -542,7 +547,8 @@ __global__ __launch_bounds__(256 * KG) void gemm_nt_kernel(const GemmNT p) {
             }
         }
     }
-    if (want_stats) {
+    const bool e3 = want_stats && p.emode == 3;                       // statistics of the final values: in the write-out phase below
+    if (want_stats && !e3) {
         if (!staged) __syncthreads();                                 // the operand ring is free: [WGP][BC][2] floats of it hold the wave sums
         // (BEHIND the staged output tile: the wave sums and the tile are written in one phase and read after ONE common barrier --
         // the statistics used to cost two barriers of their own, +2.2 us on the 11 us stage-4 GEMM)
@@ -646,7 +652,7 @@ __global__ __launch_bounds__(256 * KG) void gemm_nt_kernel(const GemmNT p) {
         }
     }
     if (staged || want_stats) __syncthreads();
-    if (want_stats && tid < BC && c_blk + tid < p.Nout) {             // one partial row per pixel tile: the WGP wave sums in fixed order
+    if (want_stats && !e3 && tid < BC && c_blk + tid < p.Nout) {      // one partial row per pixel tile: the WGP wave sums in fixed order
         const float* red = reinterpret_cast<const float*>(smem + BP * BC * 2);
         float t1 = 0.f, t2 = 0.f;
 #pragma unroll
@@ -656,6 +662,16 @@ __global__ __launch_bounds__(256 * KG) void gemm_nt_kernel(const GemmNT p) {
     }
     if (staged) {
         bf16* outp = reinterpret_cast<bf16*>(p.out);
+        float e1[8], e2[8], emu[8], ers[8];                           // emode 3: this thread's channel piece is tid % NPC in every iteration
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { e1[k] = 0.f; e2[k] = 0.f; emu[k] = 0.f; ers[k] = 0.f; }
+        if (e3) {
+            const int co = c_blk + (tid % NPC) * 8;
+            if (co < p.Nout) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { emu[k] = p.ecoef[2 * p.Nout + co + k]; ers[k] = p.ecoef[3 * p.Nout + co + k]; }
+            }
+        }
 #pragma unroll 2
         for (int idx = tid; idx < BP * NPC; idx += 256) {
             const int row = idx / NPC, pc = idx % NPC;
@@ -684,7 +700,32 @@ __global__ __launch_bounds__(256 * KG) void gemm_nt_kernel(const GemmNT p) {
                         for (int k = 0; k < 8; ++k) v[k] = f2bf(bf2f(v[k]) + bf2f(a[k]));
                     }
                 }
+                if (e3) {
+                    const bf16x8 yv = ld8(p.ey + pix * p.ld_ey + co), zv = ld8(p.ez + pix * p.ld_ez + co);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float g = bf2f(yv[k]) > 0.f ? bf2f(v[k]) : 0.f;
+                        e1[k] += g;
+                        e2[k] += g * (bf2f(zv[k]) - emu[k]) * ers[k];
+                    }
+                }
                 *reinterpret_cast<bf16x8*>(outp + orow + co) = v;
+            }
+        }
+        if (e3) {
+            // the 256 / NPC threads that share a channel piece are folded through LDS (behind the staged tile and the wave sums), in
+            // thread order: deterministic
+            float* r3 = reinterpret_cast<float*>(smem + BP * BC * 2 + WGP * BC * 8);
+            static_assert(BP * BC * 2 + WGP * BC * 8 + 256 * 16 * 4 <= R * KG * STAGE || BC < 64, "emode 3 scratch fits the operand ring");
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { r3[tid * 16 + k] = e1[k]; r3[tid * 16 + 8 + k] = e2[k]; }
+            __syncthreads();
+            if (tid < BC && c_blk + tid < p.Nout) {
+                const int pc = tid >> 3, k = tid & 7;
+                float t1 = 0.f, t2 = 0.f;
+                for (int j = 0; j < 256 / NPC; ++j) { t1 += r3[(j * NPC + pc) * 16 + k]; t2 += r3[(j * NPC + pc) * 16 + 8 + k]; }
+                p.psum[(long)p_tile * p.Nout + c_blk + tid] = t1;
+                p.psq[(long)p_tile * p.Nout + c_blk + tid] = t2;
             }
         }
     }
@@ -2787,8 +2828,8 @@ extern "C" int hn_nt_stat_rows(long M, int Nout) {               // one partial 
     return small_tile(M, Nout) ? cdiv(M, 64) : cdiv(M, 128);
 }
 
-struct NextStat { int mode; const bf16* z; int ldz; const float* coef; };
-static thread_local NextStat g_next_stat = {0, nullptr, 0, nullptr};   // set by hn_conv_gemm_nt_stat for the launch it makes
+struct NextStat { int mode; const bf16* z; int ldz; const float* coef; const bf16* y; int ldy; };
+static thread_local NextStat g_next_stat = {0, nullptr, 0, nullptr, nullptr, 0};   // set by hn_conv_gemm_nt_stat for the launch it makes
 struct NextFold { bf16* ring; const bf16* y; int ldy; };
 static thread_local NextFold g_next_fold = {nullptr, nullptr, 0};   // set by hn_conv3x3_dgrad_fold for the launch it makes
 static thread_local long* g_next_amax = nullptr;    // set by hn_conv3x3_out_argmax for the launch it makes (same thread, same call)
@@ -2886,10 +2927,26 @@ extern "C" int hn_conv_gemm_nt_stat(const void* x0, const void* x1, int mode, in
                                     int add_mode, int emode, const void* ez, int ld_ez, const float* ecoef, hipStream_t st) {
     HN_CHECK_ARG((emode == 1 || emode == 2) && psum && (psq || emode == 1) && ez && ecoef && (Nout & 7) == 0 && (ld_ez & 3) == 0 && !out_f32 &&
                  act == HN_ACT_NONE && (mode <= 1 || mode == 5) && (reinterpret_cast<uintptr_t>(ez) & 7) == 0);
-    g_next_stat = {emode, (const bf16*)ez, ld_ez, ecoef};
+    g_next_stat = {emode, (const bf16*)ez, ld_ez, ecoef, nullptr, 0};
     const int rc = conv_gemm_nt_impl(x0, x1, mode, n_img, H, W, C0, C1, ld0, ld1, up, M, w, Nout, KP, taps, bias, act, out, out_f32, ldc, rpi,
                                      img_stride, psum, psq, nullptr, nullptr, nullptr, 0, 0, addend, ld_add, add_mode, 0, 0, st);
-    g_next_stat = {0, nullptr, 0, nullptr};
+    g_next_stat = {0, nullptr, 0, nullptr, nullptr, 0};
+    return rc;
+}
+
+/* 1x1 data-gradient GEMM of an identity XBlock, dx = dz1 W1^T + g (addend, added after rounding: the staged epilogue), whose statistics rows
+ * carry the reduce pass of the PREVIOUS block's masked BatchNorm-3 backward over the dx it produces (GemmNT::emode 3): psum / psq
+ * [hn_nt_stat_rows(M, Nout)][Nout] = sum g', sum g' (ez - mu) rs with g' = dx [ey > 0]; ez = that block's pre-BatchNorm conv_block_3 output,
+ * ey = its output (= this block's input), ecoef [4][Nout] its BatchNorm-3 coefficients (net/anynet.py:65-76 backward, two blocks at once).
+ * Only for the 64 x 64 tiling (hn_nt_stat_rows(M, Nout) == ceil(M / 64)); HN_ERR_ARG otherwise. */
+extern "C" int hn_conv_gemm_nt_stat3(const void* x0, int ld0, long M, int C0, const void* w, int Nout, int KP, void* out, int ldc, float* psum,
+                                     float* psq, const void* addend, int ld_add, const void* ez, int ld_ez, const void* ey, int ld_ey,
+                                     const float* ecoef, hipStream_t st) {
+    HN_CHECK_ARG(psum && psq && ez && ey && ecoef && addend && (ld_ez & 7) == 0 && (ld_ey & 7) == 0);
+    g_next_stat = {3, (const bf16*)ez, ld_ez, ecoef, (const bf16*)ey, ld_ey};
+    const int rc = conv_gemm_nt_impl(x0, nullptr, 0, 1, 1, (int)(M < (1L << 30) ? M : 1), C0, 0, ld0, 0, 0, M, w, Nout, KP, 1, nullptr, HN_ACT_NONE, out, 0,
+                                     ldc, 0, 0, psum, psq, nullptr, nullptr, nullptr, 0, 0, addend, ld_add, 0, 0, 0, st);
+    g_next_stat = {0, nullptr, 0, nullptr, nullptr, 0};
     return rc;
 }
 
@@ -2967,7 +3024,9 @@ static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img
     g_next_lvl.coef = nullptr;
     HN_CHECK_ARG(!p.lcoef || (mode == 0 && taps == 1 && !psum && !xscale));
     HN_CHECK_ARG(p.w_rpi == 0 || (mode == 0 && taps == 1 && !xscale && p.w_rpi % 128 == 0 && M < (1L << 32)));
-    p.emode = g_next_stat.mode; p.ez = g_next_stat.z; p.ld_ez = g_next_stat.ldz; p.ecoef = g_next_stat.coef;
+    p.emode = g_next_stat.mode; p.ez = g_next_stat.z; p.ld_ez = g_next_stat.ldz; p.ecoef = g_next_stat.coef; p.ey = g_next_stat.y; p.ld_ey = g_next_stat.ldy;
+    HN_CHECK_ARG(p.emode != 3 || (mode == 0 && taps == 1 && psum && psq && !out_f32 && addend && ld_add > 0 && !add_mode && (Nout & 7) == 0 &&
+                                   (ldc & 7) == 0 && rpi == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && small_tile(M, Nout)));
     p.tile_major = g_hn_knob[11] == 1 ? 1 : 0;
     p.wpre = 0;
     p.dbg = (int)g_hn_knob[14];

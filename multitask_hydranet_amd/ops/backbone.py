@@ -163,6 +163,7 @@ def conv_bn_act(x, weight, conv_bias, bn, res=None, kind="1x1", stride=1, act=AC
 FUSED_XBLOCK = os.environ.get("HN_FUSED_XBLOCK", "1") != "0"
 EPILOGUE_STATS = os.environ.get("HN_EPILOGUE_STATS", "1") != "0"   # backward reduce passes folded into their producers' epilogues
 XBLOCK_XF_GEMM = os.environ.get("HN_XBLOCK_XF", "0") == "1"
+BN3_PARTS_FROM_DGRAD = os.environ.get("HN_BN3_PARTS_FROM_DGRAD", "1") != "0"   # the next block's last backward GEMM makes the BatchNorm-3 backward's partial sums
 
 
 class XBlockFn(torch.autograd.Function):
@@ -219,13 +220,25 @@ class XBlockFn(torch.autograd.Function):
         ctx.training, ctx.stride = training, stride
         ctx.packs = (wt1, wd2, wt3, wts)
         ctx.group = group
+        # BN3_PARTS_FROM_DGRAD: an identity block whose input IS the previous block's output lets its last backward GEMM (dx = dz1 W1 + g)
+        # make the reduce pass of that block's BatchNorm-3 backward (k_gemm_nt estat 3); the stage's group carries the hand-over
+        z3p = coef3p = None
+        if group is not None and training:
+            last = getattr(group, "bn3_last", None)
+            if (BN3_PARTS_FROM_DGRAD and EPILOGUE_STATS and last is not None and ws is None and stride == 1 and last[0] == x.data_ptr()
+                    and last[1] == tuple(x.shape) and x.is_contiguous() and cin > 64
+                    and lib().query("hn_nt_stat_rows", m_in, cin) == (m_in + 63) // 64 <= MAX_PROLOGUE_ROWS):
+                _, _, z3p, coef3p = last
+            # (the output's address, not the output: the group is reachable from the output's grad_fn, and a reference cycle through it would
+            # keep the whole stage's activations alive until a garbage collection -- inside a graph capture, past the capture)
+            group.bn3_last = (out.data_ptr(), tuple(out.shape), z3, coef3) if BN3_PARTS_FROM_DGRAD else None
         ctx.wrefs = (w1, w3, ws, w2, sw1, sb1, sw2, sb2)   # identities under which the stage's DeferredGrads node returns the gradients
-        ctx.save_for_backward(x, z1, a, z2, z3, out, coef1, coef2, coef3, pooled, hid, gate, sw1, sw2, bg, zs, coefs)
+        ctx.save_for_backward(x, z1, a, z2, z3, out, coef1, coef2, coef3, pooled, hid, gate, sw1, sw2, bg, zs, coefs, z3p, coef3p)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, z1, a, z2, z3, out, coef1, coef2, coef3, pooled, hid, gate, sw1, sw2, bg, zs, coefs = ctx.saved_tensors
+        x, z1, a, z2, z3, out, coef1, coef2, coef3, pooled, hid, gate, sw1, sw2, bg, zs, coefs, z3p, coef3p = ctx.saved_tensors
         assert ctx.training, "backward through eval-mode BatchNorm is not part of the hot path"
         wt1, wd2, wt3, wts = ctx.packs
         stride = ctx.stride
@@ -237,7 +250,13 @@ class XBlockFn(torch.autograd.Function):
         dev = x.device
         grid = (n, ho, wo)
         # out = relu(bn3(z3) + shortcut): g = dout * [out > 0] is also the gradient of the shortcut branch
-        dz3, dg3, db3, g = bn_backward_fused(dout, z3, out, coef3, ACT_RELU, m, want_g=True)
+        parts3 = None
+        handed = getattr(ctx.group, "bn3_parts", None) if ctx.group is not None else None
+        if handed is not None:                                # (dx, pg, pgx) of the next block's last GEMM: valid iff that dx IS this dout
+            ctx.group.bn3_parts = None
+            if handed[0].data_ptr() == dout.data_ptr() and handed[0].shape == dout.shape:
+                parts3 = handed[1:]
+        dz3, dg3, db3, g = bn_backward_fused(dout, z3, out, coef3, ACT_RELU, m, want_g=True, parts=parts3)
         make_bg = bg is None
         # SE gate-gradient partials sum_rows dbg * relu(bn2(z2)) from the GEMM's own epilogue (one partial row per pixel tile) where a
         # tile lies inside one image and an image has few tiles (the deep stages); otherwise by a pass over (dbg, z2) below
@@ -308,7 +327,10 @@ class XBlockFn(torch.autograd.Function):
             else:
                 dws = k_gemm_tn(x, None, 0 if stride == 1 else 1, grid, dzs, c, kp32(cin), 1, cin, defer=batch)
         dx = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and z3p is not None:
+            dx, pg3, pgx3 = k_gemm_nt(dz1, None, 0, (n, h, w), wt1, cin, kp32(c), 1, addend=addend, estat=(3, z3p, coef3p, x))
+            group.bn3_parts = (dx, pg3, pgx3)
+        elif ctx.needs_input_grad[0]:
             dx, _, _ = k_gemm_nt(dz1, None, 0, (n, h, w), wt1, cin, kp32(c), 1, addend=addend, add_s2=add_s2)
         if group is not None:
             dw1 = group.add(w1_, x, dz1, 0, (n, h, w), cin, c)

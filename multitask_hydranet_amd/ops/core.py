@@ -323,7 +323,13 @@ def k_gemm_nt(x0, x1, mode, grid, wp, nout, kp, taps, bias=None, act=ACT_NONE, o
         psq = torch.empty((pr, nout), device=dev, dtype=F32) if (estat is None or estat[0] != 1) else None
     if estat is not None:
         assert xform is None and not add_pre
-        emode, ez, ecoef = estat
+        emode, ez, ecoef = estat[:3]
+        if emode == 3:                                          # (3, ez, ecoef, ey): the previous XBlock's BN3-backward reduce pass
+            ey = estat[3]
+            assert mode == 0 and taps == 1 and addend is not None and not add_s2 and x1 is None and not out_f32
+            lib().call("hn_conv_gemm_nt_stat3", ptr(x0), ld(x0), m, c0, ptr(wp), nout, kp, ptr(out), ldc, ptr(psum), ptr(psq), ptr(addend),
+                       ld(addend), ptr(ez), ld(ez), ptr(ey), ld(ey), ptr(ecoef))
+            return out, psum, psq
         lib().call("hn_conv_gemm_nt_stat", ptr(x0), ptr(x1), mode, n, h, w, c0, c1, ld(x0), ld(x1) if x1 is not None else 0, up, m,
                    ptr(wp), nout, kp, taps, ptr(bias), act, ptr(out), 0, ldc, rpi, img_stride, ptr(psum), ptr(psq), ptr(addend),
                    ld(addend) if addend is not None else 0, 1 if add_s2 else 0, emode, ptr(ez), ld(ez), ptr(ecoef))

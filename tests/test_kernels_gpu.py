@@ -1041,6 +1041,91 @@ def test_backbone_with_epilogue_reductions_equals_reduce_passes(K):
         close(g1[k], g0[k], 5e-3, k)
 
 
+@pytest.mark.parametrize("n,h,w,c,ck", [(16, 16, 32, 376, 376), (16, 8, 16, 936, 936), (2, 8, 8, 152, 96), (1, 5, 13, 72, 72)])
+def test_next_blocks_dgrad_gemm_makes_the_batchnorm3_backward_partials(K, n, h, w, c, ck):
+    """hn_conv_gemm_nt_stat3 (GemmNT::emode 3): dx = dz1 W1 + g, and the statistics rows = the reduce pass of the previous block's masked
+    BatchNorm backward over that dx: (sum g', sum g' xhat), g' = dx [y > 0].  The output is bit-identical to the launch without the
+    operand; the sums are checked against fp64 sums over the kernel's own bf16 output (1e-5 of the column's absolute sum) and against
+    hn_bn_bwd_reduce_fused's partials; K = 936 runs the two-K-group form, the 5 x 13 grid a ragged last pixel tile."""
+    torch.manual_seed(c + h)
+    m = n * h * w
+    z = nhwc(rnd(n, c, h, w))
+    y = nhwc(rnd(n, c, h, w))
+    coef = torch.stack([torch.rand(c, device=dev()) + 0.5, torch.randn(c, device=dev()) * 0.3, torch.randn(c, device=dev()) * 0.2,
+                        torch.rand(c, device=dev()) + 0.5]).contiguous()
+    dz = nhwc(rnd(n, ck, h, w, scale=0.1))
+    g = nhwc(rnd(n, c, h, w, scale=0.1))
+    _, wt = K.pack_conv_weight(rnd(ck, c, 1, 1, scale=0.05))
+    args = (dz, None, 0, (n, h, w), wt, c, K.kp32(ck), 1)
+    plain, _, _ = K.k_gemm_nt(*args, addend=g)
+    out, ps, pq = K.k_gemm_nt(*args, addend=g, estat=(3, z, coef, y))
+    assert torch.equal(out, plain)
+    assert ps.shape == ((m + 63) // 64, c) == pq.shape
+    q = out.double().view(m, c)
+    gm = torch.where(y.view(m, c) > 0, q, torch.zeros_like(q))
+    xh = ((z.float().view(m, c) - coef[2]) * coef[3]).double()
+    for got, want, scale in [(ps.double().sum(0), gm.sum(0), gm.abs().sum(0)), (pq.double().sum(0), (gm * xh).sum(0), (gm * xh).abs().sum(0))]:
+        assert float(((got - want).abs() / (scale + 1e-6)).max()) < 1e-5
+    # the pass it replaces
+    rb = K.lib().query("hn_fused_row_block", m, c, 0, 0, 1)
+    pr = (m + rb - 1) // rb
+    pg, pgx = torch.empty((pr, c), device=dev()), torch.empty((pr, c), device=dev())
+    K.lib().call("hn_bn_bwd_reduce_fused", K.ptr(out), K.ld(out), K.ptr(z), K.ld(z), K.ptr(y), K.ld(y), K.ptr(coef), K.ACT_RELU, None, None,
+                 0, m, c, rb, K.ptr(pg), K.ptr(pgx))
+    for got, want, scale in [(ps.double().sum(0), pg.double().sum(0), gm.abs().sum(0)), (pq.double().sum(0), pgx.double().sum(0), (gm * xh).abs().sum(0))]:
+        assert float(((got - want).abs() / (scale + 1e-6)).max()) < 1e-5
+
+
+def test_backbone_with_batchnorm3_partials_from_the_next_block_equals_reduce_passes(K):
+    """ops.BN3_PARTS_FROM_DGRAD (an identity XBlock's last backward GEMM makes the previous block's BatchNorm-3 backward sums) vs the
+    separate reduce passes on the big cfg's backbone: same forward; the hand-over is taken once per identity block of stages 2..4.  The sums
+    themselves are pinned by the kernel test above (1e-5 against hn_bn_bwd_reduce_fused); this test pins the WIRING (whose z3 / coefficients /
+    mask reach which block).  A different summation order flips bf16 roundings of dz3, and 30 randomly initialised blocks with batch
+    statistics over 256..8192 samples amplify that: tools/scratch/bn3_parts_err.py shows the same 1e-3 (last blocks) .. 3e-2 (stem) of the
+    gradient's maximum for EPILOGUE_STATS on/off.  So: the last block is untouched (bit-equal), the block before it sees only the direct
+    effect (5e-3), everything else 8e-2 (a wrong operand gives O(1))."""
+    from multitask_hydranet_amd import HydraNet
+    from multitask_hydranet_amd.ops import backbone as B
+    from tests.helpers import load_cfg
+    cfgs = load_cfg("hydranet_big.yml")
+    torch.manual_seed(6)
+    net = HydraNet(cfgs).cuda().train()
+    x = torch.randn(2, 3, 512, 1024, device=dev())             # stage 4: 8 x 16 pixels per image, the smallest grid of the fused node
+    res, taken = [], []
+    real = B.k_gemm_nt
+
+    def counting(*a, **kw):
+        if kw.get("estat") is not None and kw["estat"][0] == 3:
+            taken[-1] += 1
+        return real(*a, **kw)
+
+    for on in (False, True):
+        K.BN3_PARTS_FROM_DGRAD = on
+        B.k_gemm_nt = counting
+        taken.append(0)
+        try:
+            net.zero_grad(set_to_none=True)
+            sd = {k: v.clone() for k, v in net.state_dict().items()}
+            feats = net._backbone(x)
+            net._flush_nbt()
+            loss = sum((f.float() ** 2).mean() for f in feats)
+            loss.backward()
+            res.append(([f.detach().clone() for f in feats], {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}))
+            net.load_state_dict(sd)
+        finally:
+            K.BN3_PARTS_FROM_DGRAD = True
+            B.k_gemm_nt = real
+    assert taken == [0, 9 + 13 + 3], taken                    # stage depths (1, 1, 4, 10, 14): the identity blocks of stages 2..4 (>64 ch)
+    (f0, g0), (f1, g1) = res
+    assert all(torch.equal(a, b) for a, b in zip(f0, f1))
+    assert g0.keys() == g1.keys()
+    for k in g0:
+        if "stage_4.blocks.block_13." in k:
+            assert torch.equal(g1[k], g0[k]), k
+        else:
+            close(g1[k], g0[k], 5e-3 if "stage_4.blocks.block_12." in k else 8e-2, k)
+
+
 @pytest.mark.parametrize("wd", [0.0, 1e-2])
 def test_hip_adam_tracks_torch_adam(K, wd):
     """multitask_hydranet_amd.optim.Adam (one launch for all parameters) against torch.optim.Adam: same update rule and operation order;
