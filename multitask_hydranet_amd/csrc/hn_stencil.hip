@@ -72,6 +72,47 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* x, const flo
         }
     }
     const long pix = (n * Ho + oy) * (long)Wo + ox;
+    // Whole blocks of an even-width grid own 512 consecutive pixels (pix = 2 idx): rows leave through LDS so that every store instruction
+    // of a wave writes 1 KB of consecutive addresses.  (Thread-owned rows put the 64 lanes of a 16-byte store on 64 different 128-byte
+    // lines: 16 such instructions per thread = 1 024 partial-line writes per wave where 128 full ones do.)
+    if (!(Wo & 1) && ((long)bidx + 1) * 256 <= total) {
+        const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+        const long wbase = (((long)bidx * 256 + wv * 64) * 2) * 32;      // the wave's first element of z / patches
+        if (prow) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int t = 27; t < 32; ++t) prow[h * PH + t] = f2bf(0.f);
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int P = j * 64 + ln, t = P >> 3, h = (P >> 2) & 1, q = P & 3;
+                const bf16* src = sp[h][wv * 64 + t] + q * 8;
+                const bf16x4 lo = *reinterpret_cast<const bf16x4*>(src), hi = *reinterpret_cast<const bf16x4*>(src + 4);
+                bf16x8 v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                st8(patches + wbase + (long)P * 8, v8);
+            }
+            __syncthreads();
+        }
+        // z rows: 128 bytes per thread, the eight 16-byte pieces XOR-swizzled by (thread >> 1) & 7 (writes and reads conflict free)
+        char* sz = reinterpret_cast<char*>(&sp[0][0][0]);
+        const int sw8 = (threadIdx.x >> 1) & 7;
+#pragma unroll
+        for (int q8 = 0; q8 < 8; ++q8) {
+            bf16x8 v8;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v8[k] = f2bf(acc[q8 >> 2][(q8 & 3) * 8 + k]);
+            *reinterpret_cast<bf16x8*>(sz + threadIdx.x * 128 + ((q8 ^ sw8) << 4)) = v8;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int P = j * 64 + ln, T = wv * 64 + (P >> 3), q8 = P & 7;
+            const bf16x8 v8 = *reinterpret_cast<const bf16x8*>(sz + T * 128 + ((q8 ^ ((T >> 1) & 7)) << 4));
+            st8(z + wbase + (long)P * 8, v8);
+        }
+        return;
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         if (h == 1 && !two) break;

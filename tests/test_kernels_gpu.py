@@ -149,8 +149,10 @@ def test_grouped_conv_bn_relu(K, c, stride, n, h, w):
     g.grad = b.grad = None
 
 
-def test_stem(K):
-    n, h, w = 2, 16, 24
+@pytest.mark.parametrize("n,h,w", [(2, 16, 24), (2, 64, 128), (1, 34, 68), (3, 18, 22)])
+def test_stem(K, n, h, w):
+    """(2, 64, 128): whole 256-thread blocks only (rows staged through LDS, 1 KB per store instruction); (1, 34, 68): one whole block + a
+    ragged one (thread-owned rows); (3, 18, 22): odd output width (pixel pairs straddle nothing, the last thread of a row owns one pixel)"""
     x = torch.randn(n, 3, h, w, device=dev())
     wt = torch.randn(32, 3, 3, 3, device=dev()) * 0.2
     g, b, rm, rv, nbt = bn_tuple(32)
