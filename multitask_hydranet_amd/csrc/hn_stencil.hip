@@ -1279,6 +1279,104 @@ __global__ __launch_bounds__(256) void fuse_bwd_kernel(const FuseBwd q) {
     if (threadIdx.x < 3) q.pw[bidx * 3 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
+// The top-down nodes (ONE identity input + ONE nearest-up input with a low-resolution destination: every top-down node of net/bifpn.py:
+// 185-199) in their own kernel: the generic loop above walks the four pixels of a quad one after the other, each a load -> swish' -> store
+// chain of its own, i.e. three or four 16-byte loads in flight per thread.  Here every load of the quad (4 x dout, 4 x the identity input,
+// 4 x its accumulated destination, the low-resolution pixel and its destination) is issued before the first use: up to 14 loads in
+// flight per thread.  Same arithmetic in the same order (inputs are summed in index order).
+// 136 VGPRs = three workgroups per CU; held to 128 (four) it spills six registers and measures the same.  With it the 2 x 2 sums are
+// worth folding: 863 -> 869 img/s against the separate hn_sum2x2 launches (the generic quad walk: 861).
+__global__ __launch_bounds__(256) void fuse_bwd_quads_kernel(const FuseBwd q) {
+    const int bidx = xcd_remap(blockIdx.x, gridDim.x);     // row-order placement convention (hn_common.h)
+    const Fuse& p = q.f;
+    const int C8 = p.C >> 3;
+    int ia = 0, ib = 0;                                    // the identity and the up-sampled input
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { if (p.mode[i] == 1) ia = i; if (p.mode[i] == 2) ib = i; }
+    const bool a_first = ia < ib;
+    const float wa = p.w[ia], wb = p.w[ib];
+    const bf16* ina = p.in[ia]; const int lda = p.ld[ia];
+    const bf16* inb = p.in[ib]; const int ldb = p.ld[ib];
+    bf16* da = q.din[ia]; const int ldda = q.ldin[ia]; const bool acca = da && q.acc[ia];
+    bf16* db = q.din[ib]; const int lddb = q.ldin[ib]; const bool accb = q.acc[ib];
+    const int Wq = p.W >> 1, Hq = p.H >> 1;
+    const long total = (long)p.N * Hq * Wq * C8;
+    float dwa = 0.f, dwb = 0.f;
+    for (long idx = (long)bidx * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int cg = (int)(idx % C8);
+        long t = idx / C8;
+        const int xq = (int)(t % Wq);
+        t /= Wq;
+        const int yq = (int)(t % Hq);
+        const long n = t / Hq;
+        const long orow0 = (n * p.H + 2 * yq) * (long)p.W + 2 * xq, lrow = (n * Hq + yq) * (long)Wq + xq;
+        bf16x8 rd[4], ra[4], rprev[4], rup, rprev_up;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) rd[s] = ld8(q.dout + (orow0 + (s >> 1) * p.W + (s & 1)) * q.ldd + cg * 8);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) ra[s] = ld8(ina + (orow0 + (s >> 1) * p.W + (s & 1)) * lda + cg * 8);
+        rup = ld8(inb + lrow * ldb + cg * 8);
+        if (acca) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) rprev[s] = ld8(da + (orow0 + (s >> 1) * p.W + (s & 1)) * ldda + cg * 8);
+        }
+        bf16* dup = db + lrow * lddb + cg * 8;
+        if (accb) rprev_up = ld8(dup);
+        float qsum[8], vb[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { qsum[k] = 0.f; vb[k] = bf2f(rup[k]); }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const long orow = orow0 + (s >> 1) * p.W + (s & 1);
+            float gg[8];
+            bf16x8 go;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float va = bf2f(ra[s][k]);
+                const float pre = a_first ? fmaf(wb, vb[k], fmaf(wa, va, 0.f)) : fmaf(wa, va, fmaf(wb, vb[k], 0.f));
+                gg[k] = bf2f(rd[s][k]) * act_bwd(pre, HN_ACT_SWISH);
+                go[k] = f2bf(gg[k]);
+                qsum[k] += bf2f(go[k]);
+                dwa = fmaf(gg[k], va, dwa);
+                dwb = fmaf(gg[k], vb[k], dwb);
+            }
+            st8(q.g + orow * q.ldg + cg * 8, go);
+            if (da) {
+                bf16x8 o;
+                if (acca) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) o[k] = f2bf(fmaf(wa, gg[k], bf2f(rprev[s][k])));
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) o[k] = f2bf(wa * gg[k]);
+                }
+                st8(da + orow * ldda + cg * 8, o);
+            }
+        }
+        bf16x8 o;
+        if (accb) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = f2bf(fmaf(qsum[k], wb, bf2f(rprev_up[k])));
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = f2bf(qsum[k] * wb);
+        }
+        st8(dup, o);
+    }
+    __shared__ float red[4][3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float dw[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dw[i] = i == ia ? dwa : (i == ib ? dwb : 0.f);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float sm = wave_sum(dw[i]);
+        if (lane == 0) red[wave][i] = sm;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) q.pw[bidx * 3 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // fold of the seg decoder's padded-domain dgrad: dvp [N][H+2][W+2][ldv] (channels c0..c0+C) ->
 //   up = 0: out[n, y, x, :]  = sum over padded positions reflecting onto (y, x)
@@ -1707,7 +1805,7 @@ extern "C" int hn_fuse_fwd_raw(const void* const* in, const int* ld, const int* 
 }
 extern "C" int hn_fuse_bwd_blocks(int N, int H, int W, int C) {
     long b = ((long)N * H * W * (C >> 3) + 255) / 256;
-    if (b > 768) b = 768;                  // three workgroups per CU are resident (141 VGPRs): one round, no quarter-full second one
+    if (b > 1024) b = 1024;                  // four workgroups per CU (92 VGPRs: five fit); swept 768 .. uncapped on the step: 1024 +0.6 %, 1280 / 1152 / uncapped +-0
     return (int)(b < 1 ? 1 : b);
 }
 // pw: fp32 [hn_fuse_bwd_blocks][3]; reduce with hn_rows_reduce(pw, dw, 1, blocks, 3, 1)
@@ -1720,7 +1818,12 @@ extern "C" int hn_fuse_bwd(const void* const* in, const int* ld, const int* mode
     if (rc) return rc;
     q.dout = (const bf16*)dout; q.ldd = ldd; q.g = (bf16*)g; q.ldg = ldg; q.pw = pw;
     for (int i = 0; i < 3; ++i) { q.din[i] = (bf16*)din[i]; q.ldin[i] = ldin[i]; q.acc[i] = acc ? acc[i] : 0; q.arg[i] = nullptr; }
-    hipLaunchKernelGGL(fuse_bwd_kernel, dim3(hn_fuse_bwd_blocks(N, H, W, C)), dim3(256), 0, st, q);
+    int n_id = 0, n_up = 0, n_pool = 0, up_dst = 0;
+    for (int i = 0; i < 3; ++i) { n_id += mode[i] == 1; n_up += mode[i] == 2; n_pool += mode[i] == 3; up_dst += mode[i] == 2 && q.din[i]; }
+    if (n_id == 1 && n_up == 1 && up_dst == 1 && n_pool == 0 && !(H & 1) && !(W & 1))        // a top-down node: every load of a quad in flight at once
+        hipLaunchKernelGGL(fuse_bwd_quads_kernel, dim3(hn_fuse_bwd_blocks(N, H, W, C)), dim3(256), 0, st, q);
+    else
+        hipLaunchKernelGGL(fuse_bwd_kernel, dim3(hn_fuse_bwd_blocks(N, H, W, C)), dim3(256), 0, st, q);
     HN_LAUNCH_CHECK();
 }
 /* hn_fuse_bwd that also writes, for every mode-3 (max-pooled) input i with arg_out[i] != NULL, the arg-max bytes of its pooling windows
@@ -1737,7 +1840,12 @@ extern "C" int hn_fuse_bwd_arg(const void* const* in, const int* ld, const int* 
         q.din[i] = (bf16*)din[i]; q.ldin[i] = ldin[i]; q.acc[i] = acc ? acc[i] : 0;
         q.arg[i] = mode[i] == 3 ? (unsigned char*)arg_out[i] : nullptr;
     }
-    hipLaunchKernelGGL(fuse_bwd_kernel, dim3(hn_fuse_bwd_blocks(N, H, W, C)), dim3(256), 0, st, q);
+    int n_id = 0, n_up = 0, n_pool = 0, up_dst = 0;
+    for (int i = 0; i < 3; ++i) { n_id += mode[i] == 1; n_up += mode[i] == 2; n_pool += mode[i] == 3; up_dst += mode[i] == 2 && q.din[i]; }
+    if (n_id == 1 && n_up == 1 && up_dst == 1 && n_pool == 0 && !(H & 1) && !(W & 1))        // a top-down node: every load of a quad in flight at once
+        hipLaunchKernelGGL(fuse_bwd_quads_kernel, dim3(hn_fuse_bwd_blocks(N, H, W, C)), dim3(256), 0, st, q);
+    else
+        hipLaunchKernelGGL(fuse_bwd_kernel, dim3(hn_fuse_bwd_blocks(N, H, W, C)), dim3(256), 0, st, q);
     HN_LAUNCH_CHECK();
 }
 

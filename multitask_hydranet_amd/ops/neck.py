@@ -162,10 +162,10 @@ def share(x, n):
     return Share.apply(x, slot, n), slot
 
 
-# HN_FUSE_SUM2X2=1: the 2x2 gradient sums of up-sampled fusion inputs inside hn_fuse_bwd (quad walk) instead of 12 hn_sum2x2 launches per
-# step.  Measured SLOWER (780.9 vs 783.9 img/s, same box): a thread then walks four pixels in sequence, and these launches are bound by
-# their dependent-load chains, not by their count -- off.
-FUSE_SUM2X2 = os.environ.get("HN_FUSE_SUM2X2", "0") == "1"
+# The 2x2 gradient sums of up-sampled fusion inputs inside hn_fuse_bwd instead of 12 hn_sum2x2 launches per step.  With the generic quad
+# walk (four pixels in sequence per thread) this measured SLOWER (861 vs 863 img/s); with fuse_bwd_quads_kernel, which issues every load of
+# a quad before the first use, 869.  HN_FUSE_SUM2X2=0: the separate launches.
+FUSE_SUM2X2 = os.environ.get("HN_FUSE_SUM2X2", "1") != "0"
 FUSE_ARG = os.environ.get("HN_FUSE_ARG", "1") != "0"      # the fusion backward kernel leaves the pooling arg-max bytes behind (0: hn_maxpool_bwd2's own pass)
 
 

@@ -246,9 +246,42 @@ def test_shared_gradient_slots(K, order):
         close(a, b, 1e-3, "fusion parameter gradients")
 
 
-@pytest.mark.parametrize("modes", [(1, 2, 0), (1, 1, 3), (1, 3, 0)])
-def test_bifpn_fuse(K, modes):
+@pytest.mark.parametrize("order", [0, 1])
+def test_shared_gradient_slots_of_top_down_nodes(K, order):
+    """fuse_bwd_quads_kernel with accumulating destinations: a map that is the identity input of one top-down node and the up-sampled input
+    of another (both through its GradSlot, either backward order) gets the gradient the autograd engine sums itself"""
+    n, c, h, w = 2, 24, 8, 12
+    x = rnd(n, c, h, w)
+    a_hi, lo = rnd(n, c, 2 * h, 2 * w), rnd(n, c, h // 2, w // 2)
+    ps = [torch.rand(2, device=dev()) + 0.2, torch.rand(2, device=dev()) + 0.2]
+    ups = [rnd(n, c, 2 * h, 2 * w), rnd(n, c, h, w)]
+
+    def run(shared):
+        xk = nhwc(x).requires_grad_(True)
+        (x0, x1), slot = K.share(xk, 2) if shared else ((xk, xk), None)
+        pk = [p.clone().requires_grad_(True) for p in ps]
+        nodes = [lambda: K.Fuse.apply(pk[0], 1, 2, 0, nhwc(a_hi), x0, None, (None, slot, None)),
+                 lambda: K.Fuse.apply(pk[1], 1, 2, 0, x1, nhwc(lo), None, (slot, None, None))]
+        outs = [None] * 2
+        for i in ([0, 1] if order == 0 else [1, 0]):
+            outs[i] = nodes[i]()
+        sum((o.float() * nhwc(u).float()).sum() for o, u in zip(outs, ups)).backward()
+        return xk.grad.float(), [p.grad.clone() for p in pk]
+
+    g_ref, pg_ref = run(False)
+    g, pg = run(True)
+    close(g, g_ref, 1e-2, "shared dx")
+    for a, b in zip(pg, pg_ref):
+        close(a, b, 1e-3, "fusion parameter gradients")
+
+
+@pytest.mark.parametrize("modes,sum_inside", [((1, 2, 0), True), ((1, 2, 0), False), ((1, 0, 2), True), ((1, 2, 1), True),
+                                              ((1, 1, 3), True), ((1, 3, 0), True)])
+def test_bifpn_fuse(K, modes, sum_inside):
+    """sum_inside (ops.FUSE_SUM2X2): the 2 x 2 gradient sums of the up-sampled input inside hn_fuse_bwd -- one identity + one up-sampled
+    input runs fuse_bwd_quads_kernel (the up-sampled one second or third), two identity inputs the generic quad walk; False: hn_sum2x2 launches"""
     n, c, h, w = 2, 16, 8, 12
+    K.FUSE_SUM2X2 = sum_inside
     shapes = {1: (h, w), 2: (h // 2, w // 2), 3: (2 * h, 2 * w)}
     ins = [rnd(n, c, *shapes[m]) if m else None for m in modes]
     nw = 3 if modes[2] else 2
@@ -278,6 +311,7 @@ def test_bifpn_fuse(K, modes):
         if m:
             close(nchw(ik[i].grad), ir[i].grad, GRAD_TOL, f"din{i}")
     close(pk.grad, pr.grad, GRAD_TOL, "dweights")
+    K.FUSE_SUM2X2 = True
 
 
 def test_se_gate(K):
