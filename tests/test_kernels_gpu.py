@@ -443,7 +443,8 @@ def test_pack_plan_matches_single_packs(K):
     dense 1x1 / 3x3 weights through the tiled transposing kernel (channel counts that are not multiples of 32: zero padding of both
     operand layouts), depthwise taps, grouped-conv stencil and block-diagonal operands, channel-slice and phase-form packs through the
     elementwise kernel."""
-    shapes = [(24, 32, 1), (152, 64, 1), (936, 368, 1), (65, 448, 1), (5, 64, 3), (256, 368, 3), (36, 112, 1), (64, 8, 3)]
+    shapes = [(24, 32, 1), (152, 64, 1), (936, 368, 1), (65, 448, 1), (5, 64, 3), (256, 368, 3), (36, 112, 1), (64, 8, 3),
+              (24, 30, 1), (7, 13, 3)]                 # rows that are not whole float4s: the element-wise loader
     ws = [rnd(co, ci, k, k) for co, ci, k in shapes]
     dw = [rnd(112, 1, 3, 3), rnd(36, 1, 3, 3)]
     gw = [rnd(24, 8, 3, 3), rnd(152, 8, 3, 3)]
