@@ -1889,6 +1889,52 @@ extern "C" int hn_head_grad(const float* dy, const float* y, long rpi, long img_
     HN_LAUNCH_CHECK();
 }
 
+// the same for ALL pyramid levels of a level-packed head output in one launch: dy / y rows of image n are the levels' pixels one after the
+// other ([N][sum H W][lds]); dz is the packed operand ([level][n][pixel], every level on an aligned row; the alignment rows are the caller's)
+__global__ __launch_bounds__(256) void head_grad_levels_kernel(const float* dy, const float* y, long img_stride, int lds_, int Nout, bf16* dz,
+                                                               int ldz, int N, int sigmoid, const Levels L) {
+    const int bidx = xcd_remap(blockIdx.x, gridDim.x);     // row-order placement convention (hn_common.h)
+    const long total = L.work_off[L.n];                    // real rows x (ldz / 8): a thread writes eight channels of a row (16 bytes)
+    const unsigned l8 = (unsigned)(ldz >> 3);
+    for (long idx = (long)bidx * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        int lv = 0;
+        unsigned pix0 = 0;                                 // pixels of an image before this level
+        while (lv + 1 < L.n && idx >= L.work_off[lv + 1]) { pix0 += (unsigned)(L.H[lv] * L.W[lv]); ++lv; }
+        const unsigned li = (unsigned)(idx - L.work_off[lv]);          // (< 2^32: host check)
+        const unsigned r = li / l8, c0 = (li - r * l8) * 8;
+        const unsigned hw = (unsigned)(L.H[lv] * L.W[lv]);
+        const unsigned n = r / hw, p = r - n * hw;
+        const long o = (long)n * img_stride + (long)(pix0 + p) * lds_ + c0;
+        bf16x8 v8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float v = 0.f;
+            if ((int)c0 + k < Nout) {
+                v = dy[o + k];
+                if (sigmoid) { const float sg = y[o + k]; v *= sg * (1.f - sg); }
+            }
+            v8[k] = f2bf(v);
+        }
+        st8(dz + (L.row_off[lv] + r) * ldz + c0, v8);
+    }
+}
+/* hn_head_grad for every level of a level-packed head at once (head_detect/detection.py:36-60: the towers run on the five pyramid levels
+ * with shared weights; their outputs are concatenated per image).  dy / y: fp32 [N][sum_l H_l W_l][lds]; dz: bf16, level l's N H_l W_l
+ * rows start at the row_align-aligned offset of the packing (hn_dwconv_fwd_levels); alignment rows are not written. */
+extern "C" int hn_head_grad_levels(const float* dy, const float* y, long img_stride, int lds_, int Nout, void* dz, int ldz, int N, int nlev,
+                                   const int* H, const int* W, int row_align, int sigmoid, hipStream_t st) {
+    HN_CHECK_ARG(dy && dz && Nout > 0 && ldz >= Nout && (ldz & 7) == 0 && N > 0 && (!sigmoid || y));
+    Levels L;
+    const int rc = fill_levels(L, N, nlev, H, W, row_align);
+    if (rc != HN_OK) return rc;
+    L.work_off[0] = 0;
+    for (int l = 0; l < L.n; ++l) L.work_off[l + 1] = L.work_off[l] + (long)N * L.H[l] * L.W[l] * (ldz >> 3);
+    HN_CHECK_ARG(L.work_off[L.n] < (1L << 32) && (reinterpret_cast<uintptr_t>(dz) & 15) == 0);
+    hipLaunchKernelGGL(head_grad_levels_kernel, dim3(ew_grid(L.work_off[L.n])), dim3(256), 0, st, dy, y, img_stride, lds_, Nout, (bf16*)dz, ldz, N,
+                       sigmoid, L);
+    HN_LAUNCH_CHECK();
+}
+
 extern "C" int hn_fuse_weights(const float* praw, int nw, float eps, float* wn, hipStream_t st) {
     HN_CHECK_ARG(praw && wn && nw >= 1 && nw <= 3);
     hipLaunchKernelGGL(fuse_weights_kernel, dim3(1), dim3(64), 0, st, praw, nw, eps, wn);

@@ -229,6 +229,7 @@ class PackLevels(torch.autograd.Function):
 
 
 TOWER_BN_IN_GEMM = os.environ.get("HN_TOWER_BN_IN_GEMM", "1") != "0"
+HEAD_GRAD_LEVELS = os.environ.get("HN_HEAD_GRAD_LEVELS", "1") != "0"     # head-output gradient operand of all five levels in one launch (0: one per level)
 _EVAL_COEF = {}             # id(gamma of level 0) -> (the 4 * nl BatchNorm tensors, their versions, eps, coef [nl, 4, cout])
 
 
@@ -375,12 +376,17 @@ class HeadOutPacked(torch.autograd.Function):
         total = x.shape[2]
         # alignment rows of a ragged packing must read as zeros in the bias / weight gradient sums and in the data gradient
         dz = zeros((1, 1, total, ldz), dev, BF16) if has_pad_rows(geom) else torch.empty((1, 1, total, ldz), device=dev, dtype=BF16)
-        off = 0
-        for v, h, w in zip(level_views(dz, geom), hs, ws):
-            base = off * ldc
-            lib().call("hn_head_grad", ptr(dout.view(-1)[base:]), ptr(yout.view(-1)[base:]) if yout is not None else None, h * w, img_stride,
-                       ldc, cout, ptr(v), ldz, n * h * w, 1 if act == ACT_SIGMOID else 0)
-            off += h * w
+        if HEAD_GRAD_LEVELS:                                  # all levels in one launch
+            nl, H, W, _, _ = _geom_arrays(geom)
+            lib().call("hn_head_grad_levels", ptr(dout), ptr(yout), img_stride, ldc, cout, ptr(dz), ldz, n, nl, ctypes.addressof(H),
+                       ctypes.addressof(W), LEVEL_ALIGN, 1 if act == ACT_SIGMOID else 0)
+        else:
+            off = 0
+            for v, h, w in zip(level_views(dz, geom), hs, ws):
+                base = off * ldc
+                lib().call("hn_head_grad", ptr(dout.view(-1)[base:]), ptr(yout.view(-1)[base:]) if yout is not None else None, h * w,
+                           img_stride, ldc, cout, ptr(v), ldz, n * h * w, 1 if act == ACT_SIGMOID else 0)
+                off += h * w
         dpw, dbias = k_gemm_tn(mid, None, 0, (1, 1, total), dz, cout, kp32(cin), 1, cin, want_bias=True)
         dmid, _, _ = k_gemm_nt(dz, None, 0, (1, 1, total), wt, cin, kp32(cout), 1, c0=ldz, c1=0)
         dx, ddw = k_dwconv_bwd(dmid, x, wf, geom, queue=ctx.queue, weight=ctx.wref)
