@@ -86,6 +86,12 @@ int hn_scale_weight_gate(const void* wp, const float* gate, void* out, int N, in
  * pointwise conv + BatchNorm + Swish instead of two. */
 int hn_conv_gemm_nt_lvl(const void* x0, int ld0, long M, int C0, const void* w, int Nout, int KP, const float* bias, int act, void* out,
                         int ldc, const float* coef, int nlev, const long* rows, hipStream_t stream);
+/* hn_conv_gemm_nt for level-packed plain rows whose fp32 output is the per-image concatenation of the pyramid levels (Regressor / Classifier,
+ * head_detect/detection.py:36-60: the same convs on every level, torch.cat along the anchor axis): row image * H_l W_l + pixel of level l ->
+ * out + image * img_stride + (sum_{k<l} H_k W_k + pixel) * ldc.  Levels start on row_align-aligned rows (a multiple of 128); alignment rows
+ * are not stored.  M = the packed tensor's rows.  One launch instead of one hn_conv_gemm_nt per level. */
+int hn_conv_gemm_nt_lvlout(const void* x0, int ld0, long M, int C0, const void* w, int Nout, int KP, const float* bias, int act, float* out,
+                           int ldc, long img_stride, int n_img, int nlev, const int* H, const int* W, int row_align, hipStream_t stream);
 
 /* hn_conv_gemm_nt with (a) an operand transform for modes 0/1 (bf16 output): the pixel operand is act(xscale[c]*x + xshift[c]) rounded to
  * bf16 and optionally multiplied by xgate[row / xhw][c] -- BatchNorm apply (+ReLU, + SE gate) of the producer folded into this conv's

@@ -163,6 +163,9 @@ struct GemmNT {
     // (acc + bias) + lcoef[l][1][c]) with l = the level of the pixel tile (levels start on 128-row boundaries: tile-uniform);
     // lcoef [ln][4][Nout] (scale, shift, -, -), lrow = cumulative rows per level
     const float* lcoef; int ln; long lrow[HN_MAX_LEVELS + 1];
+    // level-packed rows -> per-image concatenated output (generic epilogue only; lo_n = images, 0 = off): row r of level l (rows lrow[l]...,
+    // [image][pixel], alignment rows behind the real ones) is stored at image * img_stride + (lo_pix[l] + pixel) * ldc
+    int lo_n; unsigned lo_hw[HN_MAX_LEVELS]; unsigned lo_pix[HN_MAX_LEVELS];
     // Direct 3x3 kernel, mode 3 (data gradient on the padded (H+2) x (W+2) grid), staged bf16 epilogue: fold = 1 writes the INTERIOR of
     // the padded grid straight to the unpadded gradient out [N][H][W] (row stride ldc), multiplied by ELU'(fold_y) when the producer's
     // ELU output is given, and the one-pixel RING to ring [N][2 (W+2) + 2 H][Nout] (top row, bottom row, left column, right column);
@@ -617,6 +620,8 @@ __global__ __launch_bounds__(256 * KG) void gemm_nt_kernel(const GemmNT p) {
             }
         }
     } else {
+        int olv = 0;                                                  // (pixel tiles never straddle two levels: rows are multiples of 128)
+        if (p.lo_n) while (olv + 1 < p.ln && p_blk >= p.lrow[olv + 1]) ++olv;
 #pragma unroll
         for (int j = 0; j < TP; ++j) {
             const long pix = p_blk + wp * WP + j * 16 + (lane & 15);
@@ -625,6 +630,12 @@ __global__ __launch_bounds__(256 * KG) void gemm_nt_kernel(const GemmNT p) {
             if (p.rpi) {
                 const unsigned im = (unsigned)pix / (unsigned)p.rpi;
                 orow = (long)im * p.img_stride + (long)((unsigned)pix - im * (unsigned)p.rpi) * p.ldc;
+            }
+            if (p.lo_n) {
+                const unsigned rel = (unsigned)(pix - p.lrow[olv]), hw = p.lo_hw[olv];
+                const unsigned im = rel / hw;
+                if (im >= (unsigned)p.lo_n) continue;                 // an alignment row of the packing
+                orow = (long)im * p.img_stride + (long)(p.lo_pix[olv] + rel - im * hw) * p.ldc;
             }
 #pragma unroll
             for (int i = 0; i < TC; ++i) {
@@ -2861,8 +2872,8 @@ static thread_local NextFold g_next_fold = {nullptr, nullptr, 0};   // set by hn
 static thread_local long* g_next_amax = nullptr;    // set by hn_conv3x3_out_argmax for the launch it makes (same thread, same call)
 struct NextImgW { long stride; long rpi; };
 static thread_local NextImgW g_next_imgw = {0, 0};  // set by hn_conv_gemm_nt_imgw for the launch it makes
-struct NextLvl { const float* coef; int n; long row[HN_MAX_LEVELS + 1]; };
-static thread_local NextLvl g_next_lvl = {nullptr, 0, {0}};   // set by hn_conv_gemm_nt_lvl for the launch it makes
+struct NextLvl { const float* coef; int n; long row[HN_MAX_LEVELS + 1]; int nimg; unsigned hw[HN_MAX_LEVELS]; unsigned pix[HN_MAX_LEVELS]; };
+static thread_local NextLvl g_next_lvl = {nullptr, 0, {0}, 0, {0}, {0}};   // set by hn_conv_gemm_nt_lvl for the launch it makes
 static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img, int H, int W, int C0, int C1, int ld0, int ld1,
                              int up, long M, const void* w, int Nout, int KP, int taps, const float* bias, int act, void* out,
                              int out_f32, int ldc, long rpi, long img_stride, float* psum, float* psq, const float* xscale,
@@ -2896,7 +2907,7 @@ extern "C" int hn_conv_gemm_nt_imgw(const void* x0, int ld0, long M, int C0, con
 extern "C" int hn_conv_gemm_nt_lvl(const void* x0, int ld0, long M, int C0, const void* w, int Nout, int KP, const float* bias, int act,
                                    void* out, int ldc, const float* coef, int nlev, const long* rows, hipStream_t st) {
     HN_CHECK_ARG(coef && rows && nlev >= 1 && nlev <= HN_MAX_LEVELS);
-    NextLvl nl = {coef, nlev, {0}};
+    NextLvl nl = {coef, nlev, {0}, 0, {0}, {0}};
     for (int l = 0; l < nlev; ++l) {
         HN_CHECK_ARG(rows[l] > 0 && rows[l] % 128 == 0);
         nl.row[l + 1] = nl.row[l] + rows[l];
@@ -2906,6 +2917,33 @@ extern "C" int hn_conv_gemm_nt_lvl(const void* x0, int ld0, long M, int C0, cons
     const int rc = conv_gemm_nt_impl(x0, nullptr, 0, 1, 1, (int)(M < (1L << 30) ? M : 1), C0, 0, ld0, 0, 0, M, w, Nout, KP, 1, bias, act, out, 0, ldc, 0, 0,
                                      nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, 0, 0, 0, st);
     g_next_lvl.coef = nullptr;
+    return rc;
+}
+
+/* hn_conv_gemm_nt for level-packed plain rows (mode 0, one tap) whose fp32 output is the per-image concatenation of the levels
+ * (head_detect/detection.py:36-60: Regressor / Classifier run every pyramid level through the same convs and torch.cat the results along the
+ * anchor axis): row r = image * H_l W_l + pixel of level l is stored at out + image * img_stride + (sum_{k<l} H_k W_k + pixel) * ldc.
+ * The levels start on row_align-aligned rows (row_align a multiple of 128); alignment rows are not stored.  One launch instead of one per
+ * level. */
+extern "C" int hn_conv_gemm_nt_lvlout(const void* x0, int ld0, long M, int C0, const void* w, int Nout, int KP, const float* bias, int act,
+                                      float* out, int ldc, long img_stride, int n_img, int nlev, const int* H, const int* W, int row_align,
+                                      hipStream_t st) {
+    HN_CHECK_ARG(out && H && W && n_img > 0 && nlev >= 1 && nlev <= HN_MAX_LEVELS && row_align > 0 && row_align % 128 == 0);
+    NextLvl nl = {nullptr, nlev, {0}, n_img, {0}, {0}};
+    unsigned pix = 0;
+    for (int l = 0; l < nlev; ++l) {
+        HN_CHECK_ARG(H[l] > 0 && W[l] > 0);
+        const long real = (long)n_img * H[l] * W[l];
+        nl.row[l + 1] = nl.row[l] + (real + row_align - 1) / row_align * row_align;
+        nl.hw[l] = (unsigned)(H[l] * W[l]);
+        nl.pix[l] = pix;
+        pix += nl.hw[l];
+    }
+    HN_CHECK_ARG(nl.row[nlev] == M);
+    g_next_lvl = nl;
+    const int rc = conv_gemm_nt_impl(x0, nullptr, 0, 1, 1, (int)(M < (1L << 30) ? M : 1), C0, 0, ld0, 0, 0, M, w, Nout, KP, 1, bias, act, out, 1, ldc, 0,
+                                     img_stride, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, 0, 0, 0, st);
+    g_next_lvl.nimg = 0; g_next_lvl.n = 0;
     return rc;
 }
 
@@ -3047,8 +3085,12 @@ static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img
     g_next_imgw = {0, 0};
     p.lcoef = g_next_lvl.coef; p.ln = g_next_lvl.n;
     for (int l = 0; l <= HN_MAX_LEVELS; ++l) p.lrow[l] = g_next_lvl.row[l];
-    g_next_lvl.coef = nullptr;
+    p.lo_n = g_next_lvl.nimg;
+    for (int l = 0; l < HN_MAX_LEVELS; ++l) { p.lo_hw[l] = g_next_lvl.hw[l]; p.lo_pix[l] = g_next_lvl.pix[l]; }
+    g_next_lvl.coef = nullptr; g_next_lvl.nimg = 0;
     HN_CHECK_ARG(!p.lcoef || (mode == 0 && taps == 1 && !psum && !xscale));
+    // level-mapped output: the generic (fp32) epilogue only, plain rows
+    HN_CHECK_ARG(!p.lo_n || (mode == 0 && taps == 1 && out_f32 && !psum && !xscale && rpi == 0 && !addend && M < (1L << 32)));
     HN_CHECK_ARG(p.w_rpi == 0 || (mode == 0 && taps == 1 && !xscale && p.w_rpi % 128 == 0 && M < (1L << 32)));
     p.emode = g_next_stat.mode; p.ez = g_next_stat.z; p.ld_ez = g_next_stat.ldz; p.ecoef = g_next_stat.coef; p.ey = g_next_stat.y; p.ld_ey = g_next_stat.ldy;
     HN_CHECK_ARG(p.emode != 3 || (mode == 0 && taps == 1 && psum && psq && !out_f32 && addend && ld_add > 0 && !add_mode && (Nout & 7) == 0 &&

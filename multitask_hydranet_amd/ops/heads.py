@@ -229,6 +229,7 @@ class PackLevels(torch.autograd.Function):
 
 
 TOWER_BN_IN_GEMM = os.environ.get("HN_TOWER_BN_IN_GEMM", "1") != "0"
+HEAD_OUT_LEVELS = os.environ.get("HN_HEAD_OUT_LEVELS", "1") != "0"       # the heads' output conv of all five levels in one launch (0: one per level)
 HEAD_GRAD_LEVELS = os.environ.get("HN_HEAD_GRAD_LEVELS", "1") != "0"     # head-output gradient operand of all five levels in one launch (0: one per level)
 _EVAL_COEF = {}             # id(gamma of level 0) -> (the 4 * nl BatchNorm tensors, their versions, eps, coef [nl, 4, cout])
 
@@ -338,8 +339,8 @@ class TowerLayer(torch.autograd.Function):
 
 
 class HeadOutPacked(torch.autograd.Function):
-    """HeadOut on a level-packed input: depthwise, data gradient and all weight gradients run once for all levels; only the pointwise
-    GEMM forward (per-level output mapping into the [N, sum_l H_l*W_l*rep, k] concat) and its gradient gather stay per level."""
+    """HeadOut on a level-packed input: depthwise, pointwise GEMM (its epilogue maps the packed rows into the [N, sum_l H_l*W_l*rep, k]
+    concat: hn_conv_gemm_nt_lvlout), gradient gather (hn_head_grad_levels), data gradient and all weight gradients run once for all levels."""
 
     @staticmethod
     def forward(ctx, dw_weight, pw_weight, bias, k, act, geom, x):
@@ -353,10 +354,15 @@ class HeadOutPacked(torch.autograd.Function):
         ldc, img_stride = cout, rows_total * cout
         mid = k_dwconv_levels(x, wk, geom)
         off = 0
-        for v, h, w in zip(level_views(mid, geom), hs, ws):
-            k_gemm_nt(v, None, 0, (n, h, w), wp, cout, kp32(cin), 1, bias=bias, act=act, out=out.view(-1)[off * ldc:], out_f32=True, ldc=ldc,
-                      rpi=h * w, img_stride=img_stride)
-            off += h * w
+        if HEAD_OUT_LEVELS:                                   # all levels in one launch: the epilogue maps packed rows to the per-image layout
+            nl, H, W, _, _ = _geom_arrays(geom)
+            lib().call("hn_conv_gemm_nt_lvlout", ptr(mid), ld(mid), mid.shape[2], cin, ptr(wp), cout, kp32(cin), ptr(bias), act, ptr(out), ldc,
+                       img_stride, n, nl, ctypes.addressof(H), ctypes.addressof(W), LEVEL_ALIGN)
+        else:
+            for v, h, w in zip(level_views(mid, geom), hs, ws):
+                k_gemm_nt(v, None, 0, (n, h, w), wp, cout, kp32(cin), 1, bias=bias, act=act, out=out.view(-1)[off * ldc:], out_f32=True,
+                          ldc=ldc, rpi=h * w, img_stride=img_stride)
+                off += h * w
         ctx.meta = (k, act, ldc, img_stride, geom)
         ctx.packs = (wf, wt)
         ctx.queue, ctx.wref = (cur_queue() if dw_weight.requires_grad else None), dw_weight

@@ -1288,3 +1288,38 @@ def test_tower_pointwise_conv_with_level_batchnorm_epilogue(K):
         y = y * torch.sigmoid(y)
         close(out[0, 0, off:off + m].float(), y, ACT_TOL, f"level {l}")
         off += r
+
+
+@pytest.mark.parametrize("cout,act", [(36, 0), (10, 4), (72, 0)])       # 4 = sigmoid (the classifier)
+def test_head_output_conv_of_all_levels_in_one_launch(K, cout, act):
+    """hn_conv_gemm_nt_lvlout: level-packed rows (ragged: the levels are padded to 128-row boundaries with rows that must not be stored) ->
+    the per-image concatenation [N][sum_l H_l W_l][cout] in fp32, bit-identical to one hn_conv_gemm_nt per level with the per-image row
+    mapping (the path it replaces), and every element of the output written exactly by it (poisoned buffer)."""
+    import ctypes
+    n, c = 3, 64
+    hs, ws = (12, 6, 3, 2), (20, 10, 5, 3)
+    geom = (n, hs, ws)
+    nl, H, W, R, CNT = K._geom_arrays(geom)
+    total = sum(R)
+    x = torch.full((1, 1, total, c), 3.0, device="cuda", dtype=torch.bfloat16)     # alignment rows: garbage that must not leak
+    feats = [rnd(n, h, w, c) for h, w in zip(hs, ws)]
+    off = 0
+    for f, r in zip(feats, R):
+        x[0, 0, off:off + f.numel() // c] = f.reshape(-1, c).to(torch.bfloat16)
+        off += r
+    wt = rnd(cout, c, 1, 1, scale=c ** -0.5)
+    bias = rnd(cout, scale=0.1)
+    wp, _ = K.pack_conv_weight(wt)
+    rows_total = sum(h * w for h, w in zip(hs, ws))
+    ldc, img_stride = cout, rows_total * cout
+    out = torch.full((n, rows_total, cout), float("nan"), device="cuda")
+    K.lib().call("hn_conv_gemm_nt_lvlout", x.data_ptr(), c, total, c, wp.data_ptr(), cout, K.kp32(c), bias.data_ptr(), act, out.data_ptr(), ldc,
+                 img_stride, n, nl, ctypes.addressof(H), ctypes.addressof(W), K.LEVEL_ALIGN)
+    ref = torch.full((n, rows_total, cout), float("nan"), device="cuda")
+    off = 0
+    for v, h, w in zip(K.level_views(x, geom), hs, ws):
+        K.k_gemm_nt(v, None, 0, (n, h, w), wp, cout, K.kp32(c), 1, bias=bias, act=act, out=ref.view(-1)[off * ldc:], out_f32=True, ldc=ldc,
+                    rpi=h * w, img_stride=img_stride)
+        off += h * w
+    assert not torch.isnan(ref).any()
+    assert torch.equal(out, ref)
