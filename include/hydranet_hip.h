@@ -304,6 +304,11 @@ int hn_conv_gemm_tn_bias(const void* x0, const void* x1, int mode, int n_img, in
 int hn_head_grad(const float* dy, const float* y, long rpi, long img_stride, int lds, int Nout, void* dz, int ldz, long M, int sigmoid,
                  hipStream_t stream);
 
+/* Stacks the pyramid levels a shared-weight head runs on (head_detect/detection.py:36-60 loops over them) into the level-packed operand of
+ * the *_levels entry points: src[l] bf16 [N][H_l][W_l][C] (row stride ld[l]); level l's rows start at the row_align-aligned offset of dst
+ * (row stride ldd); alignment rows are not written. */
+int hn_pack_levels(const void* const* src, const int* ld, void* dst, int ldd, int N, int C, int nlev, const int* H, const int* W, int row_align,
+                   hipStream_t stream);
 /* hn_head_grad for every pyramid level of a level-packed head output in one launch: dy / y fp32 [N][sum_l H_l W_l][lds] (the per-image
  * concatenation of head_detect/detection.py:36-60), dz bf16 with level l's N*H_l*W_l rows at the row_align-aligned offsets of the packing
  * (as hn_dwconv_fwd_levels); alignment rows are not written. */

@@ -1935,6 +1935,40 @@ extern "C" int hn_head_grad_levels(const float* dy, const float* y, long img_str
     HN_LAUNCH_CHECK();
 }
 
+// pyramid levels [N][H_l][W_l][C] (row strides ld[l]) -> one level-packed tensor, every level on an aligned row: one launch for all levels
+struct PackSrc { const bf16* p[HN_MAX_LEVELS]; int ld[HN_MAX_LEVELS]; };
+__global__ __launch_bounds__(256) void pack_levels_kernel(const PackSrc src, bf16* dst, int ldd, int C8, const Levels L) {
+    const int bidx = xcd_remap(blockIdx.x, gridDim.x);     // row-order placement convention (hn_common.h)
+    const long total = L.work_off[L.n];                    // real rows x C / 8
+    for (long idx = (long)bidx * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        int lv = 0;
+        while (lv + 1 < L.n && idx >= L.work_off[lv + 1]) ++lv;
+        const unsigned li = (unsigned)(idx - L.work_off[lv]);
+        const unsigned r = li / (unsigned)C8, c = (li - r * (unsigned)C8) * 8;
+        st8(dst + (L.row_off[lv] + r) * ldd + c, ld8(src.p[lv] + (long)r * src.ld[lv] + c));
+    }
+}
+/* Stacks the pyramid levels a shared-weight head runs on (head_detect/detection.py:36-60 loops over them) into the level-packed operand
+ * of the *_levels entry points: src[l] bf16 [N][H_l][W_l][C] with row stride ld[l]; dst rows of level l start at the row_align-aligned
+ * offset; alignment rows are not written. */
+extern "C" int hn_pack_levels(const void* const* src, const int* ld, void* dst, int ldd, int N, int C, int nlev, const int* H, const int* W,
+                              int row_align, hipStream_t st) {
+    HN_CHECK_ARG(src && ld && dst && (C & 7) == 0 && (ldd & 7) == 0 && N > 0);
+    Levels L;
+    const int rc = fill_levels(L, N, nlev, H, W, row_align);
+    if (rc != HN_OK) return rc;
+    PackSrc ps;
+    L.work_off[0] = 0;
+    for (int l = 0; l < L.n; ++l) {
+        HN_CHECK_ARG(src[l] && (ld[l] & 7) == 0);
+        ps.p[l] = (const bf16*)src[l]; ps.ld[l] = ld[l];
+        L.work_off[l + 1] = L.work_off[l] + (long)N * L.H[l] * L.W[l] * (C >> 3);
+    }
+    HN_CHECK_ARG(L.work_off[L.n] < (1L << 32));
+    hipLaunchKernelGGL(pack_levels_kernel, dim3(ew_grid(L.work_off[L.n])), dim3(256), 0, st, ps, (bf16*)dst, ldd, C >> 3, L);
+    HN_LAUNCH_CHECK();
+}
+
 extern "C" int hn_fuse_weights(const float* praw, int nw, float eps, float* wn, hipStream_t st) {
     HN_CHECK_ARG(praw && wn && nw >= 1 && nw <= 3);
     hipLaunchKernelGGL(fuse_weights_kernel, dim3(1), dim3(64), 0, st, praw, nw, eps, wn);

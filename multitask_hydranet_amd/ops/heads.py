@@ -218,8 +218,16 @@ class PackLevels(torch.autograd.Function):
         geom = (n, tuple(f.shape[1] for f in feats), tuple(f.shape[2] for f in feats))
         total = packed_rows(geom)
         out = torch.empty((1, 1, total, c), device=feats[0].device, dtype=BF16)
-        for v, f in zip(level_views(out, geom), feats):
-            k_eltwise(2, f, alpha=1.0, out=v)
+        if PACK_LEVELS_ONE and all(f.stride(3) == 1 and f.stride(1) == f.shape[2] * f.stride(2) and f.stride(0) == f.shape[1] * f.stride(1)
+                                   for f in feats):
+            nl, H, W, _, _ = _geom_arrays(geom)                   # one launch for all levels
+            lds = (ctypes.c_int * nl)(*[ld(f) for f in feats])
+            srcs = _ptr_array(feats)                               # (kept alive across the call)
+            lib().call("hn_pack_levels", ctypes.addressof(srcs), ctypes.addressof(lds), ptr(out), ld(out), n, c, nl,
+                       ctypes.addressof(H), ctypes.addressof(W), LEVEL_ALIGN)
+        else:
+            for v, f in zip(level_views(out, geom), feats):
+                k_eltwise(2, f, alpha=1.0, out=v)
         ctx.geom = geom
         return out
 
@@ -229,6 +237,7 @@ class PackLevels(torch.autograd.Function):
 
 
 TOWER_BN_IN_GEMM = os.environ.get("HN_TOWER_BN_IN_GEMM", "1") != "0"
+PACK_LEVELS_ONE = os.environ.get("HN_PACK_LEVELS_ONE", "1") != "0"       # PackLevels: one copy launch for all levels (0: one per level)
 HEAD_OUT_LEVELS = os.environ.get("HN_HEAD_OUT_LEVELS", "1") != "0"       # the heads' output conv of all five levels in one launch (0: one per level)
 HEAD_GRAD_LEVELS = os.environ.get("HN_HEAD_GRAD_LEVELS", "1") != "0"     # head-output gradient operand of all five levels in one launch (0: one per level)
 _EVAL_COEF = {}             # id(gamma of level 0) -> (the 4 * nl BatchNorm tensors, their versions, eps, coef [nl, 4, cout])
