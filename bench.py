@@ -363,24 +363,29 @@ def infer_bench(args, net, cfgs, h, w, dev, rank, world):
 
 def other_exchange_form(run, net, cfgs, batch, dev, rank, world, payload, args, dt_primary, headline=None):
     """Time the captured step with the gradient exchange in its other form (the headline used `run.reducer.graph_overlap`) -> dict with both
-    forms' ms per step (max over ranks).  Every rank runs a watchdog: if the second capture / replay does not come back within
-    HN_BENCH_FORM_TIMEOUT seconds (default 120), the process ends with exit code 0 after rank 0 has printed the headline line with
-    exchange_forms.error set -- a wedged collective must not cost the driver its measurement."""
+    forms' ms per step (max over ranks).  Only with --both-exchange-forms.  Every rank runs a watchdog: if the second capture / replay does
+    not come back within HN_BENCH_FORM_TIMEOUT seconds (default 120), rank 0 prints the finished headline line with exchange_forms.error
+    set and EVERY rank ends with exit code 4 -- a wedged collective costs the driver neither its measurement nor a false success."""
     import threading
     primary = "graph_overlap" if run.reducer.graph_overlap else "in_line"
     other = "in_line" if primary == "graph_overlap" else "graph_overlap"
     res = {primary: {"ms_per_step": round(dt_primary / args.steps * 1e3, 3), "headline": True}}
     done = threading.Event()
-    fallback = {"armed": True, "line": headline}      # rank 0: the finished headline line (printed by the watchdog if this wedges)
+    lock = threading.Lock()                           # emit-or-exit is decided once, under the lock
+    state = {"armed": True, "line": headline}         # rank 0: the finished headline line (printed by the watchdog if this wedges)
 
     def watchdog():
-        if done.wait(float(os.environ.get("HN_BENCH_FORM_TIMEOUT", "120"))) or not fallback["armed"]:
+        if done.wait(float(os.environ.get("HN_BENCH_FORM_TIMEOUT", "120"))):
             return
-        if rank == 0 and fallback.get("line") is not None:
-            line = dict(fallback["line"])
-            line["exchange_forms"] = dict(res, **{other: {"error": "timed out (watchdog)"}})
-            emit(line)
-        os._exit(0)
+        with lock:
+            if not state["armed"]:
+                return
+            state["armed"] = False
+            if rank == 0 and state.get("line") is not None:
+                line = dict(state["line"])
+                line["exchange_forms"] = dict(res, **{other: {"error": "timed out (watchdog): exit code 4"}})
+                emit(line)
+            os._exit(4)
     th = threading.Thread(target=watchdog, daemon=True)
     th.start()
     try:
@@ -399,7 +404,8 @@ def other_exchange_form(run, net, cfgs, batch, dev, rank, world, payload, args, 
     except Exception as e:          # noqa: BLE001
         res[other] = {"error": repr(e)[:300]}
     finally:
-        fallback["armed"] = False
+        with lock:                  # (a watchdog that already took the lock ends the process before this returns)
+            state["armed"] = False
         done.set()
     return res
 
@@ -448,9 +454,7 @@ class TrainRun:
                 # (only RCCL collectives can be captured: the gloo test hook exchanges after the replay)
                 if self.reducer is not None and not exchange_after_replay and (backend == "nccl" or os.environ.get("HN_BENCH_TRY_CAPTURE") == "1"):
                     try:
-                        self.graph, self.static_loss = self._capture(with_hooks=True)
-                        self.reducer.adopt_bucket_grads()
-                        self.reducer.remove()
+                        self.graph, self.static_loss = self._capture(with_hooks=True)    # (.grad adopted, hooks removed by the recipe)
                         self.in_graph_exchange = self.reducer.captured
                     except Exception as e:              # noqa: BLE001  (an RCCL build that cannot be captured)
                         # a capture that failed half-way leaves PyTorch's graph bookkeeping unusable for a second capture in this process
@@ -506,39 +510,32 @@ class TrainRun:
 
     def _capture(self, with_hooks):
         """two eager warm-up steps on a side stream, then the capture on the same stream.  with_hooks: the reducer's autograd hooks stay
-        armed, so every bucket's gather + all-reduce is captured where its last gradient appears."""
+        armed, so every bucket's gather + all-reduce is captured where its last gradient appears (ddp.capture_exchange_step: the recipe
+        HydraTrainer(capture_step=True) runs at world size > 1)."""
         net, reducer = self.net, self.reducer
         s_ = capture_stream()                   # one stream for every warm-up and capture of this process
-        if reducer is not None:
-            reducer.set_capture_stream(s_)
+        zero = lambda: net.zero_grad(set_to_none=True)
+
+        def fwd_bwd():
+            l0 = self.fwd_bwd()
+            if os.environ.get("HN_BENCH_DEBUG") and not torch.cuda.is_current_stream_capturing():
+                print("rank", self.rank, "eager loss", float(l0.detach()), file=sys.stderr, flush=True)
+            return l0
+        if reducer is not None and with_hooks:
+            from multitask_hydranet_amd.ddp import capture_exchange_step
+            g, sl = capture_exchange_step(reducer, fwd_bwd, zero, s_, warmup=2)
+            return g, sl.detach()
         s_.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s_):
             for _ in range(2):
-                net.zero_grad(set_to_none=True)
-                l0 = self.fwd_bwd()
-                if reducer is not None and with_hooks:
-                    reducer.finish()
-                if os.environ.get("HN_BENCH_DEBUG"):
-                    print("rank", self.rank, "eager loss", float(l0.detach()), file=sys.stderr, flush=True)
+                zero()
+                fwd_bwd()
         torch.cuda.current_stream().wait_stream(s_)
         torch.cuda.synchronize()
-        if reducer is not None and with_hooks:
-            # The warm-up's collectives are complete, but the RCCL watchdog thread reaps their work objects on its own ~100 ms cadence: give
-            # it a few rounds before the capture starts.  A work object it polls while the stream its end event was recorded on is being
-            # captured makes hipEventQuery fail inside the watchdog, which aborts the process (the likely cause of one abort in ~40 runs of
-            # tests/test_train_gpu.py::test_rccl_gradient_exchange_world1_in_graph: the trace ended in WorkNCCL::isCompleted of the watchdog).
-            time.sleep(0.5)
-        net.zero_grad(set_to_none=True)
+        zero()
         g = torch.cuda.CUDAGraph()
-        # thread-local capture mode: the RCCL watchdog thread's event queries (N > 1) must not invalidate the capture
-        # The capture runs on the warm-up's stream: the reducer's hooks keep the AccumulateGrad nodes of the warm-up steps alive, and autograd
-        # runs such a node (and its post-accumulate hook, i.e. the bucket's gather + all-reduce) on the stream it was created on.  On
-        # another stream the exchange would be a fork/join of the graph, and a hipGraph with any fork replays every node slower
-        # (tools/graph_branch_probe.py; the training step: +1.0 ms for two 4-element kernels launched from the hooks).
         with torch.cuda.graph(g, stream=s_, capture_error_mode="thread_local"):
             sl = self.fwd_bwd()
-            if reducer is not None and with_hooks:
-                reducer.join_capture()
         return g, sl.detach()                   # (the value lives in graph memory; its autograd graph would pin AccumulateGrad nodes)
 
     def step(self):
@@ -715,8 +712,9 @@ def _free_port():
 def spawn_ranks(n):
     """`python bench.py --gpus N` (N > 1) started WITHOUT torch.distributed.run: start the N ranks as a CHILD process
     (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same arguments>), relay what it
-    prints (rank 0's JSON line stays the last line) and return its exit code.  Called before this process touches the GPU: no HIP call,
-    no torch.cuda.is_available() has run (device_count() does not initialise the runtime), and the child is a child, never an exec."""
+    prints (rank 0's JSON line stays the last line) and return its exit code.  Called before this process makes any HIP call of its own
+    (torch.cuda.device_count() below may initialise the runtime on builds without amdsmi -- harmless here: the ranks are started as a
+    CHILD process, never by exec)."""
     import subprocess
     have = torch.cuda.device_count()
     if have < n and os.environ.get("HN_BENCH_ONE_DEVICE") != "1":
@@ -768,6 +766,9 @@ def main():
                     "at world size 1 -- exercises the N > 1 code path on a single GPU")
     ap.add_argument("--grad-payload", default="fp32", choices=("fp32", "bf16"), help="gradient all-reduce payload type")
     ap.add_argument("--exchange-after-replay", action="store_true", help="do not capture the all-reduce inside the hipGraph")
+    ap.add_argument("--both-exchange-forms", action="store_true", help="N > 1 / --ddp-world1: after the headline, also capture and time the step with "
+                    "the exchange in its OTHER form (forked onto the side stream instead of in line); a second capture of RCCL collectives in "
+                    "one process, guarded by a watchdog (exit code 4 on a wedge)")
     ap.add_argument("--phase", default=None, choices=("lane", "det", "seg"), help="head-only fine-tuning phase (train.py:441-515)")
     args = ap.parse_args()
     h, w = (int(v) for v in args.res.split("x"))
@@ -851,7 +852,7 @@ def main():
     # the OTHER captured exchange form on the same ranks: in line on the capture stream (default) vs forked onto the side
     # stream (north_star's "overlapped with the next backward on a side HIP stream").  Timed after the headline so that it cannot disturb
     # it; a watchdog on every rank ends the process with the headline line if a second capture of RCCL collectives wedges.
-    both_forms = exchange and backend == "nccl" and run.in_graph_exchange and not args.no_extras
+    both_forms = exchange and backend == "nccl" and run.in_graph_exchange and args.both_exchange_forms
     if both_forms and rank != 0:
         other_exchange_form(run, net, cfgs, batch, dev, rank, world, payload, args, dt)
     grad_norm = None
@@ -890,7 +891,7 @@ def main():
             "config": {"workload": what + ", big cfg, fwd+loss+bwd", "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "resolution": "3x%dx%d" % (h, w), "parallelism": "dp%d" % world, "hipgraph": run.graph is not None,
                        "grad_allreduce": run.describe_exchange()},
-            **({"rccl_ranks": dist.get_world_size(), "per_rank_ms_per_step": per_rank_ms} if exchange else {}),
+            **({"dist_ranks": dist.get_world_size(), "dist_backend": backend, "per_rank_ms_per_step": per_rank_ms} if exchange else {}),
             "ms_optimizer_step": round(ms_opt, 3) if ms_opt is not None else None, "loss": round(loss_val, 4),
             **({"grad_norm": grad_norm} if grad_norm is not None else {}),
             "model_tflops": round(value * gflop_img / 1e3, 2),

@@ -58,7 +58,7 @@ int hn_pack_small_batched(const long* jobs, const int* block_job, long total_blo
  *           PADDED sizes); fold back with hn_seg_fold.
  *   mode 4: mode 2 with replicate (clamp) padding, no up-sampling / concat: the low-resolution form of a 3x3 reflect-pad conv over a
  *           nearest-x2 up-sampled map (reflection of the up-sampled index == clamping of the source index); used with 4-phase
- *           effective weights for the final seg conv (head_seg/segmentation.py:101-104), see hn_depth_to_space.  With out_f32 and
+ *           effective weights for the final seg conv (head_seg/segmentation.py:101-104).  With out_f32 and
  *           img_stride = -k (k = Nout / 4) the epilogue stores depth-to-space itself: out is fp32 [N][2H][2W][k].
  *   mode 5: grouped 3x3 conv, group width 8, stride 1, zero padding 1 (XBlock conv_block_2, net/anynet.py:34-38) on MFMA: cout tile t
  *           (64 couts = 8 groups) contracts only over input channels [64t, 64t+64) with block-diagonal weights from
@@ -137,10 +137,8 @@ int hn_conv_gemm_tn(const void* x0, const void* x1, int mode, int n_img, int H, 
 
 /* Stem: x NCHW fp32 [N,3,H,W], w fp32 [32][3][3][3] -> z NHWC bf16 [N,H/2,W/2,32] (conv 3x3 s2 p1, net/anynet.py:12,17).
  * patches (optional): bf16 im2col rows [N*H/2*W/2][32] (27 taps in weight order + 5 zeros) so that the weight gradient is one
- * hn_conv_gemm_tn(mode 0) call on MFMA; hn_stem_wgrad is the fp32 VALU alternative. */
+ * hn_conv_gemm_tn(mode 0) call on MFMA. */
 int hn_stem_fwd(const float* x, const float* w, void* z, void* patches, int N, int H, int W, hipStream_t stream);
-long hn_stem_wgrad_blocks(int N, int H, int W);
-int hn_stem_wgrad(const float* x, const void* dz, float* part, int N, int H, int W, hipStream_t stream);
 
 /* Grouped 3x3 conv, group width 8, pad 1, stride 1|2 (XBlock conv_block_2, net/anynet.py:34-35).
  * hn_gconv_pack: fp32 [C][8][3][3] -> wk[tap][i][G][o] and wd (o/i swapped; flip=1 also flips the taps for stride-1 dgrad).
@@ -192,8 +190,8 @@ int hn_sum2x2(const void* g, int ldg, void* out, int ldo, const float* wscale, i
 
 /* BiFPN fusion node out = swish(sum_i w[i]*T_i(in_i)) (net/bifpn.py:177-231); mode[i]: 0 absent, 1 same res, 2 nearest x2 of a
  * half-res map, 3 zero-pad-same max-pool of a double-res map.  w: 3 fp32 in device memory. */
-/* w = relu(p)/(sum relu(p)+eps) into wn[3] (net/bifpn.py:179-180), and its backward from the per-block partials of hn_fuse_bwd */
-int hn_fuse_weights(const float* praw, int nw, float eps, float* wn, hipStream_t stream);
+/* backward of w = relu(p)/(sum relu(p)+eps) (net/bifpn.py:179-180; the forward normalisation runs inside hn_fuse_fwd) from the per-block
+ * partials of hn_fuse_bwd */
 int hn_fuse_dweights(const float* pw, int blocks, const float* praw, int nw, float eps, float* dp, hipStream_t stream);
 int hn_fuse_fwd(const void* const* in, const int* ld, const int* mode, const float* w, void* out, int ldo, int N, int H, int W, int C,
                 hipStream_t stream);
@@ -233,9 +231,8 @@ int hn_seg_fold(const void* dvp, int ldv, int c0, void* out, int ldo, const void
                 hipStream_t stream);
 /* up = 2 selects the replicate-padding fold (backward of mode 4). */
 
-/* Pixel shuffles of the phase-decomposed final seg conv: in [N][h][w][(py*2+px)*k + o] (row stride ldi) -> out [N][2h][2w][k] fp32, and
- * the gradient gather fp32 [N][2h][2w][k] -> zero-padded bf16 [N][h][w][ldo]. */
-int hn_depth_to_space(const float* in, int ldi, float* out, int N, int h, int w, int k, hipStream_t stream);
+/* Pixel shuffle of the phase-decomposed final seg conv, gradient side: fp32 [N][2h][2w][k] -> zero-padded bf16 [N][h][w][ldo] with channel
+ * (py*2+px)*k + o (the forward shuffle is the output conv's own epilogue, mode 4 above). */
 int hn_space_to_depth(const float* dy, void* out, int ldo, int N, int h, int w, int k, hipStream_t stream);
 
 /* bf16 form: in [N][2h][2w][k] (row stride ldi) -> out [N][h][w][4k], phase-major channels (the operand layout of the phase-form convs);
@@ -422,7 +419,6 @@ int hn_eltwise(int op, const void* a, int lda, const void* b, int ldb, void* out
                hipStream_t stream);
 int hn_add_strided2(void* dx, int ldx, const void* dxs, int lds, int N, int Ho, int Wo, int C, hipStream_t stream);
 int hn_cast_f32_to_bf16_pad(const float* src, int lds, void* dst, int ldo, long M, int C, hipStream_t stream);
-int hn_cast_bf16_to_f32(const void* src, int lds, float* dst, int ldo, long M, int C, hipStream_t stream);
 
 /* ---- losses (hn_loss.hip) --------------------------------------------------------------------------------------------------- */
 

@@ -19,6 +19,15 @@ CSRC = os.path.join(_PKG, "csrc")
 # HN_TUNING=1 (tools/ only): a second build with -DHN_TUNING -- the kernels' ablation bits, in-kernel stamps and the never-shipped template
 # instantiations behind hn_debug_knob / hn_debug_* -- as libhydranet_hip_tuning.so.  The product library is built without any of it.
 TUNING = os.environ.get("HN_TUNING") == "1"
+# HN_TUNING=ab (tools/ab_*.sh): the PRODUCT library, but the policy switches below and HN_LIB_AB are read from the environment for same-box
+# A/B runs.  Without HN_TUNING the package reads no HN_* variable at all: every policy is the constant written in the source.
+AB = TUNING or os.environ.get("HN_TUNING") == "ab"
+
+
+def policy(name: str, default: str) -> str:
+    """value of a tuning / A-B policy switch: the environment's only under HN_TUNING=1 | ab (tools/), else `default`"""
+    return os.environ.get(name, default) if AB else default
+
 SO_PATH = os.path.join(_PKG, "libhydranet_hip_tuning.so" if TUNING else "libhydranet_hip.so")
 SOURCES = ["hn_gemm.hip", "hn_norm.hip", "hn_fused.hip", "hn_stencil.hip", "hn_loss.hip", "hn_post.hip"]
 
@@ -93,8 +102,8 @@ class _Lib:
             raise HipKernelError(
                 f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU / eager fallback for the HydraNet hot path)")
-        # HN_LIB_AB: tools-only hook for same-box A/B measurements of two builds (an alternate in-tree .so with the same ABI)
-        self._dll = ctypes.CDLL(os.environ.get("HN_LIB_AB") or SO_PATH)
+        # HN_LIB_AB (only under HN_TUNING=ab, tools/): same-box A/B measurements of two builds (an alternate in-tree .so with the same ABI)
+        self._dll = ctypes.CDLL(policy("HN_LIB_AB", "") or SO_PATH)
         self._sig = parse_header()
         self._fn = {}
         for name, (ret, args, has_stream) in self._sig.items():

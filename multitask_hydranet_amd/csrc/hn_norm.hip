@@ -628,15 +628,6 @@ __global__ void cast_pad_kernel(const float* src, int lds_, bf16* dst, int ldo, 
         dst[idx] = f2bf(c < C ? src[m * lds_ + c] : 0.f);
     }
 }
-__global__ void cast_f32_kernel(const bf16* src, int lds_, float* dst, int ldo, long M, int C) {
-    const long total = M * C;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const long m = idx / C;
-        const int c = (int)(idx - m * C);
-        dst[m * ldo + c] = bf2f(src[m * lds_ + c]);
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // SE excitation MLP on the pooled vectors (net/anynet.py:42-47): hid = relu(W1 p + b1), gate = sigmoid(W2 hid + b2).
 // One block per image; forward keeps hid and gate for the backward pass.
@@ -1072,12 +1063,6 @@ extern "C" int hn_add_strided2(void* dx, int ldx, const void* dxs, int lds_, int
 extern "C" int hn_cast_f32_to_bf16_pad(const float* src, int lds_, void* dst, int ldo, long M, int C, hipStream_t st) {
     HN_CHECK_ARG(src && dst && M > 0 && C > 0 && ldo >= C);
     hipLaunchKernelGGL(cast_pad_kernel, dim3(ew_grid(M * ldo)), dim3(256), 0, st, src, lds_, (bf16*)dst, ldo, M, C);
-    HN_LAUNCH_CHECK();
-}
-
-extern "C" int hn_cast_bf16_to_f32(const void* src, int lds_, float* dst, int ldo, long M, int C, hipStream_t st) {
-    HN_CHECK_ARG(src && dst && M > 0 && C > 0);
-    hipLaunchKernelGGL(cast_f32_kernel, dim3(ew_grid(M * C)), dim3(256), 0, st, (const bf16*)src, lds_, dst, ldo, M, C);
     HN_LAUNCH_CHECK();
 }
 

@@ -139,40 +139,6 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* x, const flo
     }
 }
 
-// stem wgrad partials: part[block][co*27 + t] = sum over the block's pixels of dz[pix][co] * x[n, ci, 2oy+ky-1, 2ox+kx-1]
-__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* x, const bf16* dz, float* part, int N, int H, int W, long ppb) {
-    const int Ho = H >> 1, Wo = W >> 1;
-    const long total = (long)N * Ho * Wo;
-    const int co = threadIdx.x & 31, tg = threadIdx.x >> 5;     // 8 tap groups: taps tg, tg+8, tg+16, tg+24 (<27)
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    const long p0 = (long)blockIdx.x * ppb;
-    long p1 = p0 + ppb;
-    if (p1 > total) p1 = total;
-    for (long pix = p0; pix < p1; ++pix) {
-        const int ox = (int)(pix % Wo);
-        const long t1 = pix / Wo;
-        const int oy = (int)(t1 % Ho);
-        const long n = t1 / Ho;
-        const float g = bf2f(dz[pix * 32 + co]);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int t = tg + 8 * k;
-            if (t < 27) {
-                const int ci = t / 9, r = t - ci * 9, ky = r / 3, kx = r - ky * 3;
-                const int iy = 2 * oy + ky - 1, ix = 2 * ox + kx - 1;
-                float v = 0.f;
-                if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[((n * 3 + ci) * H + iy) * (long)W + ix];
-                acc[k] = fmaf(g, v, acc[k]);
-            }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int t = tg + 8 * k;
-        if (t < 27) part[(long)blockIdx.x * 864 + co * 27 + t] = acc[k];
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // grouped 3x3 conv, group width 8, pad 1.  Packed weights wk[tap][i][G][8 o] (bf16): 16 B per (tap, i, group).
 //   out[n, oy, ox, g*8 + o] = sum_{tap, i} in[n, oy*s + ky - 1, ox*s + kx - 1, g*8 + i] * wk[tap][i][g][o]
@@ -1136,14 +1102,6 @@ __global__ __launch_bounds__(256) void fuse_fwd_kernel(const Fuse p) {
     }
 }
 
-// fast-attention weights of a fusion node: w = relu(p) / (sum relu(p) + eps)   (net/bifpn.py:179-180); wn always has 3 slots
-__global__ void fuse_weights_kernel(const float* praw, int nw, float eps, float* wn) {
-    if (threadIdx.x == 0) {
-        float r[3], sum = 0.f;
-        for (int i = 0; i < 3; ++i) { r[i] = i < nw ? fmaxf(praw[i], 0.f) : 0.f; sum += r[i]; }
-        for (int i = 0; i < 3; ++i) wn[i] = r[i] / (sum + eps);
-    }
-}
 // dp_i = [p_i > 0] * (dw_i - sum_j w_j dw_j) / (sum relu(p) + eps), dw = column sums of the per-block partials pw[blocks][3]
 __global__ __launch_bounds__(256) void fuse_dweights_kernel(const float* pw, int blocks, const float* praw, int nw, float eps, float* dp) {
     __shared__ float red[4][3];
@@ -1434,18 +1392,6 @@ __global__ __launch_bounds__(256) void seg_fold_kernel(const bf16* dvp, int ldv,
 // pixel shuffles for the phase-decomposed final seg conv (3x3 over a nearest-x2 up-sampled map == four 2x2-phase 3x3 convs on the
 // low-resolution map): in [N][h][w][(py*2+px)*k + o] <-> out [N][2h][2w][k]
 // ---------------------------------------------------------------------------------------------------------
-__global__ void depth_to_space_kernel(const float* in, int ldi, float* out, int N, int h, int w, int k) {
-    const long total = (long)N * 4 * h * w * k;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int o = (int)(idx % k);
-        long t = idx / k;
-        const int X = (int)(t % (2 * w));
-        t /= 2 * w;
-        const int Y = (int)(t % (2 * h));
-        const long n = t / (2 * h);
-        out[idx] = in[((n * h + (Y >> 1)) * (long)w + (X >> 1)) * ldi + ((Y & 1) * 2 + (X & 1)) * k + o];
-    }
-}
 __global__ void space_to_depth_kernel(const float* dy, bf16* out, int ldo, int N, int h, int w, int k) {
     const long total = (long)N * h * w * ldo;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -1541,23 +1487,6 @@ extern "C" int hn_stem_fwd(const float* x, const float* w, void* z, void* patche
     hipLaunchKernelGGL(stem_fwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, x, w, (bf16*)z, (bf16*)patches, N, H, W);
     HN_LAUNCH_CHECK();
 }
-extern "C" long hn_stem_wgrad_blocks(int N, int H, int W) {
-    const long total = (long)N * (H >> 1) * (W >> 1);
-    long blocks = total / 256;
-    if (blocks > 1024) blocks = 1024;
-    if (blocks < 1) blocks = 1;
-    return blocks;
-}
-// part: fp32 [hn_stem_wgrad_blocks][864]; reduce with hn_rows_reduce(part, dw, 1, blocks, 864, 1)
-extern "C" int hn_stem_wgrad(const float* x, const void* dz, float* part, int N, int H, int W, hipStream_t st) {
-    HN_CHECK_ARG(x && dz && part);
-    const long total = (long)N * (H >> 1) * (W >> 1);
-    const long blocks = hn_stem_wgrad_blocks(N, H, W);
-    const long ppb = (total + blocks - 1) / blocks;
-    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(blocks), dim3(256), 0, st, x, (const bf16*)dz, part, N, H, W, ppb);
-    HN_LAUNCH_CHECK();
-}
-
 extern "C" int hn_gconv_pack(const float* w, void* wk, void* wd, int C, int flip, hipStream_t st) {
     HN_CHECK_ARG(w && wk && C > 0 && (C & 7) == 0);
     const int G = C >> 3;
@@ -1860,11 +1789,6 @@ extern "C" int hn_seg_fold(const void* dvp, int ldv, int c0, void* out, int ldo,
     HN_LAUNCH_CHECK();
 }
 
-extern "C" int hn_depth_to_space(const float* in, int ldi, float* out, int N, int h, int w, int k, hipStream_t st) {
-    HN_CHECK_ARG(in && out && N > 0 && h > 0 && w > 0 && k > 0 && ldi >= 4 * k);
-    hipLaunchKernelGGL(depth_to_space_kernel, dim3(ew_grid((long)N * 4 * h * w * k)), dim3(256), 0, st, in, ldi, out, N, h, w, k);
-    HN_LAUNCH_CHECK();
-}
 extern "C" int hn_space_to_depth(const float* dy, void* out, int ldo, int N, int h, int w, int k, hipStream_t st) {
     HN_CHECK_ARG(dy && out && N > 0 && h > 0 && w > 0 && k > 0 && ldo >= 4 * k && (ldo & 7) == 0);
     hipLaunchKernelGGL(space_to_depth_kernel, dim3(ew_grid((long)N * h * w * ldo)), dim3(256), 0, st, dy, (bf16*)out, ldo, N, h, w, k);
@@ -1969,11 +1893,6 @@ extern "C" int hn_pack_levels(const void* const* src, const int* ld, void* dst, 
     HN_LAUNCH_CHECK();
 }
 
-extern "C" int hn_fuse_weights(const float* praw, int nw, float eps, float* wn, hipStream_t st) {
-    HN_CHECK_ARG(praw && wn && nw >= 1 && nw <= 3);
-    hipLaunchKernelGGL(fuse_weights_kernel, dim3(1), dim3(64), 0, st, praw, nw, eps, wn);
-    HN_LAUNCH_CHECK();
-}
 extern "C" int hn_fuse_dweights(const float* pw, int blocks, const float* praw, int nw, float eps, float* dp, hipStream_t st) {
     HN_CHECK_ARG(pw && praw && dp && blocks > 0 && nw >= 1 && nw <= 3);
     hipLaunchKernelGGL(fuse_dweights_kernel, dim3(1), dim3(256), 0, st, pw, blocks, praw, nw, eps, dp);

@@ -30,10 +30,13 @@ link busy while the backbone's backward (the longest part) is still running.
 from __future__ import annotations
 
 import os
-from typing import Iterable, List, Optional, Sequence
+import time
+from typing import Callable, Iterable, List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
+
+from ._lib import policy
 
 
 def _agree_on_avg(group, device) -> bool:
@@ -60,7 +63,7 @@ class GradReducer:
         a single GPU).  graph_overlap: inside a hipGraph capture, fork the exchange onto the side stream (True) or keep it in line on the
         capture stream (False, default: a linear graph replays faster than a forked one by more than the overlap hides)."""
         if graph_overlap is None:
-            graph_overlap = os.environ.get("HN_DDP_GRAPH_OVERLAP", "0") == "1"
+            graph_overlap = policy("HN_DDP_GRAPH_OVERLAP", "0") == "1"
         self.graph_overlap = bool(graph_overlap)
         self.group = group
         self.world = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
@@ -320,6 +323,7 @@ class GradReducer:
             return
         for bi, b in enumerate(self.buckets):
             b["pending"], b["work"], b["event"], b["keep"] = len(b["params"]), None, None, None
+            b["src"] = None                 # (static gradient tensors of an earlier captured step: the hooks gather from .grad again)
             for (n, p), off in zip(b["params"], b["offs"]):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
                 if self.active and self.payload_dtype == torch.float32:
@@ -349,6 +353,55 @@ class GradReducer:
         return "%d buckets (%s payload, %s, %.0f%% of the elements written in place by the backward kernels) %s" % (
             len(self.buckets), str(self.payload_dtype).replace("torch.", ""), "ncclAvg" if self._avg else "sum + scale",
             100.0 * self.direct_fraction(), how)
+
+
+def settle_collectives(device=None):
+    """Before a capture that follows eager collectives: wait until they are complete on the device, then give ProcessGroupNCCL's watchdog
+    thread time to reap their work objects (it polls on a fixed ~100 ms cadence and offers no handle to wait on).  A work object it still
+    polls with hipEventQuery while the stream its end event was recorded on is being captured aborts the process (seen once in ~40 runs
+    before this wait existed).  Collectives issued DURING a capture are never handed to the watchdog, so this is the only window."""
+    if torch.cuda.is_available():
+        torch.cuda.synchronize(device)
+    if dist.is_initialized():
+        time.sleep(0.35)                                    # > 3 watchdog rounds
+
+
+def capture_exchange_step(reducer: "GradReducer", fwd_bwd: Callable[[], torch.Tensor], zero_grad: Callable[[], None], stream,
+                          warmup: int = 2):
+    """One training iteration's forward + loss + backward WITH the gradient exchange as one hipGraph (the data-parallel form of
+    model/train.py:243-267 that bench.py times and HydraTrainer(capture_step=True) runs at world size > 1; RCCL only -- other backends'
+    collectives cannot be captured, see capture_plain_step):
+      * `warmup` eager iterations and the capture run on ONE stream: the reducer's hooks keep the AccumulateGrad nodes of earlier iterations
+        alive, and autograd runs such a node -- and its post-accumulate hook, i.e. the bucket's gather + all-reduce -- on the stream it was
+        created on; on any other stream the exchange becomes a fork of the graph (a hipGraph with a fork replays every node slower);
+      * gradients start from None inside the capture: the backward kernels then write into the bucket slots (ops.grad_out) or into
+        graph-private tensors the captured gather reads;
+      * after the capture the gather tables are uploaded and .grad points at the averaged buckets (adopt_bucket_grads); the hooks are
+        removed (a replay needs none).
+    -> (graph, fwd_bwd's return value: tensors of the graph's pool that every replay rewrites -- detach them before keeping them)."""
+    reducer.arm()
+    reducer.set_capture_stream(stream)
+    cur = torch.cuda.current_stream()
+    if cur != stream:
+        stream.wait_stream(cur)
+    with torch.cuda.stream(stream):
+        for _ in range(warmup):
+            zero_grad()
+            fwd_bwd()
+            reducer.finish()
+    if cur != stream:
+        cur.wait_stream(stream)
+    settle_collectives()
+    zero_grad()
+    g = torch.cuda.CUDAGraph()
+    # thread-local capture mode: helper threads (the autograd engine's allocator calls, the RCCL watchdog's event queries) must not
+    # invalidate the capture
+    with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
+        out = fwd_bwd()
+        reducer.join_capture()
+    reducer.adopt_bucket_grads()
+    reducer.remove()
+    return g, out
 
 
 def broadcast_state(module: torch.nn.Module, src: int = 0, group=None):

@@ -77,9 +77,10 @@ def spline_interp(*, lane: Sequence[dict], step_t=1) -> List[dict]:
 
 def iou_matrix(gt_lanes: Sequence[Sequence[dict]], pr_lanes: Sequence[Sequence[dict]], height: int, width: int, lane_width: int,
                device=None) -> np.ndarray:
-    """calc_iou (lane_metric.py:166-209) for every (ground truth, prediction) pair of one image, on the device"""
+    """calc_iou (lane_metric.py:166-209) for every (ground truth, prediction) pair of one image, on the device.  Any number of lanes (the
+    reference has no limit; a noisy early-epoch decode can keep more than the pair kernel's 32 x 32 block: it then runs per block)"""
     g, p = len(gt_lanes), len(pr_lanes)
-    assert 0 < g <= 32 and 0 < p <= 32, (g, p)
+    assert g > 0 and p > 0, (g, p)
     dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
     pts, seg_lane, seg_first = [], [], []
     for li, lane in enumerate(list(gt_lanes) + list(pr_lanes)):
@@ -94,9 +95,24 @@ def iou_matrix(gt_lanes: Sequence[Sequence[dict]], pr_lanes: Sequence[Sequence[d
         tp = torch.tensor(pts, dtype=torch.int32).to(dev)
         tl, tf = torch.tensor(seg_lane, dtype=torch.int32).to(dev), torch.tensor(seg_first, dtype=torch.int32).to(dev)
         lib().call("hn_lane_raster", tp.data_ptr(), tl.data_ptr(), tf.data_ptr(), len(seg_lane), int(lane_width), height, width, masks.data_ptr())
-    inter = torch.zeros((g, p), dtype=torch.int64, device=dev)
-    area = torch.zeros((g + p,), dtype=torch.int64, device=dev)
-    lib().call("hn_lane_iou", masks.data_ptr(), g, p, height * width, inter.data_ptr(), area.data_ptr())
+    B = 32                                                                  # hn_lane_iou's pair block (bit masks per pixel)
+    if g <= B and p <= B:
+        inter = torch.zeros((g, p), dtype=torch.int64, device=dev)
+        area = torch.zeros((g + p,), dtype=torch.int64, device=dev)
+        lib().call("hn_lane_iou", masks.data_ptr(), g, p, height * width, inter.data_ptr(), area.data_ptr())
+    else:
+        inter = torch.zeros((g, p), dtype=torch.int64, device=dev)
+        area = torch.zeros((g + p,), dtype=torch.int64, device=dev)
+        for g0 in range(0, g, B):
+            for p0 in range(0, p, B):
+                gc, pc = min(B, g - g0), min(B, p - p0)
+                sub = torch.cat([masks[g0:g0 + gc], masks[g + p0:g + p0 + pc]]).contiguous()
+                bi = torch.zeros((gc, pc), dtype=torch.int64, device=dev)
+                ba = torch.zeros((gc + pc,), dtype=torch.int64, device=dev)
+                lib().call("hn_lane_iou", sub.data_ptr(), gc, pc, height * width, bi.data_ptr(), ba.data_ptr())
+                inter[g0:g0 + gc, p0:p0 + pc] = bi
+                area[g0:g0 + gc] = ba[:gc]
+                area[g + p0:g + p0 + pc] = ba[gc:]
     inter, area = inter.cpu().numpy().astype(np.float64), area.cpu().numpy().astype(np.float64)
     union = area[:g, None] + area[None, g:] - inter
     # (the reference sums uint8 masks of value 255: the factor cancels in the ratio; an empty union scores 0)

@@ -263,6 +263,9 @@ class HydraNet(nn.Module):
         if self.train_detect:
             object.__setattr__(self.detectheader, "_fwd", lambda x, fused: flushed(me()._det(x, [K_to_nhwc(t) for t in fused])))
             self.detectheader.decode = _det_decode
+            from .coco_json import invert_affine       # DetectionHeader.invert_affine (head_detect/detection.py:217-230; train.py:334-336)
+            self.detectheader.invert_affine = invert_affine
+            self.detectheader.display = _unavailable("detectheader.display (cv2 box / label drawing, head_detect/detection.py:247-252)")
         if self.train_lane:
             object.__setattr__(self.laneheader, "_fwd", lambda fused: flushed(me()._lane([K_to_nhwc(t) for t in fused])))
             from . import lane_codec as LC             # LaneHeader.decode / scale_to_org (head_lane/lanedetect.py:103-124) on the device
@@ -339,11 +342,22 @@ class HydraNet(nn.Module):
                                           P[bn + ".running_var"], eps, kind)
         self._folded = folded
         self._folded_versions = [(t, t._version) for n, t in P.items() if n.split(".")[-1] != "num_batches_tracked"]
+        self._folded_epoch = K.mutation_epoch()
         return self
 
     def _check_folded(self):
-        if self._folded is not None and any(t._version != v for t, v in self._folded_versions):
+        if self._folded is None:
+            return
+        if any(t._version != v for t, v in self._folded_versions):
             raise RuntimeError("parameters or BatchNorm statistics changed after prepare_inference(): call prepare_inference() again")
+        if self._folded_epoch != K.mutation_epoch():
+            # a raw-pointer update happened somewhere in this process since the fold (hn_adam_step, a training-mode forward of any
+            # HydraNet): the version counters cannot tell whether it touched THIS module's tensors, so fold again (a few hundred small
+            # launches, once per such event; never inside a capture, where the operands must stay what the warm-up forwards used)
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("parameters may have changed since prepare_inference() (an optimizer step or a training-mode forward ran): "
+                                   "call prepare_inference() again before capturing the deploy forward")
+            self.prepare_inference()
 
     def train(self, mode: bool = True):
         if mode:
@@ -668,6 +682,8 @@ class HydraNet(nn.Module):
         if self._folded is not None and not self.training:
             self._check_folded()
         params = {id(t) for t in self.parameters()}
+        if self.training:
+            K.bump_mutation_epoch()                # the BatchNorm kernels update running statistics through raw pointers
         if self._pack_plan is not None and not self._pack_plan.valid():
             self._pack_plan = None                 # a parameter's storage was replaced: re-record the weights on this forward
         # eval mode with unchanged parameters (serving): the packed operands of the last forward are still right -- no pack launches

@@ -8,7 +8,7 @@ from typing import Optional, Sequence, Tuple
 
 import torch
 
-from .._lib import lib
+from .._lib import lib, policy
 from .core import *        # noqa: F401,F403
 
 
@@ -160,10 +160,10 @@ def conv_bn_act(x, weight, conv_bias, bn, res=None, kind="1x1", stride=1, act=AC
 # over (dbg, z2); the SE data-path backward is folded into the BN2 reduce/apply pair; the residual gradient is added in conv_block_1's
 # dgrad epilogue).  The unfused composition of ConvBnAct / SEGate nodes is ~16 + ~27 launches per block.
 # --------------------------------------------------------------------------------------------------------------
-FUSED_XBLOCK = os.environ.get("HN_FUSED_XBLOCK", "1") != "0"
-EPILOGUE_STATS = os.environ.get("HN_EPILOGUE_STATS", "1") != "0"   # backward reduce passes folded into their producers' epilogues
-XBLOCK_XF_GEMM = os.environ.get("HN_XBLOCK_XF", "0") == "1"
-BN3_PARTS_FROM_DGRAD = os.environ.get("HN_BN3_PARTS_FROM_DGRAD", "1") != "0"   # the next block's last backward GEMM makes the BatchNorm-3 backward's partial sums
+FUSED_XBLOCK = policy("HN_FUSED_XBLOCK", "1") != "0"
+EPILOGUE_STATS = policy("HN_EPILOGUE_STATS", "1") != "0"   # backward reduce passes folded into their producers' epilogues
+XBLOCK_XF_GEMM = policy("HN_XBLOCK_XF", "0") == "1"
+BN3_PARTS_FROM_DGRAD = policy("HN_BN3_PARTS_FROM_DGRAD", "1") != "0"   # the next block's last backward GEMM makes the BatchNorm-3 backward's partial sums
 
 
 class XBlockFn(torch.autograd.Function):
@@ -367,7 +367,7 @@ def fold_conv_bn(w, conv_bias, gamma, beta, rm, rv, eps, kind):
         return wp, shift.contiguous()
 
 
-INFER_GATE_IN_WEIGHTS = os.environ.get("HN_INFER_GATE_IN_WEIGHTS", "1") != "0"
+INFER_GATE_IN_WEIGHTS = policy("HN_INFER_GATE_IN_WEIGHTS", "1") != "0"
 
 
 def conv_infer(x, packed, bias, cout, kind, stride, act, res=None, gate=None):

@@ -8,7 +8,7 @@ from typing import Optional, Sequence, Tuple
 
 import torch
 
-from .._lib import lib
+from .._lib import lib, policy
 
 ACT_NONE, ACT_RELU, ACT_SWISH, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3, 4
 GCONV_MFMA = True          # stride-1 grouped 3x3 convs as block-diagonal 64-channel MFMA tiles (False: VALU stencil kernels)
@@ -78,6 +78,18 @@ def dense(t: torch.Tensor) -> torch.Tensor:
 # packed-weight cache: a weight is cast/packed once per optimizer step (keyed by storage + version counter)
 # --------------------------------------------------------------------------------------------------------------
 _PACK_CACHE = {}
+# Raw-pointer writes (hn_adam_step on the parameters, the BatchNorm running statistics written by the training-mode kernels) do not bump
+# torch's per-tensor version counters, so "nothing changed since" cannot be decided from `_version` alone: everything in this
+# library that mutates a parameter or a running statistic behind autograd's back bumps this epoch, and every freshness test includes it.
+_MUTATION_EPOCH = [0]
+
+
+def bump_mutation_epoch():
+    _MUTATION_EPOCH[0] += 1
+
+
+def mutation_epoch() -> int:
+    return _MUTATION_EPOCH[0]
 
 
 def clear_pack_cache():
@@ -203,10 +215,11 @@ class PackPlan:
                    for (_, w, meta), p_ in zip(self.entries, self.ptrs))
 
     def _versions(self):
-        return [(w._version, meta._version if isinstance(meta, torch.Tensor) else 0) for _, w, meta in self.entries]
+        return (mutation_epoch(), [(w._version, meta._version if isinstance(meta, torch.Tensor) else 0) for _, w, meta in self.entries])
 
     def fresh(self):
-        """the packed buffers still hold what run() made of the CURRENT parameter values (no in-place update since) and the pack cache still
+        """the packed buffers still hold what run() made of the CURRENT parameter values (no in-place update since -- neither through
+        autograd-visible ops (version counters) nor through this library's raw-pointer kernels (mutation epoch)) and the pack cache still
         points at them: an eval-mode forward may skip run() (serving: the weights are constants; inside a captured deploy forward the two
         pack launches then are not part of the graph at all)"""
         return self._ran == self._versions() and all(_PACK_CACHE.get((key, id(w)), (None,))[0] is w for key, w, _ in self.entries)
@@ -372,7 +385,7 @@ class WgradBatch:
         self.keep = []
 
 
-DEFER_WGRAD = os.environ.get("HN_DEFER_WGRAD", "1") != "0"   # 1x1 weight gradients of a backbone stage in one grouped launch at the stage boundary
+DEFER_WGRAD = policy("HN_DEFER_WGRAD", "1") != "0"   # 1x1 weight gradients of a backbone stage in one grouped launch at the stage boundary
 
 
 class GradQueue:
@@ -501,7 +514,7 @@ def cur_queue():
     return _CUR_QUEUE if DEFER_WGRAD else None
 
 
-SIDE_FLUSH = os.environ.get("HN_SIDE_FLUSH", "0") == "1"     # run the deferred-gradient flushes on a side HIP stream (a hipGraph branch)
+SIDE_FLUSH = policy("HN_SIDE_FLUSH", "0") == "1"     # run the deferred-gradient flushes on a side HIP stream (a hipGraph branch)
 _SIDE = {}                                                   # device -> (stream, [tensors kept alive until the join], join-queued flag)
 
 
@@ -646,8 +659,8 @@ def k_eltwise(op, a, b=None, act=ACT_NONE, alpha=1.0, out=None):
     return out
 
 
-FUSED_BN = os.environ.get("HN_FUSED_BN", "1") != "0"   # BatchNorm finalize in the prologue of the consuming elementwise kernel (hn_fused.hip); False: round-1 kernels
-MAX_PROLOGUE_ROWS = int(os.environ.get("HN_MAX_PROLOGUE_ROWS", "128"))    # partial rows a consumer prologue reduces itself (+1.5 us at 128 rows); more are folded to 32 rows first (one
+FUSED_BN = policy("HN_FUSED_BN", "1") != "0"   # BatchNorm finalize in the prologue of the consuming elementwise kernel (hn_fused.hip); False: round-1 kernels
+MAX_PROLOGUE_ROWS = int(policy("HN_MAX_PROLOGUE_ROWS", "128"))    # partial rows a consumer prologue reduces itself (+1.5 us at 128 rows); more are folded to 32 rows first (one
                            # ~5 us launch, only for the large early-stage tensors whose passes take 15-40 us anyway)
 
 

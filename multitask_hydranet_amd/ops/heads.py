@@ -8,7 +8,7 @@ from typing import Optional, Sequence, Tuple
 
 import torch
 
-from .._lib import lib
+from .._lib import lib, policy
 from .core import *        # noqa: F401,F403
 from .backbone import *        # noqa: F401,F403
 from .neck import *        # noqa: F401,F403
@@ -236,10 +236,10 @@ class PackLevels(torch.autograd.Function):
         return tuple(level_views(dense(g), ctx.geom))
 
 
-TOWER_BN_IN_GEMM = os.environ.get("HN_TOWER_BN_IN_GEMM", "1") != "0"
-PACK_LEVELS_ONE = os.environ.get("HN_PACK_LEVELS_ONE", "1") != "0"       # PackLevels: one copy launch for all levels (0: one per level)
-HEAD_OUT_LEVELS = os.environ.get("HN_HEAD_OUT_LEVELS", "1") != "0"       # the heads' output conv of all five levels in one launch (0: one per level)
-HEAD_GRAD_LEVELS = os.environ.get("HN_HEAD_GRAD_LEVELS", "1") != "0"     # head-output gradient operand of all five levels in one launch (0: one per level)
+TOWER_BN_IN_GEMM = policy("HN_TOWER_BN_IN_GEMM", "1") != "0"
+PACK_LEVELS_ONE = policy("HN_PACK_LEVELS_ONE", "1") != "0"       # PackLevels: one copy launch for all levels (0: one per level)
+HEAD_OUT_LEVELS = policy("HN_HEAD_OUT_LEVELS", "1") != "0"       # the heads' output conv of all five levels in one launch (0: one per level)
+HEAD_GRAD_LEVELS = policy("HN_HEAD_GRAD_LEVELS", "1") != "0"     # head-output gradient operand of all five levels in one launch (0: one per level)
 _EVAL_COEF = {}             # id(gamma of level 0) -> (the 4 * nl BatchNorm tensors, their versions, eps, coef [nl, 4, cout])
 
 
@@ -247,7 +247,7 @@ def _eval_coef_levels(gam, bet, rms, rvs, eps, cout, coef):
     """eval-mode (running statistics) scale / shift rows of a tower layer's per-level BatchNorms: constants until a parameter or running
     statistic changes in place, so they are computed once (five ~5 us launches per layer and forward otherwise: 30 per deploy forward)"""
     tens = (*gam, *bet, *rms, *rvs)
-    ver = tuple(t._version for t in tens)
+    ver = (mutation_epoch(), *[t._version for t in tens])       # raw-pointer updates (hn_adam_step, training-mode BatchNorm kernels) bump the epoch only
     hit = _EVAL_COEF.get(id(gam[0]))
     if hit is not None and len(hit[0]) == len(tens) and all(a is b for a, b in zip(hit[0], tens)) and hit[1] == ver and hit[2] == eps:
         return hit[3]

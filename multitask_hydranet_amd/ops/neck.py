@@ -8,7 +8,7 @@ from typing import Optional, Sequence, Tuple
 
 import torch
 
-from .._lib import lib
+from .._lib import lib, policy
 from .core import *        # noqa: F401,F403
 from .backbone import *        # noqa: F401,F403
 
@@ -165,8 +165,8 @@ def share(x, n):
 # The 2x2 gradient sums of up-sampled fusion inputs inside hn_fuse_bwd instead of 12 hn_sum2x2 launches per step.  With the generic quad
 # walk (four pixels in sequence per thread) this measured SLOWER (861 vs 863 img/s); with fuse_bwd_quads_kernel, which issues every load of
 # a quad before the first use, 869.  HN_FUSE_SUM2X2=0: the separate launches.
-FUSE_SUM2X2 = os.environ.get("HN_FUSE_SUM2X2", "1") != "0"
-FUSE_ARG = os.environ.get("HN_FUSE_ARG", "1") != "0"      # the fusion backward kernel leaves the pooling arg-max bytes behind (0: hn_maxpool_bwd2's own pass)
+FUSE_SUM2X2 = policy("HN_FUSE_SUM2X2", "1") != "0"
+FUSE_ARG = policy("HN_FUSE_ARG", "1") != "0"      # the fusion backward kernel leaves the pooling arg-max bytes behind (0: hn_maxpool_bwd2's own pass)
 
 
 class Fuse(torch.autograd.Function):

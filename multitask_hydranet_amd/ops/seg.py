@@ -8,7 +8,7 @@ from typing import Optional, Sequence, Tuple
 
 import torch
 
-from .._lib import lib
+from .._lib import lib, policy
 from .core import *        # noqa: F401,F403
 from .backbone import *        # noqa: F401,F403
 from .neck import *        # noqa: F401,F403
@@ -17,7 +17,7 @@ from .neck import *        # noqa: F401,F403
 # --------------------------------------------------------------------------------------------------------------
 # segmentation decoder block: y = act(conv3x3(reflect_pad(cat[up2(x0)|x0, x1])) + bias)
 # --------------------------------------------------------------------------------------------------------------
-SEG_FOLD_DIRECT = os.environ.get("HN_SEG_FOLD_DIRECT", "1") != "0"
+SEG_FOLD_DIRECT = policy("HN_SEG_FOLD_DIRECT", "1") != "0"
 
 
 SEG_FOLD_MIN_ELEMS = 1 << 24   # measured (step trace, N = 16): the folding epilogue wins 130 / 45 / 19 / 11 us on the 134M / 67M / 33M / 17M-element
@@ -294,8 +294,8 @@ class SegConvUp(torch.autograd.Function):
         return dx0, dx1, dw, dbias, None, None
 
 
-SEG_PHASE_UP = os.environ.get("HN_SEG_PHASE_UP", "1") != "0"
-SEG_DGRAD_PHASE_MIN_TILES = int(os.environ.get("HN_SEG_DGRAD_PHASE_MIN_TILES", "448"))
+SEG_PHASE_UP = policy("HN_SEG_PHASE_UP", "1") != "0"
+SEG_DGRAD_PHASE_MIN_TILES = int(policy("HN_SEG_DGRAD_PHASE_MIN_TILES", "448"))
 SEG_FWD_PHASE = None        # None: per-layer heuristic; True / False force the forward form (tests)
 SEG_DGRAD_PHASE = None      # the same for the data gradient w.r.t. the up-sampled operand
 

@@ -13,6 +13,7 @@ import weakref
 import torch
 
 from ._lib import lib
+from .ops.core import bump_mutation_epoch
 
 
 class Adam(torch.optim.Optimizer):
@@ -64,6 +65,7 @@ class Adam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        bump_mutation_epoch()               # hn_adam_step writes the parameters through raw pointers: eval-mode caches keyed on `_version` are stale
         for gi, group in enumerate(self.param_groups):
             b1, b2 = group["betas"]
             fast = self._fast.get(gi)

@@ -21,7 +21,7 @@ from typing import Dict, Iterable, Optional
 import torch
 import torch.distributed as dist
 
-from .ddp import GradReducer, broadcast_state, unused_parameters
+from .ddp import GradReducer, broadcast_state, capture_exchange_step, unused_parameters
 from .metrics import IntersectionOverUnion
 from .model import HydraNet
 from .optim import Adam
@@ -65,14 +65,20 @@ def run_training(trainer: "HydraTrainer", valid_every_epoch: bool = True, log=pr
 
 class HydraTrainer:
     def __init__(self, cfgs: dict, trainloader: Optional[Iterable] = None, validloader: Optional[Iterable] = None, iters_per_epoch: Optional[int] = None,
-                 grad_payload: torch.dtype = torch.float32, capture_step: bool = False, hip_adam: bool = True):
-        """capture_step (single-GPU runs): after two eager iterations the forward + loss + backward of an iteration is captured as ONE
-        hipGraph and replayed on static input buffers (710 vs 505 img/s on the bench workload: ~1600 launches per step are host-bound when
-        issued one by one); Adam / LR steps stay eager.  Needs batches of one fixed shape; a different shape re-captures."""
+                 grad_payload: torch.dtype = torch.float32, capture_step: bool = False, hip_adam: bool = True, force_distribute: bool = False):
+        """capture_step: after two eager iterations the forward + loss + backward of an iteration is captured as ONE hipGraph and replayed
+        on static input buffers (875 vs ~500 img/s on the bench workload: ~1200 launches per step are host-bound when issued one by one);
+        Adam / LR steps stay eager.  Needs batches of one fixed shape; a different shape re-captures.  With more than one rank the
+        gradient exchange is part of the captured step (RCCL: every bucket's gather + all-reduce captured in line where its last gradient
+        appears, ddp.capture_exchange_step -- the form bench.py times; other backends, whose collectives cannot be captured: the graph holds
+        forward + loss + backward and the buckets are exchanged right after each replay).
+        force_distribute: run the data-parallel machinery (process group, bucketed all-reduce, in-graph exchange) at world size 1 too --
+        the N > 1 code path on a single GPU (tests; the average over one rank is the identity)."""
         self.cfgs = cfgs
         self.capture_step = capture_step
         self._cap = None                       # (shape key, graph, static batch, static loss dict)
         self._eager_iters = 0
+        self._stream = None                    # data-parallel captured steps: ONE stream for the eager iterations and the capture (ddp.py)
         t = cfgs["train"]
         self.train_detect, self.train_seg, self.train_lane = t["train_detect"], t["train_seg"], t["train_lane"]
         self.print_interval = t.get("print_interval", 10)
@@ -81,8 +87,12 @@ class HydraTrainer:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
         torch.cuda.set_device(self.device)
-        if self.world > 1 and not dist.is_initialized():
+        self._force_distribute = bool(force_distribute)
+        if (self.world > 1 or force_distribute) and not dist.is_initialized():
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            if self.world == 1:
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29541")
             dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.device)
 
         self.hydranet = HydraNet(cfgs=cfgs).to(self.device)
@@ -90,13 +100,15 @@ class HydraTrainer:
             # files written from a DDP wrapper carry "module." prefixes (train.py:96-109 deparallel_model): load_state_dict strips them
             self.hydranet.load_state_dict(torch.load(t["weight_file"], map_location=self.device))
         broadcast_state(self.hydranet)                               # what DDP does at construction (train.py:137)
-        self.use_distribute = self.world > 1
+        self.use_distribute = self.world > 1 or self._force_distribute
         self.reducer = None
         self.phase = "joint"
         self._grad_payload = grad_payload
         self._reducers = {}                                          # one bucket plan per fine-tuning phase (the set of live gradients differs)
         if self.use_distribute:
             self.reducer = self._reducers["joint"] = self._make_reducer("joint")
+            if capture_step:
+                self._stream = torch.cuda.Stream(device=self.device)
 
         self.lr, self.weight_decay, self.epoch = t["lr"], t["weight_decay"], t["epoch"]
         n_iter = iters_per_epoch if iters_per_epoch is not None else (len(trainloader) if hasattr(trainloader, "__len__") else 1)
@@ -126,7 +138,8 @@ class HydraTrainer:
         else:
             prefix = {"lane": "laneheader.", "det": "detectheader.", "seg": "segheader."}[phase]
             named = [(n, p) for n, p in self.hydranet.named_parameters() if n.startswith(prefix)]
-        return GradReducer(named, world_size=self.world, skip=unused_parameters(self.hydranet), payload_dtype=self._grad_payload)
+        return GradReducer(named, world_size=self.world, skip=unused_parameters(self.hydranet), payload_dtype=self._grad_payload,
+                           force_collectives=self._force_distribute)
 
     def set_phase(self, phase: str):
         """One branch of main()'s schedule (train.py:462-505): the optimizer's first param group holds the parameters of the whole model
@@ -170,31 +183,48 @@ class HydraTrainer:
         return batch_data
 
     def _captured_fwd_bwd(self, batch_data: dict) -> Dict[str, torch.Tensor]:
-        """forward + loss + backward as one hipGraph replay (built on first use for this batch shape)"""
+        """forward + loss + backward (+ the gradient exchange) as one hipGraph replay (built on first use for this batch shape)"""
         keys = [k for k, v in batch_data.items() if isinstance(v, torch.Tensor) and v.is_cuda]
         sig = tuple((k, tuple(batch_data[k].shape), batch_data[k].dtype) for k in keys)
         if self._cap is None or self._cap[0] != sig:
             static = {k: batch_data[k].clone() for k in keys}
             net = self.hydranet
             guard, net.check_finite = net.check_finite, False        # the divergence guard reads the loss on the host: after the replay
+
+            def fwd_bwd():
+                outputs = net(static["image"])
+                loss_dict = net.cal_loss(outputs, static)
+                loss_dict["total_loss"] = self.cal_total_loss(loss_dict)
+                loss_dict["total_loss"].backward(self._one)
+                return loss_dict
             # parameter gradients become tensors of the graph's pool (stored by the captured backward, rewritten by every replay)
-            self.optimizer.zero_grad(set_to_none=True)
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
+            zero = lambda: self.optimizer.zero_grad(set_to_none=True)
             try:
-                # thread-local capture mode: helper threads (the autograd engine's allocator calls, an RCCL watchdog) must not invalidate it
-                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                    outputs = net(static["image"])
-                    loss_dict = net.cal_loss(outputs, static)
-                    loss_dict["total_loss"] = self.cal_total_loss(loss_dict)
-                    loss_dict["total_loss"].backward(self._one)
+                red = self.reducer
+                in_graph = red is not None and red.active and red.on_gpu and dist.get_backend(red.group) == "nccl"
+                if in_graph:
+                    # (no extra warm-up: the two eager iterations ran on self._stream with the hooks armed)
+                    graph, loss_dict = capture_exchange_step(red, fwd_bwd, zero, self._stream, warmup=0)
+                else:
+                    if red is not None:
+                        red.remove()                                 # no hooks inside this capture: the exchange follows every replay
+                    zero()
+                    torch.cuda.synchronize()
+                    graph = torch.cuda.CUDAGraph()
+                    # thread-local capture mode: helper threads (the autograd engine's allocator calls, an RCCL watchdog) must not invalidate it
+                    with torch.cuda.graph(graph, capture_error_mode="thread_local", **({"stream": self._stream} if self._stream is not None else {})):
+                        loss_dict = fwd_bwd()
+                    if red is not None:
+                        red.bind_static_grads()                      # reduce_now() gathers what each replay leaves in these tensors
             finally:
                 net.check_finite = guard
-            self._cap = (sig, graph, static, loss_dict)
-        _, graph, static, loss_dict = self._cap
+            self._cap = (sig, graph, static, loss_dict, in_graph)
+        _, graph, static, loss_dict, in_graph = self._cap
         for k in static:
             static[k].copy_(batch_data[k])
         graph.replay()
+        if self.reducer is not None and not in_graph:
+            self.reducer.reduce_now()
         if self.hydranet.check_finite:
             for name, v in loss_dict.items():
                 self.hydranet._guard(v, "cal %s diverge!" % name, allow_zero=name.startswith("loss_det"))
@@ -202,8 +232,19 @@ class HydraTrainer:
 
     def train_step(self, batch_data: dict) -> Dict[str, torch.Tensor]:
         """one iteration of train.py:243-267: forward, multitask loss, backward (gradient exchange overlapped), Adam step, LR step"""
+        if self._stream is None:
+            return self._train_step(batch_data)
+        # data-parallel + capture_step: every iteration (eager or replayed) runs on the trainer's own stream, the one the capture uses
+        cur = torch.cuda.current_stream()
+        self._stream.wait_stream(cur)
+        with torch.cuda.stream(self._stream):
+            out = self._train_step(batch_data)
+        cur.wait_stream(self._stream)
+        return out
+
+    def _train_step(self, batch_data: dict) -> Dict[str, torch.Tensor]:
         batch_data = self.to_gpu(batch_data)
-        if self.capture_step and self.reducer is None and self._eager_iters >= 2:
+        if self.capture_step and self._eager_iters >= 2:
             loss_dict = self._captured_fwd_bwd(batch_data)
             self.optimizer.step()
             self.scheduler.step()
@@ -212,6 +253,8 @@ class HydraTrainer:
         if self._cap is not None:              # back on the eager path after captured steps: gradients must not stay in the graph's pool
             self.optimizer.zero_grad(set_to_none=True)
             self._cap = None
+        if self.reducer is not None:
+            self.reducer.arm()                 # (a captured step removed the hooks; no-op while they are registered)
         outputs = self.hydranet(batch_data["image"])
         loss_dict = self.hydranet.cal_loss(outputs, batch_data)
         loss_total = self.cal_total_loss(loss_dict)
@@ -247,8 +290,11 @@ class HydraTrainer:
         prediction json of LaneHeader.scale_to_org (train.py:366-395) when a `lane_coder` (LaneCodec) is given, and -- when the batches carry
         the ground-truth lanes of train.py:393 as `gt_lane_json` (one {"Lines": [...], "Labels": [...]} dict per image) -- the lane F1 of
         train.py:188,397,433 (LaneMetric, f1_measure, IoU 0.5, width 30, score threshold 0.5).  COCOeval needs pycocotools (out of scope).
+        Deliberate deviation: train.py:397 calls `self.lane_metric(output=lane_result)` inside the batch loop with the CUMULATIVE list, so the
+        reference counts image k of a validation run (number of batches - batch index of k) times, and never resets the evaluator between
+        epochs; here every image is scored exactly once per valid() call (for a single-batch validation the two agree).
         Returns the per-class IoU tensor; everything else is left in self.last_valid."""
-        from .coco_json import detections_to_coco, invert_affine, write_results
+        from .coco_json import detections_to_coco, write_results
         from .lane_metric import LaneMetric
         lane_metric = LaneMetric(method="f1_measure", iou_thresh=0.5, lane_width=30, thresh_list=[0.5])           # train.py:188
         lane_pairs = []
@@ -280,7 +326,7 @@ class HydraTrainer:
                 preds = net.detectheader.decode(inputs, d["regression"], d["classification"], d["anchors"], conf_thres=det_conf_thres,
                                                 iou_thres=det_iou_thres)
                 metas = [[net_w, net_h, sh["width"], sh["height"], 0, 0] for sh in shapes]
-                preds = invert_affine(metas, preds)
+                preds = net.detectheader.invert_affine(metas, preds)                                       # train.py:334-336
                 detect_result += detections_to_coco(preds, iter_idx * self.cfgs["train"].get("batch_size_valid", n) + 1)
             if self.train_lane and lane_coder is not None:
                 l = self.cfgs["lane"]

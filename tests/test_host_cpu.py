@@ -57,6 +57,18 @@ def test_state_dict_contract_matches_reference(built):
     assert net.widths == [24, 64, 152, 376, 936] and net.depths == [1, 1, 4, 10, 14]
     # train.py:469-503 hands sub-module parameter lists to the optimizer
     assert len(list(net.laneheader.parameters())) == 15 and len(list(net.segheader.parameters())) == 18
+    # static helpers the callers reach through the instance: train.py:334-336, demo.py:230-244, lanedetect.py:103-178
+    import torch
+    for head, names in ((net.detectheader, ("decode", "invert_affine", "display")), (net.segheader, ("decode",)),
+                        (net.laneheader, ("decode", "scale_to_org", "visual"))):
+        for nm in names:
+            assert callable(getattr(head, nm)), nm
+    preds = [{"rois": torch.tensor([[10.0, 20.0, 30.0, 40.0]]).numpy()}, {"rois": torch.zeros(0, 4).numpy()}]
+    out = net.detectheader.invert_affine([[640, 640, 1280, 320, 0, 0]] * 2, preds)
+    assert out[0]["rois"].tolist() == [[20.0, 10.0, 60.0, 20.0]]
+    for fn in (net.detectheader.display, net.laneheader.visual):         # cv2 drawing: out of scope, says so instead of an AttributeError
+        with pytest.raises(NotImplementedError):
+            fn()
 
 
 @pytest.mark.parametrize("fixture,cfg", [("tiny_hydranet.npz", "hydranet_tiny.yml"), ("tiny4_hydranet.npz", "hydranet_tiny4.yml")])

@@ -320,7 +320,11 @@ def test_demo_loop_end_to_end(pkg):
 def test_lane_metric_device_vs_reference_recording(pkg):
     """LaneMetric on the device (hn_lane_raster + hn_lane_iou) against the recording made by the reference's own lane_metric.py
     (tests/golden/lane_metric.json): spline samples, the full IoU matrix of one image, per-image (gt, pr, hit) counts and the F1 summary for
-    two lane widths x two score thresholds -- identical (integer pixel counts on both sides; cv2.line itself is restated on both: unpinned)."""
+    two lane widths x two score thresholds -- identical (integer pixel counts on both sides).  SELF-CONSISTENCY ONLY for the fill rule:
+    cv2 is absent from this image, so the recording was made with cv2.line replaced by the oracle's restatement ("pixel centre within
+    lane_width / 2 of the segment", tests/golden/make_golden.py:40-44); OpenCV's fixed-point thick-line fill differs at boundary pixels,
+    and hit / miss decisions near IoU 0.5 are NOT pinned against real OpenCV.  What the recording does pin is everything around the
+    rasteriser: the spline, the pairing, the Hungarian assignment, the thresholds and the F1 arithmetic of the reference's own code."""
     import json
     import os
     P, O = pkg
@@ -350,3 +354,13 @@ def test_lane_metric_device_vs_reference_recording(pkg):
     ref = np.array([[O.lane_iou(g, p, 1080, 1920, 30) for p in prs] for g in gts])
     np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12)
     assert got.max() > 0.5 and got.min() == 0.0
+    # more lanes than the pair kernel's 32 x 32 block (the reference has no limit): 37 ground truths x 41 predictions in blocks
+    # == the same matrix assembled from single-block calls
+    many_g = [[{"x": float(40 + 45 * j + 3 * i), "y": float(500 - 40 * i)} for i in range(8)] for j in range(37)]
+    many_p = [[{"x": float(30 + 42 * j + 4 * i), "y": float(500 - 40 * i)} for i in range(8)] for j in range(41)]
+    big = LM.iou_matrix(many_g, many_p, 512, 2048, 30)
+    assert big.shape == (37, 41)
+    for g0_, p0_ in ((0, 0), (32, 0), (0, 32), (32, 32)):
+        blk = LM.iou_matrix(many_g[g0_:g0_ + 32], many_p[p0_:p0_ + 32], 512, 2048, 30)
+        np.testing.assert_array_equal(big[g0_:g0_ + 32, p0_:p0_ + 32], blk)
+    assert big.max() > 0.3

@@ -172,12 +172,117 @@ def test_two_rank_control_flow_on_one_gpu():
         assert o["n_gpus"] == 2 and o["config"]["global_batch"] == 4 and o["config"]["parallelism"] == "dp2" and o["scaling"] == "weak"
         assert "gloo" in o["config"]["grad_allreduce"]
         assert o["value"] > 0 and o["loss"] == o["loss"]
-        assert o["rccl_ranks"] == 2 and len(o["per_rank_ms_per_step"]) == 2
+        assert o["dist_ranks"] == 2 and o["dist_backend"] == "gloo" and len(o["per_rank_ms_per_step"]) == 2
     # a world size that does not match --gpus is refused (exit code 2, no JSON line) instead of measured under the wrong label
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                         "--master-port", str(_free_port()), os.path.join(root, "bench.py")] + tail, capture_output=True, text=True, env=env,
                        timeout=600)
     assert r.returncode != 0 and not any(l.startswith("{") for l in r.stdout.splitlines())
+
+
+def test_two_rank_gradients_are_the_mean_of_the_single_rank_gradients():
+    """DDP semantics (model/train.py:130-137) with the real HIP model at world size 2: two gloo ranks on cuda:0, a different batch per rank
+    (tests/ddp_two_rank_worker.py): the exchanged gradients of each rank == the mean of the two single-rank gradients (fp32 payload, 1e-6;
+    in-place bucket slots on the first step, accumulation into the bucket views on the second), and HydraTrainer's captured data-parallel
+    step == its eager hook form bit for bit, identical parameters on both ranks after five iterations."""
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = str(_free_port())
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tests", "ddp_two_rank_worker.py")], stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True, env=env))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=900)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for rank, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and ("rank %d ok" % rank) in o, o[-3000:]
+
+
+def test_trainer_captured_data_parallel_step_rccl_world1(setup):
+    """HydraTrainer(capture_step=True) with the data-parallel machinery on (force_distribute: RCCL process group of one rank): two eager
+    hook-mode iterations, then the captured step with every bucket's gather + ncclAvg all-reduce IN the hipGraph (ddp.capture_exchange_step,
+    the recipe bench.py times).  The average over one rank is the identity: losses, parameters and buffers after five iterations equal the
+    plain single-GPU eager trainer's bit for bit."""
+    from multitask_hydranet_amd.train import HydraTrainer
+    z, cfgs, batch = setup
+    g = torch.Generator().manual_seed(5)
+    loader = []
+    for i in range(5):
+        b = dict(batch)
+        b["image"] = batch["image"] + 0.05 * torch.randn(batch["image"].shape, generator=g)
+        loader.append(b)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(_free_port()))
+    runs = []
+    for ddp in (False, True):
+        tr = HydraTrainer(cfgs, trainloader=loader, validloader=None, iters_per_epoch=len(loader), capture_step=ddp, force_distribute=ddp)
+        tr.hydranet.load_state_dict(tiny_state(z))
+        tr.hydranet.lane_points_per_line = int(z["meta/lane_points_per_line"])
+        losses = []
+        for b in loader:
+            ld = tr.train_step({k: v.clone() for k, v in b.items()})
+            losses.append({k: float(v.detach()) for k, v in ld.items()})
+        torch.cuda.synchronize()
+        if ddp:
+            assert tr._cap is not None and tr._cap[4], "the exchange was not captured inside the hipGraph"
+            assert tr.reducer.captured and "inside the hipGraph" in tr.reducer.describe()
+        runs.append((losses, {n: p.detach().clone() for n, p in tr.hydranet.named_parameters()},
+                     {n: b_.detach().clone() for n, b_ in tr.hydranet.named_buffers()}))
+    (l0, p0, b0), (l1, p1, b1) = runs
+    assert l0 == l1, (l0, l1)
+    for n in p0:
+        assert torch.equal(p0[n], p1[n]), n
+    for n in b0:
+        assert torch.equal(b0[n], b1[n]), n
+
+
+def test_eval_after_training_steps_sees_the_updated_weights(setup):
+    """hn_adam_step and the training-mode BatchNorm kernels write parameters / running statistics through raw pointers, which
+    torch's version counters do not see.  The eval-mode caches (PackPlan.fresh, the det towers' per-level coefficient rows) must still
+    notice: eval -> train steps -> eval gives what a module with freshly packed operands gives."""
+    from multitask_hydranet_amd import HydraNet
+    from multitask_hydranet_amd.train import HydraTrainer
+    z, cfgs, batch = setup
+    tr = HydraTrainer(cfgs, trainloader=[dict(batch)] * 3, validloader=None, iters_per_epoch=3)
+    net = tr.hydranet
+    net.load_state_dict(tiny_state(z))
+    net.lane_points_per_line = int(z["meta/lane_points_per_line"])
+    x = batch["image"].cuda()
+
+    def eval_out():
+        net.eval()
+        with torch.no_grad():
+            o = net(x)
+            o2 = net(x)                                   # the second eval forward reuses the packed operands (PackPlan.fresh)
+        net.train()
+        flat = lambda d: [d["seg"], d["detection"]["regression"], d["detection"]["classification"], d["lane"]["predict_cls"], d["lane"]["predict_loc"]]
+        for a, b in zip(flat(o), flat(o2)):
+            assert torch.equal(a, b)
+        return [t.float().clone() for t in flat(o)]
+    first = eval_out()
+    for _ in range(3):
+        tr.train_step({k: v.clone() for k, v in batch.items()})
+    after = eval_out()
+    assert any(not torch.equal(a, b) for a, b in zip(first, after)), "three optimizer steps must change the eval outputs"
+    fresh = HydraNet(cfgs).cuda()
+    fresh.load_state_dict(net.state_dict())
+    fresh.eval()
+    with torch.no_grad():
+        o = fresh(x)
+    want = [o["seg"], o["detection"]["regression"], o["detection"]["classification"], o["lane"]["predict_cls"], o["lane"]["predict_loc"]]
+    for a, b in zip(after, want):
+        assert torch.equal(a, b.float()), "an eval-mode cache served operands from before the optimizer steps"
 
 
 def test_fine_tuning_schedule_two_turns(setup):

@@ -1,4 +1,5 @@
 #!/bin/bash
+export HN_TUNING=${HN_TUNING:-ab}    # product library; the package reads HN_LIB_AB / policy switches only under HN_TUNING=1|ab (_lib.policy)
 # Same-box A/B of the whole training step: working-tree library (A) against every alternate in-tree build named on the command line
 # (multitask_hydranet_amd/libhydranet_hip_<name>.so, e.g. "B" from tools/ab_head.sh), interleaved, REPS rounds (default 2).
 #   tools/ab_run.sh B [C ...]        prints: variant img/s ms_per_step      (BENCH_ARGS="--infer --batch 32 --res 1152x1920": another workload)

@@ -1,4 +1,5 @@
 #!/bin/bash
+export HN_TUNING=${HN_TUNING:-ab}    # policy switches are read from the environment only under HN_TUNING=1|ab (_lib.policy)
 # per-kernel averages of the BiFPN fusion kernels in the training step, for the working tree and (HN_LIB_AB) another build
 set -eu
 cd /tmp && export TMPDIR=/tmp

@@ -1,4 +1,5 @@
 #!/bin/bash
+export HN_TUNING=${HN_TUNING:-ab}    # product library; the package reads HN_LIB_AB / policy switches only under HN_TUNING=1|ab (_lib.policy)
 # per-dispatch durations of the seg-decoder kernels in one captured step (last replay), with and without the phase form
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/segtrace

@@ -1,4 +1,5 @@
 #!/bin/bash
+export HN_TUNING=${HN_TUNING:-ab}    # product library; the package reads HN_LIB_AB / policy switches only under HN_TUNING=1|ab (_lib.policy)
 # per-dispatch durations of the seg-decoder conv kernels in one captured step: working-tree library, then each named variant
 # (multitask_hydranet_amd/libhydranet_hip_<name>.so):   tools/seg_trace_ab.sh B
 R=${GRAFT_REPO_ROOT:-/root/repo}
