@@ -160,6 +160,61 @@ def dominant_launch_roofline(net, n, h, w, iters=100, graph_timing=False):
             "frac_executed": round(executed / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), "algorithmic_bytes_per_launch": alg_bytes}
 
 
+def time_dominant_gemm_family(net, n, h, w, iters=50):
+    """The family that takes the most TIME in the step (profiles/r04_roofline_table.md: gemm_nt_kernel<64,64,...>, the 1x1 convs of backbone
+    stages 3-4 and their data gradients: ~176 launches, ~2.6 ms per step) priced against the HBM roofline: three representative launches
+    of the big cfg -- stage-3 and stage-4 conv_block_1 / 3 (M = N*H*W/256 x 376 -> 376 and N*H*W/1024 x 936 -> 936, with the BatchNorm
+    statistics epilogue they carry in the step) -- replayed back to back from one hipGraph (as inside the step) and timed with HIP events on
+    the launch stream.  Algorithmic bytes per launch = rows * (Cin + Cout) * 2 (bf16 in, bf16 out) + Cout * Cin * 2 (weights): SURVEY 8(d)'s
+    conv-operand figure for that conv."""
+    from multitask_hydranet_amd import ops as K
+    dev = net._idx["backbone.net.stem.conv.weight"].device
+    shapes = []
+    for k in (3, 4):
+        if k < len(net.widths):
+            c = net.widths[k]
+            shapes.append((n * (h >> (k + 2)) * (w >> (k + 2)), c, "stage_%d conv_block_1/3 (%d -> %d)" % (k, c, c)))
+    per, tot_t, tot_b = [], 0.0, 0.0
+    for m, c, what in shapes:
+        x = torch.randn(1, 1, m, c, device=dev).to(torch.bfloat16)
+        wgt = torch.randn(c, c, 1, 1, device=dev) * c ** -0.5
+        wp, _ = K.pack_conv_weight(wgt)
+        out = torch.empty(1, 1, m, c, device=dev, dtype=torch.bfloat16)
+        run = lambda: K.k_gemm_nt(x, None, 0, (1, 1, m), wp, c, K.kp32(c), 1, out=out, stats=True)
+        for _ in range(3):
+            run()
+        s_ = torch.cuda.Stream()
+        s_.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s_):
+            run()
+        torch.cuda.current_stream().wait_stream(s_)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(iters):
+                run()
+        g.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / iters * 1e3
+        byts = 2.0 * m * (c + c) + 2.0 * c * c
+        per.append({"launch": what, "rows": m, "launch_us": round(us, 2), "algorithmic_bytes": byts, "GBps": round(byts / us / 1e3, 1),
+                    "frac": round(byts / us / 1e3 / PEAK_HBM_GBS, 4), "TFLOPs": round(2.0 * m * c * c / us / 1e6, 1)})
+        tot_t += us
+        tot_b += byts
+        del g
+    ach = tot_b / tot_t / 1e3
+    return {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
+            "kernel": "gemm_nt_kernel<64,64,...> (PLAIN rows): 1x1 convs of backbone stages 3-4 with the BatchNorm statistics epilogue, N=%d" % n,
+            "launches": per,
+            "note": "largest family by TIME in the step; these tensors (3.8-6.2 MB) live in L2 / Infinity Cache between launches: the launch is "
+                    "bound by per-step DMA latency and the L2 -> LDS rate of 64 x 64 tiles, not by HBM (DESIGN.md section 3)"}
+
+
 def measured_traffic(n, h, w, form):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 correction +
     WRITE_SIZE, separate passes: PMC counters cannot be read from inside this process).  The figure belongs to ONE workload: it is only
@@ -665,6 +720,10 @@ def extra_configs(args, dev, headline_net, headline_cfgs):
         out = {"value": round(batch_n * K_STEPS / dt, 2), "unit": "images/sec", "ms_per_step": round(dt / K_STEPS * 1e3, 3),
                "ms_per_step_median": round(median(per), 3), "steps": K_STEPS, "warmup": K_WARM, "batch": batch_n, "resolution": "3x%dx%d" % (h, w),
                "hipgraph": run.graph is not None, "workload": what}
+        if not backbone_only and scope is None:
+            # SURVEY 8(d) segment-wise step roofline (0.177 ms/img at 512x1024, linear in H*W): the same fraction the headline's step_roofline states
+            sc = (h * w) / (512.0 * 1024.0)
+            out["step_roofline"] = {"floor_ms_per_img": round(0.177 * sc, 4), "frac": round(out["value"] * 0.177e-3 * sc, 4)}
         if exchange:
             out["grad_allreduce"] = run.describe_exchange()
         return out
@@ -901,7 +960,14 @@ def main():
         }
         if not args.no_roofline:
             try:
+                # top-level fields = the dominant kernel by FLOPs (the contract's single entry); the same object again as
+                # `dominant_by_flops`, and the family that takes the most time in the step as `dominant_by_time`
                 res["roofline"] = dominant_launch_roofline(net, args.batch, h, w)
+                res["roofline"]["dominant_by_flops"] = {k: v for k, v in res["roofline"].items()}
+                try:
+                    res["roofline"]["dominant_by_time"] = time_dominant_gemm_family(net, args.batch, h, w)
+                except Exception as e:  # noqa: BLE001
+                    res["roofline"]["dominant_by_time"] = {"error": repr(e)[:300]}
             except Exception as e:      # noqa: BLE001
                 res["roofline"] = {"error": repr(e)}
         plain = world == 1 and not (args.backbone_only or args.phase or args.ddp_world1 or args.no_graph or args.no_extras)

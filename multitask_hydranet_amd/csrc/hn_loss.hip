@@ -1200,22 +1200,32 @@ __global__ __launch_bounds__(256) void adam_step_kernel(const long* jobs, const 
         const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vv), bc2_sqrt), eps);
         return __fsub_rn(pv, __fmul_rn(lr_over_bc1, __fdiv_rn(mv, denom)));            // param.addcdiv_(exp_avg, denom, value = -step_size)
     };
+    // ONE arithmetic instruction stream for both operand forms (whole aligned float4s / element by element): the vector and the scalar
+    // branch used to carry their own copies of `one`, and the two compiled forms differed by an ulp on a few elements per tensor -- a
+    // data-parallel run (gradients = views at arbitrary offsets of a flat bucket) then drifted from the single-GPU run bit by bit
     const bool vec = i0 + 4 <= n && ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
                                       reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+    float pv[4] = {0.f, 0.f, 0.f, 0.f}, gv[4] = {0.f, 0.f, 0.f, 0.f}, mv[4] = {0.f, 0.f, 0.f, 0.f}, vv[4] = {0.f, 0.f, 0.f, 0.f};
     if (vec) {
-        f32x4 pv = *reinterpret_cast<const f32x4*>(p + i0), gv = *reinterpret_cast<const f32x4*>(g + i0);
-        f32x4 mv = *reinterpret_cast<const f32x4*>(m + i0), vv = *reinterpret_cast<const f32x4*>(v + i0);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p + i0), b = *reinterpret_cast<const f32x4*>(g + i0);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(m + i0), d = *reinterpret_cast<const f32x4*>(v + i0);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { float a = mv[k], b = vv[k]; pv[k] = one(pv[k], gv[k], a, b); mv[k] = a; vv[k] = b; }
-        *reinterpret_cast<f32x4*>(p + i0) = pv;
-        *reinterpret_cast<f32x4*>(m + i0) = mv;
-        *reinterpret_cast<f32x4*>(v + i0) = vv;
+        for (int k = 0; k < 4; ++k) { pv[k] = a[k]; gv[k] = b[k]; mv[k] = c[k]; vv[k] = d[k]; }
     } else {
-        for (long i = i0; i < n && i < i0 + 4; ++i) {
-            float a = m[i], b = v[i];
-            p[i] = one(p[i], g[i], a, b);
-            m[i] = a; v[i] = b;
-        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i0 + k < n) { pv[k] = p[i0 + k]; gv[k] = g[i0 + k]; mv[k] = m[i0 + k]; vv[k] = v[i0 + k]; }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pv[k] = one(pv[k], gv[k], mv[k], vv[k]);
+    if (vec) {
+        *reinterpret_cast<f32x4*>(p + i0) = (f32x4){pv[0], pv[1], pv[2], pv[3]};
+        *reinterpret_cast<f32x4*>(m + i0) = (f32x4){mv[0], mv[1], mv[2], mv[3]};
+        *reinterpret_cast<f32x4*>(v + i0) = (f32x4){vv[0], vv[1], vv[2], vv[3]};
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i0 + k < n) { p[i0 + k] = pv[k]; m[i0 + k] = mv[k]; v[i0 + k] = vv[k]; }
     }
 }
 

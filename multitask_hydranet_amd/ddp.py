@@ -99,25 +99,24 @@ class GradReducer:
 
     # ------------------------------------------------------------------------------------------------------------------------------
     def _close(self, plist):
-        total = sum(p.numel() for _, p in plist)
+        # every parameter's slot starts on a 16-byte boundary of the flat buffer (fusion weights of 2-3 elements, 9-tap depthwise filters ...
+        # would otherwise leave everything behind them at odd offsets: scalar instead of float4 accesses in the Adam / gather / landing
+        # kernels that work on the bucket views).  The padding elements stay zero and ride along in the all-reduce.
+        esize = torch.empty((), dtype=self.payload_dtype).element_size()
+        al = max(1, 16 // esize)
+        offs, off = [], 0
+        for _, p in plist:
+            offs.append(off)
+            off += (p.numel() + al - 1) // al * al
+        total = off
         dev = plist[0][1].device
         flat = torch.zeros(total, device=dev, dtype=self.payload_dtype)
-        views, off = [], 0
-        for _, p in plist:
-            views.append(flat[off:off + p.numel()].view_as(p))
-            off += p.numel()
+        views = [flat[o:o + p.numel()].view_as(p) for o, (_, p) in zip(offs, plist)]
         # fp32 payload: .grad becomes a view of the bucket; reduced payload: a separate fp32 landing buffer receives the averaged values
         land = None
         if self.payload_dtype != torch.float32:
             lflat = torch.zeros(total, device=dev, dtype=torch.float32)
-            land, off = [], 0
-            for _, p in plist:
-                land.append(lflat[off:off + p.numel()].view_as(p))
-                off += p.numel()
-        offs, off = [], 0
-        for _, p in plist:
-            offs.append(off)
-            off += p.numel()
+            land = [lflat[o:o + p.numel()].view_as(p) for o, (_, p) in zip(offs, plist)]
         self.buckets.append(dict(params=plist, flat=flat, views=views, land=land, pending=len(plist), work=None, event=None, src=None, keep=None,
                                  offs=offs))
 
@@ -177,7 +176,7 @@ class GradReducer:
         """bring the bucket's gradients into its flat payload buffer (one multi-tensor launch; converts when the payload is bf16)"""
         src = b["src"] if b["src"] is not None else [p.grad for _, p in b["params"]]
         need = [(v, s) for v, s in zip(b["views"], src) if s.data_ptr() != v.data_ptr()]
-        b["direct_elems"] = b["flat"].numel() - sum(v.numel() for v, _ in need)     # produced in place by the HIP backward (ops.grad_out)
+        b["direct_elems"] = sum(v.numel() for v in b["views"]) - sum(v.numel() for v, _ in need)     # produced in place by the HIP backward (ops.grad_out)
         if need:
             dsts, srcs = [v for v, _ in need], [s for _, s in need]
             same = all(d.dtype == s.dtype for d, s in need)
@@ -342,7 +341,7 @@ class GradReducer:
 
     def direct_fraction(self) -> float:
         """share of the payload elements that the last step's backward wrote straight into the buckets (no gather copy)"""
-        tot = sum(b["flat"].numel() for b in self.buckets)
+        tot = sum(v.numel() for b in self.buckets for v in b["views"])
         return sum(b.get("direct_elems", 0) for b in self.buckets) / max(tot, 1)
 
     def describe(self, after_replay: bool = False) -> str:

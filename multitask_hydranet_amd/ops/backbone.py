@@ -429,13 +429,18 @@ def apply_gate_rows(b, gate):
 
 
 def xblock_fusable(x, w1, stride, has_se, has_shortcut):
-    """the fused node covers XBlocks with SE whose channel counts are multiples of 8 and whose output grid is a multiple of 128 pixels:
-    the stride-1 identity blocks and the stride-2 first block of a stage (projection shortcut)"""
+    """the fused node covers XBlocks with SE whose channel counts are multiples of 8: the stride-1 identity blocks and the stride-2 first
+    block of a stage (projection shortcut), at ANY output grid (round 5: the 128-pixel multiple was a requirement of the register-staged
+    operand-transform loader only -- with it the reference's default 640 x 640 input, whose stages 2-4 are 40 x 40, 20 x 20 and 10 x 10
+    maps, ran 28 of its 30 blocks as the unfused 16 + 27 launch composition and was SLOWER than 512 x 1024).  Every per-image quantity
+    (SE squeeze partial rows, gate rows) uses row blocks that divide the image's pixel count (hn_fused_row_block); the GEMM and conv
+    statistics epilogues mask their tail rows."""
     cout, cin = w1.shape[0], w1.shape[1]
     ho, wo = x.shape[1] // stride, x.shape[2] // stride
     shape_ok = (stride == 1 and not has_shortcut and cout == cin) or (stride == 2 and has_shortcut and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0)
+    xf_ok = not XBLOCK_XF_GEMM or ((ho * wo) % 128 == 0 and 3 * kp32(cout) * 4 <= 32768)
     return (FUSED_XBLOCK and FUSED_BN and GCONV_MFMA and x.is_cuda and has_se and shape_ok and cout % 8 == 0 and cin % 8 == 0
-            and (ho * wo) % 128 == 0 and 3 * kp32(cout) * 4 <= 32768 and x.shape[0] * x.shape[1] * x.shape[2] < (1 << 31))
+            and xf_ok and x.shape[0] * x.shape[1] * x.shape[2] < (1 << 31))
 
 
 # --------------------------------------------------------------------------------------------------------------

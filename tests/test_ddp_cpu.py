@@ -131,7 +131,8 @@ def _worker_real(rank, world, port, q):
         named.append((k, torch.nn.Parameter(torch.zeros(shp))))
     red = GradReducer(list(named), skip=UNUSED_5STAGE)           # DDP's 25 MiB default
     comp = [[n for n, _ in b["params"]] for b in red.buckets]
-    sizes = [int(b["flat"].numel()) for b in red.buckets]
+    sizes = [int(sum(v.numel() for v in b["views"])) for b in red.buckets]          # payload elements (slots start on 16-byte boundaries)
+    assert all(o % 4 == 0 for b in red.buckets for o in b["offs"]) and all(b["flat"].numel() % 4 == 0 for b in red.buckets)
     # after-replay mode on the real composition: static gradients, one exchange
     for j, (n, p) in enumerate(named):
         if n not in UNUSED_5STAGE:

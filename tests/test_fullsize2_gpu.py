@@ -92,8 +92,27 @@ def test_fullsize_backbone_deep_stage(big, stage):
     """every XBlock of stage k (4 / 10 / 14 blocks at 32x64 / 16x32 / 8x16, 152 / 376 / 936 channels), N = 8, teacher-forced BLOCK BY
     BLOCK: block i gets the HIP output of block i-1 as its input on both sides and a fresh random upstream gradient, so each block's
     kernels are checked at full size without the chaotic amplification of a 14-block training-mode chain."""
+    _deep_stage(big, stage, H, W, 8, f"stage{stage}")
+
+
+@pytest.mark.parametrize("stage", [2, 3, 4])
+def test_default_resolution_backbone_deep_stage(big, stage):
+    """the same at the reference's default 640 x 640 input (hydranet_joint_big_backbone.yml:29-30), N = 16: stages 2-4 are 40 x 40 /
+    20 x 20 / 10 x 10 maps -- 1600 / 400 / 100 pixels per image, no multiple of 128: SE partial rows, per-image gate rows and the GEMM /
+    conv statistics epilogues all meet image boundaries inside their tiles.  Every block must take the fused one-node path."""
+    from multitask_hydranet_amd import ops as K
+    calls = []
+    orig = K.XBlockFn.apply
+    try:
+        K.XBlockFn.apply = staticmethod(lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+        _deep_stage(big, stage, 640, 640, 16, f"stage{stage}_640")
+    finally:
+        del K.XBlockFn.apply                       # back to torch.autograd.Function's own classmethod
+    assert len(calls) == big[0].depths[stage], (len(calls), big[0].depths[stage])
+
+
+def _deep_stage(big, stage, H, W, n, tag):
     net, cfgs, O = big
-    n = 8
     p = "backbone.net."
     b = cfgs["backbone"]
     widths, depths, gws = O.regnet_stages(b["initial_width"], b["slope"], b["quantized_param"], b["network_depth"], b["bottleneck_ratio"],
@@ -120,7 +139,7 @@ def test_fullsize_backbone_deep_stage(big, stage):
                                  worst_param_cos=wc, worst_param_err=we)
         bad_all += bad
         cur = o.detach()
-    dump(f"stage{stage}", res)
+    dump(tag, res)
     for k, v in res.items():
         assert v["out"] <= ACT_TOL and v["din_cos"] >= DIN_COS and v["din_rel_l2"] <= DIN_L2, (k, v)
     assert not bad_all, bad_all

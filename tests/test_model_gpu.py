@@ -472,7 +472,9 @@ def test_seg_loss_gradient_handover_is_bit_identical(env):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cin,c,n,h,w", [(32, 24, 2, 32, 48), (64, 152, 4, 32, 64), (368, 936, 4, 16, 32)])
+@pytest.mark.parametrize("cin,c,n,h,w", [(32, 24, 2, 32, 48), (64, 152, 4, 32, 64), (368, 936, 4, 16, 32),
+                                         # output grids that are not multiples of 128 pixels (the 640 x 640 default: 20 x 20 and 10 x 10 maps)
+                                         (152, 376, 4, 40, 40), (376, 936, 16, 20, 20), (64, 152, 8, 12, 20)])
 def test_xblock_stride2_fused_node_equals_unfused_composition(cin, c, n, h, w):
     """The first block of a stage (stride 2, projection shortcut conv + BN, net/anynet.py:55-76) as ONE XBlockFn node -- stride-2 grouped
     conv on the stencil kernels, shortcut data gradient joining conv_block_1's in the GEMM epilogue on the stride-2 sub-grid -- against
@@ -527,7 +529,9 @@ def test_xblock_stride2_fused_node_equals_unfused_composition(cin, c, n, h, w):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("c,n,h,w", [(64, 2, 16, 24), (152, 4, 32, 64), (936, 8, 8, 16)])
+@pytest.mark.parametrize("c,n,h,w", [(64, 2, 16, 24), (152, 4, 32, 64), (936, 8, 8, 16),
+                                     # 640 x 640 default resolution: 40 x 40, 20 x 20, 10 x 10 maps (no multiple of 128 pixels per image)
+                                     (152, 4, 40, 40), (376, 16, 20, 20), (936, 16, 10, 10), (376, 8, 6, 10)])
 def test_xblock_fused_node_equals_unfused_composition(c, n, h, w):
     """ops.XBlockFn (one autograd node, BatchNorm finalize in kernel prologues, SE squeeze on the BN2 pass, BN2 + ReLU + gate applied in
     conv_block_3's operand loader, residual gradient added in conv_block_1's dgrad epilogue) against the composition of ConvBnAct /

@@ -5,7 +5,7 @@ O=$R/gpurun_out/trace
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 cd $R
-rocprofv3 --kernel-trace --output-format csv -d $O/kt -- python3 bench.py --no-cpu-baseline --no-optimizer --no-extras --steps ${STEPS:-3} --warmup 1 "$@" > $O/bench.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $O/kt -- python3 bench.py --no-cpu-baseline --no-optimizer --no-extras --no-roofline --steps ${STEPS:-3} --warmup 1 "$@" > $O/bench.log 2>&1
 f=$(find $O/kt -name "*kernel_trace.csv" | head -1)
 python3 - "$f" > $O/step.csv <<'PY'
 import csv, sys
