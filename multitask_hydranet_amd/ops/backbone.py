@@ -260,7 +260,7 @@ class XBlockFn(torch.autograd.Function):
         make_bg = bg is None
         # SE gate-gradient partials sum_rows dbg * relu(bn2(z2)) from the GEMM's own epilogue (one partial row per pixel tile) where a
         # tile lies inside one image and an image has few tiles (the deep stages); otherwise by a pass over (dbg, z2) below
-        bp = m // lib().query("hn_nt_stat_rows", m, c)
+        bp = lib().query("hn_nt_stat_tile", m, c)       # (not m // rows: a ragged last tile made that 60 for 8 x 60 rows in 64-row tiles)
         ep_dot = EPILOGUE_STATS and not make_bg and hw % bp == 0 and hw // bp <= 16
         dbg, pdot, _ = k_gemm_nt(dz3, None, 0, grid, wt3, c, kp32(c), 1, estat=(1, z2, coef2) if ep_dot else None)
         group = ctx.group                                     # WgradGroup: the 1x1 weight gradients wait for the stage boundary
