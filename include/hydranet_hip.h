@@ -201,18 +201,6 @@ int hn_fuse_fwd(const void* const* in, const int* ld, const int* mode, const flo
 /* the same with the normalisation of the raw fusion parameters inside the kernel (wn [3] is written for the backward pass) */
 int hn_fuse_fwd_raw(const void* const* in, const int* ld, const int* mode, const float* praw, int nw, float eps, float* wn, void* out, int ldo,
                     int N, int H, int W, int C, hipStream_t stream);
-/* One BiFPN node in one launch (round 5; net/bifpn.py:177-231 fusion node + net/common.py:104-114 SeparableConvBlock up to its BatchNorm):
- *   f = swish(sum_i w_i T_i(in_i)), w = relu(praw) / (sum relu(praw) + eps)  ->  d = depthwise3x3(f; wk [9][C], zero pad 1)
- *   ->  z = act(d W^T + bias)  (wp bf16 [Cout][KP], the hn_pack_weight layout; C, Cout <= 128, KP = 32-multiple >= C, <= 128)
- * in[] / ld[] / mode[] as hn_fuse_fwd (mode 0 absent, 1 same grid, 2 nearest x2 of a half-resolution map, 3 zero-pad-same 3x3/s2 max-pool of
- * a double-resolution map).  Same arithmetic, operation order and bf16 rounding points as hn_fuse_fwd_raw -> hn_dwconv_fwd ->
- * hn_conv_gemm_nt.  fout / dout (optional): the fused map and the depthwise output, bf16 [N][H][W][C] -- what the backward pass keeps;
- * wn (optional) [3]: the normalised fusion weights; psum / psq (optional, both or none): fp32 [hn_sepnode_tiles(N,H,W)][Cout] BatchNorm
- * partial statistics of the bf16-rounded pre-activation z (one row per 4 x 16 pixel tile, in-image pixels only). */
-long hn_sepnode_tiles(int N, int H, int W);
-int hn_sepnode_fwd(const void* const* in, const int* ld, const int* mode, const float* praw, int nw, float eps, float* wn, void* fout, int ldf,
-                   const void* wk, void* dout, int ldd, const void* wp, int KP, const float* bias, int act, void* z, int ldz, int Cout,
-                   float* psum, float* psq, int N, int H, int W, int C, hipStream_t stream);
 /* `accumulate` / acc[i] = 1 in hn_fuse_bwd, hn_sum2x2 and hn_maxpool_bwd2: the destination already holds the gradient another consumer of
  * the same tensor wrote (a BiFPN map feeds 2-3 nodes, net/bifpn.py:186-231) and this consumer's contribution is added in place (fp32 add,
  * one bf16 rounding) -- the autograd engine's separate gradient-accumulation kernels disappear (ops.Share / ops.GradSlot). */

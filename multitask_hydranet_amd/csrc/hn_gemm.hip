@@ -230,9 +230,6 @@ __device__ __forceinline__ void stat_terms4(int emode, const f32x4 q, const f32x
 // PLAIN: plain pixel rows of ONE tensor, one tap (x.mode 0: every 1x1 conv and its data gradient) -- no coordinate tables, no tap
 // bookkeeping, per-row source offsets computed once: the generic form carries ~1 000 instructions of prologue and a branchy loop body for
 // the 3x3 / stride-2 / concat modes that these launches (the latency-bound majority of the step's GEMMs) never use.
-#ifndef HN_NT_REGS
-#define HN_NT_REGS 0          // register-staged operand prefetch depth of the plain-rows instantiation (0: the LDS-DMA double buffer; tools/ab_tree.sh A/B)
-#endif
 template <int BC, int BP, int WGC, int WGP, bool OUT_F32, int R, bool XF = false, int KG = 1, bool PLAIN = false>
 __global__ __launch_bounds__(256 * KG) void gemm_nt_kernel(const GemmNT p) {
     static_assert(!XF || R == 2, "the register-staged operand transform is written for the double buffer");
@@ -367,65 +364,6 @@ __global__ __launch_bounds__(256 * KG) void gemm_nt_kernel(const GemmNT p) {
         }
         __syncthreads();                                          // the first transform (end of iteration 0) reads other threads' entries
     }
-    // PLAIN + HN_NT_REGS (round 5): the double buffer above keeps ONE stage per K group in flight while a stage is multiplied, and a stage's
-    // multiply (8 MFMAs) is a tenth of a load's trip from the Infinity Cache -- every K step of the latency-bound 1x1 GEMMs exposed a whole
-    // memory latency (0.6-1 us per step; LDS cannot hold a deeper ring without costing the co-resident workgroup that hides the rest).
-    // Here the operand stages travel through REGISTERS, HN_NT_REGS (2) stages ahead: step st writes the registers holding stage st (requested
-    // two steps ago) to LDS buffer st & 1, requests stage st + 2 into the same registers, barrier, multiply -- twice the bytes in flight per
-    // workgroup for 16 VGPRs per stage (the kernel has 71), same LDS image as the DMA path (lane-linear 16-byte pieces, source-side swizzle).
-    if constexpr (PLAIN && HN_NT_REGS > 0 && R == 2 && BC == 64 && BP == 64) {     // the 64 x 64 tile: the latency-bound launches (small_tile)
-        constexpr int D = HN_NT_REGS > 0 ? HN_NT_REGS : 1;
-        bf16x8 rx[D][XR], rw[D][WR];
-        auto fetch = [&](int st, bf16x8 (&dx)[XR], bf16x8 (&dw)[WR]) {
-            const int q = 2 * (st * KG + kg) + half;                  // (one tap: the chunk index is the channel block)
-            const bool qv = st < S && q < Q;
-            const int c = q * 32 + sub;
-            const bool cv = qv && c < Ctot;
-#pragma unroll
-            for (int i = 0; i < XR; ++i) dx[i] = ld8((cv && xoff[i] >= 0) ? p.x.x0 + xoff[i] + c : g_zero_piece);
-#pragma unroll
-            for (int i = 0; i < WR; ++i) dw[i] = ld8((qv && wo[i] >= 0) ? wimg + wo[i] + q * 32 : g_zero_piece);
-        };
-        auto stash = [&](int buf, const bf16x8 (&dx)[XR], const bf16x8 (&dw)[WR]) {
-            char* sW = smem + (buf * KG + kg) * STAGE;
-            char* sX = sW + BC * 128;
-#pragma unroll
-            for (int i = 0; i < XR; ++i) *reinterpret_cast<bf16x8*>(sX + (r0 + 32 * i) * 128 + (tid & 7) * 16) = dx[i];
-#pragma unroll
-            for (int i = 0; i < WR; ++i) *reinterpret_cast<bf16x8*>(sW + (r0 + 32 * i) * 128 + (tid & 7) * 16) = dw[i];
-        };
-        auto multiply = [&](int buf) {
-            const char* sW = smem + (buf * KG + kg) * STAGE;
-            const char* sX = sW + BC * 128;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 a[TC], b[TP];
-                const int piece = ks * 4 + (lane >> 4);
-#pragma unroll
-                for (int i = 0; i < TC; ++i) a[i] = *reinterpret_cast<const bf16x8*>(sW + swz(wc * WC + i * 16 + (lane & 15), piece));
-#pragma unroll
-                for (int j = 0; j < TP; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sX + swz(wp * WP + j * 16 + (lane & 15), piece));
-#pragma unroll
-                for (int i = 0; i < TC; ++i)
-#pragma unroll
-                    for (int j = 0; j < TP; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-            }
-        };
-#pragma unroll
-        for (int d = 0; d < D; ++d) fetch(d, rx[d], rw[d]);
-        for (int it = 0; it < S; it += D) {
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                if (it + d < S) {                                      // (workgroup-uniform)
-                    stash((it + d) & 1, rx[d], rw[d]);
-                    fetch(it + d + D, rx[d], rw[d]);
-                    __syncthreads();
-                    multiply((it + d) & 1);
-                }
-            }
-        }
-    } else
     for (int it = 0; it < S + R - 1; ++it) {
         if (it >= R - 1) {
             const int newer = (it < S ? it : S) - 1 - (it - (R - 1));

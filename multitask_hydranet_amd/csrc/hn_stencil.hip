@@ -1899,240 +1899,3 @@ extern "C" int hn_fuse_dweights(const float* pw, int blocks, const float* praw, 
     HN_LAUNCH_CHECK();
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// One BiFPN node in ONE launch (round 5): fusion -> Swish -> depthwise 3x3 -> pointwise 1x1 + bias (+ BatchNorm partial statistics)
-//   f = swish(sum_i w_i T_i(in_i))   (net/bifpn.py:177-231)      d = dw3x3(f), zero pad 1      z = d W^T + b   (net/common.py:104-114)
-// The three stages have no global dependency between them (the BatchNorm statistics come last), yet they ran as three dependent launches
-// (fuse 9 us, depthwise 8 us, GEMM 11 us on average: 24 nodes = 0.7 ms of the 1.04 ms neck forward), each writing a map the next one
-// read back.  Here a workgroup owns a 4 x 16 output patch: the fused map of the patch + a one-pixel halo (6 x 18) is built in LDS (the
-// halo is recomputed, 1.7x -- the fusion is a handful of loads per pixel), the depthwise conv reads it from there and leaves the [64][C]
-// operand tile in LDS, and four waves multiply it with the pointwise weights (LDS-DMA'd at kernel start, under the fusion's loads) on
-// MFMA 16x16x32.  Same arithmetic, operation order and bf16 rounding points as hn_fuse_fwd -> hn_dwconv_fwd -> hn_conv_gemm_nt.
-// f and d are still written (once, never read back here) when the backward pass wants them; z leaves as whole per-pixel runs.
-// LDS: fused patch 108 x 256 B | operand tile 64 x 256 B (XOR (row & 15) swizzle: conflict-free ds_read_b128 of 16 rows) | taps | bias |
-// weights Cout x 256 B (same swizzle) = 75.5 KB at Cout = 112: two workgroups per CU.
-// ---------------------------------------------------------------------------------------------------------
-struct SepNode {
-    Fuse f;                  // f.out / f.ldo: the fused map (kept for the depthwise weight gradient / fusion backward) or null
-    const bf16* wk;          // depthwise taps [9][C]
-    const bf16* wp;          // pointwise weights [Cout][KP]
-    int KP;
-    const float* bias;       // [Cout] or null
-    bf16* d; int ldd;        // depthwise output (kept for the pointwise weight gradient) or null
-    bf16* z; int ldz;        // [N*H*W][Cout]
-    float* psum; float* psq; // [tiles][Cout] or null: sums / sums of squares of the bf16-rounded z over the tile's in-image pixels
-    int Cout, act, tiles_x, tiles_y;
-};
-#define SN_TH 4
-#define SN_TW 16
-#define SN_HP ((SN_TH + 2) * (SN_TW + 2))
-#define SN_ROW 256
-__device__ __attribute__((aligned(16))) bf16 sn_zero_piece[8];
-__device__ __forceinline__ void sn_glds16(const bf16* src, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-// FUSE = true: the fusion is computed here (per-thread gathers: a dependent load round per item -- latency-bound at two workgroups per CU);
-// FUSE = false: in[0] IS the fused map (hn_fuse_fwd ran as its own fully parallel launch) and the 6 x 18 patch arrives by LDS-DMA, every
-// piece in flight at once: one memory latency per workgroup for patch and weights together.
-template <bool FUSE>
-__global__ __launch_bounds__(256, 2) void sepnode_fwd_kernel(const SepNode p) {
-    extern __shared__ __attribute__((aligned(16))) char sn_smem[];
-    char* sF = sn_smem;
-    char* sD = sF + SN_HP * SN_ROW;
-    char* sWk = sD + 64 * SN_ROW;
-    float* sBias = reinterpret_cast<float*>(sWk + 9 * SN_ROW);
-    char* sW = reinterpret_cast<char*>(sBias + 128);
-    const Fuse& f = p.f;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int C8 = f.C >> 3;
-    const int bidx = xcd_remap(blockIdx.x, gridDim.x);     // row-order placement convention (hn_common.h)
-    int t = bidx;
-    const int tx = t % p.tiles_x;
-    t /= p.tiles_x;
-    const int ty = t % p.tiles_y;
-    const long n = t / p.tiles_y;
-    const int oy0 = ty * SN_TH, ox0 = tx * SN_TW;
-    // (1) pointwise weights by LDS-DMA, requested first: their latency runs under the fusion stage.  Slot s = row * 16 + physical piece;
-    // the swizzle is applied on the SOURCE side (the DMA image is lane-linear)
-    const int wrows = (p.Cout + 15) & ~15;
-    for (int i = 0; i * 256 < wrows * 16; ++i) {
-        const int s = i * 256 + tid, row = s >> 4, lp = (s & 15) ^ (row & 15);
-        const bf16* src = (row < p.Cout && lp * 8 < p.KP) ? p.wp + (long)row * p.KP + lp * 8 : sn_zero_piece;
-        sn_glds16(src, sW + (i * 256 + wave * 64) * 16);
-    }
-    if (tid < 9 * 16) {
-        const int tap = tid >> 4, cg = tid & 15;
-        *reinterpret_cast<bf16x8*>(sWk + tap * SN_ROW + cg * 16) = cg < C8 ? ld8(p.wk + (long)tap * f.C + cg * 8) : zero8();
-    }
-    if (tid < 128) sBias[tid] = (p.bias && tid < p.Cout) ? p.bias[tid] : 0.f;
-    float wv[3] = {0.f, 0.f, 0.f};
-    if constexpr (FUSE) {              // w = relu(p) / (sum relu(p) + eps), net/bifpn.py:179-180 (as fuse_fwd_kernel)
-        float sum = 0.f;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { wv[i] = i < f.nw ? fmaxf(f.praw[i], 0.f) : 0.f; sum += wv[i]; }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) wv[i] = wv[i] / (sum + f.eps);
-        if (f.wn && bidx == 0 && tid < 3) f.wn[tid] = wv[tid];
-    }
-    if constexpr (!FUSE) {
-        // (2') the patch of the given map by LDS-DMA (lane-linear image = the [pixel][16 pieces] layout the depthwise stage reads)
-        for (int i = 0; i * 256 < SN_HP * 16; ++i) {
-            if (i * 256 + wave * 64 < SN_HP * 16) {                    // (wave-uniform: 1728 = 27 waves of 64 slots)
-                const int s_ = i * 256 + tid, cg = s_ & 15, hp = s_ >> 4;
-                const int hy = hp / (SN_TW + 2), hx = hp - hy * (SN_TW + 2);
-                const int y = oy0 - 1 + hy, x = ox0 - 1 + hx;
-                const bf16* src = (cg < C8 && y >= 0 && y < f.H && x >= 0 && x < f.W) ? f.in[0] + ((n * f.H + y) * (long)f.W + x) * f.ld[0] + cg * 8
-                                                                                      : sn_zero_piece;
-                sn_glds16(src, sF + (i * 256 + wave * 64) * 16);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-    // (2) fused map of the patch + halo -> LDS (zeros outside the image: the depthwise conv's zero padding); interior pixels also to f.out
-    for (int idx = tid; idx < SN_HP * 16; idx += 256) {
-        const int cg = idx & 15, hp = idx >> 4;
-        if (cg >= C8) continue;
-        const int hy = hp / (SN_TW + 2), hx = hp - hy * (SN_TW + 2);
-        const int y = oy0 - 1 + hy, x = ox0 - 1 + hx;
-        bf16x8 o = zero8();
-        if (y >= 0 && y < f.H && x >= 0 && x < f.W) {
-            float acc[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                if (!f.mode[i]) continue;
-                float v[8];
-                fuse_gather(f, i, n, y, x, cg * 8, v);
-                const float wi = wv[i];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) acc[k] = fmaf(wi, v[k], acc[k]);
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) o[k] = f2bf(act_fwd(acc[k], HN_ACT_SWISH));
-            if (f.out && hy >= 1 && hy <= SN_TH && hx >= 1 && hx <= SN_TW) st8(f.out + ((n * f.H + y) * (long)f.W + x) * f.ldo + cg * 8, o);
-        }
-        *reinterpret_cast<bf16x8*>(sF + hp * SN_ROW + cg * 16) = o;
-    }
-    }
-    __syncthreads();
-    // (3) depthwise 3x3 out of the LDS patch -> operand tile [64 px][128 ch] (channels >= C zero: the GEMM's K padding), and to p.d
-    for (int idx = tid; idx < 64 * 16; idx += 256) {
-        const int cg = idx & 15, px = idx >> 4, py = px >> 4, pxx = px & 15;
-        bf16x8 o = zero8();
-        if (cg < C8) {
-            float acc[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const bf16x8 r = *reinterpret_cast<const bf16x8*>(sF + ((py + ky) * (SN_TW + 2) + pxx + kx) * SN_ROW + cg * 16);
-                    const bf16x8 w8 = *reinterpret_cast<const bf16x8*>(sWk + (ky * 3 + kx) * SN_ROW + cg * 16);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) acc[k] = fmaf(bf2f(r[k]), bf2f(w8[k]), acc[k]);
-                }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) o[k] = f2bf(acc[k]);
-            const int y = oy0 + py, x = ox0 + pxx;
-            if (p.d && y < f.H && x < f.W) st8(p.d + ((n * f.H + y) * (long)f.W + x) * p.ldd + cg * 8, o);
-        }
-        *reinterpret_cast<bf16x8*>(sD + px * SN_ROW + ((cg ^ (px & 15)) << 4)) = o;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the weight DMA
-    __syncthreads();
-    // (4) pointwise conv on MFMA: wave = the 16 pixels of patch row `wave` x all couts; D[cout][px]: lane = px (lane & 15), couts (lane >> 4) * 4 + r
-    const int ntile = wrows >> 4, ksteps = p.KP >> 5;
-    const int prow = wave * 16 + (lane & 15), kg = lane >> 4;
-    f32x4 acc[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int ks = 0; ks < ksteps; ++ks) {
-        const int lp = ks * 4 + kg;
-        const bf16x8 b = *reinterpret_cast<const bf16x8*>(sD + prow * SN_ROW + ((lp ^ (lane & 15)) << 4));
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (i < ntile) {                                           // (wave-uniform)
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(sW + (i * 16 + (lane & 15)) * SN_ROW + ((lp ^ (lane & 15)) << 4));
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
-            }
-        }
-    }
-    // z = acc + bias, rounded to bf16; statistics of the rounded values (as the GEMM's statistics epilogue); the wave stages its 16 output rows
-    // in its OWN rows of the operand tile (its reads of them are complete) so that they leave as whole per-pixel runs
-    const int y = oy0 + wave, x = ox0 + (lane & 15);
-    const bool pv = y < f.H && x < f.W;
-    float* red = reinterpret_cast<float*>(sF);                         // [4 waves][128][2] (the fused patch is dead)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        if (i < ntile) {
-            const int co0 = i * 16 + kg * 4;
-            float q[4], s1[4], s2[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) q[r] = acc[i][r] + sBias[co0 + r];
-            if (p.psum) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float qf = pv ? bfround(q[r]) : 0.f;
-                    s1[r] = row16_sum(qf);
-                    s2[r] = row16_sum(qf * qf);
-                }
-                if ((lane & 15) == 0) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { red[(wave * 128 + co0 + r) * 2] = s1[r]; red[(wave * 128 + co0 + r) * 2 + 1] = s2[r]; }
-                }
-            }
-            act_fwd_n(q, p.act);
-            const bf16x4 zv = {f2bf(q[0]), f2bf(q[1]), f2bf(q[2]), f2bf(q[3])};
-            *reinterpret_cast<bf16x4*>(sD + prow * SN_ROW + co0 * 2) = zv;
-        }
-    }
-    __syncthreads();
-    if (p.psum && tid < p.Cout) {                                      // one partial row per tile: the four wave sums in fixed order
-        float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) { t1 += red[(w * 128 + tid) * 2]; t2 += red[(w * 128 + tid) * 2 + 1]; }
-        p.psum[(long)bidx * p.Cout + tid] = t1;
-        p.psq[(long)bidx * p.Cout + tid] = t2;
-    }
-    const int Co8 = p.Cout >> 3;
-    if (y < f.H) {
-        for (int s = lane; s < 256; s += 64) {
-            const int pl = s >> 4, pc = s & 15, xx = ox0 + pl;
-            if (pc < Co8 && xx < f.W)
-                st8(p.z + ((n * f.H + y) * (long)f.W + xx) * p.ldz + pc * 8, *reinterpret_cast<const bf16x8*>(sD + (wave * 16 + pl) * SN_ROW + pc * 16));
-        }
-    }
-}
-
-extern "C" long hn_sepnode_tiles(int N, int H, int W) { return (long)N * ((H + SN_TH - 1) / SN_TH) * ((W + SN_TW - 1) / SN_TW); }
-extern "C" int hn_sepnode_fwd(const void* const* in, const int* ld, const int* mode, const float* praw, int nw, float eps, float* wn, void* fout,
-                              int ldf, const void* wk, void* dout, int ldd, const void* wp, int KP, const float* bias, int act, void* z, int ldz,
-                              int Cout, float* psum, float* psq, int N, int H, int W, int C, hipStream_t st) {
-    static std::atomic<unsigned long long> optin{0};
-    HN_CHECK_ARG(((praw && nw >= 1 && nw <= 3) || (nw == 0 && mode && mode[0] == 1 && mode[1] == 0 && mode[2] == 0 && !fout)) && wk && wp && z &&
-                 N > 0 && H > 0 && W > 0);
-    HN_CHECK_ARG(C > 0 && C <= 128 && (C & 7) == 0 && Cout > 0 && Cout <= 128 && (Cout & 7) == 0 && KP >= C && KP <= 128 && (KP & 31) == 0);
-    HN_CHECK_ARG((ldz & 7) == 0 && ldz >= Cout && (!fout || ((ldf & 7) == 0 && ldf >= C)) && (!dout || ((ldd & 7) == 0 && ldd >= C)));
-    HN_CHECK_ARG((psum == nullptr) == (psq == nullptr));
-    HN_CHECK_ARG(act >= HN_ACT_NONE && act <= HN_ACT_SIGMOID);
-    SepNode p;
-    const int rc = fill_fuse(p.f, in, ld, mode, nullptr, fout, fout ? ldf : 0, N, H, W, C);
-    if (rc) return rc;
-    HN_CHECK_ARG(mode[0] != 0 || mode[1] != 0 || mode[2] != 0);
-    p.f.praw = praw; p.f.nw = nw; p.f.eps = eps; p.f.wn = wn;
-    p.wk = (const bf16*)wk; p.wp = (const bf16*)wp; p.KP = KP; p.bias = bias; p.d = (bf16*)dout; p.ldd = ldd; p.z = (bf16*)z; p.ldz = ldz;
-    p.psum = psum; p.psq = psq; p.Cout = Cout; p.act = act;
-    p.tiles_x = (W + SN_TW - 1) / SN_TW; p.tiles_y = (H + SN_TH - 1) / SN_TH;
-    const long tiles = (long)N * p.tiles_x * p.tiles_y;
-    HN_CHECK_ARG(tiles < (1L << 31));
-    const int wrows = (Cout + 15) & ~15;
-    const size_t lds = (size_t)SN_HP * SN_ROW + 64 * SN_ROW + 9 * SN_ROW + 128 * 4 + (size_t)wrows * SN_ROW;
-    if (!lds_optin(optin, {(const void*)sepnode_fwd_kernel<true>, (const void*)sepnode_fwd_kernel<false>})) return HN_ERR_LAUNCH;
-    // nw == 0: in[0] is the fused map itself (mode 1, no other input): depthwise + pointwise only, patch by LDS-DMA
-    if (nw == 0) hipLaunchKernelGGL(sepnode_fwd_kernel<false>, dim3((unsigned)tiles), dim3(256), lds, st, p);
-    else hipLaunchKernelGGL(sepnode_fwd_kernel<true>, dim3((unsigned)tiles), dim3(256), lds, st, p);
-    HN_LAUNCH_CHECK();
-}

@@ -460,20 +460,6 @@ class HydraNet(nn.Module):
         d = K.DwConv.apply(x, P[name + ".depthwise_conv.conv.weight"])
         return self._cba(d, name + ".pointwise_conv.conv", name + ".bn", BN_FPN, act=act)
 
-    def _sepnode(self, name, praw, modes, ins, slots):
-        """one BiFPN node: fusion + Swish + SeparableConvBlock (net/bifpn.py:177-231, net/common.py:104-114) -- ops.SepNode (fusion,
-        depthwise and pointwise conv in one launch) where the channel counts allow, else the Fuse -> DwConv -> ConvBnAct composition"""
-        P = self._idx
-        dw_w, pw_w = P[name + ".depthwise_conv.conv.weight"], P[name + ".pointwise_conv.conv.weight"]
-        if K.sepnode_ok(ins[0], dw_w, pw_w):
-            fold = self._folded.get(name + ".pointwise_conv.conv") if (self._folded is not None and not self.training) else None
-            if fold is not None:
-                return K.sepnode_infer(praw, modes, ins, dw_w, fold[0], fold[1], pw_w.shape[0])
-            g, b, rm, rv, _ = self._bn(name + ".bn")
-            return K.SepNode.apply(praw, *modes, *ins, slots, dw_w, pw_w, P.get(name + ".pointwise_conv.conv.bias"), g, b, rm, rv,
-                                   BN_FPN["eps"], BN_FPN["momentum"], self.training)
-        return self._sepconv(name, K.Fuse.apply(praw, *modes, *ins, slots))
-
     def _fusew(self, name):
         return self._idx[name]                      # raw fusion parameter; relu / normalisation happen inside the Fuse op
 
@@ -509,16 +495,16 @@ class HydraNet(nn.Module):
             (p7a, p7b), s7 = sh(p7_in, 2)
         else:
             (p7a, p7b), s7 = inputs[4]
+        F = K.Fuse.apply
         w = lambda nm: self._fusew(p + nm)
-        node = lambda conv, wn, modes, ins, slots: self._sepnode(p + conv, w(wn), modes, ins, slots)
-        (u6a, u6b), t6 = sh(node("conv6_up", "p6_w1", (1, 2, 0), (p6a, p7a, None), (s6, s7, None)), 2)
-        (u5a, u5b), t5 = sh(node("conv5_up", "p5_w1", (1, 2, 0), (p5a, u6a, None), (s5a, t6, None)), 2)
-        (u4a, u4b), t4 = sh(node("conv4_up", "p4_w1", (1, 2, 0), (p4a, u5a, None), (s4a, t5, None)), 2)
-        o3, q3 = sh(node("conv3_up", "p3_w1", (1, 2, 0), (p3a, u4a, None), (s3, t4, None)), 1 + ext[0])
-        o4, q4 = sh(node("conv4_down", "p4_w2", (1, 1, 3), (p4b, u4b, o3[0]), (s4b, t4, q3)), 1 + ext[1])
-        o5, q5 = sh(node("conv5_down", "p5_w2", (1, 1, 3), (p5b, u5b, o4[0]), (s5b, t5, q4)), 1 + ext[2])
-        o6, q6 = sh(node("conv6_down", "p6_w2", (1, 1, 3), (p6b, u6b, o5[0]), (s6, t6, q5)), 1 + ext[3])
-        o7, q7 = sh(node("conv7_down", "p7_w2", (1, 3, 0), (p7b, o6[0], None), (s7, q6, None)), ext[4])
+        (u6a, u6b), t6 = sh(self._sepconv(p + "conv6_up", F(w("p6_w1"), 1, 2, 0, p6a, p7a, None, (s6, s7, None))), 2)
+        (u5a, u5b), t5 = sh(self._sepconv(p + "conv5_up", F(w("p5_w1"), 1, 2, 0, p5a, u6a, None, (s5a, t6, None))), 2)
+        (u4a, u4b), t4 = sh(self._sepconv(p + "conv4_up", F(w("p4_w1"), 1, 2, 0, p4a, u5a, None, (s4a, t5, None))), 2)
+        o3, q3 = sh(self._sepconv(p + "conv3_up", F(w("p3_w1"), 1, 2, 0, p3a, u4a, None, (s3, t4, None))), 1 + ext[0])
+        o4, q4 = sh(self._sepconv(p + "conv4_down", F(w("p4_w2"), 1, 1, 3, p4b, u4b, o3[0], (s4b, t4, q3))), 1 + ext[1])
+        o5, q5 = sh(self._sepconv(p + "conv5_down", F(w("p5_w2"), 1, 1, 3, p5b, u5b, o4[0], (s5b, t5, q4))), 1 + ext[2])
+        o6, q6 = sh(self._sepconv(p + "conv6_down", F(w("p6_w2"), 1, 1, 3, p6b, u6b, o5[0], (s6, t6, q5))), 1 + ext[3])
+        o7, q7 = sh(self._sepconv(p + "conv7_down", F(w("p7_w2"), 1, 3, 0, p7b, o6[0], None, (s7, q6, None))), ext[4])
         return [(o3[1:], q3), (o4[1:], q4), (o5[1:], q5), (o6[1:], q6), (o7, q7)]
 
     def first_cell_counts(self):

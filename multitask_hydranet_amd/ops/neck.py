@@ -250,112 +250,4 @@ def fuse_backward(praw, w, ins, modes, slots, queue, pref, dout):
     return dpraw, [None if (slots[i] is not None or not modes[i]) else dst[i] for i in range(3)]
 
 
-# --------------------------------------------------------------------------------------------------------------
-# One BiFPN node = fusion -> Swish -> SeparableConvBlock (depthwise 3x3 -> pointwise 1x1 + bias -> BatchNorm), net/bifpn.py:177-231 +
-# net/common.py:104-114, as ONE autograd node whose forward is two launches: hn_sepnode_fwd (fusion, depthwise and pointwise conv of a
-# 4 x 16 pixel patch without leaving the workgroup, + BatchNorm partial statistics) and the fused BatchNorm apply pass.  The composition
-# Fuse -> DwConv -> ConvBnAct is four launches (five where the partial rows need a fold) that pass two intermediate maps through memory.
-# Backward = the same kernels as that composition, in the same order.
-# --------------------------------------------------------------------------------------------------------------
-SEPNODE = policy("HN_SEPNODE", "1") != "0"
-
-
-def sepnode_ok(a, dw_w, pw_w):
-    c, cout = dw_w.shape[0], pw_w.shape[0]
-    return (SEPNODE and FUSED_BN and a.is_cuda and a.dtype == BF16 and a.dim() == 4 and c <= 128 and cout <= 128 and c % 8 == 0 and cout % 8 == 0
-            and pw_w.shape[1] == c and pw_w.shape[2] == 1)
-
-
-SEPNODE_FUSE_INSIDE = int(policy("HN_SEPNODE_FUSE_INSIDE", "0"))     # > 0: maps of up to this many pixels per image compute the fusion in-kernel too
-
-
-def k_sepnode(praw, modes, ins, wk, wp, kp, bias, cout, act=ACT_NONE, want_fd=True, stats=True, wn=None, inside=None):
-    """-> (f | None, d | None, z, psum | None, psq | None, wn).  inside: the fusion runs inside the node kernel (one launch; per-thread gathers)
-    instead of as its own elementwise launch in front of the depthwise + pointwise kernel (two launches; the patch arrives by LDS-DMA)."""
-    a = ins[0]
-    n, h, wd, c = a.shape
-    dev = a.device
-    if inside is None:
-        inside = h * wd <= SEPNODE_FUSE_INSIDE
-    d = new_act(n, h, wd, c, dev) if want_fd else None
-    z = new_act(n, h, wd, cout, dev)
-    ps = pq = None
-    if stats:
-        tiles = lib().query("hn_sepnode_tiles", n, h, wd)
-        ps = torch.empty((tiles, cout), device=dev, dtype=F32)
-        pq = torch.empty((tiles, cout), device=dev, dtype=F32)
-    if wn is None:
-        wn = torch.empty((3,), device=dev, dtype=F32)
-    ap, al, am = _fuse_args(ins, modes)
-    if inside:
-        f = new_act(n, h, wd, c, dev) if want_fd else None
-        lib().call("hn_sepnode_fwd", ctypes.addressof(ap), ctypes.addressof(al), ctypes.addressof(am), ptr(praw), praw.numel(), 1e-4, ptr(wn),
-                   ptr(f), ld(f) if f is not None else 0, ptr(wk), ptr(d), ld(d) if d is not None else 0, ptr(wp), kp, ptr(bias), act, ptr(z),
-                   ld(z), cout, ptr(ps), ptr(pq), n, h, wd, c)
-        return f, d, z, ps, pq, wn
-    f = new_act(n, h, wd, c, dev)
-    lib().call("hn_fuse_fwd_raw", ctypes.addressof(ap), ctypes.addressof(al), ctypes.addressof(am), ptr(praw), praw.numel(), 1e-4, ptr(wn),
-               ptr(f), ld(f), n, h, wd, c)
-    fp, fl, fm = _fuse_args([f, None, None], [1, 0, 0])
-    lib().call("hn_sepnode_fwd", ctypes.addressof(fp), ctypes.addressof(fl), ctypes.addressof(fm), None, 0, 0.0, None, None, 0, ptr(wk), ptr(d),
-               ld(d) if d is not None else 0, ptr(wp), kp, ptr(bias), act, ptr(z), ld(z), cout, ptr(ps), ptr(pq), n, h, wd, c)
-    return f, d, z, ps, pq, wn
-
-
-class SepNode(torch.autograd.Function):
-    """out = BN(pointwise(depthwise(swish(sum_i w_i T_i(in_i)))) + bias); modes / slots as ops.Fuse; bn = (gamma, beta, running_mean,
-    running_var)."""
-
-    @staticmethod
-    def forward(ctx, praw, m0, m1, m2, a, b, c, slots, dw_w, pw_w, pw_b, gamma, beta, rm, rv, eps, momentum, training):
-        assert m0 == 1
-        ins, modes = [a, b, c], [m0, m1, m2]
-        n, h, wd, ch = a.shape
-        cout = pw_w.shape[0]
-        wk, wf = pack_dw_weight(dw_w)
-        wp, wt = pack_conv_weight(pw_w)
-        need_bwd = training and any(ctx.needs_input_grad)          # (grad mode is off inside forward(): ask what autograd wants back)
-        f, d, z, ps, pq, w = k_sepnode(praw, modes, ins, wk, wp, kp32(ch), pw_b, cout, want_fd=need_bwd, stats=training)
-        count = n * h * wd
-        out, coef, _, _ = k_bn_apply_fused(z, ps, pq, count, gamma, beta, eps, momentum, rm, rv, ACT_NONE, training=training)
-        ctx.modes, ctx.count, ctx.training = modes, count, training
-        ctx.slots = slots if slots is not None else (None, None, None)
-        q = cur_queue()
-        ctx.q_fuse, ctx.q_dw, ctx.q_pw = (q if praw.requires_grad else None), (q if dw_w.requires_grad else None), (q if (training and pw_w.requires_grad) else None)
-        ctx.wrefs = (praw, dw_w, pw_w)
-        ctx.has_bias = pw_b is not None
-        ctx.packs = (wf, wt)
-        ctx.save_for_backward(praw, w, f, d, z, coef, *[t for t in ins if t is not None])
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        praw, w, f, d, z, coef = ctx.saved_tensors[:6]
-        rest = list(ctx.saved_tensors[6:])
-        assert ctx.training, "backward through eval-mode BatchNorm is not part of the hot path"
-        ins = [rest.pop(0) if m else None for m in ctx.modes]
-        wf, wt = ctx.packs
-        pref, dw_ref, pw_ref = ctx.wrefs
-        dout = dense(dout)
-        n, h, wd, cout = z.shape
-        ch = f.shape[3]
-        # a conv bias that feeds BatchNorm has zero gradient: the zeros come out of the BN backward launch (no fill kernel)
-        dbias = torch.empty((cout,), device=z.device, dtype=F32) if ctx.has_bias else None
-        dz, dgamma, dbeta, _ = bn_backward_fused(dout, z, None, coef, ACT_NONE, ctx.count, zero_c=dbias)
-        dd, _, _ = k_gemm_nt(dz, None, 0, (n, h, wd), wt, ch, kp32(cout), 1)
-        if ctx.q_pw is not None:
-            dpw = ctx.q_pw.add_gemm(pw_ref, d, dz, 0, (n, h, wd), ch, cout)
-        else:
-            dpw = k_gemm_tn(d, None, 0, (n, h, wd), dz, cout, kp32(ch), 1, ch)
-        df, ddw = k_dwconv_bwd(dd, f, wf, want_dx=True, queue=ctx.q_dw, weight=dw_ref)
-        dpraw, dins = fuse_backward(praw, w, ins, ctx.modes, ctx.slots, ctx.q_fuse, pref, df)
-        return (dpraw, None, None, None, dins[0], dins[1], dins[2], None, ddw, dpw, dbias, dgamma, dbeta, None, None, None, None, None)
-
-
-def sepnode_infer(praw, modes, ins, dw_w, packed, bias, cout, act=ACT_NONE):
-    """the node with BatchNorm folded into the pointwise weights (HydraNet.prepare_inference): ONE launch, no intermediate map"""
-    wk, _ = pack_dw_weight(dw_w)
-    return k_sepnode(praw, modes, ins, wk, packed, kp32(dw_w.shape[0]), bias, cout, act=act, want_fd=False, stats=False)[2]
-
-
 __all__ = [n for n in dir() if not n.startswith("__")]      # everything, incl. single-underscore helpers: the package is one namespace
