@@ -219,7 +219,7 @@ def measured_traffic(n, h, w, form):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 correction +
     WRITE_SIZE, separate passes: PMC counters cannot be read from inside this process).  The figure belongs to ONE workload: it is only
     emitted when batch, resolution and kernel form match what the profile recorded; otherwise null."""
-    for name in ("r04_dominant_pmc.json", "r03_dominant_pmc.json", "r02_dominant_pmc.json"):
+    for name in ("r05_dominant_pmc.json", "r04_dominant_pmc.json", "r03_dominant_pmc.json", "r02_dominant_pmc.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             with open(path) as f:

@@ -2,7 +2,7 @@
 # gpurun_out/prof (tools/run_profiles.sh) + gpurun_out/segtrace_out.txt (tools/seg_trace.sh) -> profiles/${ROUND}_*
 R=$(cd "$(dirname "$0")/.." && pwd)
 P=$R/gpurun_out/prof
-ROUND=${ROUND:-r04}
+ROUND=${ROUND:-r05}
 cp $P/bench_n1.json $R/profiles/${ROUND}_bench_n1.json
 cp $P/kernel_stats.csv $R/profiles/${ROUND}_kernel_stats_hipgraph_b16_512x1024.csv
 cp $P/dominant_dispatches.csv $R/profiles/${ROUND}_dominant_dispatches.csv

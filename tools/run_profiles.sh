@@ -3,7 +3,7 @@
 # dispatch rows, PMC passes (HBM traffic + MFMA counters) on the dominant launch, the counter-backed roofline table of the whole step.
 # -> gpurun_out/prof/*; tools/copy_profiles.sh copies the summaries to profiles/${ROUND}_*
 R=${GRAFT_REPO_ROOT:-/root/repo}
-ROUND=${ROUND:-r04}
+ROUND=${ROUND:-r05}
 O=$R/gpurun_out/prof
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
