@@ -138,17 +138,6 @@ int hn_conv_gemm_tn(const void* x0, const void* x1, int mode, int n_img, int H, 
 
 /* ---- NHWC stencils (hn_stencil.hip) ----------------------------------------------------------------------------------------- */
 
-/* Grouped 3x3 conv, group width 8, stride 1, zero pad 1 (XBlock conv_block_2, net/anynet.py:34-38) on packed-bf16 dot products: the form for
- * the small maps of the deep stages (8 x 16 ... 20 x 20), where the block-diagonal MFMA form of hn_conv_gemm_nt(mode 5) is one round of
- * latency-bound workgroups.  w = an array of hn_gconv_pack(flip = 0): forward `wd` ([tap][o][G][i]) with flip = 0; data gradient `wk`
- * ([tap][i][G][o]) with flip = 1 (the kernel visits tap 8 - t).  psum / psq (optional, both or none): fp32 [hn_gconv_dot_rows(N,H,W)][C] --
- * emode 0: BatchNorm partial statistics of the bf16-rounded output; emode 2: the BatchNorm-backward partial sums sum g, sum g (ez - mu) rs
- * with g = out [sc ez + sh > 0], ecoef [4][C] = (sc, sh, mu, rs) (as hn_conv_gemm_nt_stat's emode 2).  bias / act: inference form (folded
- * BatchNorm): out = act(conv + bias), no statistics. */
-long hn_gconv_dot_rows(int N, int H, int W);
-int hn_gconv_dot(const void* in, int ldi, const void* w, void* out, int ldo, int N, int H, int W, int C, int flip, float* psum, float* psq,
-                 int emode, const void* ez, int ld_ez, const float* ecoef, const float* bias, int act, hipStream_t stream);
-
 /* Stem: x NCHW fp32 [N,3,H,W], w fp32 [32][3][3][3] -> z NHWC bf16 [N,H/2,W/2,32] (conv 3x3 s2 p1, net/anynet.py:12,17).
  * patches (optional): bf16 im2col rows [N*H/2*W/2][32] (27 taps in weight order + 5 zeros) so that the weight gradient is one
  * hn_conv_gemm_tn(mode 0) call on MFMA. */

@@ -1899,195 +1899,3 @@ extern "C" int hn_fuse_dweights(const float* pw, int blocks, const float* praw, 
     HN_LAUNCH_CHECK();
 }
 
-
-// ---------------------------------------------------------------------------------------------------------
-// Grouped 3x3 conv (group width 8, stride 1, zero pad 1) of the deep backbone stages on packed-bf16 dot products (round 5).
-// The block-diagonal MFMA form (conv3x3_direct_kernel<64>, mode 5) spends 7 of 8 MACs on zeros and -- what costs the time on the 8 x 16 ...
-// 32 x 64 maps of stages 2-4 -- carries the general kernel's prologue and statistics epilogue through ONE round of 192-384 workgroups
-// (13.8 / 16.2 / 20.4 us per launch, MFMA pipe 12 % busy).  Here the conv is what it is: 576 MACs per (pixel, group) = 288
-// v_dot2c_f32_bf16 with the contraction index (the 8 channels of a group) contiguous in both operands.
-//   workgroup = a 4*PPT x 16 pixel tile x 64 channels (8 groups); wave = one group, lane = a pixel (and PPT - 1 more, 4 rows apart): the
-//   weight pieces of a wave are wave-uniform LDS broadcasts, the input pieces come from the (4*PPT + 2) x 18 patch staged in LDS ONCE
-//   (plain loads, all in flight together: one memory round per workgroup), 30-60 KB of LDS per workgroup = many workgroups per CU.
-//   Output staged through LDS and written as whole 128-byte pixel runs; BatchNorm partial statistics (emode 0) or the BatchNorm-backward
-//   partial sums of the data-gradient form (emode 2: g = q [sc z + sh > 0]; sum g, sum g (z - mu) rs) by DPP row sums + two shuffles.
-// w: hn_gconv_pack(flip = 0) arrays -- forward: `wd` [tap][o][G][i]; data gradient: `wk` [tap][i][G][o] with flip = 1 (tap' = 8 - tap).
-// ---------------------------------------------------------------------------------------------------------
-struct GConvDot {
-    const bf16* in; int ldi;
-    const bf16* w;
-    bf16* out; int ldo;
-    int N, H, W, C, G, flip;
-    float* psum; float* psq; int emode; const bf16* ez; int ld_ez; const float* ecoef;
-    const float* bias; int act;        // inference (folded BatchNorm): out = act(conv + bias), no statistics
-    int tiles_x, tiles_y, ncb;
-};
-template <int PPT>
-__global__ __launch_bounds__(512) void gconv_dot_kernel(const GConvDot p) {
-    constexpr int TH = 4 * PPT, PR = TH + 2, HP = PR * 18;            // patch rows / pixels
-    constexpr int XL = (HP * 8 + 511) / 512;                          // 16-byte patch pieces per thread
-    extern __shared__ __attribute__((aligned(16))) char gd_smem[];
-    char* sX = gd_smem;                                               // [HP][128 B]   (later: the staged output tile [TH*16][128 B])
-    char* sWt = sX + HP * 128;                                        // [8 groups][72][16 B]
-    float* sCf = reinterpret_cast<float*>(sWt + 8 * 72 * 16);         // [4][64] (emode 2: sc, sh, mu, rs; inference: bias in row 0)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);                 // channel blocks of a tile are neighbours: they share the patch rows in L2
-    const int cb = lid % p.ncb;
-    int t = lid / p.ncb;
-    const int tx = t % p.tiles_x;
-    t /= p.tiles_x;
-    const int ty = t % p.tiles_y;
-    const long n = t / p.tiles_y;
-    const int oy0 = ty * TH, ox0 = tx * 16, c0 = cb * 64;
-    const int py0 = lane >> 4, pxx = lane & 15;
-    const int gch = c0 + wave * 8;                                    // this wave's first channel
-    const bool gv = gch < p.C;
-    // (1) everything this workgroup reads, requested up front
-    u32x4 xr[XL];
-#pragma unroll
-    for (int i = 0; i < XL; ++i) {
-        const int e = tid + 512 * i, hp = e >> 3, pc = e & 7;
-        const int hy = hp / 18, hx = hp - hy * 18;
-        const int y = oy0 - 1 + hy, x = ox0 - 1 + hx, c = c0 + pc * 8;
-        xr[i] = (u32x4){0u, 0u, 0u, 0u};
-        if (hp < HP && y >= 0 && y < p.H && x >= 0 && x < p.W && c < p.C)
-            xr[i] = *reinterpret_cast<const u32x4*>(p.in + ((n * p.H + y) * (long)p.W + x) * p.ldi + c);
-    }
-    u32x4 wr[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int e = tid + 512 * i, g = e / 72, r = e - g * 72;     // r = tap * 8 + a
-        wr[i] = (u32x4){0u, 0u, 0u, 0u};
-        if (e < 576 && c0 / 8 + g < p.G) wr[i] = *reinterpret_cast<const u32x4*>(p.w + ((long)r * p.G + c0 / 8 + g) * 8);
-    }
-    bf16x8 ezr[PPT];
-    if (p.emode == 2) {
-#pragma unroll
-        for (int r = 0; r < PPT; ++r) {
-            const int y = oy0 + py0 + 4 * r, x = ox0 + pxx;
-            ezr[r] = (gv && y < p.H && x < p.W) ? ld8(p.ez + ((n * p.H + y) * (long)p.W + x) * p.ld_ez + gch) : zero8();
-        }
-        if (tid < 256) { const int k = tid >> 6, c = c0 + (tid & 63); sCf[tid] = c < p.C ? p.ecoef[(long)k * p.C + c] : 0.f; }
-    } else if (p.bias) {
-        if (tid < 64) sCf[tid] = c0 + tid < p.C ? p.bias[c0 + tid] : 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < XL; ++i) {
-        const int e = tid + 512 * i;
-        if (e < HP * 8) *reinterpret_cast<u32x4*>(sX + e * 16) = xr[i];
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int e = tid + 512 * i;
-        if (e < 576) *reinterpret_cast<u32x4*>(sWt + e * 16) = wr[i];
-    }
-    __syncthreads();
-    // (2) nine taps: PPT input pieces + eight wave-uniform weight pieces per tap, 32 * PPT packed dots
-    float acc[PPT][8];
-#pragma unroll
-    for (int r = 0; r < PPT; ++r)
-#pragma unroll
-        for (int a = 0; a < 8; ++a) acc[r][a] = 0.f;
-    const char* wbase = sWt + wave * (72 * 16);
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        const int ky = tap / 3, kx = tap - 3 * ky;
-        const int tw = p.flip ? 8 - tap : tap;
-        u32x4 xv[PPT];
-#pragma unroll
-        for (int r = 0; r < PPT; ++r) xv[r] = *reinterpret_cast<const u32x4*>(sX + ((py0 + 4 * r + ky) * 18 + pxx + kx) * 128 + wave * 16);
-#pragma unroll
-        for (int a = 0; a < 8; ++a) {
-            const u32x4 wv = *reinterpret_cast<const u32x4*>(wbase + (tw * 8 + a) * 16);
-#pragma unroll
-            for (int r = 0; r < PPT; ++r) acc[r][a] = dot8_bf16(xv[r], wv, acc[r][a]);
-        }
-    }
-    // (3) statistics of the bf16-rounded outputs over the tile's in-image pixels (lane 0 of the wave ends up with the 64-pixel sums of its
-    // eight channels), then the tile leaves through LDS as whole per-pixel runs
-    const long tile = lid / p.ncb;
-    if (p.psum) {
-        float s1[8], s2[8];
-#pragma unroll
-        for (int a = 0; a < 8; ++a) { s1[a] = 0.f; s2[a] = 0.f; }
-#pragma unroll
-        for (int r = 0; r < PPT; ++r) {
-            const bool pv = oy0 + py0 + 4 * r < p.H && ox0 + pxx < p.W;
-#pragma unroll
-            for (int a = 0; a < 8; ++a) {
-                const float q = pv ? bfround(acc[r][a]) : 0.f;
-                if (p.emode == 2) {
-                    const float z = bf2f(ezr[r][a]);
-                    const float pre = sCf[wave * 8 + a] * z + sCf[64 + wave * 8 + a];
-                    const float g = pre > 0.f ? q : 0.f;
-                    s1[a] += g;
-                    s2[a] += g * (z - sCf[128 + wave * 8 + a]) * sCf[192 + wave * 8 + a];
-                } else {
-                    s1[a] += q;
-                    s2[a] += q * q;
-                }
-            }
-        }
-#pragma unroll
-        for (int a = 0; a < 8; ++a) {
-            s1[a] = row16_sum(s1[a]);
-            s2[a] = row16_sum(s2[a]);
-            s1[a] += __shfl_xor(s1[a], 16);
-            s2[a] += __shfl_xor(s2[a], 16);
-            s1[a] += __shfl_xor(s1[a], 32);
-            s2[a] += __shfl_xor(s2[a], 32);
-        }
-        if (lane == 0 && gv) {
-#pragma unroll
-            for (int a = 0; a < 8; ++a) { p.psum[tile * p.C + gch + a] = s1[a]; p.psq[tile * p.C + gch + a] = s2[a]; }
-        }
-    }
-    __syncthreads();                                                  // every wave is done with the patch: its LDS holds the output tile now
-#pragma unroll
-    for (int r = 0; r < PPT; ++r) {
-        float v[8];
-#pragma unroll
-        for (int a = 0; a < 8; ++a) v[a] = acc[r][a] + (p.bias ? sCf[wave * 8 + a] : 0.f);
-        act_fwd_n(v, p.act);
-        bf16x8 o;
-#pragma unroll
-        for (int a = 0; a < 8; ++a) o[a] = f2bf(v[a]);
-        *reinterpret_cast<bf16x8*>(sX + ((py0 + 4 * r) * 16 + pxx) * 128 + wave * 16) = o;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-        const int e = tid + 512 * i, px = e >> 3, pc = e & 7;
-        const int y = oy0 + (px >> 4), x = ox0 + (px & 15), c = c0 + pc * 8;
-        if (y < p.H && x < p.W && c < p.C) st8(p.out + ((n * p.H + y) * (long)p.W + x) * p.ldo + c, *reinterpret_cast<const bf16x8*>(sX + px * 128 + pc * 16));
-    }
-}
-
-// pixels per thread: one (4 x 16 tiles) while that leaves <= 128 partial rows (what a consumer prologue folds itself), else two (8 x 16)
-static int gconv_dot_ppt(int N, int H, int W) { return (long)N * ((H + 3) / 4) * ((W + 15) / 16) <= 128 ? 1 : 2; }
-extern "C" long hn_gconv_dot_rows(int N, int H, int W) {
-    const int th = 4 * gconv_dot_ppt(N, H, W);
-    return (long)N * ((H + th - 1) / th) * ((W + 15) / 16);
-}
-/* emode 0: psum / psq (optional) = BatchNorm partial statistics of the bf16-rounded output, [hn_gconv_dot_rows(N,H,W)][C];
- * emode 2: the BatchNorm-backward partial sums of (out, ez) with ecoef [4][C] (data-gradient form: flip = 1, w = the `wk` array);
- * bias / act: the inference form (folded BatchNorm), no statistics. */
-extern "C" int hn_gconv_dot(const void* in, int ldi, const void* w, void* out, int ldo, int N, int H, int W, int C, int flip, float* psum,
-                            float* psq, int emode, const void* ez, int ld_ez, const float* ecoef, const float* bias, int act, hipStream_t st) {
-    static std::atomic<unsigned long long> optin{0};
-    HN_CHECK_ARG(in && w && out && N > 0 && H > 0 && W > 0 && C > 0 && (C & 7) == 0 && ((ldi | ldo) & 7) == 0 && in != out);
-    HN_CHECK_ARG((psum == nullptr) == (psq == nullptr) && (emode == 0 || (emode == 2 && psum && ez && ecoef && (ld_ez & 7) == 0)));
-    HN_CHECK_ARG(!bias || !psum);
-    GConvDot p;
-    p.in = (const bf16*)in; p.ldi = ldi; p.w = (const bf16*)w; p.out = (bf16*)out; p.ldo = ldo; p.N = N; p.H = H; p.W = W; p.C = C; p.G = C >> 3;
-    p.flip = flip; p.psum = psum; p.psq = psq; p.emode = emode; p.ez = (const bf16*)ez; p.ld_ez = ld_ez; p.ecoef = ecoef; p.bias = bias; p.act = act;
-    const int ppt = gconv_dot_ppt(N, H, W), th = 4 * ppt;
-    p.tiles_x = (W + 15) / 16; p.tiles_y = (H + th - 1) / th; p.ncb = (C + 63) / 64;
-    const long blocks = (long)N * p.tiles_x * p.tiles_y * p.ncb;
-    HN_CHECK_ARG(blocks < (1L << 31));
-    const size_t lds = (size_t)(th + 2) * 18 * 128 + 8 * 72 * 16 + 4 * 64 * 4;
-    (void)optin;                                                      // (<= 33 KB of LDS: no opt-in needed)
-    if (ppt == 1) hipLaunchKernelGGL(gconv_dot_kernel<1>, dim3((unsigned)blocks), dim3(512), lds, st, p);
-    else hipLaunchKernelGGL(gconv_dot_kernel<2>, dim3((unsigned)blocks), dim3(512), lds, st, p);
-    HN_LAUNCH_CHECK();
-}

@@ -166,31 +166,6 @@ XBLOCK_XF_GEMM = policy("HN_XBLOCK_XF", "0") == "1"
 BN3_PARTS_FROM_DGRAD = policy("HN_BN3_PARTS_FROM_DGRAD", "1") != "0"   # the next block's last backward GEMM makes the BatchNorm-3 backward's partial sums
 
 
-GCONV_DOT_MAX_HW = int(policy("HN_GCONV_DOT_MAX_HW", "1024"))     # grouped 3x3 convs of maps up to this many pixels per image: packed-dot kernel
-
-
-def gconv_dot_ok(n, h, w):
-    """stride-1 grouped 3x3 conv on hn_gconv_dot (packed bf16 dots, 4 x 16 / 8 x 16 pixel tiles) instead of the block-diagonal MFMA tiles of
-    the direct conv: the small maps of the deep stages, where its partial-statistics rows fit a consumer prologue"""
-    return h * w <= GCONV_DOT_MAX_HW and lib().query("hn_gconv_dot_rows", n, h, w) <= MAX_PROLOGUE_ROWS
-
-
-def k_gconv_dot(x, wpack, flip=0, stats=False, estat=None):
-    """-> (out, psum | None, psq | None).  wpack: the `wd` array of pack_gconv_weight(w, 0) (forward, flip = 0) or its `wk` array (data
-    gradient, flip = 1).  estat = (ez, ecoef): the BatchNorm-backward partial sums of (out, ez) instead of the output's statistics."""
-    n, h, w, c = x.shape
-    out = new_act(n, h, w, c, x.device)
-    ps = pq = None
-    if stats or estat is not None:
-        rows_ = lib().query("hn_gconv_dot_rows", n, h, w)
-        ps = torch.empty((rows_, c), device=x.device, dtype=F32)
-        pq = torch.empty((rows_, c), device=x.device, dtype=F32)
-    ez, ecoef = estat if estat is not None else (None, None)
-    lib().call("hn_gconv_dot", ptr(x), ld(x), ptr(wpack), ptr(out), ld(out), n, h, w, c, flip, ptr(ps), ptr(pq), 2 if estat is not None else 0,
-               ptr(ez), ld(ez) if ez is not None else 0, ptr(ecoef), None, ACT_NONE)
-    return out, ps, pq
-
-
 class XBlockFn(torch.autograd.Function):
     """stride 1 without shortcut: the identity blocks; stride 2 (or a channel change) with the projection shortcut conv + BN
     (ws, gs, bs, rms, rvs): the first block of every stage.  There the grouped conv runs on the stride-2 stencil kernels, and the data
@@ -211,11 +186,7 @@ class XBlockFn(torch.autograd.Function):
         wp1, wt1 = pack_conv_weight(w1)
         z1, ps, pq = k_gemm_nt(x, None, 0, (n, h, w), wp1, c, kp32(cin), 1, stats=training)
         a, coef1, _, _ = k_bn_apply_fused(z1, ps, pq, m_in, g1, b1, eps, momentum, rm1, rv1, ACT_RELU, training=training)
-        dot2 = stride == 1 and gconv_dot_ok(n, ho, wo)
-        if dot2:                # deep stages: packed-dot kernel (forward takes the (o, i)-swapped pack, the data gradient the plain one)
-            wd2, wk2 = pack_gconv_weight(w2, 0)
-            z2, ps, pq = k_gconv_dot(a, wk2, 0, stats=training)
-        elif stride == 1:
+        if stride == 1:
             wk2, wd2 = pack_gconv_diag(w2)
             z2, ps, pq = k_gemm_nt(a, None, 5, grid, wk2, c, 64, 9, stats=training)
         else:
@@ -246,7 +217,7 @@ class XBlockFn(torch.autograd.Function):
             zs, pss, pqs = k_gemm_nt(x, None, 0 if stride == 1 else 1, grid, wps, c, kp32(cin), 1, stats=training)
             res, coefs, _, _ = k_bn_apply_fused(zs, pss, pqs, m, gs, bs, eps, momentum, rms, rvs, ACT_NONE, training=training)
         out, coef3, _, _ = k_bn_apply_fused(z3, ps, pq, m, g3, b3, eps, momentum, rm3, rv3, ACT_RELU, res=res, training=training)
-        ctx.training, ctx.stride, ctx.dot2 = training, stride, dot2
+        ctx.training, ctx.stride = training, stride
         ctx.packs = (wt1, wd2, wt3, wts)
         ctx.group = group
         # BN3_PARTS_FROM_DGRAD: an identity block whose input IS the previous block's output lets its last backward GEMM (dx = dz1 W1 + g)
@@ -325,13 +296,9 @@ class XBlockFn(torch.autograd.Function):
         parts1 = None
         if stride == 1:
             # BatchNorm-1 backward partial sums (sum g, sum g * xhat over (da, z1)) from the data-gradient conv's epilogue: one row per
-            # 16 x 16 patch (4 x 16 / 8 x 16 tile of the packed-dot kernel), folded by the apply pass's prologue
-            if ctx.dot2:
-                ep_bn = EPILOGUE_STATS
-                da, pg1, pgx1 = k_gconv_dot(dz2, wd2, 1, estat=(z1, coef1) if ep_bn else None)
-            else:
-                ep_bn = EPILOGUE_STATS and lib().query("hn_direct_stat_rows", n, ho, wo) <= MAX_PROLOGUE_ROWS
-                da, pg1, pgx1 = k_gemm_nt(dz2, None, 5, grid, wd2, c, 64, 9, estat=(2, z1, coef1) if ep_bn else None)
+            # 16 x 16 patch, folded by the apply pass's prologue
+            ep_bn = EPILOGUE_STATS and lib().query("hn_direct_stat_rows", n, ho, wo) <= MAX_PROLOGUE_ROWS
+            da, pg1, pgx1 = k_gemm_nt(dz2, None, 5, grid, wd2, c, 64, 9, estat=(2, z1, coef1) if ep_bn else None)
             if ep_bn:
                 parts1 = (pg1, pgx1)
             if group is not None:

@@ -1329,43 +1329,3 @@ def test_head_output_conv_of_all_levels_in_one_launch(K, cout, act):
     assert not torch.isnan(ref).any()
     assert torch.equal(out, ref)
 
-
-
-@pytest.mark.parametrize("c,n,h,w", [(936, 16, 8, 16), (376, 16, 16, 32), (376, 4, 20, 20), (936, 2, 10, 10), (152, 3, 6, 10), (24, 2, 5, 7), (64, 1, 1, 1)])
-def test_grouped_conv_on_packed_dots(K, c, n, h, w):
-    """hn_gconv_dot (stride-1 grouped 3x3 conv of the deep stages on v_dot2c_f32_bf16: a 4 x 16 / 8 x 16 pixel tile x 64 channels per
-    workgroup) against an fp32 torch grouped conv on the same bf16-rounded operands: forward + BatchNorm partial statistics, data gradient
-    (flipped taps, contraction over the output channels) + the BatchNorm-backward partial sums of its epilogue, and against the
-    block-diagonal MFMA form it replaces (hn_conv_gemm_nt mode 5)."""
-    from multitask_hydranet_amd._lib import lib
-    x = rnd(n, c, h, w)
-    wgt = rnd(c, 8, 3, 3, scale=72 ** -0.5)
-    pk, pd = K.pack_gconv_weight(wgt, 0)                # ([tap][i][G][o], [tap][o][G][i])
-    xk = nhwc(x)
-    z, ps, pq = K.k_gconv_dot(xk, pd, 0, stats=True)
-    ref = F.conv2d(x, wgt, padding=1, groups=c // 8)
-    close(nchw(z), ref, ACT_TOL, "forward")
-    zr = nchw(z).float()
-    assert ps.shape == (lib().query("hn_gconv_dot_rows", n, h, w), c)
-    close(ps.sum(0), zr.sum((0, 2, 3)), 1e-4, "sum z")
-    close(pq.sum(0), (zr * zr).sum((0, 2, 3)), 1e-4, "sum z^2")
-    dk, dd = K.pack_gconv_diag(wgt)
-    z_m, _, _ = K.k_gemm_nt(xk, None, 5, (n, h, w), dk, c, 64, 9)
-    close(z.float(), z_m.float(), 1e-2, "vs the MFMA form")
-    # data gradient: d in = conv_transpose(d out)
-    dz = rnd(n, c, h, w)
-    xr = x.clone().requires_grad_(True)
-    F.conv2d(xr, wgt, padding=1, groups=c // 8).backward(dz)
-    z1 = nhwc(rnd(n, c, h, w))
-    coef = torch.stack([torch.rand(c, device=dev()) + 0.5, torch.randn(c, device=dev()) * 0.2, torch.randn(c, device=dev()) * 0.1,
-                        torch.rand(c, device=dev()) + 0.5]).contiguous()
-    da, pg, pgx = K.k_gconv_dot(nhwc(dz), pk, 1, estat=(z1, coef))
-    close(nchw(da), xr.grad, GRAD_TOL, "data gradient")
-    da0, _, _ = K.k_gconv_dot(nhwc(dz), pk, 1)
-    assert torch.equal(da, da0)                        # the statistics epilogue does not touch the output
-    q = da.float()
-    zz = z1.float()
-    mask = (coef[0] * zz + coef[1]) > 0
-    g = torch.where(mask, q, torch.zeros_like(q))
-    close(pg.sum(0), g.sum((0, 1, 2)), 1e-4, "sum g")
-    close(pgx.sum(0), (g * (zz - coef[2]) * coef[3]).sum((0, 1, 2)), 1e-4, "sum g xhat")
