@@ -272,3 +272,18 @@ def test_bench_refuses_more_gpus_than_the_node_has():
     assert r.returncode == 2, (r.returncode, r.stderr[-500:])
     assert not any(l.startswith("{") for l in r.stdout.splitlines())
     assert "refusing" in r.stderr
+
+
+def test_policy_switches_are_constants_without_the_tuning_flag():
+    """the package reads no HN_* environment variable unless HN_TUNING=1 / ab is set (_lib.policy): a stray HN_FUSED_BN=0
+    or HN_LIB_AB in a user's environment must not change what the product runs"""
+    import subprocess
+    import sys
+    code = ("import os, sys; sys.path.insert(0, %r); "
+            "from multitask_hydranet_amd import _lib, ops; "
+            "print(int(ops.FUSED_BN), int(ops.FUSED_XBLOCK), _lib.policy('HN_LIB_AB', ''))" % ROOT)
+    base = {k: v for k, v in os.environ.items() if not k.startswith("HN_")}
+    plain = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(base, HN_FUSED_BN="0", HN_FUSED_XBLOCK="0", HN_LIB_AB="/nonexistent.so"))
+    assert plain.returncode == 0 and plain.stdout.split() == ["1", "1"], (plain.stdout, plain.stderr[-500:])
+    ab = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(base, HN_TUNING="ab", HN_FUSED_BN="0", HN_LIB_AB="/nonexistent.so"))
+    assert ab.returncode == 0 and ab.stdout.split() == ["0", "1", "/nonexistent.so"], (ab.stdout, ab.stderr[-500:])
