@@ -376,6 +376,11 @@ long hn_fused_row_block(long M, int C, long align, int P, int kind);
 int hn_bn_apply_fused(const void* z, int ldz, long M, int C, const float* psum, const float* psq, int P, long count, const float* gamma,
                       const float* beta, float eps, float momentum, float* rm, float* rv, float* coef, const void* res, int ldr, int act,
                       void* out, int ldo, float* pool, const float* gate, long HW, long RB, hipStream_t stream);
+/* SE excite + gated apply in one launch (net/anynet.py:44-48,68-69: the second nn.Conv2d of the SE block, its Sigmoid and the
+ * `x * se(x)` product together with the BatchNorm + ReLU in front of them): gate[n][c] = sigmoid(b2[c] + sum_j w2[c][j] hid[n][j]) (stored
+ * to `gate` [N][C] when non-null), out[row][c] = bf16(act(coef[0][c] z + coef[1][c])) * gate[row / HW][c]; coef null = identity */
+int hn_se_gate_apply(const void* z, int ldz, const float* coef, int act, const float* hid, const float* w2, const float* b2, float* gate,
+                     void* out, int ldo, int N, long HW, int C, int Cs, hipStream_t stream);
 /* BatchNorm backward.  g = dout * act'(scale*z+shift), or dout * [y > 0] when the saved block output y is given (ReLU after the residual
  * add), or, with gate/dpool (SE, RB divides HW): g = (dout*gate[n][c] + dpool[n][c]/HW) * [scale*z+shift > 0] where dout is the gradient of
  * the gated tensor.  reduce: pg/pgx [ceil(M/RB)][C] partial sums of g and g*xhat.  apply: dz = scale*(g - mean g - xhat*mean(g*xhat)),
@@ -404,7 +409,8 @@ int hn_se_bwd_apply(const void* dout, int ldd, const float* gate, const float* d
 int hn_se_mlp_fwd(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2, float* hid, float* gate, int N,
                   int C, int Cs, hipStream_t stream);
 /* forms fed by partial rows (S per image): pooled = alpha * sum of the squeeze partials of hn_bn_apply_fused (stored to `pooled`), and
- * dgate = sum of the partials of hn_se_bwd_reduce_fused -- the reductions ride on the first MLP kernel instead of their own launches */
+ * dgate = sum of the partials of hn_se_bwd_reduce_fused -- the reductions ride on the first MLP kernel instead of their own launches.
+ * hn_se_mlp_fwd_parts with gate == NULL runs the first layer only (w2 / b2 unused): the second one is hn_se_gate_apply's prologue */
 int hn_se_mlp_fwd_parts(const float* pool_part, int S, float alpha, const float* w1, const float* b1, const float* w2, const float* b2,
                         float* pooled, float* hid, float* gate, int N, int C, int Cs, hipStream_t stream);
 int hn_se_mlp_bwd_parts(const float* dgate_part, int S, const float* gate, const float* hid, const float* pooled, const float* w1,

@@ -38,11 +38,12 @@ __device__ __forceinline__ bf16x8 zero8() {
 // split, 2 fused-BatchNorm apply-pass target workgroups, 3 fused reduce-pass row-block divisor, 4 / 5 pixel thresholds of the 64x64 GEMM tile,
 // 6 = 1: no two-K-group GEMM variant (> 1: its K threshold, default 512), 7 depthwise-backward block target, 8 = 0: fused passes without the
 // XCD row-order placement, 9 grouped-TN debug bits (skip stores / MFMAs / loads), 10 grouped-TN tile variant, 11 = 1: direct 3x3 kernel walks
-// the patches of one cout tile first (measured: no gain), 12 / 13 workgroup targets of the 3x3 patch weight-gradient / grouped-conv group plans
+// the patches of one cout tile first (measured: no gain), 12 / 13 workgroup targets of the 3x3 patch weight-gradient / grouped-conv group plans,
+// 16 / 17 channels and rows per workgroup of hn_se_gate_apply (0 = the heuristic)
 #ifdef HN_TUNING
-extern long g_hn_knob[16];
+extern long g_hn_knob[20];
 #else
-extern const long g_hn_knob[16];      // product build: the shipped heuristics as constants, no setter (the library has no mutable state)
+extern const long g_hn_knob[20];      // product build: the shipped heuristics as constants, no setter (the library has no mutable state)
 #endif
 #define HN_ACT_NONE 0
 #define HN_ACT_RELU 1

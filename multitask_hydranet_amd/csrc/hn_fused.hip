@@ -445,6 +445,111 @@ __global__ __launch_bounds__(256) void fused_se_bwd_kernel(const FSeBwd p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// SE excite + gated apply in ONE launch (net/anynet.py:44-48,68-69): gate[n][c] = sigmoid(b2[c] + W2[c][:] . hid[n][:]) for the workgroup's
+// channels, then out = bf16(act(sc z + sh)) * gate over its rows.  A workgroup owns cw <= 64 channels (so its weight slice is <= 30 KB: one
+// round of loads) and RB rows of one image; the second excitation layer as a launch of its own cost 5.7 us + the gap to the apply pass
+// (r05 kernel stats), here it is ~1.5 us of prologue that the first row loads already overlap.  The summation order per channel is
+// se_fc_rows_kernel's (lanes stride the contraction, wave_sum), so the gate is the value that kernel gives.
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct FGateApply {
+    const bf16* z; int ldz;
+    const float* coef;              // [4][C] scale, shift (null = identity)
+    int act;
+    const float* hid; const float* w2; const float* b2; int Cs;
+    float* gate;                    // [N][C], written by the first row block of every image (kept for the backward pass); may be null
+    bf16* out; int ldo;
+    long HW; long M; int C; long RB; int cw; int xcd;
+};
+
+template <int GA_JMAX, int GA_KS>   // channels per wave (cw / 4); 64-lane pieces of the contraction whose loads are issued together
+__global__ __launch_bounds__(256) void se_gate_apply_kernel(const FGateApply p) {
+    __shared__ float sgate[4 * GA_JMAX];
+    int bx, by;
+    fused_block(p.xcd, bx, by);
+    const int c0 = bx * p.cw;
+    const int nch = p.C - c0 < p.cw ? p.C - c0 : p.cw;
+    const long m0 = (long)by * p.RB;
+    long m1 = m0 + p.RB;
+    if (m1 > p.M) m1 = p.M;
+    const long n = m0 / p.HW;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int cln = nch >> 3, rln = 256 / cln;
+    const int cl = tid % cln, rl = tid / cln;
+    const bool active = rl < rln;
+    const int c = c0 + cl * 8;
+    // the first two row pieces and the BatchNorm coefficients are in flight while the gate is computed
+    long m = m0 + rl;
+    const bool h0 = active && m < m1, h1 = active && m + rln < m1;
+    bf16x8 vz0 = {}, vz1 = {};
+    if (h0) vz0 = ld8(p.z + m * p.ldz + c);
+    if (h1) vz1 = ld8(p.z + (m + rln) * p.ldz + c);
+    float sc[8], sh[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        sc[k] = (p.coef && active) ? p.coef[c + k] : 1.f;
+        sh[k] = (p.coef && active) ? p.coef[p.C + c + k] : 0.f;
+    }
+    // wave wv: channels wv, wv + 4, ... of the chunk; all weight loads of a 256-wide slab of the contraction issued together
+    float acc[GA_JMAX];
+#pragma unroll
+    for (int jj = 0; jj < GA_JMAX; ++jj) acc[jj] = 0.f;
+    const float* hr = p.hid + n * p.Cs;
+    for (int base = 0; base < p.Cs; base += 64 * GA_KS) {
+        float hv[GA_KS];
+#pragma unroll
+        for (int k = 0; k < GA_KS; ++k) hv[k] = base + lane + 64 * k < p.Cs ? hr[base + lane + 64 * k] : 0.f;
+        float wvv[GA_JMAX][GA_KS];
+#pragma unroll
+        for (int jj = 0; jj < GA_JMAX; ++jj) {
+            const int j = wv + 4 * jj;
+            const float* wr = p.w2 + (long)(c0 + (j < nch ? j : 0)) * p.Cs + base + lane;
+#pragma unroll
+            for (int k = 0; k < GA_KS; ++k) wvv[jj][k] = (j < nch && base + lane + 64 * k < p.Cs) ? wr[64 * k] : 0.f;
+        }
+#pragma unroll
+        for (int jj = 0; jj < GA_JMAX; ++jj)
+#pragma unroll
+            for (int k = 0; k < GA_KS; ++k) acc[jj] += wvv[jj][k] * hv[k];
+    }
+#pragma unroll
+    for (int jj = 0; jj < GA_JMAX; ++jj) {
+        const int j = wv + 4 * jj;
+        if (j < nch) {                                                  // wave-uniform
+            const float s = wave_sum(acc[jj]) + p.b2[c0 + j];
+            const float g = 1.f / (1.f + __expf(-s));
+            if (lane == 0) {
+                sgate[j] = g;
+                if (p.gate && m0 == n * p.HW) p.gate[n * p.C + c0 + j] = g;
+            }
+        }
+    }
+    __syncthreads();
+    float gt[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) gt[k] = active ? sgate[cl * 8 + k] : 1.f;
+    auto apply = [&](const bf16x8& vz, long row) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = bf2f(vz[k]) * sc[k] + sh[k];
+        act_fwd_n(v, p.act);
+        bf16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = f2bf(bf2f(f2bf(v[k])) * gt[k]);
+        st8(p.out + row * p.ldo + c, o);
+    };
+    if (h0) apply(vz0, m);
+    if (h1) apply(vz1, m + rln);
+    if (active) {
+        for (m += 2 * rln; m + rln < m1; m += 2 * rln) {
+            const bf16x8 a = ld8(p.z + m * p.ldz + c), b = ld8(p.z + (m + rln) * p.ldz + c);
+            apply(a, m);
+            apply(b, m + rln);
+        }
+        if (m < m1) apply(ld8(p.z + m * p.ldz + c), m);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------------------
 // chunk width: C <= 128 is one chunk (whole rows contiguous); wider tensors are cut into equal chunks of <= 128 channels
@@ -499,6 +604,37 @@ extern "C" int hn_bn_apply_fused(const void* z, int ldz, long M, int C, const fl
     p.res = (const bf16*)res; p.ldr = ldr; p.act = act; p.out = (bf16*)out; p.ldo = ldo; p.pool = pool; p.M = M; p.C = C; p.RB = RB;
     p.gate = gate; p.HW = HW; p.cw = chunk_width(C); p.xcd = (int)g_hn_knob[8];
     hipLaunchKernelGGL(fused_apply_kernel, fused_grid(M, C, RB), dim3(256), 0, st, p);
+    HN_LAUNCH_CHECK();
+}
+
+// rows per workgroup of hn_se_gate_apply: every workgroup pays the gate prologue (~3 us of dependent loads), so the pass wants ONE round of
+// workgroups -- ~512 over (chunks x row blocks), measured with tools/bench_gate_apply.py: 128 rows at stage 4 ... 1024 at stage 0 -- and a
+// divisor of HW (a workgroup's rows lie inside one image)
+static long gate_apply_rows(long M, long HW, int chunks) {
+    long RB = 64;
+    while (RB * 512 < M * chunks) RB <<= 1;
+    if (g_hn_knob[17]) RB = g_hn_knob[17];
+    if (RB > HW) RB = HW;
+    while (HW % RB) ++RB;
+    return RB;
+}
+
+extern "C" int hn_se_gate_apply(const void* z, int ldz, const float* coef, int act, const float* hid, const float* w2, const float* b2, float* gate,
+                                void* out, int ldo, int N, long HW, int C, int Cs, hipStream_t st) {
+    HN_CHECK_ARG(z && hid && w2 && b2 && out && N > 0 && HW > 0 && C > 0 && Cs > 0 && (C & 7) == 0 && (ldz & 7) == 0 && (ldo & 7) == 0);
+    FGateApply p;
+    p.z = (const bf16*)z; p.ldz = ldz; p.coef = coef; p.act = act; p.hid = hid; p.w2 = w2; p.b2 = b2; p.Cs = Cs; p.gate = gate;
+    p.out = (bf16*)out; p.ldo = ldo; p.HW = HW; p.M = (long)N * HW; p.C = C;
+    // channels per workgroup: the weight slice cw * Cs * 4 B stays one round of <= 40 loads per lane (knob 16 overrides: tools/bench_gate_apply.py)
+    p.cw = g_hn_knob[16] ? (int)g_hn_knob[16] : 32;
+    const int chunks = (C + p.cw - 1) / p.cw;
+    p.RB = gate_apply_rows(p.M, HW, chunks);
+    p.xcd = (int)g_hn_knob[8];
+    const dim3 grid((unsigned)chunks, (unsigned)(p.M / p.RB));
+    if (p.cw == 32) hipLaunchKernelGGL((se_gate_apply_kernel<8, 4>), grid, dim3(256), 0, st, p);
+    else if (p.cw == 64) hipLaunchKernelGGL((se_gate_apply_kernel<16, 2>), grid, dim3(256), 0, st, p);
+    else if (p.cw == 160) hipLaunchKernelGGL((se_gate_apply_kernel<40, 1>), grid, dim3(256), 0, st, p);
+    else return HN_ERR_ARG;
     HN_LAUNCH_CHECK();
 }
 

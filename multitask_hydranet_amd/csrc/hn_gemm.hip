@@ -2851,10 +2851,10 @@ static int pick_bc(int Nout) {
 // (knob 0, the TN split target: 1024 -> 2048 workgroups measured +0.75 % on the step -- 785 -> 791 img/s, tools/knob_sweep.sh: the
 // L2 -> LDS bound weight-gradient GEMMs want two full rounds of short K loops rather than one round of long ones)
 #ifdef HN_TUNING
-long g_hn_knob[16] = {2048, 256, 1024, 512, 8192, 262144, 0, 0, 1, 0, 0, 0, 256, 384, 0, 0};
-extern "C" int hn_debug_knob(int id, long value) { if (id < 0 || id >= 16) return HN_ERR_ARG; g_hn_knob[id] = value; return HN_OK; }
+long g_hn_knob[20] = {2048, 256, 1024, 512, 8192, 262144, 0, 0, 1, 0, 0, 0, 256, 384, 0, 0, 0, 0, 0, 0};
+extern "C" int hn_debug_knob(int id, long value) { if (id < 0 || id >= 20) return HN_ERR_ARG; g_hn_knob[id] = value; return HN_OK; }
 #else
-extern const long g_hn_knob[16] = {2048, 256, 1024, 512, 8192, 262144, 0, 0, 1, 0, 0, 0, 256, 384, 0, 0};   // the shipped heuristics: constants
+extern const long g_hn_knob[20] = {2048, 256, 1024, 512, 8192, 262144, 0, 0, 1, 0, 0, 0, 256, 384, 0, 0, 0, 0, 0, 0};   // the shipped heuristics: constants
 #endif
 static bool small_tile(long M, int Nout) { return !g_nt_force_bc && Nout > 64 && (M <= g_hn_knob[4] || (M <= g_hn_knob[5] && Nout <= 128)); }
 

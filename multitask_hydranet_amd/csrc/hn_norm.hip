@@ -1079,11 +1079,12 @@ extern "C" int hn_se_mlp_fwd(const float* pooled, const float* w1, const float* 
 // the same MLP fed by S partial squeeze rows per image (pool_part [N*S][C], pooled = alpha * their sum, stored for the backward pass)
 extern "C" int hn_se_mlp_fwd_parts(const float* pool_part, int S, float alpha, const float* w1, const float* b1, const float* w2, const float* b2,
                                    float* pooled, float* hid, float* gate, int N, int C, int Cs, hipStream_t st) {
-    HN_CHECK_ARG(pool_part && S > 0 && w1 && b1 && w2 && b2 && pooled && hid && gate && N > 0 && C > 0 && Cs > 0);
+    HN_CHECK_ARG(pool_part && S > 0 && w1 && b1 && pooled && hid && (!gate || (w2 && b2)) && N > 0 && C > 0 && Cs > 0);
     hipLaunchKernelGGL(se_fc_rows_kernel<true>, dim3(cdiv((long)N * Cs, 4)), dim3(256), 0, st, w1, b1, pool_part, hid, N, Cs, C, HN_ACT_RELU, S,
                        alpha, pooled);
-    hipLaunchKernelGGL(se_fc_rows_kernel<false>, dim3(cdiv((long)N * C, 4)), dim3(256), 0, st, w2, b2, (const float*)hid, gate, N, C, Cs,
-                       HN_ACT_SIGMOID, 0, 1.f, (float*)nullptr);
+    if (gate)                                                           // null: the second layer runs in hn_se_gate_apply's prologue
+        hipLaunchKernelGGL(se_fc_rows_kernel<false>, dim3(cdiv((long)N * C, 4)), dim3(256), 0, st, w2, b2, (const float*)hid, gate, N, C, Cs,
+                           HN_ACT_SIGMOID, 0, 1.f, (float*)nullptr);
     HN_LAUNCH_CHECK();
 }
 

@@ -395,10 +395,14 @@ class HydraNet(nn.Module):
         if self._folded is not None and not self.training:            # inference: 7 launches per block, nothing but GEMM epilogues
             a = self._cba(x, q + "conv_block_1.0", q + "conv_block_1.1", BN_STD, act=ACT_RELU)
             b = self._cba(a, q + "conv_block_2.0", q + "conv_block_2.1", BN_STD, kind="g3x3", stride=stride, act=ACT_RELU)
-            gate = K.se_gate_infer(b, P[q + "se.1.weight"], P[q + "se.1.bias"], P[q + "se.3.weight"], P[q + "se.3.bias"], apply=False) if has_se else None
+            gate = None
+            if has_se:      # the gate scales conv_block_3's weights per image where that form applies, else the activation (one launch)
+                fold = K.gate_folds_into_weights(b)
+                r = K.se_gate_infer(b, P[q + "se.1.weight"], P[q + "se.1.bias"], P[q + "se.3.weight"], P[q + "se.3.bias"], apply=not fold)
+                b, gate = (b, r) if fold else (r, None)
             s = self._cba(x, q + "shortcut.0", q + "shortcut.1", BN_STD, stride=stride, act=ACT_NONE) if has_sc else x
             return self._cba(b, q + "conv_block_3.0", q + "conv_block_3.1", BN_STD, res=s, act=ACT_RELU, gate=gate)
-        if K.xblock_fusable(x, P[q + "conv_block_1.0.weight"], stride, has_se, has_sc):     # one autograd node, 9 + 21 launches
+        if K.xblock_fusable(x, P[q + "conv_block_1.0.weight"], stride, has_se, has_sc):     # one autograd node, 8 + 21 launches
             bn = [self._bn(q + f"conv_block_{i}.1")[:4] for i in (1, 2, 3)]
             sc = (P[q + "shortcut.0.weight"], *self._bn(q + "shortcut.1")[:4]) if has_sc else ()
             return K.XBlockFn.apply(x, P[q + "conv_block_1.0.weight"], *bn[0], P[q + "conv_block_2.0.weight"], *bn[1],

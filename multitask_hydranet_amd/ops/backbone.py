@@ -153,9 +153,10 @@ def conv_bn_act(x, weight, conv_bias, bn, res=None, kind="1x1", stride=1, act=AC
 # Stride-1 identity XBlock as ONE autograd node (net/anynet.py:65-76; 25 of the 30 blocks of the big backbone):
 #   z1 = conv1x1(x); a = relu(bn1(z1)); z2 = gconv3x3(a); b = relu(bn2(z2)); gate = SE(avgpool(b)); z3 = conv1x1(b * gate);
 #   out = relu(bn3(z3) + x)
-# Forward is 9 launches: the two 1x1 GEMMs and the grouped conv emit their BatchNorm partial statistics; BN1 apply and the final
+# Forward is 8 launches: the two 1x1 GEMMs and the grouped conv emit their BatchNorm partial statistics; BN1 apply and the final
 # BN3 + residual + ReLU are materialising passes; BN2's output is never stored on its own -- one pass over z2 finalizes its statistics
-# and produces the SE squeeze, a second one writes relu(bn2(z2)) * gate, the operand of conv_block_3.  Backward is 21 launches
+# and produces the SE squeeze, the first excitation layer is a launch of its own, the second one is the prologue of the pass that writes
+# relu(bn2(z2)) * gate, the operand of conv_block_3 (hn_se_gate_apply).  Backward is 21 launches
 # (BN backward = reduce + apply with the finalize in the prologue; the SE gate gradient and the gated wgrad operand come out of one pass
 # over (dbg, z2); the SE data-path backward is folded into the BN2 reduce/apply pair; the residual gradient is added in conv_block_1's
 # dgrad epilogue).  The unfused composition of ConvBnAct / SEGate nodes is ~16 + ~27 launches per block.
@@ -163,6 +164,15 @@ def conv_bn_act(x, weight, conv_bias, bn, res=None, kind="1x1", stride=1, act=AC
 FUSED_XBLOCK = policy("HN_FUSED_XBLOCK", "1") != "0"
 EPILOGUE_STATS = policy("HN_EPILOGUE_STATS", "1") != "0"   # backward reduce passes folded into their producers' epilogues
 XBLOCK_XF_GEMM = policy("HN_XBLOCK_XF", "0") == "1"
+SE_GATE_IN_APPLY = policy("HN_SE_GATE_APPLY", "1") != "0"    # second SE layer in the prologue of the gated apply pass (hn_se_gate_apply)
+SE_GATE_APPLY_MAX = 1 << 24   # ... up to this many activation elements: a bandwidth-bound pass (the 32 x 1152 x 1920 inference maps of stages
+                              # 2 / 3: 84 MB each way) runs faster on hn_bn_apply_fused's wider row pieces (tools/bench_gate_apply.py: 35.7 vs 39.2 us)
+
+
+def se_gate_in_apply(m, c):
+    return SE_GATE_IN_APPLY and m * c <= SE_GATE_APPLY_MAX
+
+
 BN3_PARTS_FROM_DGRAD = policy("HN_BN3_PARTS_FROM_DGRAD", "1") != "0"   # the next block's last backward GEMM makes the BatchNorm-3 backward's partial sums
 
 
@@ -201,14 +211,20 @@ class XBlockFn(torch.autograd.Function):
         pooled = torch.empty((n, c), device=dev, dtype=F32)
         hid = torch.empty((n, cs), device=dev, dtype=F32)
         gate = torch.empty((n, c), device=dev, dtype=F32)
+        fc2_in_apply = se_gate_in_apply(m, c) and not XBLOCK_XF_GEMM
         lib().call("hn_se_mlp_fwd_parts", ptr(pool), hw // rb, 1.0 / hw, ptr(sw1), ptr(sb1), ptr(sw2), ptr(sb2), ptr(pooled), ptr(hid),
-                   ptr(gate), n, c, cs)
+                   None if fc2_in_apply else ptr(gate), n, c, cs)
         wp3, wt3 = pack_conv_weight(w3)
         if XBLOCK_XF_GEMM:      # BN2 + ReLU + gate in conv_block_3's operand loader (register-staged: measured 7-10 us slower per launch
             bg = None           # than the LDS-DMA loader, more than the extra pass below costs)
             z3, ps, pq = k_gemm_nt(z2, None, 0, grid, wp3, c, kp32(c), 1, stats=training, xform=(coef2[0], coef2[1], gate, hw, ACT_RELU))
         else:                   # second pass over z2: bg = relu(bn2(z2)) * gate, kept for conv_block_3's weight gradient
-            bg, _, _, _ = k_bn_apply_fused(z2, None, None, m, g2, b2, eps, momentum, None, None, ACT_RELU, coef=coef2, gate=gate, hw=hw)
+            if fc2_in_apply:    # ... with the second excitation layer in its prologue (one launch less per block)
+                bg = new_act(n, ho, wo, c, dev)
+                lib().call("hn_se_gate_apply", ptr(z2), ld(z2), ptr(coef2), ACT_RELU, ptr(hid), ptr(sw2), ptr(sb2), ptr(gate), ptr(bg), ld(bg),
+                           n, hw, c, cs)
+            else:
+                bg, _, _, _ = k_bn_apply_fused(z2, None, None, m, g2, b2, eps, momentum, None, None, ACT_RELU, coef=coef2, gate=gate, hw=hw)
             z3, ps, pq = k_gemm_nt(bg, None, 0, grid, wp3, c, kp32(c), 1, stats=training)
         zs = coefs = wts = None
         res = x
@@ -396,6 +412,11 @@ def conv_infer(x, packed, bias, cout, kind, stride, act, res=None, gate=None):
     return out
 
 
+def gate_folds_into_weights(b):
+    """conv_infer(gate=...) scales the 1x1 weights per image instead of the activation (a pixel tile must lie inside one image)"""
+    return INFER_GATE_IN_WEIGHTS and (b.shape[1] * b.shape[2]) % 128 == 0
+
+
 def se_gate_infer(b, w1, b1, w2, b2, apply=True):
     """SE squeeze / excite for the inference path: per-image channel sums (one pass), the MLP fed by the partial rows, then b * gate
     (apply = False: the gate [N, C] itself, for conv_infer(gate=...))"""
@@ -413,6 +434,11 @@ def se_gate_infer(b, w1, b1, w2, b2, apply=True):
     pooled = torch.empty((n, c), device=dev, dtype=F32)
     hid = torch.empty((n, cs), device=dev, dtype=F32)
     gate = torch.empty((n, c), device=dev, dtype=F32)
+    if apply and se_gate_in_apply(m, c):      # second layer + product in one launch
+        lib().call("hn_se_mlp_fwd_parts", ptr(ps), hw // rb, 1.0 / hw, ptr(w1), ptr(b1), None, None, ptr(pooled), ptr(hid), None, n, c, cs)
+        out = new_act(n, h, w, c, dev)
+        lib().call("hn_se_gate_apply", ptr(b), ld(b), None, ACT_NONE, ptr(hid), ptr(w2), ptr(b2), None, ptr(out), ld(out), n, hw, c, cs)
+        return out
     lib().call("hn_se_mlp_fwd_parts", ptr(ps), hw // rb, 1.0 / hw, ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(pooled), ptr(hid), ptr(gate), n, c, cs)
     return gate if not apply else apply_gate_rows(b, gate)
 

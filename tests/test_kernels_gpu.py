@@ -1329,3 +1329,43 @@ def test_head_output_conv_of_all_levels_in_one_launch(K, cout, act):
     assert not torch.isnan(ref).any()
     assert torch.equal(out, ref)
 
+
+
+@pytest.mark.parametrize("n,h,w,c,cs,act", [(16, 8, 16, 936, 234, 1), (4, 16, 32, 376, 94, 1), (3, 10, 10, 152, 16, 1), (2, 20, 20, 64, 6, 0),
+                                            (2, 18, 30, 936, 234, 0), (5, 7, 9, 24, 300, 1)])
+def test_se_excite_and_gated_apply_in_one_launch(K, n, h, w, c, cs, act):
+    """hn_se_gate_apply (second SE layer + Sigmoid + BatchNorm / ReLU / product, net/anynet.py:44-48,68-69) against the two-launch
+    composition hn_se_mlp_fwd's second layer + hn_bn_apply_fused(gate=...) (same summation order: equal to an ulp), and against fp32 torch"""
+    from multitask_hydranet_amd.ops import core as C
+    lib, ptr, ld = C.lib, C.ptr, C.ld
+    hw, m = h * w, n * h * w
+    z = (torch.randn(n, h, w, c, device=dev()) * 2).bfloat16()
+    coef = torch.stack([torch.rand(c, device=dev()) + 0.5, torch.randn(c, device=dev()) * 0.3, torch.zeros(c, device=dev()),
+                        torch.ones(c, device=dev())]).contiguous()
+    pooled = torch.rand(n, c, device=dev())
+    w1 = torch.randn(cs, c, device=dev()) / c ** 0.5
+    b1 = torch.randn(cs, device=dev()) * 0.2
+    w2 = torch.randn(c, cs, device=dev()) / cs ** 0.5
+    b2 = torch.randn(c, device=dev()) * 0.2
+    hid = torch.empty(n, cs, device=dev())
+    gate2 = torch.empty(n, c, device=dev())
+    lib().call("hn_se_mlp_fwd", ptr(pooled), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(hid), ptr(gate2), n, c, cs)     # both layers: the composition
+    for use_coef in (True, False):
+        cf = coef if use_coef else None
+        gate1 = torch.empty(n, c, device=dev())
+        out1 = torch.empty_like(z)
+        lib().call("hn_se_gate_apply", ptr(z), ld(z), ptr(cf), act, ptr(hid), ptr(w2), ptr(b2), ptr(gate1), ptr(out1), ld(out1), n, hw, c, cs)
+        rb = lib().query("hn_fused_row_block", m, c, hw, 0, 0)
+        out2 = torch.empty_like(z)
+        lib().call("hn_bn_apply_fused", ptr(z), ld(z), m, c, None, None, 0, m, None, None, 0.0, 0.0, None, None, ptr(cf), None, 0, act,
+                   ptr(out2), ld(out2), None, ptr(gate2), hw, rb)
+        torch.cuda.synchronize()
+        assert float((gate1 - gate2).abs().max()) <= 2.5e-7              # an ulp of a value in (0.5, 1): the compiler contracts the two
+        close(out1, out2, 2.0 ** -7, "out vs composition")               # dot products differently; one bf16 ulp where a product rounds the other way
+        g = torch.sigmoid(hid @ w2.t() + b2)
+        v = z.float() * (coef[0] if use_coef else 1.0) + (coef[1] if use_coef else 0.0)
+        v = torch.relu(v) if act == 1 else v
+        ref = v.bfloat16().float() * g[:, None, None, :]
+        close(gate1, g, 1e-5, "gate")
+        close(out1, ref, ACT_TOL, "out")
+
