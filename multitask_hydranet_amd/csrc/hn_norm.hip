@@ -635,56 +635,90 @@ __global__ void cast_pad_kernel(const float* src, int lds_, bf16* dst, int ldo, 
 // out[n][o] = act(bias[o] + sum_i W[o][i] * in[n][i]) : one wave per (n, o), lanes stride the contraction (coalesced weight rows)
 // S > 0: `in` holds S partial rows per image (in[n][i] = alpha * sum_j part[(n*S + j)][i], e.g. the SE squeeze from the per-row-block
 // channel sums of hn_bn_apply_fused); the o == 0 wave also stores the assembled vector to `store` [N][I] (kept for the backward pass).
-template <bool FOLD>   // FOLD: `in` holds S >= 1 partial rows per image (register-heavy path); else one dense row
-__global__ __launch_bounds__(256) void se_fc_rows_kernel(const float* W, const float* bias, const float* in, float* out, int N, int O, int I,
-                                                         int act, int S, float alpha, float* store) {
+__global__ __launch_bounds__(256) void se_fc_rows_kernel(const float* W, const float* bias, const float* in, float* out, int N, int O, int I, int act) {
     // image-major wave order with the row-order placement convention (hn_common.h): image n's waves run on the XCD that holds its rows
     const long wid = (long)xcd_remap(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (wid >= (long)N * O) return;
     const int n = (int)(wid / O), o = (int)(wid - (long)n * O);
     const float* wr = W + (long)o * I;
+    const float* xr = in + (long)n * I;
     float s = 0.f;
-    if (!FOLD) {
-        const float* xr = in + (long)n * I;
-        for (int i = lane; i < I; i += 64) s += wr[i] * xr[i];
-    } else
-    // a lane owns elements lane, lane + 64, ... (<= 16 per round of 1024): their loads are issued together
-    // (the nested "for i { for j < S }" form made every load wait for the previous one: 20 us at stage 4, S = 4)
+    for (int i = lane; i < I; i += 64) s += wr[i] * xr[i];
+    s = wave_sum(s);
+    if (lane == 0) {
+        s += bias[o];
+        out[wid] = act == HN_ACT_RELU ? (s > 0.f ? s : 0.f) : 1.f / (1.f + __expf(-s));
+    }
+}
+
+// The same layer fed by S partial rows per image: in[n][i] = alpha * sum_j part[n * S + j][i] (the SE squeeze from the per-row-block channel
+// sums of hn_bn_apply_fused); the o == 0 wave also stores the assembled vector to `store` [N][I] (kept for the backward pass).  One wave per
+// (n, two outputs).  A lane owns elements lane, lane + 64, ... (<= 16 per round of 1024).  The partial rows were just written by another
+// kernel (another XCD's L2): every DEPENDENT round of loads is a trip to memory (~2 us), so the weights and the first 1 + TR partial rows
+// (S <= 8 is what hn_fused_row_block leaves per image) are all issued before the first add -- one trip.  (The nested "for i { for j < S }"
+// form made every load wait for the previous one: 20 us at stage 4; rounds of four rows: 7.3 us.)  Two outputs per wave: half the waves
+// re-reading the image's partial rows, and all of them resident at once (stage 4: 1872 waves at three per SIMD).
+template <int TR>
+__global__ __launch_bounds__(256) void se_fc_parts_kernel(const float* W, const float* bias, const float* in, float* out, int N, int O, int I,
+                                                          int act, int S, float alpha, float* store) {
+    const int OP = (O + 1) >> 1;                                       // output pairs per image
+    const long wid = (long)xcd_remap(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (wid >= (long)N * OP) return;
+    const int n = (int)(wid / OP), o = 2 * (int)(wid - (long)n * OP);
+    const bool two = o + 1 < O;
+    const float* wr0 = W + (long)o * I;
+    const float* wr1 = W + (long)(two ? o + 1 : o) * I;
+    float s0 = 0.f, s1 = 0.f;
     for (int base = 0; base < I; base += 1024) {
-        float v[16], wv[16];
+        float v[16], w0[16], w1[16], t[TR][16];
         const float* xr = in + (long)n * S * I + base + lane;
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const bool ok = base + lane + 64 * k < I;
             v[k] = ok ? xr[64 * k] : 0.f;
-            wv[k] = ok ? wr[base + lane + 64 * k] : 0.f;
+            w0[k] = ok ? wr0[base + lane + 64 * k] : 0.f;
+            w1[k] = ok ? wr1[base + lane + 64 * k] : 0.f;
         }
-        // the partial rows were just written by another kernel (another XCD's L2): every dependent round is a trip to memory (~2 us), so
-        // four rows (64 loads) are in flight per round
-        for (int j0 = 1; j0 < S; j0 += 4) {
-            float t[4][16];
+#pragma unroll
+        for (int jj = 0; jj < TR; ++jj)
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                t[jj][k] = (1 + jj < S && base + lane + 64 * k < I) ? xr[(long)(1 + jj) * I + 64 * k] : 0.f;
+#pragma unroll
+        for (int jj = 0; jj < TR; ++jj)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] += t[jj][k];
+        for (int j0 = 1 + TR; j0 < S; j0 += 4) {                         // more rows: rounds of four
+            float u[4][16];
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
                 for (int k = 0; k < 16; ++k)
-                    t[jj][k] = (j0 + jj < S && base + lane + 64 * k < I) ? xr[(long)(j0 + jj) * I + 64 * k] : 0.f;
+                    u[jj][k] = (j0 + jj < S && base + lane + 64 * k < I) ? xr[(long)(j0 + jj) * I + 64 * k] : 0.f;
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-                for (int k = 0; k < 16; ++k) v[k] += t[jj][k];
+                for (int k = 0; k < 16; ++k) v[k] += u[jj][k];
         }
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             v[k] *= alpha;
             if (store && o == 0 && base + lane + 64 * k < I) store[(long)n * I + base + lane + 64 * k] = v[k];
-            s += wv[k] * v[k];
+            s0 += w0[k] * v[k];
+            s1 += w1[k] * v[k];
         }
     }
-    s = wave_sum(s);
+    s0 = wave_sum(s0);
+    s1 = wave_sum(s1);
     if (lane == 0) {
-        s += bias[o];
-        out[wid] = act == HN_ACT_RELU ? (s > 0.f ? s : 0.f) : 1.f / (1.f + __expf(-s));
+        s0 += bias[o];
+        out[(long)n * O + o] = act == HN_ACT_RELU ? (s0 > 0.f ? s0 : 0.f) : 1.f / (1.f + __expf(-s0));
+        if (two) {
+            s1 += bias[o + 1];
+            out[(long)n * O + o + 1] = act == HN_ACT_RELU ? (s1 > 0.f ? s1 : 0.f) : 1.f / (1.f + __expf(-s1));
+        }
     }
 }
 
@@ -706,32 +740,46 @@ __global__ __launch_bounds__(16 * PARTS) void se_fc_cols_kernel(const float* W, 
     const float* inr = in + (long)n * (S > 0 ? S : 1) * I;
     const float* auxr = aux ? aux + (long)n * I : nullptr;
     const bool ov = o < O;
-    // the partition's elements (<= 16 per round) are loaded together, one round per partial row, before the first multiply
+    // the partition's elements (<= 16 per round): the weights, the gate values and up to four partial rows are issued together -- every
+    // dependent round of loads of this fresh data is a trip to memory (~2 us; the form with one round per group of rows and the gate
+    // loads behind them took three trips: 9.9 us per launch at stage 4).  PARTS == 16 (the second launch: one dense input row, no gate)
+    // is the lean form: the extra rows' registers would cost its 3776 waves at stage 4 a second round of workgroups.
+    constexpr int TR = PARTS == 64 ? 3 : 0;
     for (int ib = i0; ib < i1; ib += 16) {
-        float v[16], wv[16];
+        float v[16], wv[16], gv[16], t[TR + 1][16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const bool ok = ib + k < i1;
             v[k] = ok ? inr[ib + k] : 0.f;
             wv[k] = (ok && ov) ? W[(long)(ib + k) * O + o] : 0.f;
+            gv[k] = (TR && ok && pre) ? auxr[ib + k] : 0.f;
         }
-        for (int j0 = 1; j0 < S; j0 += 4) {                            // four partial rows per round (fresh data: a trip to memory per round)
-            float t[4][16];
+#pragma unroll
+        for (int jj = 0; jj < TR; ++jj)
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                t[jj][k] = (1 + jj < S && ib + k < i1) ? inr[(long)(1 + jj) * I + ib + k] : 0.f;
+#pragma unroll
+        for (int jj = 0; jj < TR; ++jj)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] += t[jj][k];
+        for (int j0 = 1 + TR; j0 < S; j0 += 4) {                       // more rows: four per round
+            float u[4][16];
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
                 for (int k = 0; k < 16; ++k)
-                    t[jj][k] = (j0 + jj < S && ib + k < i1) ? inr[(long)(j0 + jj) * I + ib + k] : 0.f;
+                    u[jj][k] = (j0 + jj < S && ib + k < i1) ? inr[(long)(j0 + jj) * I + ib + k] : 0.f;
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-                for (int k = 0; k < 16; ++k) v[k] += t[jj][k];
+                for (int k = 0; k < 16; ++k) v[k] += u[jj][k];
         }
         if (pre) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 if (ib + k < i1) {
-                    const float g = auxr[ib + k];
+                    const float g = TR ? gv[k] : auxr[ib + k];
                     v[k] *= g * (1.f - g);
                     if (store && bx == 0 && ox == 0) store[(long)n * I + ib + k] = v[k];
                 }
@@ -1069,10 +1117,8 @@ extern "C" int hn_cast_f32_to_bf16_pad(const float* src, int lds_, void* dst, in
 extern "C" int hn_se_mlp_fwd(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2, float* hid, float* gate,
                              int N, int C, int Cs, hipStream_t st) {
     HN_CHECK_ARG(pooled && w1 && b1 && w2 && b2 && hid && gate && N > 0 && C > 0 && Cs > 0);
-    hipLaunchKernelGGL(se_fc_rows_kernel<false>, dim3(cdiv((long)N * Cs, 4)), dim3(256), 0, st, w1, b1, pooled, hid, N, Cs, C, HN_ACT_RELU, 0, 1.f,
-                       (float*)nullptr);
-    hipLaunchKernelGGL(se_fc_rows_kernel<false>, dim3(cdiv((long)N * C, 4)), dim3(256), 0, st, w2, b2, (const float*)hid, gate, N, C, Cs,
-                       HN_ACT_SIGMOID, 0, 1.f, (float*)nullptr);
+    hipLaunchKernelGGL(se_fc_rows_kernel, dim3(cdiv((long)N * Cs, 4)), dim3(256), 0, st, w1, b1, pooled, hid, N, Cs, C, HN_ACT_RELU);
+    hipLaunchKernelGGL(se_fc_rows_kernel, dim3(cdiv((long)N * C, 4)), dim3(256), 0, st, w2, b2, (const float*)hid, gate, N, C, Cs, HN_ACT_SIGMOID);
     HN_LAUNCH_CHECK();
 }
 
@@ -1080,11 +1126,12 @@ extern "C" int hn_se_mlp_fwd(const float* pooled, const float* w1, const float* 
 extern "C" int hn_se_mlp_fwd_parts(const float* pool_part, int S, float alpha, const float* w1, const float* b1, const float* w2, const float* b2,
                                    float* pooled, float* hid, float* gate, int N, int C, int Cs, hipStream_t st) {
     HN_CHECK_ARG(pool_part && S > 0 && w1 && b1 && pooled && hid && (!gate || (w2 && b2)) && N > 0 && C > 0 && Cs > 0);
-    hipLaunchKernelGGL(se_fc_rows_kernel<true>, dim3(cdiv((long)N * Cs, 4)), dim3(256), 0, st, w1, b1, pool_part, hid, N, Cs, C, HN_ACT_RELU, S,
-                       alpha, pooled);
+    const dim3 grid(cdiv((long)N * ((Cs + 1) / 2), 4));
+    if (S <= 4) hipLaunchKernelGGL(se_fc_parts_kernel<3>, grid, dim3(256), 0, st, w1, b1, pool_part, hid, N, Cs, C, HN_ACT_RELU, S, alpha, pooled);
+    else hipLaunchKernelGGL(se_fc_parts_kernel<7>, grid, dim3(256), 0, st, w1, b1, pool_part, hid, N, Cs, C, HN_ACT_RELU, S, alpha, pooled);
     if (gate)                                                           // null: the second layer runs in hn_se_gate_apply's prologue
-        hipLaunchKernelGGL(se_fc_rows_kernel<false>, dim3(cdiv((long)N * C, 4)), dim3(256), 0, st, w2, b2, (const float*)hid, gate, N, C, Cs,
-                           HN_ACT_SIGMOID, 0, 1.f, (float*)nullptr);
+        hipLaunchKernelGGL(se_fc_rows_kernel, dim3(cdiv((long)N * C, 4)), dim3(256), 0, st, w2, b2, (const float*)hid, gate, N, C, Cs,
+                           HN_ACT_SIGMOID);
     HN_LAUNCH_CHECK();
 }
 

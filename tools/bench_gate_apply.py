@@ -65,11 +65,19 @@ def main():
             lib().call("hn_se_mlp_fwd_parts", P(pool), S, 1.0 / hw, P(w1), P(b1), None, None, P(pooled), P(hid), None, n, c, cs)
 
         t1 = timeit(fc1)
-        line = f"{name} M={m} C={c} Cs={cs}: first layer {t1:5.1f} | + second layer + apply (rb {rb}) {timeit(two) - t1:5.1f} | + gate_apply (cw, RB):"
-        for cw in (32, 64, 160):
+        # backward MLP (two launches), fed by the partial rows of the gate gradient a GEMM epilogue leaves: one per 64-row tile
+        sb = max(1, min(16, hw // 64))
+        pdot = torch.randn(n * sb, c, device=dev)
+        dpre2, dpre1, dpool = torch.empty(n, c, device=dev), torch.empty(n, cs, device=dev), torch.empty(n, c, device=dev)
+        dw1, db1, dw2, db2 = torch.empty_like(w1), torch.empty_like(b1), torch.empty_like(w2), torch.empty_like(b2)
+        gate.uniform_(0.2, 0.8); hid.uniform_(-1, 1); pooled.uniform_(0, 1)
+        tb = timeit(lambda: lib().call("hn_se_mlp_bwd_parts", P(pdot), sb, P(gate), P(hid), P(pooled), P(w1), P(w2), P(dpre2), P(dpre1), P(dpool),
+                                       None, None, None, None, n, c, cs))
+        line = f"{name} M={m} C={c} Cs={cs}: first layer (S {S}) {t1:5.1f} | backward MLP (S {sb}) {tb:5.1f} | + second layer + apply (rb {rb}) {timeit(two) - t1:5.1f} | + gate_apply (cw, RB):"
+        for cw in (32,):
             if cw == 160 and c > 160:
                 continue
-            for rbk in (0, 128, 256, 512, 1024, 2048):
+            for rbk in (0,):
                 lib().call("hn_debug_knob", 16, cw)
                 lib().call("hn_debug_knob", 17, rbk)
                 line += f" ({cw},{rbk})={timeit(one) - t1:.1f}"
