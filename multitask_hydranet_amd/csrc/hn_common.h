@@ -149,10 +149,13 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// sum over the 64 lanes of a wave (every lane gets the total; call with all lanes active): DPP row sums, then the four rows through
+// v_readlane.  (Six __shfl_xor steps are six DEPENDENT ds_bpermute round trips through the LDS pipe, ~0.4 us per sum: the eight sums of
+// hn_se_gate_apply's prologue were 3 us of its 3.8.)
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    const int b = __builtin_bit_cast(int, row16_sum(v));
+    return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16))) +
+           (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48)));
 }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

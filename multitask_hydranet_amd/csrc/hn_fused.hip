@@ -483,16 +483,20 @@ __global__ __launch_bounds__(256) void se_gate_apply_kernel(const FGateApply p) 
     bf16x8 vz0 = {}, vz1 = {};
     if (h0) vz0 = ld8(p.z + m * p.ldz + c);
     if (h1) vz1 = ld8(p.z + (m + rln) * p.ldz + c);
-    float sc[8], sh[8];
+    // (no select on the loaded values here: a v_cndmask behind a load is a wait for ALL loads in flight, in front of the weight loads)
+    const bool hc = p.coef && active;
+    const float* cp = hc ? p.coef + c : p.b2;                          // any valid address when there are no coefficients
+    const int cstep = hc ? p.C : 0;
+    float rsc[8], rsh[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        sc[k] = (p.coef && active) ? p.coef[c + k] : 1.f;
-        sh[k] = (p.coef && active) ? p.coef[p.C + c + k] : 0.f;
-    }
+    for (int k = 0; k < 8; ++k) { rsc[k] = cp[hc ? k : 0]; rsh[k] = cp[cstep + (hc ? k : 0)]; }
     // wave wv: channels wv, wv + 4, ... of the chunk; all weight loads of a 256-wide slab of the contraction issued together
-    float acc[GA_JMAX];
+    float acc[GA_JMAX], bias[GA_JMAX];
 #pragma unroll
-    for (int jj = 0; jj < GA_JMAX; ++jj) acc[jj] = 0.f;
+    for (int jj = 0; jj < GA_JMAX; ++jj) {
+        acc[jj] = 0.f;
+        bias[jj] = p.b2[c0 + (wv + 4 * jj < nch ? wv + 4 * jj : 0)];   // with the weights: behind the sums each would be a trip of its own
+    }
     const float* hr = p.hid + n * p.Cs;
     for (int base = 0; base < p.Cs; base += 64 * GA_KS) {
         float hv[GA_KS];
@@ -515,7 +519,7 @@ __global__ __launch_bounds__(256) void se_gate_apply_kernel(const FGateApply p) 
     for (int jj = 0; jj < GA_JMAX; ++jj) {
         const int j = wv + 4 * jj;
         if (j < nch) {                                                  // wave-uniform
-            const float s = wave_sum(acc[jj]) + p.b2[c0 + j];
+            const float s = wave_sum(acc[jj]) + bias[jj];
             const float g = 1.f / (1.f + __expf(-s));
             if (lane == 0) {
                 sgate[j] = g;
@@ -524,9 +528,13 @@ __global__ __launch_bounds__(256) void se_gate_apply_kernel(const FGateApply p) 
         }
     }
     __syncthreads();
-    float gt[8];
+    float gt[8], sc[8], sh[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) gt[k] = active ? sgate[cl * 8 + k] : 1.f;
+    for (int k = 0; k < 8; ++k) {
+        gt[k] = active ? sgate[cl * 8 + k] : 1.f;
+        sc[k] = hc ? rsc[k] : 1.f;
+        sh[k] = hc ? rsh[k] : 0.f;
+    }
     auto apply = [&](const bf16x8& vz, long row) {
         float v[8];
 #pragma unroll

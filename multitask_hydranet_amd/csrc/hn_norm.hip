@@ -643,11 +643,12 @@ __global__ __launch_bounds__(256) void se_fc_rows_kernel(const float* W, const f
     const int n = (int)(wid / O), o = (int)(wid - (long)n * O);
     const float* wr = W + (long)o * I;
     const float* xr = in + (long)n * I;
+    const float bo = bias[o];                                          // with the operands: behind the sum it is a trip of its own
     float s = 0.f;
     for (int i = lane; i < I; i += 64) s += wr[i] * xr[i];
     s = wave_sum(s);
     if (lane == 0) {
-        s += bias[o];
+        s += bo;
         out[wid] = act == HN_ACT_RELU ? (s > 0.f ? s : 0.f) : 1.f / (1.f + __expf(-s));
     }
 }
@@ -670,6 +671,7 @@ __global__ __launch_bounds__(256) void se_fc_parts_kernel(const float* W, const 
     const bool two = o + 1 < O;
     const float* wr0 = W + (long)o * I;
     const float* wr1 = W + (long)(two ? o + 1 : o) * I;
+    const float bo0 = bias[o], bo1 = bias[two ? o + 1 : o];           // with the operands: behind the sums they are a trip of their own
     float s0 = 0.f, s1 = 0.f;
     for (int base = 0; base < I; base += 1024) {
         float v[16], w0[16], w1[16], t[TR][16];
@@ -713,10 +715,10 @@ __global__ __launch_bounds__(256) void se_fc_parts_kernel(const float* W, const 
     s0 = wave_sum(s0);
     s1 = wave_sum(s1);
     if (lane == 0) {
-        s0 += bias[o];
+        s0 += bo0;
         out[(long)n * O + o] = act == HN_ACT_RELU ? (s0 > 0.f ? s0 : 0.f) : 1.f / (1.f + __expf(-s0));
         if (two) {
-            s1 += bias[o + 1];
+            s1 += bo1;
             out[(long)n * O + o + 1] = act == HN_ACT_RELU ? (s1 > 0.f ? s1 : 0.f) : 1.f / (1.f + __expf(-s1));
         }
     }
@@ -740,6 +742,7 @@ __global__ __launch_bounds__(16 * PARTS) void se_fc_cols_kernel(const float* W, 
     const float* inr = in + (long)n * (S > 0 ? S : 1) * I;
     const float* auxr = aux ? aux + (long)n * I : nullptr;
     const bool ov = o < O;
+    const float mask = (post && ov && part == 0) ? aux2[(long)n * O + o] : 1.f;      // (up front: behind the reduction it is a trip of its own)
     // the partition's elements (<= 16 per round): the weights, the gate values and up to four partial rows are issued together -- every
     // dependent round of loads of this fresh data is a trip to memory (~2 us; the form with one round per group of rows and the gate
     // loads behind them took three trips: 9.9 us per launch at stage 4).  PARTS == 16 (the second launch: one dense input row, no gate)
@@ -799,7 +802,7 @@ __global__ __launch_bounds__(16 * PARTS) void se_fc_cols_kernel(const float* W, 
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < PARTS; ++k) t += red[k][ox];
-        if (post && aux2[(long)n * O + o] <= 0.f) t = 0.f;
+        if (post && mask <= 0.f) t = 0.f;
         out[(long)n * O + o] = t;
     }
 }
