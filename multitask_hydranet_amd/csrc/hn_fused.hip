@@ -49,12 +49,23 @@ __device__ __forceinline__ void chunk_partial_sums(const float* p1, const float*
     if (q * 4 < nch) {
         const float* a = p1 + c0 + q * 4;
         const float* b = p2 + c0 + q * 4;
-#pragma unroll 4
-        for (int r = rl; r < P; r += 8) {
-            const f32x4 va = *reinterpret_cast<const f32x4*>(a + (long)r * C);
-            const f32x4 vb = *reinterpret_cast<const f32x4*>(b + (long)r * C);
+        // PSR rows (2 PSR loads) per round: every round is a trip to the producer's partial rows (P = 128, 16 rows per lane: three
+        // rounds; four with rounds of 4; eight per round costs the apply kernel its fourth workgroup per CU)
+        constexpr int PSR = 6;
+        for (int r0 = rl; r0 < P; r0 += 8 * PSR) {
+            f32x4 va[PSR], vb[PSR];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { s1[k] += va[k]; s2[k] += vb[k]; }
+            for (int i = 0; i < PSR; ++i) {
+                const int r = r0 + 8 * i < P ? r0 + 8 * i : rl;          // (a row past the end: re-read the lane's first row, added as zero)
+                va[i] = *reinterpret_cast<const f32x4*>(a + (long)r * C);
+                vb[i] = *reinterpret_cast<const f32x4*>(b + (long)r * C);
+            }
+#pragma unroll
+            for (int i = 0; i < PSR; ++i) {
+                const bool ok = r0 + 8 * i < P;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { s1[k] += ok ? (double)va[i][k] : 0.0; s2[k] += ok ? (double)vb[i][k] : 0.0; }
+            }
         }
     }
 #pragma unroll
@@ -70,9 +81,16 @@ __device__ __forceinline__ void chunk_partial_sums(const float* p1, const float*
 }
 
 // coefficient set of the chunk into L.coef[0..3]; `writer` (row block 0) also stores it / updates the running statistics
+template <bool STATS = true>   // STATS false: an instance without the partial-statistics path (its loads' registers: 114 vs 85 VGPRs in the apply pass)
 __device__ __forceinline__ void chunk_coefs(const BnSrc& b, int C, int c0, int nch, bool writer, FusedLds& L) {
     const int tid = threadIdx.x;
-    if (b.P > 0) {
+    if (STATS && b.P > 0) {
+        // gamma / beta / the running statistics are read BEFORE the partial sums (behind them every one of these loads was a dependent
+        // trip of its own -- rm, then rv, in the writing workgroup: ~3 us on the kernel's critical path)
+        const int cc = c0 + (tid < nch ? tid : 0);
+        const float ga = b.gamma[cc], be = b.beta[cc];
+        const bool upd = writer && b.rm && tid < nch;
+        const float rm0 = upd ? b.rm[cc] : 0.f, rv0 = upd ? b.rv[cc] : 0.f;
         chunk_partial_sums(b.psum, b.psq, b.P, C, c0, nch, L);
         if (tid < nch) {
             const int c = c0 + tid;
@@ -80,15 +98,15 @@ __device__ __forceinline__ void chunk_coefs(const BnSrc& b, int C, int c0, int n
             double var = L.r2[0][tid] / b.count - mu * mu;
             if (var < 0.0) var = 0.0;
             const float rs = (float)(1.0 / sqrt(var + (double)b.eps));
-            const float sc = b.gamma[c] * rs;
-            const float sh = b.beta[c] - (float)mu * sc;
+            const float sc = ga * rs;
+            const float sh = be - (float)mu * sc;
             L.coef[0][tid] = sc; L.coef[1][tid] = sh; L.coef[2][tid] = (float)mu; L.coef[3][tid] = rs;
             if (writer) {
                 if (b.coef) { b.coef[c] = sc; b.coef[C + c] = sh; b.coef[2 * C + c] = (float)mu; b.coef[3 * C + c] = rs; }
                 if (b.rm) {
                     const double unb = b.count > 1.0 ? var * b.count / (b.count - 1.0) : var;
-                    b.rm[c] = (1.f - b.momentum) * b.rm[c] + b.momentum * (float)mu;
-                    b.rv[c] = (1.f - b.momentum) * b.rv[c] + b.momentum * (float)unb;
+                    b.rm[c] = (1.f - b.momentum) * rm0 + b.momentum * (float)mu;
+                    b.rv[c] = (1.f - b.momentum) * rv0 + b.momentum * (float)unb;
                 }
             }
         }
@@ -153,6 +171,7 @@ struct FApply {
     long M; int C; long RB; int cw; int xcd;
 };
 
+template <bool STATS>              // false: P <= 0 launches (eval-mode / given coefficients: the inference passes, the gated second pass over z2)
 __global__ __launch_bounds__(256) void fused_apply_kernel(const FApply p) {
     __shared__ FusedLds L;
     __shared__ float scratch[2048];
@@ -160,21 +179,38 @@ __global__ __launch_bounds__(256) void fused_apply_kernel(const FApply p) {
     fused_block(p.xcd, bx, by);
     const int c0 = bx * p.cw;
     const int nch = p.C - c0 < p.cw ? p.C - c0 : p.cw;
-    chunk_coefs(p.bn, p.C, c0, nch, by == 0, L);
     const int cln = nch >> 3, rln = 256 / cln;
     const int tid = threadIdx.x, cl = tid % cln, rl = tid / cln;
     const bool active = rl < rln;
-    float sc[8], sh[8], acc[8], dummy[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { sc[k] = L.coef[0][cl * 8 + k]; sh[k] = L.coef[1][cl * 8 + k]; acc[k] = 0.f; dummy[k] = 0.f; }
     const long m0 = (long)by * p.RB;
     long m1 = m0 + p.RB;
     if (m1 > p.M) m1 = p.M;
     const int c = c0 + cl * 8;
+    // Everything the workgroup reads first is issued before the prologue's first barrier -- the row pieces of the first iteration and
+    // the gate here, the BatchNorm parameters in chunk_coefs -- so that the prologue's trip to the partial statistics and the first trip
+    // to the rows are ONE trip (they were two, plus one for the gate: ~1 us each on an 5-9 us launch, 159 launches per training step).
+    long m = m0 + rl;
+    const bool h0 = active && m < m1, h1 = active && m + rln < m1;
+    bf16x8 pz0 = {}, pz1 = {}, pr0 = {}, pr1 = {};
+    if (h0) pz0 = ld8(p.z + m * p.ldz + c);
+    if (h1) pz1 = ld8(p.z + (m + rln) * p.ldz + c);
+    if (p.res) {
+        if (h0) pr0 = ld8(p.res + m * p.ldr + c);
+        if (h1) pr1 = ld8(p.res + (m + rln) * p.ldr + c);
+    }
     float gt[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) gt[k] = (p.gate && active) ? p.gate[(m0 / p.HW) * p.C + c + k] : 1.f;
-    auto apply = [&](const bf16x8& vz, const bf16x8& vr, long m) {
+    for (int k = 0; k < 8; ++k) gt[k] = 1.f;
+    if (p.gate && active) {
+        const float* gp = p.gate + (m0 / p.HW) * p.C + c;                  // (one 64-bit division, not one per channel)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) gt[k] = gp[k];
+    }
+    chunk_coefs<STATS>(p.bn, p.C, c0, nch, by == 0, L);
+    float sc[8], sh[8], acc[8], dummy[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sc[k] = L.coef[0][cl * 8 + k]; sh[k] = L.coef[1][cl * 8 + k]; acc[k] = 0.f; dummy[k] = 0.f; }
+    auto apply = [&](const bf16x8& vz, const bf16x8& vr, long row) {
         float v[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = bf2f(vz[k]) * sc[k] + sh[k];
@@ -194,21 +230,22 @@ __global__ __launch_bounds__(256) void fused_apply_kernel(const FApply p) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) acc[k] += bf2f(o[k]);
         }
-        if (p.out) st8(p.out + m * p.ldo + c, o);
+        if (p.out) st8(p.out + row * p.ldo + c, o);
     };
+    if (h0) apply(pz0, pr0, m);
+    if (h1) apply(pz1, pr1, m + rln);
     if (active) {
-        long m = m0 + rl;
-        for (; m + rln < m1; m += 2 * rln) {
+        for (m += 2 * rln; m + rln < m1; m += 2 * rln) {
             const long mb = m + rln;
             const bf16x8 vz0 = ld8(p.z + m * p.ldz + c), vz1 = ld8(p.z + mb * p.ldz + c);
-            bf16x8 vr0 = vz0, vr1 = vz1;
+            bf16x8 vr0 = {}, vr1 = {};       // (not "= vz0": the copy is a wait for the z loads in front of the residual loads -- two trips per iteration)
             if (p.res) { vr0 = ld8(p.res + m * p.ldr + c); vr1 = ld8(p.res + mb * p.ldr + c); }
             apply(vz0, vr0, m);
             apply(vz1, vr1, mb);
         }
         if (m < m1) {
             const bf16x8 vz0 = ld8(p.z + m * p.ldz + c);
-            bf16x8 vr0 = vz0;
+            bf16x8 vr0 = {};
             if (p.res) vr0 = ld8(p.res + m * p.ldr + c);
             apply(vz0, vr0, m);
         }
@@ -246,6 +283,36 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(const FBwd p) {
     const int c0 = bx * p.cw;
     const int nch = p.C - c0 < p.cw ? p.C - c0 : p.cw;
     const int tid = threadIdx.x;
+    const int cln = nch >> 3, rln = 256 / cln;
+    const int cl = tid % cln, rl = tid / cln;
+    const bool active = rl < rln;
+    const int c = c0 + cl * 8;
+    const long m0 = (long)by * p.RB;
+    long m1 = m0 + p.RB;
+    if (m1 > p.M) m1 = p.M;
+    // Everything the workgroup reads first is issued before the first barrier (see fused_apply_kernel): the row pieces of the first
+    // iteration, the forward coefficients, the SE gate / pooled gradient -- ONE trip together with the prologue's partial sums (the apply
+    // pass made three: partial sums, then the coefficients, then the rows).
+    long mp = m0 + rl;
+    const bool h0 = active && mp < m1, h1 = active && mp + rln < m1;
+    bf16x8 qd0 = {}, qd1 = {}, qz0 = {}, qz1 = {}, qy0 = {}, qy1 = {};
+    if (h0) { qd0 = ld8(p.dout + mp * p.ldd + c); qz0 = ld8(p.z + mp * p.ldz + c); }
+    if (h1) { qd1 = ld8(p.dout + (mp + rln) * p.ldd + c); qz1 = ld8(p.z + (mp + rln) * p.ldz + c); }
+    if (VAR == 1) {
+        if (h0) qy0 = ld8(p.y + mp * p.ldy + c);
+        if (h1) qy1 = ld8(p.y + (mp + rln) * p.ldy + c);
+    }
+    const int cc = c0 + (tid < nch ? tid : 0);
+    const float f0 = p.coef[cc], f1 = p.coef[p.C + cc], f2 = p.coef[2 * p.C + cc], f3 = p.coef[3 * p.C + cc];
+    float gt[8], dp[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { gt[k] = 1.f; dp[k] = 0.f; }
+    if (VAR == 2 && active) {
+        const long n = m0 / p.HW;
+        const float inv = 1.0f / (float)p.HW;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { gt[k] = p.gate[n * p.C + c + k]; dp[k] = p.dpool[n * p.C + c + k] * inv; }
+    }
     if (APPLY) {
         chunk_partial_sums(p.pg, p.pgx, p.P, p.C, c0, nch, L);
         if (tid < nch) {
@@ -258,30 +325,14 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(const FBwd p) {
             }
         }
     }
-    if (tid < nch) {
-        const int c = c0 + tid;
-        L.coef[0][tid] = p.coef[c]; L.coef[1][tid] = p.coef[p.C + c]; L.coef[2][tid] = p.coef[2 * p.C + c]; L.coef[3][tid] = p.coef[3 * p.C + c];
-    }
+    if (tid < nch) { L.coef[0][tid] = f0; L.coef[1][tid] = f1; L.coef[2][tid] = f2; L.coef[3][tid] = f3; }
     __syncthreads();
-    const int cln = nch >> 3, rln = 256 / cln;
-    const int cl = tid % cln, rl = tid / cln;
-    const bool active = rl < rln;
-    const int c = c0 + cl * 8;
-    float sc[8], sh[8], mu[8], rs[8], mg[8], mgx[8], gt[8], dp[8], s1[8], s2[8];
-    const long m0 = (long)by * p.RB;
-    long m1 = m0 + p.RB;
-    if (m1 > p.M) m1 = p.M;
+    float sc[8], sh[8], mu[8], rs[8], mg[8], mgx[8], s1[8], s2[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         sc[k] = L.coef[0][cl * 8 + k]; sh[k] = L.coef[1][cl * 8 + k]; mu[k] = L.coef[2][cl * 8 + k]; rs[k] = L.coef[3][cl * 8 + k];
         mg[k] = APPLY ? L.coef[4][cl * 8 + k] : 0.f; mgx[k] = APPLY ? L.coef[5][cl * 8 + k] : 0.f;
-        s1[k] = 0.f; s2[k] = 0.f; gt[k] = 1.f; dp[k] = 0.f;
-    }
-    if (VAR == 2 && active) {
-        const long n = m0 / p.HW;
-        const float inv = 1.0f / (float)p.HW;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { gt[k] = p.gate[n * p.C + c + k]; dp[k] = p.dpool[n * p.C + c + k] * inv; }
+        s1[k] = 0.f; s2[k] = 0.f;
     }
     auto one = [&](const bf16x8& vd, const bf16x8& vz, const bf16x8& vy, long m) {
         float z[8], g[8];
@@ -320,8 +371,10 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(const FBwd p) {
             if (p.gout) st8(p.gout + m * p.ldg + c, og);
         }
     };
+    if (h0) one(qd0, qz0, qy0, mp);
+    if (h1) one(qd1, qz1, qy1, mp + rln);
     if (active) {
-        long m = m0 + rl;
+        long m = mp + 2 * rln;
         for (; m + rln < m1; m += 2 * rln) {
             const long mb = m + rln;
             const bf16x8 vd0 = ld8(p.dout + m * p.ldd + c), vd1 = ld8(p.dout + mb * p.ldd + c);
@@ -611,7 +664,8 @@ extern "C" int hn_bn_apply_fused(const void* z, int ldz, long M, int C, const fl
     p.bn.momentum = momentum; p.bn.rm = rm; p.bn.rv = rv; p.bn.coef = coef;
     p.res = (const bf16*)res; p.ldr = ldr; p.act = act; p.out = (bf16*)out; p.ldo = ldo; p.pool = pool; p.M = M; p.C = C; p.RB = RB;
     p.gate = gate; p.HW = HW; p.cw = chunk_width(C); p.xcd = (int)g_hn_knob[8];
-    hipLaunchKernelGGL(fused_apply_kernel, fused_grid(M, C, RB), dim3(256), 0, st, p);
+    if (P > 0) hipLaunchKernelGGL(fused_apply_kernel<true>, fused_grid(M, C, RB), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(fused_apply_kernel<false>, fused_grid(M, C, RB), dim3(256), 0, st, p);
     HN_LAUNCH_CHECK();
 }
 
