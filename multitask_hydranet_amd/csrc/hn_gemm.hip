@@ -230,7 +230,7 @@ __device__ __forceinline__ void stat_terms4(int emode, const f32x4 q, const f32x
 // PLAIN: plain pixel rows of ONE tensor, one tap (x.mode 0: every 1x1 conv and its data gradient) -- no coordinate tables, no tap
 // bookkeeping, per-row source offsets computed once: the generic form carries ~1 000 instructions of prologue and a branchy loop body for
 // the 3x3 / stride-2 / concat modes that these launches (the latency-bound majority of the step's GEMMs) never use.
-template <int BC, int BP, int WGC, int WGP, bool OUT_F32, int R, bool XF = false, int KG = 1, bool PLAIN = false>
+template <int BC, int BP, int WGC, int WGP, bool OUT_F32, int R, bool XF = false, int KG = 1, bool PLAIN = false, bool EPRE = false>
 __global__ __launch_bounds__(256 * KG) void gemm_nt_kernel(const GemmNT p) {
     static_assert(!XF || R == 2, "the register-staged operand transform is written for the double buffer");
     static_assert(!PLAIN || !XF, "the plain-rows form has no operand transform");
@@ -333,6 +333,57 @@ __global__ __launch_bounds__(256 * KG) void gemm_nt_kernel(const GemmNT p) {
     for (int i = 0; i < WR; ++i) {
         const int co = c_blk + r0 + 32 * i;
         wo[i] = (r0 + 32 * i < BC && co < p.Nout) ? (long)co * Ktot + sub : -1;
+    }
+
+    // EPRE (the instance the small-tile launches with a statistics operand or an addend take): epilogue operands whose addresses do not
+    // depend on the product are requested HERE and arrive under the K loop (older than every stage load, so the loop's counted vmcnt
+    // waits still hold): the forward tensor of the statistics epilogue (emode 1 / 2), the addend and the emode-3 operands of the write-out
+    // phase (<= 2 iterations per thread).  Behind the loop each of them was a dependent trip to memory -- one per write-out iteration --
+    // at the end of a 14-16 us launch.  (Their ~40 registers stay out of the plain instance: 76 VGPRs, six workgroups per CU.)
+    constexpr int NPC_ = BC / 8, NIT = (BP * NPC_ + 255) / 256, PRE = (EPRE && NIT <= 2) ? NIT : 0;
+    static_assert(!EPRE || NIT <= 2, "the prefetching instance is for tiles of <= 512 output pieces");
+    const bool staged_ = !OUT_F32 && (p.Nout & 7) == 0 && (p.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0 &&
+                         (p.rpi == 0 || (p.img_stride & 7) == 0);
+    const bool pre_stat = EPRE && p.psum != nullptr && (p.emode == 1 || p.emode == 2);
+    bf16x4 pez[EPRE ? TC : 1][EPRE ? TP : 1];
+    if constexpr (EPRE) {
+#pragma unroll
+        for (int i = 0; i < TC; ++i) {
+            const int co0 = c_blk + wc * WC + i * 16 + (lane >> 4) * 4;
+            const bool ev = co0 + 3 < p.Nout;
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                const long pix = p_blk + wp * WP + j * 16 + (lane & 15);
+                pez[i][j] = (bf16x4){};
+                if (pre_stat && ev && pix < p.x.M) pez[i][j] = *reinterpret_cast<const bf16x4*>(p.ez + pix * p.ld_ez + co0);
+            }
+        }
+    }
+    const bool pre_add = staged_ && p.addend && !p.add_pre, pre_e3 = staged_ && p.psum != nullptr && p.emode == 3;
+    bf16x8 padd[PRE ? PRE : 1], pey[PRE ? PRE : 1], pzz[PRE ? PRE : 1];
+    bool phas[PRE ? PRE : 1];
+#pragma unroll
+    for (int u = 0; u < PRE; ++u) {
+        const int idx = tid + 256 * u, row = idx / NPC_, pc = idx % NPC_;
+        const long pix = p_blk + row;
+        const int co = c_blk + pc * 8;
+        const bool ok = kg == 0 && idx < BP * NPC_ && pix < p.x.M && co < p.Nout;
+        padd[u] = pey[u] = pzz[u] = zero8();
+        phas[u] = false;
+        if (ok && pre_add) {
+            long arow = pix;
+            bool has = true;
+            if (p.add_s2) {
+                const unsigned W = (unsigned)p.x.W, H = (unsigned)p.x.H;
+                const unsigned x = (unsigned)pix % W, t = (unsigned)pix / W;
+                const unsigned y = t % H, n = t / H;
+                has = !((x | y) & 1u);
+                arow = ((long)n * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1);
+            }
+            phas[u] = has;
+            if (has) padd[u] = ld8(p.addend + arow * p.ld_add + co);
+        }
+        if (ok && pre_e3) { pey[u] = ld8(p.ey + pix * p.ld_ey + co); pzz[u] = ld8(p.ez + pix * p.ld_ez + co); }
     }
 
     f32x4 acc[TC][TP];
@@ -586,7 +637,10 @@ __global__ __launch_bounds__(256 * KG) void gemm_nt_kernel(const GemmNT p) {
                     q[r] = OUT_F32 ? vv[(i * TP + j) * 4 + r] : bfround(vv[(i * TP + j) * 4 + r]);
                     q[r] = pv ? q[r] : 0.f;
                 }
-                if (ev && pv) {
+                if constexpr (EPRE) {                                 // (requested before the K loop)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) z[r] = bf2f(pez[i][j][r]);
+                } else if (ev && pv) {
                     const bf16x4 zv = *reinterpret_cast<const bf16x4*>(p.ez + pix * p.ld_ez + co0);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) z[r] = bf2f(zv[r]);
@@ -683,8 +737,10 @@ __global__ __launch_bounds__(256 * KG) void gemm_nt_kernel(const GemmNT p) {
                 for (int k = 0; k < 8; ++k) { emu[k] = p.ecoef[2 * p.Nout + co + k]; ers[k] = p.ecoef[3 * p.Nout + co + k]; }
             }
         }
-#pragma unroll 2
-        for (int idx = tid; idx < BP * NPC; idx += 256) {
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int idx = tid + 256 * u;
+            if (idx >= BP * NPC) break;
             const int row = idx / NPC, pc = idx % NPC;
             const long pix = p_blk + row;
             const int co = c_blk + pc * 8;
@@ -696,23 +752,30 @@ __global__ __launch_bounds__(256 * KG) void gemm_nt_kernel(const GemmNT p) {
                     orow = (long)im * p.img_stride + (long)((unsigned)pix - im * (unsigned)p.rpi) * p.ldc;
                 }
                 if (p.addend && !p.add_pre) {
-                    long arow = pix;
                     bool has = true;
-                    if (p.add_s2) {
-                        const unsigned W = (unsigned)p.x.W, H = (unsigned)p.x.H;
-                        const unsigned x = (unsigned)pix % W, t = (unsigned)pix / W;
-                        const unsigned y = t % H, n = t / H;
-                        has = !((x | y) & 1u);
-                        arow = ((long)n * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1);
+                    bf16x8 a;
+                    if (PRE) {                                         // small tiles: requested before the K loop
+                        has = phas[u < PRE ? u : 0];
+                        a = padd[u < PRE ? u : 0];
+                    } else {
+                        long arow = pix;
+                        if (p.add_s2) {
+                            const unsigned W = (unsigned)p.x.W, H = (unsigned)p.x.H;
+                            const unsigned x = (unsigned)pix % W, t = (unsigned)pix / W;
+                            const unsigned y = t % H, n = t / H;
+                            has = !((x | y) & 1u);
+                            arow = ((long)n * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1);
+                        }
+                        a = has ? ld8(p.addend + arow * p.ld_add + co) : zero8();
                     }
                     if (has) {
-                        const bf16x8 a = ld8(p.addend + arow * p.ld_add + co);
 #pragma unroll
                         for (int k = 0; k < 8; ++k) v[k] = f2bf(bf2f(v[k]) + bf2f(a[k]));
                     }
                 }
                 if (e3) {
-                    const bf16x8 yv = ld8(p.ey + pix * p.ld_ey + co), zv = ld8(p.ez + pix * p.ld_ez + co);
+                    const bf16x8 yv = PRE ? pey[u < PRE ? u : 0] : ld8(p.ey + pix * p.ld_ey + co);
+                    const bf16x8 zv = PRE ? pzz[u < PRE ? u : 0] : ld8(p.ez + pix * p.ld_ez + co);
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
                         const float g = bf2f(yv[k]) > 0.f ? bf2f(v[k]) : 0.f;
@@ -2766,14 +2829,23 @@ static int launch_nt_r(const GemmNT& p, int out_f32, hipStream_t st) {
         if (!lds_optin(optin, {(const void*)gemm_nt_kernel<BC, BP, WGC, WGP, true, R, false, KG>,
                                (const void*)gemm_nt_kernel<BC, BP, WGC, WGP, false, R, false, KG>,
                                (const void*)gemm_nt_kernel<BC, BP, WGC, WGP, true, R, false, KG, (R == 2)>,
-                               (const void*)gemm_nt_kernel<BC, BP, WGC, WGP, false, R, false, KG, (R == 2)>}))
+                               (const void*)gemm_nt_kernel<BC, BP, WGC, WGP, false, R, false, KG, (R == 2)>,
+                               (const void*)gemm_nt_kernel<BC, BP, WGC, WGP, false, R, false, KG, (R == 2), (R == 2 && BC * BP <= 4096)>}))
             return HN_ERR_LAUNCH;
     }
 #ifndef HN_NO_PLAIN
     if constexpr (R == 2) {                                           // plain pixel rows, one tap: the lean instantiation
         if (p.x.mode == 0 && p.taps == 1 && p.x.C1 == 0) {
             if (out_f32) hipLaunchKernelGGL((gemm_nt_kernel<BC, BP, WGC, WGP, true, R, false, KG, true>), grid, dim3(256 * KG), lds, st, p);
-            else hipLaunchKernelGGL((gemm_nt_kernel<BC, BP, WGC, WGP, false, R, false, KG, true>), grid, dim3(256 * KG), lds, st, p);
+            else {
+                if constexpr (BC * BP <= 4096) {                      // small tile with late epilogue operands: the prefetching instance
+                    if ((p.psum && p.emode >= 1) || (p.addend && !p.add_pre)) {
+                        hipLaunchKernelGGL((gemm_nt_kernel<BC, BP, WGC, WGP, false, R, false, KG, true, true>), grid, dim3(256 * KG), lds, st, p);
+                        HN_LAUNCH_CHECK();
+                    }
+                }
+                hipLaunchKernelGGL((gemm_nt_kernel<BC, BP, WGC, WGP, false, R, false, KG, true>), grid, dim3(256 * KG), lds, st, p);
+            }
             HN_LAUNCH_CHECK();
         }
     }
