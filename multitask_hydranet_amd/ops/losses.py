@@ -137,22 +137,28 @@ class DetLoss(torch.autograd.Function):
         out = torch.empty((2,), device=dev, dtype=F32)
         lib().call("hn_det_loss_fwd", ptr(cls), ptr(reg), ptr(anc), ptr(ann), n, a, k, mx, ptr(assign), ptr(part), ptr(npos), ptr(out))
         ctx.save_for_backward(cls, reg, anc, ann, assign, npos)
-        return out
+        # the two losses leave as two outputs (slicing a 2-vector OUTSIDE the node cost two SliceBackward nodes -- fill + copy each -- and
+        # an add per step: seven 5 us launches)
+        return out[0:1], out[1:2]
 
     @staticmethod
-    def backward(ctx, gout):
+    def backward(ctx, gcls, greg):
         cls, reg, anc, ann, assign, npos = ctx.saved_tensors
         n, a, k = cls.shape
         dcls, dreg = torch.empty_like(cls), torch.empty_like(reg)
-        g = gout.contiguous().to(F32)
+        if (gcls is not None and greg is not None and gcls.dtype == F32 and greg.dtype == F32
+                and greg.data_ptr() == gcls.data_ptr() + 4):       # neighbours in WeightedLossSum.backward's gradient vector: used in place
+            g = gcls
+        else:
+            z = zeros((1,), cls.device)
+            g = torch.cat([(gcls if gcls is not None else z).reshape(1).to(F32), (greg if greg is not None else z).reshape(1).to(F32)])
         lib().call("hn_det_loss_bwd", ptr(cls), ptr(reg), ptr(anc), ptr(ann), n, a, k, ann.shape[1], ptr(assign), ptr(npos), ptr(g), ptr(dcls),
                    ptr(dreg))
         return dcls, dreg, None, None
 
 
 def det_loss_hip(classification, regression, anchors, annotations):
-    out = DetLoss.apply(classification, regression, anchors, annotations)
-    return out[0:1], out[1:2]
+    return DetLoss.apply(classification, regression, anchors, annotations)
 
 
 
@@ -176,6 +182,7 @@ class LaneClsLoss(torch.autograd.Function):
         ctx.alpha, ctx.shape = float(alpha), cls_preds.shape
         ctx.save_for_backward(lsm, pmask, aux)
         ctx.mark_non_differentiable(pmask, aux)
+        ctx.set_materialize_grads(False)        # (no zero-filled "gradients" of the byte mask and the aux vector: two fill launches per step)
         return out[0], out[1], pmask, aux
 
     @staticmethod
