@@ -335,6 +335,15 @@ __global__ __launch_bounds__(256 * KG) void gemm_nt_kernel(const GemmNT p) {
         wo[i] = (r0 + 32 * i < BC && co < p.Nout) ? (long)co * Ktot + sub : -1;
     }
 
+    // the tile's bias values are requested here and arrive under the K loop (behind it they were a dependent trip in front of every
+    // epilogue: all GEMMs of the folded inference path and the heads' biased convs)
+    float pbias[TC][4];
+#pragma unroll
+    for (int i = 0; i < TC; ++i) {
+        const int co0 = c_blk + wc * WC + i * 16 + (lane >> 4) * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pbias[i][r] = (p.bias && co0 + r < p.Nout) ? p.bias[co0 + r] : 0.f;
+    }
     // EPRE (the instance the small-tile launches with a statistics operand or an addend take): epilogue operands whose addresses do not
     // depend on the product are requested HERE and arrive under the K loop (older than every stage load, so the loop's counted vmcnt
     // waits still hold): the forward tensor of the statistics epilogue (emode 1 / 2), the addend and the emode-3 operands of the write-out
@@ -559,13 +568,10 @@ __global__ __launch_bounds__(256 * KG) void gemm_nt_kernel(const GemmNT p) {
 #pragma unroll
     for (int i = 0; i < TC; ++i) {
         const int co0 = c_blk + wc * WC + i * 16 + (lane >> 4) * 4;
-        float bsv[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bsv[r] = (p.bias && co0 + r < p.Nout) ? p.bias[co0 + r] : 0.f;
 #pragma unroll
         for (int j = 0; j < TP; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) vv[(i * TP + j) * 4 + r] = acc[i][j][r] + bsv[r];
+            for (int r = 0; r < 4; ++r) vv[(i * TP + j) * 4 + r] = acc[i][j][r] + pbias[i][r];
     }
     if (p.lcoef) {                                                    // per-level BatchNorm (running statistics) of the tile's level
         int lv = 0;
