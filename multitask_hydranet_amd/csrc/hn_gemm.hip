@@ -566,13 +566,11 @@ __global__ __launch_bounds__(256 * KG) void gemm_nt_kernel(const GemmNT p) {
     if (staged) __syncthreads();                                      // every wave is done reading the last K stage
     float vv[TC * TP * 4];                                            // the wave tile, flat: one uniform activation branch for all of it
 #pragma unroll
-    for (int i = 0; i < TC; ++i) {
-        const int co0 = c_blk + wc * WC + i * 16 + (lane >> 4) * 4;
+    for (int i = 0; i < TC; ++i)
 #pragma unroll
         for (int j = 0; j < TP; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) vv[(i * TP + j) * 4 + r] = acc[i][j][r] + pbias[i][r];
-    }
     if (p.lcoef) {                                                    // per-level BatchNorm (running statistics) of the tile's level
         int lv = 0;
         while (lv + 1 < p.ln && p_blk >= p.lrow[lv + 1]) ++lv;
