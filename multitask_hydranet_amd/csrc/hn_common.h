@@ -39,7 +39,7 @@ __device__ __forceinline__ bf16x8 zero8() {
 // 6 = 1: no two-K-group GEMM variant (> 1: its K threshold, default 512), 7 depthwise-backward block target, 8 = 0: fused passes without the
 // XCD row-order placement, 9 grouped-TN debug bits (skip stores / MFMAs / loads), 10 grouped-TN tile variant, 11 = 1: direct 3x3 kernel walks
 // the patches of one cout tile first (measured: no gain), 12 / 13 workgroup targets of the 3x3 patch weight-gradient / grouped-conv group plans,
-// 16 / 17 channels and rows per workgroup of hn_se_gate_apply (0 = the heuristic)
+// 16 / 17 channels and rows per workgroup of hn_se_gate_apply (0 = the heuristic), 18 = 1: no narrow-K form of the direct 3x3 kernel
 #ifdef HN_TUNING
 extern long g_hn_knob[20];
 #else

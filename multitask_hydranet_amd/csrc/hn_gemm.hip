@@ -823,18 +823,20 @@ __global__ __launch_bounds__(256 * KG) void gemm_nt_kernel(const GemmNT p) {
 // PIPE = true: ONE workgroup per CU with a software pipeline inside it: two patch buffers (the next chunk's patch lands during the
 //   current chunk's taps) and a ring of three weight tiles with counted s_waitcnt vmcnt (the tile of tap step i+2 is issued before the
 //   MFMAs of step i, so two tile loads are always in flight); up to 256 VGPRs (no scratch spills).
-template <int BC, bool OUT_F32, bool PIPE>
+template <int BC, bool OUT_F32, bool PIPE, int XB = (PIPE ? 2 : 1)>   // XB: patch buffers (PIPE with a single K chunk needs one)
 __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) {
     constexpr int KC = PIPE ? 32 : 64;                                // channels per K chunk
     constexpr int NPP = KC / 8, PB = KC * 2;                          // 16-byte pieces / bytes per pixel (or weight) row of a chunk in LDS
-    constexpr int XBUFS = PIPE ? 2 : 1, WBUFS = PIPE ? 4 : 2;
+    constexpr int XBUFS = XB, WBUFS = PIPE ? 4 : 2;
     constexpr int WCO = BC >= 64 ? 64 : BC;                           // couts per wave
     constexpr int WGC = BC / WCO, WGP = 8 / WGC, ROWS = 16 / WGP;     // rows of the patch per wave
     constexpr int TC = WCO / 16, TP = ROWS;
     // X buffer padded to whole 1 KiB DMA runs (PIPE: X and W buffers padded to whole 512-thread rounds, so that every wave issues the
     // same number of loads and the counted waits hold for all of them)
     constexpr int PPIX = 18 * 18, XL = (PPIX * NPP + 511) / 512, WL = (BC * NPP + 511) / 512;
-    constexpr int XBYTES = PIPE ? XL * 512 * 16 : (PPIX * 128 + 1023) / 1024 * 1024, WBYTES = PIPE ? WL * 512 * 16 : BC * 128;
+    // (PRE32: the 32-channel-chunk layout with ONE patch buffer and ALL tap tiles of its single chunk preloaded, unpadded: 24 + 36 KB)
+    constexpr bool PRE32 = PIPE && XB == 1;
+    constexpr int XBYTES = PIPE ? XL * 512 * 16 : (PPIX * 128 + 1023) / 1024 * 1024, WBYTES = PRE32 ? BC * PB : (PIPE ? WL * 512 * 16 : BC * 128);
     extern __shared__ __attribute__((aligned(16))) char smem[];       // X patch x2 | W tile x2
     char* sXb = smem;
     char* sWb = smem + XBUFS * XBYTES;
@@ -892,7 +894,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
     auto tap_at = [&](const Cur& c) { return p.phase_mode ? ((c.ph >> 1) + (c.ti >> 1)) * 3 + (c.ph & 1) + (c.ti & 1) : c.ti; };
     const int xc0 = xs.diag ? c_blk : 0;                              // first input channel of chunk 0
     // the tile's bias values wait in LDS behind the operand buffers (the epilogue's per-sub-tile global loads were a dependent round trip each)
-    float* sbias = reinterpret_cast<float*>(smem + XBUFS * XBYTES + (!PIPE && p.wpre ? S : WBUFS) * WBYTES);
+    float* sbias = reinterpret_cast<float*>(smem + XBUFS * XBYTES + ((!PIPE || PRE32) && p.wpre ? S : WBUFS) * WBYTES);
     if (tid < BC) sbias[tid] = (p.bias && c_blk + tid < p.Nout) ? p.bias[c_blk + tid] : 0.f;
 
     // patch pieces owned by this thread: e = tid + 512 i -> patch pixel e>>3, PHYSICAL piece e&7 (logical = physical ^ (patch column & 7)).
@@ -1014,7 +1016,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
         char* sW = sWb + slot * WBYTES;
 #pragma unroll
         for (int i = 0; i < WL; ++i) {
-            if (PIPE || wave * 8 + 64 * i < BC) {                      // wave-uniform (PIPE: every wave issues every round, padded tile)
+            if ((PIPE && !PRE32) || wave * (64 / NPP) + (512 / NPP) * i < BC) {   // wave-uniform (PIPE ring: every wave issues every round, padded tile)
                 const bf16* src = (wrow[i] >= 0 && k0 + wsub < p.KP) ? p.w + wrow[i] + koff : g_zero_piece;
                 glds16(src, sW + (512 * i + 64 * wave) * 16);
             }
@@ -1065,7 +1067,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
     };
     bool add_issued = false;
     stamp();
-    if (!PIPE && p.wpre) {
+    if ((!PIPE || PRE32) && p.wpre) {
         // Single 64-channel chunk and few tap steps (the phase-form output convs: 4 steps): the patch and ALL weight tiles are requested
         // together and the tap loop runs without barriers or DMA waits -- such a workgroup lived for ~14 us of which the four
         // barrier-separated weight-tile round trips were a third.
@@ -3199,12 +3201,19 @@ static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img
         p.wpre = (!p.x.diag && KP <= 64 && (size_t)nsteps * bc * 128 <= 32768 && g_hn_knob[11] != 2) ? 1 : 0;
         // software-pipelined variant (32-channel chunks, two patch buffers + ring of four weight tiles, counted waits; still two workgroups
         // per CU): the multi-chunk bf16 launches with >= 64 couts per tile
+        // (the multi-chunk form measured slower on every seg-decoder shape: tools/bench_seg.py; tuning builds can force it)
+        // K <= 32 channels per tap in ONE chunk (the output layer's data gradient: 24 real channels of a 64-channel chunk): 32-channel
+        // chunks halve the MFMAs, LDS fragment reads and weight DMA of a tap step, and with a single patch buffer (24 KB) + the ring of
+        // four weight tiles (32 KB) two workgroups share a CU
+        const bool narrow = bc == 64 && !out_f32 && !p.x.diag && !p.wpre && KP <= 32 && nsteps == 9 && g_hn_knob[18] == 0;
+        if (narrow) p.wpre = 1;                                     // all nine 4 KB tap tiles next to the patch: no barrier in the tap loop
 #ifdef HN_TUNING
-        const bool pipe = g_direct_pipe && bc >= 64 && !out_f32 && !p.x.diag && !p.wpre && KP > 64;
+        const bool pipe = narrow || (g_direct_pipe && bc >= 64 && !out_f32 && !p.x.diag && !p.wpre && KP > 64);
 #else
-        constexpr bool pipe = false;                                // (measured slower on every seg-decoder shape: tools/bench_seg.py)
+        const bool pipe = narrow;
 #endif
-        const size_t lds = pipe ? (size_t)2 * (((18 * 18 * 4 + 511) / 512) * 512 * 16) + 4 * (size_t)(512 * 16)
+        const size_t lds = narrow ? (size_t)(((18 * 18 * 4 + 511) / 512) * 512 * 16) + 9 * (size_t)(64 * 64)
+                         : pipe ? (size_t)2 * (((18 * 18 * 4 + 511) / 512) * 512 * 16) + 4 * (size_t)(512 * 16)
                                 : (size_t)((18 * 18 * 128 + 1023) / 1024 * 1024) + (p.wpre ? nsteps : 2) * (size_t)bc * 128;
         const size_t lds_bias = (size_t)bc * 4 + 36 * 4;            // the tile's bias values + the patch source table behind the operand buffers
         // > 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel (done on the first, un-captured call)
@@ -3214,6 +3223,10 @@ static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img
                                (const void*)conv3x3_direct_kernel<64, true, false>, (const void*)conv3x3_direct_kernel<64, false, false>,
                                (const void*)conv3x3_direct_kernel<128, true, false>, (const void*)conv3x3_direct_kernel<128, false, false>}))
             return HN_ERR_LAUNCH;
+        if (narrow) {
+            hipLaunchKernelGGL((conv3x3_direct_kernel<64, false, true, 1>), grid, dim3(512), lds + lds_bias, st, p);
+            HN_LAUNCH_CHECK();
+        }
 #ifdef HN_TUNING
         static std::atomic<unsigned long long> optin_pipe{0};
         if (pipe) {
