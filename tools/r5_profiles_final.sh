@@ -8,4 +8,4 @@ bash tools/run_profiles.sh > gpurun_out/r5_profiles.log 2>&1
 bash tools/pmc_stall.sh > gpurun_out/r5_pmc_stall.log 2>&1
 bash tools/run_stats.sh --res 640x640 > gpurun_out/r5_stats640.log 2>&1; cp gpurun_out/stats/kernel_stats.csv gpurun_out/prof/kernel_stats_640.csv
 bash tools/run_stats.sh --infer --batch 32 --res 1152x1920 > gpurun_out/r5_stats_infer.log 2>&1; cp gpurun_out/stats/kernel_stats.csv gpurun_out/prof/kernel_stats_infer.csv
-tail -3 gpurun_out/prof/bench_n1.json | cut -c1-600; tail -5 gpurun_out/r5_pmc_stall.log; tail -2 gpurun_out/r5_stats640.log gpurun_out/r5_stats_infer.log
+tail -3 gpurun_out/prof/bench_n1.json | cut -c1-600; tail -5 gpurun_out/r5_pmc_stall.log; tail -n 2 gpurun_out/r5_stats640.log; tail -n 2 gpurun_out/r5_stats_infer.log
