@@ -1324,6 +1324,36 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
             }
         }
         stamp();
+    } else if (OUT_F32 && stage_f32) {
+        // Compact form of the staged fp32 depth-to-space epilogue (the seg output conv: logits or their arg-max).  The generic loop below
+        // decides the store form per value, divides by d2s per value and loads the bias from global memory: the stamps showed 10 800 of a
+        // workgroup's 32 500 cycles in it (tools/stamp_seg.py LAYER=out).  Here: bias from LDS, ONE division per cout sub-tile (the
+        // lane's four couts advance through (phase, channel) by increment), scalar LDS stores into the 32 x 32-pixel x d2s tile.
+        const int d2s = p.d2s, rowf = 32 * d2s;
+        float* stf = reinterpret_cast<float*>(stage);
+#pragma unroll
+        for (int i = 0; i < (rows_live ? TC : 0); ++i) {
+            const int cl = wc * WCO + i * 16 + (lane >> 4) * 4, co0 = c_blk + cl;
+            const f32x4 bs = *reinterpret_cast<const f32x4*>(sbias + cl);
+            int ph = co0 / d2s, oc = co0 - ph * d2s;
+            int off[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                off[r] = co0 + r < p.Nout ? (ph >> 1) * rowf + (ph & 1) * d2s + oc : -1;
+                if (++oc == d2s) { oc = 0; ++ph; }
+            }
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                const int base = 2 * (wp * ROWS + j) * rowf + 2 * (lane & 15) * d2s;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bs[r];
+                act_fwd_n(v, p.act);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (off[r] >= 0) stf[base + off[r]] = v[r];
+            }
+        }
     } else
 #pragma unroll
     for (int i = 0; i < TC; ++i) {

@@ -28,6 +28,14 @@ if os.environ.get("LAYER") in ("g3", "g4"):       # grouped 3x3 conv (group widt
     wg = torch.randn(c, 8, 3, 3, device=dev) * 0.1
     wk2, wd2 = K.pack_gconv_diag(wg)
     run = lambda: K.k_gemm_nt(xa, None, 5, (N, hh, ww), wk2, c, 64, 9, stats=True)
+if os.environ.get("LAYER") == "out":            # seg output conv (phase form, fp32 logits): 64 -> 4 x 5 on the 256 x 512 low-res grid
+    from multitask_hydranet_amd.ops import seg as S
+    xo = torch.randn(N, 256, 512, 64, device=dev).to(torch.bfloat16)
+    wo = torch.randn(5, 64, 3, 3, device=dev) * 0.05
+    bo = torch.zeros(5, device=dev)
+    wpo, wto, beo = S.pack_phase_weight(wo, 64, bo)
+    oo = torch.empty((N, 512, 1024, 5), device=dev, dtype=torch.float32)
+    run = lambda: K.k_gemm_nt(xo, None, 4, (N, 256, 512), wpo, 20, K.kp32(64), 9, bias=beo, out=oo, out_f32=True, ldc=20, img_stride=-5)
 buf = torch.zeros(256 * 128, device=dev, dtype=torch.int64)
 for pipe in (0,):
     lib().query("hn_debug_direct_pipe", pipe)
