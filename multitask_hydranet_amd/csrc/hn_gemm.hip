@@ -1078,7 +1078,12 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
         __syncthreads();
         stamp();
         Cur cc = cur0();
-        for (int st = 0; st < S; ++st) { compute(cc, st); adv(cc); }
+        if (S == 9 && p.phase_mode == 0) {                            // nine plain taps: unrolled, so that a tap's fragment reads can be
+#pragma unroll                                                        // scheduled under the previous tap's MFMAs
+            for (int st = 0; st < 9; ++st) { compute(cc, st); adv(cc); }
+        } else {
+            for (int st = 0; st < S; ++st) { compute(cc, st); adv(cc); }
+        }
     } else if (BC == 64 && !PIPE && xs.diag) {
         // Grouped conv (group width 8) as block-diagonal 64 x 64 tiles: of the 8 KB weight tile of a tap only the eight 8 x 8 diagonal
         // blocks (1 KB) are non-zero.  All nine taps' blocks (9 KB: [tap][cout 64][8 ci]) are fetched ONCE next to the patch, and the A

@@ -36,6 +36,13 @@ if os.environ.get("LAYER") == "out":            # seg output conv (phase form, f
     wpo, wto, beo = S.pack_phase_weight(wo, 64, bo)
     oo = torch.empty((N, 512, 1024, 5), device=dev, dtype=torch.float32)
     run = lambda: K.k_gemm_nt(xo, None, 4, (N, 256, 512), wpo, 20, K.kp32(64), 9, bias=beo, out=oo, out_f32=True, ldc=20, img_stride=-5)
+if os.environ.get("LAYER") == "outdgrad":       # data gradient of the seg output conv: 4 x 5 (padded to 24) -> 64 on the 256 x 512 low-res grid, folding epilogue
+    from multitask_hydranet_amd.ops import seg as S
+    wo = torch.randn(5, 64, 3, 3, device=dev) * 0.05
+    wpo, wto, beo = S.pack_phase_weight(wo, 64, torch.zeros(5, device=dev))
+    dzo = torch.randn(N, 256, 512, 24, device=dev).to(torch.bfloat16)
+    ypo = torch.randn(N, 256, 512, 64, device=dev).to(torch.bfloat16)
+    run = lambda: S.k_dgrad_fold(dzo, wto, N, 256, 512, 64, K.kp32(20), 0, 1, ypo)
 buf = torch.zeros(256 * 128, device=dev, dtype=torch.int64)
 for pipe in (0,):
     lib().query("hn_debug_direct_pipe", pipe)
