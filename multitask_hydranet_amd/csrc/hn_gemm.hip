@@ -947,6 +947,36 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
                                   : ((gy << 16) | (sub << 13) | gx);
         }
     }
+    auto issue_x = [&](int chunk) {
+        if ((HN_DBG(p) & 4) && chunk >= XBUFS) return;
+        const int k0 = chunk * KC;
+        char* sX = sXb + (XBUFS == 2 ? (chunk & 1) : 0) * XBYTES;
+#pragma unroll
+        for (int i = 0; i < XL; ++i) {
+            if (PIPE || 512 * i + 64 * wave < PPIX * 8) {              // PIPE: every wave issues all XL rounds (padded buffer)
+                const bf16* src = g_zero_piece;
+                int pk = spack[i];
+                asm volatile("" : "+v"(pk));                          // keep the 64-bit row pointers out of loop-invariant registers
+                if (single) {
+                    const int c = xc0 + k0 + ((pk & 7) << 3);
+                    if (c < Ctot && pk >= 0) src = xs.x0 + c + (long)(pk >> 3) * xs.ld0;
+                } else {
+                    const int c = xc0 + k0 + (((pk >> 13) & 7) << 3);
+                    if (c < Ctot && pk >= 0) {
+                        const int gy = pk >> 16, gx = pk & 0x1fff;
+                        if (c < xs.C0) src = xs.x0 + c + (long)((n * (xs.Hi >> xs.up) + (gy >> xs.up)) * (xs.Wi >> xs.up) + (gx >> xs.up)) * xs.ld0;
+                        else src = xs.x1 + (c - xs.C0) + (long)((n * xs.Hi + gy) * xs.Wi + gx) * xs.ld1;
+                    }
+                }
+                glds16(src, sX + (512 * i + 64 * wave) * 16);
+            }
+        }
+    };
+    // The barrier-free forms (all tap tiles preloaded / grouped conv) start with the patch of chunk 0: requested HERE, as soon as its source
+    // table exists -- the weight-row offsets, accumulators and fragment offsets below are computed under the DMA instead of in front of it
+    // (stamps of the stage-4 grouped conv: 4 400 cycles of prologue, then 7 700 of waiting for the patch, of a 19 800-cycle workgroup)
+    const bool early_x = ((!PIPE || PRE32) && p.wpre) || (BC == 64 && !PIPE && xs.diag);
+    if (early_x) issue_x(0);
     // weight pieces: row = (tid>>3) + 64 i, physical piece tid&7 (32-channel chunks: row = (tid>>2) + 128 i, physical piece tid&3; the
     // swizzle of 64-byte rows is pswz32 below)
     const int wsub = PIPE ? (((tid & 3) ^ pswz32(tid >> 2)) << 3) : (((tid & 7) ^ ((tid >> 3) & 7)) << 3);
@@ -1022,31 +1052,6 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
             }
         }
     };
-    auto issue_x = [&](int chunk) {
-        if ((HN_DBG(p) & 4) && chunk >= XBUFS) return;
-        const int k0 = chunk * KC;
-        char* sX = sXb + (XBUFS == 2 ? (chunk & 1) : 0) * XBYTES;
-#pragma unroll
-        for (int i = 0; i < XL; ++i) {
-            if (PIPE || 512 * i + 64 * wave < PPIX * 8) {              // PIPE: every wave issues all XL rounds (padded buffer)
-                const bf16* src = g_zero_piece;
-                int pk = spack[i];
-                asm volatile("" : "+v"(pk));                          // keep the 64-bit row pointers out of loop-invariant registers
-                if (single) {
-                    const int c = xc0 + k0 + ((pk & 7) << 3);
-                    if (c < Ctot && pk >= 0) src = xs.x0 + c + (long)(pk >> 3) * xs.ld0;
-                } else {
-                    const int c = xc0 + k0 + (((pk >> 13) & 7) << 3);
-                    if (c < Ctot && pk >= 0) {
-                        const int gy = pk >> 16, gx = pk & 0x1fff;
-                        if (c < xs.C0) src = xs.x0 + c + (long)((n * (xs.Hi >> xs.up) + (gy >> xs.up)) * (xs.Wi >> xs.up) + (gx >> xs.up)) * xs.ld0;
-                        else src = xs.x1 + (c - xs.C0) + (long)((n * xs.Hi + gy) * xs.Wi + gx) * xs.ld1;
-                    }
-                }
-                glds16(src, sX + (512 * i + 64 * wave) * 16);
-            }
-        }
-    };
     // phase form with a pre-activation addend (the skip operand's partial result): all TC x TP loads of a lane are requested up front.
     // Issued one by one inside the loop below each was a dependent round trip: the stamps show 26 000 cycles for this epilogue, a
     // quarter of the workgroup's lifetime, against 16 x 3 400 cycles for all of its tap steps (tools/stamp_seg.py).
@@ -1071,16 +1076,19 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
         // Single 64-channel chunk and few tap steps (the phase-form output convs: 4 steps): the patch and ALL weight tiles are requested
         // together and the tap loop runs without barriers or DMA waits -- such a workgroup lived for ~14 us of which the four
         // barrier-separated weight-tile round trips were a third.
-        issue_x(0);
-        Cur ci = cur0();
+        Cur ci = cur0();                                                // (the patch was requested in the prologue)
         for (int st = 0; st < S; ++st) { issue_w(ci, st, 0); adv(ci); }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         stamp();
         Cur cc = cur0();
-        if (S == 9 && p.phase_mode == 0) {                            // nine plain taps: unrolled, so that a tap's fragment reads can be
-#pragma unroll                                                        // scheduled under the previous tap's MFMAs
-            for (int st = 0; st < 9; ++st) { compute(cc, st); adv(cc); }
+        if constexpr (PRE32) {                                        // (this instance only: in the others the extra code costs registers --
+            if (S == 9 && p.phase_mode == 0) {                        // 22 spilled VGPRs in the 128-cout instance)
+#pragma unroll                                                        // nine plain taps, unrolled: a tap's fragment reads under the previous tap's MFMAs
+                for (int st = 0; st < 9; ++st) { compute(cc, st); adv(cc); }
+            } else {
+                for (int st = 0; st < S; ++st) { compute(cc, st); adv(cc); }
+            }
         } else {
             for (int st = 0; st < S; ++st) { compute(cc, st); adv(cc); }
         }
@@ -1089,7 +1097,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
         // blocks (1 KB) are non-zero.  All nine taps' blocks (9 KB: [tap][cout 64][8 ci]) are fetched ONCE next to the patch, and the A
         // fragments are built from them by a lane select -- the tap loop has no barrier and no DMA wait.  The tile-streaming loop below
         // exposed one weight-DMA round trip per tap: 9 x 2.2 us = 19.8 us per launch on the deep stages, for 1 us of MFMA work.
-        issue_x(0);                                                    // (the nine taps' diagonal blocks were requested at kernel start)
+        // (the nine taps' diagonal blocks were requested at kernel start, the patch in the prologue)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int kq = lane >> 4;

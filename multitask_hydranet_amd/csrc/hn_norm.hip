@@ -742,7 +742,6 @@ __global__ __launch_bounds__(16 * PARTS) void se_fc_cols_kernel(const float* W, 
     const float* inr = in + (long)n * (S > 0 ? S : 1) * I;
     const float* auxr = aux ? aux + (long)n * I : nullptr;
     const bool ov = o < O;
-    const float mask = (post && ov && part == 0) ? aux2[(long)n * O + o] : 1.f;      // (up front: behind the reduction it is a trip of its own)
     // the partition's elements (<= 16 per round): the weights, the gate values and up to four partial rows are issued together -- every
     // dependent round of loads of this fresh data is a trip to memory (~2 us; the form with one round per group of rows and the gate
     // loads behind them took three trips: 9.9 us per launch at stage 4).  PARTS == 16 (the second launch: one dense input row, no gate)
@@ -766,15 +765,16 @@ __global__ __launch_bounds__(16 * PARTS) void se_fc_cols_kernel(const float* W, 
         for (int jj = 0; jj < TR; ++jj)
 #pragma unroll
             for (int k = 0; k < 16; ++k) v[k] += t[jj][k];
-        for (int j0 = 1 + TR; j0 < S; j0 += 4) {                       // more rows: four per round
-            float u[4][16];
+        constexpr int UR = PARTS == 64 ? 2 : 4;                        // more rows: UR per round (1024-thread workgroups: 128 VGPRs, no spills)
+        for (int j0 = 1 + TR; j0 < S; j0 += UR) {
+            float u[UR][16];
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
+            for (int jj = 0; jj < UR; ++jj)
 #pragma unroll
                 for (int k = 0; k < 16; ++k)
                     u[jj][k] = (j0 + jj < S && ib + k < i1) ? inr[(long)(j0 + jj) * I + ib + k] : 0.f;
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
+            for (int jj = 0; jj < UR; ++jj)
 #pragma unroll
                 for (int k = 0; k < 16; ++k) v[k] += u[jj][k];
         }
@@ -796,6 +796,8 @@ __global__ __launch_bounds__(16 * PARTS) void se_fc_cols_kernel(const float* W, 
             s3 += wv[k + 3] * v[k + 3];
         }
     }
+    // (requested in front of the barrier, not behind the reduction where it was a trip of its own; not at the top: one register too many)
+    const float mask = (post && ov && part == 0) ? aux2[(long)n * O + o] : 1.f;
     red[part][ox] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (part == 0 && ov) {
