@@ -420,6 +420,26 @@ int hn_se_mlp_bwd(const float* dgate, const float* gate, const float* hid, const
                   float* dpre2, float* dpre1, float* dpool, float* dw1, float* db1, float* dw2, float* db2, int N, int C, int Cs,
                   hipStream_t stream);
 
+/* ---- persistent stage kernel (hn_xstage.hip) ----------------------------------------------------------------------------------- */
+
+/* The stride-1 identity XBlocks 1..d-1 of a backbone stage (net/anynet.py:65-76,84-86; training mode) as ONE launch: 256 workgroups of 512
+ * threads, workgroup = (image, channel slice), the workgroups of an image on one XCD (read from HW_REG_XCC_ID), in-image exchanges through
+ * that XCD's L2, BatchNorm statistics exchanged device-wide as tagged 8-byte granules.  Replaces nb x the 8 launches of ops/backbone.py
+ * XBlockFn.forward and leaves every tensor that node saves: z1 / a / z2 / bg / z3 / out [nb][N*H*W][C] bf16 (dense rows), coef [nb][3][4][C]
+ * (scale, shift, mean, rstd of BatchNorm 1 / 2 / 3), pooled / gate [nb][N][C], hid [nb][N][Cs]; running statistics updated in place.
+ * tab = HOST table nb x 19 int64: {w1 packed [C][KP], w2 block-diagonal pack (hn_gconv_pack_diag wk), w3 packed, se.1.weight [Cs][C],
+ * se.1.bias, se.3.weight [C][Cs], se.3.bias, then (gamma, beta, running_mean, running_var) of BatchNorm 1, 2, 3}.  x0 = input of the first
+ * block [N*H*W][C].  alpha = 1 / (H*W).  ws = hn_xstage_ws_bytes() bytes, ZEROED ONCE when allocated and then owned by these launches
+ * (counters / tags continue across launches; one workspace per device, launches on it serialised).  ws word 64 (uint32) is the status word:
+ * 0 = every launch so far completed; non-zero = a bounded wait expired (the launch could not become co-resident): outputs invalid.
+ * stamps (optional) = [nb][16] uint64 real-time-counter stamps of one workgroup.  mode 0: XCD-local counters; 1: agent-scope counters +
+ * release / acquire fences (placement independent).  hn_xstage_supported: 0 = shape not covered (caller keeps the launch chain). */
+long hn_xstage_ws_bytes(void);
+int hn_xstage_supported(int N, int H, int W, int C, int Cs);
+int hn_xstage_fwd(const long* tab, int nb, const void* x0, void* z1, void* a, void* z2, void* bg, void* z3, void* out, float* coef,
+                  float* pooled, float* hid, float* gate, int N, int H, int W, int C, int Cs, float eps, float momentum, float alpha,
+                  void* ws, long* stamps, int mode, hipStream_t stream);
+
 /* out += b0 [+ b1] [+ b2] (bf16 [M][C] tensors, fp32 sum, one rounding): the gradient sum of a multi-consumer map whose consumers return
  * separate gradients (ops.Share.backward; net/bifpn.py outputs feed three heads) in one launch instead of one per extra consumer */
 int hn_add_n(void* out, int ldo, const void* b0, int ld0, const void* b1, int ld1, const void* b2, int ld2, long M, int C, hipStream_t stream);

@@ -29,7 +29,7 @@ def policy(name: str, default: str) -> str:
     return os.environ.get(name, default) if AB else default
 
 SO_PATH = os.path.join(_PKG, "libhydranet_hip_tuning.so" if TUNING else "libhydranet_hip.so")
-SOURCES = ["hn_gemm.hip", "hn_norm.hip", "hn_fused.hip", "hn_stencil.hip", "hn_loss.hip", "hn_post.hip"]
+SOURCES = ["hn_gemm.hip", "hn_norm.hip", "hn_fused.hip", "hn_stencil.hip", "hn_loss.hip", "hn_post.hip", "hn_xstage.hip"]
 
 _ERR = {1: "bad argument", 2: "kernel launch failure", 3: "unsupported shape"}
 
@@ -59,7 +59,7 @@ def parse_header(path: str = HEADER) -> Dict[str, Tuple[object, List[object], bo
     out = {}
     for m in re.finditer(r"\b(int|long)\s+(hn_\w+)\s*\((.*?)\)\s*;", txt, flags=re.S):
         ret, name, params = m.group(1), m.group(2), m.group(3)
-        plist = [p for p in (q.strip() for q in params.replace("\n", " ").split(",")) if p]
+        plist = [p for p in (q.strip() for q in params.replace("\n", " ").split(",")) if p and p != "void"]
         args = [_ctype(p) for p in plist]
         out[name] = (ctypes.c_int if ret == "int" else ctypes.c_long, args, bool(plist) and "hipStream_t" in plist[-1])
     return out

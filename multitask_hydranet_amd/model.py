@@ -419,6 +419,23 @@ class HydraNet(nn.Module):
             s = x
         return self._cba(b, q + "conv_block_3.0", q + "conv_block_3.1", BN_STD, res=s, act=ACT_RELU)
 
+    def _xblock_params(self, q):
+        """the 19 parameter / buffer tensors of an identity XBlock in XBlockFn.forward's argument order (ops.xstage.PER_BLOCK)"""
+        P = self._idx
+        bn = [self._bn(q + f"conv_block_{i}.1")[:4] for i in (1, 2, 3)]
+        return [P[q + "conv_block_1.0.weight"], *bn[0], P[q + "conv_block_2.0.weight"], *bn[1], P[q + "se.1.weight"], P[q + "se.1.bias"],
+                P[q + "se.3.weight"], P[q + "se.3.bias"], P[q + "conv_block_3.0.weight"], *bn[2]]
+
+    def _xstage_run(self, q, x, group):
+        """the blocks from `q` to the end of the stage can run as one persistent launch: training-mode identity blocks with SE whose shape the
+        kernel covers (hn_xstage_supported), deferred weight gradients in place (the backward walks XBlockFn.backward)"""
+        P = self._idx
+        if not (self.training and torch.is_grad_enabled() and x.requires_grad and group is not None and (q + "se.1.weight") in P
+                and (q + "shortcut.0.weight") not in P):
+            return False
+        w1 = P[q + "conv_block_1.0.weight"]
+        return K.xblock_fusable(x, w1, 1, True, False) and K.xstage_ok(x, w1, P[q + "se.1.weight"].shape[0])
+
     def _backbone(self, x):
         """AnyNetX.forward, net/anynet.py:136-145: x NCHW fp32 -> list of NHWC bf16 stage outputs."""
         return [a[0] for a, _ in self._backbone_shared(x, (1,) * len(self.depths))]
@@ -444,8 +461,21 @@ class HydraNet(nn.Module):
                     all(P[nm].requires_grad for nm in names)):
                 group = K.WgradGroup()
                 t = K.DeferredGrads.apply(t, group, *[P[nm] for nm in names])
-            for i in range(d):
-                t = self._xblock(f"{p}stage_{k}.blocks.block_{i}.", t, self.backbone_stride if i == 0 else 1, group)
+            i = 0
+            while i < d:
+                q = f"{p}stage_{k}.blocks.block_{i}."
+                if i > 0 and i < d and self._xstage_run(q, t, group):
+                    # blocks i..d-1 are stride-1 identity blocks of one shape: ONE persistent launch for their forward (ops/xstage.py)
+                    while i < d:                                   # (a launch takes up to 16 blocks)
+                        j1 = min(d, i + 16)
+                        params = []
+                        for j in range(i, j1):
+                            params += self._xblock_params(f"{p}stage_{k}.blocks.block_{j}.")
+                        t = K.xstage_apply(t, group, BN_STD["eps"], BN_STD["momentum"], params)
+                        i = j1
+                    break
+                t = self._xblock(q, t, self.backbone_stride if i == 0 else 1, group)
+                i += 1
             last = k == len(self.depths) - 1
             if last and tail is not None and K.DEFER_WGRAD and self.training and torch.is_grad_enabled() and t.requires_grad and t.is_cuda:
                 # the neck's and the det / lane heads' deferred parameter gradients (ops.GradQueue) are flushed by this node: created after

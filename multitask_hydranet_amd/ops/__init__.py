@@ -11,15 +11,16 @@ from __future__ import annotations
 import sys
 import types
 
-from . import core, backbone, neck, seg, heads, losses      # noqa: F401
+from . import core, backbone, neck, seg, heads, losses, xstage      # noqa: F401
 from .core import *          # noqa: F401,F403
 from .backbone import *      # noqa: F401,F403
 from .neck import *          # noqa: F401,F403
 from .seg import *           # noqa: F401,F403
 from .heads import *         # noqa: F401,F403
 from .losses import *        # noqa: F401,F403
+from .xstage import *        # noqa: F401,F403
 
-_SUBMODULES = (core, backbone, neck, seg, heads, losses)
+_SUBMODULES = (core, backbone, neck, seg, heads, losses, xstage)
 
 
 class _OpsPackage(types.ModuleType):

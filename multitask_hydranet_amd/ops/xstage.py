@@ -1,0 +1,145 @@
+"""ops.xstage -- the stride-1 identity XBlocks of a backbone stage as ONE persistent launch (csrc/hn_xstage.hip; reference:
+net/anynet.py:65-76,84-86).  Forward: `hn_xstage_fwd` writes every tensor XBlockFn.forward saves, for all blocks of the run; backward walks
+the blocks in reverse through XBlockFn.backward (the 21-launch chain) on those tensors."""
+from __future__ import annotations
+
+import ctypes
+from types import SimpleNamespace
+
+import torch
+
+from .._lib import lib, policy
+from .core import *        # noqa: F401,F403
+from . import backbone as _bb
+
+XSTAGE = policy("HN_XSTAGE", "1") != "0"          # persistent stage kernel for the identity blocks (0: the launch chain)
+XSTAGE_MODE = int(policy("HN_XSTAGE_MODE", "0"))  # 0: XCD-local counters, 1: agent-scope counters + fences (hydranet_hip.h)
+PER_BLOCK = 19                                    # parameter tensors of one block, in XBlockFn.forward's argument order (after x)
+
+_WS = {}          # device index -> (workspace uint8 tensor, status view)
+_CHECKED = {}     # (device, shape signature) -> number of eager launches whose status word was read back
+_DISABLED = [False]
+
+
+def xstage_ws(dev):
+    """the launches' sync workspace: one per device, zeroed once (hydranet_hip.h: counters and tags continue across launches)"""
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    w = _WS.get(key)
+    if w is None:
+        nbytes = lib().query("hn_xstage_ws_bytes")
+        buf = torch.zeros((nbytes,), device=dev, dtype=torch.uint8)
+        w = _WS[key] = (buf, buf[256:260].view(torch.int32))
+    return w
+
+
+def xstage_status(dev) -> int:
+    """status word of the device's workspace (synchronises)"""
+    return int(xstage_ws(dev)[1].item())
+
+
+def xstage_ok(x, w1, cs) -> bool:
+    """the persistent kernel covers this run of identity blocks (shape, batch, dense rows); else the caller keeps the launch chain"""
+    if not (XSTAGE and not _DISABLED[0] and x.is_cuda and x.dim() == 4 and x.dtype == BF16 and x.is_contiguous()):
+        return False
+    n, h, w, c = x.shape
+    return w1.shape[0] == c and w1.shape[1] == c and lib().query("hn_xstage_supported", n, h, w, c, cs) != 0
+
+
+def xstage_forward_raw(x, params, eps, momentum, stamps=None, mode=None):
+    """-> dict of the run's tensors.  params: nb * PER_BLOCK tensors (w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, sw1, sb1, sw2, sb2, w3, g3,
+    b3, rm3, rv3 per block)."""
+    nb = len(params) // PER_BLOCK
+    n, h, w, c = x.shape
+    dev = x.device
+    cs = params[10].shape[0]
+    tab = (ctypes.c_long * (19 * nb))()
+    packs = []
+    for b in range(nb):
+        w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, sw1, sb1, sw2, sb2, w3, g3, b3, rm3, rv3 = params[b * PER_BLOCK:(b + 1) * PER_BLOCK]
+        wp1, wt1 = pack_conv_weight(w1)
+        wk2, wd2 = pack_gconv_diag(w2)
+        wp3, wt3 = pack_conv_weight(w3)
+        packs.append((wt1, wd2, wt3, None))
+        tab[19 * b:19 * b + 19] = [t.data_ptr() for t in (wp1, wk2, wp3, sw1, sb1, sw2, sb2, g1, b1, rm1, rv1, g2, b2, rm2, rv2, g3, b3, rm3, rv3)]
+    acts = {k: torch.empty((nb, n, h, w, c), device=dev, dtype=BF16) for k in ("z1", "a", "z2", "bg", "z3", "out")}
+    coef = torch.empty((nb, 3, 4, c), device=dev, dtype=F32)
+    pooled = torch.empty((nb, n, c), device=dev, dtype=F32)
+    hid = torch.empty((nb, n, cs), device=dev, dtype=F32)
+    gate = torch.empty((nb, n, c), device=dev, dtype=F32)
+    ws, status = xstage_ws(dev)
+    lib().call("hn_xstage_fwd", ctypes.addressof(tab), nb, ptr(x), ptr(acts["z1"]), ptr(acts["a"]), ptr(acts["z2"]), ptr(acts["bg"]),
+               ptr(acts["z3"]), ptr(acts["out"]), ptr(coef), ptr(pooled), ptr(hid), ptr(gate), n, h, w, c, cs, float(eps), float(momentum),
+               1.0 / (h * w), ptr(ws), ptr(stamps), XSTAGE_MODE if mode is None else mode)
+    # the first eager launches of a shape are checked: a launch that could not become co-resident raises the status word instead of hanging
+    key = (dev.index, n, h, w, c, nb)
+    if _CHECKED.get(key, 0) < 2 and not torch.cuda.is_current_stream_capturing():
+        _CHECKED[key] = _CHECKED.get(key, 0) + 1
+        st = int(status.item())
+        if st != 0:
+            _DISABLED[0] = True
+            raise RuntimeError(f"hn_xstage_fwd: a bounded wait expired (status 0x{st:x}): the persistent stage kernel could not become "
+                               "co-resident on this device; it is disabled for this process (the launch chain runs instead)")
+    return dict(acts, coef=coef, pooled=pooled, hid=hid, gate=gate, packs=packs)
+
+
+class XStageFn(torch.autograd.Function):
+    """out = XBlock_{nb}(... XBlock_1(x)) for identity blocks (stride 1, no projection shortcut), training mode.  One forward launch."""
+
+    @staticmethod
+    def forward(ctx, x, group, eps, momentum, *params):
+        nb = len(params) // PER_BLOCK
+        r = xstage_forward_raw(x, params, eps, momentum)
+        n, h, w, c = x.shape
+        m = n * h * w
+        # hand-over of the BatchNorm-3 backward partials between consecutive identity blocks (XBlockFn.forward: BN3_PARTS_FROM_DGRAD)
+        hand_ok = (_bb.BN3_PARTS_FROM_DGRAD and _bb.EPILOGUE_STATS and group is not None and c > 64
+                   and lib().query("hn_nt_stat_rows", m, c) == (m + 63) // 64 <= MAX_PROLOGUE_ROWS)
+        first = None
+        if hand_ok:
+            last = getattr(group, "bn3_last", None)
+            if last is not None and last[0] == x.data_ptr() and last[1] == tuple(x.shape):
+                first = (last[2], last[3])
+        saved = [x]
+        meta = []
+        for b in range(nb):
+            p = params[b * PER_BLOCK:(b + 1) * PER_BLOCK]
+            w1, w2, sw1, sb1, sw2, sb2, w3 = p[0], p[5], p[10], p[11], p[12], p[13], p[14]
+            z3p = coef3p = None
+            if hand_ok and b > 0:
+                z3p, coef3p = r["z3"][b - 1], r["coef"][b - 1, 2]
+            elif hand_ok and first is not None:
+                z3p, coef3p = first
+            blk = [r["z1"][b], r["a"][b], r["z2"][b], r["z3"][b], r["out"][b], r["coef"][b, 0], r["coef"][b, 1], r["coef"][b, 2],
+                   r["pooled"][b], r["hid"][b], r["gate"][b], sw1, sw2, r["bg"][b], z3p, coef3p]
+            meta.append((len(saved), [t is not None for t in blk], r["packs"][b], (w1, w3, None, w2, sw1, sb1, sw2, sb2)))
+            saved += [t for t in blk if t is not None]
+        ctx.meta, ctx.group, ctx.nb = meta, group, nb
+        ctx.save_for_backward(*saved)
+        out = r["out"][nb - 1]
+        if group is not None:
+            group.bn3_last = (out.data_ptr(), tuple(out.shape), r["z3"][nb - 1], r["coef"][nb - 1, 2]) if _bb.BN3_PARTS_FROM_DGRAD else None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        saved = ctx.saved_tensors
+        grads = [None] * (ctx.nb * PER_BLOCK)
+        for b in reversed(range(ctx.nb)):
+            off, present, packs, wrefs = ctx.meta[b]
+            it = iter(saved[off:off + sum(present)])
+            blk = [next(it) if pz else None for pz in present]
+            z1, a, z2, z3, out, c1, c2, c3, pooled, hid, gate, sw1, sw2, bg, z3p, coef3p = blk
+            xin = saved[0] if b == 0 else saved[ctx.meta[b - 1][0] + 4]      # the previous block's `out`
+            fake = SimpleNamespace(saved_tensors=(xin, z1, a, z2, z3, out, c1, c2, c3, pooled, hid, gate, sw1, sw2, bg, None, None, z3p, coef3p),
+                                   training=True, stride=1, packs=packs, group=ctx.group, wrefs=wrefs, needs_input_grad=(True,) * 30)
+            ret = _bb.XBlockFn.backward(fake, dout)
+            dout = ret[0]
+            grads[b * PER_BLOCK:(b + 1) * PER_BLOCK] = ret[1:1 + PER_BLOCK]
+        return (dout, None, None, None, *grads)
+
+
+def xstage_apply(x, group, eps, momentum, params):
+    return XStageFn.apply(x, group, eps, momentum, *params)
+
+
+__all__ = ["XSTAGE", "XStageFn", "xstage_apply", "xstage_ok", "xstage_forward_raw", "xstage_ws", "xstage_status", "PER_BLOCK"]
