@@ -439,6 +439,18 @@ int hn_xstage_supported(int N, int H, int W, int C, int Cs);
 int hn_xstage_fwd(const long* tab, int nb, const void* x0, void* z1, void* a, void* z2, void* bg, void* z3, void* out, float* coef,
                   float* pooled, float* hid, float* gate, int N, int H, int W, int C, int Cs, float eps, float momentum, float alpha,
                   void* ws, long* stamps, int mode, hipStream_t stream);
+/* The backward of the same blocks (ops/backbone.py XBlockFn.backward, 21 launches per block), last block first, in ONE launch of the same
+ * shape: BatchNorm-backward sums cross XCDs as granules, dz3 / dz1 (the operands of the two data-gradient GEMMs) and the SE partials stay in
+ * the image's XCD, a block's dx is the next block's dout of the same workgroup.  tab = HOST table nb x 5 int64 per block, forward block
+ * order: {wt1 (transposed pack of conv_block_1, hn_pack_weight), wd2 (hn_gconv_pack_diag's data-gradient operand), wt3, se.1.weight,
+ * se.3.weight}.  Inputs: dout = gradient of the last block's output [N*H*W][C] bf16 (dense rows); the forward's stacked tensors z1 / z2 /
+ * z3 / out, coef, hid, gate.  Outputs: dz1 / dz2 / dz3 [nb][N*H*W][C] bf16 (operands of the weight gradients, which stay separate launches),
+ * dx [N*H*W][C] (gradient of the first block's input), dgb [nb][3][2][C] = (dgamma, dbeta) of BatchNorm 1 / 2 / 3, dpre2 [nb][N][C] and
+ * dpre1 [nb][N][Cs] = pre-activation gradients of the two SE layers (their outer products with hid / pooled are the SE weight gradients).
+ * ws, stamps, mode: as hn_xstage_fwd (the same workspace). */
+int hn_xstage_bwd(const long* tab, int nb, const void* dout, const void* z1, const void* z2, const void* z3, const void* out,
+                  const float* coef, const float* hid, const float* gate, void* dz1, void* dz2, void* dz3, void* dx, float* dgb,
+                  float* dpre2, float* dpre1, int N, int H, int W, int C, int Cs, void* ws, long* stamps, int mode, hipStream_t stream);
 
 /* out += b0 [+ b1] [+ b2] (bf16 [M][C] tensors, fp32 sum, one rounding): the gradient sum of a multi-consumer map whose consumers return
  * separate gradients (ops.Share.backward; net/bifpn.py outputs feed three heads) in one launch instead of one per extra consumer */

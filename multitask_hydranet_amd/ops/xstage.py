@@ -82,8 +82,42 @@ def xstage_forward_raw(x, params, eps, momentum, stamps=None, mode=None):
     return dict(acts, coef=coef, pooled=pooled, hid=hid, gate=gate, packs=packs)
 
 
+XSTAGE_BWD = policy("HN_XSTAGE_BWD", "1") != "0"  # the run's backward as one persistent launch too (0: XBlockFn.backward per block)
+
+
+def xstage_backward_raw(dout, r_or_saved, packs, sws, stamps=None, mode=None):
+    """hn_xstage_bwd on the stacked forward tensors -> dict(dz1, dz2, dz3 [nb, n, h, w, c], dx, dgb [nb, 3, 2, c], dpre2, dpre1).
+    r_or_saved: dict with z1, z2, z3, out, coef, hid, gate; packs: per block (wt1, wd2, wt3, ...); sws: per block (se.1.weight, se.3.weight)."""
+    z1, z2, z3, out, coef, hid, gate = (r_or_saved[k] for k in ("z1", "z2", "z3", "out", "coef", "hid", "gate"))
+    nb, n, h, w, c = z1.shape
+    cs = hid.shape[2]
+    dev = z1.device
+    tab = (ctypes.c_long * (5 * nb))()
+    for b in range(nb):
+        tab[5 * b:5 * b + 5] = [packs[b][0].data_ptr(), packs[b][1].data_ptr(), packs[b][2].data_ptr(), sws[b][0].data_ptr(), sws[b][1].data_ptr()]
+    dz = {k: torch.empty((nb, n, h, w, c), device=dev, dtype=BF16) for k in ("dz1", "dz2", "dz3")}
+    dx = torch.empty((n, h, w, c), device=dev, dtype=BF16)
+    dgb = torch.empty((nb, 3, 2, c), device=dev, dtype=F32)
+    dpre2 = torch.empty((nb, n, c), device=dev, dtype=F32)
+    dpre1 = torch.empty((nb, n, cs), device=dev, dtype=F32)
+    ws, status = xstage_ws(dev)
+    lib().call("hn_xstage_bwd", ctypes.addressof(tab), nb, ptr(dout), ptr(z1), ptr(z2), ptr(z3), ptr(out), ptr(coef), ptr(hid), ptr(gate),
+               ptr(dz["dz1"]), ptr(dz["dz2"]), ptr(dz["dz3"]), ptr(dx), ptr(dgb), ptr(dpre2), ptr(dpre1), n, h, w, c, cs, ptr(ws), ptr(stamps),
+               XSTAGE_MODE if mode is None else mode)
+    key = ("bwd", dev.index, n, h, w, c, nb)
+    if _CHECKED.get(key, 0) < 2 and not torch.cuda.is_current_stream_capturing():
+        _CHECKED[key] = _CHECKED.get(key, 0) + 1
+        st = int(status.item())
+        if st != 0:
+            _DISABLED[0] = True
+            raise RuntimeError(f"hn_xstage_bwd: a bounded wait expired (status 0x{st:x}): the persistent stage kernel could not become "
+                               "co-resident on this device; it is disabled for this process (the launch chain runs instead)")
+    return dict(dz, dx=dx, dgb=dgb, dpre2=dpre2, dpre1=dpre1)
+
+
 class XStageFn(torch.autograd.Function):
-    """out = XBlock_{nb}(... XBlock_1(x)) for identity blocks (stride 1, no projection shortcut), training mode.  One forward launch."""
+    """out = XBlock_{nb}(... XBlock_1(x)) for identity blocks (stride 1, no projection shortcut), training mode.  One forward launch; the
+    backward is one launch too (hn_xstage_bwd) when the stage defers its weight gradients (group), else XBlockFn.backward per block."""
 
     @staticmethod
     def forward(ctx, x, group, eps, momentum, *params):
@@ -91,30 +125,23 @@ class XStageFn(torch.autograd.Function):
         r = xstage_forward_raw(x, params, eps, momentum)
         n, h, w, c = x.shape
         m = n * h * w
-        # hand-over of the BatchNorm-3 backward partials between consecutive identity blocks (XBlockFn.forward: BN3_PARTS_FROM_DGRAD)
-        hand_ok = (_bb.BN3_PARTS_FROM_DGRAD and _bb.EPILOGUE_STATS and group is not None and c > 64
+        ctx.persistent_bwd = XSTAGE_BWD and group is not None
+        # hand-over of the BatchNorm-3 backward partials between consecutive identity blocks (XBlockFn.forward: BN3_PARTS_FROM_DGRAD): only
+        # the per-block backward uses it
+        hand_ok = (not ctx.persistent_bwd and _bb.BN3_PARTS_FROM_DGRAD and _bb.EPILOGUE_STATS and group is not None and c > 64
                    and lib().query("hn_nt_stat_rows", m, c) == (m + 63) // 64 <= MAX_PROLOGUE_ROWS)
-        first = None
+        first = (None, None)
         if hand_ok:
             last = getattr(group, "bn3_last", None)
             if last is not None and last[0] == x.data_ptr() and last[1] == tuple(x.shape):
                 first = (last[2], last[3])
-        saved = [x]
-        meta = []
-        for b in range(nb):
-            p = params[b * PER_BLOCK:(b + 1) * PER_BLOCK]
-            w1, w2, sw1, sb1, sw2, sb2, w3 = p[0], p[5], p[10], p[11], p[12], p[13], p[14]
-            z3p = coef3p = None
-            if hand_ok and b > 0:
-                z3p, coef3p = r["z3"][b - 1], r["coef"][b - 1, 2]
-            elif hand_ok and first is not None:
-                z3p, coef3p = first
-            blk = [r["z1"][b], r["a"][b], r["z2"][b], r["z3"][b], r["out"][b], r["coef"][b, 0], r["coef"][b, 1], r["coef"][b, 2],
-                   r["pooled"][b], r["hid"][b], r["gate"][b], sw1, sw2, r["bg"][b], z3p, coef3p]
-            meta.append((len(saved), [t is not None for t in blk], r["packs"][b], (w1, w3, None, w2, sw1, sb1, sw2, sb2)))
-            saved += [t for t in blk if t is not None]
-        ctx.meta, ctx.group, ctx.nb = meta, group, nb
-        ctx.save_for_backward(*saved)
+        ctx.hand_ok = hand_ok
+        ctx.has_first = first[0] is not None
+        ctx.packs, ctx.group, ctx.nb = r["packs"], group, nb
+        ctx.wrefs = [(p[0], p[14], None, p[5], p[10], p[11], p[12], p[13]) for p in (params[b * PER_BLOCK:(b + 1) * PER_BLOCK] for b in range(nb))]
+        sws = [t for b in range(nb) for t in (params[b * PER_BLOCK + 10], params[b * PER_BLOCK + 12])]
+        ctx.save_for_backward(x, r["z1"], r["a"], r["z2"], r["bg"], r["z3"], r["out"], r["coef"], r["pooled"], r["hid"], r["gate"],
+                              *([first[0], first[1]] if ctx.has_first else []), *sws)
         out = r["out"][nb - 1]
         if group is not None:
             group.bn3_last = (out.data_ptr(), tuple(out.shape), r["z3"][nb - 1], r["coef"][nb - 1, 2]) if _bb.BN3_PARTS_FROM_DGRAD else None
@@ -123,15 +150,43 @@ class XStageFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         saved = ctx.saved_tensors
-        grads = [None] * (ctx.nb * PER_BLOCK)
-        for b in reversed(range(ctx.nb)):
-            off, present, packs, wrefs = ctx.meta[b]
-            it = iter(saved[off:off + sum(present)])
-            blk = [next(it) if pz else None for pz in present]
-            z1, a, z2, z3, out, c1, c2, c3, pooled, hid, gate, sw1, sw2, bg, z3p, coef3p = blk
-            xin = saved[0] if b == 0 else saved[ctx.meta[b - 1][0] + 4]      # the previous block's `out`
-            fake = SimpleNamespace(saved_tensors=(xin, z1, a, z2, z3, out, c1, c2, c3, pooled, hid, gate, sw1, sw2, bg, None, None, z3p, coef3p),
-                                   training=True, stride=1, packs=packs, group=ctx.group, wrefs=wrefs, needs_input_grad=(True,) * 30)
+        x, z1, a, z2, bg, z3, out, coef, pooled, hid, gate = saved[:11]
+        k = 11
+        first = (None, None)
+        if ctx.has_first:
+            first = (saved[11], saved[12])
+            k = 13
+        sws = [(saved[k + 2 * b], saved[k + 2 * b + 1]) for b in range(ctx.nb)]
+        nb, group = ctx.nb, ctx.group
+        n, h, w, c = x.shape
+        grads = [None] * (nb * PER_BLOCK)
+        dout = dense(dout)
+        if ctx.persistent_bwd and not _DISABLED[0]:
+            if not dout.is_contiguous():
+                dout = dout.contiguous()
+            r = xstage_backward_raw(dout, dict(z1=z1, z2=z2, z3=z3, out=out, coef=coef, hid=hid, gate=gate), ctx.packs, sws)
+            grid = (n, h, w)
+            for b in reversed(range(nb)):           # the deferred parameter gradients, queued in the order XBlockFn.backward queues them
+                w1_, w3_, _, w2_, sw1_, sb1_, sw2_, sb2_ = ctx.wrefs[b]
+                group.add(w3_, bg[b], r["dz3"][b], 0, grid, c, c)
+                group.add_outer(sw2_, sb2_, r["dpre2"][b], hid[b])
+                group.add_outer(sw1_, sb1_, r["dpre1"][b], pooled[b])
+                group.add_gconv(w2_, a[b], r["dz2"][b], grid, c)
+                group.add(w1_, x if b == 0 else out[b - 1], r["dz1"][b], 0, grid, c, c)
+                g = grads[b * PER_BLOCK:(b + 1) * PER_BLOCK]
+                g[1], g[2], g[6], g[7], g[15], g[16] = (r["dgb"][b, 0, 0], r["dgb"][b, 0, 1], r["dgb"][b, 1, 0], r["dgb"][b, 1, 1],
+                                                        r["dgb"][b, 2, 0], r["dgb"][b, 2, 1])
+                grads[b * PER_BLOCK:(b + 1) * PER_BLOCK] = g
+            return (r["dx"], None, None, None, *grads)
+        for b in reversed(range(nb)):
+            z3p = coef3p = None
+            if ctx.hand_ok and b > 0:
+                z3p, coef3p = z3[b - 1], coef[b - 1, 2]
+            elif ctx.hand_ok:
+                z3p, coef3p = first
+            fake = SimpleNamespace(saved_tensors=(x if b == 0 else out[b - 1], z1[b], a[b], z2[b], z3[b], out[b], coef[b, 0], coef[b, 1], coef[b, 2],
+                                                  pooled[b], hid[b], gate[b], sws[b][0], sws[b][1], bg[b], None, None, z3p, coef3p),
+                                   training=True, stride=1, packs=ctx.packs[b], group=group, wrefs=ctx.wrefs[b], needs_input_grad=(True,) * 30)
             ret = _bb.XBlockFn.backward(fake, dout)
             dout = ret[0]
             grads[b * PER_BLOCK:(b + 1) * PER_BLOCK] = ret[1:1 + PER_BLOCK]
@@ -142,4 +197,5 @@ def xstage_apply(x, group, eps, momentum, params):
     return XStageFn.apply(x, group, eps, momentum, *params)
 
 
-__all__ = ["XSTAGE", "XStageFn", "xstage_apply", "xstage_ok", "xstage_forward_raw", "xstage_ws", "xstage_status", "PER_BLOCK"]
+__all__ = ["XSTAGE", "XSTAGE_BWD", "XStageFn", "xstage_apply", "xstage_ok", "xstage_forward_raw", "xstage_backward_raw", "xstage_ws",
+           "xstage_status", "PER_BLOCK"]

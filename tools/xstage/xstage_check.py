@@ -156,11 +156,107 @@ def run_case(name, mode):
     return {"case": name, "mode": mode, "worst_rel": worst, "chain_us": t_chain, "persistent_us": t_pers, "status": st, "detail": res}
 
 
+def run_bwd_case(name, mode):
+    """backward: the persistent launch against XBlockFn.backward on the SAME forward tensors (the persistent forward's), block by block with
+    the chain's own dout (teacher forced: one-block launches), then the whole run; both timed as replayed graphs (weight gradients deferred
+    and not flushed in either)."""
+    from types import SimpleNamespace
+    n, h, w, c, nb = CASES[name]
+    cs = c // 4
+    dev = torch.device("cuda:0")
+    print(f"== backward case {name}: N={n} {h}x{w} C={c} blocks={nb} mode={mode}", flush=True)
+    g = torch.Generator(device="cpu").manual_seed(7)
+    x = torch.randn(n, h, w, c, generator=g).to(dev).to(torch.bfloat16).relu_()
+    ps = make_params(nb, c, dev, 11)
+    with torch.no_grad():
+        r = XS.xstage_forward_raw(x, ps, EPS, MOM, mode=mode)
+    dout = (torch.randn(n, h, w, c, generator=g) * 0.01).to(dev).to(torch.bfloat16)
+    sws = [(ps[b * 19 + 10], ps[b * 19 + 12]) for b in range(nb)]
+    grid = (n, h, w)
+
+    def chain_block(b, d, group):
+        p = ps[b * 19:(b + 1) * 19]
+        fake = SimpleNamespace(saved_tensors=(x if b == 0 else r["out"][b - 1], r["z1"][b], r["a"][b], r["z2"][b], r["z3"][b], r["out"][b],
+                                              r["coef"][b, 0], r["coef"][b, 1], r["coef"][b, 2], r["pooled"][b], r["hid"][b], r["gate"][b],
+                                              p[10], p[12], r["bg"][b], None, None, None, None),
+                               training=True, stride=1, packs=r["packs"][b], group=group,
+                               wrefs=(p[0], p[14], None, p[5], p[10], p[11], p[12], p[13]), needs_input_grad=(True,) * 30)
+        return K.XBlockFn.backward(fake, d)
+    res = {}
+    worst = 0.0
+    d = dout
+    douts = {}
+    with torch.no_grad():
+        for b in reversed(range(nb)):
+            douts[b] = d
+            ret = chain_block(b, d, None)
+            sl = lambda t: t[b:b + 1]
+            rb = XS.xstage_backward_raw(d.contiguous(), dict(z1=sl(r["z1"]), z2=sl(r["z2"]), z3=sl(r["z3"]), out=sl(r["out"]), coef=sl(r["coef"]),
+                                                             hid=sl(r["hid"]), gate=sl(r["gate"])), [r["packs"][b]], [sws[b]], mode=mode)
+            xb = x if b == 0 else r["out"][b - 1]
+            dw1 = K.k_gemm_tn(xb, None, 0, grid, rb["dz1"][0], c, K.kp32(c), 1, c)
+            dw3 = K.k_gemm_tn(r["bg"][b], None, 0, grid, rb["dz3"][0], c, K.kp32(c), 1, c)
+            dw2 = K.k_gemm_tn(r["a"][b], None, 5, grid, rb["dz2"][0], c, 64, 9, 8, kh=3)
+            dsw2 = rb["dpre2"][0].t() @ r["hid"][b]
+            dsw1 = rb["dpre1"][0].t() @ r["pooled"][b]
+            pairs = (("dx", rb["dx"], ret[0]), ("dw1", dw1, ret[1]), ("dg1", rb["dgb"][0, 0, 0], ret[2]), ("db1", rb["dgb"][0, 0, 1], ret[3]),
+                     ("dw2", dw2, ret[6]), ("dg2", rb["dgb"][0, 1, 0], ret[7]), ("db2", rb["dgb"][0, 1, 1], ret[8]),
+                     ("dsw1", dsw1, ret[11].view(cs, c)), ("dsb1", rb["dpre1"][0].sum(0), ret[12]),
+                     ("dsw2", dsw2, ret[13].view(c, cs)), ("dsb2", rb["dpre2"][0].sum(0), ret[14]),
+                     ("dw3", dw3, ret[15]), ("dg3", rb["dgb"][0, 2, 0], ret[16]), ("db3", rb["dgb"][0, 2, 1], ret[17]))
+            for nm, ta, tb in pairs:
+                qq = cmp(f"b{b}.{nm}", ta.reshape(tb.shape) if ta.numel() == tb.numel() else ta, tb, res)
+                worst = max(worst, qq["rel_to_max"])
+            if b in (nb - 1, nb - 2, 0):
+                print("   block", b, {k.split(".")[1]: (round(v["rel_to_max"], 5), round(v["frac_differ"], 4)) for k, v in res.items()
+                                      if k.startswith(f"b{b}.")}, flush=True)
+            d = ret[0]
+        st = XS.xstage_status(dev)
+        print(f"   teacher-forced per block: worst rel-to-max {worst:.3e}, status 0x{st:x}, any nan {any(v['nan'] for v in res.values())}", flush=True)
+        # the whole run in one launch
+        stamps = torch.zeros((nb, 16), device=dev, dtype=torch.int64)
+        full = XS.xstage_backward_raw(dout.contiguous(), r, r["packs"], sws, stamps=stamps, mode=mode)
+        q0 = cmp("run.dx", full["dx"], d, res)
+        q1 = cmp("run.dg1_first", full["dgb"][0, 0, 0], ret[2], res)
+        print(f"   whole run: dx rel-to-max {q0['rel_to_max']:.3e} (differ {q0['frac_differ']:.3f}); block 0 dgamma1 {q1['rel_to_max']:.3e}", flush=True)
+        ticks = stamps.cpu().numpy().astype("float64")
+        if ticks[0, 0] > 0:
+            names = ["top", "bn3", "dz3+await", "gemm_dbg", "se+bn2", "dz2+gconv", "bn1", "dz1+await", "gemm_dx", "tail"]
+            dd = (ticks[:, 1:10] - ticks[:, 0:9]) / 100.0
+            mid = dd[1:].mean(axis=0) if nb > 1 else dd[0]
+            print("   stamps, mean us per phase over steps 1..: " + "  ".join(f"{names[i + 1]}={mid[i]:.2f}" for i in range(9)), flush=True)
+            print(f"   per block: {(ticks[1:, 9] - ticks[1:, 0]).mean() / 100.0 if nb > 1 else 0:.2f} us; whole launch (stamped wg): "
+                  f"{(ticks[nb - 1, 9] - ticks[0, 0]) / 100.0:.1f} us", flush=True)
+
+    def f_chain():
+        with torch.no_grad():
+            grp = K.WgradGroup()
+            dd = dout
+            for b in reversed(range(nb)):
+                dd = chain_block(b, dd, grp)[0]
+            grp.jobs.clear(); grp.gconv.clear(); grp.tail.clear()
+        return dd
+
+    def f_pers():
+        with torch.no_grad():
+            return XS.xstage_backward_raw(dout, r, r["packs"], sws, mode=mode)["dx"]
+    t_chain = graph_time(f_chain)
+    t_pers = graph_time(f_pers)
+    st = XS.xstage_status(dev)
+    print(f"   time per backward of the {nb} blocks (weight gradients deferred): chain {t_chain:.1f} us, persistent {t_pers:.1f} us, ratio "
+          f"{t_pers / t_chain:.3f}, status 0x{st:x}", flush=True)
+    return {"case": name, "mode": mode, "dir": "bwd", "worst_rel": worst, "chain_us": t_chain, "persistent_us": t_pers, "status": st, "detail": res}
+
+
 if __name__ == "__main__":
     mode = int(os.environ.get("XS_MODE", "0"))
     cases = [a for a in sys.argv[1:] if a in CASES] or list(CASES)
+    dirs = [a for a in sys.argv[1:] if a in ("fwd", "bwd")] or ["fwd", "bwd"]
     out = []
     for cname in cases:
-        out.append(run_case(cname, mode))
+        if "fwd" in dirs:
+            out.append(run_case(cname, mode))
+        if "bwd" in dirs:
+            out.append(run_bwd_case(cname, mode))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"xstage_check_mode{mode}.json"), "w"))
