@@ -274,21 +274,37 @@ struct XsWg {
             if (g.dbg & 4) continue;
             const char* sX = Ring + (it & 1) * XSTAGE;
             const char* sW = Wreg + it * (SL * 128);
-            bf16x8 fa[2][TC], fb[2][TP];
+            if constexpr (TP <= 2) {                       // narrow tiles: all fragment reads of the stage first, then the MFMAs
+                bf16x8 fa[2][TC], fb[2][TP];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int piece = ks * 4 + (lane >> 4);
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int piece = ks * 4 + (lane >> 4);
 #pragma unroll
-                for (int i = 0; i < TC; ++i) fa[ks][i] = *reinterpret_cast<const bf16x8*>(sW + xs_swz(wc * 32 + i * 16 + (lane & 15), piece));
+                    for (int i = 0; i < TC; ++i) fa[ks][i] = *reinterpret_cast<const bf16x8*>(sW + xs_swz(wc * 32 + i * 16 + (lane & 15), piece));
 #pragma unroll
-                for (int j = 0; j < TP; ++j) fb[ks][j] = *reinterpret_cast<const bf16x8*>(sX + xs_swz(wp * WP + j * 16 + (lane & 15), piece));
+                    for (int j = 0; j < TP; ++j) fb[ks][j] = *reinterpret_cast<const bf16x8*>(sX + xs_swz(wp * WP + j * 16 + (lane & 15), piece));
+                }
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int i = 0; i < TC; ++i)
+#pragma unroll
+                        for (int j = 0; j < TP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
+            } else {                                       // wide tiles: eight MFMAs per half stage cover the next half's reads (24 registers less)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    bf16x8 fa[TC], fb[TP];
+                    const int piece = ks * 4 + (lane >> 4);
+#pragma unroll
+                    for (int i = 0; i < TC; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sW + xs_swz(wc * 32 + i * 16 + (lane & 15), piece));
+#pragma unroll
+                    for (int j = 0; j < TP; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(sX + xs_swz(wp * WP + j * 16 + (lane & 15), piece));
+#pragma unroll
+                    for (int i = 0; i < TC; ++i)
+#pragma unroll
+                        for (int j = 0; j < TP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                }
             }
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int i = 0; i < TC; ++i)
-#pragma unroll
-                    for (int j = 0; j < TP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();                                 // every wave is done with the ring and the weight slice
     }
@@ -890,14 +906,15 @@ __global__ __launch_bounds__(XS_THREADS) void xstage_bwd_kernel(const XbArgs p) 
             //   dhid share: thread (j = tid & 255, half) owns W2[c0 + half SL/2 + k][j]; dpool: thread (c = tid % SL, part) owns W1[part JP + k][c0 + c]
             constexpr int HC = SL / 2, PARTS = XS_THREADS / SL, JP = 256 / PARTS;
             float w2r[HC], w1r[JP];
-            {
+            auto load_se = [&]() {
                 const int j = tid & 255, hc0 = (tid >> 8) * HC;
 #pragma unroll
                 for (int k = 0; k < HC; ++k) w2r[k] = (j < Cs && hc0 + k < SLv) ? B.sw2[(long)(c0 + hc0 + k) * Cs + j] : 0.f;
                 const int c = tid % SL, j0 = (tid / SL) * JP;
 #pragma unroll
                 for (int k = 0; k < JP; ++k) w1r[k] = (c < SLv && j0 + k < Cs) ? B.sw1[(long)(j0 + k) * C + c0 + c] : 0.f;
-            }
+            };
+            load_se();
             const float gatev = tid < SLv ? p.gate[((long)b * p.g.N + img) * C + c0 + tid] : 0.f;
             const float hidv = (tid < 256 && tid < Cs) ? p.hid[((long)b * p.g.N + img) * Cs + tid] : 0.f;
             bf16x4 tz2[TC][TP];
@@ -1002,10 +1019,11 @@ __global__ __launch_bounds__(XS_THREADS) void xstage_bwd_kernel(const XbArgs p) 
             w.publish(3 * it + 1);
             bf16x4 tz1[TC][TP];                           // requested behind the publish (16 KB per workgroup), used behind the grouped conv
             w.load_tile(p.z1 + (long)b * MC, tz1);
-            bf16x8 wf[TC][5];
-            w.load_wf(B.wd2, wf);                         // the grouped conv's flipped operand
+            bf16x8 wf[TC][5];                             // the grouped conv's flipped operand (wide tiles: behind the gather -- 40 registers)
+            if (TP <= 2) w.load_wf(B.wd2, wf);
             w.bn_backward(3 * it + 1, dgb + 2 * C, dgb + 3 * C);
             if (w.dead) break;
+            if (TP > 2) w.load_wf(B.wd2, wf);
             w.stamp(it, 4);
             w.zero_halo();
             bn_apply(tz2);

@@ -214,8 +214,10 @@ def test_persistent_launches_replay_in_a_graph_and_keep_their_state():
 
 @pytest.mark.gpu
 def test_model_with_and_without_the_persistent_stage_kernels():
-    """HydraNet (big backbone's deep stages at a reduced batch-16 input) trained one step with the persistent launches and with the launch
-    chain: same losses to the bf16 noise of the backbone, gradients in the same direction, every parameter has a finite gradient"""
+    """The big backbone (batch 16, 512 x 1024) forward + backward three ways: persistent forward + backward launches, persistent forward
+    with the per-block chain backward, the launch chain only.  State: random weights with the zero-init-residual conditioning of
+    tests/helpers.conditioned_state (the plain random state amplifies any perturbation ~1.5x per block, which makes end-to-end bf16
+    statements vacuous -- DESIGN.md section 4); upstream gradient: a fixed random projection of the five features."""
     import __graft_entry__ as g
     g.build()
     import yaml
@@ -224,26 +226,34 @@ def test_model_with_and_without_the_persistent_stage_kernels():
     cfgs = yaml.safe_load(open(os.path.join(ROOT, "cfgs", "hydranet_big.yml")))
     cfgs["dataloader"]["network_input_height"], cfgs["dataloader"]["network_input_width"] = 512, 1024
     res = {}
-    for on in (True, False):
-        K.XSTAGE = on
-        K.clear_pack_cache()
-        torch.manual_seed(0)
-        net = HydraNet(cfgs).to(dev).train()
-        gen = torch.Generator(device="cpu").manual_seed(1)
-        img = torch.randn(16, 3, 512, 1024, generator=gen).to(dev)
-        feats = net._backbone(img)
-        loss = sum(f.float().mean() for f in feats)
-        loss.backward()
-        grads = {k: p.grad.detach().float().clone() for k, p in net._idx.items() if p.grad is not None and k.startswith("backbone.")}
-        res[on] = (float(loss), [f.detach().float() for f in feats], grads)
-    K.XSTAGE = True
-    la, fa, ga = res[True]
-    lb, fb, gb = res[False]
-    # (a randomly initialised 30-block backbone in training mode amplifies single-ulp differences: two valid bf16 orders of summation
-    # drift apart like this on either path; the tight statements are the teacher-forced tests above and the oracle tests of the whole model)
-    assert abs(la - lb) <= 2e-2 * abs(lb), (la, lb)
-    assert _cos(fa[3], fb[3]) >= 0.99 and _cos(fa[4], fb[4]) >= 0.97, (_cos(fa[3], fb[3]), _cos(fa[4], fb[4]))
-    assert set(ga) == set(gb)
-    cs = sorted(_cos(ga[k], gb[k]) for k in ga if ga[k].numel() >= 64 and gb[k].abs().max() > 0)
-    assert cs[len(cs) // 2] >= 0.95 and cs[0] >= 0.5, (cs[0], cs[len(cs) // 10], cs[len(cs) // 2])
+    try:
+        for name, on, bwd in (("persistent", True, True), ("fwd_only", True, False), ("chain", False, False)):
+            K.XSTAGE, K.XSTAGE_BWD = on, bwd
+            K.clear_pack_cache()
+            torch.manual_seed(0)
+            net = HydraNet(cfgs).to(dev).train()
+            with torch.no_grad():
+                for k, p in net._idx.items():
+                    if k.endswith("conv_block_3.1.weight"):
+                        p.mul_(0.1)
+            gen = torch.Generator(device="cpu").manual_seed(1)
+            img = torch.randn(16, 3, 512, 1024, generator=gen).to(dev)
+            feats = net._backbone(img)
+            loss = sum((f.float() * torch.randn(f.shape, generator=gen).to(dev)).mean() for f in feats)
+            loss.backward()
+            grads = {k: p.grad.detach().float().clone() for k, p in net._idx.items() if p.grad is not None and k.startswith("backbone.")}
+            res[name] = (float(loss.detach()), [f.detach().float() for f in feats], grads)
+    finally:
+        K.XSTAGE, K.XSTAGE_BWD = True, True
+    (la, fa, ga), (lf, ff, gf), (lb, fb, gb) = res["persistent"], res["fwd_only"], res["chain"]
+    assert la == lf                                                   # the same forward launches
+    assert abs(la - lb) <= 2e-2 * abs(lb) + 1e-6, (la, lb)
+    assert _cos(fa[3], fb[3]) >= 0.995 and _cos(fa[4], fb[4]) >= 0.995, (_cos(fa[3], fb[3]), _cos(fa[4], fb[4]))
+    assert set(ga) == set(gb) == set(gf)
+    big = [k for k in ga if ga[k].numel() >= 64 and gb[k].abs().max() > 0]
+    cs = sorted(_cos(ga[k], gb[k]) for k in big)
+    assert cs[len(cs) // 2] >= 0.98 and cs[len(cs) // 10] >= 0.97 and cs[0] >= 0.75, (cs[0], cs[len(cs) // 10], cs[len(cs) // 2])
+    # the persistent backward against the chain backward on the SAME forward tensors
+    cs2 = sorted(_cos(ga[k], gf[k]) for k in big)
+    assert cs2[0] >= 0.99 and cs2[len(cs2) // 2] >= 0.9995, (cs2[0], cs2[len(cs2) // 2])
     assert all(torch.isfinite(v).all() for v in ga.values())
