@@ -923,6 +923,10 @@ def main():
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         value = args.batch * world * args.steps / dt
+        # the persistent stage launches never hang: an expired wait raises a status word and leaves invalid outputs -- a timed run with one
+        # is not a measurement (checked here, after the timed region's synchronisation)
+        from multitask_hydranet_amd.ops import xstage_assert_ok
+        xstage_assert_ok(torch.device("cuda", torch.cuda.current_device()))
         # optimizer step, reported separately (Adam as in model/train.py:147)
         ms_opt = None
         if not args.no_optimizer:

@@ -39,7 +39,7 @@
 #define XS_GRID 256
 #define XS_MAX_IMG 32
 #define XS_MAX_SLICES 16
-#define XS_TIMEOUT_TICKS 5000000ull          // 50 ms
+#define XS_TIMEOUT_TICKS 20000000ull         // 200 ms of the 100 MHz real-time counter (a collective on a side stream may hold CUs for milliseconds)
 #define XS_CNT_OFF 4096
 #define XS_HP_OFF (XS_CNT_OFF + XS_MAX_IMG * 4 * 128)
 #define XS_GRAN_OFF (XS_HP_OFF + XS_MAX_IMG * XS_MAX_SLICES * 256 * 4)

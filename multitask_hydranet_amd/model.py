@@ -426,6 +426,13 @@ class HydraNet(nn.Module):
         return [P[q + "conv_block_1.0.weight"], *bn[0], P[q + "conv_block_2.0.weight"], *bn[1], P[q + "se.1.weight"], P[q + "se.1.bias"],
                 P[q + "se.3.weight"], P[q + "se.3.bias"], P[q + "conv_block_3.0.weight"], *bn[2]]
 
+    def _xstage_shape_ok(self, q, x):
+        P = self._idx
+        if (q + "se.1.weight") not in P or (q + "shortcut.0.weight") in P:
+            return False
+        w1 = P[q + "conv_block_1.0.weight"]
+        return K.xblock_fusable(x, w1, 1, True, False) and K.xstage_ok(x, w1, P[q + "se.1.weight"].shape[0])
+
     def _xstage_run(self, q, x, group):
         """the blocks from `q` to the end of the stage can run as one persistent launch: training-mode identity blocks with SE whose shape the
         kernel covers (hn_xstage_supported), deferred weight gradients in place (the backward walks XBlockFn.backward)"""
@@ -464,6 +471,17 @@ class HydraNet(nn.Module):
             i = 0
             while i < d:
                 q = f"{p}stage_{k}.blocks.block_{i}."
+                if i > 0 and self.training and not (torch.is_grad_enabled() and t.requires_grad) and self._xstage_shape_ok(q, t):
+                    # training-mode forward without autograd (the backbone under a head-only fine-tuning phase): the persistent forward alone
+                    while i < d:
+                        j1 = min(d, i + 16)
+                        params = []
+                        for j in range(i, j1):
+                            params += self._xblock_params(f"{p}stage_{k}.blocks.block_{j}.")
+                        with torch.no_grad():
+                            t = K.xstage_forward_raw(t, params, BN_STD["eps"], BN_STD["momentum"])["out"][j1 - i - 1]
+                        i = j1
+                    break
                 if i > 0 and i < d and self._xstage_run(q, t, group):
                     # blocks i..d-1 are stride-1 identity blocks of one shape: ONE persistent launch for their forward (ops/xstage.py)
                     while i < d:                                   # (a launch takes up to 16 blocks)

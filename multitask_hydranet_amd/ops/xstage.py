@@ -37,6 +37,20 @@ def xstage_status(dev) -> int:
     return int(xstage_ws(dev)[1].item())
 
 
+def xstage_assert_ok(dev=None):
+    """raise if a persistent launch on `dev` (default: every device that has a workspace) ended with an expired wait (synchronises).  The
+    launches themselves never hang: a wait that expires raises the status word and the workgroups retire, leaving invalid outputs -- callers
+    that replay captured steps (where the per-launch check cannot run) call this where they synchronise anyway."""
+    for key, (buf, status) in list(_WS.items()):
+        if dev is not None and (dev.index if dev.index is not None else torch.cuda.current_device()) != key:
+            continue
+        st = int(status.item())
+        if st != 0:
+            _DISABLED[0] = True
+            raise RuntimeError(f"persistent stage kernel: a bounded wait expired on device {key} (status 0x{st:x}): the results of the affected "
+                               "steps are invalid; the launch chain (HN_XSTAGE=0 semantics) takes over for the rest of the process")
+
+
 def xstage_ok(x, w1, cs) -> bool:
     """the persistent kernel covers this run of identity blocks (shape, batch, dense rows); else the caller keeps the launch chain"""
     if not (XSTAGE and not _DISABLED[0] and x.is_cuda and x.dim() == 4 and x.dtype == BF16 and x.is_contiguous()):
@@ -198,4 +212,4 @@ def xstage_apply(x, group, eps, momentum, params):
 
 
 __all__ = ["XSTAGE", "XSTAGE_BWD", "XStageFn", "xstage_apply", "xstage_ok", "xstage_forward_raw", "xstage_backward_raw", "xstage_ws",
-           "xstage_status", "PER_BLOCK"]
+           "xstage_status", "xstage_assert_ok", "PER_BLOCK"]

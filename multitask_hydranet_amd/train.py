@@ -63,6 +63,9 @@ def run_training(trainer: "HydraTrainer", valid_every_epoch: bool = True, log=pr
     log("============== finish training ==============")
 
 
+from .ops.xstage import xstage_assert_ok as K_xstage_assert_ok
+
+
 class HydraTrainer:
     def __init__(self, cfgs: dict, trainloader: Optional[Iterable] = None, validloader: Optional[Iterable] = None, iters_per_epoch: Optional[int] = None,
                  grad_payload: torch.dtype = torch.float32, capture_step: bool = False, hip_adam: bool = True, force_distribute: bool = False):
@@ -92,7 +95,11 @@ class HydraTrainer:
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             if self.world == 1:
                 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-                os.environ.setdefault("MASTER_PORT", "29541")
+                if "MASTER_PORT" not in os.environ:          # a free port: a constant collides with a second trainer / a socket in TIME_WAIT
+                    import socket
+                    with socket.socket() as sk:
+                        sk.bind(("127.0.0.1", 0))
+                        os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
             dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.device)
 
         self.hydranet = HydraNet(cfgs=cfgs).to(self.device)
@@ -274,8 +281,11 @@ class HydraTrainer:
         self.hydranet.train()
         for iter_idx, batch_data in enumerate(self.trainloader):
             loss_dict = self.train_step(batch_data)
-            if self.rank == 0 and iter_idx % self.print_interval == 0:
-                self.print_loss_info(loss_dict, epoch, iter_idx)
+            if iter_idx % self.print_interval == 0:
+                if self.device.type == "cuda":
+                    K_xstage_assert_ok(self.device)          # (a replayed step cannot check its persistent launches itself: ops/xstage.py)
+                if self.rank == 0:
+                    self.print_loss_info(loss_dict, epoch, iter_idx)
 
     def print_loss_info(self, loss_dict, epoch, batch_idx, mode="train"):
         lr = self.optimizer.param_groups[0]["lr"]
