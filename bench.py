@@ -914,6 +914,34 @@ def main():
     both_forms = exchange and backend == "nccl" and run.in_graph_exchange and args.both_exchange_forms
     if both_forms and rank != 0:
         other_exchange_form(run, net, cfgs, batch, dev, rank, world, payload, args, dt)
+    # What the exchange costs on the step's critical path: the same step captured WITHOUT the exchange (no collective inside
+    # this second capture, so it is safe in-process) and timed on every rank; exposed = step with - step without, max over ranks.  The
+    # reducer's default form is in line on the capture stream; when the exposed time exceeds 3 % of the step the line says so
+    # (`exchange_advice`): the forked side-stream form (HN_DDP_GRAPH_OVERLAP=1) and the bf16 payload (--grad-payload bf16) are the two knobs.
+    exposed = None
+    if exchange and run.graph is not None and run.in_graph_exchange and not os.environ.get("HN_BENCH_GRAD_NORM"):
+        try:
+            from multitask_hydranet_amd.ddp import settle_collectives
+            settle_collectives(dev)
+            run_plain = TrainRun(net, cfgs, batch, dev, rank, world, backend, backbone_only=args.backbone_only, use_graph=True, exchange=False)
+            if run_plain.graph is not None:
+                n_pl = max(5, args.steps // 2)
+                dt_pl, _ = time_replays(run_plain.graph.replay, n_pl, 2, world)
+                t_pl = torch.tensor([dt_pl / n_pl], device=dev, dtype=torch.float64)
+                if world > 1:
+                    dist.all_reduce(t_pl, op=dist.ReduceOp.MAX)
+                ms_plain = float(t_pl) * 1e3
+                ms_with = dt / args.steps * 1e3
+                exposed = {"ms_step_with_exchange": round(ms_with, 3), "ms_step_without_exchange": round(ms_plain, 3),
+                           "exchange_exposed_ms": round(ms_with - ms_plain, 3), "exposed_frac_of_step": round((ms_with - ms_plain) / ms_with, 4),
+                           "form": "graph_overlap (forked side stream)" if run.reducer.graph_overlap else "in line on the capture stream",
+                           "payload": str(payload).replace("torch.", "")}
+                if (ms_with - ms_plain) / ms_with > 0.03:
+                    exposed["exchange_advice"] = ("exposed exchange > 3 % of the step: try HN_DDP_GRAPH_OVERLAP=1 (forked side stream) and "
+                                                  "--grad-payload bf16 (half the bytes per link)")
+            del run_plain
+        except Exception as e:          # noqa: BLE001  (the headline stands without it)
+            exposed = {"error": repr(e)[:300]}
     grad_norm = None
     if os.environ.get("HN_BENCH_GRAD_NORM"):        # tests: the gradients after the (possibly in-graph) exchange of the last step
         grad_norm = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in net.parameters() if p.grad is not None)))
@@ -955,6 +983,7 @@ def main():
                        "resolution": "3x%dx%d" % (h, w), "parallelism": "dp%d" % world, "hipgraph": run.graph is not None,
                        "grad_allreduce": run.describe_exchange()},
             **({"dist_ranks": dist.get_world_size(), "dist_backend": backend, "per_rank_ms_per_step": per_rank_ms} if exchange else {}),
+            **({"exchange_exposed": exposed} if exposed is not None else {}),
             "ms_optimizer_step": round(ms_opt, 3) if ms_opt is not None else None, "loss": round(loss_val, 4),
             **({"grad_norm": grad_norm} if grad_norm is not None else {}),
             "model_tflops": round(value * gflop_img / 1e3, 2),

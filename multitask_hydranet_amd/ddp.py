@@ -362,7 +362,9 @@ def settle_collectives(device=None):
     if torch.cuda.is_available():
         torch.cuda.synchronize(device)
     if dist.is_initialized():
-        time.sleep(0.35)                                    # > 3 watchdog rounds
+        # > 3 watchdog rounds by default; HN_SETTLE_SECONDS lengthens it on a loaded host (the work objects themselves were waited for by
+        # GradReducer.finish(); this wait only covers the watchdog's own bookkeeping, which offers no handle)
+        time.sleep(max(0.35, float(os.environ.get("HN_SETTLE_SECONDS", "0.35"))))
 
 
 def capture_exchange_step(reducer: "GradReducer", fwd_bwd: Callable[[], torch.Tensor], zero_grad: Callable[[], None], stream,
