@@ -189,10 +189,14 @@ class HydraTrainer:
             batch_data["gt_det"] = batch_data["gt_det"].to(self.device).float()
         return batch_data
 
+    @staticmethod
+    def _batch_sig(batch_data: dict):
+        return tuple((k, tuple(v.shape), v.dtype) for k, v in batch_data.items() if isinstance(v, torch.Tensor) and v.is_cuda)
+
     def _captured_fwd_bwd(self, batch_data: dict) -> Dict[str, torch.Tensor]:
         """forward + loss + backward (+ the gradient exchange) as one hipGraph replay (built on first use for this batch shape)"""
         keys = [k for k, v in batch_data.items() if isinstance(v, torch.Tensor) and v.is_cuda]
-        sig = tuple((k, tuple(batch_data[k].shape), batch_data[k].dtype) for k in keys)
+        sig = self._batch_sig(batch_data)
         if self._cap is None or self._cap[0] != sig:
             static = {k: batch_data[k].clone() for k in keys}
             net = self.hydranet
@@ -251,6 +255,12 @@ class HydraTrainer:
 
     def _train_step(self, batch_data: dict) -> Dict[str, torch.Tensor]:
         batch_data = self.to_gpu(batch_data)
+        if self.capture_step and self._eager_iters >= 2 and self._cap is not None and self._cap[0] != self._batch_sig(batch_data):
+            # A different batch shape than the captured one (the loaders' short last batch: drop_last=False, model/train.py:71,81).  The step is
+            # NOT captured again on the spot (with the exchange in the graph that would be a second capture of RCCL collectives with no
+            # warm-up at the new shape): this iteration and the next run on the eager path (hooks armed), the one after that
+            # captures at the shape it sees.
+            self._eager_iters = 0
         if self.capture_step and self._eager_iters >= 2:
             loss_dict = self._captured_fwd_bwd(batch_data)
             self.optimizer.step()

@@ -247,6 +247,48 @@ def test_trainer_captured_data_parallel_step_rccl_world1(setup):
         assert torch.equal(b0[n], b1[n]), n
 
 
+def test_trainer_short_last_batch_and_phase_switch_under_captured_data_parallel_step(setup):
+    """with the exchange captured in the step's hipGraph, a batch of another shape (the loaders' short last batch) must not
+    trigger a second capture on the spot.  It and the next iteration run on the eager hook path, the step is captured again after that --
+    and a fine-tuning phase switch does the same.  The whole sequence equals the plain eager trainer bit for bit (one rank: the average
+    is the identity)."""
+    from multitask_hydranet_amd.train import HydraTrainer
+    z, cfgs, batch = setup
+    g = torch.Generator().manual_seed(9)
+    n = batch["image"].shape[0]
+    assert n >= 2
+    loader = []
+    for i in range(9):
+        b = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+        b["image"] = batch["image"] + 0.05 * torch.randn(batch["image"].shape, generator=g)
+        if i == 4:                                            # the short batch
+            b = {k: (v[:n - 1].clone() if isinstance(v, torch.Tensor) and v.shape[:1] == (n,) else v) for k, v in b.items()}
+        loader.append(b)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(_free_port()))
+    runs = []
+    for ddp in (False, True):
+        tr = HydraTrainer(cfgs, trainloader=loader, validloader=None, iters_per_epoch=len(loader), capture_step=ddp, force_distribute=ddp)
+        tr.hydranet.load_state_dict(tiny_state(z))
+        tr.hydranet.lane_points_per_line = int(z["meta/lane_points_per_line"])
+        losses, captured = [], []
+        for i, b in enumerate(loader):
+            if i == 7:
+                tr.set_phase("seg")                           # head-only phase: its own reducer and its own captured step
+            ld = tr.train_step({k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in b.items()})
+            losses.append({k: float(v.detach()) for k, v in ld.items()})
+            captured.append(tr._cap is not None)
+        torch.cuda.synchronize()
+        if ddp:
+            # iterations 0, 1 eager; 2, 3 replayed; 4 (short) and 5 eager; 6 replayed; 7, 8 eager (new phase)
+            assert captured == [False, False, True, True, False, False, True, False, False], captured
+        runs.append((losses, {k: p.detach().clone() for k, p in tr.hydranet.named_parameters()}))
+    (l0, p0), (l1, p1) = runs
+    assert l0 == l1, (l0, l1)
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), k
+
+
 def test_eval_after_training_steps_sees_the_updated_weights(setup):
     """hn_adam_step and the training-mode BatchNorm kernels write parameters / running statistics through raw pointers, which
     torch's version counters do not see.  The eval-mode caches (PackPlan.fresh, the det towers' per-level coefficient rows) must still
