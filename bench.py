@@ -160,66 +160,83 @@ def dominant_launch_roofline(net, n, h, w, iters=100, graph_timing=False):
             "frac_executed": round(executed / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), "algorithmic_bytes_per_launch": alg_bytes}
 
 
-def time_dominant_gemm_family(net, n, h, w, iters=50):
-    """The family that takes the most TIME in the step (profiles/r04_roofline_table.md: gemm_nt_kernel<64,64,...>, the 1x1 convs of backbone
-    stages 3-4 and their data gradients: ~176 launches, ~2.6 ms per step) priced against the HBM roofline: three representative launches
-    of the big cfg -- stage-3 and stage-4 conv_block_1 / 3 (M = N*H*W/256 x 376 -> 376 and N*H*W/1024 x 936 -> 936, with the BatchNorm
-    statistics epilogue they carry in the step) -- replayed back to back from one hipGraph (as inside the step) and timed with HIP events on
-    the launch stream.  Algorithmic bytes per launch = rows * (Cin + Cout) * 2 (bf16 in, bf16 out) + Cout * Cin * 2 (weights): SURVEY 8(d)'s
-    conv-operand figure for that conv."""
+def time_dominant_gemm_family(net, n, h, w, iters=20):
+    """The launches that take the most TIME in the step since round 6: the persistent stage launches (csrc/hn_xstage.hip: the stride-1
+    identity XBlocks of backbone stages 3 and 4, forward and backward, one launch each; profiles/r06_roofline_table.md: 2.49 ms of the
+    step, the next family is the 64 x 64 1x1 GEMM at 1.07 ms).  Each launch is built on the net's own blocks (random input of the stage's
+    shape), captured alone in a hipGraph and timed with HIP events on the launch stream.  Algorithmic bytes per launch = SURVEY 8(d)'s conv
+    operand figure of the convs it contains: forward, per block, (X + Y) of the two 1x1 convs and of the grouped 3x3 conv = 6 M C 2 bytes
+    + the packed weights once; backward (data gradients only -- the weight gradients stay separate launches) the same 6 M C 2 + weights."""
     from multitask_hydranet_amd import ops as K
     dev = net._idx["backbone.net.stem.conv.weight"].device
-    shapes = []
-    for k in (3, 4):
-        if k < len(net.widths):
-            c = net.widths[k]
-            shapes.append((n * (h >> (k + 2)) * (w >> (k + 2)), c, "stage_%d conv_block_1/3 (%d -> %d)" % (k, c, c)))
     per, tot_t, tot_b = [], 0.0, 0.0
-    for m, c, what in shapes:
-        x = torch.randn(1, 1, m, c, device=dev).to(torch.bfloat16)
-        wgt = torch.randn(c, c, 1, 1, device=dev) * c ** -0.5
-        wp, _ = K.pack_conv_weight(wgt)
-        out = torch.empty(1, 1, m, c, device=dev, dtype=torch.bfloat16)
-        run = lambda: K.k_gemm_nt(x, None, 0, (1, 1, m), wp, c, K.kp32(c), 1, out=out, stats=True)
-        for _ in range(3):
-            run()
-        s_ = torch.cuda.Stream()
-        s_.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s_):
-            run()
-        torch.cuda.current_stream().wait_stream(s_)
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            for _ in range(iters):
-                run()
-        g.replay()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        g.replay()
-        e1.record()
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) / iters * 1e3
-        byts = 2.0 * m * (c + c) + 2.0 * c * c
-        per.append({"launch": what, "rows": m, "launch_us": round(us, 2), "algorithmic_bytes": byts, "GBps": round(byts / us / 1e3, 1),
-                    "frac": round(byts / us / 1e3 / PEAK_HBM_GBS, 4), "TFLOPs": round(2.0 * m * c * c / us / 1e6, 1)})
-        tot_t += us
-        tot_b += byts
-        del g
+    p = "backbone.net."
+    for k in (3, 4):
+        if k >= len(net.widths):
+            continue
+        c, d = net.widths[k], net.depths[k]
+        hh, ww = h >> (k + 2), w >> (k + 2)
+        x = torch.randn(n, hh, ww, c, device=dev).to(torch.bfloat16).relu_()
+        q0 = "%sstage_%d.blocks.block_1." % (p, k)
+        if d < 2 or not K.xstage_ok(x, net._idx[q0 + "conv_block_1.0.weight"], net._idx[q0 + "se.1.weight"].shape[0]):
+            continue
+        params = []
+        for j in range(1, d):
+            params += [t.detach().clone() if i % 19 in (3, 4, 8, 9, 17, 18) else t.detach()
+                       for i, t in enumerate(net._xblock_params("%sstage_%d.blocks.block_%d." % (p, k, j)))]
+        nb = d - 1
+        sws = [(params[b * 19 + 10], params[b * 19 + 12]) for b in range(nb)]
+        dout = (torch.randn(n, hh, ww, c, device=dev) * 0.01).to(torch.bfloat16)
+        with torch.no_grad():
+            r = K.xstage_forward_raw(x, params, 1e-5, 0.1)
+        m = n * hh * ww
+        byts = nb * (6.0 * m * c * 2 + (2 * c * K.kp32(c) + c * 576) * 2.0)
+        for what, fn in (("forward", lambda: K.xstage_forward_raw(x, params, 1e-5, 0.1)),
+                         ("backward", lambda: K.xstage_backward_raw(dout, r, r["packs"], sws))):
+            with torch.no_grad():
+                for _ in range(2):
+                    fn()
+                s_ = torch.cuda.Stream()
+                s_.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s_):
+                    fn()
+                torch.cuda.current_stream().wait_stream(s_)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    fn()
+                g.replay()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(iters):
+                    g.replay()
+                e1.record()
+                torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) / iters * 1e3
+            per.append({"launch": "stage_%d %s, %d identity blocks (%d ch, %d x %d maps)" % (k, what, nb, c, hh, ww), "rows": m, "launch_us": round(us, 1),
+                        "us_per_block": round(us / nb, 2), "algorithmic_bytes": byts, "GBps": round(byts / us / 1e3, 1),
+                        "frac": round(byts / us / 1e3 / PEAK_HBM_GBS, 4), "TFLOPs": round(nb * 2.0 * m * (2 * c * c + 72 * c) / us / 1e6, 1)})
+            tot_t += us
+            tot_b += byts
+            del g
+        K.xstage_assert_ok(dev)
+    if not per:
+        return {"error": "no persistent stage launch at this shape"}
     ach = tot_b / tot_t / 1e3
     return {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
-            "kernel": "gemm_nt_kernel<64,64,...> (PLAIN rows): 1x1 convs of backbone stages 3-4 with the BatchNorm statistics epilogue, N=%d" % n,
+            "kernel": "xstage_fwd_kernel / xstage_bwd_kernel (persistent stage launches), N=%d" % n,
             "launches": per,
-            "note": "largest family by TIME in the step; these tensors (3.8-6.2 MB) live in L2 / Infinity Cache between launches: the launch is "
-                    "bound by per-step DMA latency and the L2 -> LDS rate of 64 x 64 tiles, not by HBM (DESIGN.md section 3)"}
+            "note": "largest launches by TIME in the step.  Not bandwidth bound in the roofline sense: a block is two GEMM phases at the L2 -> LDS "
+                    "feed rate plus six inter-workgroup exchanges (DESIGN.md section 4); the launch chain they replace took 1.4-1.8x as long "
+                    "(profiles/r06_stage_persistent.md)"}
 
 
 def measured_traffic(n, h, w, form):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 correction +
     WRITE_SIZE, separate passes: PMC counters cannot be read from inside this process).  The figure belongs to ONE workload: it is only
     emitted when batch, resolution and kernel form match what the profile recorded; otherwise null."""
-    for name in ("r05_dominant_pmc.json", "r04_dominant_pmc.json", "r03_dominant_pmc.json", "r02_dominant_pmc.json"):
+    for name in ("r06_dominant_pmc.json", "r05_dominant_pmc.json", "r04_dominant_pmc.json", "r03_dominant_pmc.json", "r02_dominant_pmc.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             with open(path) as f:
