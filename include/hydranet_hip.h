@@ -229,6 +229,12 @@ int hn_maxpool_bwd_from_arg(const void* arg, const void* dout, int ldd, void* dx
 long hn_fold_ring_rows(int H, int W);
 int hn_conv3x3_dgrad_fold(const void* dz, int ldz, int Cz, int n_img, int H, int W, const void* wt, int Nout, int KP, int phase_k, int clamp,
                           void* out, int ldo, const void* yprev, int ldy, void* ring, hipStream_t stream);
+/* The same gradient (also) in SPACE-TO-DEPTH order: out_s2d [N][H/2][W/2][4 Nout] (row stride ld_s2d >= 4 Nout; H, W even), pixel (y, x)
+ * channel c at row (y/2, x/2), channel ((y&1) 2 + (x&1)) Nout + c -- the form in which the phase-form block that produced this conv's input
+ * consumes its gradient (that block's hn_space_to_depth_bf16 pass is not needed; head_seg/segmentation.py:92-104).  out = NULL: only that
+ * form (a block without a skip operand reads nothing else); otherwise both.  yprev stays [N][H][W] (row stride ldy). */
+int hn_conv3x3_dgrad_fold_s2d(const void* dz, int ldz, int Cz, int n_img, int H, int W, const void* wt, int Nout, int KP, int phase_k, int clamp,
+                              void* out, int ldo, void* out_s2d, int ld_s2d, const void* yprev, int ldy, void* ring, hipStream_t stream);
 /* Backward of ReflectionPad2d(1) (+ nearest x2, + channel split of the concat) for the seg decoder (head_seg/segmentation.py:40,92-99). */
 int hn_seg_fold(const void* dvp, int ldv, int c0, void* out, int ldo, const void* yprev, int ldy, int N, int H, int W, int C, int up,
                 hipStream_t stream);

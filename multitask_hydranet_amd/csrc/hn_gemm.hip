@@ -170,7 +170,11 @@ struct GemmNT {
     // the padded grid straight to the unpadded gradient out [N][H][W] (row stride ldc), multiplied by ELU'(fold_y) when the producer's
     // ELU output is given, and the one-pixel RING to ring [N][2 (W+2) + 2 H][Nout] (top row, bottom row, left column, right column);
     // seg_ring_fix_kernel then adds the ring to the border pixels it reflects / clamps onto.  No padded tensor, no full fold pass.
+    // fold = 2: the same values in SPACE-TO-DEPTH order, out [N][H/2][W/2][4 Nout] (pixel (y, x), channel c at row (y/2, x/2), channel
+    // ((y&1) 2 + (x&1)) Nout + c; row stride ldc): the operand form of the phase-form block that consumes this gradient
+    // fold = 3: both -- out plain, fold_out2 (row stride ld_fo2) in space-to-depth order
     int fold;
+    bf16* fold_out2; int ld_fo2;
     bf16* ring;
     const bf16* fold_y; int ld_fy;
     // Statistics epilogue operand (psum / psq rows): what is summed per channel over the tile's pixels, q = the bf16-rounded output
@@ -1504,7 +1508,9 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
                 if (oy < xs.H && oxx < xs.W && c < p.Nout) {
                     if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
                         const long pix = (long)(n * H + iy) * W + ix;
-                        dst[i] = pix * p.ldc + c;
+                        const long cell = (long)(n * (H >> 1) + (iy >> 1)) * (W >> 1) + (ix >> 1);
+                        const int pch = ((iy & 1) * 2 + (ix & 1)) * p.Nout + c;
+                        dst[i] = p.fold == 2 ? cell * p.ldc + pch : pix * p.ldc + c;
                         if (p.fold_y) yv[i] = ld8(p.fold_y + pix * p.ld_fy + c);
                     } else {
                         const int r = oy == 0 ? oxx : (oy == H + 1 ? xs.W + oxx : (oxx == 0 ? 2 * xs.W + iy : 2 * xs.W + H + iy));
@@ -1523,6 +1529,11 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
                         for (int k = 0; k < 8; ++k) { const float yy = bf2f(yv[i][k]), f = bf2f(v[k]); v[k] = f2bf(yy > 0.f ? f : f * (yy + 1.0f)); }
                     }
                     *reinterpret_cast<bf16x8*>(outp + dst[i]) = v;
+                    if (p.fold == 3) {                                 // (offset recomputed: eight more 64-bit registers would spill)
+                        const int iy = oy0 + (pl >> 4) - 1, ix = ox0 + (pl & 15) - 1;
+                        const long cell = (long)(n * (H >> 1) + (iy >> 1)) * (W >> 1) + (ix >> 1);
+                        *reinterpret_cast<bf16x8*>(p.fold_out2 + cell * p.ld_fo2 + ((iy & 1) * 2 + (ix & 1)) * p.Nout + c) = v;
+                    }
                 } else {
                     *reinterpret_cast<bf16x8*>(p.ring - dst[i] - 1) = v;
                 }
@@ -2989,8 +3000,8 @@ extern "C" int hn_nt_stat_tile(long M, int Nout) { return small_tile(M, Nout) ? 
 
 struct NextStat { int mode; const bf16* z; int ldz; const float* coef; const bf16* y; int ldy; };
 static thread_local NextStat g_next_stat = {0, nullptr, 0, nullptr, nullptr, 0};   // set by hn_conv_gemm_nt_stat for the launch it makes
-struct NextFold { bf16* ring; const bf16* y; int ldy; };
-static thread_local NextFold g_next_fold = {nullptr, nullptr, 0};   // set by hn_conv3x3_dgrad_fold for the launch it makes
+struct NextFold { bf16* ring; const bf16* y; int ldy; int form; bf16* out2; int ld2; };   // form: GemmNT::fold (1 plain, 2 space-to-depth, 3 both)
+static thread_local NextFold g_next_fold = {nullptr, nullptr, 0, 0, nullptr, 0};   // set by hn_conv3x3_dgrad_fold for the launch it makes
 static thread_local long* g_next_amax = nullptr;    // set by hn_conv3x3_out_argmax for the launch it makes (same thread, same call)
 struct NextImgW { long stride; long rpi; };
 static thread_local NextImgW g_next_imgw = {0, 0};  // set by hn_conv_gemm_nt_imgw for the launch it makes
@@ -3221,7 +3232,7 @@ static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img
     p.wpre = 0;
     p.dbg = (int)g_hn_knob[14];
     p.dbg_buf = reinterpret_cast<unsigned long long*>(g_hn_knob[15]);          // (read by the kernels with -DHN_TUNING only)
-    p.fold = g_next_fold.ring ? 1 : 0; p.ring = g_next_fold.ring; p.fold_y = g_next_fold.y; p.ld_fy = g_next_fold.ldy;
+    p.fold = g_next_fold.ring ? g_next_fold.form : 0; p.fold_out2 = g_next_fold.out2; p.ld_fo2 = g_next_fold.ld2; p.ring = g_next_fold.ring; p.fold_y = g_next_fold.y; p.ld_fy = g_next_fold.ldy;
     if (img_stride < 0) {                                            // mode 4: -img_stride = channels per depth-to-space output pixel
         HN_CHECK_ARG(p.x.clamp == 1 && (out_f32 || phase_mode == 1) && rpi == 0 && !psum && Nout == 4 * (int)(-img_stride));
         p.d2s = (int)(-img_stride);
@@ -3323,7 +3334,7 @@ static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img
 //   reflect: rows 1 and H-2 take padded rows 0 and H+1 (columns alike);  clamp: rows 0 and H-1.
 // Thread = 8 channels of one border target pixel (2 W + 2 (H - 2) per image); out += ring sum * ELU'(y).
 __global__ __launch_bounds__(256) void seg_ring_fix_kernel(bf16* out, int ldo, const bf16* ring, const bf16* y, int ldy, int N, int H, int W,
-                                                           int C, int clamp) {
+                                                           int C, int clamp, int s2d, bf16* out2, int ld2) {
     const int C8 = C >> 3, T = 2 * W + 2 * (H - 2), R = 2 * (W + 2) + 2 * H;
     const long total = (long)N * T * C8;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -3363,7 +3374,9 @@ __global__ __launch_bounds__(256) void seg_ring_fix_kernel(bf16* out, int ldo, c
             for (int k = 0; k < 8; ++k) acc[k] += bf2f(v[k]);
         }
     const long pix = (long)(n * H + yy) * W + xx;
-    bf16* o = out + pix * ldo + cg * 8;
+    const long s2d_cell = (long)(n * (H >> 1) + (yy >> 1)) * (W >> 1) + (xx >> 1);
+    const int s2d_ch = ((yy & 1) * 2 + (xx & 1)) * C + cg * 8;
+    bf16* o = s2d ? out + s2d_cell * ldo + s2d_ch : out + pix * ldo + cg * 8;                  // (GemmNT::fold = 2)
     bf16x8 cur = ld8(o);
     if (y) {
         const bf16x8 yv = ld8(y + pix * ldy + cg * 8);
@@ -3373,6 +3386,7 @@ __global__ __launch_bounds__(256) void seg_ring_fix_kernel(bf16* out, int ldo, c
 #pragma unroll
     for (int k = 0; k < 8; ++k) cur[k] = f2bf(bf2f(cur[k]) + acc[k]);
     st8(o, cur);
+    if (out2) st8(out2 + s2d_cell * ld2 + s2d_ch, cur);                                        // (GemmNT::fold = 3: the same value in both orders)
 }
 
 extern "C" long hn_fold_ring_rows(int H, int W) { return 2L * (W + 2) + 2L * H; }
@@ -3383,21 +3397,40 @@ extern "C" long hn_fold_ring_rows(int H, int W) { return 2L * (W + 2) + 2L * H; 
  * folding epilogue + a border fix-up over 2 (H + W) pixels per image).  phase_k = 0: dz [N][H][W][Cz], wt [Nout][9][KP];  phase_k > 0:
  * dz = space-to-depth gradient [N][H][W][4 k] of a phase-form conv, wt = its transposed effective weights (4 taps per phase).
  * ring: scratch [N][hn_fold_ring_rows(H, W)][Nout] bf16.  Needs Nout % 8 == 0, Nout > 32, H, W >= 4 (else HN_ERR_UNSUPPORTED). */
-extern "C" int hn_conv3x3_dgrad_fold(const void* dz, int ldz, int Cz, int n_img, int H, int W, const void* wt, int Nout, int KP, int phase_k,
-                                     int clamp, void* out, int ldo, const void* yprev, int ldy, void* ring, hipStream_t st) {
-    HN_CHECK_ARG(dz && wt && out && ring && n_img > 0 && (ldo & 7) == 0 && (!yprev || (ldy & 7) == 0) && (clamp == 0 || clamp == 1));
+static int dgrad_fold_impl(const void* dz, int ldz, int Cz, int n_img, int H, int W, const void* wt, int Nout, int KP, int phase_k,
+                           int clamp, void* out, int ldo, void* out_s2d, int ld_s2d, const void* yprev, int ldy, void* ring, hipStream_t st) {
+    HN_CHECK_ARG(dz && wt && (out || out_s2d) && ring && n_img > 0 && (ldo & 7) == 0 && (!yprev || (ldy & 7) == 0) && (clamp == 0 || clamp == 1));
     HN_CHECK_ARG(phase_k == 0 || (Cz == 4 * phase_k && phase_k % 64 == 0));
+    HN_CHECK_ARG(!out_s2d || (!(H & 1) && !(W & 1) && ld_s2d >= 4 * Nout && (ld_s2d & 7) == 0 && (reinterpret_cast<uintptr_t>(out_s2d) & 15) == 0));
     if ((Nout & 7) || Nout <= 32 || H < 4 || W < 4 || (reinterpret_cast<uintptr_t>(out) & 15)) return HN_ERR_UNSUPPORTED;
-    g_next_fold = {(bf16*)ring, (const bf16*)yprev, ldy};
+    const int form = !out_s2d ? 1 : (out ? 3 : 2);
+    void* o1 = out ? out : out_s2d;                                  // the tensor the conv epilogue / fix-up address first
+    const int l1 = out ? ldo : ld_s2d;
+    g_next_fold = {(bf16*)ring, (const bf16*)yprev, ldy, form, form == 3 ? (bf16*)out_s2d : nullptr, ld_s2d};
     const int rc = conv_gemm_nt_impl(dz, nullptr, 3, n_img, H + 2, W + 2, Cz, 0, ldz, 0, 0, (long)n_img * (H + 2) * (W + 2), wt, Nout, KP, 9,
-                                     nullptr, HN_ACT_NONE, out, 0, ldo, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, 0,
+                                     nullptr, HN_ACT_NONE, o1, 0, l1, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, 0,
                                      phase_k ? 2 : 0, phase_k, st);
-    g_next_fold = {nullptr, nullptr, 0};
+    g_next_fold = {nullptr, nullptr, 0, 0, nullptr, 0};
     if (rc != HN_OK) return rc;
     const long total = (long)n_img * (2 * W + 2 * (H - 2)) * (Nout >> 3);
-    hipLaunchKernelGGL(seg_ring_fix_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, (bf16*)out, ldo, (const bf16*)ring, (const bf16*)yprev, ldy,
-                       n_img, H, W, Nout, clamp);
+    hipLaunchKernelGGL(seg_ring_fix_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, (bf16*)o1, l1, (const bf16*)ring, (const bf16*)yprev, ldy,
+                       n_img, H, W, Nout, clamp, form == 2 ? 1 : 0, form == 3 ? (bf16*)out_s2d : nullptr, ld_s2d);
     HN_LAUNCH_CHECK();
+}
+extern "C" int hn_conv3x3_dgrad_fold(const void* dz, int ldz, int Cz, int n_img, int H, int W, const void* wt, int Nout, int KP, int phase_k,
+                                     int clamp, void* out, int ldo, const void* yprev, int ldy, void* ring, hipStream_t st) {
+    HN_CHECK_ARG(out);
+    return dgrad_fold_impl(dz, ldz, Cz, n_img, H, W, wt, Nout, KP, phase_k, clamp, out, ldo, nullptr, 0, yprev, ldy, ring, st);
+}
+/* The same gradient (also) written in SPACE-TO-DEPTH order: out_s2d [N][H/2][W/2][4 Nout] (row stride ld_s2d >= 4 Nout), value of pixel
+ * (y, x), channel c at row (y/2, x/2), channel ((y&1) 2 + (x&1)) Nout + c -- the operand form in which the phase-form block that produced
+ * this conv's input consumes its gradient (hn_conv_gemm_tn_phase / hn_conv3x3_phase mode 3): its hn_space_to_depth_bf16 pass (one read and
+ * one write of the whole gradient) is not needed.  out = NULL: only that form.  H and W even; yprev stays [N][H][W] (row stride ldy). */
+extern "C" int hn_conv3x3_dgrad_fold_s2d(const void* dz, int ldz, int Cz, int n_img, int H, int W, const void* wt, int Nout, int KP, int phase_k,
+                                         int clamp, void* out, int ldo, void* out_s2d, int ld_s2d, const void* yprev, int ldy, void* ring,
+                                         hipStream_t st) {
+    HN_CHECK_ARG(out_s2d);
+    return dgrad_fold_impl(dz, ldz, Cz, n_img, H, W, wt, Nout, KP, phase_k, clamp, out, ldo, out_s2d, ld_s2d, yprev, ldy, ring, st);
 }
 
 template <int BC, int BN, int WGC, int WGN>

@@ -596,13 +596,20 @@ class HydraNet(nn.Module):
         p = "segheader.decoder."
         # chain flags: (x0 is the previous block's ELU output, the next block folds this block's ELU' into its data gradient)
         fuse = self.seg_fuse_elu_bwd
+        s2d = False
+        slot = None      # GradSlot between a phase-form block and the block behind it (the gradient a second time in operand order)
         for i in range(n):
             x = K.SegConv.apply(x, None, P[f"{p}{2 * i}.conv.conv.weight"], P[f"{p}{2 * i}.conv.conv.bias"], 0, ACT_ELU, False,
-                                fuse and i > 0, fuse)
+                                fuse and i > 0, fuse, slot)
+            slot = None
             skip = feats_seg[n - 2 - i] if i < n - 1 else None
             wgt = P[f"{p}{2 * i + 1}.conv.conv.weight"]
             if K.seg_up_phase_ok(x, skip, wgt):        # conv over the up-sampled map in phase form on the low-resolution grid
-                x = K.SegConvUp.apply(x, skip, wgt, P[f"{p}{2 * i + 1}.conv.conv.bias"], fuse, fuse)
+                # last block in front of the phase-form output conv: that conv's data gradient arrives in this block's operand order
+                s2d = bool(fuse and i == n - 1 and self.seg_phase_output and self.training and x.requires_grad
+                           and not want_mask and K.seg_s2d_handover_ok(x, skip, wgt))
+                slot = K.GradSlot() if (fuse and not s2d and self.training and x.requires_grad) else None
+                x = K.SegConvUp.apply(x, skip, wgt, P[f"{p}{2 * i + 1}.conv.conv.bias"], fuse, fuse, s2d, slot)
             else:
                 x = K.SegConv.apply(x, skip, wgt, P[f"{p}{2 * i + 1}.conv.conv.bias"], 1, ACT_ELU, False, fuse, fuse)
         last = 2 * n
@@ -611,7 +618,7 @@ class HydraNet(nn.Module):
         if self.seg_phase_output:          # final 3x3 over the up-sampled map as a 4-phase conv on the low-resolution grid (ops.SegOutUp)
             # the loss may hand its gradient over in this node's operand form (no fp32 dlogits tensor): see _seg_loss
             slot = K.GradSlot() if (x.requires_grad and self.training) else None
-            y = K.SegOutUp.apply(x, P[f"{p}{last}.conv.weight"], P[f"{p}{last}.conv.bias"], fuse, slot)
+            y = K.SegOutUp.apply(x, P[f"{p}{last}.conv.weight"], P[f"{p}{last}.conv.bias"], fuse, slot, s2d)
             out = y.permute(0, 3, 1, 2)
             # identified by the returned tensor OBJECT (weak reference): an address + shape match can be a recycled allocation
             self._seg_grad_slot = (slot, weakref.ref(out)) if slot is not None else None

@@ -29,14 +29,34 @@ def dgrad_fold_ok(nout, h, w, n=None):
     return SEG_FOLD_DIRECT and nout % 8 == 0 and nout > 32 and h >= 4 and w >= 4 and (n is None or n * h * w * nout >= SEG_FOLD_MIN_ELEMS)
 
 
-def k_dgrad_fold(dz, wt, n, h, w, nout, kp, phase_k, clamp, yprev):
-    """dx [N,h,w,nout] = folded data gradient (* ELU'(yprev)): conv with a folding epilogue + border fix-up, no padded-grid tensor"""
+def k_dgrad_fold(dz, wt, n, h, w, nout, kp, phase_k, clamp, yprev, s2d=0):
+    """dx [N,h,w,nout] = folded data gradient (* ELU'(yprev)): conv with a folding epilogue + border fix-up, no padded-grid tensor.
+    s2d = 1: the same values in space-to-depth order instead, [N,h/2,w/2,4*nout] (the operand form of the phase-form block that consumes
+    them); s2d = 2: both -> (dx, dx_s2d)"""
     dev = dz.device
-    dx = new_act(n, h, w, nout, dev)
+    dx = new_act(n, h, w, nout, dev) if s2d != 1 else None
+    dxs = new_act(n, h // 2, w // 2, 4 * nout, dev) if s2d else None
     ring = torch.empty((n, lib().query("hn_fold_ring_rows", h, w), nout), device=dev, dtype=BF16)
-    lib().call("hn_conv3x3_dgrad_fold", ptr(dz), ld(dz), dz.shape[3], n, h, w, ptr(wt), nout, kp, phase_k, clamp, ptr(dx), ld(dx),
-               ptr(yprev), ld(yprev) if yprev is not None else 0, ptr(ring))
-    return dx
+    yargs = (ptr(yprev), ld(yprev) if yprev is not None else 0, ptr(ring))
+    if s2d:
+        lib().call("hn_conv3x3_dgrad_fold_s2d", ptr(dz), ld(dz), dz.shape[3], n, h, w, ptr(wt), nout, kp, phase_k, clamp, ptr(dx),
+                   ld(dx) if dx is not None else 0, ptr(dxs), ld(dxs), *yargs)
+    else:
+        lib().call("hn_conv3x3_dgrad_fold", ptr(dz), ld(dz), dz.shape[3], n, h, w, ptr(wt), nout, kp, phase_k, clamp, ptr(dx), ld(dx), *yargs)
+    return dxs if s2d == 1 else ((dx, dxs) if s2d == 2 else dx)
+
+
+def seg_s2d_handover_ok(x0, skip, weight, n_out_classes=None):
+    """May the block behind a SegConvUp hand the gradient over in space-to-depth order (SegOutUp(dx_s2d=True) -> SegConvUp(dy_is_s2d=True))?
+    x0 / skip / weight: the SegConvUp's operands.  Its backward must need nothing but the space-to-depth form (no skip operand, phase-form
+    data gradient) and the producer must take the folding epilogue at the up-sampled shape."""
+    n, h, w, c0 = x0.shape
+    k = weight.shape[0]
+    if skip is not None or weight.shape[1] != c0 or SEG_DGRAD_PHASE is False:
+        return False
+    tiles = n * ((h + 2 + 15) // 16) * ((w + 2 + 15) // 16) * ((c0 + 127) // 128)
+    phase = (tiles >= SEG_DGRAD_PHASE_MIN_TILES) if SEG_DGRAD_PHASE is None else SEG_DGRAD_PHASE
+    return bool(SEG_S2D_HANDOVER and phase and dgrad_fold_ok(k, 2 * h, 2 * w, n))
 
 
 class SegConv(torch.autograd.Function):
@@ -46,7 +66,10 @@ class SegConv(torch.autograd.Function):
     block."""
 
     @staticmethod
-    def forward(ctx, x0, x1, weight, bias, up, act, out_f32, x0_is_elu=False, dy_is_dz=False):
+    def forward(ctx, x0, x1, weight, bias, up, act, out_f32, x0_is_elu=False, dy_is_dz=False, dx_s2d_slot=None):
+        """dx_s2d_slot (GradSlot shared with the SegConvUp that produced x0): where the backward leaves the gradient w.r.t. x0 a second time,
+        in that block's space-to-depth operand order, when its folding epilogue runs (the block then skips its hn_space_to_depth_bf16 pass)"""
+        ctx.dx_s2d_slot = dx_s2d_slot
         n, h0, w0, c0 = x0.shape
         h, w = (h0 * 2, w0 * 2) if up else (h0, w0)
         cout, cin = weight.shape[0], weight.shape[1]
@@ -89,8 +112,11 @@ class SegConv(torch.autograd.Function):
         dx0 = dx1 = None
         if not up and not ctx.has_x1 and dgrad_fold_ok(c0, h, w, n):
             if ctx.needs_input_grad[0]:
-                dx0 = k_dgrad_fold(dz, ctx.wt, n, h, w, c0, kp32(cout), 0, 0, x0 if ctx.x0_is_elu else None)
-            return dx0, dx1, dw, dbias, None, None, None, None, None
+                both = ctx.dx_s2d_slot is not None and SEG_S2D_HANDOVER and ctx.x0_is_elu and not (h & 1) and not (w & 1)
+                dx0 = k_dgrad_fold(dz, ctx.wt, n, h, w, c0, kp32(cout), 0, 0, x0 if ctx.x0_is_elu else None, s2d=2 if both else 0)
+                if both:
+                    dx0, ctx.dx_s2d_slot.buf = dx0
+            return dx0, dx1, dw, dbias, None, None, None, None, None, None
         dvp, _, _ = k_gemm_nt(dz, None, 3, (n, h + 2, w + 2), ctx.wt, cin, kp32(cout), 9, c0=dz.shape[3], c1=0)
         if ctx.needs_input_grad[0]:
             dx0 = new_act(n, h0, w0, c0, dev)
@@ -99,7 +125,7 @@ class SegConv(torch.autograd.Function):
         if ctx.has_x1 and ctx.needs_input_grad[1]:
             dx1 = new_act(n, h, w, c1, dev)
             lib().call("hn_seg_fold", ptr(dvp), ld(dvp), c0, ptr(dx1), ld(dx1), None, 0, n, h, w, c1, 0)
-        return dx0, dx1, dw, dbias, None, None, None, None, None
+        return dx0, dx1, dw, dbias, None, None, None, None, None, None
 
 
 
@@ -131,8 +157,11 @@ class SegOutUp(torch.autograd.Function):
     """logits[N, 2h, 2w, k] (fp32) = Conv3x3(ReflectionPad2d(1)(nearest_up2(x))) + bias, x [N, h, w, c] bf16."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, x_is_elu=False, slot=None):
-        """slot: GradSlot through which the loss may deliver the gradient already in this node's space-to-depth bf16 operand form"""
+    def forward(ctx, x, weight, bias, x_is_elu=False, slot=None, dx_s2d=False):
+        """slot: GradSlot through which the loss may deliver the gradient already in this node's space-to-depth bf16 operand form.
+        dx_s2d (only with seg_s2d_handover_ok for the producer of x): the gradient w.r.t. x is returned in space-to-depth memory order under
+        x's shape; the producer is a SegConvUp(dy_is_s2d=True)"""
+        ctx.dx_s2d = dx_s2d
         n, h, w, c = x.shape
         k = weight.shape[0]
         ctx.x_is_elu = x_is_elu
@@ -162,7 +191,7 @@ class SegOutUp(torch.autograd.Function):
             lib().call("hn_space_to_depth", ptr(dy.contiguous()), ptr(d2), ldz, n, h, w, k)
             dz = d2 if dz is None else k_eltwise(0, dz, d2)
         if dz is None:
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         if wgrad_bias_ok(4, kp32(c)):
             dw_eff, db_eff = k_gemm_tn(x, None, 4, (n, h, w), dz, 4 * k, kp32(c), 9, c, kh=3, want_bias=True)       # [4k, c, 3, 3], [4k]
         else:
@@ -176,12 +205,16 @@ class SegOutUp(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             yp = x if ctx.x_is_elu else None
             if dgrad_fold_ok(c, h, w, n):
-                dx = k_dgrad_fold(dz, ctx.wt, n, h, w, c, kp32(4 * k), 0, 1, yp)
+                # (dx_s2d: space-to-depth memory order under x's shape -- autograd checks the shape, the consuming SegConvUp knows the order)
+                dx = k_dgrad_fold(dz, ctx.wt, n, h, w, c, kp32(4 * k), 0, 1, yp, s2d=1 if ctx.dx_s2d else 0)
+                if ctx.dx_s2d:
+                    dx = dx.view(n, h, w, c)
             else:
+                assert not ctx.dx_s2d, "SegOutUp(dx_s2d=True) without seg_s2d_handover_ok"
                 dvp, _, _ = k_gemm_nt(dz, None, 3, (n, h + 2, w + 2), ctx.wt, c, kp32(4 * k), 9, c0=ldz, c1=0)
                 dx = new_act(n, h, w, c, dev)
                 lib().call("hn_seg_fold", ptr(dvp), ld(dvp), 0, ptr(dx), ld(dx), ptr(yp), ld(yp) if yp is not None else 0, n, h, w, c, 2)
-        return dx, dw, dbias, None, None
+        return dx, dw, dbias, None, None, None
 
 
 def seg_out_argmax(x, weight, bias):
@@ -209,12 +242,17 @@ class SegConvUp(torch.autograd.Function):
     (no full-resolution padded grid, no 2x2 fold).  ELU' folding along the decoder chain as in SegConv (x0_is_elu / dy_is_dz)."""
 
     @staticmethod
-    def forward(ctx, x0, x1, weight, bias, x0_is_elu=False, dy_is_dz=False):
+    def forward(ctx, x0, x1, weight, bias, x0_is_elu=False, dy_is_dz=False, dy_is_s2d=False, dzs_slot=None):
+        """dy_is_s2d (with dy_is_dz, only where seg_s2d_handover_ok): the incoming gradient is this block's dz already in space-to-depth memory
+        order (written so by the consumer's folding data-gradient epilogue, SegOutUp(dx_s2d=True)).
+        dzs_slot (with dy_is_dz): GradSlot in which the consumer (SegConv(dx_s2d_slot=...)) may leave dz a second time in that order"""
+        ctx.dzs_slot = dzs_slot if dy_is_dz else None
         n, h, w, c0 = x0.shape
         k, cin = weight.shape[0], weight.shape[1]
         c1 = cin - c0
         dev = x0.device
         z1 = wt1 = wt_full = None
+        ctx.dy_is_s2d = dy_is_s2d
         # Per-layer choice of form (measured, tools/bench_seg.py): the forward runs full-resolution when the skip operand is so narrow that its
         # own conv would be mostly K padding (decoder.5: 24 channels); the data gradient w.r.t. x0 runs full-resolution when the padded
         # low-resolution grid cannot fill the chip (decoder.1: 18x34 cells -> 384 workgroups); the weight gradient is always in phase form.
@@ -235,6 +273,7 @@ class SegConvUp(torch.autograd.Function):
         else:
             y, _, _ = k_gemm_nt(x0, x1, 2, (n, 2 * h, 2 * w), wp_full, k, kp32(cin), 9, bias=bias, act=ACT_ELU, up=1)
         ctx.x0_is_elu, ctx.dy_is_dz = x0_is_elu, dy_is_dz
+        assert not dy_is_s2d or (dy_is_dz and c1 == 0 and ctx.dgrad_phase), "SegConvUp(dy_is_s2d=True) without seg_s2d_handover_ok"
         ctx.packs = (wt_eff, wt1, wt_full)
         ctx.save_for_backward(x0, x1, y if not dy_is_dz else None)
         ctx.dims = (k, c0, c1)
@@ -250,8 +289,13 @@ class SegConvUp(torch.autograd.Function):
         dy = dense(dy)
         dz = dy if ctx.dy_is_dz else k_eltwise(1, dy, y, act=ACT_ELU)
         # space-to-depth gradient: the operand of both low-resolution contractions
-        dzs = new_act(n, h, w, 4 * k, dev)
-        lib().call("hn_space_to_depth_bf16", ptr(dz), ld(dz), ptr(dzs), n, h, w, k, None)
+        if ctx.dy_is_s2d:
+            dzs, dz = dy.view(n, h, w, 4 * k), None                  # handed over in that order (nothing below reads the plain form)
+        elif ctx.dzs_slot is not None and ctx.dzs_slot.buf is not None:
+            dzs, ctx.dzs_slot.buf = ctx.dzs_slot.buf, None           # written beside the plain form by the consumer's folding epilogue
+        else:
+            dzs = new_act(n, h, w, 4 * k, dev)
+            lib().call("hn_space_to_depth_bf16", ptr(dz), ld(dz), ptr(dzs), n, h, w, k, None)
         # effective-weight gradient (zeros at the taps a phase does not use), mapped back to the 3x3 weights by the phase matrix; the bias
         # gradient (channel sums of dz, per phase) comes out of the same launches
         splits, rps, wsb = ctypes.c_int(), ctypes.c_long(), ctypes.c_long()
@@ -291,11 +335,12 @@ class SegConvUp(torch.autograd.Function):
         dw = torch.empty((k, c0 + c1, 3, 3), device=dev, dtype=F32)
         dbias = torch.empty((k,), device=dev, dtype=F32)
         lib().call("hn_phase_fold", ptr(dw_eff), ptr(dw1), ptr(db_eff), ptr(dw), ptr(dbias), k, c0, c1)
-        return dx0, dx1, dw, dbias, None, None
+        return dx0, dx1, dw, dbias, None, None, None, None
 
 
 SEG_PHASE_UP = policy("HN_SEG_PHASE_UP", "1") != "0"
 SEG_DGRAD_PHASE_MIN_TILES = int(policy("HN_SEG_DGRAD_PHASE_MIN_TILES", "448"))
+SEG_S2D_HANDOVER = policy("HN_SEG_S2D_HANDOVER", "1") != "0"   # the output conv's data gradient written in the last block's operand order
 SEG_FWD_PHASE = None        # None: per-layer heuristic; True / False force the forward form (tests)
 SEG_DGRAD_PHASE = None      # the same for the data gradient w.r.t. the up-sampled operand
 

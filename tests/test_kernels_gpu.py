@@ -438,6 +438,68 @@ def test_seg_out_phase_form(K, c, k, n, h, w):
     close(bk.grad, br.grad, GRAD_TOL, "dbias")
 
 
+@pytest.mark.parametrize("c0,cout,k,n,h,w", [(64, 64, 5, 2, 12, 20), (64, 64, 5, 16, 32, 64), (128, 64, 5, 2, 8, 8)])
+def test_seg_out_gradient_handed_over_in_space_to_depth_order(K, c0, cout, k, n, h, w):
+    """SegConvUp -> SegOutUp (the last decoder block and the output conv, head_seg/segmentation.py:100-104) with the output conv's data
+    gradient written straight in the block's space-to-depth operand order (hn_conv3x3_dgrad_fold_s2d: no hn_space_to_depth_bf16 pass)
+    == the same chain with the plain hand-over, bit for bit: every gradient, incl. the border pixels the ring fix-up touches."""
+    x0 = rnd(n, c0, h, w)
+    wt = rnd(cout, c0, 3, 3, scale=(9 * c0) ** -0.5)
+    bs = rnd(cout, scale=0.1)
+    wo = rnd(k, cout, 3, 3, scale=(9 * cout) ** -0.5)
+    bo = rnd(k, scale=0.1)
+    upg = rnd(n, 4 * h, 4 * w, k)
+    K.SEG_DGRAD_PHASE = True
+    fold_min = K.seg.SEG_FOLD_MIN_ELEMS
+    K.SEG_FOLD_MIN_ELEMS = 0
+    try:
+        assert K.seg_s2d_handover_ok(nhwc(x0), None, wt)
+        got = []
+        for s2d in (False, True):
+            leaves = [t.clone().requires_grad_(True) for t in (nhwc(x0), wt, bs, wo, bo)]
+            y = K.SegConvUp.apply(leaves[0], None, leaves[1], leaves[2], False, True, s2d)
+            out = K.SegOutUp.apply(y, leaves[3], leaves[4], True, None, s2d)
+            out.backward(upg)
+            got.append([t.grad.clone() for t in leaves])
+    finally:
+        K.SEG_DGRAD_PHASE = None
+        K.SEG_FOLD_MIN_ELEMS = fold_min
+    for name, a, b in zip(("dx0", "dw", "dbias", "dw_out", "dbias_out"), got[0], got[1]):
+        assert torch.equal(a, b), f"{name}: max diff {(a.float() - b.float()).abs().max().item():.3e}"
+
+
+@pytest.mark.parametrize("c0,c1,cout,k2,n,h,w", [(128, 24, 128, 64, 2, 12, 20), (256, 112, 256, 128, 16, 16, 32), (64, 0, 64, 64, 1, 8, 8)])
+def test_seg_block_gradient_left_in_both_orders(K, c0, c1, cout, k2, n, h, w):
+    """SegConvUp -> SegConv (decoder blocks 2i+1 -> 2i+2, head_seg/segmentation.py:92-99): the second block's folding data-gradient epilogue
+    leaves the gradient a second time in the first block's space-to-depth operand order (GradSlot; hn_conv3x3_dgrad_fold_s2d with both
+    outputs) == the chain in which the first block makes that copy itself, bit for bit."""
+    x0 = rnd(n, c0, h, w)
+    x1 = rnd(n, c1, 2 * h, 2 * w) if c1 else None
+    wt = rnd(cout, c0 + c1, 3, 3, scale=(9 * (c0 + c1)) ** -0.5)
+    bs = rnd(cout, scale=0.1)
+    w2 = rnd(k2, cout, 3, 3, scale=(9 * cout) ** -0.5)
+    b2 = rnd(k2, scale=0.1)
+    upg = nhwc(rnd(n, k2, 2 * h, 2 * w))
+    fold_min = K.seg.SEG_FOLD_MIN_ELEMS
+    K.SEG_FOLD_MIN_ELEMS = 0
+    try:
+        got = []
+        for use_slot in (False, True):
+            leaves = [t.clone().requires_grad_(True) for t in ([nhwc(x0)] + ([nhwc(x1)] if c1 else []) + [wt, bs, w2, b2])]
+            xa, xb = leaves[0], (leaves[1] if c1 else None)
+            wa, ba, wb, bb = leaves[-4:]
+            slot = K.GradSlot() if use_slot else None
+            y = K.SegConvUp.apply(xa, xb, wa, ba, False, True, False, slot)
+            out = K.SegConv.apply(y, None, wb, bb, 0, 3, False, True, False, slot)
+            out.backward(upg)
+            assert slot is None or slot.buf is None                    # taken by the first block's backward
+            got.append([t.grad.clone() for t in leaves])
+    finally:
+        K.SEG_FOLD_MIN_ELEMS = fold_min
+    for i, (a, b) in enumerate(zip(got[0], got[1])):
+        assert torch.equal(a, b), f"gradient {i}: max diff {(a.float() - b.float()).abs().max().item():.3e}"
+
+
 def test_pack_plan_matches_single_packs(K):
     """ops.PackPlan (every per-step weight pack of a model in two launches) writes bit for bit what the single-weight entry points write:
     dense 1x1 / 3x3 weights through the tiled transposing kernel (channel counts that are not multiples of 32: zero padding of both
