@@ -199,7 +199,9 @@ struct XsWg {
         cur_b = 0;
         touched = 0;
     }
-    __device__ __forceinline__ void ids() { lane = tid & 63; wave = tid >> 6; wc = wave / WGP; wp = wave % WGP; }
+    // (the wave index as a scalar: derived from the opaque tid it lives in a vector register, and so does every LDS-DMA destination, M0
+    // value and row base computed from it -- the wide backward kernel spilled those and reloaded them in front of every stage's requests)
+    __device__ __forceinline__ void ids() { lane = tid & 63; wave = __builtin_amdgcn_readfirstlane(tid >> 6); wc = wave / WGP; wp = wave % WGP; }
     // (opaque per block: per-lane address arithmetic is recomputed where it is used; hoisted out of the block loop it was ~55 spilled
     // 64-bit values whose reloads queue behind the prefetches in the in-order vmcnt stream)
     __device__ __forceinline__ void refresh() { asm volatile("" : "+v"(tid)); ids(); }
