@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256 * KG) void gemm_nt_kernel(const GemmNT p) {
     constexpr int XR = BP / 32, WR = (BC + 31) / 32;
     constexpr int STAGE = (BC + BP) * 128;                        // one K stage (64 k) of both operands
     extern __shared__ __attribute__((aligned(16))) char smem[];   // R stages, ONE array (keeps the compiler's LDS-DMA waits minimal)
-    const int tid = threadIdx.x & 255, kg = threadIdx.x >> 8, lane = tid & 63, wave = tid >> 6;   // (thread / wave index inside the K group)
+    const int tid = threadIdx.x & 255, kg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (thread / wave index inside the K group)
     const int wc = wave / WGP, wp = wave % WGP;
     const int ncy = (p.Nout + BC - 1) / BC;                       // cout tiles: fastest logical index => they share the pixel tile in L2
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
@@ -844,7 +844,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
     extern __shared__ __attribute__((aligned(16))) char smem[];       // X patch x2 | W tile x2
     char* sXb = smem;
     char* sWb = smem + XBUFS * XBYTES;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (a scalar: M0 values, LDS bases and wave-uniform branches off the vector unit)
     const int wc = wave / WGP, wp = wave % WGP;
     const XSrc& xs = p.x;
     const int ncy = (p.Nout + BC - 1) / BC;
@@ -1592,7 +1592,7 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTN& p, const int lid) {  
     constexpr int ZL = (64 * ZPR + NT - 1) / NT, XL = (64 * XPR + NT - 1) / NT;
     constexpr int ZB = 64 * BC * 2, XB = 64 * BN * 2, STAGE = ZB + XB;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // two stages of [dZ tile | X tile]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (a scalar: M0 values, LDS bases and wave-uniform branches off the vector unit)
     const int wc = wave / WGN, wn = wave % WGN;
     const int ntile = (p.KP + BN - 1) / BN;
     // logical block id: (tap, ci tile) fastest, then cout tile, then pixel split -- the blocks of one split share dZ / X rows in one L2
@@ -1811,7 +1811,7 @@ __device__ __forceinline__ void gemm_tn_ring_body(const GemmTN& p, const int lid
     constexpr int ZL = BK * ZPR / NT, XL = BK * XPR / NT, G = ZL + XL;
     constexpr int ZB = BK * BC * 2, XB = BK * BN * 2, STAGE = ZB + XB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (a scalar: M0 values, LDS bases and wave-uniform branches off the vector unit)
     const int wc = wave / WGN, wn = wave % WGN;
     const int ntile = (p.KP + BN - 1) / BN;
     const int bx = lid % ntile, by = (lid / ntile) % p.gy, bz = lid / (ntile * p.gy);
@@ -1951,7 +1951,7 @@ __device__ __forceinline__ void gemm_tn_regs_body(const GemmTN& p, const int lid
     constexpr int ZL = 64 * ZPR / NT, XL = 64 * XPR / NT;
     constexpr int ZB = 64 * BC * 2, XB = 64 * BN * 2, STAGE = ZB + XB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (a scalar: M0 values, LDS bases and wave-uniform branches off the vector unit)
     const int wc = wave / WGN, wn = wave % WGN;
     const int ntile = (p.KP + BN - 1) / BN;
     const int bx = lid % ntile, by = (lid / ntile) % p.gy, bz = lid / (ntile * p.gy);
@@ -2199,7 +2199,7 @@ __device__ __forceinline__ void wgrad3x3_patch_body(const GemmTN& p, const int p
     constexpr int ZL = (128 * (BC / 8) + 511) / 512, XL = (XPIX * XNP + 511) / 512;
     constexpr int STAGE = ZB + XB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (a scalar: M0 values, LDS bases and wave-uniform branches off the vector unit)
     const int wn = wave % WGN, wc = (wave / WGN) % WGC, wk = wave / (WGN * WGC);
     const XSrc& xs = p.x;
     const int ntile = (p.KP + CI - 1) / CI;                            // (diag: KP == CI == 64 -> 1)
