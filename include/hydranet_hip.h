@@ -175,6 +175,9 @@ int hn_dwconv_wgrad_levels(const void* x, int ldx, const void* dz, int ldz, floa
  * [9][C] bf16) and the weight-gradient partial rows part [hn_dwconv_bwd_blocks(strips, C)][C*9] (strips = sum over levels of
  * N * H * ceil(W / 4)); reduce with hn_rows_reduce.  Reference: the backward of SeparableConvBlock.depthwise_conv (net/common.py:91-92,104). */
 long hn_dwconv_bwd_blocks(long strips, int C);
+/* ... for these maps, whichever form of the kernel hn_dwconv_bwd_levels takes (strips walked by lanes, or -- C <= 120, >= 512 tiles -- 8 x 16-pixel
+ * tiles staged in LDS: two workgroups per CU, one partial row each); -1: bad argument.  Callers size `part` with THIS. */
+long hn_dwconv_bwd_blocks_levels(int N, int C, int nlev, const int* H, const int* W);
 int hn_dwconv_bwd_levels(const void* dz, int ldz, const void* x, int ldx, const void* wf, void* dx, int lddx, float* part, int N, int C,
                          int nlev, const int* H, const int* W, int row_align, int accumulate, hipStream_t stream);
 

@@ -816,6 +816,167 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const bf16* dz, int ldz
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same one-pass backward, LDS-tiled (round 6; C <= 120, maps of >= 512 tiles).  The strip kernel above asks the cache hierarchy for every
+// dz element 5.5 times (18 eight-byte loads per 4-pixel strip) and its threads walk their strips one after the other -- loads, wait,
+// ~450 VALU instructions, stores -- so the memory system idles while the lanes compute: 2.0-2.5 TB/s of dz + x + dx on the level-packed
+// tower tensor and the P3 maps.  Here a workgroup owns 8 x 16-pixel output tiles with ALL channels: the 10 x 18 dz halo tile and the x tile
+// arrive by LDS-DMA in whole 224-byte pixel rows (every byte of dz crosses L2 -> LDS 1.4 times), two workgroups per CU cover each other's
+// DMA waits, a thread = (4 channels, two tile columns) slides a 3 x 3 window down the tile's 8 rows (3 + 1 ds_read_b64 per output pixel)
+// with its 36 weights in registers, and its 36 weight-gradient accumulators live across the workgroup's `tpw` tiles.  dx: the same
+// products in the same order as dwconv_fwd_kernel with the flipped weights (bit-identical); dweight: one partial row per workgroup
+// (fixed-order LDS fold).  Measured and not kept: 8 channels per thread with the weights re-read from LDS (latency of 18 reads per row:
+// 50 us on the tower tensor), 4 x 16 tiles double-buffered (more halo, more requests: 47), one 512-thread workgroup per CU with two
+// 8 x 16 buffers and the per-piece coordinates precomputed (45); this form: 42.5 (strip form 56.7).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) bf16 st_zero_piece[8];
+struct DwTiles { long tile_off[HN_MAX_LEVELS + 1]; int ty[HN_MAX_LEVELS], tx[HN_MAX_LEVELS]; };
+__device__ __forceinline__ void st_glds16(const bf16* src, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+#define DWT_TH 8                                                     // tile rows (x 16 columns)
+template <bool HAS_DX>
+__global__ __launch_bounds__(256, 2) void dwconv_bwd_tiled_kernel(const bf16* dz, int ldz, const bf16* x, int ldx, const bf16* wf, bf16* dx, int lddx,
+                                                                  float* part, int N, int C, int tpw, int blocks, const Levels L, const DwTiles T,
+                                                                  int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TH = DWT_TH, ZPX = (TH + 2) * 18, XPX = TH * 16;
+    const int C8 = C >> 3, C4 = C >> 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if ((int)blockIdx.x >= blocks) {                                   // ragged level packing: the alignment rows of dx are zeroed
+        long idx = ((long)blockIdx.x - blocks) * 256 + tid;
+        for (int l = 0; l < L.n; ++l) {
+            const long real = (long)N * L.H[l] * L.W[l];
+            const long pad = L.row_off[l + 1] - L.row_off[l] - real;
+            if (idx < pad * C8) {
+                st8(dx + (L.row_off[l] + real + idx / C8) * lddx + (idx % C8) * 8, zero8());
+                return;
+            }
+            idx -= pad * C8;
+        }
+        return;
+    }
+    const int ZCH = (ZPX * C8 + 63) >> 6, XCH = (XPX * C8 + 63) >> 6;   // 1 KB DMA chunks of the dz halo tile / the x tile
+    char* sZ = smem;
+    char* sX = smem + ZCH * 1024;
+    const int bidx = xcd_remap(blockIdx.x, blocks);
+    const long total = T.tile_off[L.n];
+    const long t0 = (long)bidx * tpw;
+    long t1 = t0 + tpw;
+    if (t1 > total) t1 = total;
+    // thread = (4 channels, tile columns colh and colh + 8): 9 x 4 weights, 9 x 4 weight-gradient accumulators and the 3 x 3 window in
+    // registers (108 of the 256 a wave has with two 4-wave workgroups per CU; 8 channels per thread would be 216 + temporaries)
+    const int cq = tid % C4, colh = tid / C4;
+    const bool active = colh < 8;
+    float wr[9][4], acc[9][4];
+#pragma unroll
+    for (int tq = 0; tq < 9; ++tq) {
+        const bf16x4 wv = (HAS_DX && active) ? ld4(wf + tq * C + cq * 4) : zero4();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { wr[tq][k] = bf2f(wv[k]); acc[tq][k] = 0.f; }
+    }
+    const unsigned magic = (65536u + C8 - 1) / C8;                      // e / C8 = (e * magic) >> 16 for e < 4096 (C8 <= 16)
+    int lv = 0;
+    for (long t = t0; t < t1; ++t) {
+        while (lv + 1 < L.n && t >= T.tile_off[lv + 1]) ++lv;           // (tiles are visited in increasing order: lv only grows)
+        const int H = L.H[lv], W = L.W[lv];
+        long lt = t - T.tile_off[lv];
+        const int tx = (int)(lt % T.tx[lv]);
+        lt /= T.tx[lv];
+        const int ty = (int)(lt % T.ty[lv]);
+        const long n = lt / T.ty[lv];
+        const int oy0 = ty * TH, ox0 = tx * 16;
+        const long row0 = L.row_off[lv] + n * H * (long)W;
+        __syncthreads();                                               // the previous tile's readers are done
+        for (int ch = wave; ch < ZCH; ch += 4) {
+            const int e = ch * 64 + lane;
+            const int px = (int)(((unsigned)e * magic) >> 16), pc = e - px * C8;
+            const int py = px / 18, pxx = px - py * 18;
+            const int iy = oy0 - 1 + py, ix = ox0 - 1 + pxx;
+            const bf16* src = (px < ZPX && iy >= 0 && iy < H && ix >= 0 && ix < W) ? dz + (row0 + (long)iy * W + ix) * ldz + pc * 8 : st_zero_piece;
+            st_glds16(src, sZ + ch * 1024);
+        }
+        for (int ch = wave; ch < XCH; ch += 4) {
+            const int e = ch * 64 + lane;
+            const int px = (int)(((unsigned)e * magic) >> 16), pc = e - px * C8;
+            const int iy = oy0 + (px >> 4), ix = ox0 + (px & 15);
+            const bf16* src = (px < XPX && iy < H && ix < W) ? x + (row0 + (long)iy * W + ix) * ldx + pc * 8 : st_zero_piece;
+            st_glds16(src, sX + ch * 1024);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (active)
+#pragma unroll 1
+        for (int col = colh; col < 16; col += 8) {
+            bf16x4 win[3][3];                                          // dz rows r-1, r, r+1 (halo rows r, r+1, r+2) x halo columns col, col+1, col+2
+            auto load_row = [&](int py, bf16x4 (&w3)[3]) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) w3[j] = *reinterpret_cast<const bf16x4*>(sZ + ((py * 18 + col + j) * C4 + cq) * 8);
+            };
+            load_row(0, win[0]);
+            load_row(1, win[1]);
+            // rows in groups of three (the window's slot of a row is then a compile-time index) inside a ROLLED loop: fully unrolled, the
+            // compiler requests all ten halo rows up front
+#pragma unroll 1
+            for (int r3 = 0; r3 < TH; r3 += 3)
+#pragma unroll
+            for (int rq = 0; rq < 3; ++rq) {
+                const int r = r3 + rq;
+                if (r >= TH) break;
+                load_row(r + 2, win[(rq + 2) % 3]);
+                const bf16x4 xb = *reinterpret_cast<const bf16x4*>(sX + ((r * 16 + col) * C4 + cq) * 8);
+                float xv[4], da[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { xv[k] = bf2f(xb[k]); da[k] = 0.f; }
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const bf16x4 zq = win[(rq + rr) % 3][j];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float zf = bf2f(zq[k]);
+                            if (HAS_DX) da[k] = fmaf(zf, wr[rr * 3 + j][k], da[k]);
+                            acc[8 - (rr * 3 + j)][k] = fmaf(xv[k], zf, acc[8 - (rr * 3 + j)][k]);
+                        }
+                    }
+                if (HAS_DX && oy0 + r < H && ox0 + col < W) {
+                    bf16* dst = dx + (row0 + (long)(oy0 + r) * W + ox0 + col) * lddx + cq * 4;
+                    bf16x4 v;
+                    if (accumulate) {
+                        const bf16x4 prev = ld4(dst);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] = f2bf(da[k] + bf2f(prev[k]));
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] = f2bf(da[k]);
+                    }
+                    *reinterpret_cast<bf16x4*>(dst) = v;
+                }
+            }
+        }
+    }
+    // one partial row per workgroup: the 8 column lanes of a channel group are folded through LDS in lane order
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);                      // [8 * C4][37]
+    if (active) {
+#pragma unroll
+        for (int tq = 0; tq < 9; ++tq)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) red[(colh * C4 + cq) * 37 + tq * 4 + k] = acc[tq][k];
+    }
+    __syncthreads();
+    float* dst = part + (long)bidx * C * 9;
+    for (int o = tid; o < C4 * 36; o += 256) {
+        const int g = o / 36, v = o - g * 36;
+        float sum = 0.f;
+#pragma unroll
+        for (int c2 = 0; c2 < 8; ++c2) sum += red[(c2 * C4 + g) * 37 + v];
+        dst[(long)(g * 4 + (v & 3)) * 9 + (v >> 2)] = sum;
+    }
+}
+
 // fp32 [C][1][3][3] -> wk[tap][C] and flipped wkf[8 - tap][C]
 __global__ void dw_pack_kernel(const float* w, bf16* wk, bf16* wkf, int C) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1622,12 +1783,50 @@ extern "C" int hn_dwconv_wgrad_levels(const void* x, int ldx, const void* dz, in
 }
 
 // one-pass backward of the depthwise conv (data gradient + weight-gradient partial rows): blocks / launch
-extern "C" long hn_dwconv_bwd_blocks(long strips, int C) {
+static long dwconv_bwd_strip_blocks(long strips, int C) {
     const int lanes = 256 / (C >> 2);
     const long tb = g_hn_knob[7] > 0 ? g_hn_knob[7] : 768;        // ~768 blocks: three co-resident per CU, the lane reduction amortised (knob 7: sweeps)
     long spl = (strips + (tb - 1) * lanes) / (tb * lanes);
     if (spl < 2) spl = 2;
     return (strips + spl * lanes - 1) / (spl * lanes);
+}
+extern "C" long hn_dwconv_bwd_blocks(long strips, int C) { return dwconv_bwd_strip_blocks(strips, C); }
+// The LDS-tiled form takes maps with enough 8 x 16 tiles to fill the chip and channel counts whose tiles leave room for two workgroups per
+// CU; tiles per workgroup so that ~512 workgroups (two per CU) share the launch.  (knob 7 < 0: the strip form always -- tools/ A-B)
+static size_t dwconv_bwd_tiled_lds(int C8) {      // (dz halo tile | x tile) in 1 KB DMA chunks (>= the final fold's 8 * C/4 * 37 floats)
+    return (size_t)((((DWT_TH + 2) * 18 * C8 + 63) >> 6) + ((DWT_TH * 16 * C8 + 63) >> 6)) * 1024;
+}
+static bool dwconv_bwd_tiled_plan(int N, int C, const Levels& L, DwTiles& T, int& tpw, long& blocks) {
+    T.tile_off[0] = 0;
+    for (int l = 0; l < L.n; ++l) {
+        T.ty[l] = (L.H[l] + DWT_TH - 1) / DWT_TH;
+        T.tx[l] = (L.W[l] + 15) >> 4;
+        T.tile_off[l + 1] = T.tile_off[l] + (long)N * T.ty[l] * T.tx[l];
+    }
+    const long total = T.tile_off[L.n];
+    const int C8 = C >> 3;
+    const size_t lds = dwconv_bwd_tiled_lds(C8);
+    // (measured, tools/bench_dwconv_bwd.py: towers 42.5 vs 56.7 us, P3 map 33.2 vs 41.1; the 256-tile P4 map 18.4 vs 17.1 -- one tile per
+    // workgroup on half the slots -- stays with the strip form)
+#ifdef HN_NO_DW_TILED      // tools/ab_tree.sh: the strip form always (same-box A-B of the product build)
+    return false;
+#endif
+    if (g_hn_knob[7] < 0 || C8 > 16 || lds > 80 * 1024 || total < 512) return false;
+    tpw = (int)((total + 511) / 512);
+    blocks = (total + tpw - 1) / tpw;
+    return true;
+}
+/* partial rows of hn_dwconv_bwd_levels for these maps (either form of the kernel) */
+extern "C" long hn_dwconv_bwd_blocks_levels(int N, int C, int nlev, const int* H, const int* W) {
+    Levels L;
+    if (fill_levels(L, N, nlev, H, W) != HN_OK || (C & 7) || C < 8) return -1;
+    DwTiles T;
+    int tpw = 0;
+    long blocks = 0;
+    if (dwconv_bwd_tiled_plan(N, C, L, T, tpw, blocks)) return blocks;
+    long strips = 0;
+    for (int l = 0; l < nlev; ++l) strips += (long)N * H[l] * ((W[l] + 3) >> 2);
+    return dwconv_bwd_strip_blocks(strips, C);
 }
 extern "C" int hn_dwconv_bwd_levels(const void* dz, int ldz, const void* x, int ldx, const void* wf, void* dx, int lddx, float* part, int N, int C,
                                     int nlev, const int* H, const int* W, int row_align, int accumulate, hipStream_t st) {
@@ -1635,15 +1834,34 @@ extern "C" int hn_dwconv_bwd_levels(const void* dz, int ldz, const void* x, int 
     const int rc = fill_levels(L, N, nlev, H, W, row_align);
     if (rc != HN_OK) return rc;
     HN_CHECK_ARG(dz && x && part && (!dx || wf) && (C & 7) == 0 && C >= 8 && C <= 1024 && ((ldz | ldx) & 7) == 0 && (!dx || (lddx & 7) == 0));
+    long pad_items = 0;
+    if (dx && !accumulate)
+        for (int l = 0; l < L.n; ++l) pad_items += (L.row_off[l + 1] - L.row_off[l] - (long)N * L.H[l] * L.W[l]) * (C >> 3);
+    DwTiles T;
+    int tpw = 0;
+    long tblocks = 0;
+    if (dwconv_bwd_tiled_plan(N, C, L, T, tpw, tblocks)) {
+        const int C8 = C >> 3;
+        const size_t lds = dwconv_bwd_tiled_lds(C8);
+        if (lds > 64 * 1024) {
+            static std::atomic<unsigned long long> optin_t{0};
+            if (!lds_optin(optin_t, {(const void*)dwconv_bwd_tiled_kernel<true>, (const void*)dwconv_bwd_tiled_kernel<false>})) return HN_ERR_LAUNCH;
+        }
+        L.work_off[0] = 0;
+        if (dx)
+            hipLaunchKernelGGL(dwconv_bwd_tiled_kernel<true>, dim3((unsigned)(tblocks + cdiv(pad_items, 256))), dim3(256), lds, st, (const bf16*)dz,
+                               ldz, (const bf16*)x, ldx, (const bf16*)wf, (bf16*)dx, lddx, part, N, C, tpw, (int)tblocks, L, T, accumulate);
+        else
+            hipLaunchKernelGGL(dwconv_bwd_tiled_kernel<false>, dim3((unsigned)tblocks), dim3(256), lds, st, (const bf16*)dz, ldz, (const bf16*)x, ldx,
+                               (const bf16*)wf, (bf16*)dx, lddx, part, N, C, tpw, (int)tblocks, L, T, accumulate);
+        HN_LAUNCH_CHECK();
+    }
     L.work_off[0] = 0;
     for (int l = 0; l < L.n; ++l) L.work_off[l + 1] = L.work_off[l] + (long)N * L.H[l] * ((L.W[l] + 3) >> 2);
     const long strips = L.work_off[L.n];
     const int lanes = 256 / (C >> 2);
-    const long blocks = hn_dwconv_bwd_blocks(strips, C);
+    const long blocks = dwconv_bwd_strip_blocks(strips, C);
     const int spl = (int)((strips + blocks * lanes - 1) / (blocks * lanes));
-    long pad_items = 0;
-    if (dx && !accumulate)
-        for (int l = 0; l < L.n; ++l) pad_items += (L.row_off[l + 1] - L.row_off[l] - (long)N * L.H[l] * L.W[l]) * (C >> 3);
     const size_t lds = (256 * 37 + 9 * (size_t)C) * sizeof(float);
     if (lds > 64 * 1024) {                                             // > 64 KiB of dynamic LDS: opt-in once per device (C > 727)
         static std::atomic<unsigned long long> optin{0};

@@ -40,12 +40,10 @@ def k_dwconv_bwd(dz, x, wf, geom=None, want_dx=True, into=None, queue=None, weig
     if geom is None:
         n, h, w, _ = x.shape
         H, W, nl, align = (ctypes.c_int * 1)(h), (ctypes.c_int * 1)(w), 1, 1
-        strips = n * h * ((w + 3) // 4)
     else:
         nl, H, W, _, _ = _geom_arrays(geom)
         n, align = geom[0], LEVEL_ALIGN
-        strips = sum(n * hh * ((ww + 3) // 4) for hh, ww in zip(geom[1], geom[2]))
-    blocks = lib().query("hn_dwconv_bwd_blocks", strips, c)
+    blocks = lib().query("hn_dwconv_bwd_blocks_levels", n, c, nl, ctypes.addressof(H), ctypes.addressof(W))
     part = torch.empty((blocks, c * 9), device=x.device, dtype=F32)
     dx = None
     if want_dx:

@@ -6,7 +6,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 NAME=$1; shift
 T=$(mktemp -d)
 objs=""
-for f in hn_gemm hn_norm hn_fused hn_stencil hn_loss hn_post; do
+for f in hn_gemm hn_norm hn_fused hn_stencil hn_loss hn_post hn_xstage; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 "$@" -c $R/multitask_hydranet_amd/csrc/$f.hip -o $T/$f.o &
   objs="$objs $T/$f.o"
 done
