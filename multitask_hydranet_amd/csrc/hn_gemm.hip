@@ -2795,6 +2795,7 @@ __global__ __launch_bounds__(256) void pack_w_batched_kernel(const long* jobs, i
 //   kind 2: grouped [C][8][3][3] -> stencil operands out0 = wk[tap][i][G][o], out1 = wd[tap'][o][G][i]      p0 = G, p1 = flip
 //   kind 3: grouped -> the DIAGONAL blocks of the block-diagonal MFMA operands out0 = wk, out1 = wd [C][9][64] (buffers zero-filled by the owner)   p0 = C
 //   kind 4: hn_pack_weight_ex (channel slice / phase form): out0 = wp, out1 = wt, out2 = b_eff             p0..p5 = Cout, Cin_total, ci0, Cin, taps, phase
+//           (work items: numel(wp) / 8 + numel(wt) / 8 + CoutE -- eight K entries per thread)
 __global__ __launch_bounds__(256) void pack_small_batched_kernel(const long* jobs, const int* block_job) {
     const long* jb = jobs + (long)block_job[blockIdx.x] * 16;
     const float* w = reinterpret_cast<const float*>(jb[0]);
@@ -2832,24 +2833,32 @@ __global__ __launch_bounds__(256) void pack_small_batched_kernel(const long* job
         o0[dst] = f2bf(a);
         o1[dst] = f2bf(b);
     } else if (kind == 4) {
+        // eight consecutive K entries per thread (one 16-byte store; K is padded to a multiple of 32): with one 2-byte store per lane the
+        // 19 M elements of the decoder's phase-form operands were 75 us of address time for 38 MB
         const int Cout = (int)jb[7], Cin_total = (int)jb[8], ci0 = (int)jb[9], Cin = (int)jb[10], taps = (int)jb[11], phase = (int)jb[12];
         float* b_eff = reinterpret_cast<float*>(jb[3]);
         const float* bias = reinterpret_cast<const float*>(jb[4]);
         const int CoutE = phase ? 4 * Cout : Cout;
         const int KPi = (Cin + 31) / 32 * 32, KPo = (CoutE + 31) / 32 * 32;
-        const long nf = (long)CoutE * taps * KPi;
-        const long nt = o1 ? (long)Cin * taps * KPo : 0;
+        const long nf = (long)CoutE * taps * (KPi >> 3);
+        const long nt = o1 ? (long)Cin * taps * (KPo >> 3) : 0;
         if (idx < nf) {
-            const int k = (int)(idx % KPi);
-            const long t = idx / KPi;
+            const int k0 = (int)(idx % (KPi >> 3)) * 8;
+            const long t = idx / (KPi >> 3);
             const int tap = (int)(t % taps), co = (int)(t / taps);
-            o0[idx] = f2bf(k < Cin ? packed_w_value(w, Cout, Cin_total, ci0, taps, phase, co, k, tap) : 0.f);
+            bf16x8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = f2bf(k0 + j < Cin ? packed_w_value(w, Cout, Cin_total, ci0, taps, phase, co, k0 + j, tap) : 0.f);
+            st8(o0 + idx * 8, v);
         } else if (idx < nf + nt) {
-            const long j = idx - nf;
-            const int k = (int)(j % KPo);
-            const long t = j / KPo;
+            const long jx = idx - nf;
+            const int k0 = (int)(jx % (KPo >> 3)) * 8;
+            const long t = jx / (KPo >> 3);
             const int tap = (int)(t % taps), ci = (int)(t / taps);
-            o1[j] = f2bf(k < CoutE ? packed_w_value(w, Cout, Cin_total, ci0, taps, phase, k, ci, tap) : 0.f);
+            bf16x8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = f2bf(k0 + j < CoutE ? packed_w_value(w, Cout, Cin_total, ci0, taps, phase, k0 + j, ci, tap) : 0.f);
+            st8(o1 + jx * 8, v);
         } else if (b_eff && idx < nf + nt + CoutE) {
             const int co = (int)(idx - nf - nt);
             b_eff[co] = bias[co % Cout];

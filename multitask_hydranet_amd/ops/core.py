@@ -190,7 +190,7 @@ class PackPlan:
                 bias = meta if phase else None
                 small([w.data_ptr(), wp.data_ptr(), wt.data_ptr() if wt is not None else 0, b_eff.data_ptr() if phase else 0,
                        bias.data_ptr() if phase else 0, 4, 0, cout, cin_total, ci0, cin, taps, phase],
-                      wp.numel() + (wt.numel() if wt is not None else 0) + (coute if phase else 0))
+                      wp.numel() // 8 + (wt.numel() // 8 if wt is not None else 0) + (coute if phase else 0))   # eight K entries per thread
                 self.values.append((wp, wt, b_eff, bias) if phase else (wp, wt))
             else:
                 raise KeyError(key)
