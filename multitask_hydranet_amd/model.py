@@ -276,6 +276,10 @@ class HydraNet(nn.Module):
 
     def _reindex(self):
         self._idx = {k: v for k, v in itertools.chain(self.named_parameters(), self.named_buffers()) if not k.startswith("_")}
+        # raw-pointer writes to these tensors (this module's training forward, an optimizer that holds them) bump THIS module's epoch
+        if getattr(self, "_mut_cell", None) is None:
+            self._mut_cell = K.new_mutation_cell()
+        K.tag_mutation_owner(self._idx.values(), self._mut_cell)
         # the parameters whose deferred gradients the flush node behind the backbone hands back (neck + det / lane heads): built once per
         # (re)index, not on every forward (~700 named_parameters() walks per step on the eager path)
         self._tail_params = [t for n_, t in self.named_parameters() if n_.startswith(("neck.", "detectheader.", "laneheader."))]
@@ -342,22 +346,22 @@ class HydraNet(nn.Module):
                                           P[bn + ".running_var"], eps, kind)
         self._folded = folded
         self._folded_versions = [(t, t._version) for n, t in P.items() if n.split(".")[-1] != "num_batches_tracked"]
-        self._folded_epoch = K.mutation_epoch()
+        self._folded_epoch = K.mutation_epoch(self._mut_cell)
         return self
 
     def _check_folded(self):
+        """the folded operands are constants of the parameters / running statistics as they were at prepare_inference(): any change since --
+        visible to autograd (version counters) or made through raw pointers by this library (this module's mutation epoch: its own
+        training forward, an optimizer step on its parameters) -- folds again (a few hundred small launches, once per such event), except
+        inside a capture, where the operands must stay what the warm-up forwards used"""
         if self._folded is None:
             return
-        if any(t._version != v for t, v in self._folded_versions):
-            raise RuntimeError("parameters or BatchNorm statistics changed after prepare_inference(): call prepare_inference() again")
-        if self._folded_epoch != K.mutation_epoch():
-            # a raw-pointer update happened somewhere in this process since the fold (hn_adam_step, a training-mode forward of any
-            # HydraNet): the version counters cannot tell whether it touched THIS module's tensors, so fold again (a few hundred small
-            # launches, once per such event; never inside a capture, where the operands must stay what the warm-up forwards used)
-            if torch.cuda.is_current_stream_capturing():
-                raise RuntimeError("parameters may have changed since prepare_inference() (an optimizer step or a training-mode forward ran): "
-                                   "call prepare_inference() again before capturing the deploy forward")
-            self.prepare_inference()
+        if all(t._version == v for t, v in self._folded_versions) and self._folded_epoch == K.mutation_epoch(self._mut_cell):
+            return
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("parameters or BatchNorm statistics changed since prepare_inference(): call prepare_inference() again before "
+                               "capturing the deploy forward")
+        self.prepare_inference()
 
     def train(self, mode: bool = True):
         if mode:
@@ -742,7 +746,7 @@ class HydraNet(nn.Module):
             self._check_folded()
         params = {id(t) for t in self.parameters()}
         if self.training:
-            K.bump_mutation_epoch()                # the BatchNorm kernels update running statistics through raw pointers
+            K.bump_mutation_epoch([self._mut_cell])   # the BatchNorm kernels update this module's running statistics through raw pointers
         if self._pack_plan is not None and not self._pack_plan.valid():
             self._pack_plan = None                 # a parameter's storage was replaced: re-record the weights on this forward
         # eval mode with unchanged parameters (serving): the packed operands of the last forward are still right -- no pack launches

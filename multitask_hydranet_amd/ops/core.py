@@ -80,16 +80,42 @@ def dense(t: torch.Tensor) -> torch.Tensor:
 _PACK_CACHE = {}
 # Raw-pointer writes (hn_adam_step on the parameters, the BatchNorm running statistics written by the training-mode kernels) do not bump
 # torch's per-tensor version counters, so "nothing changed since" cannot be decided from `_version` alone: everything in this
-# library that mutates a parameter or a running statistic behind autograd's back bumps this epoch, and every freshness test includes it.
+# library that mutates a parameter or a running statistic behind autograd's back bumps an epoch, and every freshness test includes it.
+# The epoch is scoped to the OWNER of the tensors: a module tags its parameters and buffers with its own cell
+# (tag_mutation_owner), mutators that know which tensors they write bump those cells only, and a prepared (folded) module is not
+# invalidated by another module's optimizer step or training forward.  Tensors nobody tagged fall back to the process-wide cell.
 _MUTATION_EPOCH = [0]
 
 
-def bump_mutation_epoch():
-    _MUTATION_EPOCH[0] += 1
+def new_mutation_cell():
+    return [0]
 
 
-def mutation_epoch() -> int:
-    return _MUTATION_EPOCH[0]
+def tag_mutation_owner(tensors, cell):
+    for t in tensors:
+        t._hn_mut_cell = cell
+
+
+def mutation_cells(tensors):
+    """the distinct owner cells of `tensors` (the process-wide cell stands in for untagged ones): what a mutator of exactly these tensors bumps"""
+    cells = {}
+    for t in tensors:
+        c = getattr(t, "_hn_mut_cell", None)
+        c = _MUTATION_EPOCH if c is None else c
+        cells[id(c)] = c
+    return list(cells.values())
+
+
+def bump_mutation_epoch(cells=None):
+    """cells: mutation_cells(the tensors written); None: owner unknown, everything in the process is stale"""
+    for c in ([_MUTATION_EPOCH] if cells is None else cells):
+        c[0] += 1
+
+
+def mutation_epoch(owner=None):
+    """freshness key for the tensors of `owner` (a tagged tensor, a cell, or None = untagged)"""
+    c = owner if isinstance(owner, list) else getattr(owner, "_hn_mut_cell", None)
+    return (_MUTATION_EPOCH[0], -1 if c is None else c[0])
 
 
 def clear_pack_cache():
@@ -215,7 +241,8 @@ class PackPlan:
                    for (_, w, meta), p_ in zip(self.entries, self.ptrs))
 
     def _versions(self):
-        return (mutation_epoch(), [(w._version, meta._version if isinstance(meta, torch.Tensor) else 0) for _, w, meta in self.entries])
+        return (mutation_epoch(self.entries[0][1] if self.entries else None),
+                [(w._version, meta._version if isinstance(meta, torch.Tensor) else 0) for _, w, meta in self.entries])
 
     def fresh(self):
         """the packed buffers still hold what run() made of the CURRENT parameter values (no in-place update since -- neither through

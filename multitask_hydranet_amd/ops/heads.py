@@ -247,7 +247,7 @@ def _eval_coef_levels(gam, bet, rms, rvs, eps, cout, coef):
     """eval-mode (running statistics) scale / shift rows of a tower layer's per-level BatchNorms: constants until a parameter or running
     statistic changes in place, so they are computed once (five ~5 us launches per layer and forward otherwise: 30 per deploy forward)"""
     tens = (*gam, *bet, *rms, *rvs)
-    ver = (mutation_epoch(), *[t._version for t in tens])       # raw-pointer updates (hn_adam_step, training-mode BatchNorm kernels) bump the epoch only
+    ver = (mutation_epoch(gam[0]), *[t._version for t in tens])   # raw-pointer updates (hn_adam_step, training-mode BatchNorm kernels) bump the owner's epoch only
     hit = _EVAL_COEF.get(id(gam[0]))
     if hit is not None and len(hit[0]) == len(tens) and all(a is b for a, b in zip(hit[0], tens)) and hit[1] == ver and hit[2] == eps:
         return hit[3]

@@ -13,7 +13,7 @@ import weakref
 import torch
 
 from ._lib import lib
-from .ops.core import bump_mutation_epoch
+from .ops.core import bump_mutation_epoch, mutation_cells
 
 
 class Adam(torch.optim.Optimizer):
@@ -65,7 +65,12 @@ class Adam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        bump_mutation_epoch()               # hn_adam_step writes the parameters through raw pointers: eval-mode caches keyed on `_version` are stale
+        # hn_adam_step writes the parameters through raw pointers: eval-mode caches keyed on `_version` are stale -- those of the modules that own
+        # these parameters (the owner cells are collected once per parameter list, not per step)
+        sig = tuple(len(g["params"]) for g in self.param_groups)
+        if getattr(self, "_mut_sig", None) != sig:
+            self._mut_sig, self._mut_cells = sig, mutation_cells([p for g in self.param_groups for p in g["params"]])
+        bump_mutation_epoch(self._mut_cells)
         for gi, group in enumerate(self.param_groups):
             b1, b2 = group["betas"]
             fast = self._fast.get(gi)
