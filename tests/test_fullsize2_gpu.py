@@ -236,7 +236,12 @@ def _oracle_step(net, cfgs, O, batch, ppl, training=True, mirror=True):
     return sd, out, ld
 
 
-LOSS_TOL = dict(loss_seg=2e-2, loss_det_cls=2e-2, loss_det_reg=2e-2, loss_lane_cls_pos=6e-2, loss_lane_cls_neg=6e-2, loss_lane_loc=6e-2)
+# The tight statement about the loss path lives HERE, on the full-size batch (16 images, 98 208 anchors: nothing is normalised over a handful
+# of samples).  Measured: seg 3e-5, det_cls 1.5e-3, det_reg 4.5e-3, lane_cls_pos 5.4e-3, lane_cls_neg 5.5e-3, lane_loc 3.5e-3, total 1.5e-3.
+# The 2-image 128x128 fixtures of test_model_gpu.py move by +-0.6 % per change of an fp32 summation order and keep looser bounds (2.5e-2 / 6e-2).
+# (loss_lane_cls_pos -- hard-example mining over the deepest features -- is the one term whose ORACLE value moves between runs of the
+# torch-on-device mirror: 8.80 ... 8.98 against 9.03 here; it keeps 6e-2)
+LOSS_TOL = dict(loss_seg=5e-3, loss_det_cls=1e-2, loss_det_reg=1e-2, loss_lane_cls_pos=6e-2, loss_lane_cls_neg=2e-2, loss_lane_loc=2e-2)
 
 
 def test_fullsize_training_step_n16(big):
@@ -267,7 +272,7 @@ def test_fullsize_training_step_n16(big):
     for k, tol in LOSS_TOL.items():
         a, b = res[k]
         assert abs(a - b) <= tol * abs(b), (k, a, b)
-    assert abs(res["total"][0] - res["total"][1]) <= 2e-2 * abs(res["total"][1])
+    assert abs(res["total"][0] - res["total"][1]) <= 1e-2 * abs(res["total"][1])
 
 
 def test_fullsize_backbone_only_n8(big):
