@@ -1557,6 +1557,161 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_kernel(const GemmNT p) 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// The seg head's output conv (64 channels -> 4 phases x k <= 8 classes on the low-resolution grid, replicate padding; fp32 logits in
+// depth-to-space order, or their arg-max) as a PERSISTENT launch with the weights in registers (round 6).  Through conv3x3_direct_kernel<32>
+// the layer is 8 192 workgroups of ~30 us whose life is 25 % prologue, 50 % nine tap steps that each wait for a 4 KB weight tile, and
+// 25 % write-out, for 72 MFMAs per wave.  Here: one 512-thread workgroup per CU walks its share of the 16 x 16-pixel patches; the 36 weight
+// fragments of a wave (2 cout tiles x 9 taps x 2 K halves = 144 registers) are loaded ONCE; the 18 x 18 x 64-channel patch of the NEXT
+// iteration lands by LDS-DMA in the second buffer while this one is multiplied (no tap-step barriers at all); the 32 x 32 x k fp32 tile
+// is staged and leaves as whole rows.  Same products in the same order as the direct kernel (bit-identical logits).
+// ---------------------------------------------------------------------------------------------------------
+struct SegOut { const bf16* x; int ldx, N, H, W; const bf16* w; int Nout, k; const float* bias; float* out; long* amax; int npatch, ppw; };
+template <bool AMAX>
+__global__ __launch_bounds__(512, 2) void seg_out_conv_kernel(const SegOut p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int PPIX = 18 * 18, XCH = (PPIX * 8 + 63) / 64, XBYTES = XCH * 1024;     // 41 one-KB DMA chunks per patch buffer
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* stf = reinterpret_cast<float*>(smem + 2 * XBYTES);          // [32][32 * k] fp32 output tile
+    const int k = p.k, rowf = 32 * k;
+    const int tx_n = (p.W + 15) >> 4, ty_n = (p.H + 15) >> 4;
+    const int bidx = xcd_remap(blockIdx.x, gridDim.x);
+    const int t0 = bidx * p.ppw;
+    int t1 = t0 + p.ppw;
+    if (t1 > p.npatch) t1 = p.npatch;
+    if (t0 >= t1) return;
+    // weight fragments: A operand of v_mfma_f32_16x16x32_bf16 = 16 couts x 32 channels, lane = (cout l & 15, 8 channels (l >> 4) * 8)
+    bf16x8 wf[2][9][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int co = i * 16 + (lane & 15);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                wf[i][tap][ks] = co < p.Nout ? *reinterpret_cast<const bf16x8*>(p.w + ((long)co * 9 + tap) * 64 + ks * 32 + (lane >> 4) * 8) : zero8();
+    }
+    float bs[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = i * 16 + (lane >> 4) * 4 + r;
+            bs[i][r] = (p.bias && co < p.Nout) ? p.bias[co] : 0.f;
+        }
+    // the thread's DMA requests, resolved once: request i covers piece e = (wave + 8 i) 64 + lane of the patch = (pixel e >> 3, PHYSICAL
+    // piece e & 7); the logical piece is physical ^ (patch column & 7) -- the swizzle the fragment reads undo
+    int req[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int e = (wave + 8 * i) * 64 + lane, pp = e >> 3;
+        const int py = pp / 18, px = pp - py * 18;
+        req[i] = (wave + 8 * i < XCH && pp < PPIX) ? ((py << 16) | (px << 8) | ((e & 7) ^ (px & 7))) : -1;
+    }
+    auto issue = [&](int t, char* sX) {
+        const int tx = t % tx_n, t2 = t / tx_n, ty = t2 % ty_n, n = t2 / ty_n;
+        const int oy0 = ty * 16, ox0 = tx * 16;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            if (wave + 8 * i < XCH) {                                  // (wave-uniform)
+                const int rq = req[i];
+                int cy = oy0 - 1 + (rq >> 16), cx = ox0 - 1 + ((rq >> 8) & 255);
+                cy = cy < 0 ? 0 : (cy >= p.H ? p.H - 1 : cy);             // replicate padding = clamped source coordinates
+                cx = cx < 0 ? 0 : (cx >= p.W ? p.W - 1 : cx);
+                const bf16* src = rq >= 0 ? p.x + ((long)(n * p.H + cy) * p.W + cx) * p.ldx + (rq & 255) * 8 : g_zero_piece;
+                glds16(src, sX + (wave + 8 * i) * 1024);
+            }
+        }
+    };
+    // B fragment offsets: pixel (patch row 2 wave + j + ky, column (l & 15) + kx), 8 channels (l >> 4) + 4 ks
+    int bofs[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int pc = (lane & 15) + d;
+        bofs[d] = (wave * 2 * 18 + pc) * 128 + (((lane >> 4) ^ (pc & 7)) << 4);
+    }
+    issue(t0, smem);
+    for (int t = t0; t < t1; ++t) {
+        const int slot = (t - t0) & 1;
+        // (vmcnt(0) also waits for the previous tile's stores; counted waits that leave them in flight measured the same: the launch moves
+        // 1.27 x the input + the fp32 logits at ~4.1 TB/s)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                               // patch t landed; the other buffer and the output tile are free
+        if (t + 1 < t1) issue(t + 1, smem + (slot ^ 1) * XBYTES);
+        const char* sX = smem + slot * XBYTES;
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            const int xo = ky * (18 * 128) + bofs[kx];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int xk = ks ? (xo ^ 64) : xo;
+                bf16x8 b[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sX + xk + j * 18 * 128);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][tap][ks], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        // depth-to-space staging: cout c = (phase, class) -> output pixel (2 ly + py, 2 lx + px), class
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int co0 = i * 16 + (lane >> 4) * 4;
+            int ph = co0 / k, oc = co0 - ph * k;
+            int off[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                off[r] = co0 + r < p.Nout ? (ph >> 1) * rowf + (ph & 1) * k + oc : -1;
+                if (++oc == k) { oc = 0; ++ph; }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int base = 2 * (wave * 2 + j) * rowf + 2 * (lane & 15) * k;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (off[r] >= 0) stf[base + off[r]] = acc[i][j][r] + bs[i][r];
+            }
+        }
+        __syncthreads();
+        const int tx = t % tx_n, t2 = t / tx_n, ty = t2 % ty_n, n = t2 / ty_n;
+        const int oy0 = ty * 16, ox0 = tx * 16;
+        if (AMAX) {
+            for (int idx = tid; idx < 32 * 32; idx += 512) {           // one output pixel per thread: arg-max of its k logits (first maximum wins)
+                const int Y = idx >> 5, X = idx & 31;
+                const int gy = 2 * oy0 + Y, gx = 2 * ox0 + X;
+                if (gy < 2 * p.H && gx < 2 * p.W) {
+                    const float* r = stf + Y * rowf + X * k;
+                    float best = r[0];
+                    int arg = 0;
+                    for (int c = 1; c < k; ++c)
+                        if (r[c] > best) { best = r[c]; arg = c; }
+                    p.amax[(long)(n * 2 * p.H + gy) * (2 * p.W) + gx] = arg;
+                }
+            }
+        } else {
+            const int row4 = rowf >> 2;                                 // float4 per tile row (32 k % 4 == 0)
+            for (int idx = tid; idx < 32 * row4; idx += 512) {
+                const int Y = idx / row4, q4 = idx - Y * row4;
+                const int gy = 2 * oy0 + Y;
+                const int valid = (2 * p.W - 2 * ox0) * k;             // floats of this row that lie inside the image
+                if (gy < 2 * p.H && q4 * 4 < valid) {
+                    float* dst = p.out + ((long)(n * 2 * p.H + gy) * (2 * p.W) + 2 * ox0) * k + q4 * 4;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(stf + Y * rowf + q4 * 4);
+                    if (q4 * 4 + 4 <= valid) *reinterpret_cast<f32x4*>(dst) = v;
+                    else for (int c = 0; q4 * 4 + c < valid; ++c) dst[c] = v[c];
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // wgrad: part[split][cout][tap*KP + ci] = sum over this split's pixel rows of dZ[pixel][cout] * X[pixel(tap)][ci]
 // ---------------------------------------------------------------------------------------------------------
 struct GemmTN {
@@ -3248,6 +3403,25 @@ static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img
         p.img_stride = 0;
     }
     if (mode >= 2 && (!psum || p.x.diag) && !rpi) {      // statistics epilogue: grouped convs only (one partial row per 16x16 patch)
+        // the seg output conv on a map big enough to give every CU several patches: the persistent form with the weights in registers
+        if (p.x.clamp == 1 && !p.x.diag && out_f32 && p.d2s && taps == 9 && KP == 64 && C0 == 64 && C1 == 0 && Nout == 4 * p.d2s && Nout <= 32 &&
+            !psum && !addend && phase_mode == 0 && act == HN_ACT_NONE && (ld0 & 7) == 0 && ((32 * p.d2s) & 3) == 0 && ((2 * W * p.d2s) & 3) == 0 &&
+            (reinterpret_cast<uintptr_t>(out) & 15) == 0 && g_hn_knob[11] != 3) {
+            const long npatch = (long)cdiv(W, 16) * cdiv(H, 16) * n_img;
+            if (npatch >= 1024) {
+                SegOut q;
+                q.x = (const bf16*)x0; q.ldx = ld0; q.N = n_img; q.H = H; q.W = W; q.w = (const bf16*)w; q.Nout = Nout; q.k = p.d2s; q.bias = bias;
+                q.out = p.amax ? nullptr : (float*)out; q.amax = p.amax; q.npatch = (int)npatch;
+                q.ppw = cdiv(npatch, 256);
+                const int grid = cdiv(npatch, q.ppw);
+                const size_t lds = 2 * (size_t)((18 * 18 * 8 + 63) / 64) * 1024 + (size_t)32 * 32 * p.d2s * 4;
+                static std::atomic<unsigned long long> optin_so{0};
+                if (!lds_optin(optin_so, {(const void*)seg_out_conv_kernel<true>, (const void*)seg_out_conv_kernel<false>})) return HN_ERR_LAUNCH;
+                if (p.amax) hipLaunchKernelGGL(seg_out_conv_kernel<true>, dim3(grid), dim3(512), lds, st, q);
+                else hipLaunchKernelGGL(seg_out_conv_kernel<false>, dim3(grid), dim3(512), lds, st, q);
+                HN_LAUNCH_CHECK();
+            }
+        }
         HN_CHECK_ARG(p.x.Wi < 8192 && p.x.Hi < 32768);  // packed patch coordinates of the direct kernel
         int bc = p.x.diag ? 64 : (Nout <= 16 ? 16 : (Nout <= 32 ? 32 : (Nout <= 64 ? 64 : 128)));
         if (phase_mode == 1 && phase_span < bc) bc = 64;            // a cout tile must lie inside one phase

@@ -417,7 +417,8 @@ def test_seg_conv_up_phase_form(K, c0, c1, cout, n, h, w, fwd_phase, dgrad_phase
     close(bk.grad, br.grad, GRAD_TOL, "dbias")
 
 
-@pytest.mark.parametrize("c,k,n,h,w", [(64, 5, 2, 8, 12), (64, 5, 1, 20, 36), (16, 3, 2, 4, 4)])
+@pytest.mark.parametrize("c,k,n,h,w", [(64, 5, 2, 8, 12), (64, 5, 1, 20, 36), (16, 3, 2, 4, 4),
+                                       (64, 5, 5, 250, 330), (64, 5, 4, 256, 256)])   # >= 1024 patches: the persistent form (ragged / whole patches)
 def test_seg_out_phase_form(K, c, k, n, h, w):
     """ops.SegOutUp (4-phase conv with replicate padding on the low-resolution grid) == Conv3x3(reflect_pad(nearest_up2(x))); h, w = INPUT size."""
     x = rnd(n, c, h, w)
@@ -599,7 +600,8 @@ def test_head_out_cat(K, ca, cb):
         close(got.grad, ref.grad, GRAD_TOL, nm)
 
 
-@pytest.mark.parametrize("c,k,n,h,w", [(64, 5, 2, 8, 12), (64, 5, 1, 20, 36), (64, 3, 2, 16, 18), (48, 8, 1, 4, 6)])
+@pytest.mark.parametrize("c,k,n,h,w", [(64, 5, 2, 8, 12), (64, 5, 1, 20, 36), (64, 3, 2, 16, 18), (48, 8, 1, 4, 6),
+                                       (64, 5, 5, 250, 330), (64, 8, 4, 256, 256)])   # >= 1024 patches: the persistent form
 def test_seg_out_argmax_fused(K, c, k, n, h, w):
     """hn_conv3x3_out_argmax (deploy: the output conv's epilogue takes the arg-max over the classes, the logits are never written) ==
     arg-max of the logits SegOutUp writes, bit for bit (same accumulation, first maximum wins); h, w = INPUT size."""
