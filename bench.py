@@ -154,6 +154,10 @@ def dominant_launch_roofline(net, n, h, w, iters=100, graph_timing=False):
     ms = e0.elapsed_time(e1) / iters
     ach = flops / (ms * 1e-3) / 1e12
     traffic, source = measured_traffic(n, h, w, form)
+    if _LIVE_TRAFFIC.get("bytes") and form == "phase":
+        traffic, source = _LIVE_TRAFFIC["bytes"], _LIVE_TRAFFIC["source"]
+    elif _LIVE_TRAFFIC.get("error") and source:
+        source += " (live sampling: %s)" % _LIVE_TRAFFIC["error"]
     return {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
             "traffic": traffic, "traffic_source": source, "kernel": kname, "launch_ms": round(ms, 4), "flop_per_launch": flops,
             "executed_flop_per_launch": executed, "executed_tflops": round(executed / (ms * 1e-3) / 1e12, 2),
@@ -247,6 +251,57 @@ def measured_traffic(n, h, w, form):
         if rec.get("batch") == n and rec.get("res") == "%dx%d" % (h, w) and rec.get("form") == form:
             return d["hbm_bytes_per_launch"], "profiles/" + name
     return None, None
+
+
+_LIVE_TRAFFIC = {}     # filled by sample_traffic_live() at the start of main(): {"bytes": ..., "source": ...} or {"error": ...}
+
+
+def sample_traffic_live(args, timeout_s=150):
+    """HBM bytes per launch of the dominant kernel sampled IN THIS RUN: two child processes `rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE>
+    --kernel-trace -- python3 bench.py --dominant-only --steps 10` (separate passes, program directly behind `--`; started before this
+    process touches the GPU), counters corrected as MI355X_MICROARCH.md prescribes (both in KB; gfx950 tallies 128-byte read requests at 64 B:
+    FETCH_SIZE x 2).  Bounded: any failure or a pass over its time limit leaves the committed profile's figure in place (`traffic_source`
+    says which one the line carries).  HN_BENCH_LIVE_TRAFFIC=0 / --no-live-traffic: skip."""
+    import csv, shutil, signal, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return {"error": "rocprofv3 not found"}
+    vals = {}
+    t_start = time.perf_counter()
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        left = timeout_s - (time.perf_counter() - t_start)
+        if left < 20:
+            return {"error": "time limit"}
+        with tempfile.TemporaryDirectory(prefix="hn_pmc_", dir="/tmp") as d:
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+                   "--dominant-only", "--steps", "10", "--batch", str(args.batch), "--res", args.res, "--cfg", args.cfg]
+            env = dict(os.environ, TMPDIR="/tmp", HN_BENCH_LIVE_TRAFFIC="0")
+            try:
+                pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+                try:
+                    pr.wait(timeout=left)
+                except subprocess.TimeoutExpired:
+                    os.killpg(pr.pid, signal.SIGKILL)             # the process group we started (the profiler and its child), nothing else
+                    pr.wait()
+                    return {"error": counter + " pass over its time limit"}
+                if pr.returncode != 0:
+                    return {"error": "%s pass exited with %d" % (counter, pr.returncode)}
+                rows = []
+                for root, _, files in os.walk(d):
+                    for f in files:
+                        if f.endswith("counter_collection.csv"):
+                            rows += [r for r in csv.DictReader(open(os.path.join(root, f)))
+                                     if "conv3x3_direct" in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter]
+                v = [float(r["Counter_Value"]) for r in rows]
+                v = v[4:] if len(v) > 8 else v                      # the skip-operand conv and the warm-up launches
+                if not v:
+                    return {"error": counter + ": no rows of the dominant kernel"}
+                vals[counter] = sum(v) / len(v)
+            except Exception as e:       # noqa: BLE001
+                return {"error": "%s: %s" % (type(e).__name__, e)}
+    return {"bytes": (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0,
+            "source": "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --dominant-only --steps 10` inside this run "
+                      "(%.0f s)" % (time.perf_counter() - t_start)}
 
 
 def usable_cores():
@@ -836,6 +891,8 @@ def main():
                     "state initialisation and multi-tensor kernels out of the kernel statistics)")
     ap.add_argument("--backbone-only", action="store_true", help="BASELINE config[1]: backbone fwd+bwd, loss = sum of feature means")
     ap.add_argument("--dominant-only", action="store_true", help="launch only the dominant kernel (for rocprofv3 --pmc passes) and exit")
+    ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed profile instead of two rocprofv3 --pmc "
+                    "child passes inside this run")
     ap.add_argument("--infer", action="store_true", help="BASELINE config 5: eval-mode deploy forward with folded BatchNorm, hipGraph-captured "
                     "(use with --res 1152x1920 --batch 32: a 1080-row frame is zero-padded by 36 rows top and bottom after normalisation)")
     ap.add_argument("--ddp-world1", action="store_true", help="run the gradient exchange (RCCL init, ncclAvg, side stream, in-graph capture) "
@@ -858,6 +915,14 @@ def main():
               % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # roofline.traffic of the headline line, sampled in this run (children under rocprofv3, started before this process uses the GPU)
+    if (world == 1 and rank == 0 and not (args.dominant_only or args.no_roofline or args.no_live_traffic or args.infer or args.backbone_only
+                                          or args.phase or args.ddp_world1)
+            and args.batch == 16 and args.res == "512x1024" and os.environ.get("HN_BENCH_LIVE_TRAFFIC", "1") != "0"
+            and not any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) and "rocprof" not in os.environ.get("LD_PRELOAD", "")):   # (not nested)
+        import __graft_entry__ as ge0
+        ge0.build()                                   # (the children must find the library built: they run under a time limit)
+        _LIVE_TRAFFIC.update(sample_traffic_live(args))
     # test hooks for a 1-GPU box: HN_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and HN_BENCH_BACKEND=gloo replaces RCCL (which refuses
     # two ranks on one device), so the whole N>1 control flow can be exercised without a second GPU.  Never set by the driver.
     if os.environ.get("HN_BENCH_ONE_DEVICE") == "1":

@@ -1,4 +1,5 @@
 #!/bin/bash
+export HN_BENCH_LIVE_TRAFFIC=0
 export HN_TUNING=${HN_TUNING:-ab}    # product library; the package reads HN_LIB_AB / policy switches only under HN_TUNING=1|ab (_lib.policy)
 # Same-box A/B of two builds: `tools/ab_build.sh save` copies the current in-tree library to libhydranet_hip_B.so (variant B); change /
 # revert the sources, rebuild (variant A), then on the GPU box run bench.py with and without HN_LIB_AB=<repo>/multitask_hydranet_amd/libhydranet_hip_B.so.
