@@ -1711,6 +1711,130 @@ __global__ __launch_bounds__(512, 2) void seg_out_conv_kernel(const SegOut p) {
     }
 }
 
+// The same persistent form for the last decoder block's phase-form conv (64 channels -> 4 phases x 64 couts on the low-resolution grid,
+// 4 of the 9 effective taps per phase, bias + ELU, bf16 depth-to-space output): through conv3x3_direct_kernel<64> it is 8 192 workgroups
+// of 64 MFMAs per wave each (180 us for 335 MB and 69 GFLOP).  A workgroup owns ONE phase (its 4 x 4 x 2 weight fragments = 128
+// registers) and walks the patches; the four phase workgroups of a patch range are neighbours on one XCD (the patch comes from HBM once).
+struct SegPhase { const bf16* x; int ldx, N, H, W; const bf16* w; const float* bias; bf16* out; int ldc, act, npatch, ppw; };
+__global__ __launch_bounds__(512, 2) void seg_phase64_conv_kernel(const SegPhase p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int PPIX = 18 * 18, XCH = (PPIX * 8 + 63) / 64, XBYTES = XCH * 1024;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char* stage = smem + 2 * XBYTES;                                   // [256 px][64 couts] bf16, 16-byte pieces XOR-swizzled by the pixel
+    const int tx_n = (p.W + 15) >> 4, ty_n = (p.H + 15) >> 4;
+    const int bidx = xcd_remap(blockIdx.x, gridDim.x);
+    const int ph = bidx & 3, py = ph >> 1, px = ph & 1;
+    const int t0 = (bidx >> 2) * p.ppw;
+    int t1 = t0 + p.ppw;
+    if (t1 > p.npatch) t1 = p.npatch;
+    if (t0 >= t1) return;
+    bf16x8 wf[4][4][2];                                                // [cout tile][tap of the phase][K half]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int co = ph * 64 + i * 16 + (lane & 15);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int tap = (py + (t >> 1)) * 3 + px + (t & 1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                wf[i][t][ks] = *reinterpret_cast<const bf16x8*>(p.w + ((long)co * 9 + tap) * 64 + ks * 32 + (lane >> 4) * 8);
+        }
+    }
+    f32x4 bs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bs[i][r] = p.bias ? p.bias[ph * 64 + i * 16 + (lane >> 4) * 4 + r] : 0.f;
+    int req[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int e = (wave + 8 * i) * 64 + lane, pp = e >> 3;
+        const int qy = pp / 18, qx = pp - qy * 18;
+        req[i] = (wave + 8 * i < XCH && pp < PPIX) ? ((qy << 16) | (qx << 8) | ((e & 7) ^ (qx & 7))) : -1;
+    }
+    auto issue = [&](int t, char* sX) {
+        const int tx = t % tx_n, t2 = t / tx_n, ty = t2 % ty_n, n = t2 / ty_n;
+        const int oy0 = ty * 16, ox0 = tx * 16;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            if (wave + 8 * i < XCH) {
+                const int rq = req[i];
+                int cy = oy0 - 1 + (rq >> 16), cx = ox0 - 1 + ((rq >> 8) & 255);
+                cy = cy < 0 ? 0 : (cy >= p.H ? p.H - 1 : cy);
+                cx = cx < 0 ? 0 : (cx >= p.W ? p.W - 1 : cx);
+                const bf16* src = rq >= 0 ? p.x + ((long)(n * p.H + cy) * p.W + cx) * p.ldx + (rq & 255) * 8 : g_zero_piece;
+                glds16(src, sX + (wave + 8 * i) * 1024);
+            }
+        }
+    };
+    int bofs[2];                                                       // the phase's two tap columns
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        const int pc = (lane & 15) + px + d;
+        bofs[d] = ((wave * 2 + py) * 18 + pc) * 128 + (((lane >> 4) ^ (pc & 7)) << 4);
+    }
+    issue(t0, smem);
+    for (int t = t0; t < t1; ++t) {
+        const int slot = (t - t0) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < t1) issue(t + 1, smem + (slot ^ 1) * XBYTES);
+        const char* sX = smem + slot * XBYTES;
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tq = 0; tq < 4; ++tq) {
+            const int xo = (tq >> 1) * (18 * 128) + bofs[tq & 1];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int xk = ks ? (xo ^ 64) : xo;
+                bf16x8 b[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sX + xk + j * 18 * 128);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][tq][ks], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] += bs[i];
+            if (p.act == HN_ACT_ELU) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const float v = acc[i][j][r]; acc[i][j][r] = v > 0.f ? v : (__expf(v) - 1.0f); }
+            }
+            const int cl = i * 16 + (lane >> 4) * 4;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int pl = (wave * 2 + j) * 16 + (lane & 15);
+                const bf16x4 tv = {f2bf(acc[i][j][0]), f2bf(acc[i][j][1]), f2bf(acc[i][j][2]), f2bf(acc[i][j][3])};
+                *reinterpret_cast<bf16x4*>(stage + pl * 128 + ((((cl >> 3) ^ pl) & 7) << 4) + (cl & 7) * 2) = tv;
+            }
+        }
+        __syncthreads();
+        const int tx = t % tx_n, t2 = t / tx_n, ty = t2 % ty_n, n = t2 / ty_n;
+        const int oy0 = ty * 16, ox0 = tx * 16;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = tid + 512 * u;
+            const int pl = idx >> 3, pc = idx & 7;
+            const int oy = oy0 + (pl >> 4), oxx = ox0 + (pl & 15);
+            if (oy < p.H && oxx < p.W) {
+                const long opix = (long)(n * 2 * p.H + 2 * oy + py) * (2 * p.W) + 2 * oxx + px;
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(stage + pl * 128 + (((pc ^ pl) & 7) << 4));
+                *reinterpret_cast<bf16x8*>(p.out + opix * p.ldc + pc * 8) = v;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // wgrad: part[split][cout][tap*KP + ci] = sum over this split's pixel rows of dZ[pixel][cout] * X[pixel(tap)][ci]
 // ---------------------------------------------------------------------------------------------------------
@@ -3403,6 +3527,24 @@ static int conv_gemm_nt_impl(const void* x0, const void* x1, int mode, int n_img
         p.img_stride = 0;
     }
     if (mode >= 2 && (!psum || p.x.diag) && !rpi) {      // statistics epilogue: grouped convs only (one partial row per 16x16 patch)
+        // the last decoder block's phase-form conv (64 -> 4 x 64): the persistent form, one phase per workgroup
+        if (p.x.clamp == 1 && !p.x.diag && !out_f32 && p.d2s == 64 && phase_mode == 1 && phase_span == 64 && taps == 9 && KP == 64 && C0 == 64 && C1 == 0 &&
+            Nout == 256 && !psum && !addend && (act == HN_ACT_ELU || act == HN_ACT_NONE) && (ld0 & 7) == 0 && (ldc & 7) == 0 && ldc >= 64 &&
+            (reinterpret_cast<uintptr_t>(out) & 15) == 0 && g_hn_knob[11] != 3) {
+            const long npatch = (long)cdiv(W, 16) * cdiv(H, 16) * n_img;
+            if (npatch >= 1024) {
+                SegPhase q;
+                q.x = (const bf16*)x0; q.ldx = ld0; q.N = n_img; q.H = H; q.W = W; q.w = (const bf16*)w; q.bias = bias; q.out = (bf16*)out; q.ldc = ldc;
+                q.act = act; q.npatch = (int)npatch;
+                q.ppw = cdiv(npatch, 64);                              // 64 patch ranges x 4 phases = 256 workgroups
+                const int grid = 4 * cdiv(npatch, q.ppw);
+                const size_t lds = 2 * (size_t)((18 * 18 * 8 + 63) / 64) * 1024 + 256 * 128;
+                static std::atomic<unsigned long long> optin_sp{0};
+                if (!lds_optin(optin_sp, {(const void*)seg_phase64_conv_kernel})) return HN_ERR_LAUNCH;
+                hipLaunchKernelGGL(seg_phase64_conv_kernel, dim3(grid), dim3(512), lds, st, q);
+                HN_LAUNCH_CHECK();
+            }
+        }
         // the seg output conv on a map big enough to give every CU several patches: the persistent form with the weights in registers
         if (p.x.clamp == 1 && !p.x.diag && out_f32 && p.d2s && taps == 9 && KP == 64 && C0 == 64 && C1 == 0 && Nout == 4 * p.d2s && Nout <= 32 &&
             !psum && !addend && phase_mode == 0 && act == HN_ACT_NONE && (ld0 & 7) == 0 && ((32 * p.d2s) & 3) == 0 && ((2 * W * p.d2s) & 3) == 0 &&

@@ -381,6 +381,8 @@ def test_seg_conv(K, c0, c1, cout, up, act, f32, n, h, w):
     (256, 112, 256, 1, 16, 32),      # decoder.3 (the dominant launch): 128-cout tiles, four K chunks per phase in the data gradient
     (64, 16, 64, 3, 10, 6),          # ragged tiles (output 10x6 low-res cells)
     (256, 112, 256, 8, 48, 96),      # decoder.3 at a many-workgroup size (phase forward with addend, skip conv, phase data gradient)
+    (64, 0, 64, 8, 128, 256),        # decoder.7: >= 1024 patches -> the persistent one-phase-per-workgroup forward (whole patches)
+    (64, 0, 64, 5, 250, 330),        # ... ragged patches
 ])
 @pytest.mark.parametrize("fwd_phase,dgrad_phase", [(True, True), (False, True), (True, False), (None, None)])
 def test_seg_conv_up_phase_form(K, c0, c1, cout, n, h, w, fwd_phase, dgrad_phase):
