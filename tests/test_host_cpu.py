@@ -3,6 +3,8 @@ include/hydranet_hip.h declares, the module reproduces the reference's state_dic
 the oracle's per-image loops."""
 import ctypes
 import os
+import sys
+import time
 
 import numpy as np
 import pytest
@@ -272,6 +274,26 @@ def test_bench_refuses_more_gpus_than_the_node_has():
     assert r.returncode == 2, (r.returncode, r.stderr[-500:])
     assert not any(l.startswith("{") for l in r.stdout.splitlines())
     assert "refusing" in r.stderr
+
+
+def test_live_traffic_sampling_fails_soft():
+    """bench.py samples roofline.traffic with two rocprofv3 child passes; whatever goes wrong there (no profiler, no GPU as in this container,
+    a pass over its time limit) must come back as {"error": ...} -- the line then keeps the committed profile's figure and says so -- and
+    must never raise or hang.  The figure's bookkeeping: a live result replaces the committed one only for the workload it was taken on."""
+    import argparse
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("on a GPU box the passes succeed (covered by the bench run itself)")
+    sys.path.insert(0, ROOT)
+    import bench
+    args = argparse.Namespace(batch=16, res="512x1024", cfg=os.path.join(ROOT, "cfgs", "hydranet_big.yml"))
+    t0 = time.perf_counter()
+    r = bench.sample_traffic_live(args, timeout_s=60)
+    assert isinstance(r, dict) and "error" in r and "bytes" not in r, r
+    assert time.perf_counter() - t0 < 90
+    committed, src = bench.measured_traffic(16, 512, 1024, "phase")
+    assert committed and src.startswith("profiles/r06_")
+    assert bench.measured_traffic(8, 512, 1024, "phase") == (None, None)
 
 
 def test_policy_switches_are_constants_without_the_tuning_flag():
